@@ -1,0 +1,262 @@
+"""Pins the C restatement (oracle/csdr_oracle.c) against the compiled, unmodified reference
+(oracle/_ref/libcsdr_ref.so).  CPU only.  Bit-exact for converters / integer geometry; <=1e-5 relative
+RMS (usually far tighter) for float paths -- the reference build uses -ffast-math, so float paths are
+not expected to be bit-identical."""
+import numpy as np
+import pytest
+from oracle import relrms
+
+c64 = np.complex64
+f32 = np.float32
+
+
+def crand(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(c64)
+
+
+# ---------------------------------------------------------------- converters: bit exact, exhaustive
+def test_convert_u8_s8_s16_exhaustive(port, ref):
+    u8 = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(port.convert_u8_f(u8).view(np.uint32), ref.convert_u8_f(u8).view(np.uint32))
+    s8 = np.arange(-128, 128, dtype=np.int8)
+    assert np.array_equal(port.convert_s8_f(s8).view(np.uint32), ref.convert_s8_f(s8).view(np.uint32))
+    s16 = np.arange(-32768, 32768, dtype=np.int16)
+    assert np.array_equal(port.convert_s16_f(s16).view(np.uint32), ref.convert_s16_f(s16).view(np.uint32))
+
+
+def float_probe_set():
+    rng = np.random.default_rng(7)
+    grid = np.linspace(-1, 1, 65537, dtype=f32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.nextafter(f32(1), f32(0)), -np.nextafter(f32(1), f32(0)),
+                        1.5, -1.5, 3.0, -3.0, 1e-40, -1e-40, 1e-30, 0.999999, 2.0, -2.0, 100.0, -100.0,
+                        65535.9, -65536.2, 7e4, -7e4], dtype=f32)
+    wide = rng.uniform(-4, 4, 20000).astype(f32)
+    return np.concatenate([grid, special, wide])
+
+
+@pytest.mark.parametrize("name", ["convert_f_u8", "convert_f_s8", "convert_f_s16"])
+def test_convert_f_int_bit_exact(port, ref, name):
+    x = float_probe_set()
+    assert np.array_equal(getattr(port, name)(x), getattr(ref, name)(x))
+
+
+@pytest.mark.parametrize("big", [0, 1])
+def test_convert_s24_bit_exact(port, ref, big):
+    x = float_probe_set()
+    a, b = port.convert_f_s24(x, big), ref.convert_f_s24(x, big)
+    assert np.array_equal(a, b)
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 256, 3 * 50000, dtype=np.uint8)
+    fa, fb = port.convert_s24_f(raw, big), ref.convert_s24_f(raw, big)
+    assert np.array_equal(fa.view(np.uint32), fb.view(np.uint32))
+
+
+# ---------------------------------------------------------------- design helpers
+def test_filter_len_pow2(port, ref):
+    for tbw in [0.05, 0.005, 0.03, 0.001, 0.002, 0.01, 0.1, 0.25, 4.0 / 63, 4.0 / 4095]:
+        assert port.firdes_filter_len(tbw) == ref.firdes_filter_len(tbw)
+    for x in list(range(0, 70)) + [127, 128, 129, 65535, 65536, 65537, 1 << 20]:
+        assert port.next_pow2(x) == ref.next_pow2(x)
+        assert port.log2n(x) == ref.log2n(x)
+    assert port.firdes_filter_len(0.05) == 79 and port.firdes_filter_len(0.005) == 801
+
+
+@pytest.mark.parametrize("window", ["HAMMING", "BLACKMAN", "BOXCAR"])
+@pytest.mark.parametrize("length,cutoff", [(79, 0.05), (801, 0.01), (133, 0.125), (8193, 0.5 / 256)])
+def test_firdes_lowpass(port, ref, window, length, cutoff):
+    a, b = port.firdes_lowpass_f(length, cutoff, window), ref.firdes_lowpass_f(length, cutoff, window)
+    assert relrms(a, b) < 5e-6          # float normalisation sum is reassociated by the reference's -ffast-math
+    assert abs(a.sum() - 1) < 1e-5
+
+
+def test_firdes_bandpass(port, ref):
+    for (length, lo, hi) in [(79, -0.1, 0.2), (4095, -0.1, 0.2), (63, 0.1, 0.3), (8193, 0.3 - 0.5 / 256, 0.3 + 0.5 / 256)]:
+        a, b = port.firdes_bandpass_c(length, lo, hi), ref.firdes_bandpass_c(length, lo, hi)
+        assert relrms(a, b) < 3e-6
+
+
+# ---------------------------------------------------------------- shifters
+@pytest.mark.parametrize("rate", [-0.085, 0.3141, 4e-4, 0.5, -0.5])
+def test_shift_addition_stream(port, ref, rate):
+    rng = np.random.default_rng(11)
+    x = crand(rng, 1024 * 200)
+    (a, pa), (b, pb) = port.shift_addition_cc(x, rate), ref.shift_addition_cc(x, rate)
+    assert relrms(a, b) < 2e-6
+    assert abs(pa - pb) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["shift_math_cc", "shift_table_cc", "shift_unroll_cc", "shift_addfast_cc"])
+@pytest.mark.parametrize("rate", [-0.085, 0.3141, 4e-4])
+def test_shift_variants(port, ref, name, rate):
+    rng = np.random.default_rng(12)
+    x = crand(rng, 1024 * 64)
+    (a, pa), (b, pb) = getattr(port, name)(x, rate), getattr(ref, name)(x, rate)
+    tol = 2e-4 if name == "shift_table_cc" else 2e-6    # table index truncation can flip an entry under fast-math
+    assert relrms(a, b) < tol
+    assert abs(pa - pb) < 1e-4
+
+
+def test_shift_addition_fc_and_decimating(port, ref):
+    rng = np.random.default_rng(13)
+    xr = rng.uniform(-1, 1, 4096 * 4).astype(f32)
+    (a, _), (b, _) = port.shift_addition_fc(xr, 0.11), ref.shift_addition_fc(xr, 0.11)
+    assert relrms(a, b) < 2e-6
+    x = crand(rng, 448)
+    st_a = st_b = (0, 0.0, 0)
+    for _ in range(50):
+        ya, st_a = port.decimating_shift_addition_cc(x, 0.0123, 3, st_a)
+        yb, st_b = ref.decimating_shift_addition_cc(x, 0.0123, 3, st_b)
+        assert st_a[0] == st_b[0] and st_a[2] == st_b[2]
+        assert relrms(ya, yb) < 2e-6
+
+
+# ---------------------------------------------------------------- FIR decimator
+@pytest.mark.parametrize("D,ntaps", [(10, 79), (50, 801), (2, 133), (256, 3999), (10, 1023)])
+def test_fir_decimate_stream(port, ref, D, ntaps):
+    rng = np.random.default_rng(1234)
+    x = crand(rng, 16384 * 5 + 777)
+    taps = ref.firdes_lowpass_f(ntaps, 0.5 / D)
+    a = port.fir_decimate_cc(x, D, taps)
+    b = ref.fir_decimate_cc(x, D, taps)
+    assert a.size == b.size == (x.size - ntaps) // D + 1
+    assert relrms(a, b) < 2e-6
+
+
+def test_fir_decimate_c1_block(port, ref):
+    """BASELINE config 1: one 16384 block, decim 10, 79 taps -> 1631 outputs."""
+    rng = np.random.default_rng(1234)
+    x = crand(rng, 16384)
+    taps = ref.firdes_lowpass_f(79, 0.05)
+    b = ref.fir_decimate_cc_block(x, 10, taps)
+    assert b.size == 1631
+    assert relrms(port.fir_decimate_cc(x, 10, taps), b) < 2e-6
+
+
+# ---------------------------------------------------------------- demod + audio
+def fm_signal(rng, n, dev=0.03125):
+    t = np.arange(n)
+    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * t) + 0.3 * rng.uniform(-1, 1, n)
+    ph = 2 * np.pi * np.cumsum(dev * msg)
+    return (0.7 * np.exp(1j * ph) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))).astype(c64)
+
+
+def test_fmdemod(port, ref):
+    rng = np.random.default_rng(21)
+    x = fm_signal(rng, 1024 * 40)
+    x[100] = 0; x[5000:5003] = 0                      # denominator-zero branch
+    (a, la), (b, lb) = port.fmdemod_quadri_cf(x), ref.fmdemod_quadri_cf(x)
+    assert relrms(a, b) < 1e-6 and la == lb
+    assert a[100] == 0 and b[100] == 0
+    (c, _) = ref.fmdemod_quadri_novect_cf(x[1:], (float(x[0].real), float(x[0].imag)))
+    ok = np.isfinite(c)
+    assert relrms(a[1:][ok], c[ok]) < 1e-6
+
+
+def test_fractional_decimator(port, ref):
+    rng = np.random.default_rng(22)
+    x = rng.uniform(-1, 1, 1024 * 30).astype(f32)
+    a = port.fractional_decimator_ff(x, 5.0)
+    b_cli = ref.fractional_decimator_ff(x, 5.0, bufsize=1024)
+    b_one = ref.fractional_decimator_ff(x, 5.0)
+    n = b_cli.size
+    assert n > 6000
+    assert np.array_equal(a[:n], x[10:10 + 5 * n:5])            # exact gather x[5k+10]
+    assert np.array_equal(b_cli, x[10:10 + 5 * n:5])
+    assert np.array_equal(b_one, a)
+    for rate in [2.5, 4.17]:
+        a = port.fractional_decimator_ff(x, rate); b = ref.fractional_decimator_ff(x, rate)
+        assert a.size == b.size and relrms(a, b) < 1e-5
+    taps = ref.firdes_lowpass_f(133, 0.5 / (2.5 - 0.03))
+    a = port.fractional_decimator_ff(x, 2.5, taps=taps); b = ref.fractional_decimator_ff(x, 2.5, taps=taps)
+    assert a.size == b.size and relrms(a, b) < 1e-5
+
+
+def test_deemphasis_limit_gain_agc(port, ref):
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1.5, 1.5, 1024 * 20).astype(f32)
+    (a, la), (b, lb) = port.deemphasis_wfm_ff(x, 50e-6, 48000), ref.deemphasis_wfm_ff(x, 50e-6, 48000)
+    assert relrms(a, b) < 1e-6
+    assert np.array_equal(port.limit_ff(x, 1.0), ref.limit_ff(x, 1.0))
+    assert np.array_equal(port.gain_ff(x, 0.37), ref.gain_ff(x, 0.37))
+    for sr in [48000, 44100, 8000, 11025]:
+        taps = ref.nfm_taps(sr)
+        a = port.deemphasis_nfm_ff(x[:4096], taps); b = ref.deemphasis_nfm_ff(x[:4096], sr)
+        assert a.size == b.size == 4096 - taps.size and relrms(a, b) < 2e-6
+    assert ref.deemphasis_nfm_ff(x[:1024], 12345).size == 0
+    env = (0.05 + np.abs(np.sin(np.arange(x.size) / 3000.0))).astype(f32)
+    a = port.fastagc_ff(x * env); b = ref.fastagc_ff(x * env)
+    assert np.all(a[:2048] == 0) and np.all(b[:2048] == 0)
+    assert relrms(a, b) < 1e-6
+
+
+# ---------------------------------------------------------------- FFT paths
+def test_fft_shim_vs_numpy(port):
+    rng = np.random.default_rng(31)
+    for n in [8, 512, 65536, 12]:
+        x = crand(rng, n)
+        assert relrms(port.fft_c2c(x, True), np.fft.fft(x.astype(np.complex128))) < 2e-7
+        assert relrms(port.fft_c2c(x, False), np.fft.ifft(x.astype(np.complex128)) * n) < 2e-7
+
+
+@pytest.mark.parametrize("ntaps,fft_size", [(63, 1024), (255, 4096), (4095, 65536), (63, 65536)])
+def test_bandpass_fir_fft(port, ref, ntaps, fft_size):
+    rng = np.random.default_rng(3)
+    inp = fft_size - ntaps + 1
+    x = crand(rng, inp * 4)
+    taps = ref.firdes_bandpass_c(ntaps, -0.1, 0.2)
+    a = port.bandpass_fir_fft_cc(x, taps, fft_size); b = ref.bandpass_fir_fft_cc(x, taps, fft_size)
+    assert relrms(a, b) < 2e-6
+    if fft_size <= 4096:
+        direct = np.convolve(x.astype(np.complex128), taps.astype(np.complex128))[:a.size]
+        assert relrms(a, direct) < 2e-6
+
+
+def test_fastddc_geometry(port, ref):
+    for D in [2, 3, 4, 6, 8, 10, 16, 24, 50, 64, 100, 128, 256]:
+        for tbw in [0.05, 0.005, 0.001]:
+            for s in [0.0, -0.1, 0.4, 0.123456, -0.5 + 0.5 / 256, 0.25]:
+                da, ea = port.fastddc_init(tbw, D, s); db, eb = ref.fastddc_init(tbw, D, s)
+                A, B = da.as_dict(), db.as_dict()
+                assert ea == eb
+                for k in A:
+                    if k in ("output_scrape",):
+                        continue               # never initialised by the reference (fastddc.c:38-72)
+                    if isinstance(A[k], int):
+                        assert A[k] == B[k], (D, tbw, s, k, A[k], B[k])
+                    elif isinstance(A[k], tuple):
+                        assert np.allclose(A[k], B[k], rtol=0, atol=2e-6), (D, tbw, s, k)
+                    else:
+                        assert abs(A[k] - B[k]) <= 1e-6 * max(1, abs(B[k])), (D, tbw, s, k)
+    d, _ = port.fastddc_init(0.001, 256, 0.0)
+    assert (d.fft_size, d.taps_length, d.input_size, d.fft_inv_size, d.scrap, d.post_input_size,
+            d.pre_decimation, d.post_decimation) == (65536, 8193, 57344, 512, 64, 448, 128, 2)
+
+
+@pytest.mark.parametrize("D,tbw,shift", [(16, 0.05, -0.1), (256, 0.005, 0.3 + 0.5 / 256), (6, 0.05, 0.2)])
+def test_fastddc_stream(port, ref, D, tbw, shift):
+    rng = np.random.default_rng(4)
+    da, _ = port.fastddc_init(tbw, D, shift); db, _ = ref.fastddc_init(tbw, D, shift)
+    x = crand(rng, da.input_size * 12)
+    sa = port.fastddc_fwd_cc(x, da); sb = ref.fastddc_fwd_cc(x, db)
+    assert relrms(sa, sb) < 1e-6
+    ta = port.fastddc_taps_fft(da, shift, D); tb = ref.fastddc_taps_fft(db, shift, D)
+    assert relrms(ta, tb) < 5e-6
+    ya = port.fastddc_inv_cc(sa, da, ta); yb = ref.fastddc_inv_cc(sb, db, tb)
+    assert ya.size == yb.size and ya.size > 0
+    assert relrms(ya, yb) < 1e-5
+
+
+# ---------------------------------------------------------------- the WFM chain
+def test_wfm_chain(port, ref):
+    rng = np.random.default_rng(1000)
+    n = 16384 * 12
+    sig = fm_signal(rng, n) * np.exp(2j * np.pi * 0.085 * np.arange(n))
+    iq = np.empty(2 * n, f32); iq[0::2] = sig.real; iq[1::2] = sig.imag
+    u8 = np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+    taps = ref.firdes_lowpass_f(79, 0.05)
+    (sa, fa), (sb, fb) = port.wfm_chain(u8, -0.085, 10, taps), ref.wfm_chain(u8, -0.085, 10, taps)
+    n = min(fa.size, fb.size)
+    assert n >= 16384 * 12 // 50 - 8
+    assert relrms(fa[:n], fb[:n]) < 1e-5
+    d = np.abs(sa[:n].astype(np.int32) - sb[:n].astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.05
