@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: complex MS/s in->out for the WFM demod chain @2.4 MS/s x N streams,
+with the % of the HBM roofline of the dominant kernel.
+
+Workload (BASELINE.json configs[1]): the full WFM pipe
+    convert_u8_f | shift_addition_cc -0.085 | fir_decimate_cc 10 0.05 HAMMING | fmdemod_quadri_cf |
+    fractional_decimator_ff 5 | deemphasis_wfm_ff 48000 50e-6 | convert_f_s16
+on 1024 parallel 2.4 MS/s u8 IQ streams per GPU, synthetic i.i.d. uniform u8 (SURVEY.md section 8d "throughput
+signal"), inputs resident in HBM before the timed region.  One step = one block of 2344*1024 = 2 400 256 complex
+samples (1.0001 s of signal) of every stream through the whole chain (state carried from step to step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--block T] [--no-cpu-baseline]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; streams are independent, so ranks share nothing on
+the data path (replicas of the per-GPU workload, "scaling": "weak"); barrier + max-over-ranks timing over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_SAMPLE = 2.0 + 2.0 / 50.0      # u8 IQ in + s16 audio out per complex input sample
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def cpu_baseline(seconds_of_signal=20.0):
+    """Reference CPU path on the host cores, bounded sample (rank 0, N=1 only)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "cpu_bench_ref")
+    port = os.path.join(ROOT, "oracle", "cpu_bench_port")
+    exe = ref if os.path.exists(ref) else port
+    if not os.path.exists(exe):
+        return None
+    cores = os.cpu_count() or 1
+    out = {}
+    try:
+        one = json.loads(subprocess.run([exe, "1", str(seconds_of_signal)], capture_output=True, text=True, timeout=300, check=True).stdout)
+        per_thread = max(2.0, seconds_of_signal * 4 / cores) if cores > 4 else seconds_of_signal
+        allc = json.loads(subprocess.run([exe, str(cores), str(per_thread)], capture_output=True, text=True, timeout=600, check=True).stdout)
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+    out = {"value": round(allc["msps"], 3), "unit": "complex MS/s", "cores": cores, "kind": one["kind"],
+           "sample": "%d threads x %.1f s of 2.4 MS/s u8 IQ each through the 7-stage chain in process (CLI block framing); "
+                     "1 thread alone: %.1f MS/s" % (cores, per_thread, one["msps"]),
+           "single_core_value": round(one["msps"], 3)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=1024)
+    ap.add_argument("--block", type=int, default=2344 * 1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import csdr_amd
+    ctx = csdr_amd.Context(local_rank)           # own non-blocking HIP stream; timed with HIP events on that stream
+    L = ctx.L
+    S, T = args.streams, args.block
+    assert T % 1024 == 0
+    taps = ctx.firdes_lowpass_f(ctx.firdes_filter_len(0.05), 0.5 / 10, "HAMMING")      # csdr.c:1144-1158
+    pitch = 2 * T
+    # synthetic input resident in HBM (torch is only the allocator / RNG here)
+    g = torch.Generator(device="cuda"); g.manual_seed(42 + rank)
+    x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda", generator=g)
+    n_audio_max = T // 50 + 64
+    out_s16 = torch.empty((S, n_audio_max), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+    if not w:
+        raise SystemExit("wfm_create: " + ctx.err())
+
+    def step():
+        n = L.csdr_amd_wfm_process(w, x.data_ptr(), pitch, T, out_s16.data_ptr(), None, n_audio_max)
+        if n < 0:
+            raise SystemExit("wfm_process: " + ctx.err())
+        return n
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync(); torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    L.csdr_amd_wfm_set_profiling(w, 1)
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    audio = 0
+    for _ in range(args.steps):
+        audio += step()
+    ev_ms = ctx.timer_stop_ms()                  # HIP events on the kernels' own stream (includes the sync)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    kms = C.c_double(0); kl = C.c_long(0)
+    L.csdr_amd_wfm_kernel_time(w, C.byref(kms), C.byref(kl))
+    kernel_name = L.csdr_amd_wfm_kernel_name(w).decode()
+
+    if rank == 0:
+        samples_per_step_gpu = S * T
+        total_samples = samples_per_step_gpu * args.steps * world
+        msps = total_samples / wall / 1e6
+        k_avg_ms = kms.value / max(kl.value, 1)
+        achieved_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step_gpu / (k_avg_ms * 1e-3) / 1e9
+        res = {
+            "metric": "complex MS/s in->out, WFM demod chain @2.4 MS/s x N streams",
+            "value": round(msps, 1), "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: full WFM pipe u8 IQ -> s16 audio (convert_u8_f|shift_addition_cc -0.085|fir_decimate_cc 10 0.05 HAMMING|"
+                                   "fmdemod_quadri_cf|fractional_decimator_ff 5|deemphasis_wfm_ff 48000 50e-6|convert_f_s16)",
+                       "streams_per_gpu": S, "block_samples_per_stream": T, "stream_rate_sps": 2400000,
+                       "realtime_streams_equivalent": round(msps / 2.4, 1), "parallelism": "streams sharded, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step_gpu,
+                         "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches_timed": kl.value,
+                         "frac_of_measured_copy_ceiling_6290": round(achieved_gbs / 6290.0, 4),
+                         "hip_event_ms_per_step_all_kernels": round(ev_ms / args.steps, 4)},
+            "audio_samples_per_step_per_stream": audio // max(args.steps, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    L.csdr_amd_wfm_destroy(w)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

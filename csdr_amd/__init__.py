@@ -1,0 +1,440 @@
+"""csdr_amd -- Python harness over libcsdr_amd.so (the MI355X-native libcsdr hot path).
+
+The product is the C-ABI shared library (include/csdr_amd.h, include/libcsdr_amd_compat.h) built from
+csdr_amd/csrc/*.hip for gfx950.  This module only loads it with ctypes and offers numpy-in/numpy-out
+conveniences for the tests and bench.py; it contains no DSP and NO fallback: if the library or the GPU is
+missing, everything raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcsdr_amd.so")
+ROOT = os.path.dirname(HERE)
+
+c64 = np.complex64
+f32 = np.float32
+
+SHIFT = {"addition": 0, "math": 1, "table": 2, "unroll": 3, "addfast": 4}
+WINDOWS = {"BOXCAR": 0, "BLACKMAN": 1, "HAMMING": 2}
+
+
+class CsdrAmdError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into csdr_amd/libcsdr_amd.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise CsdrAmdError("libcsdr_amd build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+class FastDDC(C.Structure):       # csdr_fastddc_t == fastddc_t (fastddc.h:5-24)
+    _fields_ = [(n, C.c_int) for n in ("pre_decimation", "post_decimation", "taps_length", "taps_min_length",
+                                       "overlap_length", "fft_size", "fft_inv_size", "input_size", "post_input_size")] + \
+               [("pre_shift", C.c_float), ("startbin", C.c_int), ("v", C.c_int), ("offsetbin", C.c_int),
+                ("post_shift", C.c_float), ("output_scrape", C.c_int), ("scrap", C.c_int),
+                ("sindelta", C.c_float), ("cosdelta", C.c_float), ("rate", C.c_float)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n not in ("sindelta", "cosdelta", "rate")}
+        d["dsadata"] = (self.sindelta, self.cosdelta, self.rate)
+        return d
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CsdrAmdError("%s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` first" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i, fl = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    L.csdr_amd_ctx_create.restype = vp; L.csdr_amd_ctx_create.argtypes = [i, vp]
+    L.csdr_amd_ctx_destroy.argtypes = [vp]
+    L.csdr_amd_ctx_sync.argtypes = [vp]
+    L.csdr_amd_ctx_stream.restype = vp; L.csdr_amd_ctx_stream.argtypes = [vp]
+    L.csdr_amd_last_error.restype = C.c_char_p
+    L.csdr_amd_device_arch.restype = C.c_char_p; L.csdr_amd_device_arch.argtypes = [vp]
+    L.csdr_amd_malloc.restype = vp; L.csdr_amd_malloc.argtypes = [vp, sz]
+    L.csdr_amd_free.argtypes = [vp, vp]
+    L.csdr_amd_h2d.argtypes = [vp, vp, vp, sz]
+    L.csdr_amd_d2h.argtypes = [vp, vp, vp, sz]
+    L.csdr_amd_memset.argtypes = [vp, vp, i, sz]
+    L.csdr_amd_timer_start.argtypes = [vp]
+    L.csdr_amd_timer_stop_ms.argtypes = [vp, C.POINTER(fl)]
+    L.csdr_amd_firdes_filter_len.argtypes = [fl]
+    L.csdr_amd_firdes_lowpass_f.argtypes = [vp, i, fl, i]
+    L.csdr_amd_firdes_bandpass_c.argtypes = [vp, i, fl, fl, i]
+    L.csdr_amd_nfm_deemph_taps.argtypes = [i, C.POINTER(vp)]
+    L.csdr_amd_shift_addition_init.argtypes = [fl, vp]
+    for nm in ("u8_f", "s8_f", "s16_f", "f_u8", "f_s8", "f_s16"):
+        getattr(L, "csdr_amd_convert_" + nm).argtypes = [vp, vp, vp, sz]
+    L.csdr_amd_convert_f_s24.argtypes = [vp, vp, vp, sz, i]
+    L.csdr_amd_convert_s24_f.argtypes = [vp, vp, vp, sz, i]
+    L.csdr_amd_rotator_generate.argtypes = [vp, i, fl, vp, vp, sz, i, i]
+    L.csdr_amd_mix_cc.argtypes = [vp, vp, vp, vp, i, sz, sz, sz]
+    L.csdr_amd_mix_fc.argtypes = [vp, vp, vp, vp, i, sz, sz, sz]
+    L.csdr_amd_shift_cc.argtypes = [vp, i, fl, vp, vp, vp, i, sz, sz, sz, i, i]
+    L.csdr_amd_decimating_shift_addition_cc.argtypes = [vp, vp, vp, i, i, sz, sz, vp, i, vp]
+    L.csdr_amd_fir_decimate_cc.argtypes = [vp, vp, vp, i, i, sz, sz, i, vp, i]
+    L.csdr_amd_fir_ff.argtypes = [vp, vp, vp, i, i, sz, sz, vp, i]
+    L.csdr_amd_fmdemod_quadri_cf.argtypes = [vp, vp, vp, i, sz, sz, sz, vp]
+    L.csdr_amd_limit_ff.argtypes = [vp, vp, vp, sz, fl]
+    L.csdr_amd_gain_ff.argtypes = [vp, vp, vp, sz, fl]
+    L.csdr_amd_deemphasis_wfm_ff.argtypes = [vp, vp, vp, i, sz, sz, sz, fl, i, vp]
+    L.csdr_amd_fastagc_ff.argtypes = [vp, vp, vp, i, i, i, sz, sz, fl, vp]
+    L.csdr_amd_fracdec_create.restype = vp; L.csdr_amd_fracdec_create.argtypes = [fl, i, vp, i]
+    L.csdr_amd_fracdec_destroy.argtypes = [vp]
+    L.csdr_amd_fractional_decimator_ff.argtypes = [vp, vp, vp, vp, i, i, sz, sz, C.POINTER(i)]
+    L.csdr_amd_fftfilt_create.restype = vp; L.csdr_amd_fftfilt_create.argtypes = [vp, i, vp, i, i, i]
+    L.csdr_amd_fftfilt_destroy.argtypes = [vp]
+    L.csdr_amd_fftfilt_input_size.argtypes = [vp]
+    L.csdr_amd_fftfilt_reset.argtypes = [vp]
+    L.csdr_amd_fftfilt_process.argtypes = [vp, vp, vp, i, sz, sz]
+    L.csdr_amd_fft_c2c.argtypes = [vp, vp, vp, i, i]
+    L.csdr_amd_fastddc_init.argtypes = [vp, fl, i, fl]
+    L.csdr_amd_fastddc_fwd_create.restype = vp; L.csdr_amd_fastddc_fwd_create.argtypes = [vp, vp, i]
+    L.csdr_amd_fastddc_fwd_destroy.argtypes = [vp]
+    L.csdr_amd_fastddc_fwd_process.argtypes = [vp, vp, vp, i]
+    L.csdr_amd_fastddc_inv_create.restype = vp; L.csdr_amd_fastddc_inv_create.argtypes = [vp, fl, i, vp, i, i, i]
+    L.csdr_amd_fastddc_inv_destroy.argtypes = [vp]
+    L.csdr_amd_fastddc_inv_geometry.argtypes = [vp, i, vp]
+    L.csdr_amd_fastddc_inv_max_output.argtypes = [vp, i]
+    L.csdr_amd_fastddc_inv_process.argtypes = [vp, vp, i, vp, sz, vp]
+    L.csdr_amd_wfm_create.restype = vp; L.csdr_amd_wfm_create.argtypes = [vp, i, fl, i, vp, i, i, fl, i, sz]
+    L.csdr_amd_wfm_destroy.argtypes = [vp]
+    L.csdr_amd_wfm_reset.argtypes = [vp]
+    L.csdr_amd_wfm_process.restype = C.c_long; L.csdr_amd_wfm_process.argtypes = [vp, vp, sz, sz, vp, vp, sz]
+    L.csdr_amd_wfm_kernel_name.restype = C.c_char_p; L.csdr_amd_wfm_kernel_name.argtypes = [vp]
+    L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
+    L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    _lib = L
+    return L
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ptr = lib().csdr_amd_malloc(ctx.h, max(self.nbytes, 16))
+        if not self.ptr:
+            raise CsdrAmdError(ctx.err())
+
+    def free(self):
+        if self.ptr:
+            lib().csdr_amd_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def at(self, byte_offset):
+        return C.c_void_p(self.ptr + int(byte_offset))
+
+
+class Context:
+    """csdr_amd_ctx: one GPU, one HIP stream."""
+
+    def __init__(self, device=0, hip_stream=None):
+        self.L = lib()
+        self.h = self.L.csdr_amd_ctx_create(device, hip_stream)
+        if not self.h:
+            raise CsdrAmdError("csdr_amd_ctx_create failed: " + self.L.csdr_amd_last_error().decode())
+
+    def err(self):
+        return self.L.csdr_amd_last_error().decode()
+
+    def check(self, rc, what=""):
+        if rc < 0:
+            raise CsdrAmdError("%s failed (%d): %s" % (what, rc, self.err()))
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.csdr_amd_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        self.check(self.L.csdr_amd_ctx_sync(self.h), "sync")
+
+    def arch(self):
+        return self.L.csdr_amd_device_arch(self.h).decode()
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = DevBuf(self, arr.nbytes)
+        if arr.nbytes:
+            self.check(self.L.csdr_amd_h2d(self.h, b.ptr, _hp(arr), arr.nbytes), "h2d")
+        return b
+
+    def download(self, buf, dtype, count, byte_offset=0):
+        out = np.empty(count, dtype=dtype)
+        if out.nbytes:
+            self.check(self.L.csdr_amd_d2h(self.h, _hp(out), buf.at(byte_offset), out.nbytes), "d2h")
+        return out
+
+    def timer_start(self):
+        self.check(self.L.csdr_amd_timer_start(self.h), "timer_start")
+
+    def timer_stop_ms(self):
+        ms = C.c_float(0)
+        self.check(self.L.csdr_amd_timer_stop_ms(self.h, C.byref(ms)), "timer_stop")
+        return ms.value
+
+    # ------------------------------------------------------------------ host-side design
+    def firdes_filter_len(self, tbw):
+        return self.L.csdr_amd_firdes_filter_len(tbw)
+
+    def firdes_lowpass_f(self, length, cutoff, window="HAMMING"):
+        t = np.zeros(length, f32); self.L.csdr_amd_firdes_lowpass_f(_hp(t), length, cutoff, WINDOWS[window]); return t
+
+    def firdes_bandpass_c(self, length, lo, hi, window="HAMMING"):
+        t = np.zeros(length, c64); self.L.csdr_amd_firdes_bandpass_c(_hp(t), length, lo, hi, WINDOWS[window]); return t
+
+    def nfm_taps(self, sample_rate):
+        p = C.c_void_p()
+        n = self.L.csdr_amd_nfm_deemph_taps(sample_rate, C.byref(p))
+        if not n:
+            return np.zeros(0, f32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (n,)).copy()
+
+    # ------------------------------------------------------------------ numpy conveniences (single call, 2-D batches)
+    def _conv(self, name, x, in_dt, out_dt, n_out=None, extra=()):
+        x = np.ascontiguousarray(x, in_dt)
+        n = x.size if in_dt != np.uint8 or name != "csdr_amd_convert_s24_f" else x.size // 3
+        n_out = n if n_out is None else n_out
+        di = self.upload(np.concatenate([x.ravel(), np.zeros(16, in_dt)]))
+        do = self.alloc(np.dtype(out_dt).itemsize * (n_out + 16))
+        self.check(getattr(self.L, name)(self.h, di.ptr, do.ptr, n, *extra), name)
+        return self.download(do, out_dt, n_out)
+
+    def convert_u8_f(self, x): return self._conv("csdr_amd_convert_u8_f", x, np.uint8, f32)
+    def convert_s8_f(self, x): return self._conv("csdr_amd_convert_s8_f", x, np.int8, f32)
+    def convert_s16_f(self, x): return self._conv("csdr_amd_convert_s16_f", x, np.int16, f32)
+    def convert_f_u8(self, x): return self._conv("csdr_amd_convert_f_u8", x, f32, np.uint8)
+    def convert_f_s8(self, x): return self._conv("csdr_amd_convert_f_s8", x, f32, np.int8)
+    def convert_f_s16(self, x): return self._conv("csdr_amd_convert_f_s16", x, f32, np.int16)
+
+    def convert_f_s24(self, x, bigendian=0):
+        x = np.ascontiguousarray(x, f32)
+        return self._conv("csdr_amd_convert_f_s24", x, f32, np.uint8, n_out=3 * x.size, extra=(int(bigendian),))
+
+    def convert_s24_f(self, x, bigendian=0):
+        x = np.ascontiguousarray(x, np.uint8)
+        return self._conv("csdr_amd_convert_s24_f", x, np.uint8, f32, n_out=x.size // 3, extra=(int(bigendian),))
+
+    @staticmethod
+    def _2d(x, dt):
+        x = np.ascontiguousarray(x, dt)
+        return (x[None, :], True) if x.ndim == 1 else (x, False)
+
+    def shift_cc(self, x, rate, variant="addition", phase=0.0, chunk=1024, aux=0):
+        """x: [n] or [streams, n] complex64 -> (shifted, new_phase)"""
+        x2, squeeze = self._2d(x, c64)
+        s, n = x2.shape
+        di = self.upload(x2); do = self.alloc(x2.nbytes + 64)
+        dph = self.upload(np.array([phase], f32))
+        self.check(self.L.csdr_amd_shift_cc(self.h, SHIFT[variant], rate, dph.ptr, di.ptr, do.ptr, s, n, n, n, chunk, aux), "shift_cc")
+        y = self.download(do, c64, s * n).reshape(s, n)
+        ph = float(self.download(dph, f32, 1)[0])
+        return (y[0] if squeeze else y), ph
+
+    def shift_addition_fc(self, x, rate, phase=0.0, chunk=1024):
+        x = np.ascontiguousarray(x, f32); n = x.size
+        di = self.upload(x); do = self.alloc(8 * n + 64); rot = self.alloc(8 * n + 64)
+        dph = self.upload(np.array([phase], f32))
+        self.check(self.L.csdr_amd_rotator_generate(self.h, 0, rate, dph.ptr, rot.ptr, n, chunk, 0), "rotator")
+        self.check(self.L.csdr_amd_mix_fc(self.h, di.ptr, do.ptr, rot.ptr, 1, n, n, n), "mix_fc")
+        return self.download(do, c64, n), float(self.download(dph, f32, 1)[0])
+
+    def decimating_shift_addition_cc(self, x, rate, decimation, status=(0, 0.0, 0)):
+        x = np.ascontiguousarray(x, c64); n = x.size
+        dsa = np.zeros(3, f32); self.L.csdr_amd_shift_addition_init(np.float32(rate) * np.float32(decimation), _hp(dsa))
+        st = np.zeros(3, np.int32); st[0] = status[0]; st[1] = np.array([status[1]], f32).view(np.int32)[0]; st[2] = status[2]
+        di = self.upload(x); do = self.alloc(8 * (n // decimation + 4)); dd = self.upload(dsa); ds = self.upload(st)
+        self.check(self.L.csdr_amd_decimating_shift_addition_cc(self.h, di.ptr, do.ptr, 1, n, n, n // decimation + 4, dd.ptr, decimation, ds.ptr), "dsa")
+        st = self.download(ds, np.int32, 3)
+        y = self.download(do, c64, int(st[2]))
+        return y, (int(st[0]), float(st[1:2].view(f32)[0]), int(st[2]))
+
+    def fir_decimate_cc(self, x, decimation, taps):
+        x2, squeeze = self._2d(x, c64); taps = np.ascontiguousarray(taps, f32)
+        s, n = x2.shape
+        opitch = n // decimation + 2
+        di = self.upload(x2); dt = self.upload(taps); do = self.alloc(8 * s * opitch + 64)
+        no = self.check(self.L.csdr_amd_fir_decimate_cc(self.h, di.ptr, do.ptr, s, n, n, opitch, decimation, dt.ptr, taps.size), "fir_decimate_cc")
+        y = self.download(do, c64, s * opitch).reshape(s, opitch)[:, :no]
+        return y[0].copy() if squeeze else y.copy()
+
+    def fir_ff(self, x, taps):
+        x2, squeeze = self._2d(x, f32); taps = np.ascontiguousarray(taps, f32)
+        s, n = x2.shape
+        di = self.upload(x2); dt = self.upload(taps); do = self.alloc(4 * s * n + 64)
+        no = self.check(self.L.csdr_amd_fir_ff(self.h, di.ptr, do.ptr, s, n, n, n, dt.ptr, taps.size), "fir_ff")
+        y = self.download(do, f32, s * n).reshape(s, n)[:, :no]
+        return y[0].copy() if squeeze else y.copy()
+
+    def fmdemod_quadri_cf(self, x, last=None):
+        x2, squeeze = self._2d(x, c64)
+        s, n = x2.shape
+        lst = np.zeros(s, c64) if last is None else np.ascontiguousarray(last, c64).reshape(s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); dl = self.upload(lst)
+        self.check(self.L.csdr_amd_fmdemod_quadri_cf(self.h, di.ptr, do.ptr, s, n, n, n, dl.ptr), "fmdemod")
+        y = self.download(do, f32, s * n).reshape(s, n); lo = self.download(dl, c64, s)
+        return (y[0], lo[0]) if squeeze else (y, lo)
+
+    def limit_ff(self, x, m=1.0):
+        x = np.ascontiguousarray(x, f32); di = self.upload(x); do = self.alloc(x.nbytes + 64)
+        self.check(self.L.csdr_amd_limit_ff(self.h, di.ptr, do.ptr, x.size, m), "limit"); return self.download(do, f32, x.size).reshape(x.shape)
+
+    def gain_ff(self, x, g):
+        x = np.ascontiguousarray(x, f32); di = self.upload(x); do = self.alloc(x.nbytes + 64)
+        self.check(self.L.csdr_amd_gain_ff(self.h, di.ptr, do.ptr, x.size, g), "gain"); return self.download(do, f32, x.size).reshape(x.shape)
+
+    def deemphasis_wfm_ff(self, x, tau, sample_rate, last=None):
+        x2, squeeze = self._2d(x, f32)
+        s, n = x2.shape
+        lst = np.zeros(s, f32) if last is None else np.ascontiguousarray(last, f32).reshape(s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); dl = self.upload(lst)
+        self.check(self.L.csdr_amd_deemphasis_wfm_ff(self.h, di.ptr, do.ptr, s, n, n, n, tau, int(sample_rate), dl.ptr), "deemph")
+        y = self.download(do, f32, s * n).reshape(s, n); lo = self.download(dl, f32, s)
+        return (y[0], lo[0]) if squeeze else (y, lo)
+
+    def fastagc_ff(self, x, block=1024, reference=1.0, calls=1):
+        """x: [n] or [streams, n]; whole blocks only; `calls` splits the blocks over several API calls (state carry)."""
+        x2, squeeze = self._2d(x, f32)
+        s, n = x2.shape; nb = n // block
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64)
+        dst = self.upload(np.zeros(s * (2 * block + 4), f32))
+        per = max(1, (nb + calls - 1) // calls); b = 0
+        while b < nb:
+            k = min(per, nb - b)
+            self.check(self.L.csdr_amd_fastagc_ff(self.h, di.at(4 * b * block), do.at(4 * b * block), s, k, block, n, n, reference, dst.ptr), "fastagc")
+            b += k
+        y = self.download(do, f32, s * n).reshape(s, n)[:, :nb * block]
+        return y[0].copy() if squeeze else y.copy()
+
+    def fractional_decimator_ff(self, x, rate, num_poly_points=12, taps=None):
+        x2, squeeze = self._2d(x, f32)
+        s, n = x2.shape
+        tp = None if taps is None else np.ascontiguousarray(taps, f32)
+        d = self.L.csdr_amd_fracdec_create(rate, num_poly_points, None if tp is None else _hp(tp), 0 if tp is None else tp.size)
+        if not d:
+            raise CsdrAmdError(self.err())
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); proc = C.c_int(0)
+        no = self.check(self.L.csdr_amd_fractional_decimator_ff(self.h, d, di.ptr, do.ptr, s, n, n, n, C.byref(proc)), "fracdec")
+        self.sync(); self.L.csdr_amd_fracdec_destroy(d)
+        y = self.download(do, f32, s * n).reshape(s, n)[:, :no]
+        return y[0].copy() if squeeze else y.copy()
+
+    def fft_c2c(self, x, forward=True):
+        x = np.ascontiguousarray(x, c64); di = self.upload(x); do = self.alloc(x.nbytes + 64)
+        self.check(self.L.csdr_amd_fft_c2c(self.h, di.ptr, do.ptr, x.size, int(forward)), "fft"); return self.download(do, c64, x.size)
+
+    def bandpass_fir_fft_cc(self, x, taps, fft_size, blocks_per_call=None):
+        x2, squeeze = self._2d(x, c64); taps = np.ascontiguousarray(taps, c64)
+        s, n = x2.shape
+        inp = fft_size - taps.size + 1; nb = n // inp
+        per = nb if not blocks_per_call else blocks_per_call
+        f = self.L.csdr_amd_fftfilt_create(self.h, fft_size, _hp(taps), taps.size, s, max(per, 1))
+        if not f:
+            raise CsdrAmdError(self.err())
+        di = self.upload(x2); do = self.alloc(x2.nbytes + 64)
+        b = 0
+        while b < nb:
+            k = min(per, nb - b)
+            self.check(self.L.csdr_amd_fftfilt_process(f, di.at(8 * b * inp), do.at(8 * b * inp), k, n, n), "fftfilt")
+            b += k
+        y = self.download(do, c64, s * n).reshape(s, n)[:, :nb * inp]
+        self.L.csdr_amd_fftfilt_destroy(f)
+        return y[0].copy() if squeeze else y.copy()
+
+    def fastddc_init(self, tbw, decimation, shift_rate):
+        d = FastDDC(); err = self.L.csdr_amd_fastddc_init(C.byref(d), tbw, decimation, shift_rate); return d, err
+
+    def fastddc_fwd_cc(self, x, ddc, blocks_per_call=None):
+        x = np.ascontiguousarray(x, c64); nb = x.size // ddc.input_size
+        per = nb if not blocks_per_call else blocks_per_call
+        f = self.L.csdr_amd_fastddc_fwd_create(self.h, C.byref(ddc), max(per, 1))
+        if not f:
+            raise CsdrAmdError(self.err())
+        di = self.upload(x); do = self.alloc(8 * nb * ddc.fft_size + 64)
+        b = 0
+        while b < nb:
+            k = min(per, nb - b)
+            self.check(self.L.csdr_amd_fastddc_fwd_process(f, di.at(8 * b * ddc.input_size), do.at(8 * b * ddc.fft_size), k), "fastddc_fwd")
+            b += k
+        y = self.download(do, c64, nb * ddc.fft_size).reshape(nb, ddc.fft_size)
+        self.L.csdr_amd_fastddc_fwd_destroy(f)
+        return y
+
+    def fastddc_inv_cc(self, spectra, tbw, decimation, shift_rates, window="HAMMING", blocks_per_call=None):
+        """spectra [n_blocks, fft] -> list of per-channel outputs."""
+        spectra = np.ascontiguousarray(spectra, c64); nb = spectra.shape[0]
+        rates = np.ascontiguousarray(shift_rates, f32); nc = rates.size
+        per = nb if not blocks_per_call else blocks_per_call
+        f = self.L.csdr_amd_fastddc_inv_create(self.h, tbw, decimation, _hp(rates), nc, WINDOWS[window], max(per, 1))
+        if not f:
+            raise CsdrAmdError(self.err())
+        fft = spectra.shape[1]
+        di = self.upload(spectra)
+        outs = [[] for _ in range(nc)]
+        b = 0
+        while b < nb:
+            k = min(per, nb - b)
+            pitch = self.L.csdr_amd_fastddc_inv_max_output(f, k) + 8
+            do = self.alloc(8 * nc * pitch)
+            counts = np.zeros(nc, np.int32)
+            self.check(self.L.csdr_amd_fastddc_inv_process(f, di.at(8 * b * fft), k, do.ptr, pitch, _hp(counts)), "fastddc_inv")
+            y = self.download(do, c64, nc * pitch).reshape(nc, pitch)
+            for c in range(nc):
+                outs[c].append(y[c, :counts[c]].copy())
+            b += k
+        self.L.csdr_amd_fastddc_inv_destroy(f)
+        return [np.concatenate(o) for o in outs]
+
+    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None):
+        """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call."""
+        x2, squeeze = self._2d(iq_u8, np.uint8)
+        s, nbytes = x2.shape; n = nbytes // 2
+        pitch = (nbytes + 15) // 16 * 16
+        xx = np.zeros((s, pitch), np.uint8); xx[:, :nbytes] = x2
+        taps = np.ascontiguousarray(taps, f32)
+        block = n if block is None else block
+        w = self.L.csdr_amd_wfm_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, frac_rate, tau, audio_rate, max(block, 1024))
+        if not w:
+            raise CsdrAmdError(self.err())
+        di = self.upload(xx)
+        apitch = n // (decimation * frac_rate) + 64
+        ds = self.alloc(2 * s * apitch); df = self.alloc(4 * s * apitch)
+        pos = 0; na = 0
+        while pos < n:
+            k = min(block, n - pos)
+            got = self.check(self.L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na), apitch), "wfm_process")
+            pos += k; na += got
+        s16 = self.download(ds, np.int16, s * apitch).reshape(s, apitch)[:, :na]
+        af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na]
+        self.L.csdr_amd_wfm_destroy(w)
+        return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())

@@ -1,0 +1,331 @@
+// audio.hip -- demodulator and audio-rate blocks of the receive chains.
+//   fmdemod_quadri_cf       libcsdr.c:1021,1040-1071
+//   limit_ff / gain_ff      libcsdr.c:1130-1142
+//   deemphasis_wfm_ff       libcsdr.c:1081-1097
+//   fastagc_ff              libcsdr.c:946-991
+//   fractional_decimator_ff libcsdr.c:715-793
+// File is built with -ffp-contract=off: products and sums round separately like the reference's SSE code.
+#include "common.hpp"
+#include <math.h>
+#include <vector>
+#include <string.h>
+using namespace csdr_amd;
+
+namespace {
+
+// ------------------------------------------------------------------ fmdemod_quadri_cf
+__global__ __launch_bounds__(256) void k_fmdemod(const cf32 *__restrict__ in, float *__restrict__ out, size_t n,
+                                                 size_t in_pitch, size_t out_pitch, const cf32 *__restrict__ last)
+{
+    const double K = 0.340447550238101026565118445432744920253753662109375;   // libcsdr.c:1021
+    const cf32 *src = in + (size_t)blockIdx.y * in_pitch;
+    float *dst = out + (size_t)blockIdx.y * out_pitch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const cf32 x = src[k];
+        const cf32 p = k ? src[k - 1] : last[blockIdx.y];
+        const float dq = x.q - p.q, di = x.i - p.i;
+        const float num = x.i * dq - x.q * di;
+        const float den = x.i * x.i + x.q * x.q;
+        dst[k] = (den != 0.f) ? (float)(K * (double)num / (double)den) : 0.f;   // double scaling/division, :1067
+    }
+}
+__global__ void k_store_last(const cf32 *__restrict__ in, size_t n, size_t in_pitch, cf32 *__restrict__ last, int n_streams)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_streams) last[s] = in[(size_t)s * in_pitch + n - 1];
+}
+
+// ------------------------------------------------------------------ limit / gain
+__global__ __launch_bounds__(256) void k_limit(const float *__restrict__ in, float *__restrict__ out, size_t n, float m)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nv = n / 4;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+        float4 x = reinterpret_cast<const float4 *>(in)[v];
+        x.x = (m < x.x) ? m : x.x; x.x = (-m > x.x) ? -m : x.x;
+        x.y = (m < x.y) ? m : x.y; x.y = (-m > x.y) ? -m : x.y;
+        x.z = (m < x.z) ? m : x.z; x.z = (-m > x.z) ? -m : x.z;
+        x.w = (m < x.w) ? m : x.w; x.w = (-m > x.w) ? -m : x.w;
+        reinterpret_cast<float4 *>(out)[v] = x;
+    }
+    const size_t t = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) { float x = in[t]; x = (m < x) ? m : x; out[t] = (-m > x) ? -m : x; }
+}
+__global__ __launch_bounds__(256) void k_gain(const float *__restrict__ in, float *__restrict__ out, size_t n, float g)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nv = n / 4;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+        float4 x = reinterpret_cast<const float4 *>(in)[v];
+        x.x *= g; x.y *= g; x.z *= g; x.w *= g;
+        reinterpret_cast<float4 *>(out)[v] = x;
+    }
+    const size_t t = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = g * in[t];
+}
+
+// ------------------------------------------------------------------ deemphasis_wfm_ff
+// One wave owns 64 streams.  Time is walked in tiles of 64 samples: the 64x64 tile is loaded with
+// coalesced row reads (256 B per stream row) into LDS, each lane then runs ITS stream's recurrence
+// over the tile from LDS (row stride 65 floats: conflict free), and the tile is stored back coalesced.
+// The recurrence itself is the reference's, operation for operation (bit exact for finite input).
+__global__ __launch_bounds__(64) void k_deemph_wfm(const float *__restrict__ in, float *__restrict__ out, int n_streams, size_t n,
+                                                   size_t in_pitch, size_t out_pitch, float alpha, float *__restrict__ last_io)
+{
+    __shared__ float tile[64 * 65];
+    const int lane = threadIdx.x;
+    const int s0 = blockIdx.x * 64;
+    const int rows = min(64, n_streams - s0);
+    float y = 0.f;
+    if (lane < rows) { y = last_io[s0 + lane]; if (y != y) y = 0.f; }      // NaN state reset, libcsdr.c:1092
+    const float one_minus = 1 - alpha;
+    for (size_t t0 = 0; t0 < n; t0 += 64) {
+        const int cols = (int)((n - t0 < 64) ? (n - t0) : 64);
+        for (int r = 0; r < rows; r++) if (lane < cols) tile[r * 65 + lane] = in[(size_t)(s0 + r) * in_pitch + t0 + lane];
+        __syncthreads();
+        if (lane < rows) for (int k = 0; k < cols; k++) { y = alpha * tile[lane * 65 + k] + one_minus * y; tile[lane * 65 + k] = y; }
+        __syncthreads();
+        for (int r = 0; r < rows; r++) if (lane < cols) out[(size_t)(s0 + r) * out_pitch + t0 + lane] = tile[r * 65 + lane];
+        __syncthreads();
+    }
+    if (lane < rows) last_io[s0 + lane] = y;
+}
+
+// ------------------------------------------------------------------ fastagc_ff
+// State layout per stream: [buffer_1 (block) | buffer_2 (block) | peak_1 peak_2 last_gain pad]
+__device__ __forceinline__ const float *agc_seq_block(const float *state, const float *in_row, int block, int j)
+{   // the conceptual block sequence: buffer_1, buffer_2, in_0, in_1, ...
+    return (j == 0) ? state : (j == 1) ? state + block : in_row + (size_t)(j - 2) * block;
+}
+__global__ __launch_bounds__(256) void k_agc_peaks(const float *__restrict__ in, size_t in_pitch, int block, int n_blocks, float *__restrict__ peaks)
+{   // grid (n_blocks, n_streams): peak |x| of one new block (libcsdr.c:957-962)
+    const float *x = in + (size_t)blockIdx.y * in_pitch + (size_t)blockIdx.x * block;
+    float m = 0.f;
+    for (int k = threadIdx.x; k < block; k += 256) m = fmaxf(m, fabsf(x[k]));
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) peaks[(size_t)blockIdx.y * (n_blocks + 2) + 2 + blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+__global__ void k_agc_gains(float *__restrict__ peaks, float *__restrict__ gains, const float *__restrict__ state, int block, int n_blocks, int n_streams, float reference)
+{   // one lane per stream: the short sequential chain of target gains (libcsdr.c:964-971)
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_streams) return;
+    const float *st = state + (size_t)s * (2 * block + 4) + 2 * block;
+    float *pk = peaks + (size_t)s * (n_blocks + 2);
+    float *g = gains + (size_t)s * (n_blocks + 1);
+    pk[0] = st[0]; pk[1] = st[1]; g[0] = st[2];
+    for (int j = 0; j < n_blocks; j++) {
+        float peak = pk[j + 2];
+        if (peak < pk[j + 1]) peak = pk[j + 1];
+        if (peak < pk[j]) peak = pk[j];
+        float target = reference / peak;
+        if (target > 50.f) target = 50.f;
+        g[j + 1] = target;
+    }
+}
+__global__ __launch_bounds__(256) void k_agc_apply(const float *__restrict__ in, float *__restrict__ out, size_t in_pitch, size_t out_pitch,
+                                                   int block, int n_blocks, const float *__restrict__ state, const float *__restrict__ gains)
+{   // grid (n_blocks, n_streams): output block j = sequence block j with the gain ramped from g[j] to g[j+1] (:973-978)
+    const int j = blockIdx.x; const size_t s = blockIdx.y;
+    const float *x = agc_seq_block(state + s * (2 * block + 4), in + s * in_pitch, block, j);
+    const float g0 = gains[s * (n_blocks + 1) + j], g1 = gains[s * (n_blocks + 1) + j + 1];
+    float *y = out + s * out_pitch + (size_t)j * block;
+    for (int k = threadIdx.x; k < block; k += 256) {
+        const float r = (float)k / (float)block;
+        const float g = (float)((double)g0 * (1.0 - (double)r) + (double)(g1 * r));
+        y[k] = x[k] * g;
+    }
+}
+__global__ __launch_bounds__(256) void k_agc_update(const float *__restrict__ in, size_t in_pitch, int block, int n_blocks,
+                                                    float *__restrict__ state, const float *__restrict__ peaks, const float *__restrict__ gains)
+{   // grid (1, n_streams): rotate the two look-ahead buffers (libcsdr.c:983-989)
+    const size_t s = blockIdx.y;
+    float *st = state + s * (2 * block + 4);
+    const float *row = in + s * in_pitch;
+    for (int k = threadIdx.x; k < block; k += 256) {
+        const float nb1 = *(agc_seq_block(st, row, block, n_blocks) + k);
+        const float nb2 = *(agc_seq_block(st, row, block, n_blocks + 1) + k);
+        st[k] = nb1; st[block + k] = nb2;
+    }
+    if (threadIdx.x == 0) {
+        st[2 * block + 0] = peaks[s * (n_blocks + 2) + n_blocks];
+        st[2 * block + 1] = peaks[s * (n_blocks + 2) + n_blocks + 1];
+        st[2 * block + 2] = gains[s * (n_blocks + 1) + n_blocks];
+    }
+}
+
+// ------------------------------------------------------------------ fractional_decimator_ff
+__global__ __launch_bounds__(256) void k_fracdec(const float *__restrict__ in, float *__restrict__ out, int n_out, size_t in_pitch, size_t out_pitch,
+                                                 const int *__restrict__ lo_idx, const float *__restrict__ coef, int P,
+                                                 const float *__restrict__ taps, int ntaps)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    const float *x = in + (size_t)blockIdx.y * in_pitch + lo_idx[k];
+    const float *c = coef + (size_t)k * P;
+    float acc = 0.f;
+    for (int w = 0; w < P; w++) {
+        float y;
+        if (ntaps) { y = 0.f; for (int t = 0; t < ntaps; t++) y += taps[t] * x[w + t]; }   // fir_one_pass_ff libcsdr.c:675-680
+        else y = x[w];
+        acc += c[w] * y;
+    }
+    out[(size_t)blockIdx.y * out_pitch + k] = acc;
+}
+
+} // namespace
+
+struct csdr_amd_fracdec {
+    float where, rate; int input_processed, num_poly_points, xifirst, xilast, taps_length;
+    std::vector<float> denom, taps;
+    // cached plan
+    float plan_where; int plan_n; bool plan_valid; int plan_outputs, plan_processed; float plan_where_after;
+    std::vector<int> lo; std::vector<float> coef;
+    int *d_lo; float *d_coef; float *d_taps; size_t d_cap;
+};
+
+extern "C" {
+
+int csdr_amd_fmdemod_quadri_cf(csdr_amd_ctx *c, const csdr_complexf *in, float *out, int n_streams, size_t n,
+                               size_t in_pitch, size_t out_pitch, csdr_complexf *last_io)
+{
+    if (!n || n_streams <= 0) return 0;
+    size_t gx = (n + 255) / 256; if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_fmdemod, dim3((unsigned)gx, (unsigned)n_streams), dim3(256), 0, c->stream, in, out, n, in_pitch, out_pitch, last_io);
+    CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_store_last, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, n, in_pitch, last_io, n_streams);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int csdr_amd_limit_ff(csdr_amd_ctx *c, const float *in, float *out, size_t n, float m)
+{
+    if (!n) return 0;
+    if (((uintptr_t)in | (uintptr_t)out) & 15) return fail_msg(-3, "limit_ff: pointers must be 16-byte aligned");
+    size_t g = (n / 4 + 255) / 256; g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    hipLaunchKernelGGL(k_limit, dim3((unsigned)g), dim3(256), 0, c->stream, in, out, n, m); CSDR_LAUNCH_CHECK();
+    return 0;
+}
+int csdr_amd_gain_ff(csdr_amd_ctx *c, const float *in, float *out, size_t n, float gval)
+{
+    if (!n) return 0;
+    if (((uintptr_t)in | (uintptr_t)out) & 15) return fail_msg(-3, "gain_ff: pointers must be 16-byte aligned");
+    size_t g = (n / 4 + 255) / 256; g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    hipLaunchKernelGGL(k_gain, dim3((unsigned)g), dim3(256), 0, c->stream, in, out, n, gval); CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int csdr_amd_deemphasis_wfm_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams, size_t n,
+                               size_t in_pitch, size_t out_pitch, float tau, int sample_rate, float *last_io)
+{
+    if (!n || n_streams <= 0) return 0;
+    const float dt = (float)(1.0 / sample_rate);            // libcsdr.c:1090-1091, float after a double division
+    const float alpha = dt / (tau + dt);
+    hipLaunchKernelGGL(k_deemph_wfm, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, n, in_pitch, out_pitch, alpha, last_io);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int csdr_amd_fastagc_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams, int n_blocks, int block,
+                        size_t in_pitch, size_t out_pitch, float reference, float *state_io)
+{
+    if (n_blocks <= 0 || n_streams <= 0) return 0;
+    float *peaks = (float *)c->get_scratch(3, sizeof(float) * (size_t)n_streams * (2 * n_blocks + 3));
+    if (!peaks) return -2;
+    float *gains = peaks + (size_t)n_streams * (n_blocks + 2);
+    hipLaunchKernelGGL(k_agc_peaks, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, peaks); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_agc_gains, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, peaks, gains, state_io, block, n_blocks, n_streams, reference); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_agc_apply, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, out, in_pitch, out_pitch, block, n_blocks, state_io, gains); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_agc_update, dim3(1, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, state_io, peaks, gains); CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+csdr_amd_fracdec *csdr_amd_fracdec_create(float rate, int num_poly_points, const float *host_taps, int taps_length)
+{   // fractional_decimator_ff_init libcsdr.c:715-748
+    if (!(rate > 1.0f) || num_poly_points < 2 || num_poly_points > 64) { fail_msg(-3, "fracdec: need rate > 1 and 2 <= num_poly_points <= 64"); return nullptr; }
+    csdr_amd_fracdec *d = new csdr_amd_fracdec();
+    d->num_poly_points = num_poly_points & ~1;
+    d->xifirst = -(num_poly_points / 2) + 1; d->xilast = num_poly_points / 2;
+    for (int a = d->xifirst; a <= d->xilast; a++) {
+        float prod = 1;
+        for (int b = d->xifirst; b <= d->xilast; b++) if (a != b) prod *= (a - b);
+        d->denom.push_back(prod);
+    }
+    d->where = (float)(-d->xifirst); d->rate = rate; d->input_processed = 0;
+    d->taps_length = host_taps ? taps_length : 0;
+    if (d->taps_length) d->taps.assign(host_taps, host_taps + taps_length);
+    d->plan_valid = false; d->d_lo = nullptr; d->d_coef = nullptr; d->d_taps = nullptr; d->d_cap = 0;
+    return d;
+}
+
+void  csdr_amd_fracdec_set_where(csdr_amd_fracdec *d, float where) { d->where = where; }
+float csdr_amd_fracdec_get_where(const csdr_amd_fracdec *d) { return d->where; }
+
+void csdr_amd_fracdec_destroy(csdr_amd_fracdec *d)
+{
+    if (!d) return;
+    if (d->d_lo) (void)hipFree(d->d_lo);
+    if (d->d_coef) (void)hipFree(d->d_coef);
+    if (d->d_taps) (void)hipFree(d->d_taps);
+    delete d;
+}
+
+int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const float *in, float *out, int n_streams, int input_size,
+                                     size_t in_pitch, size_t out_pitch, int *input_processed)
+{
+    const int P = d->num_poly_points;
+    if (!(d->plan_valid && d->plan_where == d->where && d->plan_n == input_size)) {
+        // Replay the reference's float position bookkeeping (libcsdr.c:762-792) on the host: it does not depend
+        // on the samples, only on (where, rate, input_size).
+        d->lo.clear(); d->coef.clear();
+        float where = d->where; int hi;
+        for (; (hi = (int)ceilf(where)) + P + d->taps_length < input_size; where += d->rate) {
+            const int lo = hi - 1;
+            const float x = where - lo;
+            d->lo.push_back(lo);
+            int idx = 0;
+            for (int a = d->xifirst; a <= d->xilast; a++, idx++) {
+                float prod = 1;
+                for (int b = d->xifirst; b <= d->xilast; b++) if (a != b) prod *= (x - b);
+                d->coef.push_back(prod / d->denom[idx]);
+            }
+        }
+        d->plan_processed = (hi - 1) + d->xifirst;
+        d->plan_where_after = where - d->plan_processed;
+        d->plan_outputs = (int)d->lo.size();
+        d->plan_where = d->where; d->plan_n = input_size;
+        const size_t need = d->lo.size() + 1;
+        if (need > d->d_cap) {
+            CSDR_HIP(hipStreamSynchronize(c->stream));
+            if (d->d_lo) (void)hipFree(d->d_lo);
+            if (d->d_coef) (void)hipFree(d->d_coef);
+            d->d_cap = need + need / 2;
+            CSDR_HIP(hipMalloc((void **)&d->d_lo, sizeof(int) * d->d_cap));
+            CSDR_HIP(hipMalloc((void **)&d->d_coef, sizeof(float) * d->d_cap * P));
+        }
+        if (d->taps_length && !d->d_taps) {
+            CSDR_HIP(hipMalloc((void **)&d->d_taps, sizeof(float) * d->taps_length));
+            CSDR_HIP(hipMemcpy(d->d_taps, d->taps.data(), sizeof(float) * d->taps_length, hipMemcpyHostToDevice));
+        }
+        if (d->plan_outputs) {
+            CSDR_HIP(hipStreamSynchronize(c->stream));     // previous launch may still read the old plan
+            CSDR_HIP(hipMemcpy(d->d_lo, d->lo.data(), sizeof(int) * d->lo.size(), hipMemcpyHostToDevice));
+            CSDR_HIP(hipMemcpy(d->d_coef, d->coef.data(), sizeof(float) * d->coef.size(), hipMemcpyHostToDevice));
+        }
+        d->plan_valid = true;
+    }
+    if (d->plan_outputs && n_streams > 0) {
+        hipLaunchKernelGGL(k_fracdec, dim3(cdiv(d->plan_outputs, 256), n_streams), dim3(256), 0, c->stream, in, out, d->plan_outputs,
+                           in_pitch, out_pitch, d->d_lo, d->d_coef, P, d->d_taps, d->taps_length);
+        CSDR_LAUNCH_CHECK();
+    }
+    d->input_processed = d->plan_processed;
+    d->where = d->plan_where_after;
+    if (input_processed) *input_processed = d->input_processed;
+    return d->plan_outputs;
+}
+
+} // extern "C"

@@ -1,0 +1,39 @@
+// common.hpp -- shared host-side plumbing for libcsdr_amd.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/csdr_amd.h"
+
+namespace csdr_amd {
+
+typedef csdr_complexf cf32;
+
+int fail(hipError_t e, const char *what, const char *file, int line);
+int fail_msg(int code, const char *fmt, ...);
+
+#define CSDR_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return ::csdr_amd::fail(e__, #expr, __FILE__, __LINE__); } while (0)
+#define CSDR_LAUNCH_CHECK() CSDR_HIP(hipGetLastError())
+
+// float constant PI exactly as the reference defines it (libcsdr.h:65): a float, not a double
+static const float PI_F = (float)3.14159265358979323846;
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+enum { SCRATCH_SLOTS = 8 };
+
+} // namespace csdr_amd
+
+struct csdr_amd_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    std::string arch;
+    void *scratch[csdr_amd::SCRATCH_SLOTS];
+    size_t scratch_bytes[csdr_amd::SCRATCH_SLOTS];
+    hipEvent_t ev0, ev1;
+    // returns a device buffer of at least `bytes` that stays valid until the next request on the same slot
+    void *get_scratch(int slot, size_t bytes);
+};

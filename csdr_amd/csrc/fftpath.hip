@@ -1,0 +1,515 @@
+// fftpath.hip -- the FFT-domain filters of the hot path, FFTs by hipFFT/rocFFT (batched), everything
+// around them (framing, bin products, alias folding, overlap stitching, residual shift) as HIP kernels:
+//
+//   bandpass_fir_fft_cc  csdr.c:1810-1886 + apply_fir_fft_cc libcsdr.c:814-849   (overlap-add)
+//   fastddc_fwd_cc       csdr.c:2255-2300                                        (overlap-save framing + big FFT)
+//   fastddc_inv_cc       csdr.c:2302-2378 + fastddc.c:106-166                    (fold x taps, small IFFT, scrap, shift)
+//
+// Blocks of one call are transformed together (one batched plan) and stitched on the device; the
+// block-to-block dependency of the reference (previous block's tail) becomes a gather from the neighbouring
+// block of the batch plus a small carry buffer between calls.
+#include "common.hpp"
+#include <hipfft/hipfft.h>
+#include <math.h>
+#include <vector>
+#include <map>
+#include <string.h>
+using namespace csdr_amd;
+
+#define CSDR_FFT(expr) do { hipfftResult r__ = (expr); if (r__ != HIPFFT_SUCCESS) return ::csdr_amd::fail_msg(-5, "hipFFT error %d at %s:%d: %s", (int)r__, __FILE__, __LINE__, #expr); } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------ overlap-add filter kernels
+__global__ __launch_bounds__(256) void k_oa_frame(const cf32 *__restrict__ in, size_t in_pitch, cf32 *__restrict__ padded,
+                                                  int fft, int inp, int n_blocks)
+{   // grid (fft/256.., n_blocks, n_streams): zero padded copy of each input block (csdr.c:1864,1873)
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= fft) return;
+    const size_t s = blockIdx.z, b = blockIdx.y;
+    cf32 v = cf32{0.f, 0.f};
+    if (k < inp) v = in[s * in_pitch + b * (size_t)inp + k];
+    padded[(s * n_blocks + b) * (size_t)fft + k] = v;
+}
+__global__ __launch_bounds__(256) void k_bin_product(cf32 *__restrict__ spec, const cf32 *__restrict__ taps_fft, int fft, size_t total)
+{   // libcsdr.c:826-830
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const cf32 a = spec[idx], h = taps_fft[idx % fft];
+    spec[idx] = cf32{a.i * h.i - a.q * h.q, a.i * h.q + a.q * h.i};
+}
+__global__ __launch_bounds__(256) void k_oa_stitch(const cf32 *__restrict__ td, const cf32 *__restrict__ carry, cf32 *__restrict__ out, size_t out_pitch,
+                                                   int fft, int inp, int ovl, int n_blocks, float inv_n)
+{   // out position P = b*inp + i receives every block's inverse-FFT sample that lands on it plus the carried tail
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= inp) return;
+    const size_t s = blockIdx.z; const int b = blockIdx.y;
+    const cf32 *base = td + s * n_blocks * (size_t)fft;
+    float ai = 0.f, aq = 0.f;
+    // oldest contribution first (the reference accumulates tails forward in time, libcsdr.c:843-847)
+    int mmax = (fft - 1 - i) / inp; if (mmax > b) mmax = b;
+    const size_t P = (size_t)b * inp + i;
+    if (P < (size_t)ovl) { const cf32 c0 = carry[s * ovl + P]; ai = c0.i; aq = c0.q; }
+    for (int m = mmax; m >= 0; m--) {
+        const cf32 v = base[(size_t)(b - m) * fft + i + (size_t)m * inp];
+        ai += v.i * inv_n; aq += v.q * inv_n;
+    }
+    out[s * out_pitch + P] = cf32{ai, aq};
+}
+__global__ __launch_bounds__(256) void k_oa_carry(const cf32 *__restrict__ td, const cf32 *__restrict__ carry_in, cf32 *__restrict__ carry_out,
+                                                  int fft, int inp, int ovl, int n_blocks, float inv_n)
+{   // pending tail after n_blocks blocks: contributions landing on positions n_blocks*inp + i, i < ovl
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ovl) return;
+    const size_t s = blockIdx.y;
+    const cf32 *base = td + s * n_blocks * (size_t)fft;
+    const size_t P = (size_t)n_blocks * inp + i;
+    float ai = 0.f, aq = 0.f;
+    if (P < (size_t)ovl) { const cf32 c0 = carry_in[s * ovl + P]; ai = c0.i; aq = c0.q; }
+    for (int b = 0; b < n_blocks; b++) {
+        const size_t idx = P - (size_t)b * inp;
+        if (idx < (size_t)fft) { const cf32 v = base[(size_t)b * fft + idx]; ai += v.i * inv_n; aq += v.q * inv_n; }
+    }
+    carry_out[s * ovl + i] = cf32{ai, aq};
+}
+
+// ------------------------------------------------------------------ fastddc kernels
+__global__ __launch_bounds__(256) void k_os_frame(const cf32 *__restrict__ in, const cf32 *__restrict__ tail, cf32 *__restrict__ win,
+                                                  int fft, int inp, int ovl)
+{   // overlap-save window b = stream[b*inp - ovl, b*inp + inp) (csdr.c:2292-2293); positions < 0 come from the kept tail
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= fft) return;
+    const long long pos = (long long)blockIdx.y * inp - ovl + k;
+    win[(size_t)blockIdx.y * fft + k] = (pos < 0) ? tail[ovl + pos] : in[pos];
+}
+__global__ __launch_bounds__(256) void k_os_tail(const cf32 *__restrict__ in, const cf32 *__restrict__ tail_in, cf32 *__restrict__ tail_out, int inp, int ovl, int n_blocks)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ovl) return;
+    const long long pos = (long long)n_blocks * inp - ovl + k;
+    tail_out[k] = (pos < 0) ? tail_in[ovl + pos] : in[pos];
+}
+__global__ __launch_bounds__(256) void k_swap_halves(cf32 *__restrict__ a, int n, size_t total)
+{   // fft_swap_sides fastddc.c:91-104 over a batch, out of place not needed: pairwise exchange
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t half = n / 2;
+    const size_t row = idx / half, k = idx % half;
+    if (row * n >= total) return;
+    cf32 *p = a + row * n;
+    const cf32 t = p[k]; p[k] = p[k + half]; p[k + half] = t;
+}
+
+struct ChanGeom { int offsetbin; float sindelta, cosdelta, rate2; };
+
+// alias fold: inv_in[c][b][(m + inv/2) % inv] = (1/pre) * sum_q Xs[i0 + q*inv] * H[c][i0 + q*inv],  i0 = (m + offsetbin - inv/2) mod inv
+// (fastddc.c:123-150; Xs = fft_swap_sides(X), the final index shift is the second fft_swap_sides)
+__global__ __launch_bounds__(256) void k_ddc_fold(const cf32 *__restrict__ spectra, const cf32 *__restrict__ H, cf32 *__restrict__ inv_in,
+                                                  const ChanGeom *__restrict__ geom, int fft, int inv, int pre, int n_blocks, int b_chunk)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= inv) return;
+    const int c = blockIdx.z;
+    const int off = geom[c].offsetbin;
+    int i0 = (m + off - inv / 2) % inv; if (i0 < 0) i0 += inv;
+    const cf32 *h = H + (size_t)c * fft;
+    const int dst = (m + inv / 2) % inv;
+    const float scale = 1.0f / (float)pre;
+    const int b0 = blockIdx.y * b_chunk, b1 = min(n_blocks, b0 + b_chunk);
+    for (int b = b0; b < b1; b++) {
+        const cf32 *x = spectra + (size_t)b * fft;
+        float ai = 0.f, aq = 0.f;
+        for (int q = 0; q < pre; q++) {
+            const int i = i0 + q * inv;
+            const cf32 xv = x[(i + fft / 2) % fft], hv = h[i];
+            ai += xv.i * hv.i - xv.q * hv.q;
+            aq += xv.i * hv.q + xv.q * hv.i;
+        }
+        inv_in[((size_t)c * n_blocks + b) * inv + dst] = cf32{ai * scale, aq * scale};
+    }
+}
+
+struct DdcChanState { int remain; float phase; };
+// per channel: the (remain, phase, output offset) chain over the blocks of this call -- data independent
+__global__ void k_ddc_chain(DdcChanState *__restrict__ state, const ChanGeom *__restrict__ geom, int n_channels, int n_blocks,
+                            int post_in, int post_dec, int *__restrict__ blk_remain, float *__restrict__ blk_phase, int *__restrict__ blk_off, int *__restrict__ counts)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_channels) return;
+    DdcChanState s = state[c];
+    const float r = geom[c].rate2;
+    int off = 0;
+    for (int b = 0; b < n_blocks; b++) {
+        blk_remain[(size_t)c * n_blocks + b] = s.remain; blk_phase[(size_t)c * n_blocks + b] = s.phase; blk_off[(size_t)c * n_blocks + b] = off;
+        int k = 0, pos = s.remain;
+        if (pos < post_in) { k = (post_in - 1 - pos) / post_dec + 1; pos += k * post_dec; }
+        s.remain = pos - post_in;
+        float p = s.phase + r * PI_F * (float)k;                       // libcsdr_gpl.c:155
+        while (p > PI_F) p -= 2 * PI_F;
+        while (p < -PI_F) p += 2 * PI_F;
+        s.phase = p; off += k;
+    }
+    state[c] = s; counts[c] = off;
+}
+// one lane per (channel, block): scrap + /inv + decimating_shift_addition_cc replay (fastddc.c:153-162, libcsdr_gpl.c:131-160)
+__global__ __launch_bounds__(64) void k_ddc_post(const cf32 *__restrict__ td, cf32 *__restrict__ out, size_t out_pitch, const ChanGeom *__restrict__ geom,
+                                                 int n_channels, int n_blocks, int inv, int scrap, int post_in, int post_dec,
+                                                 const int *__restrict__ blk_remain, const float *__restrict__ blk_phase, const int *__restrict__ blk_off)
+{
+    const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (idx >= (size_t)n_channels * n_blocks) return;
+    const int c = (int)(idx / n_blocks);
+    const cf32 *x = td + idx * inv + scrap;
+    cf32 *dst = out + (size_t)c * out_pitch + blk_off[idx];
+    const float sd = geom[c].sindelta, cd = geom[c].cosdelta;
+    const float ph = blk_phase[idx];
+    float co = (float)cos((double)ph), sn = (float)sin((double)ph);
+    const float inv_n = 1.0f / (float)inv;
+    int k = 0;
+    for (int pos = blk_remain[idx]; pos < post_in; pos += post_dec) {
+        const cf32 v = cf32{x[pos].i * inv_n, x[pos].q * inv_n};
+        dst[k++] = cf32{co * v.i - sn * v.q, sn * v.i + co * v.q};
+        const float c1 = co * cd - sn * sd, s1 = sn * cd + co * sd;
+        co = c1; sn = s1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cmul(const cf32 *__restrict__ a, const cf32 *__restrict__ b, cf32 *__restrict__ out, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const cf32 x = a[k], h = b[k];
+    out[k] = cf32{x.i * h.i - x.q * h.q, x.i * h.q + x.q * h.i};
+}
+__global__ __launch_bounds__(256) void k_scale_add(cf32 *__restrict__ io, size_t n, float scale, const cf32 *__restrict__ add, size_t n_add)
+{
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    cf32 v = io[k]; v.i *= scale; v.q *= scale;
+    if (k < n_add) { v.i += add[k].i; v.q += add[k].q; }
+    io[k] = v;
+}
+
+} // namespace
+
+// cached single-transform plans for the drop-in FFT layer
+static std::map<std::pair<int, long>, hipfftHandle> g_c2c_plans;
+
+extern "C" {
+
+int csdr_amd_fft_c2c(csdr_amd_ctx *c, const csdr_complexf *in, csdr_complexf *out, int n, int forward)
+{
+    auto key = std::make_pair(n, (long)(uintptr_t)c->stream);
+    if (!g_c2c_plans.count(key)) {
+        hipfftHandle h;
+        CSDR_FFT(hipfftPlan1d(&h, n, HIPFFT_C2C, 1));
+        CSDR_FFT(hipfftSetStream(h, c->stream));
+        g_c2c_plans[key] = h;
+    }
+    CSDR_FFT(hipfftExecC2C(g_c2c_plans[key], (hipfftComplex *)in, (hipfftComplex *)out, forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    return 0;
+}
+int csdr_amd_bin_product(csdr_amd_ctx *c, const csdr_complexf *a, const csdr_complexf *b, csdr_complexf *out, size_t n)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_cmul, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, a, b, out, n); CSDR_LAUNCH_CHECK();
+    return 0;
+}
+int csdr_amd_scale_add(csdr_amd_ctx *c, csdr_complexf *io, size_t n, float scale, const csdr_complexf *add, size_t n_add)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_scale_add, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, io, n, scale, add, n_add); CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"
+
+// ====================================================================================== overlap-add object
+struct csdr_amd_fftfilt {
+    csdr_amd_ctx *ctx;
+    int fft, taps_len, inp, ovl, n_streams, max_blocks;
+    cf32 *d_taps_fft, *d_pad, *d_td, *d_carry[2];
+    int flip;
+    hipfftHandle plan_one, plan_batch; int plan_batch_n;
+};
+
+static int fftfilt_make_batch_plan(csdr_amd_fftfilt *f, int batch)
+{
+    if (f->plan_batch_n == batch) return 0;
+    if (f->plan_batch_n) { hipfftDestroy(f->plan_batch); f->plan_batch_n = 0; }
+    int n[1] = {f->fft};
+    CSDR_FFT(hipfftPlanMany(&f->plan_batch, 1, n, nullptr, 1, f->fft, nullptr, 1, f->fft, HIPFFT_C2C, batch));
+    CSDR_FFT(hipfftSetStream(f->plan_batch, f->ctx->stream));
+    f->plan_batch_n = batch;
+    return 0;
+}
+
+extern "C" {
+
+int csdr_amd_fftfilt_set_taps(csdr_amd_fftfilt *f, const csdr_complexf *host_taps, int taps_length)
+{   // csdr.c:1869-1871: zero padded taps -> forward FFT
+    if (taps_length != f->taps_len) return fail_msg(-3, "fftfilt: taps_length changed (%d -> %d); create a new filter", f->taps_len, taps_length);
+    std::vector<cf32> pad((size_t)f->fft, cf32{0.f, 0.f});
+    for (int k = 0; k < taps_length; k++) pad[k] = host_taps[k];
+    CSDR_HIP(hipStreamSynchronize(f->ctx->stream));
+    CSDR_HIP(hipMemcpy(f->d_taps_fft, pad.data(), sizeof(cf32) * f->fft, hipMemcpyHostToDevice));
+    CSDR_FFT(hipfftExecC2C(f->plan_one, (hipfftComplex *)f->d_taps_fft, (hipfftComplex *)f->d_taps_fft, HIPFFT_FORWARD));
+    return 0;
+}
+
+csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const csdr_complexf *host_taps, int taps_length, int n_streams, int max_blocks)
+{
+    if (fft_size < 4 || (fft_size & (fft_size - 1)) || taps_length < 1 || taps_length > fft_size || n_streams < 1 || max_blocks < 1) {
+        fail_msg(-3, "fftfilt: need power-of-two fft_size >= taps_length"); return nullptr; }
+    csdr_amd_fftfilt *f = new csdr_amd_fftfilt();
+    f->ctx = ctx; f->fft = fft_size; f->taps_len = taps_length; f->inp = fft_size - taps_length + 1; f->ovl = taps_length - 1;
+    f->n_streams = n_streams; f->max_blocks = max_blocks; f->flip = 0; f->plan_batch_n = 0;
+    const size_t tot = (size_t)n_streams * max_blocks * fft_size;
+    hipError_t e = hipMalloc((void **)&f->d_taps_fft, sizeof(cf32) * fft_size);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_pad, sizeof(cf32) * tot);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_td, sizeof(cf32) * tot);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_carry[0], sizeof(cf32) * (size_t)n_streams * (f->ovl + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_carry[1], sizeof(cf32) * (size_t)n_streams * (f->ovl + 1));
+    if (e != hipSuccess) { fail(e, "hipMalloc(fftfilt)", __FILE__, __LINE__); delete f; return nullptr; }
+    if (hipfftPlan1d(&f->plan_one, fft_size, HIPFFT_C2C, 1) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlan1d(%d) failed", fft_size); delete f; return nullptr; }
+    hipfftSetStream(f->plan_one, ctx->stream);
+    if (csdr_amd_fftfilt_set_taps(f, host_taps, taps_length) || csdr_amd_fftfilt_reset(f)) { delete f; return nullptr; }
+    return f;
+}
+
+void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f)
+{
+    if (!f) return;
+    (void)hipStreamSynchronize(f->ctx->stream);
+    hipfftDestroy(f->plan_one); if (f->plan_batch_n) hipfftDestroy(f->plan_batch);
+    (void)hipFree(f->d_taps_fft); (void)hipFree(f->d_pad); (void)hipFree(f->d_td); (void)hipFree(f->d_carry[0]); (void)hipFree(f->d_carry[1]);
+    delete f;
+}
+
+int csdr_amd_fftfilt_input_size(const csdr_amd_fftfilt *f) { return f->inp; }
+
+int csdr_amd_fftfilt_reset(csdr_amd_fftfilt *f)
+{   // csdr.c:1862: the first block's overlap source is all zeros
+    CSDR_HIP(hipMemsetAsync(f->d_carry[0], 0, sizeof(cf32) * (size_t)f->n_streams * (f->ovl + 1), f->ctx->stream));
+    CSDR_HIP(hipMemsetAsync(f->d_carry[1], 0, sizeof(cf32) * (size_t)f->n_streams * (f->ovl + 1), f->ctx->stream));
+    f->flip = 0;
+    return 0;
+}
+
+int csdr_amd_fftfilt_process(csdr_amd_fftfilt *f, const csdr_complexf *in, csdr_complexf *out, int n_blocks, size_t in_pitch, size_t out_pitch)
+{
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > f->max_blocks) return fail_msg(-3, "fftfilt: %d blocks exceed max_blocks %d", n_blocks, f->max_blocks);
+    hipStream_t st = f->ctx->stream;
+    const int batch = f->n_streams * n_blocks;
+    int rc = fftfilt_make_batch_plan(f, batch); if (rc) return rc;
+    hipLaunchKernelGGL(k_oa_frame, dim3(cdiv(f->fft, 256), n_blocks, f->n_streams), dim3(256), 0, st, in, in_pitch, f->d_pad, f->fft, f->inp, n_blocks); CSDR_LAUNCH_CHECK();
+    CSDR_FFT(hipfftExecC2C(f->plan_batch, (hipfftComplex *)f->d_pad, (hipfftComplex *)f->d_pad, HIPFFT_FORWARD));
+    const size_t total = (size_t)batch * f->fft;
+    hipLaunchKernelGGL(k_bin_product, dim3(cdiv(total, 256)), dim3(256), 0, st, f->d_pad, f->d_taps_fft, f->fft, total); CSDR_LAUNCH_CHECK();
+    CSDR_FFT(hipfftExecC2C(f->plan_batch, (hipfftComplex *)f->d_pad, (hipfftComplex *)f->d_td, HIPFFT_BACKWARD));
+    const float inv_n = 1.0f / (float)f->fft;
+    hipLaunchKernelGGL(k_oa_stitch, dim3(cdiv(f->inp, 256), n_blocks, f->n_streams), dim3(256), 0, st, f->d_td, f->d_carry[f->flip], out, out_pitch,
+                       f->fft, f->inp, f->ovl, n_blocks, inv_n); CSDR_LAUNCH_CHECK();
+    if (f->ovl > 0) {
+        hipLaunchKernelGGL(k_oa_carry, dim3(cdiv(f->ovl, 256), f->n_streams), dim3(256), 0, st, f->d_td, f->d_carry[f->flip], f->d_carry[f->flip ^ 1],
+                           f->fft, f->inp, f->ovl, n_blocks, inv_n); CSDR_LAUNCH_CHECK();
+        f->flip ^= 1;
+    }
+    return 0;
+}
+
+} // extern "C"
+
+// ====================================================================================== fastddc forward
+struct csdr_amd_fastddc_fwd {
+    csdr_amd_ctx *ctx; csdr_fastddc_t ddc; int max_blocks;
+    cf32 *d_win, *d_tail[2]; int flip;
+    std::map<int, hipfftHandle> plans;
+};
+
+extern "C" {
+
+csdr_amd_fastddc_fwd *csdr_amd_fastddc_fwd_create(csdr_amd_ctx *ctx, const csdr_fastddc_t *ddc, int max_blocks)
+{
+    csdr_amd_fastddc_fwd *f = new csdr_amd_fastddc_fwd();
+    f->ctx = ctx; f->ddc = *ddc; f->max_blocks = max_blocks; f->flip = 0;
+    hipError_t e = hipMalloc((void **)&f->d_win, sizeof(cf32) * (size_t)max_blocks * ddc->fft_size);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_tail[0], sizeof(cf32) * (size_t)(ddc->overlap_length + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_tail[1], sizeof(cf32) * (size_t)(ddc->overlap_length + 1));
+    if (e != hipSuccess) { fail(e, "hipMalloc(fastddc_fwd)", __FILE__, __LINE__); delete f; return nullptr; }
+    (void)hipMemsetAsync(f->d_tail[0], 0, sizeof(cf32) * (size_t)(ddc->overlap_length + 1), ctx->stream);   // csdr.c:2279 null input buffer
+    (void)hipMemsetAsync(f->d_tail[1], 0, sizeof(cf32) * (size_t)(ddc->overlap_length + 1), ctx->stream);
+    return f;
+}
+
+void csdr_amd_fastddc_fwd_destroy(csdr_amd_fastddc_fwd *f)
+{
+    if (!f) return;
+    (void)hipStreamSynchronize(f->ctx->stream);
+    for (auto &kv : f->plans) hipfftDestroy(kv.second);
+    (void)hipFree(f->d_win); (void)hipFree(f->d_tail[0]); (void)hipFree(f->d_tail[1]);
+    delete f;
+}
+
+int csdr_amd_fastddc_fwd_process(csdr_amd_fastddc_fwd *f, const csdr_complexf *in, csdr_complexf *spectra, int n_blocks)
+{
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > f->max_blocks) return fail_msg(-3, "fastddc_fwd: %d blocks exceed max_blocks %d", n_blocks, f->max_blocks);
+    hipStream_t st = f->ctx->stream;
+    const int fft = f->ddc.fft_size, inp = f->ddc.input_size, ovl = f->ddc.overlap_length;
+    if (!f->plans.count(n_blocks)) {
+        hipfftHandle h; int n[1] = {fft};
+        CSDR_FFT(hipfftPlanMany(&h, 1, n, nullptr, 1, fft, nullptr, 1, fft, HIPFFT_C2C, n_blocks));
+        CSDR_FFT(hipfftSetStream(h, st));
+        f->plans[n_blocks] = h;
+    }
+    hipLaunchKernelGGL(k_os_frame, dim3(cdiv(fft, 256), n_blocks), dim3(256), 0, st, in, f->d_tail[f->flip], f->d_win, fft, inp, ovl); CSDR_LAUNCH_CHECK();
+    CSDR_FFT(hipfftExecC2C(f->plans[n_blocks], (hipfftComplex *)f->d_win, (hipfftComplex *)spectra, HIPFFT_FORWARD));
+    hipLaunchKernelGGL(k_os_tail, dim3(cdiv(ovl, 256)), dim3(256), 0, st, in, f->d_tail[f->flip], f->d_tail[f->flip ^ 1], inp, ovl, n_blocks); CSDR_LAUNCH_CHECK();
+    f->flip ^= 1;
+    return 0;
+}
+
+} // extern "C"
+
+// ====================================================================================== fastddc inverse (multi channel)
+struct csdr_amd_fastddc_inv {
+    csdr_amd_ctx *ctx; int n_channels, max_blocks;
+    std::vector<csdr_fastddc_t> geom;
+    cf32 *d_H, *d_inv_in, *d_td;
+    ChanGeom *d_geom; DdcChanState *d_state;
+    int *d_blk_remain, *d_blk_off, *d_counts; float *d_blk_phase;
+    std::map<int, hipfftHandle> plans;
+};
+
+extern "C" {
+
+csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *shift_rates,
+                                                  int n_channels, int window, int max_blocks)
+{
+    if (n_channels < 1 || max_blocks < 1) { fail_msg(-3, "fastddc_inv: bad sizes"); return nullptr; }
+    csdr_amd_fastddc_inv *f = new csdr_amd_fastddc_inv();
+    f->ctx = ctx; f->n_channels = n_channels; f->max_blocks = max_blocks;
+    f->geom.resize(n_channels);
+    std::vector<ChanGeom> cg(n_channels);
+    for (int c = 0; c < n_channels; c++) {
+        if (csdr_amd_fastddc_init(&f->geom[c], transition_bw, decimation, shift_rates[c])) { fail_msg(-3, "fastddc_init failed (fft_size <= 2)"); delete f; return nullptr; }
+        cg[c].offsetbin = f->geom[c].offsetbin; cg[c].sindelta = f->geom[c].dsadata.sindelta; cg[c].cosdelta = f->geom[c].dsadata.cosdelta; cg[c].rate2 = f->geom[c].dsadata.rate;
+    }
+    const csdr_fastddc_t &g = f->geom[0];
+    const int fft = g.fft_size, inv = g.fft_inv_size;
+    hipError_t e = hipMalloc((void **)&f->d_H, sizeof(cf32) * (size_t)n_channels * fft);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_inv_in, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_td, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_geom, sizeof(ChanGeom) * n_channels);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_state, sizeof(DdcChanState) * n_channels);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_blk_remain, sizeof(int) * (size_t)n_channels * max_blocks);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_blk_off, sizeof(int) * (size_t)n_channels * max_blocks);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_blk_phase, sizeof(float) * (size_t)n_channels * max_blocks);
+    if (e == hipSuccess) e = hipMalloc((void **)&f->d_counts, sizeof(int) * n_channels);
+    if (e != hipSuccess) { fail(e, "hipMalloc(fastddc_inv)", __FILE__, __LINE__); delete f; return nullptr; }
+    (void)hipMemcpy(f->d_geom, cg.data(), sizeof(ChanGeom) * n_channels, hipMemcpyHostToDevice);
+    (void)hipMemset(f->d_state, 0, sizeof(DdcChanState) * n_channels);                 // csdr.c:2363-2364 bzero(shift_stat)
+    // per channel band-pass taps (csdr.c:2345-2349), zero padded, FFT'd in one batch, then fft_swap_sides (csdr.c:2350-2351)
+    {
+        std::vector<cf32> taps((size_t)n_channels * fft, cf32{0.f, 0.f});
+        std::vector<cf32> one(g.taps_length);
+        const float half_bw = 0.5f / (float)decimation;
+        for (int c = 0; c < n_channels; c++) {
+            csdr_amd_firdes_bandpass_c(one.data(), g.taps_length, (-shift_rates[c]) - half_bw, (-shift_rates[c]) + half_bw, window);
+            for (int k = 0; k < g.taps_length; k++) taps[(size_t)c * fft + k] = one[k];
+        }
+        (void)hipMemcpy(f->d_H, taps.data(), sizeof(cf32) * taps.size(), hipMemcpyHostToDevice);
+        hipfftHandle h; int n[1] = {fft};
+        if (hipfftPlanMany(&h, 1, n, nullptr, 1, fft, nullptr, 1, fft, HIPFFT_C2C, n_channels) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlanMany(taps) failed"); delete f; return nullptr; }
+        hipfftSetStream(h, ctx->stream);
+        hipfftExecC2C(h, (hipfftComplex *)f->d_H, (hipfftComplex *)f->d_H, HIPFFT_FORWARD);
+        const size_t total = (size_t)n_channels * fft;
+        hipLaunchKernelGGL(k_swap_halves, dim3(cdiv(total / 2, 256)), dim3(256), 0, ctx->stream, f->d_H, fft, total);
+        (void)hipStreamSynchronize(ctx->stream);
+        hipfftDestroy(h);
+    }
+    return f;
+}
+
+void csdr_amd_fastddc_inv_destroy(csdr_amd_fastddc_inv *f)
+{
+    if (!f) return;
+    (void)hipStreamSynchronize(f->ctx->stream);
+    for (auto &kv : f->plans) hipfftDestroy(kv.second);
+    (void)hipFree(f->d_H); (void)hipFree(f->d_inv_in); (void)hipFree(f->d_td); (void)hipFree(f->d_geom); (void)hipFree(f->d_state);
+    (void)hipFree(f->d_blk_remain); (void)hipFree(f->d_blk_off); (void)hipFree(f->d_blk_phase); (void)hipFree(f->d_counts);
+    delete f;
+}
+
+int csdr_amd_fastddc_inv_geometry(const csdr_amd_fastddc_inv *f, int channel, csdr_fastddc_t *ddc)
+{
+    if (channel < 0 || channel >= f->n_channels) return fail_msg(-3, "fastddc_inv: channel out of range");
+    *ddc = f->geom[channel]; return 0;
+}
+
+int csdr_amd_fastddc_inv_max_output(const csdr_amd_fastddc_inv *f, int n_blocks)
+{
+    const csdr_fastddc_t &g = f->geom[0];
+    return n_blocks * (g.post_input_size / g.post_decimation + 1);
+}
+
+int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *spectra, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > f->max_blocks) return fail_msg(-3, "fastddc_inv: %d blocks exceed max_blocks %d", n_blocks, f->max_blocks);
+    hipStream_t st = f->ctx->stream;
+    const csdr_fastddc_t &g = f->geom[0];
+    const int fft = g.fft_size, inv = g.fft_inv_size, pre = g.pre_decimation;
+    if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_inv: out_pitch too small");
+    const int batch = f->n_channels * n_blocks;
+    if (!f->plans.count(batch)) {
+        hipfftHandle h; int n[1] = {inv};
+        CSDR_FFT(hipfftPlanMany(&h, 1, n, nullptr, 1, inv, nullptr, 1, inv, HIPFFT_C2C, batch));
+        CSDR_FFT(hipfftSetStream(h, st));
+        f->plans[batch] = h;
+    }
+    const int b_chunk = 4;
+    hipLaunchKernelGGL(k_ddc_fold, dim3(cdiv(inv, 256), cdiv(n_blocks, b_chunk), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom,
+                       fft, inv, pre, n_blocks, b_chunk); CSDR_LAUNCH_CHECK();
+    CSDR_FFT(hipfftExecC2C(f->plans[batch], (hipfftComplex *)f->d_inv_in, (hipfftComplex *)f->d_td, HIPFFT_BACKWARD));
+    hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(f->n_channels, 64)), dim3(64), 0, st, f->d_state, f->d_geom, f->n_channels, n_blocks, g.post_input_size, g.post_decimation,
+                       f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ddc_post, dim3(cdiv((size_t)batch, 64)), dim3(64), 0, st, f->d_td, out, out_pitch, f->d_geom, f->n_channels, n_blocks, inv, g.scrap,
+                       g.post_input_size, g.post_decimation, f->d_blk_remain, f->d_blk_phase, f->d_blk_off); CSDR_LAUNCH_CHECK();
+    if (out_counts) {
+        CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
+        CSDR_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+} // extern "C"
+
+extern "C" int csdr_amd_fastddc_inv_block(csdr_amd_ctx *c, const csdr_complexf *d_spectrum, const csdr_complexf *d_taps_fft, const csdr_fastddc_t *ddc,
+                                          void *status_io, csdr_complexf *d_inv_in, csdr_complexf *d_td, csdr_complexf *d_out)
+{
+    hipStream_t st = c->stream;
+    const int fft = ddc->fft_size, inv = ddc->fft_inv_size;
+    ChanGeom g; g.offsetbin = ddc->offsetbin; g.sindelta = ddc->dsadata.sindelta; g.cosdelta = ddc->dsadata.cosdelta; g.rate2 = ddc->dsadata.rate;
+    char *scratch = (char *)c->get_scratch(3, 256);
+    if (!scratch) return -2;
+    ChanGeom *d_g = (ChanGeom *)scratch; DdcChanState *d_s = (DdcChanState *)(scratch + 64);
+    int *d_rem = (int *)(scratch + 96), *d_off = (int *)(scratch + 112), *d_cnt = (int *)(scratch + 128); float *d_ph = (float *)(scratch + 144);
+    struct { int remain; float phase; int produced; } hs;
+    memcpy(&hs, status_io, sizeof(hs));
+    DdcChanState s0; s0.remain = hs.remain; s0.phase = hs.phase;
+    CSDR_HIP(hipMemcpyAsync(d_g, &g, sizeof(g), hipMemcpyHostToDevice, st));
+    CSDR_HIP(hipMemcpyAsync(d_s, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_ddc_fold, dim3(cdiv(inv, 256), 1, 1), dim3(256), 0, st, d_spectrum, d_taps_fft, d_inv_in, d_g, fft, inv, ddc->pre_decimation, 1, 1); CSDR_LAUNCH_CHECK();
+    int rc = csdr_amd_fft_c2c(c, d_inv_in, d_td, inv, 0); if (rc) return rc;
+    hipLaunchKernelGGL(k_ddc_chain, dim3(1), dim3(64), 0, st, d_s, d_g, 1, 1, ddc->post_input_size, ddc->post_decimation, d_rem, d_ph, d_off, d_cnt); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ddc_post, dim3(1), dim3(64), 0, st, d_td, d_out, (size_t)0, d_g, 1, 1, inv, ddc->scrap, ddc->post_input_size, ddc->post_decimation, d_rem, d_ph, d_off); CSDR_LAUNCH_CHECK();
+    DdcChanState s1; int cnt = 0;
+    CSDR_HIP(hipMemcpyAsync(&s1, d_s, sizeof(s1), hipMemcpyDeviceToHost, st));
+    CSDR_HIP(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+    CSDR_HIP(hipStreamSynchronize(st));
+    hs.remain = s1.remain; hs.phase = s1.phase; hs.produced = cnt;
+    memcpy(status_io, &hs, sizeof(hs));
+    return 0;
+}

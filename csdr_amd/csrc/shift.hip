@@ -1,0 +1,304 @@
+// shift.hip -- frequency shifters (libcsdr.c:186-465, libcsdr_gpl.c:27-160).
+//
+// Design: every shifter variant of the reference is "complex multiply by a rotator sequence" where the
+// sequence is produced by that variant's own float32 phase bookkeeping (per-sample accumulation for
+// shift_math/table, per-1024-chunk re-seeding for shift_addition/addfast/unroll).  That bookkeeping is
+// part of the contract (the reference drifts from the ideal mixer by 3e-3 RMS within 16 k samples), so it
+// is replayed EXACTLY -- same operations, same order, no FMA contraction (file built with
+// -ffp-contract=off) -- by small generator kernels that write a rotator table rot[0..n).  The table is
+// data independent: N streams that share (rate, phase) share one table, and the HBM-bound part is a
+// single vectorised mixing kernel (16 B in + 16 B out per complex sample pair, table from L2).
+#include "common.hpp"
+#include <math.h>
+using namespace csdr_amd;
+
+namespace {
+
+__device__ __forceinline__ float wrap_pm_pi(float p)
+{
+    const float pi = PI_F;
+    while (p > pi) p -= 2 * pi;
+    while (p < -pi) p += 2 * pi;
+    return p;
+}
+__device__ __forceinline__ float wrap_0_2pi(float p)
+{
+    const float pi = PI_F;
+    while (p > 2 * pi) p -= 2 * pi;
+    while (p < 0) p += 2 * pi;
+    return p;
+}
+// (float)cos((double)x): the reference calls libm's double cos on a float phase and stores a float
+__device__ __forceinline__ float cos_like_libm(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float sin_like_libm(float x) { return (float)sin((double)x); }
+
+// ---- chunk start phases for the chunked variants (one lane; n/chunk sequential float adds)
+// libcsdr_gpl.c:48-51 / libcsdr.c:302-304, 429-431 with the CLI's chunking csdr.c:911-918, 785, 836.
+__global__ void k_chunk_phases(float *__restrict__ phases, float *__restrict__ phase_io, float inc_per_sample, size_t n, int chunk)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    float p = *phase_io;
+    size_t m = 0;
+    for (size_t pos = 0; pos < n; pos += chunk, m++) {
+        phases[m] = p;
+        const int len = (n - pos > (size_t)chunk) ? chunk : (int)(n - pos);
+        p = wrap_pm_pi(p + inc_per_sample * (float)len);
+    }
+    *phase_io = p;
+}
+
+// ---- shift_addition_cc: one lane replays one chunk's phasor recurrence (libcsdr_gpl.c:33-47)
+__global__ __launch_bounds__(64) void k_fill_addition(cf32 *__restrict__ rot, const float *__restrict__ phases, float sindelta, float cosdelta, size_t n, int chunk)
+{
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = m * (size_t)chunk;
+    if (base >= n) return;
+    const int len = (n - base > (size_t)chunk) ? chunk : (int)(n - base);
+    float c = cos_like_libm(phases[m]), s = sin_like_libm(phases[m]);
+    for (int k = 0; k < len; k++) {
+        rot[base + k] = cf32{c, s};
+        const float c1 = c * cosdelta - s * sindelta;
+        const float s1 = s * cosdelta + c * sindelta;
+        c = c1; s = s1;
+    }
+}
+
+// ---- shift_addfast_cc (libcsdr.c:406-434): four phasors per step, restart from the fourth
+struct Quad { float dsin[4], dcos[4]; };
+__global__ __launch_bounds__(64) void k_fill_addfast(cf32 *__restrict__ rot, const float *__restrict__ phases, Quad q, size_t n, int chunk)
+{
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t base = m * (size_t)chunk;
+    if (base >= n) return;
+    const int len = (n - base > (size_t)chunk) ? chunk : (int)(n - base);
+    float c0 = cos_like_libm(phases[m]), s0 = sin_like_libm(phases[m]);
+    for (int g = 0; g < len / 4; g++) {
+        float c[4], s[4];
+        for (int j = 0; j < 4; j++) { c[j] = c0 * q.dcos[j] - s0 * q.dsin[j]; s[j] = s0 * q.dcos[j] + c0 * q.dsin[j]; }
+        for (int j = 0; j < 4; j++) rot[base + 4 * g + j] = cf32{c[j], s[j]};
+        c0 = c[3]; s0 = s[3];
+    }
+    for (int k = (len / 4) * 4; k < len; k++) rot[base + k] = cf32{1.0f, 0.0f};   // the reference leaves a non-multiple-of-4 tail unwritten
+}
+
+// ---- shift_unroll_cc: table of (k+1) increments accumulated in float (libcsdr.c:268-284), then per sample
+__global__ void k_unroll_table_phases(float *__restrict__ acc_phase, float inc, int size)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    float a = 0;
+    for (int k = 0; k < size; k++) { a = wrap_pm_pi(a + inc); acc_phase[k] = a; }
+}
+__global__ __launch_bounds__(256) void k_sincos_table(const float *__restrict__ ph, float *__restrict__ dsin, float *__restrict__ dcos, int size)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < size) { dsin[k] = sin_like_libm(ph[k]); dcos[k] = cos_like_libm(ph[k]); }
+}
+__global__ __launch_bounds__(256) void k_fill_unroll(cf32 *__restrict__ rot, const float *__restrict__ phases, const float *__restrict__ dsin, const float *__restrict__ dcos, size_t n, int chunk)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const size_t m = k / (size_t)chunk; const int off = (int)(k - m * (size_t)chunk);
+    const float c0 = cos_like_libm(phases[m]), s0 = sin_like_libm(phases[m]);
+    rot[k] = cf32{c0 * dcos[off] - s0 * dsin[off], s0 * dcos[off] + c0 * dsin[off]};
+}
+
+// ---- shift_math_cc / shift_table_cc: float phase advanced and wrapped PER SAMPLE (libcsdr.c:202-204, 260-262).
+// Inherently sequential per (rate, phase) group: one lane walks the block and stores every phase.
+__global__ void k_sample_phases(float *__restrict__ ph, float *__restrict__ phase_io, float inc, size_t n)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    float p = *phase_io;
+    for (size_t k = 0; k < n; k++) { ph[k] = p; p = wrap_0_2pi(p + inc); }
+    *phase_io = p;
+}
+__global__ __launch_bounds__(256) void k_fill_math(cf32 *__restrict__ rot, const float *__restrict__ ph, size_t n)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) rot[k] = cf32{cos_like_libm(ph[k]), sin_like_libm(ph[k])};
+}
+__global__ __launch_bounds__(256) void k_quarter_table(float *__restrict__ table, int size)
+{   // libcsdr.c:211-222
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < size) table[k] = sin_like_libm(((float)k / (float)size) * (PI_F / 2));
+}
+__global__ __launch_bounds__(256) void k_fill_table(cf32 *__restrict__ rot, const float *__restrict__ ph, const float *__restrict__ table, int size, size_t n)
+{   // libcsdr.c:236-253: quadrant folding, truncated index
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float q90 = PI_F / 2, p = ph[k];
+    const int quadrant = (int)(p / q90);
+    const float within = p - (float)quadrant * q90;
+    int si = (int)((within / q90) * (float)size), ci = size - 1 - si;
+    if (quadrant & 1) { const int t = si; si = ci; ci = t; }
+    si = si < 0 ? 0 : (si >= size ? size - 1 : si);     // the reference would index out of bounds here
+    ci = ci < 0 ? 0 : (ci >= size ? size - 1 : ci);
+    const float s = (quadrant > 1 ? -1.0f : 1.0f) * table[si];
+    const float c = ((quadrant && quadrant < 3) ? -1.0f : 1.0f) * table[ci];
+    rot[k] = cf32{c, s};
+}
+
+// ---- the mixing kernel: out = in * rot, two complex samples (one float4) per lane per step
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_mix_cc(const cf32 *__restrict__ in, cf32 *__restrict__ out, const cf32 *__restrict__ rot,
+                                                size_t n, size_t in_pitch, size_t out_pitch)
+{
+    const cf32 *src = in + (size_t)blockIdx.y * in_pitch;
+    cf32 *dst = out + (size_t)blockIdx.y * out_pitch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    if (VEC) {
+        const size_t npair = n / 2;
+        for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < npair; v += stride) {
+            const float4 x = reinterpret_cast<const float4 *>(src)[v];
+            const float4 r = reinterpret_cast<const float4 *>(rot)[v];
+            float4 y;
+            y.x = r.x * x.x - r.y * x.y; y.y = r.y * x.x + r.x * x.y;
+            y.z = r.z * x.z - r.w * x.w; y.w = r.w * x.z + r.z * x.w;
+            reinterpret_cast<float4 *>(dst)[v] = y;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const cf32 x = src[n - 1], r = rot[n - 1];
+            dst[n - 1] = cf32{r.i * x.i - r.q * x.q, r.q * x.i + r.i * x.q};
+        }
+    } else {
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+            const cf32 x = src[k], r = rot[k];
+            dst[k] = cf32{r.i * x.i - r.q * x.q, r.q * x.i + r.i * x.q};
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mix_fc(const float *__restrict__ in, cf32 *__restrict__ out, const cf32 *__restrict__ rot,
+                                                size_t n, size_t in_pitch, size_t out_pitch)
+{   // libcsdr_gpl.c:65-66
+    const float *src = in + (size_t)blockIdx.y * in_pitch;
+    cf32 *dst = out + (size_t)blockIdx.y * out_pitch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const float x = src[k]; const cf32 r = rot[k];
+        dst[k] = cf32{r.i * x, r.q * x};
+    }
+}
+
+// ---- decimating_shift_addition_cc (libcsdr_gpl.c:131-160): one lane per stream-block
+struct DsaStatus { int remain; float phase; int produced; };
+__global__ __launch_bounds__(64) void k_dsa(const cf32 *__restrict__ in, cf32 *__restrict__ out, int n_streams, int input_size,
+                                            size_t in_pitch, size_t out_pitch, const float *__restrict__ dsa, int decimation, DsaStatus *__restrict__ st)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_streams) return;
+    const cf32 *src = in + (size_t)sidx * in_pitch; cf32 *dst = out + (size_t)sidx * out_pitch;
+    const float sd = dsa[3 * sidx], cd = dsa[3 * sidx + 1], r = dsa[3 * sidx + 2];   // shift_addition_data_t {sindelta, cosdelta, rate}
+    DsaStatus s = st[sidx];
+    float c = cos_like_libm(s.phase), sn = sin_like_libm(s.phase);
+    int pos, k = 0;
+    for (pos = s.remain; pos < input_size; pos += decimation) {
+        const cf32 x = src[pos];
+        dst[k++] = cf32{c * x.i - sn * x.q, sn * x.i + c * x.q};
+        const float c1 = c * cd - sn * sd, s1 = sn * cd + c * sd;
+        c = c1; sn = s1;
+    }
+    s.remain = pos - input_size;
+    s.phase = wrap_pm_pi(s.phase + r * PI_F * (float)k);
+    s.produced = k;
+    st[sidx] = s;
+}
+
+} // namespace
+
+extern "C" {
+
+int csdr_amd_rotator_generate(csdr_amd_ctx *c, int variant, float rate, float *phase_io, csdr_complexf *rot, size_t n, int chunk, int aux)
+{
+    if (!n) return 0;
+    hipStream_t st = c->stream;
+    const float rate2 = rate * 2;                      // shift_addition_init / "rate*=2" (libcsdr_gpl.c:83, libcsdr.c:188)
+    const float inc = rate2 * PI_F;                    // float product, as in the reference
+    if (variant == CSDR_SHIFT_ADDITION || variant == CSDR_SHIFT_ADDFAST || variant == CSDR_SHIFT_UNROLL) {
+        if (chunk <= 0) chunk = 1024;
+        const size_t nchunks = (n + chunk - 1) / chunk;
+        float *phases = (float *)c->get_scratch(0, sizeof(float) * (nchunks + 1));
+        if (!phases) return -2;
+        hipLaunchKernelGGL(k_chunk_phases, dim3(1), dim3(1), 0, st, phases, phase_io, inc, n, chunk); CSDR_LAUNCH_CHECK();
+        if (variant == CSDR_SHIFT_ADDITION) {
+            const float sd = (float)sin((double)inc), cd = (float)cos((double)inc);   // libcsdr_gpl.c:85-86 (host libm, like the reference)
+            hipLaunchKernelGGL(k_fill_addition, dim3(cdiv(nchunks, 64)), dim3(64), 0, st, rot, phases, sd, cd, n, chunk); CSDR_LAUNCH_CHECK();
+        } else if (variant == CSDR_SHIFT_ADDFAST) {
+            Quad q;                                                                     // libcsdr.c:307-317
+            for (int j = 0; j < 4; j++) { q.dsin[j] = (float)sin((double)(inc * (j + 1))); q.dcos[j] = (float)cos((double)(inc * (j + 1))); }
+            hipLaunchKernelGGL(k_fill_addfast, dim3(cdiv(nchunks, 64)), dim3(64), 0, st, rot, phases, q, n, chunk); CSDR_LAUNCH_CHECK();
+        } else {
+            const int size = aux > 0 ? aux : chunk;
+            if (size < chunk) return fail_msg(-3, "shift_unroll: table size %d smaller than chunk %d", size, chunk);
+            float *tab = (float *)c->get_scratch(1, sizeof(float) * 3 * (size_t)size);
+            if (!tab) return -2;
+            hipLaunchKernelGGL(k_unroll_table_phases, dim3(1), dim3(1), 0, st, tab, inc, size); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_sincos_table, dim3(cdiv(size, 256)), dim3(256), 0, st, tab, tab + size, tab + 2 * size, size); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_fill_unroll, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, phases, tab + size, tab + 2 * size, n, chunk); CSDR_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    if (variant == CSDR_SHIFT_MATH || variant == CSDR_SHIFT_TABLE) {
+        float *ph = (float *)c->get_scratch(0, sizeof(float) * n);
+        if (!ph) return -2;
+        hipLaunchKernelGGL(k_sample_phases, dim3(1), dim3(1), 0, st, ph, phase_io, inc, n); CSDR_LAUNCH_CHECK();
+        if (variant == CSDR_SHIFT_MATH) {
+            hipLaunchKernelGGL(k_fill_math, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, n); CSDR_LAUNCH_CHECK();
+        } else {
+            const int size = aux > 0 ? aux : 65536;     // csdr.c:731
+            float *table = (float *)c->get_scratch(1, sizeof(float) * (size_t)size);
+            if (!table) return -2;
+            hipLaunchKernelGGL(k_quarter_table, dim3(cdiv(size, 256)), dim3(256), 0, st, table, size); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_fill_table, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, table, size, n); CSDR_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    return fail_msg(-3, "unknown shifter variant %d", variant);
+}
+
+int csdr_amd_mix_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_complexf *out, const csdr_complexf *rot,
+                    int n_streams, size_t n, size_t in_pitch, size_t out_pitch)
+{
+    if (!n || n_streams <= 0) return 0;
+    const bool vec = !(((uintptr_t)in | (uintptr_t)out | (uintptr_t)rot) & 15) && !(in_pitch & 1) && !(out_pitch & 1);
+    size_t gx = (n / 2 + 255) / 256; if (gx < 1) gx = 1;
+    const size_t cap = (size_t)(4096 / (n_streams < 4096 ? n_streams : 4096)); if (gx > (cap ? cap : 1) * 8) gx = (cap ? cap : 1) * 8;
+    dim3 grid((unsigned)gx, (unsigned)n_streams);
+    if (vec) hipLaunchKernelGGL((k_mix_cc<true>), grid, dim3(256), 0, c->stream, in, out, rot, n, in_pitch, out_pitch);
+    else     hipLaunchKernelGGL((k_mix_cc<false>), grid, dim3(256), 0, c->stream, in, out, rot, n, in_pitch, out_pitch);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int csdr_amd_mix_fc(csdr_amd_ctx *c, const float *in, csdr_complexf *out, const csdr_complexf *rot,
+                    int n_streams, size_t n, size_t in_pitch, size_t out_pitch)
+{
+    if (!n || n_streams <= 0) return 0;
+    size_t gx = (n + 255) / 256; if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(k_mix_fc, dim3((unsigned)gx, (unsigned)n_streams), dim3(256), 0, c->stream, in, out, rot, n, in_pitch, out_pitch);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int csdr_amd_shift_cc(csdr_amd_ctx *c, int variant, float rate, float *phase_io, const csdr_complexf *in, csdr_complexf *out,
+                      int n_streams, size_t n, size_t in_pitch, size_t out_pitch, int chunk, int aux)
+{
+    if (!n) return 0;
+    csdr_complexf *rot = (csdr_complexf *)c->get_scratch(2, sizeof(csdr_complexf) * (n + 2));
+    if (!rot) return -2;
+    int rc = csdr_amd_rotator_generate(c, variant, rate, phase_io, rot, n, chunk, aux);
+    if (rc) return rc;
+    return csdr_amd_mix_cc(c, in, out, rot, n_streams, n, in_pitch, out_pitch);
+}
+
+int csdr_amd_decimating_shift_addition_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_complexf *out, int n_streams, int input_size,
+                                          size_t in_pitch, size_t out_pitch, const void *dsa_data, int decimation, void *status_io)
+{
+    if (n_streams <= 0) return 0;
+    if (decimation <= 0) return fail_msg(-3, "decimation must be positive");
+    hipLaunchKernelGGL(k_dsa, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, input_size, in_pitch, out_pitch,
+                       (const float *)dsa_data, decimation, (DsaStatus *)status_io);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,327 @@
+// wfm.hip -- fused wide-FM receive chain (BASELINE.json config 2; README.md:66, csdr-fm:41):
+//
+//   convert_u8_f | shift_addition_cc r | fir_decimate_cc D | fmdemod_quadri_cf |
+//   fractional_decimator_ff F | deemphasis_wfm_ff | convert_f_s16
+//
+// for N independent u8 IQ streams.  Stream model being implemented (verified against the
+// compiled reference in tests/test_oracle_vs_ref.py::test_wfm_chain):
+//
+//   x'[n]  = u8->float(iq[n]) * rot[n]              rot = shift_addition_cc's float32 phasor, 1024-chunks
+//   y[k]   = sum_t h[t] x'[D k + t]                 no zero history in front
+//   d[m]   = K (I dQ - Q dI)/(I^2+Q^2)  of y[m], y[m-1]
+//   a[j]   = d[F j + 10]                            integer-rate Lagrange decimator == pure gather (exact)
+//   e[j]   = alpha a[j] + (1-alpha) e[j-1]          de-emphasis
+//   s16[j] = trunc(e[j] * 32767)
+//
+// Only y[Fj+9] and y[Fj+10] feed the audio, so 2 of every F FIR outputs are computed (exact, 2.5x fewer MACs
+// at F = 5).  HBM traffic: 2 B in per complex sample + 2/(D F) B out: every input byte is read once.
+//
+// Round-1 structure (two launches per block):
+//   k_wfm_front : (stream, tile of A audio samples) per workgroup.  u8 window -> float -> rotate -> LDS;
+//                 FIR pairs from LDS (two lanes per output, 40 taps each); quadrature demod; writes the
+//                 pre-de-emphasis audio float (4 B per D*F input samples) to a scratch row.
+//   k_wfm_back  : de-emphasis + s16.  The one-pole IIR forgets its state as (1-alpha)^k (0.706^48 = 5.6e-8),
+//                 so every 64-sample segment is started 48 samples early from zero state and is then
+//                 independent of its predecessor to float precision; the first segment of a call uses the
+//                 exact carried state.
+#include "common.hpp"
+#include <math.h>
+#include <vector>
+#include <string>
+using namespace csdr_amd;
+
+namespace {
+
+constexpr int HIST = 256;          // complex samples of input history kept per stream (>= D*(F-1+..)+taps needs 88 for 10/79/5)
+constexpr int TILE_A = 64;         // audio samples per workgroup
+constexpr int WARM = 48;           // de-emphasis warm-up samples
+
+struct WfmParams {
+    int D, L, F;                   // decimation, taps, audio decimation
+    int T;                         // complex samples in this block
+    long long B;                   // global index of the block's first sample
+    long long j_first;             // first audio index produced by this call
+    int n_audio;                   // audio samples produced by this call
+};
+
+__device__ __forceinline__ float u8_to_f(uint32_t v) { return fmaf((float)v, 0x1.010102p-7f, -1.0f); }   // v/127.5 - 1 (<= 1 ulp)
+
+__global__ __launch_bounds__(256) void k_wfm_front(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ hist,
+                                                   const cf32 *__restrict__ rot, const float *__restrict__ taps,
+                                                   float *__restrict__ demod, size_t demod_pitch, WfmParams p)
+{
+    extern __shared__ float4 lds_raw[];
+    float2 *win = reinterpret_cast<float2 *>(lds_raw);
+    const int s = blockIdx.y;
+    const int a0 = blockIdx.x * TILE_A;
+    const int na = min(TILE_A, p.n_audio - a0);
+    if (na <= 0) return;
+    const long long j0 = p.j_first + a0;
+    const int DF = p.D * p.F;
+    // window of input needed: FIR outputs F*j+9 .. F*(j0+na-1)+10
+    const long long g_first = (long long)p.D * (p.F * j0 + 9);
+    const long long g_last = (long long)p.D * (p.F * (j0 + na - 1) + 10) + p.L - 1;
+    const long long r_first = (g_first - p.B) & ~7LL;                 // block-relative, aligned down to 8 samples (B is a multiple of 8)
+    const int wl = (int)(g_last - p.B - r_first + 1);
+    const int nvec = (wl + 7) / 8;
+    const uint8_t *row = in + (size_t)s * in_pitch;
+    const uint8_t *hrow = hist + (size_t)s * (2 * HIST);
+    float2 *ybuf = win + nvec * 8;                                    // 2*TILE_A FIR outputs
+    for (int v = threadIdx.x; v < nvec; v += 256) {
+        const long long r0 = r_first + 8LL * v;
+        uint4 w = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+        if (r0 < 0) w = *reinterpret_cast<const uint4 *>(hrow + 2 * (r0 + HIST));
+        else if (r0 + 8 <= p.T) w = *reinterpret_cast<const uint4 *>(row + 2 * r0);
+        else { // ragged end of the final block: byte-wise
+            uint32_t b[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+            for (int k = 0; k < 16; k++) if (r0 + k / 2 < p.T) { const uint32_t by = row[2 * r0 + k]; b[k / 4] = (b[k / 4] & ~(0xffu << (8 * (k & 3)))) | (by << (8 * (k & 3))); }
+            w = make_uint4(b[0], b[1], b[2], b[3]);
+        }
+        const cf32 *rr = rot + (r0 + HIST);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float i0 = u8_to_f(ww[k] & 0xff), q0 = u8_to_f((ww[k] >> 8) & 0xff);
+            const float i1 = u8_to_f((ww[k] >> 16) & 0xff), q1 = u8_to_f(ww[k] >> 24);
+            const float4 r2 = *reinterpret_cast<const float4 *>(rr + 2 * k);
+            float4 o;
+            o.x = r2.x * i0 - r2.y * q0; o.y = r2.y * i0 + r2.x * q0;
+            o.z = r2.z * i1 - r2.w * q1; o.w = r2.w * i1 + r2.z * q1;
+            *reinterpret_cast<float4 *>(win + 8 * v + 2 * k) = o;
+        }
+    }
+    __syncthreads();
+    // FIR: lane pair (2p, 2p+1) computes output p = 2*a + which  (which = 0: y[Fj+9], 1: y[Fj+10])
+    {
+        const int pidx = threadIdx.x >> 1, half = threadIdx.x & 1;
+        const int a = pidx >> 1, which = pidx & 1;
+        float ai = 0.f, aq = 0.f;
+        if (a < na) {
+            const long long g = (long long)p.D * (p.F * (j0 + a) + 9 + which);
+            const float2 *x = win + (int)(g - p.B - r_first);
+            const int split = (p.L + 1) / 2;
+            const int t0 = half ? split : 0, t1 = half ? p.L : split;
+            for (int t = t0; t < t1; t++) { const float h = taps[t]; const float2 v = x[t]; ai = fmaf(v.x, h, ai); aq = fmaf(v.y, h, aq); }
+        }
+        ai += __shfl_xor(ai, 1, 64); aq += __shfl_xor(aq, 1, 64);
+        if (half == 0) ybuf[pidx] = make_float2(ai, aq);
+    }
+    __syncthreads();
+    if (threadIdx.x < na) {
+        const float2 pv = ybuf[2 * threadIdx.x], cv = ybuf[2 * threadIdx.x + 1];
+        const float dq = cv.y - pv.y, di = cv.x - pv.x;
+        const float num = cv.x * dq - cv.y * di, den = cv.x * cv.x + cv.y * cv.y;
+        const float K = 0.340447550238101026565118445432744920253753662109375f;
+        demod[(size_t)s * demod_pitch + a0 + threadIdx.x] = (den != 0.f) ? (K * num) / den : 0.f;
+        (void)DF;
+    }
+}
+
+// de-emphasis + convert_f_s16; block = 64 lanes = 64 segments of 64 audio samples of one stream
+__global__ __launch_bounds__(64) void k_wfm_back(const float *__restrict__ demod, size_t demod_pitch, int n_audio, float alpha,
+                                                 const float *__restrict__ last_in, float *__restrict__ last_out,
+                                                 int16_t *__restrict__ s16, float *__restrict__ audio_f, size_t out_pitch)
+{
+    __shared__ float seg[64 * 65 + WARM + 16];
+    __shared__ float oseg[64 * 65];
+    const int s = blockIdx.y;
+    const int t0 = blockIdx.x * 4096;
+    const int cnt = min(4096, n_audio - t0);
+    if (cnt <= 0) return;
+    const float *row = demod + (size_t)s * demod_pitch;
+    const int lead = (t0 >= WARM) ? WARM : t0;                      // samples before t0 available for warm-up
+    // LDS position of sample (t0 - lead + q): q + q/64 (one pad float per 64: lane stride 65 -> conflict free)
+    for (int q = threadIdx.x; q < cnt + lead; q += 64) seg[q + (q >> 6)] = row[t0 - lead + q];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int my0 = lane * 64;                                       // first sample of my segment, relative to t0
+    const float one_minus = 1 - alpha;
+    if (my0 < cnt) {
+        float y;
+        int q;                                                       // index into the staged run
+        if (t0 + my0 == 0) { y = last_in[s]; if (y != y) y = 0.f; q = lead + my0; }
+        else {
+            y = 0.f;
+            const int back = (my0 + lead >= WARM) ? WARM : (my0 + lead);
+            q = lead + my0 - back;
+            for (int k = 0; k < back; k++, q++) y = alpha * seg[q + (q >> 6)] + one_minus * y;
+        }
+        const int mine = min(64, cnt - my0);
+        for (int k = 0; k < mine; k++, q++) {
+            y = alpha * seg[q + (q >> 6)] + one_minus * y;
+            oseg[(my0 + k) + ((my0 + k) >> 6)] = y;
+        }
+        if (t0 + my0 + mine == n_audio) last_out[s] = y;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < cnt; q += 64) {
+        const float e = oseg[q + (q >> 6)];
+        const float scaled = e * 32767.0f;                           // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
+        const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
+        s16[(size_t)s * out_pitch + t0 + q] = (int16_t)(iv & 0xffff);
+        if (audio_f) audio_f[(size_t)s * out_pitch + t0 + q] = e;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wfm_save_hist(const uint8_t *__restrict__ in, size_t in_pitch, int T, uint8_t *__restrict__ hist)
+{   // keep the last HIST complex samples of every stream for the next block's FIR windows
+    const int s = blockIdx.x;
+    const uint8_t *src = in + (size_t)s * in_pitch + 2 * (size_t)(T - HIST);
+    uint8_t *dst = hist + (size_t)s * (2 * HIST);
+    for (int k = threadIdx.x; k < 2 * HIST / 4; k += 256) reinterpret_cast<uint32_t *>(dst)[k] = reinterpret_cast<const uint32_t *>(src)[k];
+}
+
+} // namespace
+
+struct csdr_amd_wfm {
+    csdr_amd_ctx *ctx;
+    int n_streams, D, L, F, audio_rate;
+    float shift_rate, tau, alpha;
+    size_t max_block;
+    float *d_taps, *d_phase, *d_demod, *d_last[2];
+    cf32 *d_rot;
+    uint8_t *d_hist;
+    size_t demod_pitch;
+    long long B, next_j;
+    int last_T, flip;
+    bool ended;
+    std::string kernel_name;
+    // optional HIP-event timing of the dominant kernel (bench.py roofline leg)
+    bool profiling;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used;
+    double prof_ms; long prof_launches;
+};
+
+extern "C" {
+
+csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps,
+                                  int taps_length, int frac_rate, float tau, int audio_rate, size_t max_block_samples)
+{
+    if (n_streams <= 0 || decimation <= 0 || taps_length <= 0 || frac_rate <= 1) { fail_msg(-3, "wfm: bad parameters"); return nullptr; }
+    if (decimation * 1 + taps_length + 8 > HIST) { fail_msg(-3, "wfm: D + taps (%d + %d) exceed the %d-sample history", decimation, taps_length, HIST); return nullptr; }
+    if (max_block_samples < 1024) max_block_samples = 1024;
+    csdr_amd_wfm *w = new csdr_amd_wfm();
+    w->ctx = ctx; w->n_streams = n_streams; w->D = decimation; w->L = taps_length; w->F = frac_rate; w->audio_rate = audio_rate;
+    w->shift_rate = shift_rate; w->tau = tau; w->max_block = max_block_samples;
+    const float dt = (float)(1.0 / audio_rate); w->alpha = dt / (tau + dt);          // libcsdr.c:1090-1091
+    const size_t max_audio = max_block_samples / ((size_t)decimation * frac_rate) + 8;
+    w->demod_pitch = (max_audio + 63) & ~(size_t)63;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc((void **)&w->d_taps, sizeof(float) * taps_length);
+    alloc((void **)&w->d_phase, sizeof(float) * 4);
+    alloc((void **)&w->d_demod, sizeof(float) * w->demod_pitch * n_streams);
+    alloc((void **)&w->d_last[0], sizeof(float) * n_streams);
+    alloc((void **)&w->d_last[1], sizeof(float) * n_streams);
+    alloc((void **)&w->d_rot, sizeof(cf32) * (HIST + max_block_samples + 64));
+    alloc((void **)&w->d_hist, (size_t)2 * HIST * n_streams);
+    if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
+    (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
+    w->kernel_name = "k_wfm_front";
+    w->profiling = false; w->ev_used = 0; w->prof_ms = 0; w->prof_launches = 0;
+    if (csdr_amd_wfm_reset(w)) { delete w; return nullptr; }
+    return w;
+}
+
+void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
+{
+    if (!w) return;
+    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)hipFree(w->d_taps); (void)hipFree(w->d_phase); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]);
+    (void)hipFree(w->d_rot); (void)hipFree(w->d_hist);
+    for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete w;
+}
+
+int csdr_amd_wfm_reset(csdr_amd_wfm *w)
+{
+    hipStream_t st = w->ctx->stream;
+    CSDR_HIP(hipMemsetAsync(w->d_phase, 0, sizeof(float) * 4, st));
+    CSDR_HIP(hipMemsetAsync(w->d_last[0], 0, sizeof(float) * w->n_streams, st));
+    CSDR_HIP(hipMemsetAsync(w->d_last[1], 0, sizeof(float) * w->n_streams, st));
+    CSDR_HIP(hipMemsetAsync(w->d_rot, 0, sizeof(cf32) * (HIST + w->max_block + 64), st));
+    CSDR_HIP(hipMemsetAsync(w->d_hist, 0x80, (size_t)2 * HIST * w->n_streams, st));
+    w->B = 0; w->next_j = 0; w->last_T = 0; w->flip = 0; w->ended = false;
+    return 0;
+}
+
+const char *csdr_amd_wfm_kernel_name(const csdr_amd_wfm *w) { return w->kernel_name.c_str(); }
+
+int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on)
+{
+    w->profiling = on != 0; w->ev_used = 0; w->prof_ms = 0; w->prof_launches = 0;
+    return 0;
+}
+
+int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches)
+{   // resolves the recorded event pairs (synchronises the stream)
+    CSDR_HIP(hipStreamSynchronize(w->ctx->stream));
+    for (size_t k = 0; k < w->ev_used; k++) {
+        float ms = 0; CSDR_HIP(hipEventElapsedTime(&ms, w->ev_pool[k].first, w->ev_pool[k].second));
+        w->prof_ms += ms; w->prof_launches++;
+    }
+    w->ev_used = 0;
+    if (total_ms) *total_ms = w->prof_ms;
+    if (launches) *launches = w->prof_launches;
+    return 0;
+}
+
+long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, size_t block_samples,
+                          int16_t *audio_s16, float *audio_f, size_t out_pitch)
+{
+    csdr_amd_ctx *c = w->ctx; hipStream_t st = c->stream;
+    if (w->ended) return fail_msg(-3, "wfm: stream already ended by a block that was not a multiple of 1024 samples; reset first");
+    if (block_samples == 0) return 0;
+    if (block_samples > w->max_block) return fail_msg(-3, "wfm: block of %zu samples exceeds max_block_samples %zu", block_samples, w->max_block);
+    if (((uintptr_t)in & 15) || (in_pitch & 15)) return fail_msg(-3, "wfm: input pointer and pitch must be 16-byte aligned");
+    const int T = (int)block_samples;
+    // 1. rotator table for this block behind the previous block's tail (history positions keep their own phasors)
+    if (w->last_T) CSDR_HIP(hipMemcpyAsync(w->d_rot, w->d_rot + w->last_T, sizeof(cf32) * HIST, hipMemcpyDeviceToDevice, st));
+    int rc = csdr_amd_rotator_generate(c, CSDR_SHIFT_ADDITION, w->shift_rate, w->d_phase, w->d_rot + HIST, (size_t)T, 1024, 0);
+    if (rc) return rc;
+    // 2. audio samples that become computable with this block: F*j+10 is the newest FIR output, needs input up to D*(F*j+10)+L-1
+    const long long avail_last = w->B + T - 1;
+    long long j_hi = -1;
+    if (avail_last - (w->L - 1) >= 0) {
+        const long long k_max = (avail_last - (w->L - 1)) / w->D;          // newest complete FIR output index
+        if (k_max >= 10) j_hi = (k_max - 10) / w->F;
+    }
+    const long long n_audio_ll = j_hi - w->next_j + 1;
+    const int n_audio = n_audio_ll > 0 ? (int)n_audio_ll : 0;
+    if ((size_t)n_audio > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
+    if (n_audio > 0) {
+        if ((size_t)n_audio > out_pitch) return fail_msg(-3, "wfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, n_audio);
+        WfmParams p; p.D = w->D; p.L = w->L; p.F = w->F; p.T = T; p.B = w->B; p.j_first = w->next_j; p.n_audio = n_audio;
+        const int span = w->D * (w->F * (TILE_A - 1) + 1) + w->L + 16;          // samples per tile window (+alignment slack)
+        const size_t lds = (size_t)((span + 7) / 8 * 8 + 2 * TILE_A) * sizeof(float2) + 64;
+        if (lds > 64 * 1024) CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (w->profiling) {
+            if (w->ev_used == w->ev_pool.size()) {
+                hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b));
+                w->ev_pool.emplace_back(a, b);
+            }
+            e0 = w->ev_pool[w->ev_used].first; e1 = w->ev_pool[w->ev_used].second; w->ev_used++;
+            CSDR_HIP(hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL(k_wfm_front, dim3(cdiv(n_audio, TILE_A), w->n_streams), dim3(256), lds, st,
+                           in, in_pitch, w->d_hist, w->d_rot, w->d_taps, w->d_demod, w->demod_pitch, p);
+        CSDR_LAUNCH_CHECK();
+        if (w->profiling) CSDR_HIP(hipEventRecord(e1, st));
+        hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, 4096), w->n_streams), dim3(64), 0, st,
+                           w->d_demod, w->demod_pitch, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
+        CSDR_LAUNCH_CHECK();
+        w->flip ^= 1;
+    }
+    // 3. history for the next block
+    if (T >= HIST) {
+        hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, st, in, in_pitch, T, w->d_hist);
+        CSDR_LAUNCH_CHECK();
+    }
+    if (T % 1024) w->ended = true;
+    w->B += T; w->next_j += n_audio; w->last_T = T;
+    return n_audio;
+}
+
+} // extern "C"

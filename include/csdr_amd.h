@@ -1,0 +1,242 @@
+/* include/csdr_amd.h -- C ABI of the MI355X-native libcsdr hot path (libcsdr_amd.so).
+ *
+ * Two layers, both plain C (no torch / C++ types in any signature):
+ *
+ *  1. DEVICE BATCH API  (csdr_amd_*):  device pointers, N independent sample streams per call,
+ *     stream-major layout  buf[stream * pitch + sample]  (pitch in ELEMENTS of the buffer's type),
+ *     asynchronous on the context's HIP stream.  This is what bench.py and the parity tests drive.
+ *     Cross-block state (phases, last samples, filter history) is explicit and caller-owned, exactly
+ *     like the reference's by-value state, but held in device arrays of
+ *     n_streams entries so that a call never synchronises with the host.
+ *
+ *  2. DROP-IN HOST API  (include/libcsdr_amd_compat.h): the reference's own symbols
+ *     (libcsdr.h:85-229, libcsdr_gpl.h:26-46, fastddc.h:26-29, fft_fftw.h:24-27) with identical
+ *     signatures and struct layouts, operating on host pointers (H2D -> kernels -> D2H).
+ *
+ * Every entry point cites the reference interface it replaces.  Return value: 0 on success,
+ * negative on error (csdr_amd_last_error() gives the text) unless stated otherwise.
+ * The library FAILS LOUDLY (error return, never a CPU fallback) when no gfx950 device is usable.
+ */
+#ifndef CSDR_AMD_H
+#define CSDR_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* libcsdr.h:46 -- interleaved I/Q pair, 8 bytes */
+typedef struct csdr_complexf_s { float i, q; } csdr_complexf;
+
+/* libcsdr.h:70-73 */
+typedef enum { CSDR_WINDOW_BOXCAR = 0, CSDR_WINDOW_BLACKMAN = 1, CSDR_WINDOW_HAMMING = 2 } csdr_window_t;
+
+typedef struct csdr_amd_ctx csdr_amd_ctx;
+
+/* ------------------------------------------------------------------ context / memory */
+/* hip_stream: a hipStream_t owned by the caller (e.g. torch.cuda.current_stream().cuda_stream) or
+ * NULL to let the context create its own non-blocking stream. */
+csdr_amd_ctx *csdr_amd_ctx_create(int device, void *hip_stream);
+void          csdr_amd_ctx_destroy(csdr_amd_ctx *ctx);
+int           csdr_amd_ctx_sync(csdr_amd_ctx *ctx);
+void         *csdr_amd_ctx_stream(csdr_amd_ctx *ctx);
+const char   *csdr_amd_last_error(void);
+int           csdr_amd_device_count(void);
+/* "gfx950:sramecc+:xnack-" style architecture name of the context's device */
+const char   *csdr_amd_device_arch(csdr_amd_ctx *ctx);
+
+void *csdr_amd_malloc(csdr_amd_ctx *ctx, size_t bytes);
+void  csdr_amd_free(csdr_amd_ctx *ctx, void *dptr);
+int   csdr_amd_h2d(csdr_amd_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* sync */
+int   csdr_amd_d2h(csdr_amd_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* sync */
+int   csdr_amd_memset(csdr_amd_ctx *ctx, void *dst_dev, int value, size_t bytes);           /* async */
+
+/* HIP-event timing on the context's stream (bench.py: the kernel stream is not torch's stream) */
+int   csdr_amd_timer_start(csdr_amd_ctx *ctx);
+int   csdr_amd_timer_stop_ms(csdr_amd_ctx *ctx, float *ms);   /* records, synchronises, returns elapsed */
+
+/* ------------------------------------------------------------------ host-side design helpers */
+int  csdr_amd_firdes_filter_len(float transition_bw);                                        /* libcsdr.c:169-174 */
+void csdr_amd_firdes_lowpass_f(float *taps, int length, float cutoff_rate, int window);      /* libcsdr.c:117-142 */
+void csdr_amd_firdes_bandpass_c(csdr_complexf *taps, int length, float lowcut, float highcut, int window); /* :144-167 */
+int  csdr_amd_next_pow2(int x);                                                              /* libcsdr.c:1235-1243 */
+int  csdr_amd_log2n(int x);                                                                  /* libcsdr.c:1220-1233 */
+/* fixed NFM de-emphasis FIR tables (predefined.h:56-68): returns tap count or 0 for an unsupported rate */
+int  csdr_amd_nfm_deemph_taps(int sample_rate, const float **taps);
+
+/* ------------------------------------------------------------------ sample-format converters (bit exact)
+ * libcsdr.c:2363-2437 / libcsdr.h:220-229.  n = number of VALUES (not bytes). */
+int csdr_amd_convert_u8_f (csdr_amd_ctx *ctx, const uint8_t *in, float *out, size_t n);
+int csdr_amd_convert_s8_f (csdr_amd_ctx *ctx, const int8_t *in, float *out, size_t n);
+int csdr_amd_convert_s16_f(csdr_amd_ctx *ctx, const int16_t *in, float *out, size_t n);
+int csdr_amd_convert_f_u8 (csdr_amd_ctx *ctx, const float *in, uint8_t *out, size_t n);
+int csdr_amd_convert_f_s8 (csdr_amd_ctx *ctx, const float *in, int8_t *out, size_t n);
+int csdr_amd_convert_f_s16(csdr_amd_ctx *ctx, const float *in, int16_t *out, size_t n);
+int csdr_amd_convert_f_s24(csdr_amd_ctx *ctx, const float *in, uint8_t *out, size_t n, int bigendian);
+int csdr_amd_convert_s24_f(csdr_amd_ctx *ctx, const uint8_t *in, float *out, size_t n, int bigendian);
+
+/* ------------------------------------------------------------------ frequency shifters
+ * All shifter variants are "rotator generators" (the variant's own float32 phase bookkeeping replayed
+ * exactly on the device) feeding one mixing kernel.  The rotator table rot[0..n) is shared by every
+ * stream that has the same rate and starting phase.
+ *
+ * phase_io: device float[1]; read as the starting phase, overwritten with the phase after n samples
+ * (the reference returns it by value: libcsdr_gpl.c:48-51, libcsdr.c:206, 302-304). */
+enum {
+    CSDR_SHIFT_ADDITION = 0,   /* shift_addition_cc  libcsdr_gpl.c:27-52, 1024-chunks per csdr.c:911-918 */
+    CSDR_SHIFT_MATH     = 1,   /* shift_math_cc      libcsdr.c:186-207 */
+    CSDR_SHIFT_TABLE    = 2,   /* shift_table_cc     libcsdr.c:229-265 (aux = table_size) */
+    CSDR_SHIFT_UNROLL   = 3,   /* shift_unroll_cc    libcsdr.c:268-305 (aux = table size = chunk, csdr.c:821) */
+    CSDR_SHIFT_ADDFAST  = 4    /* shift_addfast_cc   libcsdr.c:307-317, 406-434, 1024-chunks csdr.c:785 */
+};
+int csdr_amd_rotator_generate(csdr_amd_ctx *ctx, int variant, float rate, float *phase_io,
+                              csdr_complexf *rot, size_t n, int chunk, int aux);
+/* out[s][k] = in[s][k] * rot[k]   (four float products, two sums, no FMA contraction) */
+int csdr_amd_mix_cc(csdr_amd_ctx *ctx, const csdr_complexf *in, csdr_complexf *out, const csdr_complexf *rot,
+                    int n_streams, size_t n, size_t in_pitch, size_t out_pitch);
+/* real input variant: shift_addition_fc libcsdr_gpl.c:54-79 */
+int csdr_amd_mix_fc(csdr_amd_ctx *ctx, const float *in, csdr_complexf *out, const csdr_complexf *rot,
+                    int n_streams, size_t n, size_t in_pitch, size_t out_pitch);
+/* convenience: generate + mix with context scratch */
+int csdr_amd_shift_cc(csdr_amd_ctx *ctx, int variant, float rate, float *phase_io,
+                      const csdr_complexf *in, csdr_complexf *out, int n_streams, size_t n,
+                      size_t in_pitch, size_t out_pitch, int chunk, int aux);
+
+/* decimating_shift_addition_cc (libcsdr_gpl.c:131-160), one call per stream-block.
+ * dsa_data: device array of n_streams {sindelta, cosdelta, rate} = shift_addition_data_t (libcsdr_gpl.h:26-31) as
+ * returned by decimating_shift_addition_init (csdr_amd_shift_addition_init(rate*decimation) on the host).
+ * status_io: device int32[3*n_streams] = {decimation_remain, float bits of starting_phase, output_size}
+ * laid out exactly like decimating_shift_addition_status_t (libcsdr_gpl.h:39-44). */
+int csdr_amd_decimating_shift_addition_cc(csdr_amd_ctx *ctx, const csdr_complexf *in, csdr_complexf *out,
+                                          int n_streams, int input_size, size_t in_pitch, size_t out_pitch,
+                                          const void *dsa_data, int decimation, void *status_io);
+/* shift_addition_init libcsdr_gpl.c:81-89 (host): out3 = {sindelta, cosdelta, 2*rate} */
+void csdr_amd_shift_addition_init(float rate, float *out3);
+
+/* ------------------------------------------------------------------ FIR decimator
+ * fir_decimate_cc libcsdr.c:528-549: out[s][o] = sum_t in[s][D*o+t]*taps[t] for all o with D*o+taps<=input_size.
+ * Returns the number of outputs per stream (>=0) or a negative error.  taps: DEVICE pointer. */
+int csdr_amd_fir_decimate_cc(csdr_amd_ctx *ctx, const csdr_complexf *in, csdr_complexf *out,
+                             int n_streams, int input_size, size_t in_pitch, size_t out_pitch,
+                             int decimation, const float *taps, int taps_length);
+/* real FIR without decimation = deemphasis_nfm_ff libcsdr.c:1101-1128 (outputs for i < input_size-taps_length).
+ * Returns outputs per stream. */
+int csdr_amd_fir_ff(csdr_amd_ctx *ctx, const float *in, float *out, int n_streams, int input_size,
+                    size_t in_pitch, size_t out_pitch, const float *taps, int taps_length);
+
+/* ------------------------------------------------------------------ demod / audio
+ * fmdemod_quadri_cf libcsdr.c:1040-1071.  last_io: device complexf[n_streams] (in: previous block's last
+ * sample, out: this block's last sample). */
+int csdr_amd_fmdemod_quadri_cf(csdr_amd_ctx *ctx, const csdr_complexf *in, float *out, int n_streams,
+                               size_t n, size_t in_pitch, size_t out_pitch, csdr_complexf *last_io);
+/* limit_ff / gain_ff libcsdr.c:1130-1142 (flat arrays) */
+int csdr_amd_limit_ff(csdr_amd_ctx *ctx, const float *in, float *out, size_t n, float max_amplitude);
+int csdr_amd_gain_ff(csdr_amd_ctx *ctx, const float *in, float *out, size_t n, float gain);
+/* deemphasis_wfm_ff libcsdr.c:1081-1097.  last_io: device float[n_streams]. */
+int csdr_amd_deemphasis_wfm_ff(csdr_amd_ctx *ctx, const float *in, float *out, int n_streams, size_t n,
+                               size_t in_pitch, size_t out_pitch, float tau, int sample_rate, float *last_io);
+/* fastagc_ff libcsdr.c:946-991 over n_blocks consecutive blocks per stream.
+ * state_io: device float[n_streams * (2*block + 4)] = {buffer_1[block], buffer_2[block], peak_1, peak_2,
+ * last_gain, pad}; zero-initialised = the CLI's calloc'ed state (csdr.c:1393-1394). */
+int csdr_amd_fastagc_ff(csdr_amd_ctx *ctx, const float *in, float *out, int n_streams, int n_blocks, int block,
+                        size_t in_pitch, size_t out_pitch, float reference, float *state_io);
+
+/* fractional_decimator_ff libcsdr.c:715-793 (Lagrange, optional FIR prefilter).  The float `where`
+ * bookkeeping is data independent, so the plan (sample indices + interpolation coefficients) is built on the
+ * host with the reference's float arithmetic and applied to all streams by one kernel.
+ * state: opaque host object carrying where/input_processed between calls. */
+typedef struct csdr_amd_fracdec csdr_amd_fracdec;
+csdr_amd_fracdec *csdr_amd_fracdec_create(float rate, int num_poly_points, const float *host_taps, int taps_length);
+void csdr_amd_fracdec_destroy(csdr_amd_fracdec *d);
+/* returns outputs per stream; *input_processed receives the reference's d->input_processed */
+int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *ctx, csdr_amd_fracdec *d, const float *in, float *out,
+                                     int n_streams, int input_size, size_t in_pitch, size_t out_pitch,
+                                     int *input_processed);
+void  csdr_amd_fracdec_set_where(csdr_amd_fracdec *d, float where);   /* fractional_decimator_ff_t.where */
+float csdr_amd_fracdec_get_where(const csdr_amd_fracdec *d);
+
+/* ------------------------------------------------------------------ FFT overlap-add filter
+ * bandpass_fir_fft_cc (csdr.c:1810-1886) = apply_fir_fft_cc (libcsdr.c:814-849) per block.
+ * One object per (fft_size, taps); processes n_blocks blocks of input_size = fft_size-taps_length+1 samples
+ * for n_streams streams per call; the inter-block overlap is carried inside the object per stream. */
+typedef struct csdr_amd_fftfilt csdr_amd_fftfilt;
+csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const csdr_complexf *host_taps,
+                                          int taps_length, int n_streams, int max_blocks);
+void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f);
+int  csdr_amd_fftfilt_set_taps(csdr_amd_fftfilt *f, const csdr_complexf *host_taps, int taps_length);
+int  csdr_amd_fftfilt_input_size(const csdr_amd_fftfilt *f);
+int  csdr_amd_fftfilt_reset(csdr_amd_fftfilt *f);
+int  csdr_amd_fftfilt_process(csdr_amd_fftfilt *f, const csdr_complexf *in, csdr_complexf *out,
+                              int n_blocks, size_t in_pitch, size_t out_pitch);
+
+/* building blocks used by the drop-in apply_fir_fft_cc / make_fft_c2c (libcsdr.c:814-849, fft_fftw.c:6-45) */
+int csdr_amd_fft_c2c(csdr_amd_ctx *ctx, const csdr_complexf *in, csdr_complexf *out, int n, int forward);  /* unnormalised, cached plan */
+int csdr_amd_bin_product(csdr_amd_ctx *ctx, const csdr_complexf *a, const csdr_complexf *b, csdr_complexf *out, size_t n);
+/* io[k] = io[k]*scale (+ add[k] for k < n_add) */
+int csdr_amd_scale_add(csdr_amd_ctx *ctx, csdr_complexf *io, size_t n, float scale, const csdr_complexf *add, size_t n_add);
+
+/* ------------------------------------------------------------------ fastddc channelizer
+ * fastddc_init fastddc.c:38-72 (layout == fastddc_t fastddc.h:5-24, 76 bytes) */
+typedef struct csdr_fastddc_s {
+    int pre_decimation, post_decimation, taps_length, taps_min_length, overlap_length,
+        fft_size, fft_inv_size, input_size, post_input_size;
+    float pre_shift; int startbin, v, offsetbin; float post_shift; int output_scrape, scrap;
+    struct { float sindelta, cosdelta, rate; } dsadata;
+} csdr_fastddc_t;
+int csdr_amd_fastddc_init(csdr_fastddc_t *ddc, float transition_bw, int decimation, float shift_rate);
+
+/* forward half = `csdr fastddc_fwd_cc` (csdr.c:2255-2300): overlap-save framing + fft_size forward FFT.
+ * in: n_blocks*input_size new samples; spectra: [n_blocks][fft_size].  The overlap tail is kept in the object. */
+typedef struct csdr_amd_fastddc_fwd csdr_amd_fastddc_fwd;
+csdr_amd_fastddc_fwd *csdr_amd_fastddc_fwd_create(csdr_amd_ctx *ctx, const csdr_fastddc_t *ddc, int max_blocks);
+void csdr_amd_fastddc_fwd_destroy(csdr_amd_fastddc_fwd *f);
+int  csdr_amd_fastddc_fwd_process(csdr_amd_fastddc_fwd *f, const csdr_complexf *in, csdr_complexf *spectra, int n_blocks);
+
+/* inverse half = `csdr fastddc_inv_cc` x n_channels (csdr.c:2302-2378, fastddc.c:106-166): per channel
+ * alias-fold X*H into fft_inv_size bins, small inverse FFT, scrap, residual shift + post-decimation.
+ * All channels share decimation/transition_bw (hence geometry) and differ by shift_rate.
+ * out: [n_channels][out_pitch]; out_counts (host int[n_channels], may be NULL) receives samples written. */
+typedef struct csdr_amd_fastddc_inv csdr_amd_fastddc_inv;
+csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float transition_bw, int decimation,
+                                                  const float *host_shift_rates, int n_channels, int window,
+                                                  int max_blocks);
+void csdr_amd_fastddc_inv_destroy(csdr_amd_fastddc_inv *f);
+int  csdr_amd_fastddc_inv_geometry(const csdr_amd_fastddc_inv *f, int channel, csdr_fastddc_t *ddc);
+int  csdr_amd_fastddc_inv_max_output(const csdr_amd_fastddc_inv *f, int n_blocks);
+int  csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *spectra, int n_blocks,
+                                  csdr_complexf *out, size_t out_pitch, int *out_counts);
+/* one channel, one block, explicit taps_fft and status = fastddc_inv_cc itself (fastddc.c:106-166).
+ * status_io: HOST {decimation_remain, float starting_phase, output_size} (decimating_shift_addition_status_t).
+ * d_inv_in / d_td: device scratch of fft_inv_size complexf (folded bins after the second swap / IFFT output, unnormalised). */
+int  csdr_amd_fastddc_inv_block(csdr_amd_ctx *ctx, const csdr_complexf *d_spectrum, const csdr_complexf *d_taps_fft,
+                                const csdr_fastddc_t *ddc, void *status_io, csdr_complexf *d_inv_in, csdr_complexf *d_td,
+                                csdr_complexf *d_out);
+
+/* ------------------------------------------------------------------ fused WFM receive chain (BASELINE config 2)
+ * README.md:66 / csdr-fm:41:  convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw HAMMING |
+ * fmdemod_quadri_cf | fractional_decimator_ff R | deemphasis_wfm_ff fs tau | convert_f_s16
+ * for n_streams independent u8 IQ streams in one pass: each input byte is read from HBM once, each
+ * audio sample written once.  Streaming: call repeatedly with consecutive blocks; all cross-block state
+ * (shift phase, FIR/demod history, de-emphasis state, decimator position) lives in the object. */
+typedef struct csdr_amd_wfm csdr_amd_wfm;
+csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation,
+                                  const float *host_taps, int taps_length, int frac_rate,
+                                  float tau, int audio_rate, size_t max_block_samples);
+void csdr_amd_wfm_destroy(csdr_amd_wfm *w);
+int  csdr_amd_wfm_reset(csdr_amd_wfm *w);
+/* in: u8 IQ, [n_streams][in_pitch bytes], block_samples complex samples per stream (multiple of 1024 except
+ * for the last block of a stream).  audio_s16: [n_streams][out_pitch]; audio_f (optional, may be NULL)
+ * receives the float audio before convert_f_s16 (parity tap).  Returns audio samples written per stream. */
+long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, size_t block_samples,
+                          int16_t *audio_s16, float *audio_f, size_t out_pitch);
+/* name and launch count of the dominant kernel of the last process() call (bench.py roofline leg) */
+const char *csdr_amd_wfm_kernel_name(const csdr_amd_wfm *w);
+/* HIP-event timing of that kernel, on the context's stream: enable, run, then read the accumulated time. */
+int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on);
+int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

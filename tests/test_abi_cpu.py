@@ -1,0 +1,101 @@
+"""CPU-only checks of the boundary: libcsdr_amd.so loads and exports every symbol that include/*.h declares,
+struct layouts match the reference ABI, and without a GPU the library fails loudly."""
+import ctypes as C
+import os
+import re
+import subprocess
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//.*", "", txt)
+    txt = re.sub(r"#define[^\n]*\n", "\n", txt)
+    names = set()
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt):
+        n = m.group(1)
+        if n in ("defined", "sizeof") or n.isupper():
+            continue
+        names.add(n)
+    return names
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    import csdr_amd
+    if not os.path.exists(csdr_amd.LIB_PATH):
+        csdr_amd.build()
+    return csdr_amd.LIB_PATH
+
+
+def test_exports_every_declared_symbol(libpath):
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    for header in ("csdr_amd.h", "libcsdr_amd_compat.h"):
+        missing = sorted(declared_symbols(header) - exported)
+        assert not missing, "%s declares symbols the library does not export: %s" % (header, missing)
+
+
+def test_library_loads_and_fails_loudly_without_gpu(libpath):
+    import csdr_amd
+    L = csdr_amd.lib()
+    if L.csdr_amd_device_count() > 0:
+        pytest.skip("a GPU is present; the no-GPU failure path is exercised on CPU-only hosts")
+    with pytest.raises(csdr_amd.CsdrAmdError):
+        csdr_amd.Context(0)
+    assert b"no HIP device" in L.csdr_amd_last_error() or b"HIP" in L.csdr_amd_last_error()
+
+
+def test_host_design_matches_oracle(libpath, port):
+    """firdes / geometry code of the product (host side, no GPU needed) against the oracle."""
+    import numpy as np
+    import csdr_amd
+    L = csdr_amd.lib()
+    for tbw in [0.05, 0.005, 0.03, 0.001]:
+        assert L.csdr_amd_firdes_filter_len(tbw) == port.firdes_filter_len(tbw)
+    for x in [0, 1, 2, 3, 127, 128, 129, 65536]:
+        assert L.csdr_amd_next_pow2(x) == port.next_pow2(x) and L.csdr_amd_log2n(x) == port.log2n(x)
+    for (n, fc, w) in [(79, 0.05, "HAMMING"), (801, 0.01, "BLACKMAN"), (133, 0.125, "BOXCAR")]:
+        t = np.zeros(n, np.float32)
+        L.csdr_amd_firdes_lowpass_f(t.ctypes.data_as(C.c_void_p), n, fc, csdr_amd.WINDOWS[w])
+        assert np.array_equal(t, port.firdes_lowpass_f(n, fc, w))
+    t = np.zeros(4095, np.complex64)
+    L.csdr_amd_firdes_bandpass_c(t.ctypes.data_as(C.c_void_p), 4095, -0.1, 0.2, 2)
+    assert np.array_equal(t, port.firdes_bandpass_c(4095, -0.1, 0.2))
+    for D in [2, 6, 10, 16, 50, 256]:
+        for tbw in [0.05, 0.005, 0.001]:
+            for s in [0.0, -0.1, 0.4, 0.123456, -0.5 + 0.5 / 256]:
+                a = csdr_amd.FastDDC(); ea = L.csdr_amd_fastddc_init(C.byref(a), tbw, D, s)
+                b, eb = port.fastddc_init(tbw, D, s)
+                A, B = a.as_dict(), b.as_dict()
+                assert ea == eb and A == B, (D, tbw, s, A, B)
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))
+    for sr in [48000, 44100, 8000, 11025]:
+        p = C.c_void_p(); n = L.csdr_amd_nfm_deemph_taps(sr, C.byref(p))
+        got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (n,))
+        assert np.array_equal(got.view(np.uint32), golden["sr%d" % sr].view(np.uint32))
+    assert L.csdr_amd_nfm_deemph_taps(12345, None) == 0
+
+
+def test_struct_layouts():
+    """sizeof/offsets of the by-value structs via a tiny C program against our header."""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "libcsdr_amd_compat.h"
+int main(void){
+ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(complexf), sizeof(shift_table_data_t), sizeof(shift_addfast_data_t),
+   sizeof(shift_unroll_data_t), sizeof(shift_addition_data_t), sizeof(decimating_shift_addition_status_t),
+   sizeof(fastagc_ff_t), sizeof(fractional_decimator_ff_t), sizeof(fastddc_t));
+ printf("%zu %zu %zu %zu %zu\n", offsetof(fastagc_ff_t, last_gain), offsetof(fractional_decimator_ff_t, taps_length),
+   offsetof(fastddc_t, dsadata), offsetof(shift_unroll_data_t, size), sizeof(struct fft_plan_s));
+ return 0; }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(v) for v in out] == [8, 16, 36, 24, 12, 12, 48, 72, 76, 40, 64, 64, 20, 32]

@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP path (through the C ABI of libcsdr_amd.so) against the CPU oracle
+(oracle/csdr_oracle.c, pinned to the compiled reference by tests/test_oracle_vs_ref.py) on identical seeded
+inputs.  Gates (BASELINE.json north_star): bit exact for convert_*; relative RMS <= 1e-5 for float paths."""
+import numpy as np
+import pytest
+from oracle import relrms
+
+pytestmark = pytest.mark.gpu
+c64 = np.complex64
+f32 = np.float32
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch  # noqa: F401  (loads the HIP runtime torch bundles first, as bench.py does)
+    import csdr_amd
+    ctx = csdr_amd.Context(0)
+    assert ctx.arch().startswith("gfx950")
+    yield ctx
+    ctx.close()
+
+
+def crand(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(c64)
+
+
+def fm_signal(rng, n, dev=0.03125, offset=0.0):
+    t = np.arange(n)
+    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * t) + 0.3 * rng.uniform(-1, 1, n)
+    ph = 2 * np.pi * np.cumsum(dev * msg) + 2 * np.pi * offset * t
+    return (0.7 * np.exp(1j * ph) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))).astype(c64)
+
+
+def to_u8(sig):
+    iq = np.empty(2 * sig.size, f32); iq[0::2] = sig.real; iq[1::2] = sig.imag
+    return np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------- converters: bit exact
+def float_probe_set():
+    rng = np.random.default_rng(7)
+    grid = np.linspace(-1, 1, 65537, dtype=f32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.nextafter(f32(1), f32(0)), 1.5, -1.5, 3.0, -3.0, 1e-40, -1e-40,
+                        2.0, -2.0, 100.0, -100.0, 65535.9, -65536.2, 7e4, -7e4, 3e9, -3e9, 1e20, np.inf, -np.inf, np.nan], dtype=f32)
+    wide = rng.uniform(-4, 4, 20001).astype(f32)
+    return np.concatenate([grid, special, wide])
+
+
+def test_convert_to_float_exhaustive(gpu, port):
+    u8 = np.arange(256, dtype=np.uint8).repeat(3)[:-1]            # odd length: exercises the scalar tail
+    assert np.array_equal(gpu.convert_u8_f(u8).view(np.uint32), port.convert_u8_f(u8).view(np.uint32))
+    s8 = np.arange(-128, 128, dtype=np.int8)
+    assert np.array_equal(gpu.convert_s8_f(s8).view(np.uint32), port.convert_s8_f(s8).view(np.uint32))
+    s16 = np.arange(-32768, 32768, dtype=np.int16)
+    assert np.array_equal(gpu.convert_s16_f(s16).view(np.uint32), port.convert_s16_f(s16).view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["convert_f_u8", "convert_f_s8", "convert_f_s16"])
+def test_convert_from_float_bit_exact(gpu, port, name):
+    x = float_probe_set()
+    assert np.array_equal(getattr(gpu, name)(x), getattr(port, name)(x))
+
+
+@pytest.mark.parametrize("big", [0, 1])
+def test_convert_s24_bit_exact(gpu, port, big):
+    x = float_probe_set()
+    assert np.array_equal(gpu.convert_f_s24(x, big), port.convert_f_s24(x, big))
+    raw = np.random.default_rng(3).integers(0, 256, 3 * 50001, dtype=np.uint8)
+    assert np.array_equal(gpu.convert_s24_f(raw, big).view(np.uint32), port.convert_s24_f(raw, big).view(np.uint32))
+
+
+def test_convert_empty(gpu):
+    assert gpu.convert_u8_f(np.zeros(0, np.uint8)).size == 0
+
+
+# ---------------------------------------------------------------- shifters
+@pytest.mark.parametrize("rate", [-0.085, 0.3141, 4e-4, 0.5, -0.5])
+def test_shift_addition(gpu, port, rate):
+    rng = np.random.default_rng(11)
+    x = crand(rng, 1024 * 1000)                                  # >= 1000 consecutive 1024-chunks
+    (a, pa), (b, pb) = gpu.shift_cc(x, rate, "addition"), port.shift_addition_cc(x, rate)
+    assert relrms(a, b) < 1e-6                                    # exact replay: expected bit identical up to libm last bits
+    assert abs(pa - pb) < 1e-6
+    # state carry across calls
+    (a1, p1) = gpu.shift_cc(x[:1024 * 300], rate, "addition")
+    (a2, p2) = gpu.shift_cc(x[1024 * 300:], rate, "addition", phase=p1)
+    assert relrms(np.concatenate([a1, a2]), b) < 1e-6
+
+
+@pytest.mark.parametrize("variant", ["math", "table", "unroll", "addfast"])
+@pytest.mark.parametrize("rate", [-0.085, 0.3141, 4e-4])
+def test_shift_variants(gpu, port, variant, rate):
+    rng = np.random.default_rng(12)
+    x = crand(rng, 1024 * 64)
+    a, pa = gpu.shift_cc(x, rate, variant)
+    b, pb = getattr(port, "shift_%s_cc" % variant)(x, rate)
+    assert relrms(a, b) < TOL
+    assert abs(pa - pb) < 1e-5
+
+
+def test_shift_batch_and_fc_and_decimating(gpu, port):
+    rng = np.random.default_rng(13)
+    x = np.stack([crand(rng, 4096) for _ in range(5)])
+    a, _ = gpu.shift_cc(x, 0.11)
+    for s in range(5):
+        assert relrms(a[s], port.shift_addition_cc(x[s], 0.11)[0]) < 1e-6
+    xr = rng.uniform(-1, 1, 4096 * 4).astype(f32)
+    assert relrms(gpu.shift_addition_fc(xr, 0.11)[0], port.shift_addition_fc(xr, 0.11)[0]) < 1e-6
+    x1 = crand(rng, 448)
+    sa = sb = (0, 0.0, 0)
+    for _ in range(20):
+        ya, sa = gpu.decimating_shift_addition_cc(x1, 0.0123, 3, sa)
+        yb, sb = port.decimating_shift_addition_cc(x1, 0.0123, 3, sb)
+        assert sa[0] == sb[0] and sa[2] == sb[2] and abs(sa[1] - sb[1]) < 1e-6
+        assert relrms(ya, yb) < 1e-6
+
+
+# ---------------------------------------------------------------- FIR decimator
+@pytest.mark.parametrize("D,ntaps", [(10, 79), (50, 801), (2, 133), (256, 3999), (10, 1023), (3, 7)])
+def test_fir_decimate(gpu, port, D, ntaps):
+    rng = np.random.default_rng(1234)
+    x = crand(rng, 16384 * 5 + 777)                                # length not a multiple of D
+    taps = port.firdes_lowpass_f(ntaps, 0.5 / D)
+    a, b = gpu.fir_decimate_cc(x, D, taps), port.fir_decimate_cc(x, D, taps)
+    assert a.size == b.size == (x.size - ntaps) // D + 1
+    assert relrms(a, b) < TOL
+
+
+def test_fir_decimate_c1_and_edges(gpu, port):
+    rng = np.random.default_rng(1234)
+    x = crand(rng, 16384)                                          # BASELINE config 1
+    taps = port.firdes_lowpass_f(79, 0.05)
+    a = gpu.fir_decimate_cc(x, 10, taps)
+    assert a.size == 1631 and relrms(a, port.fir_decimate_cc(x, 10, taps)) < TOL
+    assert gpu.fir_decimate_cc(x[:78], 10, taps).size == 0          # shorter than the filter: no output
+    assert gpu.fir_decimate_cc(x[:79], 10, taps).size == 1
+    xs = np.stack([crand(rng, 5000) for _ in range(7)])             # batch of ragged-length-free streams
+    ys = gpu.fir_decimate_cc(xs, 10, taps)
+    for s in range(7):
+        assert relrms(ys[s], port.fir_decimate_cc(xs[s], 10, taps)) < TOL
+
+
+# ---------------------------------------------------------------- demod + audio
+def test_fmdemod(gpu, port):
+    rng = np.random.default_rng(21)
+    x = fm_signal(rng, 1024 * 40)
+    x[100] = 0; x[5000:5003] = 0
+    (a, la), (b, lb) = gpu.fmdemod_quadri_cf(x), port.fmdemod_quadri_cf(x)
+    assert relrms(a, b) < 1e-6 and a[100] == 0
+    assert (float(la.real), float(la.imag)) == lb
+    (a2, _) = gpu.fmdemod_quadri_cf(x[1024:], last=np.array([x[1023]]))
+    assert relrms(a2, b[1024:]) < 1e-6
+
+
+def test_fractional_decimator(gpu, port):
+    rng = np.random.default_rng(22)
+    x = rng.uniform(-1, 1, 1024 * 30).astype(f32)
+    a = gpu.fractional_decimator_ff(x, 5.0)
+    assert np.array_equal(a, port.fractional_decimator_ff(x, 5.0))
+    assert np.array_equal(a, x[10:10 + 5 * a.size:5])
+    for rate in [2.5, 4.17]:
+        a, b = gpu.fractional_decimator_ff(x, rate), port.fractional_decimator_ff(x, rate)
+        assert a.size == b.size and relrms(a, b) < TOL
+    taps = port.firdes_lowpass_f(133, 0.5 / (2.5 - 0.03))
+    a, b = gpu.fractional_decimator_ff(x, 2.5, taps=taps), port.fractional_decimator_ff(x, 2.5, taps=taps)
+    assert a.size == b.size and relrms(a, b) < TOL
+
+
+def test_deemphasis_limit_gain(gpu, port):
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1.5, 1.5, (70, 1024 * 3 + 17)).astype(f32)
+    a, la = gpu.deemphasis_wfm_ff(x, 50e-6, 48000)
+    for s in range(70):
+        b, lb = port.deemphasis_wfm_ff(x[s], 50e-6, 48000)
+        assert np.array_equal(a[s], b) and la[s] == f32(lb)          # same operations in the same order: bit exact
+    assert np.array_equal(gpu.limit_ff(x, 1.0).ravel(), port.limit_ff(x.ravel(), 1.0))
+    assert np.array_equal(gpu.gain_ff(x, 0.37).ravel(), port.gain_ff(x.ravel(), 0.37))
+    for sr in [48000, 44100, 8000, 11025]:
+        taps = gpu.nfm_taps(sr)
+        a, b = gpu.fir_ff(x[0, :3000], taps), port.deemphasis_nfm_ff(x[0, :3000], taps)
+        assert a.size == b.size == 3000 - taps.size and relrms(a, b) < TOL
+    assert gpu.nfm_taps(12345).size == 0
+
+
+def test_fastagc(gpu, port):
+    rng = np.random.default_rng(24)
+    n = 1024 * 24
+    env = (0.05 + np.abs(np.sin(np.arange(n) / 3000.0))).astype(f32)
+    x = (rng.uniform(-1.5, 1.5, (3, n)).astype(f32)) * env
+    for calls in (1, 5, 24):
+        a = gpu.fastagc_ff(x, calls=calls)
+        for s in range(3):
+            b = port.fastagc_ff(x[s])
+            assert np.all(a[s, :2048] == 0)
+            assert relrms(a[s], b) < 1e-6
+
+
+# ---------------------------------------------------------------- FFT paths
+def test_fft(gpu):
+    rng = np.random.default_rng(31)
+    for n in [512, 65536]:
+        x = crand(rng, n)
+        assert relrms(gpu.fft_c2c(x, True), np.fft.fft(x.astype(np.complex128))) < 2e-6
+
+
+@pytest.mark.parametrize("ntaps", [63, 127, 255, 511, 1023, 2047, 4095])
+def test_bandpass_fir_fft_c3(gpu, port, ntaps):
+    """BASELINE config 3: fft 65536, taps sweep; vs oracle on 4 blocks, vs direct convolution prefix."""
+    rng = np.random.default_rng(3)
+    fft = 65536; inp = fft - ntaps + 1
+    x = crand(rng, inp * 4)
+    taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
+    a = gpu.bandpass_fir_fft_cc(x, taps, fft)
+    b = port.bandpass_fir_fft_cc(x, taps, fft)
+    assert relrms(a, b) < TOL
+    a2 = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=1)     # carry across calls
+    assert relrms(a2, b) < TOL
+    direct = np.convolve(x[:20000].astype(np.complex128), taps.astype(np.complex128))[:20000]
+    assert relrms(a[:20000], direct) < TOL
+
+
+def test_bandpass_small_and_chained_overlap(gpu, port):
+    rng = np.random.default_rng(5)
+    for ntaps, fft in [(79, 256), (601, 1024)]:                        # second case: input_size (424) < overlap (600)
+        inp = fft - ntaps + 1
+        x = np.stack([crand(rng, inp * 9) for _ in range(3)])
+        taps = port.firdes_bandpass_c(ntaps, 0.1, 0.3)
+        for per in (None, 2):
+            a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=per)
+            for s in range(3):
+                assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, fft)) < TOL
+
+
+@pytest.mark.parametrize("D,tbw,shifts", [(16, 0.05, [-0.1, 0.2, 0.33]), (256, 0.005, [0.3 + 0.5 / 256, -0.45]), (6, 0.05, [0.2])])
+def test_fastddc(gpu, port, D, tbw, shifts):
+    rng = np.random.default_rng(4)
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    pd, _ = port.fastddc_init(tbw, D, 0.0)
+    nb = 40 if ddc.fft_size <= 4096 else 12
+    x = crand(rng, ddc.input_size * nb)
+    spec = gpu.fastddc_fwd_cc(x, ddc, blocks_per_call=7)
+    pspec = port.fastddc_fwd_cc(x, pd)
+    assert relrms(spec, pspec) < TOL
+    outs = gpu.fastddc_inv_cc(pspec, tbw, D, shifts, blocks_per_call=5)
+    for c, s in enumerate(shifts):
+        pdc, _ = port.fastddc_init(tbw, D, s)
+        ref_out = port.fastddc_inv_cc(pspec, pdc, port.fastddc_taps_fft(pdc, s, D))
+        assert outs[c].size == ref_out.size and ref_out.size > 0
+        assert relrms(outs[c], ref_out) < TOL
+
+
+# ---------------------------------------------------------------- the fused WFM chain (BASELINE config 2)
+def wfm_inputs(n_streams, n):
+    return np.stack([to_u8(fm_signal(np.random.default_rng(1000 + s), n, offset=0.085)) for s in range(n_streams)])
+
+
+def check_chain(s16, af, port, u8, taps, n_streams):
+    for s in range(n_streams):
+        ps, pf = port.wfm_chain(u8[s], -0.085, 10, taps)
+        n = min(pf.size, af.shape[1])
+        assert n >= u8.shape[1] // 2 // 50 - 8
+        assert relrms(af[s, :n], pf[:n]) < TOL, "stream %d" % s
+        d = np.abs(s16[s, :n].astype(np.int32) - ps[:n].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.05
+
+
+def test_wfm_chain_single_call(gpu, port):
+    taps = port.firdes_lowpass_f(79, 0.05)
+    u8 = wfm_inputs(4, 16384 * 12)
+    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps)
+    check_chain(s16, af, port, u8, taps, 4)
+
+
+def test_wfm_chain_streaming_blocks(gpu, port):
+    taps = port.firdes_lowpass_f(79, 0.05)
+    u8 = wfm_inputs(3, 16384 * 10 + 1024 * 3 + 500)                  # ragged tail: last block not a multiple of 1024
+    for block in (16384, 1024 * 7):
+        s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=block)
+        check_chain(s16, af, port, u8, taps, 3)
+    one, _ = gpu.wfm_chain(u8, -0.085, 10, taps)
+    blk, _ = gpu.wfm_chain(u8, -0.085, 10, taps, block=16384)
+    n = min(one.shape[1], blk.shape[1])
+    assert np.abs(one[:, :n].astype(np.int32) - blk[:, :n]).max() <= 1  # block-size invariance
+
+
+def test_wfm_chain_full_size_properties(gpu, port):
+    """BASELINE config-2 shape at reduced stream count x full block length: properties that need no oracle run.
+    (a) streams with identical input give identical output; (b) first seconds match the oracle on one stream."""
+    taps = port.firdes_lowpass_f(79, 0.05)
+    n = 2400000
+    base = to_u8(fm_signal(np.random.default_rng(1000), n, offset=0.085))
+    u8 = np.stack([base, base, to_u8(fm_signal(np.random.default_rng(1001), n, offset=0.085))])
+    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps)
+    assert s16.shape[1] >= 48000 - 4
+    assert np.array_equal(s16[0], s16[1]) and not np.array_equal(s16[0], s16[2])
+    ps, pf = port.wfm_chain(base, -0.085, 10, taps)
+    m = min(pf.size, af.shape[1])
+    assert relrms(af[0, :m], pf[:m]) < TOL
