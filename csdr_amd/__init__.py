@@ -82,10 +82,10 @@ def lib():
         getattr(L, "csdr_amd_convert_" + nm).argtypes = [vp, vp, vp, sz]
     L.csdr_amd_convert_f_s24.argtypes = [vp, vp, vp, sz, i]
     L.csdr_amd_convert_s24_f.argtypes = [vp, vp, vp, sz, i]
-    L.csdr_amd_rotator_generate.argtypes = [vp, i, fl, vp, vp, sz, i, i]
+    L.csdr_amd_rotator_generate.argtypes = [vp, i, fl, C.POINTER(fl), vp, sz, i, i]
     L.csdr_amd_mix_cc.argtypes = [vp, vp, vp, vp, i, sz, sz, sz]
     L.csdr_amd_mix_fc.argtypes = [vp, vp, vp, vp, i, sz, sz, sz]
-    L.csdr_amd_shift_cc.argtypes = [vp, i, fl, vp, vp, vp, i, sz, sz, sz, i, i]
+    L.csdr_amd_shift_cc.argtypes = [vp, i, fl, C.POINTER(fl), vp, vp, i, sz, sz, sz, i, i]
     L.csdr_amd_decimating_shift_addition_cc.argtypes = [vp, vp, vp, i, i, sz, sz, vp, i, vp]
     L.csdr_amd_fir_decimate_cc.argtypes = [vp, vp, vp, i, i, sz, sz, i, vp, i]
     L.csdr_amd_fir_ff.argtypes = [vp, vp, vp, i, i, sz, sz, vp, i]
@@ -255,19 +255,18 @@ class Context:
         x2, squeeze = self._2d(x, c64)
         s, n = x2.shape
         di = self.upload(x2); do = self.alloc(x2.nbytes + 64)
-        dph = self.upload(np.array([phase], f32))
-        self.check(self.L.csdr_amd_shift_cc(self.h, SHIFT[variant], rate, dph.ptr, di.ptr, do.ptr, s, n, n, n, chunk, aux), "shift_cc")
+        ph = C.c_float(phase)
+        self.check(self.L.csdr_amd_shift_cc(self.h, SHIFT[variant], rate, C.byref(ph), di.ptr, do.ptr, s, n, n, n, chunk, aux), "shift_cc")
         y = self.download(do, c64, s * n).reshape(s, n)
-        ph = float(self.download(dph, f32, 1)[0])
-        return (y[0] if squeeze else y), ph
+        return (y[0] if squeeze else y), ph.value
 
     def shift_addition_fc(self, x, rate, phase=0.0, chunk=1024):
         x = np.ascontiguousarray(x, f32); n = x.size
         di = self.upload(x); do = self.alloc(8 * n + 64); rot = self.alloc(8 * n + 64)
-        dph = self.upload(np.array([phase], f32))
-        self.check(self.L.csdr_amd_rotator_generate(self.h, 0, rate, dph.ptr, rot.ptr, n, chunk, 0), "rotator")
+        ph = C.c_float(phase)
+        self.check(self.L.csdr_amd_rotator_generate(self.h, 0, rate, C.byref(ph), rot.ptr, n, chunk, 0), "rotator")
         self.check(self.L.csdr_amd_mix_fc(self.h, di.ptr, do.ptr, rot.ptr, 1, n, n, n), "mix_fc")
-        return self.download(do, c64, n), float(self.download(dph, f32, 1)[0])
+        return self.download(do, c64, n), ph.value
 
     def decimating_shift_addition_cc(self, x, rate, decimation, status=(0, 0.0, 0)):
         x = np.ascontiguousarray(x, c64); n = x.size

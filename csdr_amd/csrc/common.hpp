@@ -36,4 +36,9 @@ struct csdr_amd_ctx {
     hipEvent_t ev0, ev1;
     // returns a device buffer of at least `bytes` that stays valid until the next request on the same slot
     void *get_scratch(int slot, size_t bytes);
+    // pinned host staging for small host-computed tables (phase sequences, plans): acquire() waits until the
+    // previous upload from the buffer has completed, upload() queues the async copy on the context's stream
+    void *pinned; size_t pinned_bytes; hipEvent_t pinned_ev; bool pinned_in_flight;
+    void *pinned_acquire(size_t bytes);
+    int pinned_upload(void *dst_dev, size_t bytes);
 };

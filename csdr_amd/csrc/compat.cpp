@@ -66,11 +66,9 @@ float run_shifter(int variant, complexf *in, complexf *out, int n, float rate, f
     csdr_amd_ctx *c = ctx();
     cf32 *din = stage_in<cf32>(4, (const cf32 *)in, n);
     cf32 *dout = stage_out<cf32>(5, n);
-    float *dph = stage_in<float>(6, &phase, 1);
-    MUST(csdr_amd_shift_cc(c, variant, rate, dph, din, dout, 1, (size_t)n, (size_t)n, (size_t)n, n, aux));   // one library call = one chunk
+    MUST(csdr_amd_shift_cc(c, variant, rate, &phase, din, dout, 1, (size_t)n, (size_t)n, (size_t)n, n, aux));   // one library call = one chunk
     fetch((cf32 *)out, dout, n);
-    float ph; fetch(&ph, dph, 1);
-    return ph;
+    return phase;
 }
 
 struct FftPlanImpl { int kind; int forward; };   // kind 0: c2c, 1: r2c, 2: c2r
@@ -205,12 +203,11 @@ float shift_addition_fc(float *in, complexf *out, int n, shift_addition_data_t d
     if (n <= 0) return phase;
     csdr_amd_ctx *c = ctx();
     float *din = stage_in<float>(4, in, n); cf32 *dout = stage_out<cf32>(5, n);
-    float *dph = stage_in<float>(6, &phase, 1);
     cf32 *rot = stage_out<cf32>(7, n);
-    MUST(csdr_amd_rotator_generate(c, CSDR_SHIFT_ADDITION, d.rate / 2, dph, rot, n, n, 0));
+    MUST(csdr_amd_rotator_generate(c, CSDR_SHIFT_ADDITION, d.rate / 2, &phase, rot, n, n, 0));
     MUST(csdr_amd_mix_fc(c, din, dout, rot, 1, n, n, n));
     fetch((cf32 *)out, dout, n);
-    float ph; fetch(&ph, dph, 1); return ph;
+    return phase;
 }
 shift_addition_data_t decimating_shift_addition_init(float rate, int decimation) { return shift_addition_init(rate * decimation); }
 decimating_shift_addition_status_t decimating_shift_addition_cc(complexf *in, complexf *out, int n, shift_addition_data_t d, int decimation, decimating_shift_addition_status_t s)

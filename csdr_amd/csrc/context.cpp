@@ -31,6 +31,27 @@ void *csdr_amd_ctx::get_scratch(int slot, size_t bytes)
     return p;
 }
 
+void *csdr_amd_ctx::pinned_acquire(size_t bytes)
+{
+    if (pinned_in_flight) { (void)hipEventSynchronize(pinned_ev); pinned_in_flight = false; }
+    if (bytes > pinned_bytes) {
+        if (pinned) (void)hipHostFree(pinned);
+        pinned = nullptr; pinned_bytes = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc(&pinned, want, hipHostMallocDefault) != hipSuccess) { fail_msg(-2, "pinned allocation of %zu bytes failed", want); return nullptr; }
+        pinned_bytes = want;
+    }
+    return pinned;
+}
+
+int csdr_amd_ctx::pinned_upload(void *dst_dev, size_t bytes)
+{
+    CSDR_HIP(hipMemcpyAsync(dst_dev, pinned, bytes, hipMemcpyHostToDevice, stream));
+    CSDR_HIP(hipEventRecord(pinned_ev, stream));
+    pinned_in_flight = true;
+    return 0;
+}
+
 extern "C" {
 
 const char *csdr_amd_last_error(void) { return g_err; }
@@ -60,7 +81,8 @@ csdr_amd_ctx *csdr_amd_ctx_create(int device, void *hip_stream)
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fail_msg(-1, "hipStreamCreate failed"); delete c; return nullptr; }
         c->own_stream = true;
     }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { fail_msg(-1, "hipEventCreate failed"); delete c; return nullptr; }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreateWithFlags(&c->pinned_ev, hipEventDisableTiming) != hipSuccess) { fail_msg(-1, "hipEventCreate failed"); delete c; return nullptr; }
+    c->pinned = nullptr; c->pinned_bytes = 0; c->pinned_in_flight = false;
     return c;
 }
 
@@ -70,7 +92,8 @@ void csdr_amd_ctx_destroy(csdr_amd_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < SCRATCH_SLOTS; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->pinned_ev);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

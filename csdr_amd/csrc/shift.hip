@@ -32,20 +32,14 @@ __device__ __forceinline__ float wrap_0_2pi(float p)
 __device__ __forceinline__ float cos_like_libm(float x) { return (float)cos((double)x); }
 __device__ __forceinline__ float sin_like_libm(float x) { return (float)sin((double)x); }
 
-// ---- chunk start phases for the chunked variants (one lane; n/chunk sequential float adds)
-// libcsdr_gpl.c:48-51 / libcsdr.c:302-304, 429-431 with the CLI's chunking csdr.c:911-918, 785, 836.
-__global__ void k_chunk_phases(float *__restrict__ phases, float *__restrict__ phase_io, float inc_per_sample, size_t n, int chunk)
-{
-    if (blockIdx.x || threadIdx.x) return;
-    float p = *phase_io;
-    size_t m = 0;
-    for (size_t pos = 0; pos < n; pos += chunk, m++) {
-        phases[m] = p;
-        const int len = (n - pos > (size_t)chunk) ? chunk : (int)(n - pos);
-        p = wrap_pm_pi(p + inc_per_sample * (float)len);
-    }
-    *phase_io = p;
-}
+// The phase SEQUENCES (chunk start phases; per-sample phases of shift_math/table; shift_unroll's table angles) are
+// pure float32 recurrences p <- wrap(p + c): strictly sequential, data independent, a few thousand to a few
+// million steps.  One GPU lane needs ~1.8 us per step for them (measured: 4.3 ms per 2344 chunks, 38 % of the
+// round-1 WFM step), a host core ~1 ns, so they are computed on the host in the reference's float arithmetic
+// (SSE float add/compare = IEEE binary32, identical results) and uploaded through pinned staging; the device
+// does the parallel part (libm-grade sin/cos, the per-chunk phasor replay, the mixing).
+static inline float h_wrap_pm_pi(float p) { while (p > PI_F) p -= 2 * PI_F; while (p < -PI_F) p += 2 * PI_F; return p; }
+static inline float h_wrap_0_2pi(float p) { while (p > 2 * PI_F) p -= 2 * PI_F; while (p < 0) p += 2 * PI_F; return p; }
 
 // ---- shift_addition_cc: one lane replays one chunk's phasor recurrence (libcsdr_gpl.c:33-47)
 __global__ __launch_bounds__(64) void k_fill_addition(cf32 *__restrict__ rot, const float *__restrict__ phases, float sindelta, float cosdelta, size_t n, int chunk)
@@ -82,12 +76,6 @@ __global__ __launch_bounds__(64) void k_fill_addfast(cf32 *__restrict__ rot, con
 }
 
 // ---- shift_unroll_cc: table of (k+1) increments accumulated in float (libcsdr.c:268-284), then per sample
-__global__ void k_unroll_table_phases(float *__restrict__ acc_phase, float inc, int size)
-{
-    if (blockIdx.x || threadIdx.x) return;
-    float a = 0;
-    for (int k = 0; k < size; k++) { a = wrap_pm_pi(a + inc); acc_phase[k] = a; }
-}
 __global__ __launch_bounds__(256) void k_sincos_table(const float *__restrict__ ph, float *__restrict__ dsin, float *__restrict__ dcos, int size)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -102,15 +90,8 @@ __global__ __launch_bounds__(256) void k_fill_unroll(cf32 *__restrict__ rot, con
     rot[k] = cf32{c0 * dcos[off] - s0 * dsin[off], s0 * dcos[off] + c0 * dsin[off]};
 }
 
-// ---- shift_math_cc / shift_table_cc: float phase advanced and wrapped PER SAMPLE (libcsdr.c:202-204, 260-262).
-// Inherently sequential per (rate, phase) group: one lane walks the block and stores every phase.
-__global__ void k_sample_phases(float *__restrict__ ph, float *__restrict__ phase_io, float inc, size_t n)
-{
-    if (blockIdx.x || threadIdx.x) return;
-    float p = *phase_io;
-    for (size_t k = 0; k < n; k++) { ph[k] = p; p = wrap_0_2pi(p + inc); }
-    *phase_io = p;
-}
+// ---- shift_math_cc / shift_table_cc: float phase advanced and wrapped PER SAMPLE (libcsdr.c:202-204, 260-262);
+// the phase of every sample arrives from the host scan
 __global__ __launch_bounds__(256) void k_fill_math(cf32 *__restrict__ rot, const float *__restrict__ ph, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,12 +194,24 @@ int csdr_amd_rotator_generate(csdr_amd_ctx *c, int variant, float rate, float *p
     hipStream_t st = c->stream;
     const float rate2 = rate * 2;                      // shift_addition_init / "rate*=2" (libcsdr_gpl.c:83, libcsdr.c:188)
     const float inc = rate2 * PI_F;                    // float product, as in the reference
+    float p = *phase_io;
     if (variant == CSDR_SHIFT_ADDITION || variant == CSDR_SHIFT_ADDFAST || variant == CSDR_SHIFT_UNROLL) {
         if (chunk <= 0) chunk = 1024;
         const size_t nchunks = (n + chunk - 1) / chunk;
-        float *phases = (float *)c->get_scratch(0, sizeof(float) * (nchunks + 1));
-        if (!phases) return -2;
-        hipLaunchKernelGGL(k_chunk_phases, dim3(1), dim3(1), 0, st, phases, phase_io, inc, n, chunk); CSDR_LAUNCH_CHECK();
+        const int size = (variant == CSDR_SHIFT_UNROLL) ? (aux > 0 ? aux : chunk) : 0;
+        if (variant == CSDR_SHIFT_UNROLL && size < chunk) return fail_msg(-3, "shift_unroll: table size %d smaller than chunk %d", size, chunk);
+        float *hp = (float *)c->pinned_acquire(sizeof(float) * (nchunks + 1 + (size_t)size));
+        float *phases = (float *)c->get_scratch(0, sizeof(float) * (nchunks + 1 + (size_t)size));
+        if (!hp || !phases) return -2;
+        // chunk start phases: libcsdr_gpl.c:48-51 / libcsdr.c:302-304, 429-431 with the CLI's chunking csdr.c:911-918, 785, 836
+        size_t m = 0;
+        for (size_t pos = 0; pos < n; pos += chunk, m++) {
+            hp[m] = p;
+            const int len = (n - pos > (size_t)chunk) ? chunk : (int)(n - pos);
+            p = h_wrap_pm_pi(p + inc * (float)len);
+        }
+        if (size) { float a = 0; for (int k = 0; k < size; k++) { a = h_wrap_pm_pi(a + inc); hp[nchunks + 1 + k] = a; } }   // libcsdr.c:275-282
+        int rc = c->pinned_upload(phases, sizeof(float) * (nchunks + 1 + (size_t)size)); if (rc) return rc;
         if (variant == CSDR_SHIFT_ADDITION) {
             const float sd = (float)sin((double)inc), cd = (float)cos((double)inc);   // libcsdr_gpl.c:85-86 (host libm, like the reference)
             hipLaunchKernelGGL(k_fill_addition, dim3(cdiv(nchunks, 64)), dim3(64), 0, st, rot, phases, sd, cd, n, chunk); CSDR_LAUNCH_CHECK();
@@ -227,20 +220,20 @@ int csdr_amd_rotator_generate(csdr_amd_ctx *c, int variant, float rate, float *p
             for (int j = 0; j < 4; j++) { q.dsin[j] = (float)sin((double)(inc * (j + 1))); q.dcos[j] = (float)cos((double)(inc * (j + 1))); }
             hipLaunchKernelGGL(k_fill_addfast, dim3(cdiv(nchunks, 64)), dim3(64), 0, st, rot, phases, q, n, chunk); CSDR_LAUNCH_CHECK();
         } else {
-            const int size = aux > 0 ? aux : chunk;
-            if (size < chunk) return fail_msg(-3, "shift_unroll: table size %d smaller than chunk %d", size, chunk);
-            float *tab = (float *)c->get_scratch(1, sizeof(float) * 3 * (size_t)size);
+            float *tab = (float *)c->get_scratch(1, sizeof(float) * 2 * (size_t)size);
             if (!tab) return -2;
-            hipLaunchKernelGGL(k_unroll_table_phases, dim3(1), dim3(1), 0, st, tab, inc, size); CSDR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_sincos_table, dim3(cdiv(size, 256)), dim3(256), 0, st, tab, tab + size, tab + 2 * size, size); CSDR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_fill_unroll, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, phases, tab + size, tab + 2 * size, n, chunk); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_sincos_table, dim3(cdiv(size, 256)), dim3(256), 0, st, phases + nchunks + 1, tab, tab + size, size); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_fill_unroll, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, phases, tab, tab + size, n, chunk); CSDR_LAUNCH_CHECK();
         }
+        *phase_io = p;
         return 0;
     }
     if (variant == CSDR_SHIFT_MATH || variant == CSDR_SHIFT_TABLE) {
+        float *hp = (float *)c->pinned_acquire(sizeof(float) * n);
         float *ph = (float *)c->get_scratch(0, sizeof(float) * n);
-        if (!ph) return -2;
-        hipLaunchKernelGGL(k_sample_phases, dim3(1), dim3(1), 0, st, ph, phase_io, inc, n); CSDR_LAUNCH_CHECK();
+        if (!hp || !ph) return -2;
+        for (size_t k = 0; k < n; k++) { hp[k] = p; p = h_wrap_0_2pi(p + inc); }        // libcsdr.c:202-204
+        int rc = c->pinned_upload(ph, sizeof(float) * n); if (rc) return rc;
         if (variant == CSDR_SHIFT_MATH) {
             hipLaunchKernelGGL(k_fill_math, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, n); CSDR_LAUNCH_CHECK();
         } else {
@@ -250,6 +243,7 @@ int csdr_amd_rotator_generate(csdr_amd_ctx *c, int variant, float rate, float *p
             hipLaunchKernelGGL(k_quarter_table, dim3(cdiv(size, 256)), dim3(256), 0, st, table, size); CSDR_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_fill_table, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, table, size, n); CSDR_LAUNCH_CHECK();
         }
+        *phase_io = p;
         return 0;
     }
     return fail_msg(-3, "unknown shifter variant %d", variant);

@@ -25,14 +25,17 @@
 //                 independent of its predecessor to float precision; the first segment of a call uses the
 //                 exact carried state.
 #include "common.hpp"
+#include "wfm_mfma.hpp"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 #include <string>
+#include <string.h>
 using namespace csdr_amd;
 
 namespace {
 
-constexpr int HIST = 256;          // complex samples of input history kept per stream (>= D*(F-1+..)+taps needs 88 for 10/79/5)
+constexpr int HIST = WFM_HIST;     // complex samples of input history kept per stream (>= D*(F-1+..)+taps needs 88 for 10/79/5)
 constexpr int TILE_A = 64;         // audio samples per workgroup
 constexpr int WARM = 48;           // de-emphasis warm-up samples
 
@@ -52,8 +55,9 @@ __global__ __launch_bounds__(256) void k_wfm_front(const uint8_t *__restrict__ i
 {
     extern __shared__ float4 lds_raw[];
     float2 *win = reinterpret_cast<float2 *>(lds_raw);
-    const int s = blockIdx.y;
-    const int a0 = blockIdx.x * TILE_A;
+    // grid: x = stream (fastest), y = time tile -- workgroups that run together share the same rotator window in L2
+    const int s = blockIdx.x;
+    const int a0 = blockIdx.y * TILE_A;
     const int na = min(TILE_A, p.n_audio - a0);
     if (na <= 0) return;
     const long long j0 = p.j_first + a0;
@@ -178,7 +182,8 @@ struct csdr_amd_wfm {
     int n_streams, D, L, F, audio_rate;
     float shift_rate, tau, alpha;
     size_t max_block;
-    float *d_taps, *d_phase, *d_demod, *d_last[2];
+    float *d_taps, *d_demod, *d_last[2];
+    float phase;                     // shift_addition_cc starting_phase (host float, like the reference's by-value state)
     cf32 *d_rot;
     uint8_t *d_hist;
     size_t demod_pitch;
@@ -191,6 +196,11 @@ struct csdr_amd_wfm {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used;
     double prof_ms; long prof_launches;
+    // matrix-core front end (wfm_mfma.hip)
+    bool use_mfma;
+    WfmMfmaDevice mfma;
+    float2 *d_ctab; size_t ctab_cap;
+    float2 c_prev;                   // phasor seed of the previous block's last chunk (history windows)
 };
 
 extern "C" {
@@ -210,7 +220,6 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&w->d_taps, sizeof(float) * taps_length);
-    alloc((void **)&w->d_phase, sizeof(float) * 4);
     alloc((void **)&w->d_demod, sizeof(float) * w->demod_pitch * n_streams);
     alloc((void **)&w->d_last[0], sizeof(float) * n_streams);
     alloc((void **)&w->d_last[1], sizeof(float) * n_streams);
@@ -219,6 +228,26 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
     (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     w->kernel_name = "k_wfm_front";
+    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_straddle = nullptr;
+    {
+        const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons)
+        const bool want_mfma = !(force && !strcmp(force, "valu"));
+        if (want_mfma && wfm_mfma_supported(decimation, taps_length, frac_rate)) {
+            WfmMfmaTable t;
+            wfm_mfma_build_table(decimation, taps_length, frac_rate, shift_rate, host_taps, t);
+            w->mfma.tile_stride_bytes = t.tile_stride_bytes; w->mfma.win_off_bytes = t.win_off_bytes; w->mfma.n_phases = t.n_phases; w->mfma.scale = t.scale;
+            w->ctab_cap = max_block_samples / 1024 + 8;
+            hipError_t e2 = hipMalloc(&w->mfma.d_frags, t.frags.size());
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_consts, t.consts.size() * sizeof(float));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_straddle, t.straddle.size() * sizeof(int));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->d_ctab, w->ctab_cap * sizeof(float2));
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_frags, t.frags.data(), t.frags.size(), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_consts, t.consts.data(), t.consts.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_straddle, t.straddle.data(), t.straddle.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) { fail(e2, "hipMalloc/hipMemcpy(wfm mfma table)", __FILE__, __LINE__); delete w; return nullptr; }
+            w->use_mfma = true; w->kernel_name = "k_wfm_mfma";
+        }
+    }
     w->profiling = false; w->ev_used = 0; w->prof_ms = 0; w->prof_launches = 0;
     if (csdr_amd_wfm_reset(w)) { delete w; return nullptr; }
     return w;
@@ -228,21 +257,26 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
 {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
-    (void)hipFree(w->d_taps); (void)hipFree(w->d_phase); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]);
+    (void)hipFree(w->d_taps); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]);
     (void)hipFree(w->d_rot); (void)hipFree(w->d_hist);
     for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (w->mfma.d_frags) (void)hipFree(w->mfma.d_frags);
+    if (w->mfma.d_consts) (void)hipFree(w->mfma.d_consts);
+    if (w->mfma.d_straddle) (void)hipFree(w->mfma.d_straddle);
+    if (w->d_ctab) (void)hipFree(w->d_ctab);
     delete w;
 }
 
 int csdr_amd_wfm_reset(csdr_amd_wfm *w)
 {
     hipStream_t st = w->ctx->stream;
-    CSDR_HIP(hipMemsetAsync(w->d_phase, 0, sizeof(float) * 4, st));
+    w->phase = 0.f;
     CSDR_HIP(hipMemsetAsync(w->d_last[0], 0, sizeof(float) * w->n_streams, st));
     CSDR_HIP(hipMemsetAsync(w->d_last[1], 0, sizeof(float) * w->n_streams, st));
     CSDR_HIP(hipMemsetAsync(w->d_rot, 0, sizeof(cf32) * (HIST + w->max_block + 64), st));
     CSDR_HIP(hipMemsetAsync(w->d_hist, 0x80, (size_t)2 * HIST * w->n_streams, st));
     w->B = 0; w->next_j = 0; w->last_T = 0; w->flip = 0; w->ended = false;
+    w->c_prev = make_float2(1.f, 0.f);
     return 0;
 }
 
@@ -276,10 +310,34 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     if (block_samples > w->max_block) return fail_msg(-3, "wfm: block of %zu samples exceeds max_block_samples %zu", block_samples, w->max_block);
     if (((uintptr_t)in & 15) || (in_pitch & 15)) return fail_msg(-3, "wfm: input pointer and pitch must be 16-byte aligned");
     const int T = (int)block_samples;
-    // 1. rotator table for this block behind the previous block's tail (history positions keep their own phasors)
-    if (w->last_T) CSDR_HIP(hipMemcpyAsync(w->d_rot, w->d_rot + w->last_T, sizeof(cf32) * HIST, hipMemcpyDeviceToDevice, st));
-    int rc = csdr_amd_rotator_generate(c, CSDR_SHIFT_ADDITION, w->shift_rate, w->d_phase, w->d_rot + HIST, (size_t)T, 1024, 0);
-    if (rc) return rc;
+    int rc = 0;
+    if (w->use_mfma) {
+        // 1a. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping
+        //     (libcsdr_gpl.c:33-34, 48-51; chunks of 1024 per csdr.c:911-918).  ctab[0] belongs to the previous block's last chunk.
+        const size_t nch = ((size_t)T + 1023) / 1024;
+        if (nch + 3 > w->ctab_cap) return fail_msg(-3, "wfm: chunk table too small");
+        float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * (nch + 3));
+        if (!hc) return -2;
+        const float inc = (w->shift_rate * 2) * PI_F;
+        float ph = w->phase;
+        hc[0] = w->c_prev;
+        for (size_t m = 0; m <= nch + 1; m++) {
+            hc[1 + m] = make_float2((float)cos((double)ph), (float)sin((double)ph));
+            if (m + 1 == nch) w->c_prev = hc[1 + m];
+            const int len = (m < nch && (size_t)T - m * 1024 < 1024) ? (int)((size_t)T - m * 1024) : 1024;
+            float nx = ph + inc * (float)len;
+            while (nx > PI_F) nx -= 2 * PI_F;
+            while (nx < -PI_F) nx += 2 * PI_F;
+            if (m + 1 == nch) w->phase = nx;
+            ph = nx;
+        }
+        rc = c->pinned_upload(w->d_ctab, sizeof(float2) * (nch + 3)); if (rc) return rc;
+    } else {
+        // 1b. rotator table for this block behind the previous block's tail (history positions keep their own phasors)
+        if (w->last_T) CSDR_HIP(hipMemcpyAsync(w->d_rot, w->d_rot + w->last_T, sizeof(cf32) * HIST, hipMemcpyDeviceToDevice, st));
+        rc = csdr_amd_rotator_generate(c, CSDR_SHIFT_ADDITION, w->shift_rate, &w->phase, w->d_rot + HIST, (size_t)T, 1024, 0);
+        if (rc) return rc;
+    }
     // 2. audio samples that become computable with this block: F*j+10 is the newest FIR output, needs input up to D*(F*j+10)+L-1
     const long long avail_last = w->B + T - 1;
     long long j_hi = -1;
@@ -305,9 +363,14 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
             e0 = w->ev_pool[w->ev_used].first; e1 = w->ev_pool[w->ev_used].second; w->ev_used++;
             CSDR_HIP(hipEventRecord(e0, st));
         }
-        hipLaunchKernelGGL(k_wfm_front, dim3(cdiv(n_audio, TILE_A), w->n_streams), dim3(256), lds, st,
-                           in, in_pitch, w->d_hist, w->d_rot, w->d_taps, w->d_demod, w->demod_pitch, p);
-        CSDR_LAUNCH_CHECK();
+        if (w->use_mfma) {
+            rc = wfm_mfma_launch(st, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(k_wfm_front, dim3(w->n_streams, cdiv(n_audio, TILE_A)), dim3(256), lds, st,
+                               in, in_pitch, w->d_hist, w->d_rot, w->d_taps, w->d_demod, w->demod_pitch, p);
+            CSDR_LAUNCH_CHECK();
+        }
         if (w->profiling) CSDR_HIP(hipEventRecord(e1, st));
         hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, 4096), w->n_streams), dim3(64), 0, st,
                            w->d_demod, w->demod_pitch, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);

@@ -81,8 +81,10 @@ int csdr_amd_convert_s24_f(csdr_amd_ctx *ctx, const uint8_t *in, float *out, siz
  * exactly on the device) feeding one mixing kernel.  The rotator table rot[0..n) is shared by every
  * stream that has the same rate and starting phase.
  *
- * phase_io: device float[1]; read as the starting phase, overwritten with the phase after n samples
- * (the reference returns it by value: libcsdr_gpl.c:48-51, libcsdr.c:206, 302-304). */
+ * phase_io: HOST float; read as the starting phase, overwritten with the phase after n samples (the reference
+ * returns it by value: libcsdr_gpl.c:48-51, libcsdr.c:206, 302-304).  The float32 phase recurrences are strictly
+ * sequential and data independent; they run on the host (identical IEEE arithmetic) and are uploaded, the
+ * device does the parallel part (sin/cos, per-chunk phasor replay, mixing).  Calls do not block on the GPU. */
 enum {
     CSDR_SHIFT_ADDITION = 0,   /* shift_addition_cc  libcsdr_gpl.c:27-52, 1024-chunks per csdr.c:911-918 */
     CSDR_SHIFT_MATH     = 1,   /* shift_math_cc      libcsdr.c:186-207 */
@@ -235,6 +237,12 @@ const char *csdr_amd_wfm_kernel_name(const csdr_amd_wfm *w);
 /* HIP-event timing of that kernel, on the context's stream: enable, run, then read the accumulated time. */
 int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on);
 int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches);
+
+/* Test hook: CPU evaluation of one matrix-core tile with the kernel's own weight table and layout (no GPU needed);
+ * out16 must hold 32 floats (16 results + scratch).  See csdr_amd/csrc/wfm_mfma.hip. */
+int csdr_amd_debug_wfm_mfma_tile(int D, int L, int F, float shift_rate, const float *taps, int phase, const uint8_t *window,
+                                 const float *C0, const float *C1, float *out16, int *n_phases, int *straddle,
+                                 int *tile_stride_bytes, int *win_off_bytes);
 
 #ifdef __cplusplus
 }
