@@ -37,11 +37,19 @@ def cpu_baseline(seconds_of_signal=1500.0):
     exe = ref if os.path.exists(ref) else port
     if not os.path.exists(exe):
         return None
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                              # a container CPU quota caps what `cores` threads can deliver
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(float(q) / float(per), 2)
+    except Exception:  # noqa: BLE001
+        pass
     out = {}
     try:
         one = json.loads(subprocess.run([exe, "1", str(seconds_of_signal)], capture_output=True, text=True, timeout=300, check=True).stdout)
-        per_thread = seconds_of_signal / 4.0          # ~5 s of wall per thread; all threads run concurrently
+        # all host threads, each on its own stream, sized for ~15 s of wall at the measured aggregate rate of a short probe
+        probe = json.loads(subprocess.run([exe, str(cores), "4"], capture_output=True, text=True, timeout=300, check=True).stdout)
+        per_thread = max(4.0, min(seconds_of_signal, 15.0 * probe["msps"] * 1e6 / 2.4e6 / cores))
         allc = json.loads(subprocess.run([exe, str(cores), str(per_thread)], capture_output=True, text=True, timeout=600, check=True).stdout)
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
@@ -49,8 +57,25 @@ def cpu_baseline(seconds_of_signal=1500.0):
            "sample": "%d threads x %.0f s of 2.4 MS/s u8 IQ signal each (%.2e complex samples in total, %.1f s wall) through the 7-stage "
                      "chain in process with the CLI's block framing; 1 thread alone on %.0f s of signal: %.1f MS/s (%.1f s wall)"
                      % (cores, per_thread, allc["samples"], allc["wall_s"], seconds_of_signal, one["msps"], one["wall_s"]),
-           "single_core_value": round(one["msps"], 3)}
+           "single_core_value": round(one["msps"], 3), "cgroup_cpu_quota_cores": quota}
     return out
+
+
+def pmc_traffic(kernel_name, streams, block):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
+    produced by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  bench.py cannot
+    read PMCs itself; the value is reported only when the summary was taken on the same kernel and workload, else null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        w = d.get("workload", {})
+        if d.get("kernel", "").startswith(kernel_name) and w.get("streams_per_gpu") == streams and w.get("block_samples_per_stream") == block:
+            best = (d["traffic_bytes_per_launch"], os.path.basename(f))
+    return best
 
 
 def main():
@@ -141,13 +166,17 @@ def main():
                        "streams_per_gpu": S, "block_samples_per_stream": T, "stream_rate_sps": 2400000,
                        "realtime_streams_equivalent": round(msps / 2.4, 1), "parallelism": "streams sharded, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step_gpu,
                          "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches_timed": kl.value,
                          "frac_of_measured_copy_ceiling_6290": round(achieved_gbs / 6290.0, 4),
                          "hip_event_ms_per_step_all_kernels": round(ev_ms / args.steps, 4)},
             "audio_samples_per_step_per_stream": audio // max(args.steps, 1),
         }
+        tr = pmc_traffic(kernel_name, S, T)
+        if tr:
+            res["roofline"]["traffic"] = tr[0]
+            res["roofline"]["traffic_source"] = "profiles/" + tr[1] + " (rocprofv3 PMC passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_wfm_front(const uint8_t *__restrict__ i
 }
 
 // de-emphasis + convert_f_s16; block = 64 lanes = 64 segments of 64 audio samples of one stream
-__global__ __launch_bounds__(64) void k_wfm_back(const float *__restrict__ demod, size_t demod_pitch, int n_audio, float alpha,
+__global__ __launch_bounds__(64) void k_wfm_back(const float *__restrict__ demod_base, size_t demod_pitch, int skip, int n_audio, float alpha,
                                                  const float *__restrict__ last_in, float *__restrict__ last_out,
                                                  int16_t *__restrict__ s16, float *__restrict__ audio_f, size_t out_pitch)
 {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void k_wfm_back(const float *__restrict__ demod
     const int t0 = blockIdx.x * 4096;
     const int cnt = min(4096, n_audio - t0);
     if (cnt <= 0) return;
-    const float *row = demod + (size_t)s * demod_pitch;
+    const float *row = demod_base + (size_t)s * demod_pitch + skip;   // the matrix-core front end stores whole 4-sample tiles
     const int lead = (t0 >= WARM) ? WARM : t0;                      // samples before t0 available for warm-up
     // LDS position of sample (t0 - lead + q): q + q/64 (one pad float per 64: lane stride 65 -> conflict free)
     for (int q = threadIdx.x; q < cnt + lead; q += 64) seg[q + (q >> 6)] = row[t0 - lead + q];
@@ -216,7 +216,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     w->shift_rate = shift_rate; w->tau = tau; w->max_block = max_block_samples;
     const float dt = (float)(1.0 / audio_rate); w->alpha = dt / (tau + dt);          // libcsdr.c:1090-1091
     const size_t max_audio = max_block_samples / ((size_t)decimation * frac_rate) + 8;
-    w->demod_pitch = (max_audio + 63) & ~(size_t)63;
+    w->demod_pitch = (max_audio + 8 + 63) & ~(size_t)63;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&w->d_taps, sizeof(float) * taps_length);
@@ -228,7 +228,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
     (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     w->kernel_name = "k_wfm_front";
-    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_straddle = nullptr;
+    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_set_of = nullptr;
     {
         const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons)
         const bool want_mfma = !(force && !strcmp(force, "valu"));
@@ -239,11 +239,11 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
             w->ctab_cap = max_block_samples / 1024 + 8;
             hipError_t e2 = hipMalloc(&w->mfma.d_frags, t.frags.size());
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_consts, t.consts.size() * sizeof(float));
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_straddle, t.straddle.size() * sizeof(int));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_set_of, t.set_of.size() * sizeof(int));
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->d_ctab, w->ctab_cap * sizeof(float2));
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_frags, t.frags.data(), t.frags.size(), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_consts, t.consts.data(), t.consts.size() * sizeof(float), hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_straddle, t.straddle.data(), t.straddle.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_set_of, t.set_of.data(), t.set_of.size() * sizeof(int), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) { fail(e2, "hipMalloc/hipMemcpy(wfm mfma table)", __FILE__, __LINE__); delete w; return nullptr; }
             w->use_mfma = true; w->kernel_name = "k_wfm_mfma";
         }
@@ -262,7 +262,7 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
     for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (w->mfma.d_frags) (void)hipFree(w->mfma.d_frags);
     if (w->mfma.d_consts) (void)hipFree(w->mfma.d_consts);
-    if (w->mfma.d_straddle) (void)hipFree(w->mfma.d_straddle);
+    if (w->mfma.d_set_of) (void)hipFree(w->mfma.d_set_of);
     if (w->d_ctab) (void)hipFree(w->d_ctab);
     delete w;
 }
@@ -347,7 +347,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     }
     const long long n_audio_ll = j_hi - w->next_j + 1;
     const int n_audio = n_audio_ll > 0 ? (int)n_audio_ll : 0;
-    if ((size_t)n_audio > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
+    if ((size_t)n_audio + 8 > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
     if (n_audio > 0) {
         if ((size_t)n_audio > out_pitch) return fail_msg(-3, "wfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, n_audio);
         WfmParams p; p.D = w->D; p.L = w->L; p.F = w->F; p.T = T; p.B = w->B; p.j_first = w->next_j; p.n_audio = n_audio;
@@ -373,7 +373,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
         }
         if (w->profiling) CSDR_HIP(hipEventRecord(e1, st));
         hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, 4096), w->n_streams), dim3(64), 0, st,
-                           w->d_demod, w->demod_pitch, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
+                           w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j - 4 * (w->next_j / 4)) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
         CSDR_LAUNCH_CHECK();
         w->flip ^= 1;
     }

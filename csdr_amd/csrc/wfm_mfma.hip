@@ -27,6 +27,7 @@
 #include "common.hpp"
 #include "wfm_mfma.hpp"
 #include <math.h>
+#include <stdlib.h>
 #include <complex>
 #include <vector>
 using namespace csdr_amd;
@@ -45,10 +46,11 @@ bool wfm_mfma_supported(int D, int L, int F)
     return true;
 }
 
-// Builds the periodic weight table.  Layout:
-//   frags : [n_phases][WFM_SLOTS][3 digits][64 lanes] int8x16   (lane l: row l%16, K bytes 16*(l/16) .. +15 of the slot's K-step)
-//   consts: [n_phases][2 parts][16 rows] float                  (the +1/255 offset of u8->float through the filter)
-//   straddle: [n_phases] int                                    (-1, or the K-step that contains the chunk boundary)
+// Builds the periodic weight table.  A window that contains a shift_addition_cc chunk boundary gets TWO weight sets
+// (samples before / after the boundary, the other side zero) so that each side can be scaled by its own chunk phasor.
+//   frags : [n_sets][WFM_NK][3 digits][64 lanes] int8x16   (lane l: row l%16, K bytes 16*(l/16) .. +15 of that K-step)
+//   set_of: [n_phases][2]                                  (weight set of each side; -1 when the window has one side only)
+//   consts: [n_phases][2 sides][16 rows] float             (the +1/255 offset of u8->float through the filter)
 void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *taps, WfmMfmaTable &t)
 {
     t.D = D; t.L = L; t.F = F;
@@ -67,18 +69,19 @@ void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *ta
     if (gmax == 0) gmax = 1;
     const double qscale = 4194304.0 / gmax;                          // 2^22: three balanced base-256 digits stay inside int8
     t.scale = (float)(gmax / 4194304.0);
-    const size_t frag_bytes = (size_t)WFM_SLOTS * 3 * 64 * 16;
-    t.frags.assign((size_t)t.n_phases * frag_bytes, 0);
+    const size_t set_bytes = (size_t)WFM_FRAG_V4 * 16;
+    t.frags.clear();
     t.consts.assign((size_t)t.n_phases * 32, 0.f);
-    t.straddle.assign(t.n_phases, -1);
+    t.set_of.assign((size_t)t.n_phases * 2, -1);
     const int base_off_samples = t.win_off_bytes / 2;
+    int n_sets = 0;
     for (int ph = 0; ph < t.n_phases; ph++) {
         const long s0 = (long)4 * D * F * ph + base_off_samples;     // window base sample in the periodic frame
         const long chunk0 = s0 / 1024;
-        const long bb = (chunk0 + 1) * 1024 - s0;                    // samples from the window base to the next chunk boundary
-        const int S = (2 * bb < 64 * WFM_NK) ? (int)(2 * bb / 64) : -1;
-        t.straddle[ph] = S;
-        int8_t *fr = t.frags.data() + (size_t)ph * frag_bytes;
+        const bool two_sides = (chunk0 + 1) * 1024 - s0 < 32 * WFM_NK;   // a chunk boundary inside the 256-sample window
+        t.set_of[2 * ph] = n_sets++;
+        if (two_sides) t.set_of[2 * ph + 1] = n_sets++;
+        t.frags.resize((size_t)n_sets * set_bytes, 0);
         float *cst = t.consts.data() + (size_t)ph * 32;
         for (int r = 0; r < 16; r++) {
             const int q = r / 4, which = (r % 4) / 2, comp = r % 2;
@@ -86,26 +89,22 @@ void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *ta
             std::complex<double> csum[2] = {0, 0};
             for (int tp = 0; tp < L; tp++) {
                 const long rel = off + tp, g = s0 + rel;
-                const int part = (int)(g / 1024 - chunk0);
+                const int side = (int)(g / 1024 - chunk0);
                 const std::complex<double> G = a * (double)taps[tp] * Dk[g % 1024];
-                csum[part] += (double)taps[tp] * Dk[g % 1024];
+                csum[side] += (double)taps[tp] * Dk[g % 1024];
+                int8_t *fr = t.frags.data() + (size_t)t.set_of[2 * ph + side] * set_bytes;
                 for (int c = 0; c < 2; c++) {
                     // real form of (Gr + j Gi)(I + j Q): Re row takes (Gr, -Gi) on (I, Q); Im row takes (Gi, Gr)
                     const double val = comp == 0 ? (c == 0 ? G.real() : -G.imag()) : (c == 0 ? G.imag() : G.real());
-                    const long col = 2 * rel + c;
-                    const int ks = (int)(col / 64), b = (int)(col % 64);
-                    int slot;
-                    if (S < 0) slot = ks;
-                    else if (ks < S) slot = ks;
-                    else if (ks == S) slot = S + part;
-                    else slot = ks + 1;
+                    const long colb = 2 * rel + c;
+                    const int ks = (int)(colb / 64), b = (int)(colb % 64);
                     long qv = lrint(val * qscale);
                     const int w2 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w2) / 256;
                     const int w1 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w1) / 256;
                     const int w0 = (int)qv;
                     const int lane = 16 * (b / 16) + r, byte = b % 16;
                     const int dig[3] = {w0, w1, w2};
-                    for (int l = 0; l < 3; l++) fr[((size_t)(slot * 3 + l) * 64 + lane) * 16 + byte] = (int8_t)dig[l];
+                    for (int l = 0; l < 3; l++) fr[((size_t)(ks * 3 + l) * 64 + lane) * 16 + byte] = (int8_t)dig[l];
                 }
             }
             for (int p = 0; p < 2; p++) {
@@ -127,137 +126,161 @@ struct MfmaParams {
     long long B;                      // global sample index of the block start (multiple of 1024)
     long long j_first; int n_audio;   // audio samples produced by this call: j_first .. j_first+n_audio-1
     long long tile_first; int n_tiles, tiles_per_wave;
+    long long tile_out0;              // tile whose 4 audio samples land at demod[stream][0..3]
     int tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
 };
-
-template <int S>
-__device__ __forceinline__ void tile_mfma(const v4i (&A)[WFM_SLOTS * 3], const v4i (&Bf)[WFM_NK], v4i (&acc0)[3], v4i (&acc1)[3])
-{
-#pragma unroll
-    for (int ks = 0; ks < WFM_NK; ks++) {
-        if (S < 0 || ks < S) {
-#pragma unroll
-            for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc0[l], 0, 0, 0);
-        } else if (ks == S) {
-#pragma unroll
-            for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc0[l], 0, 0, 0);
-#pragma unroll
-            for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[(ks + 1) * 3 + l], Bf[ks], acc1[l], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[(ks + 1) * 3 + l], Bf[ks], acc1[l], 0, 0, 0);
-        }
-    }
-}
 
 __device__ __forceinline__ float combine_digits(int a0, int a1, int a2)
 {   // exact integers (<= 22 bits each) recombined in float: value = a0*65536 + a1*256 + a2
     return fmaf((float)a0, 65536.0f, fmaf((float)a1, 256.0f, (float)a2));
 }
 
-// One wave = one block of 64 streams (4 groups of 16) x tiles_per_wave consecutive tiles of 4 audio samples.
+// B operand of one (tile, stream group): 8 x 16 raw bytes per lane straight from the input rows.
+// EDGE = false: the window lies inside this block (no checks).  EDGE = true: it reaches into the history kept from
+// the previous block and/or beyond the ragged end of the last block (only the first/last few tiles of a call).
+template <bool EDGE>
+__device__ __forceinline__ void load_B(v4i (&Bf)[WFM_NK], const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ hist,
+                                       int stream, long long wbr, long long two_T, int q)
+{
+    const uint8_t *row = in + (size_t)stream * in_pitch;
+    if (!EDGE) {
+        const uint8_t *src = row + wbr + 16 * q;
+#pragma unroll
+        for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks);
+    } else {
+        const uint8_t *hrow = hist + (size_t)stream * (2 * WFM_HIST);
+#pragma unroll 1
+        for (int ks = 0; ks < WFM_NK; ks++) {
+            const long long off = wbr + 64 * ks + 16 * q;
+            v4i v = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+            if (off < 0) { if (off >= -2 * WFM_HIST) v = *reinterpret_cast<const v4i *>(hrow + off + 2 * WFM_HIST); }
+            else if (off + 16 <= two_T) v = *reinterpret_cast<const v4i *>(row + off);
+            else { // ragged end of the last block: byte-wise
+                uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+                for (int k = 0; k < 16; k++) if (off + k < two_T) { const uint32_t by = row[off + k]; w[k / 4] = (w[k / 4] & ~(0xffu << (8 * (k & 3)))) | (by << (8 * (k & 3))); }
+                v = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+            }
+            Bf[ks] = v;
+        }
+    }
+}
+
+// One wave = 64 streams (4 groups of 16) x ONE TILE PHASE: it owns the tiles ti = ph, ph + n_phases, ph + 2 n_phases, ...
+// of its launch range.  All those tiles use the same weights, so the 24 (48 when the phase's window contains a chunk
+// boundary) int8x16 weight fragments are loaded ONCE per wave and stay in registers for the whole launch.  (With
+// consecutive tiles per wave the weights had to be re-read for every tile: 5.9 GB per step against 4.9 GB of input, and the
+// kernel sat at 1.65 ms = the sum of both streams at the ~7 TB/s the memory side delivers; see profiles/r1_notes.md.)
+//   * input  : ring of 4 B-operand buffers (one per stream group); a group's buffer is refilled with the window of the
+//              wave's NEXT tile as soon as its MFMAs have been issued (4 x 8 KiB per wave in flight, one wave per SIMD);
+//   * grid   : x = stream block, y = tile phase, z = segment of the tile range.  Blocks are placed on XCD (linear id % 8)
+//              and gridDim.x is a multiple of 8 for >= 512 streams, so every phase of one stream block runs on the same XCD:
+//              the 28 % window overlap between neighbouring tiles (different waves) is served by that XCD's L2;
+//   * output : the quadrature demodulator is lane local; 4 audio samples per stream leave as one aligned 16-byte store.
+template <bool EDGE>
 __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ hist,
-                                                 const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ straddle,
+                                                 const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ set_of,
                                                  const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, MfmaParams p)
 {
-    const int lane = threadIdx.x;
-    const int col = lane & 15, q = lane >> 4;
-    const int sb = blockIdx.x;
-    const long long t_begin = p.tile_first + (long long)blockIdx.y * p.tiles_per_wave;
-    long long t_end = t_begin + p.tiles_per_wave;
-    const long long t_last = p.tile_first + p.n_tiles;
-    if (t_end > t_last) t_end = t_last;
-    const long long two_T = 2LL * p.T;
-    for (long long ti = t_begin; ti < t_end; ti++) {
-        const int ph = (int)(ti % p.n_phases);
-        const int S = straddle[ph];
-        // weights of this tile phase -> registers (reused by the 4 stream groups)
-        v4i A[WFM_SLOTS * 3];
-        const v4i *fa = frags + (size_t)ph * (WFM_SLOTS * 3 * 64) + lane;
+    const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
+    const int ph = blockIdx.y;
+    // tiles of this phase inside [tile_first, tile_first + n_tiles): ti = t0 + m * n_phases, m in this segment
+    const long long t_lim = p.tile_first + p.n_tiles;
+    long long t0 = p.tile_first + (((long long)ph - p.tile_first) % p.n_phases + p.n_phases) % p.n_phases;
+    if (t0 >= t_lim) return;
+    const long long m_total = (t_lim - 1 - t0) / p.n_phases + 1;
+    const long long m_per = (m_total + gridDim.z - 1) / gridDim.z;
+    const long long m_begin = (long long)blockIdx.z * m_per;
+    long long m_end = m_begin + m_per; if (m_end > m_total) m_end = m_total;
+    if (m_begin >= m_end) return;
+    const long long step = (long long)p.n_phases * p.tile_stride_bytes;               // bytes between this wave's consecutive windows
+    const long long two_T = 2LL * p.T, B2 = 2 * p.B;
+    const int stream_base = blockIdx.x * 64 + col, last_stream = p.n_streams - 1;
+    // ---- weights: once per wave
+    const int set0 = set_of[2 * ph], set1 = set_of[2 * ph + 1];
+    const bool two = set1 >= 0;
+    v4i A0[WFM_NK * 3], A1[WFM_NK * 3];
+    {
+        const v4i *fa = frags + (size_t)set0 * WFM_FRAG_V4 + lane;
 #pragma unroll
-        for (int s = 0; s < WFM_SLOTS * 3; s++) A[s] = fa[s * 64];
-        const float4 k0 = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 4 * q);
-        const float4 k1 = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 16 + 4 * q);
-        const long long wb = ti * p.tile_stride_bytes + p.win_off_bytes;          // global byte index of the window base
-        const long long wbr = wb - 2 * p.B;                                        // relative to this block's first byte
-        const long long chunk_rel = (wb / 2) / 1024 - p.B / 1024;                  // -1 for windows that start in the history
+        for (int s = 0; s < WFM_NK * 3; s++) A0[s] = fa[s * 64];
+        const v4i *fb = frags + (size_t)(two ? set1 : set0) * WFM_FRAG_V4 + lane;
+#pragma unroll
+        for (int s = 0; s < WFM_NK * 3; s++) A1[s] = fb[s * 64];
+    }
+    const float4 k0v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 4 * q);
+    const float4 k1v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 16 + 4 * q);
+    const float k0[4] = {k0v.x, k0v.y, k0v.z, k0v.w}, k1[4] = {k1v.x, k1v.y, k1v.z, k1v.w};
+    // ---- per-group row pointers, computed once (the hot loop only adds the running window offset)
+    const uint8_t *rowp[4]; float *dstp[4]; int sidx[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        sidx[g] = stream_base + 16 * g;
+        const int sc = min(sidx[g], last_stream);
+        rowp[g] = in + (size_t)sc * in_pitch + 16 * q;
+        dstp[g] = demod + (size_t)sc * demod_pitch;
+    }
+    // ---- input ring
+    long long ti = t0 + m_begin * p.n_phases;
+    long long wbr = ti * p.tile_stride_bytes + p.win_off_bytes - B2;                   // window base relative to this block's first byte
+    v4i Bq[4][WFM_NK];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (!EDGE) {
+#pragma unroll
+            for (int ks = 0; ks < WFM_NK; ks++) Bq[g][ks] = *reinterpret_cast<const v4i *>(rowp[g] + wbr + 64 * ks);
+        } else load_B<true>(Bq[g], in, in_pitch, hist, min(sidx[g], last_stream), wbr, two_T, q);
+    }
+    const float K = 0.340447550238101026565118445432744920253753662109375f;
+    for (long long m = m_begin; m < m_end; m++, ti += p.n_phases, wbr += step) {
+        const bool refill = m + 1 < m_end;
+        const long long chunk_rel = ((wbr + B2) >> 11) - (B2 >> 11);                  // chunk of the window base relative to the block; -1 = history
         const float2 C0 = ctab[chunk_rel + 1], C1 = ctab[chunk_rel + 2];
-        const bool interior = (wbr >= 0) && (wbr + 64 * WFM_NK <= two_T);
-        const long long j0 = 4 * ti;
-#pragma unroll 1
+        const long long out_off = 4 * (ti - p.tile_out0);
+#pragma unroll
         for (int g = 0; g < 4; g++) {
-            int stream = sb * 64 + g * 16 + col;
-            const bool stream_ok = stream < p.n_streams;
-            if (stream >= p.n_streams) stream = p.n_streams - 1;
-            const uint8_t *row = in + (size_t)stream * in_pitch;
-            v4i Bf[WFM_NK];
-            if (interior) {
-                const uint8_t *src = row + wbr + 16 * q;
 #pragma unroll
-                for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks);
-            } else {
-                const uint8_t *hrow = hist + (size_t)stream * (2 * WFM_HIST);
-#pragma unroll
-                for (int ks = 0; ks < WFM_NK; ks++) {
-                    const long long off = wbr + 64 * ks + 16 * q;
-                    v4i v = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-                    if (off < 0) { if (off >= -2 * WFM_HIST) v = *reinterpret_cast<const v4i *>(hrow + off + 2 * WFM_HIST); }
-                    else if (off + 16 <= two_T) v = *reinterpret_cast<const v4i *>(row + off);
-                    else { // ragged end of the last block: byte-wise
-                        uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-                        for (int k = 0; k < 16; k++) if (off + k < two_T) { const uint32_t by = row[off + k]; w[k / 4] = (w[k / 4] & ~(0xffu << (8 * (k & 3)))) | (by << (8 * (k & 3))); }
-                        v = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-                    }
-                    Bf[ks] = v;
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] ^= (int)0x80808080;              // u8 - 128 as int8
+            for (int ks = 0; ks < WFM_NK; ks++) Bq[g][ks] ^= (int)0x80808080;          // u8 - 128 as int8, in place
             v4i acc0[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, acc1[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-            switch (S) {
-                case 0: tile_mfma<0>(A, Bf, acc0, acc1); break;
-                case 1: tile_mfma<1>(A, Bf, acc0, acc1); break;
-                case 2: tile_mfma<2>(A, Bf, acc0, acc1); break;
-                case 3: tile_mfma<3>(A, Bf, acc0, acc1); break;
-                case 4: tile_mfma<4>(A, Bf, acc0, acc1); break;
-                case 5: tile_mfma<5>(A, Bf, acc0, acc1); break;
-                case 6: tile_mfma<6>(A, Bf, acc0, acc1); break;
-                case 7: tile_mfma<7>(A, Bf, acc0, acc1); break;
-                default: tile_mfma<-1>(A, Bf, acc0, acc1); break;
-            }
-            // lane (col, q): rows 4q..4q+3 = Re/Im of y[Fj+9], Re/Im of y[Fj+10] for audio j = j0+q of stream `col`
-            float u0[4], u1[4];
-            const float kk0[4] = {k0.x, k0.y, k0.z, k0.w}, kk1[4] = {k1.x, k1.y, k1.z, k1.w};
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                u0[r] = fmaf(combine_digits(acc0[0][r], acc0[1][r], acc0[2][r]), p.scale, kk0[r]);
-                u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, kk1[r]);
+            for (int ks = 0; ks < WFM_NK; ks++)
+#pragma unroll
+                for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks * 3 + l], Bq[g][ks], acc0[l], 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int ks = 0; ks < WFM_NK; ks++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[ks * 3 + l], Bq[g][ks], acc1[l], 0, 0, 0);
             }
-            // y = C_m * u0 + C_{m+1} * u1   (complex)
-            const float pI = C0.x * u0[0] - C0.y * u0[1] + (C1.x * u1[0] - C1.y * u1[1]);
-            const float pQ = C0.x * u0[1] + C0.y * u0[0] + (C1.x * u1[1] + C1.y * u1[0]);
-            const float cI = C0.x * u0[2] - C0.y * u0[3] + (C1.x * u1[2] - C1.y * u1[3]);
-            const float cQ = C0.x * u0[3] + C0.y * u0[2] + (C1.x * u1[3] + C1.y * u1[2]);
+            if (refill) {
+                if (!EDGE) {
+#pragma unroll
+                    for (int ks = 0; ks < WFM_NK; ks++) Bq[g][ks] = *reinterpret_cast<const v4i *>(rowp[g] + (wbr + step) + 64 * ks);
+                } else load_B<true>(Bq[g], in, in_pitch, hist, min(sidx[g], last_stream), wbr + step, two_T, q);
+            }
+            // lane (col, q): rows 4q..4q+3 = Re/Im of y[Fj+9], Re/Im of y[Fj+10] for audio j = 4*ti+q of stream col;  y = C_m u0 + C_{m+1} u1
+            float pI, pQ, cI, cQ;
+            {
+                float u0[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) u0[r] = fmaf(combine_digits(acc0[0][r], acc0[1][r], acc0[2][r]), p.scale, k0[r]);
+                pI = C0.x * u0[0] - C0.y * u0[1]; pQ = C0.x * u0[1] + C0.y * u0[0];
+                cI = C0.x * u0[2] - C0.y * u0[3]; cQ = C0.x * u0[3] + C0.y * u0[2];
+            }
+            if (two) {
+                float u1[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, k1[r]);
+                pI += C1.x * u1[0] - C1.y * u1[1]; pQ += C1.x * u1[1] + C1.y * u1[0];
+                cI += C1.x * u1[2] - C1.y * u1[3]; cQ += C1.x * u1[3] + C1.y * u1[2];
+            }
             // fmdemod_quadri_cf (libcsdr.c:1040-1071) on (previous = y[Fj+9], current = y[Fj+10])
             const float dq = cQ - pQ, di = cI - pI;
             const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
-            const float K = 0.340447550238101026565118445432744920253753662109375f;
             const float a = (den != 0.f) ? (K * num) / den : 0.f;
-            // gather the 4 audio samples of a stream into lane `col` and store them
             const float a1 = __shfl(a, col + 16, 64), a2 = __shfl(a, col + 32, 64), a3 = __shfl(a, col + 48, 64);
-            if (q == 0 && stream_ok) {
-                const long long jr = j0 - p.j_first;                       // position of the tile's first audio sample in this call's output
-                float *dst = demod + (size_t)stream * demod_pitch;
-                const float vals[4] = {a, a1, a2, a3};
-                if (jr >= 0 && jr + 4 <= p.n_audio) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) dst[jr + k] = vals[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) if (jr + k >= 0 && jr + k < p.n_audio) dst[jr + k] = vals[k];
-                }
-            }
+            if (q == 0 && sidx[g] < p.n_streams)
+                *reinterpret_cast<float4 *>(dstp[g] + out_off) = make_float4(a, a1, a2, a3);
         }
     }
 }
@@ -271,22 +294,34 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
 {
     MfmaParams p;
     p.n_streams = n_streams; p.T = T; p.B = B; p.j_first = j_first; p.n_audio = n_audio;
-    p.tile_first = j_first / 4;
-    const long long tile_last = (j_first + n_audio - 1) / 4;
-    p.n_tiles = (int)(tile_last - p.tile_first + 1);
     p.tile_stride_bytes = dev.tile_stride_bytes; p.win_off_bytes = dev.win_off_bytes; p.n_phases = dev.n_phases; p.scale = dev.scale;
+    const long long tile_first = j_first / 4, tile_last = (j_first + n_audio - 1) / 4;
+    p.tile_out0 = tile_first;                                        // the scratch rows hold whole tiles; k_wfm_back skips j_first - 4*tile_first samples
+    // interior tiles: window entirely inside [0, 2T) of this block (no history, no ragged end)
+    long long t_a = tile_first, t_b = tile_last;
+    while (t_a <= tile_last && t_a * p.tile_stride_bytes + p.win_off_bytes - 2 * B < 0) t_a++;
+    while (t_b >= t_a && t_b * p.tile_stride_bytes + p.win_off_bytes - 2 * B + 64 * WFM_NK > 2LL * T) t_b--;
     const int n_sb = (n_streams + 63) / 64;
-    // aim at >= 2048 waves (2 per SIMD) while keeping >= 8 tiles per wave
-    int chunks = (2048 + n_sb - 1) / n_sb;
-    if (chunks > p.n_tiles / 8) chunks = p.n_tiles / 8;
-    if (chunks < 1) chunks = 1;
-    if (chunks > 65535) chunks = 65535;
-    p.tiles_per_wave = (p.n_tiles + chunks - 1) / chunks;
-    chunks = (p.n_tiles + p.tiles_per_wave - 1) / p.tiles_per_wave;
-    hipLaunchKernelGGL(k_wfm_mfma, dim3(n_sb, chunks), dim3(64), 0, st, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_straddle,
-                       ctab, demod, demod_pitch, p);
-    CSDR_LAUNCH_CHECK();
-    return 0;
+    static int target = 0;
+    if (!target) { const char *e = getenv("CSDR_AMD_WFM_WAVES"); target = e ? atoi(e) : 2048; if (target < 1) target = 2048; }
+    auto launch = [&](long long first, long long last, bool edge) -> int {
+        if (last < first) return 0;
+        p.tile_first = first; p.n_tiles = (int)(last - first + 1); p.tiles_per_wave = 0;
+        // waves = stream blocks x phases x segments: aim at `target` waves, keep >= 4 tiles per wave
+        const long long per_phase = (p.n_tiles + p.n_phases - 1) / p.n_phases;
+        int z = (int)((target + (long long)n_sb * p.n_phases - 1) / ((long long)n_sb * p.n_phases));
+        if (z > per_phase / 4) z = (int)(per_phase / 4);
+        if (z < 1) z = 1;
+        dim3 grid(n_sb, p.n_phases, z);
+        if (edge) hipLaunchKernelGGL((k_wfm_mfma<true>), grid, dim3(64), 0, st, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
+        else      hipLaunchKernelGGL((k_wfm_mfma<false>), grid, dim3(64), 0, st, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
+        CSDR_LAUNCH_CHECK();
+        return 0;
+    };
+    int rc = launch(t_a, t_b, false); if (rc) return rc;                 // the bulk: no bounds logic at all
+    rc = launch(tile_first, t_a - 1 < tile_last ? t_a - 1 : tile_last, true); if (rc) return rc;      // leading tiles (history)
+    if (t_b + 1 > t_a - 1) rc = launch(t_b + 1 > t_a ? t_b + 1 : t_a, tile_last, true);               // trailing tiles (ragged end / partial tile)
+    return rc;
 }
 
 } // namespace csdr_amd
@@ -306,29 +341,22 @@ extern "C" int csdr_amd_debug_wfm_mfma_tile(int D, int L, int F, float shift_rat
     if (tile_stride_bytes) *tile_stride_bytes = t.tile_stride_bytes;
     if (win_off_bytes) *win_off_bytes = t.win_off_bytes;
     if (phase < 0 || phase >= t.n_phases) return -2;
-    const int S = t.straddle[phase];
-    if (straddle) *straddle = S;
-    const int8_t *fr = t.frags.data() + (size_t)phase * WFM_SLOTS * 3 * 64 * 16;
+    if (straddle) *straddle = t.set_of[2 * phase + 1] >= 0;
     const float *cst = t.consts.data() + (size_t)phase * 32;
-    for (int r = 0; r < 16; r++) {
-        long acc[2][3] = {{0, 0, 0}, {0, 0, 0}};
-        for (int ks = 0; ks < WFM_NK; ks++) {
-            for (int pass = 0; pass < 2; pass++) {
-                int slot, part;
-                if (S < 0 || ks < S) { if (pass) continue; slot = ks; part = 0; }
-                else if (ks == S) { slot = ks + pass; part = pass; }
-                else { if (pass) continue; slot = ks + 1; part = 1; }
-                for (int kg = 0; kg < 4; kg++) for (int b = 0; b < 16; b++) {
+    for (int side = 0; side < 2; side++) {
+        const int set = t.set_of[2 * phase + side];
+        for (int r = 0; r < 16; r++) {
+            long acc[3] = {0, 0, 0};
+            if (set >= 0) {
+                const int8_t *fr = t.frags.data() + (size_t)set * WFM_FRAG_V4 * 16;
+                for (int ks = 0; ks < WFM_NK; ks++) for (int kg = 0; kg < 4; kg++) for (int b = 0; b < 16; b++) {
                     const int v = (int)(int8_t)(window[64 * ks + 16 * kg + b] ^ 0x80);
-                    for (int l = 0; l < 3; l++) acc[part][l] += (long)fr[((size_t)(slot * 3 + l) * 64 + (16 * kg + r)) * 16 + b] * v;
+                    for (int l = 0; l < 3; l++) acc[l] += (long)fr[((size_t)(ks * 3 + l) * 64 + (16 * kg + r)) * 16 + b] * v;
                 }
-            }
+                out16[16 * side + r] = fmaf(fmaf((float)acc[0], 65536.0f, fmaf((float)acc[1], 256.0f, (float)acc[2])), t.scale, cst[side * 16 + r]);
+            } else out16[16 * side + r] = 0.f;
         }
-        float u[2];
-        for (int p = 0; p < 2; p++) u[p] = fmaf(fmaf((float)acc[p][0], 65536.0f, fmaf((float)acc[p][1], 256.0f, (float)acc[p][2])), t.scale, cst[p * 16 + r]);
-        out16[r] = u[0]; out16[16 + r] = u[1];
     }
-    // complex recombination exactly as the kernel's epilogue
     float res[16];
     for (int q = 0; q < 4; q++) for (int w = 0; w < 2; w++) {
         const float *u0 = out16 + 4 * q + 2 * w, *u1 = out16 + 16 + 4 * q + 2 * w;

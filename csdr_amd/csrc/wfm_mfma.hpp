@@ -7,20 +7,20 @@ namespace csdr_amd {
 
 constexpr int WFM_HIST = 256;      // complex samples of input history kept per stream between blocks
 constexpr int WFM_NK = 8;          // 64-byte K-steps per tile window (4 audio samples)
-constexpr int WFM_SLOTS = WFM_NK + 1;
+constexpr int WFM_FRAG_V4 = WFM_NK * 3 * 64;   // int8x16 vectors per weight set: [K-step][digit][lane]
 
 struct WfmMfmaTable {              // host side
     int D, L, F, tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
-    std::vector<int8_t> frags;     // [n_phases][WFM_SLOTS][3][64][16]
+    std::vector<int8_t> frags;     // [n_sets][WFM_NK][3][64][16]; set index from set_of
     std::vector<float> consts;     // [n_phases][2][16]
-    std::vector<int> straddle;     // [n_phases]
+    std::vector<int> set_of;       // [n_phases][2]: weight set of (phase, side of the chunk boundary); -1 = no second side
 };
 
 struct WfmMfmaDevice {             // device copies
     int tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
-    void *d_frags; float *d_consts; int *d_straddle;
+    void *d_frags; float *d_consts; int *d_set_of;
 };
 
 bool wfm_mfma_supported(int D, int L, int F);

@@ -99,3 +99,17 @@ int main(void){
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
         out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
     assert [int(v) for v in out] == [8, 16, 36, 24, 12, 12, 48, 72, 76, 40, 64, 64, 20, 32]
+
+
+def test_reference_client_links_against_our_library(libpath, tmp_path):
+    """a client compiled against the REFERENCE headers links against libcsdr_amd.so."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "libcsdr.h")):
+        pytest.skip("reference headers not present on this host")
+    exe = str(tmp_path / "client")
+    r = subprocess.run(["gcc", "-std=gnu99", "-DUSE_FFTW", "-DLIBCSDR_GPL", "-I", ref, "-I", os.path.join(ROOT, "oracle"),
+                        os.path.join(ROOT, "tests", "data", "dropin_client.c"), "-L", os.path.dirname(libpath), "-l:libcsdr_amd.so",
+                        "-Wl,-rpath," + os.path.dirname(libpath), "-o", exe, "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    import shutil
+    shutil.copy(exe, os.path.join(ROOT, "tests", "data", "dropin_client.bin"))      # travels to the GPU box for the -m gpu run

@@ -1,0 +1,83 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU layer: stream/channel sharding, the max-over-ranks timing reduction of
+the bench contract, and the fastddc spectrum broadcast + channel sharding checked against the unsharded oracle."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from csdr_amd import dist as cd
+    import oracle
+    r, lr, w = cd.init("gloo")
+    assert (r, w) == (rank, world)
+    # 1. timing reduction of the bench contract
+    mx = cd.max_over_ranks(1.0 + rank)
+    sm = cd.sum_over_ranks(10.0)
+    # 2. fastddc: forward FFT on rank 0, broadcast, channels sharded
+    port_o = oracle.port()
+    D, tbw = 16, 0.05
+    rates = [-0.1, 0.2, 0.33, -0.4, 0.05]
+    ddc, _ = port_o.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(4)
+    n = ddc.input_size * 6
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+
+    def fwd(xx):
+        return torch.from_numpy(port_o.fastddc_fwd_cc(xx, ddc).view(np.float32).reshape(-1, ddc.fft_size, 2).copy())
+
+    def inv(spec, rr):
+        s = spec.numpy().reshape(-1, ddc.fft_size * 2).view(np.complex64)
+        outs = []
+        for rate in rr:
+            d, _ = port_o.fastddc_init(tbw, D, rate)
+            outs.append(port_o.fastddc_inv_cc(s, d, port_o.fastddc_taps_fft(d, rate, D)))
+        return outs
+
+    first, outs = cd.fastddc_sharded(x if rank == 0 else None, n, ddc.fft_size, ddc.input_size, rates, fwd, inv, rank, world)
+    cd.barrier()
+    q.put((rank, mx, sm, first, [o.tolist() for o in outs]))
+
+
+def test_gloo_world2_sharding_broadcast_and_timing():
+    import oracle
+    from csdr_amd import dist as cd
+    assert [cd.shard(1024, r, 8) for r in range(8)] == [(128 * r, 128) for r in range(8)]
+    assert [cd.shard(5, r, 2) for r in range(2)] == [(0, 3), (3, 2)]
+    assert sum(cd.shard(4097, r, 8)[1] for r in range(8)) == 4097
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(abs(r[1] - 2.0) < 1e-12 for r in res)             # max over ranks of (1, 2)
+    assert all(abs(r[2] - 20.0) < 1e-12 for r in res)
+    # unsharded reference
+    po = oracle.port()
+    D, tbw = 16, 0.05
+    rates = [-0.1, 0.2, 0.33, -0.4, 0.05]
+    ddc, _ = po.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(4)
+    n = ddc.input_size * 6
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    spec = po.fastddc_fwd_cc(x, ddc)
+    got = {}
+    for rank, _, _, first, outs in res:
+        for k, o in enumerate(outs):
+            got[first + k] = np.array(o, dtype=np.complex64)
+    assert sorted(got) == list(range(len(rates)))
+    for c, rate in enumerate(rates):
+        d, _ = po.fastddc_init(tbw, D, rate)
+        ref = po.fastddc_inv_cc(spec, d, po.fastddc_taps_fft(d, rate, D))
+        assert np.array_equal(got[c], ref)

@@ -297,3 +297,23 @@ def test_wfm_chain_full_size_properties(gpu, port):
     ps, pf = port.wfm_chain(base, -0.085, 10, taps)
     m = min(pf.size, af.shape[1])
     assert relrms(af[0, :m], pf[:m]) < TOL
+
+
+def test_dropin_client_binary(gpu):
+    """The client of tests/data/dropin_client.c (compiled against the reference's headers on the build host, linked against
+    libcsdr_amd.so) runs on the GPU and reproduces the reference's results."""
+    import os, re, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "data", "dropin_client.bin")
+    if not os.path.exists(exe):
+        pytest.skip("dropin_client.bin not built (needs the reference headers on the build host)")
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "csdr_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"ntaps=(\d+) outputs=(\d+) phase=(\S+) demod_energy=(\S+) last=\((\S+),(\S+)\) fft=(\d+) err=(\d+)", out.stdout)
+    assert m, out.stdout
+    assert int(m.group(1)) == 79 and int(m.group(2)) == 1631 and int(m.group(7)) == 65536 and int(m.group(8)) == 0
+    golden = open(os.path.join(root, "tests", "golden", "dropin_client_ref.txt")).read()
+    g = re.search(r"phase=(\S+) demod_energy=(\S+)", golden)
+    assert abs(float(m.group(3)) - float(g.group(1))) < 2e-5
+    assert abs(float(m.group(4)) / float(g.group(2)) - 1) < 1e-4
