@@ -102,9 +102,13 @@ __global__ __launch_bounds__(256) void k_swap_halves(cf32 *__restrict__ a, int n
 struct ChanGeom { int offsetbin; float sindelta, cosdelta, rate2; };
 
 // alias fold: inv_in[c][b][(m + inv/2) % inv] = (1/pre) * sum_q Xs[i0 + q*inv] * H[c][i0 + q*inv],  i0 = (m + offsetbin - inv/2) mod inv
-// (fastddc.c:123-150; Xs = fft_swap_sides(X), the final index shift is the second fft_swap_sides)
+// (fastddc.c:123-150; Xs = fft_swap_sides(X), the final index shift is the second fft_swap_sides).
+// This is the channelizer's traffic: H is fft_size complexf PER CHANNEL (512 KiB at 65536; 128 MiB for 256 channels).  The reference
+// streams it once per block; here one lane owns output bin m of one channel for BT blocks at once, so each taps_fft value is
+// loaded once per call and reused from a register for all blocks of the call (lanes = consecutive m: coalesced for H and X).
+template <int BT>
 __global__ __launch_bounds__(256) void k_ddc_fold(const cf32 *__restrict__ spectra, const cf32 *__restrict__ H, cf32 *__restrict__ inv_in,
-                                                  const ChanGeom *__restrict__ geom, int fft, int inv, int pre, int n_blocks, int b_chunk)
+                                                  const ChanGeom *__restrict__ geom, int fft, int inv, int pre, int n_blocks)
 {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= inv) return;
@@ -114,18 +118,29 @@ __global__ __launch_bounds__(256) void k_ddc_fold(const cf32 *__restrict__ spect
     const cf32 *h = H + (size_t)c * fft;
     const int dst = (m + inv / 2) % inv;
     const float scale = 1.0f / (float)pre;
-    const int b0 = blockIdx.y * b_chunk, b1 = min(n_blocks, b0 + b_chunk);
-    for (int b = b0; b < b1; b++) {
-        const cf32 *x = spectra + (size_t)b * fft;
-        float ai = 0.f, aq = 0.f;
-        for (int q = 0; q < pre; q++) {
-            const int i = i0 + q * inv;
-            const cf32 xv = x[(i + fft / 2) % fft], hv = h[i];
-            ai += xv.i * hv.i - xv.q * hv.q;
-            aq += xv.i * hv.q + xv.q * hv.i;
+    const int b0 = blockIdx.y * BT;
+    const int nb = min(BT, n_blocks - b0);
+    float ai[BT], aq[BT];
+#pragma unroll
+    for (int k = 0; k < BT; k++) { ai[k] = 0.f; aq[k] = 0.f; }
+    const int half = fft / 2;
+    for (int q = 0; q < pre; q++) {
+        const int i = i0 + q * inv;
+        const cf32 hv = h[i];
+        const int xi = (i + half) & (fft - 1);                      // fft_size is a power of two (fastddc.c:50)
+        const cf32 *x = spectra + (size_t)b0 * fft + xi;
+#pragma unroll
+        for (int k = 0; k < BT; k++) {
+            if (k < nb) {
+                const cf32 xv = x[(size_t)k * fft];
+                ai[k] += xv.i * hv.i - xv.q * hv.q;
+                aq[k] += xv.i * hv.q + xv.q * hv.i;
+            }
         }
-        inv_in[((size_t)c * n_blocks + b) * inv + dst] = cf32{ai * scale, aq * scale};
     }
+#pragma unroll
+    for (int k = 0; k < BT; k++)
+        if (k < nb) inv_in[((size_t)c * n_blocks + b0 + k) * inv + dst] = cf32{ai[k] * scale, aq[k] * scale};
 }
 
 struct DdcChanState { int remain; float phase; };
@@ -469,9 +484,11 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
         CSDR_FFT(hipfftSetStream(h, st));
         f->plans[batch] = h;
     }
-    const int b_chunk = 4;
-    hipLaunchKernelGGL(k_ddc_fold, dim3(cdiv(inv, 256), cdiv(n_blocks, b_chunk), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom,
-                       fft, inv, pre, n_blocks, b_chunk); CSDR_LAUNCH_CHECK();
+    if (n_blocks >= 16)
+        hipLaunchKernelGGL((k_ddc_fold<16>), dim3(cdiv(inv, 256), cdiv(n_blocks, 16), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks);
+    else
+        hipLaunchKernelGGL((k_ddc_fold<4>), dim3(cdiv(inv, 256), cdiv(n_blocks, 4), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks);
+    CSDR_LAUNCH_CHECK();
     CSDR_FFT(hipfftExecC2C(f->plans[batch], (hipfftComplex *)f->d_inv_in, (hipfftComplex *)f->d_td, HIPFFT_BACKWARD));
     hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(f->n_channels, 64)), dim3(64), 0, st, f->d_state, f->d_geom, f->n_channels, n_blocks, g.post_input_size, g.post_decimation,
                        f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); CSDR_LAUNCH_CHECK();
@@ -501,7 +518,7 @@ extern "C" int csdr_amd_fastddc_inv_block(csdr_amd_ctx *c, const csdr_complexf *
     DdcChanState s0; s0.remain = hs.remain; s0.phase = hs.phase;
     CSDR_HIP(hipMemcpyAsync(d_g, &g, sizeof(g), hipMemcpyHostToDevice, st));
     CSDR_HIP(hipMemcpyAsync(d_s, &s0, sizeof(s0), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_ddc_fold, dim3(cdiv(inv, 256), 1, 1), dim3(256), 0, st, d_spectrum, d_taps_fft, d_inv_in, d_g, fft, inv, ddc->pre_decimation, 1, 1); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_ddc_fold<4>), dim3(cdiv(inv, 256), 1, 1), dim3(256), 0, st, d_spectrum, d_taps_fft, d_inv_in, d_g, fft, inv, ddc->pre_decimation, 1); CSDR_LAUNCH_CHECK();
     int rc = csdr_amd_fft_c2c(c, d_inv_in, d_td, inv, 0); if (rc) return rc;
     hipLaunchKernelGGL(k_ddc_chain, dim3(1), dim3(64), 0, st, d_s, d_g, 1, 1, ddc->post_input_size, ddc->post_decimation, d_rem, d_ph, d_off, d_cnt); CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ddc_post, dim3(1), dim3(64), 0, st, d_td, d_out, (size_t)0, d_g, 1, 1, inv, ddc->scrap, ddc->post_input_size, ddc->post_decimation, d_rem, d_ph, d_off); CSDR_LAUNCH_CHECK();

@@ -366,6 +366,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
         if (w->use_mfma) {
             rc = wfm_mfma_launch(st, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio);
             if (rc) return rc;
+            w->kernel_name = wfm_mfma_last_kernel();
         } else {
             hipLaunchKernelGGL(k_wfm_front, dim3(w->n_streams, cdiv(n_audio, TILE_A)), dim3(256), lds, st,
                                in, in_pitch, w->d_hist, w->d_rot, w->d_taps, w->d_demod, w->demod_pitch, p);

@@ -285,9 +285,189 @@ __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup variant: 4 waves = 4 CONSECUTIVE tile phases (a "quad": 16 audio samples) x 32 streams.
+// PMC on the per-wave kernel above (profiles/r1_pmc_traffic.json): 1.49 x the algorithmic bytes cross the fabric -- the 512-byte
+// windows of neighbouring tiles overlap by 112 bytes (28 %) and live in different waves, and the 16-byte demod stores are
+// written back as partial lines (2.2 x write amplification).  Here the quad's input (3*stride + 512 = 1712 bytes per stream)
+// is fetched ONCE per workgroup with row-contiguous 16-byte loads into LDS (double buffered: the next quad is in flight while
+// the current one is multiplied), each wave takes its window from LDS with ds_read_b128 (row pitch 107 x 16 B: odd, so the 16
+// streams of a group fall into different bank slots), and the 16 audio samples of a stream leave as one contiguous 64-byte row.
+// Every wave still owns one tile phase, so the weights stay register resident.
+struct WgParams {
+    int n_streams; long long B2; long long quad_first; int n_quads; long long tile_out0;
+    int stride, win_off, n_phases, row_bytes; float scale;
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// SB = streams per workgroup (SB/16 groups per wave), NB = input ring depth in quads (NB-1 quads in flight).
+// Measured (profiles/r1_notes.md): SB=32/NB=2 streams 4.4 TB/s with one quad (54.8 KB per CU) in flight -- latency bound;
+// SB=16/NB=5 keeps 4 quads (110 KB per CU) in flight.
+template <int SB, int NB>
+__global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__ in, size_t in_pitch,
+                                                     const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ set_of,
+                                                     const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, WgParams p)
+{
+    extern __shared__ float4 lds_raw[];
+    uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);                         // NB quad buffers, rows back to back inside each
+    constexpr int quad_bytes = 4 * ((SB * 107 + 255) / 256) * 1024;                 // buffer stride = what 4 waves x DMA_PW x 1 KiB cover (>= SB*1712)
+    float *lds_out = reinterpret_cast<float *>(lds_in + NB * quad_bytes);           // 2 x SB x 16 floats
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    const int n_qph = p.n_phases / 4;                                               // quad phases
+    const int qph = blockIdx.x;                                                     // x = quad phase: the 32 phases of a stream block are co-resident and
+                                                                                    // together sweep each input row contiguously (DRAM page locality)
+    // quads of this quad-phase inside [quad_first, quad_first + n_quads): Qg = q0 + m * n_qph, m in this segment
+    const long long q_lim = p.quad_first + p.n_quads;
+    const long long q0 = p.quad_first + (((long long)qph - p.quad_first) % n_qph + n_qph) % n_qph;
+    if (q0 >= q_lim) return;
+    const long long m_total = (q_lim - 1 - q0) / n_qph + 1;
+    const long long m_per = (m_total + gridDim.z - 1) / gridDim.z;
+    const long long m_begin = (long long)blockIdx.z * m_per;
+    long long m_end = m_begin + m_per; if (m_end > m_total) m_end = m_total;
+    if (m_begin >= m_end) return;
+    const int ph = 4 * qph + w;                                                     // this wave's tile phase
+    const int s0 = blockIdx.y * SB, last_stream = p.n_streams - 1;
+    // ---- weights: once per wave
+    const int set0 = set_of[2 * ph], set1 = set_of[2 * ph + 1];
+    const bool two = set1 >= 0;
+    v4i A0[WFM_NK * 3], A1[WFM_NK * 3];
+    {
+        const v4i *fa = frags + (size_t)set0 * WFM_FRAG_V4 + lane;
+#pragma unroll
+        for (int s = 0; s < WFM_NK * 3; s++) A0[s] = fa[s * 64];
+        const v4i *fb = frags + (size_t)(two ? set1 : set0) * WFM_FRAG_V4 + lane;
+#pragma unroll
+        for (int s = 0; s < WFM_NK * 3; s++) A1[s] = fb[s * 64];
+    }
+    const float4 k0v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 4 * q);
+    const float4 k1v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 16 + 4 * q);
+    const float k0[4] = {k0v.x, k0v.y, k0v.z, k0v.w}, k1[4] = {k1v.x, k1v.y, k1v.z, k1v.w};
+    const float K = 0.340447550238101026565118445432744920253753662109375f;
+    // ---- input staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at M0 + 16*lane, no VGPR round trip).
+    // A quad buffer is one contiguous run of SB x n_cols sixteen-byte pieces; wave w issues pieces (DMA_PW*w + k)*64 + lane.
+    const int n_cols = p.row_bytes / 16;                                            // 107
+    const int n_pieces = SB * n_cols;
+    constexpr int DMA_PW = (SB * 107 + 255) / 256;                                  // DMA instructions per wave per quad (row_bytes = 1712)
+    long long goff[DMA_PW];                                                         // per-lane global offset of each piece (iteration invariant)
+#pragma unroll
+    for (int k = 0; k < DMA_PW; k++) {
+        const int P = (w * DMA_PW + k) * 64 + lane;
+        const int row = P / n_cols, cc = P - row * n_cols;
+        goff[k] = (P < n_pieces) ? (long long)min(s0 + row, last_stream) * (long long)in_pitch + 16 * cc : -1;
+    }
+    const long long quad_step = (long long)n_qph * 4 * p.stride;                    // bytes between this workgroup's consecutive quads
+    long long Qg = q0 + m_begin * n_qph;
+    long long wq = Qg * 4 * p.stride + p.win_off - p.B2;                            // quad window base relative to the block start
+    // Inline asm on purpose: hipcc models __builtin_amdgcn_global_load_lds as a store to LDS and puts `s_waitcnt vmcnt(0)` in
+    // front of the ds_reads of the OTHER buffers (it cannot prove they do not alias), serialising the DMA with the math.
+    // Completion is counted by hand: every wave issues exactly DMA_PW instructions per quad, VMEM returns in order, so
+    // `vmcnt(DMA_PW * n)` leaves at most the n newest quads in flight (wave 0's demod store sits in the same queue, which only
+    // makes its wait slightly conservative).
+    const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
+    auto dma_quad = [&](long long base, int buf) {
+        const uint32_t ldst = __builtin_amdgcn_readfirstlane((int)(lds_in_addr + buf * quad_bytes + (w * DMA_PW) * 1024));
+#pragma unroll
+        for (int k = 0; k < DMA_PW; k++) {
+            // every lane executes the instruction (fixed count per wave); lanes past the end re-read piece 0 into the pad area
+            const uint8_t *gp = in + (goff[k] >= 0 ? goff[k] : goff[0]) + base;
+            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + k * 1024));
+            uint32_t keep;
+            // nt: the input is read exactly once, by one CU (MI355X_MICROARCH.md row nt-weights; measured here 1.135 -> 1.110 ms)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gp), "s"(la) : "memory");
+        }
+    };
+    auto wait_newer = [&](long long newer) {                                        // all but the `newer` most recent quads have landed
+        switch ((int)newer) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<DMA_PW>(); break;
+            case 2: wait_vmcnt<DMA_PW * 2>(); break;
+            case 3: wait_vmcnt<DMA_PW * 3>(); break;
+            default: wait_vmcnt<(DMA_PW * 4 < 63 ? DMA_PW * 4 : DMA_PW * 3)>(); break;
+        }
+    };
+    // Ring discipline: quad n lives in buffer n % NB.  Prologue: quads 0 .. NB-1 in flight; at the end of iteration m (after the
+    // barrier) buffer m % NB is free and takes quad m + NB.  At the wait point of iteration m the quads issued beyond m+1 are
+    // m+2 .. min(m+NB-1, last): that many may stay in flight.
+    for (int k = 0; k < NB; k++) if (m_begin + k < m_end) dma_quad(wq + k * quad_step, k);
+    {
+        const long long issued = (m_end - m_begin < NB) ? (m_end - m_begin) : NB;
+        long long newer = issued - 1; if (newer > 4) newer = 4; if (DMA_PW * 4 >= 63 && newer > 3) newer = 3;
+        wait_newer(newer);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long long m = m_begin; m < m_end; m++, Qg += n_qph, wq += quad_step) {
+        const long long wb2 = wq + p.B2 + (long long)w * p.stride;                  // global byte index of this wave's window base
+        const long long chunk_rel = (wb2 >> 11) - (p.B2 >> 11);
+        const float2 C0 = ctab[chunk_rel + 1], C1 = ctab[chunk_rel + 2];
+        const uint8_t *lrow = lds_in + buf * quad_bytes + w * p.stride + 16 * q;
+        float *lout = lds_out + (int)(m & 1) * (SB * 16);
+#pragma unroll
+        for (int g = 0; g < SB / 16; g++) {
+            v4i Bf[WFM_NK];
+            const uint8_t *src = lrow + (16 * g + col) * p.row_bytes;
+#pragma unroll
+            for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks) ^ (int)0x80808080;
+            v4i acc0[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, acc1[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+            for (int ks = 0; ks < WFM_NK; ks++)
+#pragma unroll
+                for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks * 3 + l], Bf[ks], acc0[l], 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int ks = 0; ks < WFM_NK; ks++)
+#pragma unroll
+                    for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[ks * 3 + l], Bf[ks], acc1[l], 0, 0, 0);
+            }
+            float pI, pQ, cI, cQ;
+            {
+                float u0[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) u0[r] = fmaf(combine_digits(acc0[0][r], acc0[1][r], acc0[2][r]), p.scale, k0[r]);
+                pI = C0.x * u0[0] - C0.y * u0[1]; pQ = C0.x * u0[1] + C0.y * u0[0];
+                cI = C0.x * u0[2] - C0.y * u0[3]; cQ = C0.x * u0[3] + C0.y * u0[2];
+            }
+            if (two) {
+                float u1[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, k1[r]);
+                pI += C1.x * u1[0] - C1.y * u1[1]; pQ += C1.x * u1[1] + C1.y * u1[0];
+                cI += C1.x * u1[2] - C1.y * u1[3]; cQ += C1.x * u1[3] + C1.y * u1[2];
+            }
+            const float dq = cQ - pQ, di = cI - pI;
+            const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
+            lout[(16 * g + col) * 16 + 4 * w + q] = (den != 0.f) ? (K * num) / den : 0.f;      // audio 4*ti+q of stream 16g+col
+        }
+        // quad m+1 must have landed before anyone passes the barrier; quads m+2 .. m+NB-1 stay in flight.  After the barrier this
+        // quad's buffer is free and takes quad m+NB: the input stream never pauses.
+        {
+            long long left = m_end - 1 - (m + 1);                                   // quads issued beyond m+1
+            if (left < 0) left = 0;
+            if (left > NB - 2) left = NB - 2;
+            if (left > 4) left = 4;
+            if (DMA_PW * 4 >= 63 && left > 3) left = 3;
+            wait_newer(left);
+        }
+        __syncthreads();
+        if (m + NB < m_end) dma_quad(wq + NB * quad_step, buf);
+        if (tid < SB * 4) {                                                         // 4 threads x 16 B = one contiguous 64-byte row per stream
+            const int srow = tid >> 2, part = tid & 3;
+            if (s0 + srow < p.n_streams)
+                *reinterpret_cast<float4 *>(demod + (size_t)(s0 + srow) * demod_pitch + 4 * (4 * Qg + part - p.tile_out0)) =
+                    *reinterpret_cast<const float4 *>(lout + srow * 16 + 4 * part);
+        }
+        buf = (buf + 1 == NB) ? 0 : buf + 1;
+    }
+}
+
 } // namespace
 
 namespace csdr_amd {
+
+static const char *g_last_kernel = "k_wfm_mfma";
+const char *wfm_mfma_last_kernel() { return g_last_kernel; }
 
 int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
                     float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio)
@@ -318,7 +498,43 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
         CSDR_LAUNCH_CHECK();
         return 0;
     };
-    int rc = launch(t_a, t_b, false); if (rc) return rc;                 // the bulk: no bounds logic at all
+    static int use_wg = -1;
+    if (use_wg < 0) { const char *e = getenv("CSDR_AMD_WFM_WG"); use_wg = e ? atoi(e) : 1; }
+    int rc = 0;
+    const long long qa = (t_a + 3) / 4, qb = (t_b + 1) / 4 - 1;             // whole quads inside the interior tile range
+    if (use_wg && (p.n_phases % 4) == 0 && 3 * p.tile_stride_bytes + 64 * WFM_NK == 1712 && qb - qa + 1 >= 2 * (p.n_phases / 4)) {
+        WgParams wp;
+        wp.n_streams = n_streams; wp.B2 = 2 * B; wp.quad_first = qa; wp.n_quads = (int)(qb - qa + 1); wp.tile_out0 = tile_first;
+        wp.stride = p.tile_stride_bytes; wp.win_off = p.win_off_bytes; wp.n_phases = p.n_phases; wp.scale = p.scale;
+        wp.row_bytes = 3 * wp.stride + 64 * WFM_NK;                       // rows back to back (the DMA fills one contiguous run); 107 slots: odd
+        static int cfg = -1;                                             // 0: 16 streams x ring of 5 quads (default), 1: 32 streams x ring of 2
+        if (cfg < 0) { const char *e = getenv("CSDR_AMD_WFM_WGCFG"); cfg = e ? atoi(e) : 0; }
+        const int SBv = cfg == 1 ? 32 : 16, NBv = cfg == 1 ? 2 : 5;
+        const int n_qph = p.n_phases / 4, n_wsb = (n_streams + SBv - 1) / SBv;
+        const long long per_qph = (wp.n_quads + n_qph - 1) / n_qph;
+        int z = (int)((1024 + (long long)n_wsb * n_qph - 1) / ((long long)n_wsb * n_qph));        // >= 1024 workgroups
+        if (z > per_qph / 8) z = (int)(per_qph / 8);
+        if (z < 1) z = 1;
+        const size_t lds = (size_t)NBv * (4 * ((SBv * 107 + 255) / 256) * 1024) + 2 * SBv * 16 * sizeof(float);
+        if (wp.row_bytes != 1712) return fail_msg(-3, "wfm: workgroup kernel is specialised for 1712-byte quad rows");
+        if (cfg == 1) {
+            static bool done1 = false;
+            if (!done1) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done1 = true; }
+            hipLaunchKernelGGL((k_wfm_mfma_wg<32, 2>), dim3(n_qph, n_wsb, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
+        } else {
+            static bool done0 = false;
+            if (!done0) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done0 = true; }
+            hipLaunchKernelGGL((k_wfm_mfma_wg<16, 5>), dim3(n_qph, n_wsb, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
+        }
+        CSDR_LAUNCH_CHECK();
+        g_last_kernel = "k_wfm_mfma_wg";
+        // leftovers around the quad range run on the per-wave kernel (bounds-checked variant: a handful of tiles)
+        rc = launch(tile_first, 4 * qa - 1, true); if (rc) return rc;
+        rc = launch(4 * (qb + 1), tile_last, true);
+        return rc;
+    }
+    g_last_kernel = "k_wfm_mfma";
+    rc = launch(t_a, t_b, false); if (rc) return rc;                        // the bulk: no bounds logic at all
     rc = launch(tile_first, t_a - 1 < tile_last ? t_a - 1 : tile_last, true); if (rc) return rc;      // leading tiles (history)
     if (t_b + 1 > t_a - 1) rc = launch(t_b + 1 > t_a ? t_b + 1 : t_a, tile_last, true);               // trailing tiles (ragged end / partial tile)
     return rc;
