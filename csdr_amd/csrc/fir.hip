@@ -5,9 +5,11 @@
 // Layout / tiling: one workgroup = one (stream, tile of TO outputs).  The input window of
 // D*TO + taps - 1 samples is staged once through LDS with coalesced 16-byte global loads (interleaved
 // complexf kept as is: a float2 per sample), so every input sample is read from HBM once (+ halo).
-// Each lane then produces R consecutive outputs (register blocking: one LDS read of a sample feeds up to
-// R accumulators), taps are wave-uniform and come through the scalar path (s_load -> SGPR operand).
-// Algorithmic traffic: 8 B in + 8/D B out per input sample => HBM bound (3.6 flop/B).
+// Each lane then produces outputs from LDS; taps are wave-uniform and come through the scalar path (s_load -> SGPR operand).
+// Algorithmic traffic: 8 B in + 8/D B out per input sample => HBM bound on paper (3.6 flop/B).
+// Measured (profiles/r1_ops.jsonl): 2.9 TB/s algorithmic at D=10/79 taps on long streams (37 % of peak), 1.4 TB/s at D=50/801 taps.
+// A register-blocked variant (5 consecutive outputs per lane, zero-padded taps) was tried in round 1 and was SLOWER (2.1 TB/s):
+// the kernel is not LDS-read bound; it is the next kernel to restructure (round 2).
 #include "common.hpp"
 using namespace csdr_amd;
 
@@ -55,54 +57,6 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ i
             dst[o] = a;
         }
     }
-}
-
-// Register-blocked decimator specialised on D: lane computes R consecutive outputs, walking the
-// (R-1)*D + ntaps samples of its window once.  Accumulator r is fed by tap t = j - r*D for sample j.
-// The tap loop is ordered by t so that taps stay wave-uniform scalar loads.
-template <int D, int R>
-__global__ __launch_bounds__(256) void k_fir_decim_blocked(const float2 *__restrict__ in, float2 *__restrict__ out, int n_out,
-                                                           size_t in_pitch, size_t out_pitch, const float *__restrict__ taps, int ntaps)
-{
-    extern __shared__ float4 lds_raw[];
-    float2 *win = reinterpret_cast<float2 *>(lds_raw);
-    constexpr int TO = 256 * R;
-    const int o0 = blockIdx.x * TO;
-    const int outs = min(TO, n_out - o0);
-    if (outs <= 0) return;
-    const size_t s = blockIdx.y;
-    const float2 *src = in + s * in_pitch + (size_t)o0 * D;
-    const int win_samples = (outs - 1) * D + ntaps;
-    if ((((uintptr_t)src) & 15) == 0) {
-        const int nv = win_samples / 2;
-        for (int v = threadIdx.x; v < nv; v += 256) reinterpret_cast<float4 *>(win)[v] = reinterpret_cast<const float4 *>(src)[v];
-        if ((win_samples & 1) && threadIdx.x == 0) win[win_samples - 1] = src[win_samples - 1];
-    } else {
-        for (int k = threadIdx.x; k < win_samples; k += 256) win[k] = src[k];
-    }
-    __syncthreads();
-    // lane -> outputs [lo, lo+R): interleave lanes so that the R outputs of a lane are consecutive
-    const int lo = threadIdx.x * R;
-    if (lo >= outs) return;
-    const float2 *x = win + (size_t)lo * D;
-    const int last_valid = (outs - lo < R) ? outs - lo : R;   // outputs of this lane that exist
-    // samples beyond the staged window are only touched by non-existent outputs: clamp reads
-    const int max_j = win_samples - lo * D;                    // valid sample count from x
-    float ai[R], aq[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) { ai[r] = 0.f; aq[r] = 0.f; }
-    for (int t = 0; t < ntaps; t++) {
-        const float h = taps[t];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int j = t + r * D;
-            const float2 v = (j < max_j) ? x[j] : make_float2(0.f, 0.f);
-            ai[r] = fmaf(v.x, h, ai[r]); aq[r] = fmaf(v.y, h, aq[r]);
-        }
-    }
-    float2 *dst = out + s * out_pitch + (size_t)o0 + lo;
-#pragma unroll
-    for (int r = 0; r < R; r++) if (r < last_valid) dst[r] = make_float2(ai[r], aq[r]);
 }
 
 } // namespace
