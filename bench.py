@@ -114,7 +114,7 @@ def main():
     # synthetic input resident in HBM (torch is only the allocator / RNG here)
     g = torch.Generator(device="cuda"); g.manual_seed(42 + rank)
     x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda", generator=g)
-    n_audio_max = T // 50 + 64
+    n_audio_max = (T // 50 + 64 + 63) // 64 * 64          # 128-byte aligned s16 rows (16-byte vector stores in the back end)
     out_s16 = torch.empty((S, n_audio_max), dtype=torch.int16, device="cuda")
     torch.cuda.synchronize()
     w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)

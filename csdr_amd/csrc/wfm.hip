@@ -121,49 +121,65 @@ __global__ __launch_bounds__(256) void k_wfm_front(const uint8_t *__restrict__ i
     }
 }
 
-// de-emphasis + convert_f_s16; block = 64 lanes = 64 segments of 64 audio samples of one stream
-__global__ __launch_bounds__(64) void k_wfm_back(const float *__restrict__ demod_base, size_t demod_pitch, int skip, int n_audio, float alpha,
-                                                 const float *__restrict__ last_in, float *__restrict__ last_out,
-                                                 int16_t *__restrict__ s16, float *__restrict__ audio_f, size_t out_pitch)
+// de-emphasis + convert_f_s16.  Block = 256 lanes x 16-sample segments = 4096 audio samples of one stream; every lane starts
+// WARM (48) samples early from zero state (0.706^48 = 5.6e-8: the predecessor's state is forgotten to float precision), the very
+// first segment of a call starts from the exact carried state.  Input staged once through LDS (lane stride 17 floats: conflict free),
+// each lane leaves 16 s16 = 32 contiguous bytes -> fully coalesced 8 KiB per block.
+constexpr int BK_SEG = 16, BK_CHUNK = 256 * BK_SEG;
+__global__ __launch_bounds__(256) void k_wfm_back(const float *__restrict__ demod_base, size_t demod_pitch, int skip, int n_audio, float alpha,
+                                                  const float *__restrict__ last_in, float *__restrict__ last_out,
+                                                  int16_t *__restrict__ s16, float *__restrict__ audio_f, size_t out_pitch)
 {
-    __shared__ float seg[64 * 65 + WARM + 16];
-    __shared__ float oseg[64 * 65];
+    __shared__ float seg[(BK_CHUNK + WARM) + (BK_CHUNK + WARM) / 16 + 16];
     const int s = blockIdx.y;
-    const int t0 = blockIdx.x * 4096;
-    const int cnt = min(4096, n_audio - t0);
+    const int t0 = blockIdx.x * BK_CHUNK;
+    const int cnt = min(BK_CHUNK, n_audio - t0);
     if (cnt <= 0) return;
     const float *row = demod_base + (size_t)s * demod_pitch + skip;   // the matrix-core front end stores whole 4-sample tiles
-    const int lead = (t0 >= WARM) ? WARM : t0;                      // samples before t0 available for warm-up
-    // LDS position of sample (t0 - lead + q): q + q/64 (one pad float per 64: lane stride 65 -> conflict free)
-    for (int q = threadIdx.x; q < cnt + lead; q += 64) seg[q + (q >> 6)] = row[t0 - lead + q];
+    const int lead = (t0 >= WARM) ? WARM : t0;                        // samples before t0 available for warm-up
+    for (int q = threadIdx.x; q < cnt + lead; q += 256) seg[q + (q >> 4)] = row[t0 - lead + q];
     __syncthreads();
-    const int lane = threadIdx.x;
-    const int my0 = lane * 64;                                       // first sample of my segment, relative to t0
+    const int my0 = threadIdx.x * BK_SEG;                             // first sample of my segment, relative to t0
+    if (my0 >= cnt) return;
     const float one_minus = 1 - alpha;
-    if (my0 < cnt) {
-        float y;
-        int q;                                                       // index into the staged run
-        if (t0 + my0 == 0) { y = last_in[s]; if (y != y) y = 0.f; q = lead + my0; }
-        else {
-            y = 0.f;
-            const int back = (my0 + lead >= WARM) ? WARM : (my0 + lead);
-            q = lead + my0 - back;
-            for (int k = 0; k < back; k++, q++) y = alpha * seg[q + (q >> 6)] + one_minus * y;
-        }
-        const int mine = min(64, cnt - my0);
-        for (int k = 0; k < mine; k++, q++) {
-            y = alpha * seg[q + (q >> 6)] + one_minus * y;
-            oseg[(my0 + k) + ((my0 + k) >> 6)] = y;
-        }
-        if (t0 + my0 + mine == n_audio) last_out[s] = y;
+    // warm-up window: up to WARM samples before my segment; when it reaches the first sample of this call the exact carried
+    // state is the starting point (NaN state reset as libcsdr.c:1092), otherwise zero
+    const int back = (my0 + lead >= WARM) ? WARM : (my0 + lead);
+    int q = lead + my0 - back;
+    float y = 0.f;
+    if (t0 + my0 - back == 0) { y = last_in[s]; if (y != y) y = 0.f; }
+    for (int k = 0; k < back; k++, q++) y = alpha * seg[q + (q >> 4)] + one_minus * y;
+    const int mine = min(BK_SEG, cnt - my0);
+    float e[BK_SEG];
+#pragma unroll
+    for (int k = 0; k < BK_SEG; k++) {
+        if (k < mine) { y = alpha * seg[q + (q >> 4)] + one_minus * y; q++; }
+        e[k] = y;
     }
-    __syncthreads();
-    for (int q = threadIdx.x; q < cnt; q += 64) {
-        const float e = oseg[q + (q >> 6)];
-        const float scaled = e * 32767.0f;                           // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
-        const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
-        s16[(size_t)s * out_pitch + t0 + q] = (int16_t)(iv & 0xffff);
-        if (audio_f) audio_f[(size_t)s * out_pitch + t0 + q] = e;
+    if (t0 + my0 + mine == n_audio) last_out[s] = y;
+    uint32_t pk[BK_SEG / 2];
+#pragma unroll
+    for (int k = 0; k < BK_SEG; k += 2) {
+        int iv[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float scaled = e[k + h] * 32767.0f;                 // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
+            iv[h] = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
+        }
+        pk[k / 2] = (uint32_t)(iv[0] & 0xffff) | ((uint32_t)iv[1] << 16);
+    }
+    int16_t *dst = s16 + (size_t)s * out_pitch + t0 + my0;
+    if (mine == BK_SEG && ((((uintptr_t)dst) & 15) == 0)) {
+        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < BK_SEG; k++) if (k < mine) dst[k] = (int16_t)((k & 1) ? (pk[k / 2] >> 16) : (pk[k / 2] & 0xffff));
+    }
+    if (audio_f) {
+        float *df = audio_f + (size_t)s * out_pitch + t0 + my0;
+#pragma unroll
+        for (int k = 0; k < BK_SEG; k++) if (k < mine) df[k] = e[k];
     }
 }
 
@@ -373,7 +389,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
             CSDR_LAUNCH_CHECK();
         }
         if (w->profiling) CSDR_HIP(hipEventRecord(e1, st));
-        hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, 4096), w->n_streams), dim3(64), 0, st,
+        hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, BK_CHUNK), w->n_streams), dim3(256), 0, st,
                            w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j - 4 * (w->next_j / 4)) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
         CSDR_LAUNCH_CHECK();
         w->flip ^= 1;
