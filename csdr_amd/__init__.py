@@ -437,3 +437,40 @@ class Context:
         af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na]
         self.L.csdr_amd_wfm_destroy(w)
         return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())
+
+    def nfm_chain(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024):
+        """BASELINE config 5 / README.md:87, stage by stage through the device batch API with the data resident on the GPU between
+        stages: convert_u8_f | shift_addition_cc | fir_decimate_cc D tbw HAMMING | fmdemod_quadri_cf | limit_ff | deemphasis_nfm_ff |
+        fastagc_ff | convert_f_s16.   iq_u8: [streams, 2n] uint8  ->  (s16 [streams, na], float audio [streams, na])."""
+        x2, squeeze = self._2d(iq_u8, np.uint8)
+        S, nbytes = x2.shape; n = nbytes // 2
+        L = self.L
+        d_u8 = self.upload(x2)
+        d_f = self.alloc(4 * S * nbytes + 64)
+        self.check(L.csdr_amd_convert_u8_f(self.h, d_u8.ptr, d_f.ptr, S * nbytes), "convert_u8_f")
+        d_sh = self.alloc(8 * S * n + 64)
+        ph = C.c_float(0.0)
+        self.check(L.csdr_amd_shift_cc(self.h, SHIFT["addition"], shift_rate, C.byref(ph), d_f.ptr, d_sh.ptr, S, n, n, n, 1024, 0), "shift")
+        nt = self.firdes_filter_len(tbw)
+        taps = self.upload(self.firdes_lowpass_f(nt, 0.5 / decimation))
+        pd = n // decimation + 2
+        d_dec = self.alloc(8 * S * pd + 64)
+        nd = self.check(L.csdr_amd_fir_decimate_cc(self.h, d_sh.ptr, d_dec.ptr, S, n, n, pd, decimation, taps.ptr, nt), "fir_decimate_cc")
+        d_dem = self.alloc(4 * S * pd + 64); d_last = self.upload(np.zeros(S, c64))
+        self.check(L.csdr_amd_fmdemod_quadri_cf(self.h, d_dec.ptr, d_dem.ptr, S, nd, pd, pd, d_last.ptr), "fmdemod")
+        d_lim = self.alloc(4 * S * pd + 64)
+        self.check(L.csdr_amd_limit_ff(self.h, d_dem.ptr, d_lim.ptr, S * pd, 1.0), "limit")
+        dtaps_h = self.nfm_taps(audio_rate)
+        d_dt = self.upload(dtaps_h)
+        d_de = self.alloc(4 * S * pd + 64)
+        ne = self.check(L.csdr_amd_fir_ff(self.h, d_lim.ptr, d_de.ptr, S, nd, pd, pd, d_dt.ptr, dtaps_h.size), "deemphasis_nfm")
+        nb = ne // agc_block
+        d_agc = self.alloc(4 * S * pd + 64)
+        d_st = self.upload(np.zeros(S * (2 * agc_block + 4), f32))
+        self.check(L.csdr_amd_fastagc_ff(self.h, d_de.ptr, d_agc.ptr, S, nb, agc_block, pd, pd, 1.0, d_st.ptr), "fastagc")
+        na = nb * agc_block
+        d_pcm = self.alloc(2 * S * pd + 64)
+        self.check(L.csdr_amd_convert_f_s16(self.h, d_agc.ptr, d_pcm.ptr, S * pd), "convert_f_s16")
+        af = self.download(d_agc, f32, S * pd).reshape(S, pd)[:, :na]
+        pcm = self.download(d_pcm, np.int16, S * pd).reshape(S, pd)[:, :na]
+        return (pcm[0].copy(), af[0].copy()) if squeeze else (pcm.copy(), af.copy())

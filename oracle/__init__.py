@@ -323,6 +323,18 @@ class Port:
         return s16[:na].copy(), af[:na].copy()
 
 
+    def nfm_chain(self, iq_u8, shift_rate, nfm_taps, decimation=50, tbw=0.005, agc_block=1024):
+        """README.md:87 stage by stage on one stream (stream models of the CLI loops)."""
+        xf = self.convert_u8_f(iq_u8).view(c64)
+        sh, _ = self.shift_addition_cc(xf, shift_rate)
+        nt = self.firdes_filter_len(tbw)
+        dec = self.fir_decimate_cc(sh, decimation, self.firdes_lowpass_f(nt, 0.5 / decimation))
+        dem, _ = self.fmdemod_quadri_cf(dec)
+        de = self.deemphasis_nfm_ff(self.limit_ff(dem, 1.0), nfm_taps)
+        agc = self.fastagc_ff(de, agc_block, 1.0)
+        return self.convert_f_s16(agc), agc
+
+
 # =====================================================================================
 class Ref:
     """The unmodified reference, compiled into _ref/libcsdr_ref.so.  Signatures: libcsdr.h:85-229,
@@ -355,8 +367,10 @@ class Ref:
     def available():
         return os.path.exists(LIB_REF)
 
-    def __init__(self):
-        L = self.L = C.CDLL(LIB_REF)
+    def __init__(self, lib_path=None):
+        """lib_path=None: the compiled reference.  Any other library that exports the reference's symbols with the reference's
+        signatures can be driven through this same harness (tests/test_compat_gpu.py passes libcsdr_amd.so)."""
+        L = self.L = C.CDLL(lib_path or LIB_REF)
         for name in ("shift_math_cc", "shift_table_cc", "shift_unroll_cc", "shift_addfast_cc", "shift_addition_cc",
                      "shift_addition_fc", "deemphasis_wfm_ff"):
             getattr(L, name).restype = C.c_float
@@ -371,7 +385,8 @@ class Ref:
         L.shift_unroll_init.restype = Ref.ShiftUnroll
         L.fractional_decimator_ff_init.restype = Ref.FracDec
         L.make_fft_c2c.restype = C.POINTER(Ref.FftPlan)
-        L.fftwf_malloc.restype = C.c_void_p
+        if lib_path is None:
+            L.fftwf_malloc.restype = C.c_void_p
 
     def nfm_taps(self, sample_rate):
         n = {48000: 201, 44100: 123, 8000: 81, 11025: 81}[sample_rate]

@@ -317,3 +317,18 @@ def test_dropin_client_binary(gpu):
     g = re.search(r"phase=(\S+) demod_energy=(\S+)", golden)
     assert abs(float(m.group(3)) - float(g.group(1))) < 2e-5
     assert abs(float(m.group(4)) / float(g.group(2)) - 1) < 1e-4
+
+
+def test_nfm_chain_device_resident(gpu, port):
+    """BASELINE config 5 shape (README.md:87) at reduced size: 3 channels x 0.25 s, every stage a device batch call."""
+    n = 600000
+    u8 = np.stack([to_u8(fm_signal(np.random.default_rng(5000 + s), n, dev=5e3 / 2.4e6, offset=0.05)) for s in range(3)])
+    pcm, af = gpu.nfm_chain(u8, -0.05)
+    taps = gpu.nfm_taps(48000)
+    for s in range(3):
+        ps, pf = port.nfm_chain(u8[s], -0.05, taps)
+        assert pf.size == af.shape[1] and pf.size >= 10 * 1024
+        assert np.all(af[s, :2048] == 0)                               # fastagc's two-block latency
+        assert relrms(af[s], pf) < TOL
+        d = np.abs(pcm[s].astype(np.int32) - ps.astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.05
