@@ -327,7 +327,13 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
     long long m_end = m_begin + m_per; if (m_end > m_total) m_end = m_total;
     if (m_begin >= m_end) return;
     const int ph = 4 * qph + w;                                                     // this wave's tile phase
-    const int s0 = blockIdx.y * SB, last_stream = p.n_streams - 1;
+    const int last_stream = p.n_streams - 1;
+    // persistent over stream blocks: this workgroup owns stream blocks blockIdx.y, blockIdx.y + gridDim.y, ... and walks the item
+    // sequence (stream block, quad m) without draining the input ring in between; the weights are loaded once per WORKGROUP LIFETIME
+    const int n_wsb = (p.n_streams + SB - 1) / SB;
+    const int my_sb = (n_wsb - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;      // stream blocks of this workgroup
+    if (my_sb <= 0) return;
+    const long long M = m_end - m_begin, n_items = (long long)my_sb * M;
     // ---- weights: once per wave
     const int set0 = set_of[2 * ph], set1 = set_of[2 * ph + 1];
     const bool two = set1 >= 0;
@@ -349,34 +355,39 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
     const int n_cols = p.row_bytes / 16;                                            // 107
     const int n_pieces = SB * n_cols;
     constexpr int DMA_PW = (SB * 107 + 255) / 256;                                  // DMA instructions per wave per quad (row_bytes = 1712)
-    long long goff[DMA_PW];                                                         // per-lane global offset of each piece (iteration invariant)
+    int prow[DMA_PW], pcol[DMA_PW];                                                 // per-lane (row, 16-byte column) of each piece (iteration invariant)
 #pragma unroll
     for (int k = 0; k < DMA_PW; k++) {
-        const int P = (w * DMA_PW + k) * 64 + lane;
-        const int row = P / n_cols, cc = P - row * n_cols;
-        goff[k] = (P < n_pieces) ? (long long)min(s0 + row, last_stream) * (long long)in_pitch + 16 * cc : -1;
+        int P = (w * DMA_PW + k) * 64 + lane;
+        if (P >= n_pieces) P = 0;                                                   // lanes past the end re-read piece 0 into the pad area
+        prow[k] = P / n_cols; pcol[k] = 16 * (P - prow[k] * n_cols);
     }
     const long long quad_step = (long long)n_qph * 4 * p.stride;                    // bytes between this workgroup's consecutive quads
-    long long Qg = q0 + m_begin * n_qph;
-    long long wq = Qg * 4 * p.stride + p.win_off - p.B2;                            // quad window base relative to the block start
+    const long long Qg0 = q0 + m_begin * n_qph;
+    const long long wq0 = Qg0 * 4 * p.stride + p.win_off - p.B2;                    // first quad's window base relative to the block start
     // Inline asm on purpose: hipcc models __builtin_amdgcn_global_load_lds as a store to LDS and puts `s_waitcnt vmcnt(0)` in
     // front of the ds_reads of the OTHER buffers (it cannot prove they do not alias), serialising the DMA with the math.
     // Completion is counted by hand: every wave issues exactly DMA_PW instructions per quad, VMEM returns in order, so
     // `vmcnt(DMA_PW * n)` leaves at most the n newest quads in flight (wave 0's demod store sits in the same queue, which only
     // makes its wait slightly conservative).
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
-    auto dma_quad = [&](long long base, int buf) {
+    // DMA cursor: the next item to fetch (stream block cs, quad cm); advances independently of the compute position
+    int cs = blockIdx.y; long long cm = 0, c_issued = 0;
+    auto dma_next = [&](int buf) {
         const uint32_t ldst = __builtin_amdgcn_readfirstlane((int)(lds_in_addr + buf * quad_bytes + (w * DMA_PW) * 1024));
+        const long long base = wq0 + cm * quad_step;
+        const int cs0 = cs * SB;
 #pragma unroll
-        for (int k = 0; k < DMA_PW; k++) {
-            // every lane executes the instruction (fixed count per wave); lanes past the end re-read piece 0 into the pad area
-            const uint8_t *gp = in + (goff[k] >= 0 ? goff[k] : goff[0]) + base;
+        for (int k = 0; k < DMA_PW; k++) {                                          // every lane executes every instruction (fixed count per wave)
+            const uint8_t *gp = in + (long long)min(cs0 + prow[k], last_stream) * (long long)in_pitch + pcol[k] + base;
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + k * 1024));
             uint32_t keep;
             // nt: the input is read exactly once, by one CU (MI355X_MICROARCH.md row nt-weights; measured here 1.135 -> 1.110 ms)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gp), "s"(la) : "memory");
         }
+        c_issued++;
+        if (++cm == M) { cm = 0; cs += gridDim.y; }
     };
     auto wait_newer = [&](long long newer) {                                        // all but the `newer` most recent quads have landed
         switch ((int)newer) {
@@ -390,20 +401,20 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
     // Ring discipline: quad n lives in buffer n % NB.  Prologue: quads 0 .. NB-1 in flight; at the end of iteration m (after the
     // barrier) buffer m % NB is free and takes quad m + NB.  At the wait point of iteration m the quads issued beyond m+1 are
     // m+2 .. min(m+NB-1, last): that many may stay in flight.
-    for (int k = 0; k < NB; k++) if (m_begin + k < m_end) dma_quad(wq + k * quad_step, k);
+    for (int k = 0; k < NB; k++) if (c_issued < n_items) dma_next(k);
     {
-        const long long issued = (m_end - m_begin < NB) ? (m_end - m_begin) : NB;
-        long long newer = issued - 1; if (newer > 4) newer = 4; if (DMA_PW * 4 >= 63 && newer > 3) newer = 3;
+        long long newer = c_issued - 1; if (newer > 4) newer = 4; if (DMA_PW * 4 >= 63 && newer > 3) newer = 3;
         wait_newer(newer);
     }
     __syncthreads();
     int buf = 0;
-    for (long long m = m_begin; m < m_end; m++, Qg += n_qph, wq += quad_step) {
+    int s0 = blockIdx.y * SB; long long m = 0, Qg = Qg0, wq = wq0;                  // compute position
+    for (long long it = 0; it < n_items; it++) {
         const long long wb2 = wq + p.B2 + (long long)w * p.stride;                  // global byte index of this wave's window base
         const long long chunk_rel = (wb2 >> 11) - (p.B2 >> 11);
         const float2 C0 = ctab[chunk_rel + 1], C1 = ctab[chunk_rel + 2];
         const uint8_t *lrow = lds_in + buf * quad_bytes + w * p.stride + 16 * q;
-        float *lout = lds_out + (int)(m & 1) * (SB * 16);
+        float *lout = lds_out + (int)(it & 1) * (SB * 16);
 #pragma unroll
         for (int g = 0; g < SB / 16; g++) {
             v4i Bf[WFM_NK];
@@ -443,15 +454,14 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
         // quad m+1 must have landed before anyone passes the barrier; quads m+2 .. m+NB-1 stay in flight.  After the barrier this
         // quad's buffer is free and takes quad m+NB: the input stream never pauses.
         {
-            long long left = m_end - 1 - (m + 1);                                   // quads issued beyond m+1
+            long long left = c_issued - 1 - (it + 1);                               // items issued beyond it+1
             if (left < 0) left = 0;
-            if (left > NB - 2) left = NB - 2;
             if (left > 4) left = 4;
             if (DMA_PW * 4 >= 63 && left > 3) left = 3;
             wait_newer(left);
         }
         __syncthreads();
-        if (m + NB < m_end) dma_quad(wq + NB * quad_step, buf);
+        if (c_issued < n_items) dma_next(buf);
         if (tid < SB * 4) {                                                         // 4 threads x 16 B = one contiguous 64-byte row per stream
             const int srow = tid >> 2, part = tid & 3;
             if (s0 + srow < p.n_streams)
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
                     *reinterpret_cast<const float4 *>(lout + srow * 16 + 4 * part);
         }
         buf = (buf + 1 == NB) ? 0 : buf + 1;
+        if (++m == M) { m = 0; Qg = Qg0; wq = wq0; s0 += gridDim.y * SB; } else { Qg += n_qph; wq += quad_step; }
     }
 }
 
@@ -512,7 +523,11 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
         const int SBv = cfg == 1 ? 32 : 16, NBv = cfg == 1 ? 2 : 5;
         const int n_qph = p.n_phases / 4, n_wsb = (n_streams + SBv - 1) / SBv;
         const long long per_qph = (wp.n_quads + n_qph - 1) / n_qph;
-        int z = (int)((1024 + (long long)n_wsb * n_qph - 1) / ((long long)n_wsb * n_qph));        // >= 1024 workgroups
+        // persistent grid: one workgroup per CU (256); a workgroup owns a quad phase and walks its share of the stream blocks
+        static int n_cu = 0;
+        if (!n_cu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n_cu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
+        int gy = n_cu / n_qph; if (gy < 1) gy = 1; if (gy > n_wsb) gy = n_wsb;
+        int z = n_cu / (n_qph * gy); if (z < 1) z = 1;
         if (z > per_qph / 8) z = (int)(per_qph / 8);
         if (z < 1) z = 1;
         const size_t lds = (size_t)NBv * (4 * ((SBv * 107 + 255) / 256) * 1024) + 2 * SBv * 16 * sizeof(float);
@@ -520,11 +535,11 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
         if (cfg == 1) {
             static bool done1 = false;
             if (!done1) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done1 = true; }
-            hipLaunchKernelGGL((k_wfm_mfma_wg<32, 2>), dim3(n_qph, n_wsb, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
+            hipLaunchKernelGGL((k_wfm_mfma_wg<32, 2>), dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
         } else {
             static bool done0 = false;
             if (!done0) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done0 = true; }
-            hipLaunchKernelGGL((k_wfm_mfma_wg<16, 5>), dim3(n_qph, n_wsb, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
+            hipLaunchKernelGGL((k_wfm_mfma_wg<16, 5>), dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
         }
         CSDR_LAUNCH_CHECK();
         g_last_kernel = "k_wfm_mfma_wg";

@@ -1,0 +1,193 @@
+"""`csdr <function>` front end (csdr_amd/csdr, built from csdr_amd/csrc/csdr_cli.cpp) on the GPU: raw streams in and out through real
+pipes, compared with the oracle's stream models of the reference CLI loops (csdr.c, cited per test) and -- when the compiled reference
+CLI travelled with the snapshot (oracle/_ref/csdr) -- with the reference processes themselves in the README.md:66 pipeline.
+Small CSDR_AMD_BLOCK values force several host iterations so that every carry path (refeed, overlap, phase, AGC history) is crossed."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from oracle import relrms
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "csdr_amd", "csdr")
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "csdr")
+c64 = np.complex64
+f32 = np.float32
+TOL = 1e-5
+
+
+def run(args, data, block=8192, cli=CLI):
+    assert os.path.exists(cli), "csdr_amd/csdr not built (make -C csdr_amd/csrc)"
+    env = dict(os.environ, CSDR_AMD_BLOCK=str(block))
+    p = subprocess.run([cli] + [str(a) for a in args], input=np.ascontiguousarray(data).tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    return p.stdout
+
+
+def crand(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(c64)
+
+
+def test_cli_converters_bit_exact(port):
+    rng = np.random.default_rng(1)
+    u8 = rng.integers(0, 256, 50001, dtype=np.uint8)
+    assert run(["convert_u8_f"], u8) == port.convert_u8_f(u8).tobytes()
+    x = rng.uniform(-1.2, 1.2, 30011).astype(f32)
+    assert run(["convert_f_s16"], x) == port.convert_f_s16(x).tobytes()
+    assert run(["convert_f_i16"], x) == port.convert_f_s16(x).tobytes()
+    assert run(["convert_f_u8"], x) == port.convert_f_u8(x).tobytes()
+    assert run(["convert_f_s8"], x) == port.convert_f_s8(x).tobytes()
+    s16 = rng.integers(-32768, 32768, 20001, dtype=np.int16)
+    assert run(["convert_s16_f"], s16) == port.convert_s16_f(s16).tobytes()
+    s8 = rng.integers(-128, 128, 20001, dtype=np.int8)
+    assert run(["convert_s8_f"], s8) == port.convert_s8_f(s8).tobytes()
+    assert run(["convert_f_s24"], x) == port.convert_f_s24(x).tobytes()
+    assert run(["convert_f_s24", "--bigendian"], x) == port.convert_f_s24(x, 1).tobytes()
+    s24 = rng.integers(0, 256, 3 * 10001, dtype=np.uint8)
+    assert run(["convert_s24_f"], s24) == port.convert_s24_f(s24).tobytes()
+
+
+@pytest.mark.parametrize("cmd,fn,extra", [("shift_addition_cc", "shift_addition_cc", []), ("shift_math_cc", "shift_math_cc", []),
+                                          ("shift_addfast_cc", "shift_addfast_cc", []), ("shift_unroll_cc", "shift_unroll_cc", []),
+                                          ("shift_table_cc", "shift_table_cc", [4096])])
+def test_cli_shift(port, cmd, fn, extra):
+    rng = np.random.default_rng(2)
+    x = crand(rng, 5 * 8192 + 1024 + 300)                  # several host blocks, a whole chunk and a ragged tail
+    got = np.frombuffer(run([cmd, -0.085] + extra, x), c64)
+    want = getattr(port, fn)(x, -0.085, *extra)[0]
+    assert got.size == x.size
+    assert relrms(got, want) <= TOL
+
+
+def test_cli_shift_addition_fc(port):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, 3 * 8192 + 77).astype(f32)
+    got = np.frombuffer(run(["shift_addition_fc", 0.21], x), c64)
+    assert relrms(got, port.shift_addition_fc(x, 0.21)[0]) <= TOL
+
+
+def test_cli_fir_decimate_refeed(port):
+    """csdr.c:1114-1177: every output of the stream appears exactly once, whatever the block size."""
+    rng = np.random.default_rng(4)
+    x = crand(rng, 100000)
+    taps = port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.5 / 10)
+    want = port.fir_decimate_cc(x, 10, taps)
+    for block in (4096, 8192, 65536):
+        got = np.frombuffer(run(["fir_decimate_cc", 10, 0.05, "HAMMING"], x, block), c64)
+        assert got.size == want.size
+        assert relrms(got, want) <= TOL
+
+
+def test_cli_fm_audio_stages(port):
+    rng = np.random.default_rng(5)
+    x = crand(rng, 40000)
+    got = np.frombuffer(run(["fmdemod_quadri_cf"], x), f32)
+    assert relrms(got, port.fmdemod_quadri_cf(x)[0]) <= TOL
+    a = rng.uniform(-1.5, 1.5, 50000).astype(f32)
+    assert run(["limit_ff"], a) == port.limit_ff(a, 1.0).tobytes()
+    assert run(["limit_ff", 0.5], a) == port.limit_ff(a, 0.5).tobytes()
+    got = np.frombuffer(run(["deemphasis_wfm_ff", 48000, 50e-6], a), f32)
+    assert relrms(got, port.deemphasis_wfm_ff(a, 50e-6, 48000)[0]) <= TOL
+    got = np.frombuffer(run(["fractional_decimator_ff", 5], a), f32)
+    want = port.fractional_decimator_ff(a, 5.0)
+    assert abs(got.size - want.size) <= 1
+    m = min(got.size, want.size)
+    assert relrms(got[:m], want[:m]) <= TOL
+    got = np.frombuffer(run(["fractional_decimator_ff", 2.5, 4], a), f32)
+    want = port.fractional_decimator_ff(a, 2.5, 4)
+    m = min(got.size, want.size)
+    assert m >= want.size - 2 and relrms(got[:m], want[:m]) <= TOL
+    got = np.frombuffer(run(["fastagc_ff", 1024, 0.8], a), f32)
+    want = port.fastagc_ff(a, 1024, 0.8)
+    assert got.size == want.size and relrms(got, want) <= TOL
+
+
+def test_cli_deemphasis_nfm(port):
+    rng = np.random.default_rng(6)
+    a = rng.uniform(-1, 1, 30000).astype(f32)
+    taps = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    got = np.frombuffer(run(["deemphasis_nfm_ff", 48000], a), f32)
+    want = port.deemphasis_nfm_ff(a, taps)
+    assert got.size == want.size and relrms(got, want) <= TOL
+    p = subprocess.run([CLI, "deemphasis_nfm_ff", "12345"], input=b"", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"sample rate" in p.stderr
+
+
+def test_cli_bandpass_fir_fft(port):
+    """csdr.c:1810-1886 with the CLI's own fft_size rule (next_pow2(taps), doubled when the padding is < 200)."""
+    rng = np.random.default_rng(7)
+    x = crand(rng, 60000)
+    nt = port.firdes_filter_len(0.02)
+    fft = port.next_pow2(nt)
+    if fft - nt < 200:
+        fft *= 2
+    taps = port.firdes_bandpass_c(nt, -0.1, 0.2)
+    want = port.bandpass_fir_fft_cc(x, taps, fft)
+    got = np.frombuffer(run(["bandpass_fir_fft_cc", -0.1, 0.2, 0.02], x, 4096), c64)
+    assert got.size == want.size and relrms(got, want) <= TOL
+
+
+def test_cli_fastddc_pipe(port):
+    """`fastddc_fwd_cc D tbw | fastddc_inv_cc shift D tbw` (csdr.c:2255-2378) as two processes joined by a pipe."""
+    rng = np.random.default_rng(8)
+    D, tbw, shift = 16, 0.02, 0.11
+    ddc, err = port.fastddc_init(tbw, D, shift)
+    assert err == 0
+    x = crand(rng, 9 * ddc.input_size + 100)
+    spectra = port.fastddc_fwd_cc(x, ddc)
+    want = port.fastddc_inv_cc(spectra, ddc, port.fastddc_taps_fft(ddc, shift, D))
+    mid = run(["fastddc_fwd_cc", D, tbw], x, 4096)
+    assert relrms(np.frombuffer(mid, c64), spectra.ravel()) <= TOL
+    got = np.frombuffer(run(["fastddc_inv_cc", shift, D, tbw], np.frombuffer(mid, np.uint8), 4096), c64)
+    assert got.size == want.size and relrms(got, want) <= TOL
+
+
+def wfm_pipeline(cli, iq, block=None):
+    stages = [["convert_u8_f"], ["shift_addition_cc", "-0.085"], ["fir_decimate_cc", "10", "0.05", "HAMMING"], ["fmdemod_quadri_cf"],
+              ["fractional_decimator_ff", "5"], ["deemphasis_wfm_ff", "48000", "50e-6"], ["convert_f_s16"]]
+    env = dict(os.environ)
+    if block:
+        env["CSDR_AMD_BLOCK"] = str(block)
+    procs = []
+    prev = subprocess.PIPE
+    for i, st in enumerate(stages):
+        p = subprocess.Popen([cli] + st, stdin=prev if i else subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        if i:
+            procs[-1].stdout.close()
+        prev = p.stdout
+        procs.append(p)
+    import threading
+    t = threading.Thread(target=lambda: (procs[0].stdin.write(iq.tobytes()), procs[0].stdin.close()))
+    t.start()
+    out = procs[-1].stdout.read()
+    t.join()
+    for p in procs:
+        p.wait(timeout=60)
+    return np.frombuffer(out, np.int16)
+
+
+def test_cli_wfm_shell_pipeline(port):
+    """README.md:66 as seven processes and as the fused `wfm_chain_u8_s16`, against the oracle chain and the reference's own CLI."""
+    rng = np.random.default_rng(9)
+    n = 480000
+    t = np.arange(n)
+    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * t) + 0.3 * rng.uniform(-1, 1, n)
+    sig = 0.7 * np.exp(1j * (2 * np.pi * np.cumsum(0.03125 * msg) + 2 * np.pi * 0.085 * t)) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    iq = np.empty(2 * n, f32); iq[0::2] = sig.real; iq[1::2] = sig.imag
+    iq = np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+    want_s16, _ = port.wfm_chain(iq, -0.085, 10, port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05))
+    piped = wfm_pipeline(CLI, iq, 16384)
+    fused = np.frombuffer(run(["wfm_chain_u8_s16", -0.085], iq, 65536), np.int16)
+    for got in (piped, fused):
+        m = min(got.size, want_s16.size)
+        assert m >= want_s16.size - 2
+        d = np.abs(got[:m].astype(np.int32) - want_s16[:m].astype(np.int32))
+        assert d.max() <= 1 and np.mean(d != 0) < 0.01            # float path then a truncating s16 cast: isolated +-1 LSB at most
+    if os.path.exists(REF_CLI):
+        ref = wfm_pipeline(REF_CLI, iq)
+        m = min(ref.size, piped.size, want_s16.size)               # the reference CLI's EOF handling differs in the tail
+        assert m > 9000
+        d = np.abs(ref[:m].astype(np.int32) - piped[:m].astype(np.int32))
+        assert d.max() <= 1 and np.mean(d != 0) < 0.01
