@@ -110,7 +110,7 @@ def main():
     S, T = args.streams, args.block
     assert T % 1024 == 0
     taps = ctx.firdes_lowpass_f(ctx.firdes_filter_len(0.05), 0.5 / 10, "HAMMING")      # csdr.c:1144-1158
-    pitch = 2 * T
+    pitch = 2 * T + int(os.environ.get("CSDR_BENCH_PITCH_PAD", "0"))     # row pitch in bytes (experiments: channel/bank spreading)
     # synthetic input resident in HBM (torch is only the allocator / RNG here)
     g = torch.Generator(device="cuda"); g.manual_seed(42 + rank)
     x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda", generator=g)

@@ -2,16 +2,25 @@
 //   fir_decimate_cc   libcsdr.c:528-549  (real taps on interleaved complexf, decimation D)
 //   deemphasis_nfm_ff libcsdr.c:1101-1128 (fixed real FIR on floats, no decimation)
 //
-// Layout / tiling: one workgroup = one (stream, tile of TO outputs).  The input window of
-// D*TO + taps - 1 samples is staged once through LDS with coalesced 16-byte global loads (interleaved
-// complexf kept as is: a float2 per sample), so every input sample is read from HBM once (+ halo).
-// Each lane then produces outputs from LDS; taps are wave-uniform and come through the scalar path (s_load -> SGPR operand).
+// k_fir_poly (the default): one wave = one (stream, tile of 64*R consecutive outputs).  The input window is staged ONCE through LDS,
+// but stored polyphase-decomposed: sample n goes to row n % D, column n / D.  Output o needs x[D*o + a*D + p] = row p, column o + a, so
+// for a fixed tap phase p the lanes of a wave read CONSECUTIVE columns (conflict-free 8/16-byte ds_reads) instead of addresses D*8 bytes
+// apart (which for D = 10 hit the same LDS banks 4 ways -- the round-1 generic kernel ran at 31-37 % of the HBM roofline because of that).
+// Each lane produces R consecutive outputs from a sliding register window, so an LDS value is used R times; the taps sit in LDS in the same
+// phase-major order, zero padded to a multiple of R (uniform address = broadcast read).  One wave per workgroup and ~21 KiB of LDS at
+// D = 10 / 79 taps -> 7 independent waves per CU overlap their staging and their arithmetic.
+// Summation order differs from the reference's t = 0..taps-1 (phase-major here); both are float32 sums, parity gate 1e-5 relative RMS.
 // Algorithmic traffic: 8 B in + 8/D B out per input sample => HBM bound on paper (3.6 flop/B).
-// Measured (profiles/r1_ops.jsonl): 2.9 TB/s algorithmic at D=10/79 taps on long streams (37 % of peak), 1.4 TB/s at D=50/801 taps.
-// A register-blocked variant (5 consecutive outputs per lane, zero-padded taps) was tried in round 1 and was SLOWER (2.1 TB/s):
-// the kernel is not LDS-read bound; it is the next kernel to restructure (round 2).
+// k_fir_generic: natural-layout fallback for shapes whose polyphase tile does not fit in LDS.
 #include "common.hpp"
 using namespace csdr_amd;
+
+// Buffer loads with the hardware range check (out-of-window lanes read 0).  Declared as the LLVM intrinsics directly: hipcc 7.2's
+// __builtin_amdgcn_raw_buffer_load_b64 emits a single-dword load and duplicates it (checked in the ISA), so the builtins are avoided.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ f32x2_t buf_load_f32x2(i32x4_t rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ float buf_load_f32(i32x4_t rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
 namespace {
 
@@ -59,6 +68,175 @@ __global__ __launch_bounds__(256) void k_fir_generic(const float *__restrict__ i
     }
 }
 
+// Polyphase-layout kernel, see the file header.  blockDim = 64.  LDS: x[D][Q] of T, then ht[D][NA] floats.
+// NA = ceil(ntaps / D) rounded up to a multiple of 2R;  Q = 64*R + NA + R (+2 so that Q = 2 mod 4).
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ float zero_of<float>() { return 0.f; }
+template <> __device__ __forceinline__ float2 zero_of<float2>() { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ void mac(float &acc, float v, float h) { acc = fmaf(v, h, acc); }
+__device__ __forceinline__ void mac(float2 &acc, float2 v, float h) { acc.x = fmaf(v.x, h, acc.x); acc.y = fmaf(v.y, h, acc.y); }
+
+template <typename T, int R, int U>
+__global__ __launch_bounds__(64) void k_fir_poly(const T *__restrict__ in, T *__restrict__ out, int n_out, size_t in_pitch, size_t out_pitch,
+                                                 int D, const float *__restrict__ taps, int ntaps, int NA, int Q, int n_tiles, int tiles_per_wg)
+{
+    extern __shared__ float4 lds_raw[];
+    T *x = reinterpret_cast<T *>(lds_raw);
+    float *ht = reinterpret_cast<float *>(x + (size_t)D * Q);
+    constexpr int TO = 64 * R;
+    constexpr bool SWZ = sizeof(T) * R == 32;
+    const int lane = threadIdx.x;
+    int tile = blockIdx.x * tiles_per_wg;
+    const int tile_end = min(n_tiles, tile + tiles_per_wg);
+    if (tile >= tile_end) return;
+    const T *in_s = in + (size_t)blockIdx.y * in_pitch;
+    T *out_s = out + (size_t)blockIdx.y * out_pitch;
+    for (int k = lane; k < D * NA; k += 64) {                      // taps, phase major, zero padded: once per workgroup
+        const int p = k / NA, a = k - p * NA, t = a * D + p;
+        ht[k] = t < ntaps ? taps[t] : 0.f;
+    }
+    const int total = D * Q;                                       // total <= 64*U (host guarantees)
+    // LDS byte address of sample n = lane + 64u of a window: fixed per lane, computed once (row n % D, column n / D, swizzled), two 16-bit
+    // values per register.  Samples past the tile (n >= total) go to one spare cell behind the taps.
+    unsigned idx2[(U + 1) / 2];
+    {
+        const int dp = 64 % D, dq = 64 / D;
+        const unsigned spare = (unsigned)((size_t)D * Q * sizeof(T) + (size_t)D * NA * 4);
+        int p = lane % D, q = lane / D;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            unsigned byte = (unsigned)(p * Q + ((SWZ && q < (Q & ~3)) ? (q ^ ((q >> 3) & 2)) : q)) * (unsigned)sizeof(T);
+            if (lane + 64 * u >= total) byte = spare;
+            if (u & 1) idx2[u / 2] |= byte << 16; else idx2[u / 2] = byte;
+            p += dp; q += dq;
+            if (p >= D) { p -= D; q++; }
+        }
+    }
+    // The NEXT tile's window is register resident and in flight while the current tile is computed (U x 512 B per wave for complexf).
+    // A second window in flight (tiles t+1 and t+2) was tried: 303 VGPRs -> one wave per SIMD -> slower (3.2 vs 4.1 TB/s).
+    // Loads are buffer loads whose descriptor covers exactly the samples the tile reads: lanes past the window get 0 from the hardware
+    // range check -- no per-load compares, no branches, and every LDS cell of the tile is (re)written each time with data or zero.
+    T va[U];
+    auto fetch = [&](T (&v)[U], int t) {
+        const int outs = min(TO, n_out - t * TO);
+        const unsigned win_bytes = (unsigned)((outs - 1) * D + ntaps) * (unsigned)sizeof(T);
+        const unsigned long long base = (unsigned long long)(in_s + (size_t)t * TO * D);       // wave uniform
+        const i32x4_t rsrc = {(int)(unsigned)base, (int)((base >> 32) & 0xffffu), (int)win_bytes, 0x00020000};
+        const int voff = lane * (int)sizeof(T);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if constexpr (sizeof(T) == 8) {
+                const f32x2_t r = buf_load_f32x2(rsrc, voff, 64 * u * 8, 0);
+                v[u] = make_float2(r.x, r.y);
+            } else {
+                v[u] = buf_load_f32(rsrc, voff, 64 * u * 4, 0);
+            }
+        }
+    };
+    auto stage = [&](T (&v)[U]) {
+        char *xb = reinterpret_cast<char *>(x);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned byte = (u & 1) ? (idx2[u / 2] >> 16) : (idx2[u / 2] & 0xffffu);
+            *reinterpret_cast<T *>(xb + byte) = v[u];
+        }
+    };
+    // R consecutive samples m*R .. m*R+R-1 of a row.  For complexf with R = 4 a lane's chunk is 32 bytes, so the two 16-byte halves of
+    // consecutive lanes would only ever touch half of the LDS banks per instruction; every other 128-byte group is stored with its
+    // halves exchanged (column index bit 1 ^= bit 4), which makes both ds_read_b128 of a chunk conflict free.
+    auto chunk = [&](const char *rowb, int m, T *dstw) {
+        if constexpr (SWZ) {
+            const int lo_off = 32 * m + ((m & 4) << 2);             // bit 4 of the column index 4m -> exchange the 16-byte halves
+            const float4 lo = *reinterpret_cast<const float4 *>(rowb + lo_off);
+            const float4 hi = *reinterpret_cast<const float4 *>(rowb + (lo_off ^ 16));
+            dstw[0] = make_float2(lo.x, lo.y); dstw[1] = make_float2(lo.z, lo.w);
+            dstw[2] = make_float2(hi.x, hi.y); dstw[3] = make_float2(hi.z, hi.w);
+        } else {
+            const T *row = reinterpret_cast<const T *>(rowb);
+#pragma unroll
+            for (int r = 0; r < R; r++) dstw[r] = row[R * m + r];
+        }
+    };
+    auto block = [&](T (&acc)[R], const T *w0, const T *w1, const float *h) {   // R taps x R outputs on the window (w0, w1)
+#pragma unroll
+        for (int j = 0; j < R; j++)
+#pragma unroll
+            for (int r = 0; r < R; r++) mac(acc[r], (r + j < R) ? w0[r + j] : w1[r + j - R], h[j]);
+    };
+    auto compute = [&](int t) {
+        T acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = zero_of<T>();
+        const char *rowb = reinterpret_cast<const char *>(x);
+        const float *hp = ht;
+        for (int p = 0; p < D; p++, rowb += (size_t)Q * sizeof(T), hp += NA) {
+            T wa[R], wb[R];
+            chunk(rowb, lane, wa);
+            for (int a = 0, m = lane + 1; a < NA; a += 2 * R, m += 2) {   // NA is a multiple of 2R: two blocks per trip, no window moves
+                float h[2 * R];
+                chunk(rowb, m, wb);
+#pragma unroll
+                for (int r = 0; r < 2 * R; r++) h[r] = hp[a + r];
+                block(acc, wa, wb, h);
+                chunk(rowb, m + 1, wa);
+                block(acc, wb, wa, h + R);
+            }
+        }
+        const int outs = min(TO, n_out - t * TO);
+        T *dst = out_s + (size_t)t * TO + R * lane;
+        if (R * lane + R <= outs && sizeof(T) * R >= 16 && (((uintptr_t)dst) & 15) == 0) {          // whole lane: 16-byte stores
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+            const float *af = reinterpret_cast<const float *>(acc);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(T) * R / 16); k++) d4[k] = make_float4(af[4 * k], af[4 * k + 1], af[4 * k + 2], af[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) if (R * lane + r < outs) dst[r] = acc[r];
+        }
+    };
+    __syncthreads();
+    fetch(va, tile);
+    for (; tile < tile_end; tile++) {
+        stage(va);
+        __syncthreads();
+        if (tile + 1 < tile_end) fetch(va, tile + 1);
+        compute(tile);
+        __syncthreads();                                           // everyone is done reading x[][] before the next tile overwrites it
+    }
+}
+
+struct PolyCfg { int R, U, NA, Q; size_t lds; };
+static bool poly_cfg(int D, int ntaps, size_t elem, PolyCfg &c)
+{
+    const int rs[2] = {4, 2}, us[2] = {24, 44};
+    for (int i = 0; i < 2; i++) {
+        const int R = rs[i];
+        const int NA = ((ntaps + D - 1) / D + 2 * R - 1) / (2 * R) * (2 * R);
+        int Q = (64 * R + NA + R + 1) & ~1;
+        if (Q % 4 == 0) Q += 2;                                      // row pitch = 2 (mod 4) samples: the D rows of the staging scatter start in different banks
+        const size_t lds = (size_t)D * Q * elem + (size_t)D * NA * 4 + 32;   // + the spare cell
+        if (lds > 48u * 1024) continue;
+        for (int k = 0; k < 2; k++)
+            if ((size_t)D * Q <= 64u * us[k]) { c = {R, us[k], NA, Q, lds}; return true; }
+    }
+    return false;
+}
+template <typename T>
+static void launch_poly(csdr_amd_ctx *c, const PolyCfg &g, const T *in, T *out, int n_out, int n_streams, size_t in_pitch, size_t out_pitch,
+                        int D, const float *taps, int ntaps)
+{
+    // few, fat workgroups: ~16 resident-wave generations per CU at most; each walks a contiguous range of tiles with the next tile's loads in flight
+    const int n_tiles = cdiv(n_out, 64 * g.R);
+    static const long want = getenv("CSDR_AMD_FIR_WGS") ? atol(getenv("CSDR_AMD_FIR_WGS")) : 256L * 7 * 4;
+    const int per = (int)(((long)n_tiles * n_streams + want - 1) / want);
+    const int tiles_per_wg = per < 1 ? 1 : per;
+    dim3 grid(cdiv(n_tiles, tiles_per_wg), (unsigned)n_streams);
+#define POLY(RR, UU) hipLaunchKernelGGL((k_fir_poly<T, RR, UU>), grid, dim3(64), g.lds, c->stream, in, out, n_out, in_pitch, out_pitch, D, taps, ntaps, g.NA, g.Q, n_tiles, tiles_per_wg)
+    if (g.R == 4) { if (g.U == 24) POLY(4, 24); else POLY(4, 44); }
+    else          { if (g.U == 24) POLY(2, 24); else POLY(2, 44); }
+#undef POLY
+}
+
 } // namespace
 
 static int pick_tile(int D, int ntaps, int floats_per_sample, int n_out)
@@ -78,6 +256,12 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     if (decimation <= 0 || taps_length <= 0) return fail_msg(-3, "fir_decimate_cc: bad decimation/taps_length");
     if (input_size < taps_length || n_streams <= 0) return 0;
     const int n_out = (input_size - taps_length) / decimation + 1;     // libcsdr.c:536-538 loop bound
+    PolyCfg g;
+    if (!getenv("CSDR_AMD_FIR_GENERIC") && poly_cfg(decimation, taps_length, 8, g)) {
+        launch_poly<float2>(c, g, (const float2 *)in, (float2 *)out, n_out, n_streams, in_pitch, out_pitch, decimation, taps, taps_length);
+        CSDR_LAUNCH_CHECK();
+        return n_out;
+    }
     const int to = pick_tile(decimation, taps_length, 2, n_out);
     const size_t win_bytes = ((size_t)(to - 1) * decimation + taps_length) * 8;
     if (win_bytes > 160 * 1024 - 256) return fail_msg(-3, "fir_decimate_cc: %d taps exceed the LDS window (use the FFT path)", taps_length);
@@ -95,6 +279,12 @@ int csdr_amd_fir_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams,
     if (taps_length <= 0) return 0;
     const int n_out = input_size - taps_length;                         // libcsdr.c:1121: i < input_size - taps_length
     if (n_out <= 0 || n_streams <= 0) return 0;
+    PolyCfg g;
+    if (!getenv("CSDR_AMD_FIR_GENERIC") && poly_cfg(1, taps_length, 4, g)) {
+        launch_poly<float>(c, g, in, out, n_out, n_streams, in_pitch, out_pitch, 1, taps, taps_length);
+        CSDR_LAUNCH_CHECK();
+        return n_out;
+    }
     // window for n outputs of the generic kernel is (outs-1)*1 + ntaps, exactly what those outputs read
     const int to = pick_tile(1, taps_length, 1, n_out);
     const size_t win_bytes = ((size_t)(to - 1) + taps_length) * 4;
