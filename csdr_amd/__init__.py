@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcsdr_amd.so")
+LIB_PATH = os.environ.get("CSDR_AMD_LIB") or os.path.join(HERE, "libcsdr_amd.so")     # override: A/B builds on one GPU box
 ROOT = os.path.dirname(HERE)
 
 c64 = np.complex64

@@ -124,6 +124,13 @@ int csdr_amd_d2h(csdr_amd_ctx *c, void *dst, const void *src, size_t bytes)
     CSDR_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
+int csdr_amd_d2d(csdr_amd_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return 0;
+    CSDR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 int csdr_amd_memset(csdr_amd_ctx *c, void *dst, int value, size_t bytes)
 {
     CSDR_HIP(hipMemsetAsync(dst, value, bytes, c->stream));

@@ -2,18 +2,27 @@
 //
 // Same argv grammar, same raw native-endian sample streams on stdin/stdout as the reference CLI (csdr.c:56-181 usage string;
 // per-command loops cited below), so a shell pipeline keeps working when `csdr` is replaced by this binary.  What differs, on purpose:
-//   * each process moves LARGE blocks (CSDR_AMD_BLOCK elements, default 262144) through the GPU per iteration instead of
-//     1024/16384-sample blocks per libcsdr call; the sample VALUES follow the reference's block semantics exactly where they are
-//     observable (shift_* re-seed every 1024 samples like csdr.c:785,836,911-918; fastagc_ff works on its own block size) and the
-//     stream models verified against the reference (fir_decimate_cc refeed, fractional_decimator_ff refeed, overlap-add, fastddc);
-//   * EOF is clean: every complete input sample is processed once; the reference's stale extra block at EOF is not emitted;
-//   * the dynamic bufsize preamble ("csdr"+int, csdr.c:325-392) and the --fifo/--fd live retune channel are not implemented yet:
-//     `setbuf` passes data through unchanged, CSDR_DYNAMIC_BUFSIZE_ON is rejected with a message.
+//   * each process moves LARGE blocks (CSDR_AMD_BLOCK elements, default 262144; 65536 when a control channel is open) through the GPU
+//     per iteration instead of 1024/16384-sample blocks per libcsdr call; the sample VALUES follow the reference's block semantics
+//     exactly where they are observable (shift_* re-seed every 1024 samples like csdr.c:785,836,911-918; fastagc_ff works on its own
+//     block size; decimating_shift_addition_cc restarts its recurrence every the_bufsize samples) and the stream models verified against
+//     the reference (fir_decimate_cc refeed, fractional_decimator_ff refeed, overlap-add, fastddc);
+//   * EOF is clean: every complete input sample is processed once; the reference's stale extra block at EOF is not emitted.
+// Wire protocol either side of every command (csdr.c:325-419): CSDR_FIXED_BUFSIZE and CSDR_PRINT_BUFSIZES are honoured,
+// CSDR_DYNAMIC_BUFSIZE_ON=1 makes every command consume the 8-byte "csdr"+int preamble from stdin and send its own (with the per-command
+// size rule of the reference: /decimation, /rate, fft_size, ...) before its data; `setbuf N` starts such a chain.
+// Live retune (csdr.c:252-323): `--fifo <path>` / `--fd <n>` in place of the rate arguments of shift_addition_cc, bandpass_fir_fft_cc and
+// fastddc_inv_cc; the newest complete line is applied between two blocks.
+// Fusion (the part of f1 that a process-per-command shell pipeline cannot give): `csdr chain "<cmd> <args> | <cmd> <args> | ..."` runs
+// the listed hot-path commands in ONE process with every intermediate stream resident in HBM (PCIe carries only the first input and the
+// last output), and replaces the README.md:66 WFM pattern by the fused matrix-core kernel.
 // There is no CPU fallback: without a gfx950 device the process exits with status 3 and the reason on stderr.
 #include "../../include/csdr_amd.h"
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,6 +63,9 @@ struct Stage {
     // returns elements written; *consumed = input elements that need not be presented again
     virtual long process(csdr_amd_ctx *c, const void *d_in, size_t n_in, void *d_out, size_t out_cap, size_t *consumed) = 0;
     virtual size_t out_capacity(size_t n_in) { return n_in + 16; }
+    virtual int next_bufsize(int b) { return b; }                   // what the reference passes to sendbufsize() for this command
+    virtual const char *ctl_format() { return nullptr; }            // scanf format of a control line, if the command has a control channel
+    virtual void retune(csdr_amd_ctx *, float, float) {}
 };
 
 struct Convert : Stage {
@@ -77,13 +89,16 @@ struct Convert : Stage {
 };
 
 struct Shift : Stage {   // csdr.c:703-925
-    int variant; float rate; float phase = 0; int aux; bool real_in = false; csdr_complexf *rot = nullptr;
+    int variant; float rate; float phase = 0; int aux; bool real_in = false; csdr_complexf *rot = nullptr; size_t rot_cap = 0;
     Shift(int v, float r, int a) : variant(v), rate(r), aux(a) { in_elem = 8; out_elem = 8; granule = 1024; }
+    const char *ctl_format() override { return variant == CSDR_SHIFT_ADDITION && !real_in ? "%g\n" : nullptr; }
+    void retune(csdr_amd_ctx *, float r, float) override { rate = r; fprintf(stderr, "csdr shift_addition_cc: reinitialized to %g\n", r); }   // phase carries on (csdr.c:896-921)
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
     {
         *cons = n;
         if (real_in) {   // shift_addition_fc csdr.c:927-980
-            if (!rot) rot = (csdr_complexf *)csdr_amd_malloc(c, 8 * (block_elems() + 4 * 65536 + 8192));
+            if (!rot) { rot_cap = n + 8192; rot = (csdr_complexf *)csdr_amd_malloc(c, 8 * rot_cap); }
+            else if (n + 16 > rot_cap) { csdr_amd_free(c, rot); rot_cap = n + 8192; rot = (csdr_complexf *)csdr_amd_malloc(c, 8 * rot_cap); }
             MUST(csdr_amd_rotator_generate(c, CSDR_SHIFT_ADDITION, rate, &phase, rot, n, 1024, 0));
             MUST(csdr_amd_mix_fc(c, (const float *)i, (csdr_complexf *)o, rot, 1, n, n, n));
         } else MUST(csdr_amd_shift_cc(c, variant, rate, &phase, (const csdr_complexf *)i, (csdr_complexf *)o, 1, n, n, n, 1024, aux));
@@ -104,6 +119,7 @@ struct FirDecimate : Stage {   // csdr.c:1114-1177
         MUST(csdr_amd_h2d(c, d_taps, t.data(), 4 * ntaps));
     }
     size_t out_capacity(size_t n) override { return n / D + 16; }
+    int next_bufsize(int b) override { return b / D; }               // csdr.c:1140
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
     {
         long no = csdr_amd_fir_decimate_cc(c, (const csdr_complexf *)i, (csdr_complexf *)o, 1, (int)n, n, cap, D, d_taps, ntaps);
@@ -152,7 +168,11 @@ struct FastAgc : Stage {   // csdr.c:1377-1406
     int block; float ref; float *d_state;
     FastAgc(csdr_amd_ctx *c, int b, float r) : block(b), ref(r)
     {
-        granule = b; flush_partial = false;
+        granule = b; flush_partial = false; init_state(c, b);
+    }
+    int next_bufsize(int) override { return block; }                 // csdr.c:1386
+    void init_state(csdr_amd_ctx *c, int b)
+    {
         d_state = (float *)csdr_amd_malloc(c, 4 * (2 * (size_t)b + 4)); MUST(csdr_amd_memset(c, d_state, 0, 4 * (2 * (size_t)b + 4)));
     }
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
@@ -167,6 +187,7 @@ struct FracDec : Stage {   // csdr.c:1465-1525
     csdr_amd_fracdec *d; float rate;
     FracDec(float r, int points, const float *taps, int ntaps) : rate(r) { d = csdr_amd_fracdec_create(r, points, taps, ntaps); if (!d) { badsyntax(csdr_amd_last_error()); exit(255); } }
     size_t out_capacity(size_t n) override { return (size_t)(n / rate) + 64; }
+    int next_bufsize(int b) override { return (int)(b / rate); }     // csdr.c:1497
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
     {
         int processed = 0;
@@ -176,11 +197,19 @@ struct FracDec : Stage {   // csdr.c:1465-1525
 };
 
 struct Bandpass : Stage {   // csdr.c:1810-1886
-    csdr_amd_fftfilt *f; int inp;
+    csdr_amd_fftfilt *f; int inp; int n_taps, win;
+    const char *ctl_format() override { return "%g %g\n"; }
+    void retune(csdr_amd_ctx *, float lo, float hi) override       // new band edges, the overlap carries on (csdr.c:1862-1880)
+    {
+        fprintf(stderr, "csdr bandpass_fir_fft_cc: filter initialized, low_cut = %g, high_cut = %g\n", lo, hi);
+        std::vector<csdr_complexf> t(n_taps);
+        csdr_amd_firdes_bandpass_c(t.data(), n_taps, lo, hi, win);
+        MUST(csdr_amd_fftfilt_set_taps(f, t.data(), n_taps));
+    }
     Bandpass(csdr_amd_ctx *c, float lo, float hi, float tbw, int window, size_t block)
     {
         in_elem = 8; out_elem = 8; flush_partial = false;
-        const int ntaps = csdr_amd_firdes_filter_len(tbw);
+        const int ntaps = csdr_amd_firdes_filter_len(tbw); n_taps = ntaps; win = window;
         int fft = csdr_amd_next_pow2(ntaps);
         if (fft - ntaps < 200) fft <<= 1;                                            // csdr.c:1834-1836
         inp = fft - ntaps + 1;
@@ -209,6 +238,7 @@ struct DdcFwd : Stage {   // csdr.c:2255-2300
         granule = ddc.input_size;
     }
     size_t out_capacity(size_t n) override { return (n / ddc.input_size + 1) * (size_t)ddc.fft_size; }
+    int next_bufsize(int) override { return ddc.fft_size; }          // csdr.c:2274
     long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t, size_t *cons) override
     {
         const int nb = (int)(n / ddc.input_size); *cons = (size_t)nb * ddc.input_size;
@@ -218,13 +248,22 @@ struct DdcFwd : Stage {   // csdr.c:2255-2300
 };
 
 struct DdcInv : Stage {   // csdr.c:2302-2378
-    csdr_amd_fastddc_inv *f; csdr_fastddc_t ddc; int maxb;
-    DdcInv(csdr_amd_ctx *c, float shift, int D, float tbw, int window, size_t block)
+    csdr_amd_fastddc_inv *f = nullptr; csdr_fastddc_t ddc; int maxb, dec, win; float tbw_;
+    void build(csdr_amd_ctx *c, float shift)                         // the reference rebuilds everything on a retune, status included (csdr.c:2329-2376)
+    {
+        if (f) csdr_amd_fastddc_inv_destroy(f);
+        if (csdr_amd_fastddc_init(&ddc, tbw_, dec, shift)) { badsyntax("error in fastddc_init()"); exit(1); }
+        f = csdr_amd_fastddc_inv_create(c, tbw_, dec, &shift, 1, win, maxb); if (!f) die("fastddc_inv_create");
+    }
+    const char *ctl_format() override { return "%g\n"; }
+    void retune(csdr_amd_ctx *c, float shift, float) override { build(c, shift); }
+    int next_bufsize(int) override { return ddc.post_input_size / ddc.post_decimation; }   // csdr.c:2339
+    DdcInv(csdr_amd_ctx *c, float shift, int D, float tbw, int window, size_t block) : dec(D), win(window), tbw_(tbw)
     {
         in_elem = 8; out_elem = 8; flush_partial = false;
         if (csdr_amd_fastddc_init(&ddc, tbw, D, shift)) { badsyntax("error in fastddc_init()"); exit(1); }
         maxb = (int)(block / ddc.fft_size + 2);
-        f = csdr_amd_fastddc_inv_create(c, tbw, D, &shift, 1, window, maxb); if (!f) die("fastddc_inv_create");
+        build(c, shift);
         granule = ddc.fft_size;
     }
     size_t out_capacity(size_t n) override { return (n / ddc.fft_size + 1) * (size_t)(ddc.post_input_size / ddc.post_decimation + 2) + 16; }
@@ -248,9 +287,45 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
         w = csdr_amd_wfm_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024); if (!w) die("wfm_create");
     }
     size_t out_capacity(size_t n) override { return n / 50 + 64; }
+    int next_bufsize(int b) override { return b / 50; }
     long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
     { *cons = n; long na = csdr_amd_wfm_process(w, (const uint8_t *)i, 2 * n, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
 };
+
+struct DecimatingShift : Stage {   // csdr.c:851-875: one libcsdr call per the_bufsize samples, status carried between calls
+    int dec, bufsize; float dsa[3]; void *d_dsa, *d_status;
+    DecimatingShift(csdr_amd_ctx *c, float rate, int decimation, int the_bufsize) : dec(decimation), bufsize(the_bufsize)
+    {
+        in_elem = 8; out_elem = 8; granule = the_bufsize; flush_partial = true;
+        csdr_amd_shift_addition_init(rate * (float)decimation, dsa);        // decimating_shift_addition_init libcsdr_gpl.c:126-129
+        d_dsa = csdr_amd_malloc(c, 12); d_status = csdr_amd_malloc(c, 12);
+        MUST(csdr_amd_h2d(c, d_dsa, dsa, 12)); MUST(csdr_amd_memset(c, d_status, 0, 12));
+    }
+    size_t out_capacity(size_t n) override { return n / dec + n / bufsize + 16; }
+    int next_bufsize(int b) override { return b / dec; }             // csdr.c:861
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    {
+        *cons = n;
+        long total = 0;
+        for (size_t at = 0; at < n; at += bufsize) {
+            const int m = (int)((n - at < (size_t)bufsize) ? n - at : bufsize);
+            MUST(csdr_amd_decimating_shift_addition_cc(c, (const csdr_complexf *)i + at, (csdr_complexf *)o + total, 1, m, m, m, d_dsa, dec, d_status));
+            int st[3]; MUST(csdr_amd_d2h(c, st, d_status, 12));
+            total += st[2];
+        }
+        return total;
+    }
+};
+
+// ------------------------------------------------------------------ wire protocol (csdr.c:325-419)
+int g_dynamic = 0, g_fixed = 1024, g_fixed_big = 16384, g_print = 0;
+void parse_env()
+{   // csdr.c:393-419
+    if (const char *e = getenv("CSDR_DYNAMIC_BUFSIZE_ON")) { g_dynamic = !!atoi(e); g_fixed = 0; }
+    else if (const char *f = getenv("CSDR_FIXED_BUFSIZE")) g_fixed = g_fixed_big = atoi(f);
+    if (const char *e = getenv("CSDR_PRINT_BUFSIZES")) g_print = atoi(e);
+}
+int unitround(int what) { return what <= 0 ? 4 : ((what - 1) & ~3) + 4; }   // csdr.c:352-358
 
 bool read_full(void *buf, size_t bytes, size_t *got)
 {   // blocking read until `bytes` or EOF; returns false on EOF (with *got possibly > 0)
@@ -272,60 +347,280 @@ void write_full(const void *buf, size_t bytes)
         done += (size_t)r;
     }
 }
+int get_bufsize(bool big)
+{   // csdr.c:330-341: in dynamic mode the first 8 bytes of stdin are "csdr" + int
+    if (!g_dynamic) return unitround(big ? g_fixed_big : g_fixed);
+    int first[2] = {0, 0}; size_t got = 0;
+    read_full(first, 8, &got);
+    if (got != 8 || memcmp(first, "csdr", 4) != 0) {
+        badsyntax("warning! Did not match preamble on the beginning of the stream. You should put \"csdr setbuf <buffer size>\" at the beginning of the chain! Falling back to default buffer size: 1024");
+        return 1024;
+    }
+    if (first[1] <= 0) { badsyntax("warning! Invalid buffer size."); exit(254); }
+    if (g_print) fprintf(stderr, "csdr %s: buffer size set to %d\n", g_cmd, unitround(first[1]));
+    return unitround(first[1]);
+}
+void send_bufsize(int size)
+{   // csdr.c:375-391
+    if (!g_dynamic) return;
+    if (g_print) fprintf(stderr, "csdr %s: next process proposed input buffer size is %d\n", g_cmd, size);
+    int first[2]; memcpy(first, "csdr", 4); first[1] = size;
+    write_full(first, 8);
+}
 
-int run(csdr_amd_ctx *c, Stage *s, size_t block)
+// ------------------------------------------------------------------ control channel (csdr.c:252-323)
+struct Control {
+    int fd = 0; char buf[1024]; int fill = 0;
+    bool open_from(int argc, char **argv)
+    {
+        if (argc < 4) return false;
+        if (!strcmp(argv[2], "--fifo")) { fprintf(stderr, "csdr %s: fifo control mode on\n", g_cmd); fd = open(argv[3], O_RDONLY); }
+        else if (!strcmp(argv[2], "--fd")) { if (sscanf(argv[3], "%d", &fd) <= 0) return false; fprintf(stderr, "csdr %s: fd control mode on, fd=%d\n", g_cmd, fd); }
+        else return false;
+        if (fd <= 0) { fd = 0; return false; }
+        fcntl(fd, F_SETFL, fcntl(fd, F_GETFL, 0) | O_NONBLOCK);
+        return true;
+    }
+    // newest complete line, parsed with the command's scanf format; non-blocking
+    bool poll(const char *fmt, float *a, float *b)
+    {
+        if (!fd) return false;
+        const ssize_t r = read(fd, buf + fill, sizeof(buf) - 1 - fill);
+        if (r <= 0) return false;
+        const int end = fill + (int)r;
+        int prev = 0, last = 0;
+        for (int i = 0; i < end; i++) if (buf[i] == '\n') { prev = last; last = i + 1; }
+        if (!last) { fill = end; return false; }
+        buf[end] = 0;
+        float x = 0, y = 0;
+        const int n = sscanf(buf + prev, fmt, &x, &y);
+        memmove(buf, buf + last, end - last); fill = end - last;
+        if (n < 1) return false;
+        *a = x; *b = y; return true;
+    }
+    void wait_first(const char *fmt, float *a, float *b) { while (!poll(fmt, a, b)) usleep(10000); }
+};
+
+// ------------------------------------------------------------------ the streaming loop: one or more stages, intermediates in HBM
+struct Link { Stage *s; char *d_in[2] = {nullptr, nullptr}; char *d_stage = nullptr; int cur = 0; size_t cap_b = 0, have_b = 0; };   // byte counts: a pipe carries bytes,
+                                                                                                               // the reader picks the element size
+int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps, Control *ctl)
 {
-    if (block < 4 * s->min_block) block = 4 * s->min_block;
-    if (block < 2 * s->granule) block = 2 * s->granule;
-    const size_t cap_in = block + 64;
-    const size_t cap_out = s->out_capacity(cap_in) + 64;
+    const size_t n_st = stages.size();
+    std::vector<Link> L(n_st);
+    for (size_t k = 0; k < n_st; k++) {
+        L[k].s = stages[k]; L[k].cap_b = caps[k] * stages[k]->in_elem;
+        for (int b = 0; b < (k == 0 ? 1 : 2); b++) { L[k].d_in[b] = (char *)csdr_amd_malloc(c, L[k].cap_b + 256); if (!L[k].d_in[b]) die("device buffers"); }
+        if (k) { L[k].d_stage = (char *)csdr_amd_malloc(c, L[k].cap_b + 256); if (!L[k].d_stage) die("device buffers"); }
+    }
+    Stage *first = stages[0], *last = stages[n_st - 1];
+    const size_t block = caps[0];
+    const size_t cap_out = last->out_capacity(caps[n_st - 1]) + 64;
     void *h_in = nullptr, *h_out = nullptr;
-    if (hipHostMalloc(&h_in, cap_in * s->in_elem, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&h_out, cap_out * s->out_elem, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&h_in, (block + 64) * first->in_elem, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&h_out, cap_out * last->out_elem, hipHostMallocDefault) != hipSuccess) {
         fprintf(stderr, "csdr %s: cannot allocate pinned host buffers\n", g_cmd); exit(3);
     }
-    void *d_in = csdr_amd_malloc(c, cap_in * s->in_elem + 64), *d_out = csdr_amd_malloc(c, cap_out * s->out_elem + 64);
-    if (!d_in || !d_out) die("device buffers");
-    size_t have = 0;                                               // elements at the front of h_in: the unconsumed tail of the previous block
+    void *d_out = csdr_amd_malloc(c, cap_out * last->out_elem + 256);
+    if (!d_out) die("device buffers");
+    size_t have0 = 0;                                              // elements at the front of h_in: the unconsumed tail of the previous block
     for (bool eof = false; !eof;) {
         size_t got = 0;
-        if (!read_full((char *)h_in + have * s->in_elem, (block - have) * s->in_elem, &got)) eof = true;
-        have += got / s->in_elem;
-        size_t n = have;
-        if (!(eof && s->flush_partial)) n -= n % s->granule;
-        if (n == 0) continue;
-        MUST(csdr_amd_h2d(c, d_in, h_in, n * s->in_elem));
-        size_t consumed = 0;
-        const long n_out = s->process(c, d_in, n, d_out, cap_out, &consumed);
-        if (n_out > 0) { MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_out * s->out_elem)); write_full(h_out, (size_t)n_out * s->out_elem); }
-        if (consumed > have) consumed = have;
-        if (consumed == 0 && have == block && !eof) { fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); return 1; }
-        memmove(h_in, (char *)h_in + consumed * s->in_elem, (have - consumed) * s->in_elem);
-        have -= consumed;
+        if (!read_full((char *)h_in + have0 * first->in_elem, (block - have0) * first->in_elem, &got)) eof = true;
+        have0 += got / first->in_elem;
+        if (ctl && ctl->fd && first->ctl_format()) { float a, b; if (ctl->poll(first->ctl_format(), &a, &b)) first->retune(c, a, b); }
+        size_t n = have0;
+        if (!(eof && first->flush_partial)) n -= n % first->granule;
+        if (n == 0 && !(eof && n_st > 1)) continue;                 // at EOF a chain still flushes what its later stages carry
+        if (n) MUST(csdr_amd_h2d(c, L[0].d_in[0], h_in, n * first->in_elem));
+        // stage 0 consumes from the host-staged block; stages k > 0 consume [carry | new] from their own device buffer
+        size_t n_in = n; const char *d_src = L[0].d_in[0];
+        long n_out = 0;
+        for (size_t k = 0; k < n_st; k++) {
+            Stage *s = stages[k];
+            void *dst = d_out; size_t dst_cap = cap_out;
+            if (k + 1 < n_st) {
+                Link &nx = L[k + 1];
+                // several element-wise kernels want 16-byte aligned pointers: when the consumer's carry is not a multiple of 16 bytes the
+                // producer writes to an aligned staging buffer and the result is appended behind the carry by a device copy
+                dst = (nx.have_b % 16 == 0) ? nx.d_in[nx.cur] + nx.have_b : nx.d_stage;
+                dst_cap = (nx.cap_b - nx.have_b) / s->out_elem;
+                if (nx.have_b % s->out_elem) { fprintf(stderr, "csdr chain: element sizes of \"%s\" and its consumer do not line up\n", g_cmd); return 1; }
+            }
+            size_t consumed = 0;
+            n_out = n_in ? s->process(c, d_src, n_in, dst, dst_cap, &consumed) : 0;
+            if (k == 0) {
+                if (consumed > have0) consumed = have0;
+                if (consumed == 0 && have0 == block && !eof) { fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); return 1; }
+                memmove(h_in, (char *)h_in + consumed * first->in_elem, (have0 - consumed) * first->in_elem);
+                have0 -= consumed;
+            } else {
+                Link &lk = L[k];
+                const size_t rest_b = lk.have_b - consumed * s->in_elem;
+                if (rest_b) MUST(csdr_amd_d2d(c, lk.d_in[lk.cur ^ 1], lk.d_in[lk.cur] + consumed * s->in_elem, rest_b));
+                lk.cur ^= 1; lk.have_b = rest_b;
+            }
+            if (k + 1 == n_st) break;
+            Link &nx = L[k + 1];
+            if (n_out > 0 && nx.have_b % 16 != 0) MUST(csdr_amd_d2d(c, nx.d_in[nx.cur] + nx.have_b, nx.d_stage, (size_t)n_out * s->out_elem));
+            nx.have_b += (n_out > 0 ? (size_t)n_out : 0) * s->out_elem;
+            n_in = nx.have_b / stages[k + 1]->in_elem;
+            if (!(eof && stages[k + 1]->flush_partial)) n_in -= n_in % stages[k + 1]->granule;
+            d_src = nx.d_in[nx.cur];
+        }
+        if (n_out > 0) { MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_out * last->out_elem)); write_full(h_out, (size_t)n_out * last->out_elem); }
     }
     return 0;
 }
 
-int passthrough()
-{   // setbuf / clone / through: plumbing commands pipelines use around the hot path (csdr.c:432-470, 2046-2082)
+int passthrough(bool read_preamble, int send_size)
+{   // setbuf / clone / through: plumbing commands pipelines use around the hot path (csdr.c:429-451, 2046-2082)
+    int b = read_preamble ? get_bufsize(false) : 0;
+    send_bufsize(send_size > 0 ? send_size : b);
     std::vector<char> buf(1 << 20);
     for (;;) { size_t got = 0; bool more = read_full(buf.data(), buf.size(), &got); if (got) write_full(buf.data(), got); if (!more) return 0; }
+}
+
+// Build the operator for one command line.  `block` = the largest input this stage will be handed in one call.
+// ctl: opened when the command line carries --fifo/--fd (single-command mode only).  Returns nullptr after printing why.
+Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control *ctl, int the_bufsize)
+{
+    g_cmd = argv[1];
+    const std::string cmd = argv[1];
+    const bool has_ctl = ctl && ctl->open_from(argc, argv);
+    if (cmd == "convert_u8_f") return new Convert(0, 1, 4);
+    if (cmd == "convert_f_u8") return new Convert(1, 4, 1);
+    if (cmd == "convert_s8_f") return new Convert(2, 1, 4);
+    if (cmd == "convert_f_s8") return new Convert(3, 4, 1);
+    if (cmd == "convert_f_s16" || cmd == "convert_f_i16") return new Convert(4, 4, 2);
+    if (cmd == "convert_s16_f" || cmd == "convert_i16_f") return new Convert(5, 2, 4);
+    if (cmd == "convert_f_s24") { Convert *cv = new Convert(6, 4, 3); cv->bigendian = argc > 2 && !strcmp(argv[2], "--bigendian"); cv->granule = 4; return cv; }
+    if (cmd == "convert_s24_f") { Convert *cv = new Convert(7, 3, 4); cv->bigendian = argc > 2 && !strcmp(argv[2], "--bigendian"); cv->granule = 4; return cv; }
+    if (cmd == "shift_math_cc" || cmd == "shift_addition_cc" || cmd == "shift_table_cc" || cmd == "shift_addfast_cc" || cmd == "shift_unroll_cc" || cmd == "shift_addition_fc") {
+        float rate = 0;
+        if (has_ctl && cmd == "shift_addition_cc") { float d; ctl->wait_first("%g\n", &rate, &d); }
+        else { if (argc <= 2) { badsyntax("need required parameter (rate)"); return nullptr; } sscanf(argv[2], "%g", &rate); }
+        int variant = CSDR_SHIFT_ADDITION, aux = 0;
+        if (cmd == "shift_math_cc") variant = CSDR_SHIFT_MATH;
+        else if (cmd == "shift_table_cc") { variant = CSDR_SHIFT_TABLE; aux = 65536; if (argc > 3) sscanf(argv[3], "%d", &aux); }       // csdr.c:731
+        else if (cmd == "shift_addfast_cc") variant = CSDR_SHIFT_ADDFAST;
+        else if (cmd == "shift_unroll_cc") { variant = CSDR_SHIFT_UNROLL; aux = 1024; }                                                  // csdr.c:821
+        Shift *sh = new Shift(variant, rate, aux);
+        if (cmd == "shift_addition_fc") { sh->real_in = true; sh->in_elem = 4; }
+        return sh;
+    }
+    if (cmd == "decimating_shift_addition_cc") {
+        if (argc <= 2) { badsyntax("need required parameter (rate)"); return nullptr; }
+        float rate; int dec = 1; sscanf(argv[2], "%g", &rate); if (argc > 3) sscanf(argv[3], "%d", &dec);
+        if (dec < 1) { badsyntax("decimation must be >= 1"); return nullptr; }
+        return new DecimatingShift(c, rate, dec, the_bufsize);
+    }
+    if (cmd == "fir_decimate_cc") {
+        if (argc <= 2) { badsyntax("need required parameter (decimation factor)"); return nullptr; }
+        int factor; sscanf(argv[2], "%d", &factor);
+        float tbw = 0.05f; if (argc >= 4) sscanf(argv[3], "%g", &tbw);
+        int window = CSDR_WINDOW_HAMMING; if (argc >= 5) window = window_from(argv[4]); else fprintf(stderr, "csdr fir_decimate_cc: window = HAMMING\n");
+        return new FirDecimate(c, factor, tbw, window);
+    }
+    if (cmd == "fmdemod_quadri_cf" || cmd == "fmdemod_quadri_novect_cf") return new Fmdemod(c);
+    if (cmd == "limit_ff") { float m = 1.0f; if (argc >= 3) sscanf(argv[2], "%g", &m); return new Limit(m); }
+    if (cmd == "deemphasis_wfm_ff") {
+        if (argc <= 3) { badsyntax("need required parameters (sample rate, tau)"); return nullptr; }
+        int rate; float tau; sscanf(argv[2], "%d", &rate); sscanf(argv[3], "%g", &tau);
+        fprintf(stderr, "csdr deemphasis_wfm_ff: tau = %g, sample_rate = %d\n", tau, rate);
+        return new DeemphWfm(c, rate, tau);
+    }
+    if (cmd == "deemphasis_nfm_ff") { if (argc <= 2) { badsyntax("need required parameter (sample rate)"); return nullptr; } int rate; sscanf(argv[2], "%d", &rate); return new DeemphNfm(c, rate); }
+    if (cmd == "fastagc_ff") { int b = 1024; float ref = 1.0f; if (argc >= 3) sscanf(argv[2], "%d", &b); if (argc >= 4) sscanf(argv[3], "%g", &ref); return new FastAgc(c, b, ref); }
+    if (cmd == "fractional_decimator_ff") {
+        if (argc <= 2) { badsyntax("need required parameters (rate)"); return nullptr; }
+        float rate; sscanf(argv[2], "%g", &rate);
+        int points = 12; if (argc >= 4) sscanf(argv[3], "%d", &points);
+        if (points & 1) { badsyntax("num_poly_points should be even"); return nullptr; }
+        if (points < 2) { badsyntax("num_poly_points should be >= 2"); return nullptr; }
+        std::vector<float> taps;
+        if (argc >= 5 && !strcmp(argv[4], "--prefilter")) {                          // csdr.c:1481-1486, 1499-1507: only --prefilter enables it
+            const float tbw = 0.03f;
+            const int nt = csdr_amd_firdes_filter_len(tbw); taps.resize(nt);
+            csdr_amd_firdes_lowpass_f(taps.data(), nt, 0.5f / (rate - tbw), CSDR_WINDOW_HAMMING);
+        }
+        return new FracDec(rate, points, taps.empty() ? nullptr : taps.data(), (int)taps.size());
+    }
+    if (cmd == "bandpass_fir_fft_cc") {
+        float lo = 0, hi = 0, tbw = 0;
+        if (has_ctl) { ctl->wait_first("%g %g\n", &lo, &hi); if (argc <= 4) { badsyntax("need more required parameters (transition_bw)"); return nullptr; } }
+        else { if (argc <= 4) { badsyntax("need required parameters (low_cut, high_cut, transition_bw)"); return nullptr; } sscanf(argv[2], "%g", &lo); sscanf(argv[3], "%g", &hi); }
+        sscanf(argv[4], "%g", &tbw);
+        return new Bandpass(c, lo, hi, tbw, argc >= 6 ? window_from(argv[5]) : CSDR_WINDOW_HAMMING, block);
+    }
+    if (cmd == "fastddc_fwd_cc") {
+        if (argc <= 2) { badsyntax("need required parameter (decimation)"); return nullptr; }
+        int D; sscanf(argv[2], "%d", &D); float tbw = 0.05f; if (argc > 3) sscanf(argv[3], "%g", &tbw);
+        return new DdcFwd(c, D, tbw, block);
+    }
+    if (cmd == "fastddc_inv_cc") {
+        float shift = 0; int plus = 0;
+        if (has_ctl) { float d; ctl->wait_first("%g\n", &shift, &d); plus = 1; }
+        else { if (argc <= 2) { badsyntax("need required parameter (rate)"); return nullptr; } sscanf(argv[2], "%g", &shift); }
+        if (argc <= 3 + plus) { badsyntax("need required parameter (decimation)"); return nullptr; }
+        int D; sscanf(argv[3 + plus], "%d", &D);
+        float tbw = 0.05f; if (argc > 4 + plus) sscanf(argv[4 + plus], "%g", &tbw);
+        return new DdcInv(c, shift, D, tbw, argc > 5 + plus ? window_from(argv[5 + plus]) : CSDR_WINDOW_HAMMING, block);
+    }
+    if (cmd == "wfm_chain_u8_s16") { float shift = 0; if (argc > 2) sscanf(argv[2], "%g", &shift); return new WfmChain(c, shift, block); }
+    fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]);
+    return nullptr;
+}
+
+// "a b c | d e" -> {{"csdr","a","b","c"},{"csdr","d","e"}}
+std::vector<std::vector<std::string>> split_chain(const char *spec)
+{
+    std::vector<std::vector<std::string>> out(1, std::vector<std::string>(1, "csdr"));
+    std::string tok;
+    auto flush = [&]() { if (!tok.empty()) { if (tok != "csdr" || out.back().size() > 1) out.back().push_back(tok); tok.clear(); } };
+    for (const char *p = spec; *p; p++) {
+        if (*p == '|') { flush(); out.push_back(std::vector<std::string>(1, "csdr")); }
+        else if (*p == ' ' || *p == '\t' || *p == '\n') flush();
+        else tok.push_back(*p);
+    }
+    flush();
+    return out;
+}
+
+bool is_wfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *shift)
+{   // README.md:66 exactly: the shape the fused matrix-core kernel implements
+    if (cmds.size() != 7) return false;
+    auto is = [&](size_t k, std::initializer_list<const char *> want) {
+        if (cmds[k].size() != want.size() + 1) return false;
+        size_t j = 1; for (const char *w : want) { if (w[0] != '*' && cmds[k][j] != w) return false; j++; }
+        return true;
+    };
+    if (!is(0, {"convert_u8_f"}) || !is(1, {"shift_addition_cc", "*"}) || !is(2, {"fir_decimate_cc", "10", "0.05", "HAMMING"}) || !is(3, {"fmdemod_quadri_cf"}) ||
+        !is(4, {"fractional_decimator_ff", "5"}) || !is(5, {"deemphasis_wfm_ff", "48000", "50e-6"}) || !is(6, {"convert_f_s16"})) return false;
+    return sscanf(cmds[1][2].c_str(), "%g", shift) == 1;
 }
 
 } // namespace
 
 int main(int argc, char **argv)
 {
+    parse_env();
     if (argc <= 1 || !strcmp(argv[1], "--help")) {
         fprintf(stderr, "csdr (MI355X back end): convert_u8_f convert_f_u8 convert_s8_f convert_f_s8 convert_f_s16 convert_s16_f convert_f_i16 convert_i16_f "
                         "convert_f_s24 convert_s24_f shift_math_cc shift_addition_cc shift_addition_fc shift_table_cc shift_addfast_cc shift_unroll_cc "
-                        "fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff deemphasis_nfm_ff limit_ff "
-                        "fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c setbuf clone through wfm_chain_u8_s16\n");
+                        "decimating_shift_addition_cc fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff "
+                        "deemphasis_nfm_ff limit_ff fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c "
+                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, chain \"<cmd> <args> | <cmd> <args> ...\"\n");
         return -1;
     }
     g_cmd = argv[1];
     const std::string cmd = argv[1];
-    if (getenv("CSDR_DYNAMIC_BUFSIZE_ON") && atoi(getenv("CSDR_DYNAMIC_BUFSIZE_ON"))) return badsyntax("CSDR_DYNAMIC_BUFSIZE_ON is not supported by the MI355X back end yet");
-    if (cmd == "setbuf" || cmd == "clone" || cmd == "through") return passthrough();
+    if (cmd == "setbuf") {   // csdr.c:429-438
+        if (argc <= 2) return badsyntax("need required parameter (buffer size)");
+        int b = 0; sscanf(argv[2], "%d", &b);
+        if (b <= 0) return badsyntax("buffer size <= 0 is invalid");
+        return passthrough(false, b);
+    }
+    if (cmd == "clone" || cmd == "REM" || cmd == "through") return passthrough(true, 0);
     if (cmd == "firdes_lowpass_f" || cmd == "firdes_bandpass_c") {   // csdr.c:1251-1335: print the designed taps ("%g " each), --octave wraps them in a plot script
         const bool bp = cmd == "firdes_bandpass_c";
         const int a0 = bp ? 5 : 4;                                    // argv index of the optional window
@@ -351,87 +646,48 @@ int main(int argc, char **argv)
         if (octave) { fflush(stdout); getchar(); }                   // keep octave's window open until the user closes the pipe
         return 0;
     }
+    if (cmd == "fractional_decimator_ff" && argc > 2) { float r = 0; sscanf(argv[2], "%g", &r); if (r == 1) return passthrough(true, 0); }   // csdr.c:1494
     const char *dev = getenv("CSDR_AMD_DEVICE");
     csdr_amd_ctx *c = csdr_amd_ctx_create(dev ? atoi(dev) : 0, nullptr);
     if (!c) { fprintf(stderr, "csdr %s: %s\n", g_cmd, csdr_amd_last_error()); return 3; }
-    const size_t block = block_elems();
-    Stage *s = nullptr;
-    if (cmd == "convert_u8_f") s = new Convert(0, 1, 4);
-    else if (cmd == "convert_f_u8") s = new Convert(1, 4, 1);
-    else if (cmd == "convert_s8_f") s = new Convert(2, 1, 4);
-    else if (cmd == "convert_f_s8") s = new Convert(3, 4, 1);
-    else if (cmd == "convert_f_s16" || cmd == "convert_f_i16") s = new Convert(4, 4, 2);
-    else if (cmd == "convert_s16_f" || cmd == "convert_i16_f") s = new Convert(5, 2, 4);
-    else if (cmd == "convert_f_s24") { Convert *cv = new Convert(6, 4, 3); cv->bigendian = argc > 2 && !strcmp(argv[2], "--bigendian"); cv->granule = 4; s = cv; }
-    else if (cmd == "convert_s24_f") { Convert *cv = new Convert(7, 3, 4); cv->bigendian = argc > 2 && !strcmp(argv[2], "--bigendian"); cv->granule = 4; s = cv; }
-    else if (cmd == "shift_math_cc" || cmd == "shift_addition_cc" || cmd == "shift_table_cc" || cmd == "shift_addfast_cc" || cmd == "shift_unroll_cc" || cmd == "shift_addition_fc") {
-        if (argc <= 2) return badsyntax("need required parameter (rate)");
-        if (!strcmp(argv[2], "--fifo") || !strcmp(argv[2], "--fd")) return badsyntax("--fifo/--fd control is not supported by the MI355X back end yet");
-        float rate; sscanf(argv[2], "%g", &rate);
-        int variant = CSDR_SHIFT_ADDITION, aux = 0;
-        if (cmd == "shift_math_cc") variant = CSDR_SHIFT_MATH;
-        else if (cmd == "shift_table_cc") { variant = CSDR_SHIFT_TABLE; aux = 65536; if (argc > 3) sscanf(argv[3], "%d", &aux); }       // csdr.c:731
-        else if (cmd == "shift_addfast_cc") variant = CSDR_SHIFT_ADDFAST;
-        else if (cmd == "shift_unroll_cc") { variant = CSDR_SHIFT_UNROLL; aux = 1024; }                                                  // csdr.c:821
-        Shift *sh = new Shift(variant, rate, aux);
-        if (cmd == "shift_addition_fc") { sh->real_in = true; sh->in_elem = 4; }
-        s = sh;
-    }
-    else if (cmd == "fir_decimate_cc") {
-        if (argc <= 2) return badsyntax("need required parameter (decimation factor)");
-        int factor; sscanf(argv[2], "%d", &factor);
-        float tbw = 0.05f; if (argc >= 4) sscanf(argv[3], "%g", &tbw);
-        int window = CSDR_WINDOW_HAMMING; if (argc >= 5) window = window_from(argv[4]); else fprintf(stderr, "fir_decimate_cc: window = HAMMING\n");
-        s = new FirDecimate(c, factor, tbw, window);
-    }
-    else if (cmd == "fmdemod_quadri_cf" || cmd == "fmdemod_quadri_novect_cf") s = new Fmdemod(c);
-    else if (cmd == "limit_ff") { float m = 1.0f; if (argc >= 3) sscanf(argv[2], "%g", &m); s = new Limit(m); }
-    else if (cmd == "deemphasis_wfm_ff") {
-        if (argc <= 3) return badsyntax("need required parameters (sample rate, tau)");
-        int rate; float tau; sscanf(argv[2], "%d", &rate); sscanf(argv[3], "%g", &tau);
-        fprintf(stderr, "csdr deemphasis_wfm_ff: tau = %g, sample_rate = %d\n", tau, rate);
-        s = new DeemphWfm(c, rate, tau);
-    }
-    else if (cmd == "deemphasis_nfm_ff") { if (argc <= 2) return badsyntax("need required parameter (sample rate)"); int rate; sscanf(argv[2], "%d", &rate); s = new DeemphNfm(c, rate); }
-    else if (cmd == "fastagc_ff") { int b = 1024; float ref = 1.0f; if (argc >= 3) sscanf(argv[2], "%d", &b); if (argc >= 4) sscanf(argv[3], "%g", &ref); s = new FastAgc(c, b, ref); }
-    else if (cmd == "fractional_decimator_ff") {
-        if (argc <= 2) return badsyntax("need required parameters (rate)");
-        float rate; sscanf(argv[2], "%g", &rate);
-        int points = 12; if (argc >= 4) sscanf(argv[3], "%d", &points);
-        if (points & 1) return badsyntax("num_poly_points should be even");
-        if (points < 2) return badsyntax("num_poly_points should be >= 2");
-        if (rate == 1) return passthrough();
-        std::vector<float> taps;
-        if (argc >= 5) {
-            float tbw = 0.03f; int window = CSDR_WINDOW_HAMMING;
-            if (strcmp(argv[4], "--prefilter")) { sscanf(argv[4], "%g", &tbw); if (argc >= 6) window = window_from(argv[5]); }
-            if (!strcmp(argv[4], "--prefilter")) {                                 // csdr.c:1481-1486, 1499-1507: only --prefilter enables it
-                const int nt = csdr_amd_firdes_filter_len(tbw); taps.resize(nt);
-                csdr_amd_firdes_lowpass_f(taps.data(), nt, 0.5f / (rate - tbw), window);
-            }
+    size_t block = block_elems();
+    std::vector<Stage *> stages; std::vector<size_t> caps;
+    Control ctl;
+    std::vector<std::vector<std::string>> cmds;
+    if (cmd == "chain") {
+        if (argc <= 2) return badsyntax("need the pipeline as one argument: \"<cmd> <args> | <cmd> <args> ...\"");
+        cmds = split_chain(argv[2]);
+        float shift = 0;
+        if (is_wfm_pattern(cmds, &shift)) {
+            fprintf(stderr, "csdr chain: WFM receive pattern recognised -> fused matrix-core kernel\n");
+            char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
+            cmds.assign(1, {"csdr", "wfm_chain_u8_s16", sh});
         }
-        s = new FracDec(rate, points, taps.empty() ? nullptr : taps.data(), (int)taps.size());
+    } else {
+        cmds.assign(1, std::vector<std::string>(argv, argv + argc));
     }
-    else if (cmd == "bandpass_fir_fft_cc") {
-        if (argc <= 4) return badsyntax("need required parameters (low_cut, high_cut, transition_bw)");
-        if (!strcmp(argv[2], "--fifo") || !strcmp(argv[2], "--fd")) return badsyntax("--fifo/--fd control is not supported by the MI355X back end yet");
-        float lo, hi, tbw; sscanf(argv[2], "%g", &lo); sscanf(argv[3], "%g", &hi); sscanf(argv[4], "%g", &tbw);
-        s = new Bandpass(c, lo, hi, tbw, argc >= 6 ? window_from(argv[5]) : CSDR_WINDOW_HAMMING, block);
+    const int in_bufsize = get_bufsize(cmds[0].size() > 1 && (cmds[0][1] == "shift_addition_cc" || cmds[0][1] == "decimating_shift_addition_cc" || cmds[0][1] == "shift_addition_fc"));
+    int out_bufsize = in_bufsize;
+    size_t cap = block; bool cap_is_bytes = false;
+    for (size_t k = 0; k < cmds.size(); k++) {
+        std::vector<char *> av; for (auto &t : cmds[k]) av.push_back(const_cast<char *>(t.c_str()));
+        if (av.size() < 2) return badsyntax("empty command in chain");
+        // element size of the next command is only known once it is built; size its block for the worst case (1-byte elements) first
+        Stage *s = make_stage(c, (int)av.size(), av.data(), cap, cmds.size() == 1 ? &ctl : nullptr, out_bufsize);
+        if (!s) return -1;
+        if (cap_is_bytes) cap = cap / s->in_elem;
+        if (k == 0 && ctl.fd && block > 65536 && !getenv("CSDR_AMD_BLOCK")) cap = block = 65536;        // retune latency
+        if (cap < 4 * s->min_block) cap = 4 * s->min_block;
+        if (cap < 2 * s->granule) cap = 2 * s->granule;
+        if (k == 0) { cap -= cap % s->granule; block = cap; }
+        stages.push_back(s); caps.push_back(cap + (k ? 64 : 0));
+        out_bufsize = s->next_bufsize(out_bufsize);
+        cap = s->out_capacity(caps.back()) * s->out_elem + 8 * (size_t)65536 * 8;    // BYTES the next stage may be handed: this stage's output plus its own carry
+        cap_is_bytes = true;
     }
-    else if (cmd == "fastddc_fwd_cc") {
-        if (argc <= 2) return badsyntax("need required parameter (decimation)");
-        int D; sscanf(argv[2], "%d", &D); float tbw = 0.05f; if (argc > 3) sscanf(argv[3], "%g", &tbw);
-        s = new DdcFwd(c, D, tbw, block);
-    }
-    else if (cmd == "fastddc_inv_cc") {
-        if (argc <= 3) return badsyntax("need required parameters (rate, decimation)");
-        float shift; int D; sscanf(argv[2], "%g", &shift); sscanf(argv[3], "%d", &D);
-        float tbw = 0.05f; if (argc > 4) sscanf(argv[4], "%g", &tbw);
-        s = new DdcInv(c, shift, D, tbw, argc > 5 ? window_from(argv[5]) : CSDR_WINDOW_HAMMING, block);
-    }
-    else if (cmd == "wfm_chain_u8_s16") { float shift = 0; if (argc > 2) sscanf(argv[2], "%g", &shift); s = new WfmChain(c, shift, block); }
-    else { fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]); return -1; }
-    const int rc = run(c, s, block);
+    g_cmd = argv[1];
+    send_bufsize(out_bufsize);
+    const int rc = run(c, stages, caps, &ctl);
     (void)csdr_amd_ctx_sync(c);
     return rc;
 }

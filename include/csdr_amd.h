@@ -50,6 +50,7 @@ void *csdr_amd_malloc(csdr_amd_ctx *ctx, size_t bytes);
 void  csdr_amd_free(csdr_amd_ctx *ctx, void *dptr);
 int   csdr_amd_h2d(csdr_amd_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* sync */
 int   csdr_amd_d2h(csdr_amd_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* sync */
+int   csdr_amd_d2d(csdr_amd_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);    /* async, regions must not overlap */
 int   csdr_amd_memset(csdr_amd_ctx *ctx, void *dst_dev, int value, size_t bytes);           /* async */
 
 /* HIP-event timing on the context's stream (bench.py: the kernel stream is not torch's stream) */

@@ -144,6 +144,15 @@ def test_cli_fastddc_pipe(port):
     assert got.size == want.size and relrms(got, want) <= TOL
 
 
+def fm_iq(rng, n):
+    """u8 IQ of an FM signal 0.085 fs above centre (the WFM chain shifts it down): well conditioned for the demodulator, unlike noise."""
+    t = np.arange(n)
+    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * t) + 0.3 * rng.uniform(-1, 1, n)
+    sig = 0.7 * np.exp(1j * (2 * np.pi * np.cumsum(0.03125 * msg) + 2 * np.pi * 0.085 * t)) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    iq = np.empty(2 * n, f32); iq[0::2] = sig.real; iq[1::2] = sig.imag
+    return np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+
+
 def wfm_pipeline(cli, iq, block=None):
     stages = [["convert_u8_f"], ["shift_addition_cc", "-0.085"], ["fir_decimate_cc", "10", "0.05", "HAMMING"], ["fmdemod_quadri_cf"],
               ["fractional_decimator_ff", "5"], ["deemphasis_wfm_ff", "48000", "50e-6"], ["convert_f_s16"]]
@@ -170,13 +179,7 @@ def wfm_pipeline(cli, iq, block=None):
 
 def test_cli_wfm_shell_pipeline(port):
     """README.md:66 as seven processes and as the fused `wfm_chain_u8_s16`, against the oracle chain and the reference's own CLI."""
-    rng = np.random.default_rng(9)
-    n = 480000
-    t = np.arange(n)
-    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * t) + 0.3 * rng.uniform(-1, 1, n)
-    sig = 0.7 * np.exp(1j * (2 * np.pi * np.cumsum(0.03125 * msg) + 2 * np.pi * 0.085 * t)) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))
-    iq = np.empty(2 * n, f32); iq[0::2] = sig.real; iq[1::2] = sig.imag
-    iq = np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+    iq = fm_iq(np.random.default_rng(9), 480000)
     want_s16, _ = port.wfm_chain(iq, -0.085, 10, port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05))
     piped = wfm_pipeline(CLI, iq, 16384)
     fused = np.frombuffer(run(["wfm_chain_u8_s16", -0.085], iq, 65536), np.int16)
@@ -191,3 +194,101 @@ def test_cli_wfm_shell_pipeline(port):
         assert m > 9000
         d = np.abs(ref[:m].astype(np.int32) - piped[:m].astype(np.int32))
         assert d.max() <= 1 and np.mean(d != 0) < 0.01
+
+
+# ---------------------------------------------------------------- f1: protocol, control channel, in-process chains
+def test_cli_decimating_shift_addition(port):
+    """csdr.c:851-875: one library call per the_bufsize (16384 by default) samples, status carried."""
+    rng = np.random.default_rng(10)
+    x = crand(rng, 3 * 16384 + 5000)
+    got = np.frombuffer(run(["decimating_shift_addition_cc", 0.07, 6], x, 32768), c64)
+    outs, st = [], (0, 0.0, 0)
+    for at in range(0, x.size, 16384):
+        y, st = port.decimating_shift_addition_cc(x[at:at + 16384], 0.07, 6, st)
+        outs.append(y)
+    want = np.concatenate(outs)
+    assert got.size == want.size and relrms(got, want) <= TOL
+
+
+def test_cli_chain_equals_pipeline(port):
+    """`csdr chain "a | b | c"`: same bytes as the process-per-command pipeline, intermediates never leave HBM."""
+    rng = np.random.default_rng(11)
+    iq = rng.integers(0, 256, 2 * 300000, dtype=np.uint8)
+    nfm = "convert_u8_f | shift_addition_cc 0.11 | fir_decimate_cc 50 0.005 HAMMING | fmdemod_quadri_cf | limit_ff | deemphasis_nfm_ff 48000 | fastagc_ff | convert_f_s16"
+    got = np.frombuffer(run(["chain", nfm], iq, 65536), np.int16)
+    taps = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    want, _ = port.nfm_chain(iq, 0.11, taps)
+    assert got.size == want.size
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.01
+    # the README.md:66 pattern is replaced by the fused kernel
+    wfm = "csdr convert_u8_f | csdr shift_addition_cc -0.085 | csdr fir_decimate_cc 10 0.05 HAMMING | csdr fmdemod_quadri_cf | csdr fractional_decimator_ff 5 | csdr deemphasis_wfm_ff 48000 50e-6 | csdr convert_f_s16"
+    env = dict(os.environ, CSDR_AMD_BLOCK="65536")
+    iq = fm_iq(rng, 300000)
+    p = subprocess.run([CLI, "chain", wfm], input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0 and b"fused" in p.stderr
+    got = np.frombuffer(p.stdout, np.int16)
+    want, _ = port.wfm_chain(iq, -0.085, 10, port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05))
+    m = min(got.size, want.size)
+    assert m >= want.size - 2
+    d = np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.01
+
+
+def test_cli_dynamic_bufsize_preamble(port):
+    """csdr.c:330-391: with CSDR_DYNAMIC_BUFSIZE_ON=1 every command eats the "csdr"+int preamble and sends its own (size rule per command)."""
+    import struct
+    rng = np.random.default_rng(12)
+    x = crand(rng, 50000)
+    env = dict(os.environ, CSDR_DYNAMIC_BUFSIZE_ON="1", CSDR_AMD_BLOCK="8192")
+
+    def one(cli, args, data):
+        p = subprocess.run([cli] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=60)
+        assert p.returncode == 0, p.stderr.decode()
+        return p.stdout
+    head = one(CLI, ["setbuf", "2048"], x.tobytes())
+    assert head[:8] == b"csdr" + struct.pack("i", 2048) and head[8:] == x.tobytes()
+    out = one(CLI, ["fir_decimate_cc", "10", "0.05", "HAMMING"], head)
+    assert out[:8] == b"csdr" + struct.pack("i", 204)                     # the_bufsize / factor
+    taps = port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05)
+    want = port.fir_decimate_cc(x, 10, taps)
+    got = np.frombuffer(out[8:], c64)
+    assert got.size == want.size and relrms(got, want) <= TOL
+    out2 = one(CLI, ["fmdemod_quadri_cf"], out)
+    assert out2[:8] == b"csdr" + struct.pack("i", 204)
+    if os.path.exists(REF_CLI):                                            # the reference CLI sends the same preambles
+        r1 = one(REF_CLI, ["fir_decimate_cc", "10", "0.05", "HAMMING"], head)
+        assert r1[:8] == out[:8]
+    # a stream without the preamble: warning, 8 bytes consumed, default size proposed (csdr.c:335-336)
+    p = subprocess.run([CLI, "convert_u8_f"], input=bytes(range(64)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=60)
+    assert b"preamble" in p.stderr and p.stdout[:8] == b"csdr" + struct.pack("i", 1024) and len(p.stdout) == 8 + 4 * 56
+
+
+def test_cli_fifo_retune(port, tmp_path):
+    """csdr.c:252-323, 883-921: `shift_addition_cc --fifo <path>`: first rate from the fifo, a later line retunes between blocks, phase carries on."""
+    import threading
+    import time
+    rng = np.random.default_rng(13)
+    x = crand(rng, 2 * 4096)
+    fifo = str(tmp_path / "ctl")
+    os.mkfifo(fifo)
+    env = dict(os.environ, CSDR_AMD_BLOCK="4096")
+    p = subprocess.Popen([CLI, "shift_addition_cc", "--fifo", fifo], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    ctl = open(fifo, "w")
+    ctl.write("0.05\n"); ctl.flush()
+    out = []
+    t = threading.Thread(target=lambda: out.append(p.stdout.read()))
+    t.start()
+    p.stdin.write(x[:4096].tobytes()); p.stdin.flush()
+    time.sleep(1.5)                                                        # block 1 is through; the process now waits for block 2
+    ctl.write("-0.2\n"); ctl.flush()
+    time.sleep(0.3)
+    p.stdin.write(x[4096:].tobytes()); p.stdin.close()
+    t.join(timeout=60)
+    ctl.close()
+    assert p.wait(timeout=30) == 0
+    got = np.frombuffer(out[0], c64)
+    a, ph = port.shift_addition_cc(x[:4096], 0.05)
+    b, _ = port.shift_addition_cc(x[4096:], -0.2, phase=ph)
+    assert got.size == x.size
+    assert relrms(got[:4096], a) <= TOL and relrms(got[4096:], b) <= TOL
