@@ -71,6 +71,20 @@ def lib():
     L.csdr_amd_h2d.argtypes = [vp, vp, vp, sz]
     L.csdr_amd_d2h.argtypes = [vp, vp, vp, sz]
     L.csdr_amd_memset.argtypes = [vp, vp, i, sz]
+    sh = C.c_short
+    L.csdr_amd_d2d.argtypes = [vp, vp, vp, sz]
+    L.csdr_amd_amdemod_cf.argtypes = [vp, vp, vp, sz]
+    L.csdr_amd_amdemod_estimator_cf.argtypes = [vp, vp, vp, sz, fl, fl]
+    L.csdr_amd_realpart_cf.argtypes = [vp, vp, vp, sz]
+    L.csdr_amd_logpower_cf.argtypes = [vp, vp, vp, sz, fl]
+    L.csdr_amd_fmdemod_atan_cf.argtypes = [vp, vp, vp, i, sz, sz, sz, vp]
+    L.csdr_amd_dcblock_ff.argtypes = [vp, vp, vp, i, sz, sz, sz, fl, vp]
+    L.csdr_amd_fastdcblock_ff.argtypes = [vp, vp, vp, i, i, i, sz, sz, vp]
+    L.csdr_amd_agc_ff.argtypes = [vp, vp, vp, i, sz, i, sz, sz, fl, fl, fl, fl, sh, sh, fl, vp]
+    L.csdr_amd_precalculate_window.argtypes = [vp, i, i]; L.csdr_amd_precalculate_window.restype = None
+    L.csdr_amd_fftcc_create.restype = vp; L.csdr_amd_fftcc_create.argtypes = [vp, i, i, i, i]
+    L.csdr_amd_fftcc_destroy.argtypes = [vp]; L.csdr_amd_fftcc_destroy.restype = None
+    L.csdr_amd_fftcc_process.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
     L.csdr_amd_timer_start.argtypes = [vp]
     L.csdr_amd_timer_stop_ms.argtypes = [vp, C.POINTER(fl)]
     L.csdr_amd_firdes_filter_len.argtypes = [fl]
@@ -294,6 +308,91 @@ class Context:
         no = self.check(self.L.csdr_amd_fir_ff(self.h, di.ptr, do.ptr, s, n, n, n, dt.ptr, taps.size), "fir_ff")
         y = self.download(do, f32, s * n).reshape(s, n)[:, :no]
         return y[0].copy() if squeeze else y.copy()
+
+
+    # ---- f2 blocks
+    def _cf_to_f(self, fn, x, *extra):
+        x = np.ascontiguousarray(x, c64).ravel()
+        di = self.upload(x); do = self.alloc(4 * x.size + 64)
+        self.check(fn(self.h, di.ptr, do.ptr, x.size, *extra), fn.__name__)
+        return self.download(do, f32, x.size)
+
+    def amdemod_cf(self, x): return self._cf_to_f(self.L.csdr_amd_amdemod_cf, x)
+    def amdemod_estimator_cf(self, x, alpha=0.0, beta=0.0): return self._cf_to_f(self.L.csdr_amd_amdemod_estimator_cf, x, alpha, beta)
+    def realpart_cf(self, x): return self._cf_to_f(self.L.csdr_amd_realpart_cf, x)
+    def logpower_cf(self, x, add_db=0.0): return self._cf_to_f(self.L.csdr_amd_logpower_cf, x, add_db)
+
+    def fmdemod_atan_cf(self, x, last_phase=None, calls=1):
+        x2, squeeze = self._2d(x, c64)
+        s, n = x2.shape
+        lp = np.zeros(s, f32) if last_phase is None else np.ascontiguousarray(last_phase, f32).reshape(s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); dl = self.upload(lp)
+        per = (n + calls - 1) // calls; at = 0
+        while at < n:
+            k = min(per, n - at)
+            self.check(self.L.csdr_amd_fmdemod_atan_cf(self.h, di.at(8 * at), do.at(4 * at), s, k, n, n, dl.ptr), "fmdemod_atan"); at += k
+        y = self.download(do, f32, s * n).reshape(s, n); lo = self.download(dl, f32, s)
+        return (y[0], lo[0]) if squeeze else (y, lo)
+
+    def dcblock_ff(self, x, a=0.0, state=None, calls=1):
+        x2, squeeze = self._2d(x, f32)
+        s, n = x2.shape
+        st = np.zeros(2 * s, f32) if state is None else np.ascontiguousarray(state, f32).reshape(2 * s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); ds = self.upload(st)
+        per = (n + calls - 1) // calls; at = 0
+        while at < n:
+            k = min(per, n - at)
+            self.check(self.L.csdr_amd_dcblock_ff(self.h, di.at(4 * at), do.at(4 * at), s, k, n, n, a, ds.ptr), "dcblock"); at += k
+        y = self.download(do, f32, s * n).reshape(s, n); so = self.download(ds, f32, 2 * s).reshape(s, 2)
+        return (y[0], so[0]) if squeeze else (y, so)
+
+    def fastdcblock_ff(self, x, block=1024, last_dc=None, calls=1):
+        x2, squeeze = self._2d(x, f32)
+        s, n = x2.shape; nb = n // block
+        ld = np.zeros(s, f32) if last_dc is None else np.ascontiguousarray(last_dc, f32).reshape(s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); dl = self.upload(ld)
+        per = max(1, (nb + calls - 1) // calls); b = 0
+        while b < nb:
+            k = min(per, nb - b)
+            self.check(self.L.csdr_amd_fastdcblock_ff(self.h, di.at(4 * b * block), do.at(4 * b * block), s, k, block, n, n, dl.ptr), "fastdcblock"); b += k
+        y = self.download(do, f32, s * n).reshape(s, n)[:, :nb * block]; lo = self.download(dl, f32, s)
+        return (y[0].copy(), lo[0]) if squeeze else (y.copy(), lo)
+
+    def agc_ff(self, x, block=1024, hang_time=200, reference=0.2, attack_rate=0.01, decay_rate=0.0001, max_gain=65536.0,
+               attack_wait=0, filter_alpha=0.999, last_gain=None):
+        x2, squeeze = self._2d(x, f32)
+        s, n = x2.shape
+        lg = np.ones(s, f32) if last_gain is None else np.ascontiguousarray(last_gain, f32).reshape(s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); dl = self.upload(lg)
+        self.check(self.L.csdr_amd_agc_ff(self.h, di.ptr, do.ptr, s, n, block, n, n, reference, attack_rate, decay_rate, max_gain, hang_time, attack_wait,
+                                          filter_alpha, dl.ptr), "agc_ff")
+        y = self.download(do, f32, s * n).reshape(s, n); lo = self.download(dl, f32, s)
+        return (y[0], lo[0]) if squeeze else (y, lo)
+
+    def precalculate_window(self, size, window="HAMMING"):
+        w = np.zeros(size, f32); self.L.csdr_amd_precalculate_window(_hp(w), size, WINDOWS[window]); return w
+
+    def fft_cc(self, x, fft_size, every_n, window="HAMMING", calls=1):
+        x = np.ascontiguousarray(x, c64).ravel()
+        frames_max = x.size // every_n + 1
+        f = self.L.csdr_amd_fftcc_create(self.h, fft_size, every_n, WINDOWS[window], frames_max)
+        if not f:
+            raise CsdrAmdError(self.err())
+        di = self.upload(x); do = self.alloc(8 * fft_size * frames_max + 64)
+        per = (x.size + calls - 1) // calls; at = 0; total = 0; left = 0
+        while at < x.size or left:
+            take = min(per, x.size - at) + left
+            start = at - left
+            cons = C.c_size_t(0)
+            nf = self.L.csdr_amd_fftcc_process(f, di.at(8 * start), take, do.at(8 * fft_size * total), C.byref(cons))
+            self.check(nf, "fft_cc")
+            total += nf
+            at = start + take; left = take - cons.value
+            if at >= x.size and (nf == 0 or left < every_n):
+                break
+        y = self.download(do, c64, fft_size * total)
+        self.L.csdr_amd_fftcc_destroy(f)
+        return y
 
     def fmdemod_quadri_cf(self, x, last=None):
         x2, squeeze = self._2d(x, c64)

@@ -430,4 +430,75 @@ decimating_shift_addition_status_t fastddc_inv_cc(complexf *input, complexf *out
     return st;
 }
 
+
+// ------------------------------------------------------------------ f2 blocks (libcsdr.c:861-941, 1004-1019, 1245-1303; libcsdr_gpl.c:163-260)
+void amdemod_cf(complexf *in, float *out, int n)
+{
+    if (n <= 0) return;
+    cf32 *din = stage_in<cf32>(4, (const cf32 *)in, n); float *dout = stage_out<float>(5, n);
+    MUST(csdr_amd_amdemod_cf(ctx(), (const csdr_complexf *)din, dout, n)); fetch(out, dout, n);
+}
+void amdemod_estimator_cf(complexf *in, float *out, int n, float alpha, float beta)
+{
+    if (n <= 0) return;
+    cf32 *din = stage_in<cf32>(4, (const cf32 *)in, n); float *dout = stage_out<float>(5, n);
+    MUST(csdr_amd_amdemod_estimator_cf(ctx(), (const csdr_complexf *)din, dout, n, alpha, beta)); fetch(out, dout, n);
+}
+void logpower_cf(complexf *in, float *out, int n, float add_db)
+{
+    if (n <= 0) return;
+    cf32 *din = stage_in<cf32>(4, (const cf32 *)in, n); float *dout = stage_out<float>(5, n);
+    MUST(csdr_amd_logpower_cf(ctx(), (const csdr_complexf *)din, dout, n, add_db)); fetch(out, dout, n);
+}
+float fmdemod_atan_cf(complexf *in, float *out, int n, float last_phase)
+{
+    if (n <= 0) return last_phase;
+    cf32 *din = stage_in<cf32>(4, (const cf32 *)in, n); float *dout = stage_out<float>(5, n); float *dl = stage_in<float>(6, &last_phase, 1);
+    MUST(csdr_amd_fmdemod_atan_cf(ctx(), (const csdr_complexf *)din, dout, 1, n, n, n, dl));
+    fetch(out, dout, n);
+    float l; fetch(&l, dl, 1); return l;
+}
+dcblock_preserve_t dcblock_ff(float *in, float *out, int n, float a, dcblock_preserve_t preserved)
+{
+    if (n <= 0) return preserved;
+    float *din = stage_in<float>(4, in, n); float *dout = stage_out<float>(5, n); float *ds = stage_in<float>(6, &preserved.last_input, 2);
+    MUST(csdr_amd_dcblock_ff(ctx(), din, dout, 1, n, n, n, a, ds));
+    fetch(out, dout, n);
+    fetch(&preserved.last_input, ds, 2);
+    return preserved;
+}
+float fastdcblock_ff(float *in, float *out, int n, float last_dc_level)
+{
+    if (n <= 0) return last_dc_level;
+    float *din = stage_in<float>(4, in, n); float *dout = stage_out<float>(5, n); float *dl = stage_in<float>(6, &last_dc_level, 1);
+    MUST(csdr_amd_fastdcblock_ff(ctx(), din, dout, 1, 1, n, n, n, dl));
+    fetch(out, dout, n);                                                 // in == out is allowed by the reference: the device buffers are distinct
+    float l; fetch(&l, dl, 1); return l;
+}
+float agc_ff(float *in, float *out, int n, float reference, float attack_rate, float decay_rate, float max_gain, short hang_time, short attack_wait_time,
+             float gain_filter_alpha, float last_gain)
+{
+    if (n <= 0) return last_gain;
+    float *din = stage_in<float>(4, in, n); float *dout = stage_out<float>(5, n); float *dl = stage_in<float>(6, &last_gain, 1);
+    MUST(csdr_amd_agc_ff(ctx(), din, dout, 1, n, n, n, n, reference, attack_rate, decay_rate, max_gain, hang_time, attack_wait_time, gain_filter_alpha, dl));
+    fetch(out, dout, n);
+    float l; fetch(&l, dl, 1); return l;
+}
+float *precalculate_window(int size, window_t window)
+{   // libcsdr.c:1256-1267: caller owns the malloc'ed table
+    float *w = (float *)malloc(sizeof(float) * (size > 0 ? size : 1));
+    if (w && size > 0) csdr_amd_precalculate_window(w, size, (int)window);
+    return w;
+}
+void apply_precalculated_window_c(complexf *in, complexf *out, int size, float *windowt)
+{   // libcsdr.c:1269-1276: one float product per component; a host loop is the whole job at this size, the device path is csdr_amd_fftcc
+    for (int k = 0; k < size; k++) { out[k].i = in[k].i * windowt[k]; out[k].q = in[k].q * windowt[k]; }
+}
+void apply_window_c(complexf *in, complexf *out, int size, window_t window)
+{   // libcsdr.c:1245-1254
+    float *w = precalculate_window(size, window);
+    apply_precalculated_window_c(in, out, size, w);
+    free(w);
+}
+
 } // extern "C"

@@ -317,6 +317,75 @@ struct DecimatingShift : Stage {   // csdr.c:851-875: one libcsdr call per the_b
     }
 };
 
+
+// ------------------------------------------------------------------ f2 commands (csdr.c:634-672, 927-983, 1088-1112, 1338-1375, 1569-1661)
+struct CfToF : Stage {   // amdemod_cf / amdemod_estimator_cf / realpart_cf / logpower_cf
+    int op; float p0;
+    CfToF(int o, float a) : op(o), p0(a) { in_elem = 8; out_elem = 4; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    {
+        *cons = n;
+        const csdr_complexf *x = (const csdr_complexf *)i; float *y = (float *)o;
+        switch (op) {
+            case 0: MUST(csdr_amd_amdemod_cf(c, x, y, n)); break;
+            case 1: MUST(csdr_amd_amdemod_estimator_cf(c, x, y, n, 0.f, 0.f)); break;            // csdr.c:1108
+            case 2: MUST(csdr_amd_realpart_cf(c, x, y, n)); break;
+            default: MUST(csdr_amd_logpower_cf(c, x, y, n, p0)); break;
+        }
+        return (long)n;
+    }
+};
+struct Gain : Stage {    // csdr.c:658-672
+    float g; Gain(float gg) : g(gg) { granule = 4; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { *cons = n; MUST(csdr_amd_gain_ff(c, (const float *)i, (float *)o, n, g)); return (long)n; }
+};
+struct FmdemodAtan : Stage {   // csdr.c:962-977
+    float *d_last;
+    FmdemodAtan(csdr_amd_ctx *c) { in_elem = 8; out_elem = 4; d_last = (float *)csdr_amd_malloc(c, 4); MUST(csdr_amd_memset(c, d_last, 0, 4)); }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { *cons = n; MUST(csdr_amd_fmdemod_atan_cf(c, (const csdr_complexf *)i, (float *)o, 1, n, n, n, d_last)); return (long)n; }
+};
+struct DcBlock : Stage {       // csdr.c:927-939 (a = 0 selects 0.999)
+    float *d_state;
+    DcBlock(csdr_amd_ctx *c) { d_state = (float *)csdr_amd_malloc(c, 8); MUST(csdr_amd_memset(c, d_state, 0, 8)); }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { *cons = n; MUST(csdr_amd_dcblock_ff(c, (const float *)i, (float *)o, 1, n, n, n, 0.f, d_state)); return (long)n; }
+};
+struct FastDcBlock : Stage {   // csdr.c:941-960
+    int block; float *d_last;
+    FastDcBlock(csdr_amd_ctx *c, int b) : block(b) { granule = b; flush_partial = false; d_last = (float *)csdr_amd_malloc(c, 4); MUST(csdr_amd_memset(c, d_last, 0, 4)); }
+    int next_bufsize(int) override { return block; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    {
+        const int nb = (int)(n / block); *cons = (size_t)nb * block;
+        if (nb) MUST(csdr_amd_fastdcblock_ff(c, (const float *)i, (float *)o, 1, nb, block, n, n, d_last));
+        return (long)nb * block;
+    }
+};
+struct Agc : Stage {           // csdr.c:1338-1375: one agc_ff call per the_bufsize samples
+    short hang, wait; float ref, attack, decay, maxg, alpha; int bufsize; float *d_gain;
+    Agc(csdr_amd_ctx *c, int the_bufsize) : bufsize(the_bufsize)
+    {
+        granule = the_bufsize;
+        d_gain = (float *)csdr_amd_malloc(c, 4); const float one = 1.0f; MUST(csdr_amd_h2d(c, d_gain, &one, 4));
+    }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { *cons = n; MUST(csdr_amd_agc_ff(c, (const float *)i, (float *)o, 1, n, bufsize, n, n, ref, attack, decay, maxg, hang, wait, alpha, d_gain)); return (long)n; }
+};
+struct FftCc : Stage {         // csdr.c:1569-1641 (binary output; --octave text mode is not offered)
+    csdr_amd_fftcc *f; int fft, every;
+    FftCc(csdr_amd_ctx *c, int fft_size, int every_n, int window, size_t block) : fft(fft_size), every(every_n)
+    {
+        in_elem = 8; out_elem = 8; granule = every_n; flush_partial = false;
+        f = csdr_amd_fftcc_create(c, fft_size, every_n, window, (int)(block / every_n + 2)); if (!f) die("fftcc_create");
+    }
+    size_t out_capacity(size_t n) override { return (n / every + 1) * (size_t)fft; }
+    int next_bufsize(int) override { return fft; }                   // csdr.c:1596
+    long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { size_t used = 0; int nf = csdr_amd_fftcc_process(f, (const csdr_complexf *)i, n, (csdr_complexf *)o, &used); MUST(nf); *cons = used; return (long)nf * fft; }
+};
+
 // ------------------------------------------------------------------ wire protocol (csdr.c:325-419)
 int g_dynamic = 0, g_fixed = 1024, g_fixed_big = 16384, g_print = 0;
 void parse_env()
@@ -566,6 +635,34 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
         float tbw = 0.05f; if (argc > 4 + plus) sscanf(argv[4 + plus], "%g", &tbw);
         return new DdcInv(c, shift, D, tbw, argc > 5 + plus ? window_from(argv[5 + plus]) : CSDR_WINDOW_HAMMING, block);
     }
+    if (cmd == "amdemod_cf") return new CfToF(0, 0);
+    if (cmd == "amdemod_estimator_cf") return new CfToF(1, 0);
+    if (cmd == "realpart_cf") return new CfToF(2, 0);
+    if (cmd == "logpower_cf") { float add_db = 0; if (argc >= 3) sscanf(argv[2], "%g", &add_db); return new CfToF(3, add_db); }
+    if (cmd == "gain_ff") { if (argc <= 2) { badsyntax("need required parameter (gain)"); return nullptr; } float g; sscanf(argv[2], "%g", &g); return new Gain(g); }
+    if (cmd == "fmdemod_atan_cf") return new FmdemodAtan(c);
+    if (cmd == "dcblock_ff") return new DcBlock(c);
+    if (cmd == "fastdcblock_ff") { int b = 1024; if (argc >= 3) sscanf(argv[2], "%d", &b); if (b <= 0) { badsyntax("block size must be positive"); return nullptr; } return new FastDcBlock(c, b); }
+    if (cmd == "agc_ff") {   // defaults csdr.c:1343-1361
+        Agc *a = new Agc(c, the_bufsize);
+        a->hang = 200; a->ref = 0.2f; a->attack = 0.01f; a->decay = 0.0001f; a->maxg = 65536; a->wait = 0; a->alpha = 0.999f;
+        if (argc >= 3) sscanf(argv[2], "%hd", &a->hang);
+        if (argc >= 4) sscanf(argv[3], "%g", &a->ref);
+        if (argc >= 5) sscanf(argv[4], "%g", &a->attack);
+        if (argc >= 6) sscanf(argv[5], "%g", &a->decay);
+        if (argc >= 7) sscanf(argv[6], "%g", &a->maxg);
+        if (argc >= 8) sscanf(argv[7], "%hd", &a->wait);
+        if (argc >= 9) sscanf(argv[8], "%g", &a->alpha);
+        return a;
+    }
+    if (cmd == "fft_cc") {
+        if (argc <= 3) { badsyntax("need required parameters (fft_size, out_of_every_n_samples)"); return nullptr; }
+        int fft, every; sscanf(argv[2], "%d", &fft); sscanf(argv[3], "%d", &every);
+        if (csdr_amd_log2n(fft) == -1) { badsyntax("fft_size should be power of 2"); return nullptr; }
+        if (every <= 0) { badsyntax("out_of_every_n_samples must be positive"); return nullptr; }
+        if (argc >= 6 && !strcmp(argv[5], "--octave")) { badsyntax("--octave text output is not offered by the MI355X back end"); return nullptr; }
+        return new FftCc(c, fft, every, argc >= 5 ? window_from(argv[4]) : CSDR_WINDOW_HAMMING, block);
+    }
     if (cmd == "wfm_chain_u8_s16") { float shift = 0; if (argc > 2) sscanf(argv[2], "%g", &shift); return new WfmChain(c, shift, block); }
     fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]);
     return nullptr;
@@ -609,6 +706,7 @@ int main(int argc, char **argv)
                         "convert_f_s24 convert_s24_f shift_math_cc shift_addition_cc shift_addition_fc shift_table_cc shift_addfast_cc shift_unroll_cc "
                         "decimating_shift_addition_cc fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff "
                         "deemphasis_nfm_ff limit_ff fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c "
+                        "amdemod_cf amdemod_estimator_cf fmdemod_atan_cf dcblock_ff fastdcblock_ff agc_ff gain_ff realpart_cf logpower_cf fft_cc "
                         "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, chain \"<cmd> <args> | <cmd> <args> ...\"\n");
         return -1;
     }

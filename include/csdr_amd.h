@@ -159,6 +159,35 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *ctx, csdr_amd_fracdec *d, con
 void  csdr_amd_fracdec_set_where(csdr_amd_fracdec *d, float where);   /* fractional_decimator_ff_t.where */
 float csdr_amd_fracdec_get_where(const csdr_amd_fracdec *d);
 
+/* ------------------------------------------------------------------ f2: the remaining simple blocks
+ * amdemod_cf / amdemod_estimator_cf libcsdr.c:861-901, realpart_cf csdr.c:634-645, logpower_cf libcsdr.c:1296-1303: flat arrays */
+int csdr_amd_amdemod_cf(csdr_amd_ctx *ctx, const csdr_complexf *in, float *out, size_t n);
+int csdr_amd_amdemod_estimator_cf(csdr_amd_ctx *ctx, const csdr_complexf *in, float *out, size_t n, float alpha, float beta);
+int csdr_amd_realpart_cf(csdr_amd_ctx *ctx, const csdr_complexf *in, float *out, size_t n);
+int csdr_amd_logpower_cf(csdr_amd_ctx *ctx, const csdr_complexf *in, float *out, size_t n, float add_db);
+/* fmdemod_atan_cf libcsdr.c:1004-1019.  last_phase_io: device float[n_streams] */
+int csdr_amd_fmdemod_atan_cf(csdr_amd_ctx *ctx, const csdr_complexf *in, float *out, int n_streams, size_t n,
+                             size_t in_pitch, size_t out_pitch, float *last_phase_io);
+/* dcblock_ff libcsdr.c:903-918.  state_io: device float[2*n_streams] = {last_input, last_output} (dcblock_preserve_t, libcsdr.h:110-114) */
+int csdr_amd_dcblock_ff(csdr_amd_ctx *ctx, const float *in, float *out, int n_streams, size_t n, size_t in_pitch, size_t out_pitch,
+                        float a, float *state_io);
+/* fastdcblock_ff libcsdr.c:920-941 over n_blocks consecutive blocks per stream.  last_dc_io: device float[n_streams] */
+int csdr_amd_fastdcblock_ff(csdr_amd_ctx *ctx, const float *in, float *out, int n_streams, int n_blocks, int block,
+                            size_t in_pitch, size_t out_pitch, float *last_dc_io);
+/* agc_ff libcsdr_gpl.c:163-260: n samples per stream processed as consecutive calls of `block` samples (the CLI's the_bufsize,
+ * csdr.c:1338-1375: the hang/attack counters restart with every call).  last_gain_io: device float[n_streams] */
+int csdr_amd_agc_ff(csdr_amd_ctx *ctx, const float *in, float *out, int n_streams, size_t n, int block, size_t in_pitch, size_t out_pitch,
+                    float reference, float attack_rate, float decay_rate, float max_gain, short hang_time, short attack_wait_time,
+                    float gain_filter_alpha, float *last_gain_io);
+/* precalculate_window libcsdr.c:1256-1267 (host) */
+void csdr_amd_precalculate_window(float *host_windowt, int size, int window);
+/* `csdr fft_cc <fft_size> <out_of_every_n_samples> [window]` (csdr.c:1569-1641): windowed FFT of the newest fft_size samples every
+ * every_n_samples new samples; the sliding buffer is carried inside the object.  Returns the number of spectra written. */
+typedef struct csdr_amd_fftcc csdr_amd_fftcc;
+csdr_amd_fftcc *csdr_amd_fftcc_create(csdr_amd_ctx *ctx, int fft_size, int every_n_samples, int window, int max_frames);
+void csdr_amd_fftcc_destroy(csdr_amd_fftcc *f);
+int  csdr_amd_fftcc_process(csdr_amd_fftcc *f, const csdr_complexf *in, size_t n_in, csdr_complexf *out, size_t *consumed);
+
 /* ------------------------------------------------------------------ FFT overlap-add filter
  * bandpass_fir_fft_cc (csdr.c:1810-1886) = apply_fir_fft_cc (libcsdr.c:814-849) per block.
  * One object per (fft_size, taps); processes n_blocks blocks of input_size = fft_size-taps_length+1 samples

@@ -91,6 +91,20 @@ int next_pow2(int x);
 void apply_fir_fft_cc(FFT_PLAN_T *plan, FFT_PLAN_T *plan_inverse, complexf *taps_fft, complexf *last_overlap, int overlap_size);
 void gain_ff(float *input, float *output, int input_size, float gain);
 
+/* f2 blocks: libcsdr.h:97-99, 110-116, 142-147; libcsdr_gpl.h:37 */
+float fmdemod_atan_cf(complexf *input, float *output, int input_size, float last_phase);
+void amdemod_cf(complexf *input, float *output, int input_size);
+void amdemod_estimator_cf(complexf *input, float *output, int input_size, float alpha, float beta);
+typedef struct dcblock_preserve_s { float last_input; float last_output; } dcblock_preserve_t;             /* libcsdr.h:110-114 */
+dcblock_preserve_t dcblock_ff(float *input, float *output, int input_size, float a, dcblock_preserve_t preserved);
+float fastdcblock_ff(float *input, float *output, int input_size, float last_dc_level);
+float *precalculate_window(int size, window_t window);
+void apply_window_c(complexf *input, complexf *output, int size, window_t window);
+void apply_precalculated_window_c(complexf *input, complexf *output, int size, float *windowt);
+void logpower_cf(complexf *input, float *output, int size, float add_db);
+float agc_ff(float *input, float *output, int input_size, float reference, float attack_rate, float decay_rate, float max_gain,
+             short hang_time, short attack_wait_time, float gain_filter_alpha, float last_gain);
+
 /* converters, libcsdr.h:220-229 */
 void convert_u8_f(unsigned char *input, float *output, int input_size);
 void convert_f_u8(float *input, unsigned char *output, int input_size);

@@ -45,6 +45,10 @@ class _DsaStatus(C.Structure):      # libcsdr_gpl.h:39-44
     _fields_ = [("decimation_remain", C.c_int), ("starting_phase", C.c_float), ("output_size", C.c_int)]
 
 
+class _DcBlock(C.Structure):       # libcsdr.h:110-114
+    _fields_ = [("last_input", C.c_float), ("last_output", C.c_float)]
+
+
 class _FastDDC(C.Structure):        # fastddc.h:5-24
     _fields_ = [(n, C.c_int) for n in ("pre_decimation", "post_decimation", "taps_length", "taps_min_length",
                                        "overlap_length", "fft_size", "fft_inv_size", "input_size",
@@ -91,6 +95,10 @@ class Port:
         L.orc_stream_shift_addition_cc.restype = C.c_float
         L.orc_stream_fir_decimate_cc.restype = C.c_long
         L.orc_stream_wfm_chain.restype = C.c_long
+        L.orc_fmdemod_atan_cf.restype = C.c_float
+        L.orc_dcblock_ff.restype = _DcBlock
+        L.orc_fastdcblock_ff.restype = C.c_float
+        L.orc_agc_ff.restype = C.c_float
 
     # ---- design
     def firdes_filter_len(self, tbw):
@@ -252,6 +260,66 @@ class Port:
         self.L.orc_fractional_decimator_ff(_p(x), _p(y), x.size, C.byref(d))
         return y[:d.output_size].copy()
 
+
+    # ---- f2 blocks (AM/SSB chains, waterfall path)
+    def amdemod_cf(self, x):
+        x = _cf(x); y = np.zeros(x.size, f32); self.L.orc_amdemod_cf(_p(x), _p(y), x.size); return y
+
+    def amdemod_estimator_cf(self, x, alpha=0.0, beta=0.0):
+        x = _cf(x); y = np.zeros(x.size, f32)
+        self.L.orc_amdemod_estimator_cf(_p(x), _p(y), x.size, C.c_float(alpha), C.c_float(beta)); return y
+
+    def fmdemod_atan_cf(self, x, last_phase=0.0):
+        x = _cf(x); y = np.zeros(x.size, f32)
+        ph = self.L.orc_fmdemod_atan_cf(_p(x), _p(y), x.size, C.c_float(last_phase)); return y, ph
+
+    def dcblock_ff(self, x, a=0.0, state=(0.0, 0.0)):
+        x = np.ascontiguousarray(x, f32); y = np.zeros_like(x)
+        st = self.L.orc_dcblock_ff(_p(x), _p(y), x.size, C.c_float(a), _DcBlock(*state)); return y, (st.last_input, st.last_output)
+
+    def fastdcblock_ff(self, x, block=1024, last_dc=0.0):
+        """csdr.c:943-960 framing: whole blocks only."""
+        x = np.ascontiguousarray(x, f32); nb = x.size // block; y = np.zeros(nb * block, f32)
+        for b in range(nb):
+            last_dc = self.L.orc_fastdcblock_ff(_p(x[b * block:]), _p(y[b * block:]), block, C.c_float(last_dc))
+        return y, last_dc
+
+    def agc_ff(self, x, block=1024, hang_time=200, reference=0.2, attack_rate=0.01, decay_rate=0.0001, max_gain=65536.0,
+               attack_wait=0, filter_alpha=0.999, last_gain=1.0):
+        """csdr.c:1338-1375 framing: one call per the_bufsize block, counters restart, last_gain carried."""
+        x = np.ascontiguousarray(x, f32); y = np.zeros_like(x)
+        for at in range(0, x.size, block):
+            n = min(block, x.size - at)
+            last_gain = self.L.orc_agc_ff(_p(x[at:]), _p(y[at:]), n, C.c_float(reference), C.c_float(attack_rate), C.c_float(decay_rate),
+                                          C.c_float(max_gain), C.c_short(hang_time), C.c_short(attack_wait), C.c_float(filter_alpha), C.c_float(last_gain))
+        return y, last_gain
+
+    def realpart_cf(self, x):
+        x = _cf(x); y = np.zeros(x.size, f32); self.L.orc_realpart_cf(_p(x), _p(y), x.size); return y
+
+    def logpower_cf(self, x, add_db=0.0):
+        x = _cf(x); y = np.zeros(x.size, f32); self.L.orc_logpower_cf(_p(x), _p(y), x.size, C.c_float(add_db)); return y
+
+    def precalculate_window(self, size, window="HAMMING"):
+        w = np.zeros(size, f32); self.L.orc_precalculate_window(_p(w), size, WINDOWS[window]); return w
+
+    def fft_cc(self, x, fft_size, every_n, window="HAMMING"):
+        """csdr.c:1569-1641 stream model (clean EOF): windowed FFT of the last fft_size samples every `every_n` new samples."""
+        x = _cf(x); w = self.precalculate_window(fft_size, window)
+        buf = np.zeros(fft_size, c64); out = []
+        pos = 0
+        while True:
+            if every_n > fft_size:
+                if pos + every_n > x.size: break
+                buf[:] = x[pos:pos + fft_size]; pos += every_n
+            else:
+                if pos + every_n > x.size: break
+                buf[:fft_size - every_n] = buf[every_n:].copy(); buf[fft_size - every_n:] = x[pos:pos + every_n]; pos += every_n
+            win = np.zeros(fft_size, c64)
+            self.L.orc_apply_precalculated_window_c(_p(buf), _p(win), fft_size, _p(w))
+            out.append(self.fft_c2c(win, True))
+        return np.concatenate(out) if out else np.zeros(0, c64)
+
     # ---- FFT paths
     def fft_c2c(self, x, forward=True):
         x = _cf(x); y = np.zeros_like(x)
@@ -385,8 +453,55 @@ class Ref:
         L.shift_unroll_init.restype = Ref.ShiftUnroll
         L.fractional_decimator_ff_init.restype = Ref.FracDec
         L.make_fft_c2c.restype = C.POINTER(Ref.FftPlan)
+        for name in ("fmdemod_atan_cf", "fastdcblock_ff", "agc_ff"):
+            getattr(L, name).restype = C.c_float
+        L.dcblock_ff.restype = _DcBlock
+        L.precalculate_window.restype = C.POINTER(C.c_float)
         if lib_path is None:
             L.fftwf_malloc.restype = C.c_void_p
+
+
+    # ---- f2 blocks
+    def amdemod_cf(self, x):
+        x = _cf(x); y = np.zeros(x.size, f32); self.L.amdemod_cf(_p(x), _p(y), x.size); return y
+
+    def amdemod_estimator_cf(self, x, alpha=0.0, beta=0.0):
+        x = _cf(x); y = np.zeros(x.size, f32)
+        self.L.amdemod_estimator_cf(_p(x), _p(y), x.size, C.c_float(alpha), C.c_float(beta)); return y
+
+    def fmdemod_atan_cf(self, x, last_phase=0.0):
+        x = _cf(x); y = np.zeros(x.size, f32)
+        ph = self.L.fmdemod_atan_cf(_p(x), _p(y), x.size, C.c_float(last_phase)); return y, ph
+
+    def dcblock_ff(self, x, a=0.0, state=(0.0, 0.0)):
+        x = np.ascontiguousarray(x, f32); y = np.zeros_like(x)
+        st = self.L.dcblock_ff(_p(x), _p(y), x.size, C.c_float(a), _DcBlock(*state)); return y, (st.last_input, st.last_output)
+
+    def fastdcblock_ff(self, x, block=1024, last_dc=0.0):
+        x = np.ascontiguousarray(x, f32); nb = x.size // block; y = np.zeros(nb * block, f32)
+        for b in range(nb):
+            last_dc = self.L.fastdcblock_ff(_p(x[b * block:]), _p(y[b * block:]), block, C.c_float(last_dc))
+        return y, last_dc
+
+    def agc_ff(self, x, block=1024, hang_time=200, reference=0.2, attack_rate=0.01, decay_rate=0.0001, max_gain=65536.0,
+               attack_wait=0, filter_alpha=0.999, last_gain=1.0):
+        x = np.ascontiguousarray(x, f32); y = np.zeros_like(x)
+        for at in range(0, x.size, block):
+            n = min(block, x.size - at)
+            last_gain = self.L.agc_ff(_p(x[at:]), _p(y[at:]), n, C.c_float(reference), C.c_float(attack_rate), C.c_float(decay_rate),
+                                      C.c_float(max_gain), C.c_short(hang_time), C.c_short(attack_wait), C.c_float(filter_alpha), C.c_float(last_gain))
+        return y, last_gain
+
+    def logpower_cf(self, x, add_db=0.0):
+        x = _cf(x); y = np.zeros(x.size, f32); self.L.logpower_cf(_p(x), _p(y), x.size, C.c_float(add_db)); return y
+
+    def precalculate_window(self, size, window="HAMMING"):
+        p = self.L.precalculate_window(size, WINDOWS[window])
+        return np.ctypeslib.as_array(p, (size,)).copy()
+
+    def apply_precalculated_window_c(self, x, w):
+        x = _cf(x); w = np.ascontiguousarray(w, f32); y = np.zeros_like(x)
+        self.L.apply_precalculated_window_c(_p(x), _p(y), x.size, _p(w)); return y
 
     def nfm_taps(self, sample_rate):
         n = {48000: 201, 44100: 123, 8000: 81, 11025: 81}[sample_rate]

@@ -525,3 +525,102 @@ long orc_stream_wfm_chain(const unsigned char *iq_u8, long n_complex, float shif
     free(aud); free(de);
     return na;
 }
+
+
+/* ================================================================== f2 blocks */
+void orc_amdemod_cf(const orc_cf *in, float *out, int n)
+{   /* libcsdr.c:861-873: i*i+q*q in float, then sqrt() -- the double sqrt of a float, rounded back to float */
+    for (int k = 0; k < n; k++) out[k] = in[k].i * in[k].i + in[k].q * in[k].q;
+    for (int k = 0; k < n; k++) out[k] = (float)sqrt((double)out[k]);
+}
+
+void orc_amdemod_estimator_cf(const orc_cf *in, float *out, int n, float alpha, float beta)
+{   /* libcsdr.c:875-901: alpha*max(|i|,|q|) + beta*min(|i|,|q|); (0,*) selects the minimum-RMS-error pair (double literals -> float) */
+    if (alpha == 0) { alpha = 0.947543636291; beta = 0.392485425092; }
+    for (int k = 0; k < n; k++) {
+        float ai = in[k].i; if (ai < 0) ai = -ai;
+        float aq = in[k].q; if (aq < 0) aq = -aq;
+        float mx = ai; if (aq > mx) mx = aq;
+        float mn = ai; if (aq < mn) mn = aq;
+        out[k] = alpha * mx + beta * mn;
+    }
+}
+
+float orc_fmdemod_atan_cf(const orc_cf *in, float *out, int n, float last_phase)
+{   /* libcsdr.c:1004-1019: phase = (float)atan2(q, i) (double atan2, libcsdr.h:52); unwrap with the FLOAT constant PI (libcsdr.h:65) */
+    const float PIf = (float)3.14159265358979323846;
+    for (int k = 0; k < n; k++) {
+        float phase = (float)atan2((double)in[k].q, (double)in[k].i);
+        float d = phase - last_phase;
+        if (d < -PIf) d += 2 * PIf;
+        if (d > PIf) d -= 2 * PIf;
+        out[k] = d / PIf;
+        last_phase = phase;
+    }
+    return last_phase;
+}
+
+orc_dcblock_t orc_dcblock_ff(const float *in, float *out, int n, float a, orc_dcblock_t p)
+{   /* libcsdr.c:903-918: y[i] = x[i] - x[i-1] + a*y[i-1]; a == 0 selects 0.999 */
+    if (a == 0) a = 0.999;
+    out[0] = in[0] - p.last_input + a * p.last_output;
+    for (int k = 1; k < n; k++) out[k] = in[k] - in[k - 1] + a * out[k - 1];
+    p.last_input = in[n - 1]; p.last_output = out[n - 1];
+    return p;
+}
+
+float orc_fastdcblock_ff(const float *in, float *out, int n, float last_dc_level)
+{   /* libcsdr.c:920-941: block mean, removal level ramps linearly from the previous block's mean to this one's */
+    float avg = 0.0f;
+    for (int k = 0; k < n; k++) avg += in[k];
+    avg /= n;
+    const float diff = avg - last_dc_level;
+    for (int k = 0; k < n; k++) { float lvl = last_dc_level + diff * ((float)k / n); out[k] = in[k] - lvl; }
+    return avg;
+}
+
+float orc_agc_ff(const float *in, float *out, int n, float reference, float attack_rate, float decay_rate, float max_gain,
+                 short hang_time, short attack_wait_time, float gain_filter_alpha, float last_gain)
+{   /* libcsdr_gpl.c:163-260: envelope-following AGC with hang / attack-wait counters (reset every call) and a one-pole filter on the gain */
+    short hang_counter = 0, attack_wait_counter = 0;
+    float gain = last_gain, last_peak = reference / last_gain, dgain;
+    out[0] = last_gain * in[0];
+    for (int k = 1; k < n; k++) {
+        const float a = fabsf(in[k]);
+        const float error = reference / a - gain;
+        if (in[k] != 0) {
+            if (error < 0) {
+                if (last_peak < a) { attack_wait_counter = attack_wait_time; last_peak = a; }
+                if (attack_wait_counter > 0) { attack_wait_counter--; dgain = 0; }
+                else { dgain = error * attack_rate; hang_counter = hang_time; }
+            } else {
+                if (hang_counter > 0) { hang_counter--; dgain = 0; }
+                else dgain = error * decay_rate;
+            }
+            gain = gain + dgain;
+        }
+        if (gain > max_gain) gain = max_gain;
+        if (gain < 0) gain = 0;
+        gain = gain + last_gain - gain_filter_alpha * last_gain;
+        out[k] = gain * in[k];
+        last_gain = gain;
+    }
+    return gain;
+}
+
+void orc_realpart_cf(const orc_cf *in, float *out, int n) { for (int k = 0; k < n; k++) out[k] = in[k].i; }   /* csdr.c:634-645 */
+
+void orc_logpower_cf(const orc_cf *in, float *out, int n, float add_db)
+{   /* libcsdr.c:1296-1303: |x|^2 in float, log10() in double rounded to float, then 10*y + add_db in float */
+    for (int k = 0; k < n; k++) out[k] = in[k].i * in[k].i + in[k].q * in[k].q;
+    for (int k = 0; k < n; k++) out[k] = (float)log10((double)out[k]);
+    for (int k = 0; k < n; k++) out[k] = 10 * out[k] + add_db;
+}
+
+void orc_precalculate_window(float *windowt, int size, int window)
+{   /* libcsdr.c:1256-1267: kernel(2*rate + 1) with rate = (float)i/(size-1); the argument is formed in double and passed as float */
+    for (int k = 0; k < size; k++) { float rate = (float)k / (size - 1); windowt[k] = window_kernel(window, (float)(2.0 * rate + 1.0)); }
+}
+
+void orc_apply_precalculated_window_c(const orc_cf *in, orc_cf *out, int size, const float *windowt)
+{ for (int k = 0; k < size; k++) { out[k].i = in[k].i * windowt[k]; out[k].q = in[k].q * windowt[k]; } }   /* libcsdr.c:1269-1276 */

@@ -93,6 +93,20 @@ void orc_fft_swap_sides(orc_cf *io, int fft_size);                              
 /* spectrum is NOT modified (the reference swaps it in place; we work on a copy) */
 orc_dsa_status_t orc_fastddc_inv_cc(const orc_cf *spectrum, orc_cf *out, const orc_fastddc_t *ddc, const orc_cf *taps_fft, orc_dsa_status_t st); /* fastddc.c:106-166 */
 
+/* ---- f2: the remaining simple blocks of the AM/SSB receive chains and the waterfall path ---- */
+void  orc_amdemod_cf(const orc_cf *in, float *out, int n);                               /* libcsdr.c:861-873 */
+void  orc_amdemod_estimator_cf(const orc_cf *in, float *out, int n, float alpha, float beta); /* :875-901 */
+float orc_fmdemod_atan_cf(const orc_cf *in, float *out, int n, float last_phase);        /* :1004-1019 */
+typedef struct { float last_input, last_output; } orc_dcblock_t;                         /* libcsdr.h:110-114 */
+orc_dcblock_t orc_dcblock_ff(const float *in, float *out, int n, float a, orc_dcblock_t preserved); /* libcsdr.c:903-918 */
+float orc_fastdcblock_ff(const float *in, float *out, int n, float last_dc_level);       /* :920-941 */
+float orc_agc_ff(const float *in, float *out, int n, float reference, float attack_rate, float decay_rate, float max_gain,
+                 short hang_time, short attack_wait_time, float gain_filter_alpha, float last_gain); /* libcsdr_gpl.c:163-260 */
+void  orc_realpart_cf(const orc_cf *in, float *out, int n);                              /* csdr.c:634-645 */
+void  orc_logpower_cf(const orc_cf *in, float *out, int n, float add_db);                /* libcsdr.c:1296-1303 */
+void  orc_precalculate_window(float *windowt, int size, int window);                     /* :1256-1267 */
+void  orc_apply_precalculated_window_c(const orc_cf *in, orc_cf *out, int size, const float *windowt); /* :1269-1276 */
+
 /* ---- whole-stream models of the csdr CLI loops (block framing included) ---- */
 /* csdr.c:877-925: 1024-sample chunks, phase threaded through; n need not be a multiple of 1024 only for the last chunk */
 float orc_stream_shift_addition_cc(const orc_cf *in, orc_cf *out, long n, float rate, float starting_phase, int chunk);

@@ -292,3 +292,66 @@ def test_cli_fifo_retune(port, tmp_path):
     b, _ = port.shift_addition_cc(x[4096:], -0.2, phase=ph)
     assert got.size == x.size
     assert relrms(got[:4096], a) <= TOL and relrms(got[4096:], b) <= TOL
+
+
+# ---------------------------------------------------------------- f2 commands
+def test_cli_f2_commands(port):
+    rng = np.random.default_rng(14)
+    x = crand(rng, 30000)
+    assert relrms(np.frombuffer(run(["amdemod_cf"], x), f32), port.amdemod_cf(x)) <= TOL
+    assert run(["amdemod_estimator_cf"], x) == port.amdemod_estimator_cf(x).tobytes()
+    assert run(["realpart_cf"], x) == port.realpart_cf(x).tobytes()
+    assert relrms(np.frombuffer(run(["logpower_cf", -70], x), f32), port.logpower_cf(x, -70)) <= TOL
+    assert relrms(np.frombuffer(run(["fmdemod_atan_cf"], x), f32), port.fmdemod_atan_cf(x)[0]) <= TOL
+    a = (rng.uniform(-1, 1, 50000) + 0.2).astype(f32)
+    assert run(["gain_ff", 2.5], a) == port.gain_ff(a, 2.5).tobytes()
+    assert relrms(np.frombuffer(run(["dcblock_ff"], a), f32), port.dcblock_ff(a)[0]) <= TOL
+    got = np.frombuffer(run(["fastdcblock_ff"], a), f32); want = port.fastdcblock_ff(a)[0]
+    assert got.size == want.size and relrms(got, want) <= TOL
+    sig = (a * np.repeat(rng.uniform(0.01, 1, 500), 100)).astype(f32)
+    assert relrms(np.frombuffer(run(["agc_ff"], sig), f32), port.agc_ff(sig)[0]) <= TOL
+    assert relrms(np.frombuffer(run(["agc_ff", 20, 0.5, 0.05, 0.001, 100, 5, 0.99], sig), f32),
+                  port.agc_ff(sig, 1024, 20, 0.5, 0.05, 0.001, 100.0, 5, 0.99)[0]) <= TOL
+    got = np.frombuffer(run(["fft_cc", 1024, 300, "HAMMING"], x, 4096), c64); want = port.fft_cc(x, 1024, 300)
+    assert got.size == want.size and relrms(got, want) <= TOL
+    got = np.frombuffer(run(["fft_cc", 256, 5000], x, 8192), c64); want = port.fft_cc(x, 256, 5000)
+    assert got.size == want.size and relrms(got, want) <= TOL
+
+
+def test_cli_am_and_ssb_chains(port):
+    """README.md:95 (AM) and :110 (SSB) as in-process chains against the oracle, stage by stage stream models."""
+    rng = np.random.default_rng(15)
+    n = 400000
+    t = np.arange(n)
+    audio = 0.5 * np.sin(2 * np.pi * 700 / 2.4e6 * t)
+    am = (0.5 * (1 + audio) * np.exp(2j * np.pi * 0.25 * t) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n)))
+    iq = np.empty(2 * n, f32); iq[0::2] = am.real; iq[1::2] = am.imag
+    iq = np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+    xf = port.convert_u8_f(iq).view(c64)
+    sh, _ = port.shift_addition_cc(xf, -0.25)
+    taps = port.firdes_lowpass_f(port.firdes_filter_len(0.005), 0.5 / 50)
+    dec = port.fir_decimate_cc(sh, 50, taps)
+    # AM
+    d, _ = port.fastdcblock_ff(port.amdemod_cf(dec))
+    want = port.convert_f_s16(port.limit_ff(port.agc_ff(d)[0], 1.0))
+    got = np.frombuffer(run(["chain", "convert_u8_f | shift_addition_cc -0.25 | fir_decimate_cc 50 0.005 HAMMING | amdemod_cf | fastdcblock_ff | agc_ff | limit_ff | convert_f_s16"], iq, 65536), np.int16)
+    assert got.size == want.size
+    dd = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert dd.max() <= 2 and np.mean(dd != 0) < 0.02
+    # SSB
+    nt = port.firdes_filter_len(0.05); fft = port.next_pow2(nt)
+    if fft - nt < 200:
+        fft *= 2
+    bp = port.bandpass_fir_fft_cc(dec, port.firdes_bandpass_c(nt, 0.0, 0.1), fft)
+    ssb = "convert_u8_f | shift_addition_cc -0.25 | fir_decimate_cc 50 0.005 HAMMING | bandpass_fir_fft_cc 0 0.1 0.05 | realpart_cf | %slimit_ff | convert_f_s16"
+    want = port.convert_f_s16(port.limit_ff(port.gain_ff(port.realpart_cf(bp), 3.0), 1.0))
+    got = np.frombuffer(run(["chain", ssb % "gain_ff 3 | "], iq, 65536), np.int16)
+    assert got.size == want.size
+    dd = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert dd.max() <= 2 and np.mean(dd != 0) < 0.02
+    # with agc_ff in the chain only a loose comparison is meaningful: its hang/attack logic branches on float comparisons, so inputs that
+    # differ in the last bit (here: the FFT filter's rounding) legitimately give gain tracks that differ by a fraction of a percent for
+    # a while.  agc_ff itself is compared on identical input in test_cli_f2_commands / tests/test_gpu_parity.py::test_f2_agc.
+    want = port.convert_f_s16(port.limit_ff(port.agc_ff(port.realpart_cf(bp))[0], 1.0))
+    got = np.frombuffer(run(["chain", ssb % "agc_ff | "], iq, 65536), np.int16)
+    assert got.size == want.size and relrms(got.astype(f32), want.astype(f32)) < 2e-2

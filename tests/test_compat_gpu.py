@@ -118,3 +118,25 @@ def test_fastddc_inv_cc_dropin(ours, port):
     a = ours.fastddc_inv_cc(spec, d2, tf)
     b = port.fastddc_inv_cc(spec, ddc, tf)
     assert a.size == b.size and relrms(a, b) < TOL
+
+
+def test_f2_dropin_symbols(ours, port):
+    """amdemod_cf ... agc_ff called exactly as a libcsdr client would (host pointers, by-value state structs)."""
+    rng = np.random.default_rng(51)
+    x = crand(rng, 9000)
+    assert relrms(ours.amdemod_cf(x), port.amdemod_cf(x)) <= TOL
+    assert np.array_equal(ours.amdemod_estimator_cf(x), port.amdemod_estimator_cf(x))
+    a, pa = ours.fmdemod_atan_cf(x, 0.3); b, pb = port.fmdemod_atan_cf(x, 0.3)
+    assert relrms(a, b) <= TOL and abs(pa - pb) <= 1e-6
+    assert relrms(ours.logpower_cf(x, 3.0), port.logpower_cf(x, 3.0)) <= TOL
+    r = (rng.uniform(-1, 1, 9000) + 0.3).astype(f32)
+    (y, s), (w, ws) = ours.dcblock_ff(r, 0, (0.1, 0.2)), port.dcblock_ff(r, 0, (0.1, 0.2))
+    assert relrms(y, w) <= TOL and np.allclose(s, ws, atol=1e-5)
+    (y, l), (w, wl) = ours.fastdcblock_ff(r, 1024, 0.1), port.fastdcblock_ff(r, 1024, 0.1)
+    assert relrms(y, w) <= TOL and abs(l - wl) <= 1e-6
+    sig = (r * np.repeat(rng.uniform(0.01, 1, 90), 100)).astype(f32)
+    (y, g), (w, wg) = ours.agc_ff(sig, 1024), port.agc_ff(sig, 1024)
+    assert relrms(y, w) <= TOL and abs(g - wg) <= 1e-4 * max(1.0, abs(wg))
+    assert np.array_equal(ours.precalculate_window(512, "BLACKMAN"), port.precalculate_window(512, "BLACKMAN"))
+    wnd = port.precalculate_window(512)
+    assert np.array_equal(ours.apply_precalculated_window_c(x[:512], wnd), (x[:512].view(f32).reshape(-1, 2) * wnd[:, None]).reshape(-1).view(c64))

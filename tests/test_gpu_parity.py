@@ -332,3 +332,61 @@ def test_nfm_chain_device_resident(gpu, port):
         assert relrms(af[s], pf) < TOL
         d = np.abs(pcm[s].astype(np.int32) - ps.astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 0.05
+
+
+# ---------------------------------------------------------------- f2 blocks
+def test_f2_elementwise(gpu, port):
+    rng = np.random.default_rng(41)
+    x = (rng.normal(size=100003) + 1j * rng.normal(size=100003)).astype(c64)
+    x[:4] = [0, 1, -1j, 1e-20]
+    assert relrms(gpu.amdemod_cf(x), port.amdemod_cf(x)) <= TOL
+    assert np.array_equal(gpu.amdemod_estimator_cf(x), port.amdemod_estimator_cf(x))          # no rounding freedom: two products and a sum
+    assert np.array_equal(gpu.amdemod_estimator_cf(x, 0.9, 0.4), port.amdemod_estimator_cf(x, 0.9, 0.4))
+    assert np.array_equal(gpu.realpart_cf(x), port.realpart_cf(x))
+    assert relrms(gpu.logpower_cf(x[4:], -7.5), port.logpower_cf(x[4:], -7.5)) <= TOL
+    for w in ("HAMMING", "BLACKMAN", "BOXCAR"):
+        assert np.array_equal(gpu.precalculate_window(1024, w), port.precalculate_window(1024, w))
+
+
+def test_f2_fmdemod_atan_streams_and_carry(gpu, port):
+    rng = np.random.default_rng(42)
+    x = crand(rng, 3 * 5000).reshape(3, 5000)
+    y, lp = gpu.fmdemod_atan_cf(x, last_phase=[0.0, 0.5, -1.0], calls=3)
+    for s, p0 in enumerate([0.0, 0.5, -1.0]):
+        w, wl = port.fmdemod_atan_cf(x[s], p0)
+        assert relrms(y[s], w) <= TOL and abs(lp[s] - wl) <= 1e-6
+
+
+def test_f2_dcblock_and_fastdcblock(gpu, port):
+    rng = np.random.default_rng(43)
+    x = (rng.uniform(-1, 1, 2 * 70001) + 0.25).astype(f32).reshape(2, 70001)
+    for a in (0.0, 0.95):
+        y, st = gpu.dcblock_ff(x, a, state=[0.1, 0.2, -0.3, 0.05], calls=3)
+        for s, st0 in enumerate([(0.1, 0.2), (-0.3, 0.05)]):
+            w, ws = port.dcblock_ff(x[s], a, st0)
+            assert relrms(y[s], w) <= TOL and np.allclose(st[s], ws, atol=1e-5)
+    y, ld = gpu.fastdcblock_ff(x, 1024, last_dc=[0.1, -0.2], calls=2)
+    for s, l0 in enumerate([0.1, -0.2]):
+        w, wl = port.fastdcblock_ff(x[s], 1024, l0)
+        assert y[s].size == w.size and relrms(y[s], w) <= TOL and abs(ld[s] - wl) <= 1e-6
+
+
+def test_f2_agc(gpu, port):
+    rng = np.random.default_rng(44)
+    sig = (rng.uniform(-1, 1, 3 * 20000) * np.repeat(rng.uniform(0.01, 1, 600), 100)).astype(f32).reshape(3, 20000)
+    sig[1, 500:520] = 0
+    for kw in ({}, dict(hang_time=20, reference=0.5, attack_rate=0.05, decay_rate=0.001, max_gain=100.0, attack_wait=5, filter_alpha=0.99)):
+        y, g = gpu.agc_ff(sig, 1024, **kw)
+        for s in range(3):
+            w, wg = port.agc_ff(sig[s], 1024, **kw)
+            assert relrms(y[s], w) <= TOL and abs(g[s] - wg) <= 1e-4 * max(1.0, abs(wg))
+
+
+@pytest.mark.parametrize("fft,every", [(1024, 300), (1024, 1024), (256, 1000), (4096, 4000)])
+def test_f2_fft_cc(gpu, port, fft, every):
+    rng = np.random.default_rng(45)
+    x = crand(rng, 20000)
+    want = port.fft_cc(x, fft, every, "HAMMING")
+    for calls in (1, 3):
+        got = gpu.fft_cc(x, fft, every, "HAMMING", calls=calls)
+        assert got.size == want.size and relrms(got, want) <= TOL

@@ -260,3 +260,41 @@ def test_wfm_chain(port, ref):
     assert relrms(fa[:n], fb[:n]) < 1e-5
     d = np.abs(sa[:n].astype(np.int32) - sb[:n].astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.05
+
+
+# ---------------------------------------------------------------- f2 blocks
+def test_f2_elementwise(port, ref):
+    rng = np.random.default_rng(31)
+    x = (rng.normal(size=20000) + 1j * rng.normal(size=20000)).astype(np.complex64)
+    x[:4] = [0, 1, -1j, 1e-20]
+    assert relrms(port.amdemod_cf(x), ref.amdemod_cf(x)) <= 1e-6
+    assert np.array_equal(port.amdemod_estimator_cf(x), ref.amdemod_estimator_cf(x))
+    assert np.array_equal(port.amdemod_estimator_cf(x, 0.9, 0.4), ref.amdemod_estimator_cf(x, 0.9, 0.4))
+    a, pa = port.fmdemod_atan_cf(x, 0.3); b, pb = ref.fmdemod_atan_cf(x, 0.3)
+    assert relrms(a, b) <= 1e-6 and abs(pa - pb) <= 1e-6
+    with np.errstate(divide="ignore"):
+        lp, lr = port.logpower_cf(x[4:], 3.0), ref.logpower_cf(x[4:], 3.0)       # (a denormal power is flushed by the reference build)
+    assert relrms(lp, lr) <= 1e-6
+    for w in ("HAMMING", "BLACKMAN", "BOXCAR"):
+        assert np.abs(port.precalculate_window(1024, w) - ref.precalculate_window(1024, w)).max() <= 1e-6
+    w = port.precalculate_window(512)
+    out = np.zeros(512, np.complex64)
+    import ctypes as C
+    port.L.orc_apply_precalculated_window_c(x[:512].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), 512, w.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, ref.apply_precalculated_window_c(x[:512], w))
+
+
+def test_f2_recursive_blocks(port, ref):
+    rng = np.random.default_rng(32)
+    a = (rng.uniform(-1, 1, 30000) + 0.3).astype(np.float32)
+    (y, s), (yr, sr) = port.dcblock_ff(a, 0, (0.1, 0.2)), ref.dcblock_ff(a, 0, (0.1, 0.2))
+    assert relrms(y, yr) <= 5e-6 and np.allclose(s, sr, atol=2e-6)
+    (y, s), (yr, sr) = port.dcblock_ff(a, 0.95), ref.dcblock_ff(a, 0.95)
+    assert relrms(y, yr) <= 5e-6
+    (y, l), (yr, lr) = port.fastdcblock_ff(a, 1024, 0.1), ref.fastdcblock_ff(a, 1024, 0.1)
+    assert relrms(y, yr) <= 1e-6 and abs(l - lr) <= 1e-6
+    sig = (rng.uniform(-1, 1, 40000) * np.repeat(rng.uniform(0.01, 1, 400), 100)).astype(np.float32)
+    sig[1000:1010] = 0
+    for kw in ({}, dict(hang_time=20, reference=0.5, attack_rate=0.05, decay_rate=0.001, max_gain=100.0, attack_wait=5, filter_alpha=0.99)):
+        (y, g), (yr, gr) = port.agc_ff(sig, 1024, **kw), ref.agc_ff(sig, 1024, **kw)
+        assert relrms(y, yr) <= 5e-6 and abs(g - gr) <= 1e-5 * max(1, abs(gr))
