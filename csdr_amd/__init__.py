@@ -85,6 +85,9 @@ def lib():
     L.csdr_amd_fftcc_create.restype = vp; L.csdr_amd_fftcc_create.argtypes = [vp, i, i, i, i]
     L.csdr_amd_fftcc_destroy.argtypes = [vp]; L.csdr_amd_fftcc_destroy.restype = None
     L.csdr_amd_fftcc_process.argtypes = [vp, vp, sz, vp, C.POINTER(sz)]
+    L.csdr_amd_encode_ima_adpcm_i16_u8.argtypes = [vp, vp, vp, i, sz, sz, sz, vp]
+    L.csdr_amd_decode_ima_adpcm_u8_i16.argtypes = [vp, vp, vp, i, sz, sz, sz, vp]
+    L.csdr_amd_compress_fft_adpcm_f_u8.argtypes = [vp, vp, vp, i, i]
     L.csdr_amd_timer_start.argtypes = [vp]
     L.csdr_amd_timer_stop_ms.argtypes = [vp, C.POINTER(fl)]
     L.csdr_amd_firdes_filter_len.argtypes = [fl]
@@ -393,6 +396,38 @@ class Context:
         y = self.download(do, c64, fft_size * total)
         self.L.csdr_amd_fftcc_destroy(f)
         return y
+
+
+    # ---- f3: IMA ADPCM
+    def encode_ima_adpcm_i16_u8(self, x, state=None, calls=1):
+        x2, squeeze = self._2d(x, np.int16)
+        s, n = x2.shape
+        st = np.zeros(2 * s, np.int32) if state is None else np.ascontiguousarray(state, np.int32).reshape(2 * s)
+        di = self.upload(x2); do = self.alloc(s * (n // 2) + 64); ds = self.upload(st)
+        per = ((n + calls - 1) // calls + 1) & ~1; at = 0
+        while at < n:
+            k = min(per, n - at)
+            self.check(self.L.csdr_amd_encode_ima_adpcm_i16_u8(self.h, di.at(2 * at), do.at(at // 2), s, k, n, n // 2, ds.ptr), "adpcm encode"); at += k
+        y = self.download(do, np.uint8, s * (n // 2)).reshape(s, n // 2); so = self.download(ds, np.int32, 2 * s).reshape(s, 2)
+        return (y[0], so[0]) if squeeze else (y, so)
+
+    def decode_ima_adpcm_u8_i16(self, x, state=None, calls=1):
+        x2, squeeze = self._2d(x, np.uint8)
+        s, n = x2.shape
+        st = np.zeros(2 * s, np.int32) if state is None else np.ascontiguousarray(state, np.int32).reshape(2 * s)
+        di = self.upload(x2); do = self.alloc(4 * s * n + 64); ds = self.upload(st)
+        per = (n + calls - 1) // calls; at = 0
+        while at < n:
+            k = min(per, n - at)
+            self.check(self.L.csdr_amd_decode_ima_adpcm_u8_i16(self.h, di.at(at), do.at(4 * at), s, k, n, 2 * n, ds.ptr), "adpcm decode"); at += k
+        y = self.download(do, np.int16, 2 * s * n).reshape(s, 2 * n); so = self.download(ds, np.int32, 2 * s).reshape(s, 2)
+        return (y[0], so[0]) if squeeze else (y, so)
+
+    def compress_fft_adpcm_f_u8(self, x, fft_size):
+        x = np.ascontiguousarray(x, f32).ravel(); nb = x.size // fft_size; ob = (fft_size + 10) // 2
+        di = self.upload(x); do = self.alloc(nb * ob + 64)
+        self.check(self.L.csdr_amd_compress_fft_adpcm_f_u8(self.h, di.ptr, do.ptr, nb, fft_size), "compress_fft")
+        return self.download(do, np.uint8, nb * ob)
 
     def fmdemod_quadri_cf(self, x, last=None):
         x2, squeeze = self._2d(x, c64)

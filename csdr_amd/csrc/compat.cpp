@@ -501,4 +501,23 @@ void apply_window_c(complexf *in, complexf *out, int size, window_t window)
     free(w);
 }
 
+
+// ------------------------------------------------------------------ f3: IMA ADPCM (ima_adpcm.h:5-11)
+ima_adpcm_state_t encode_ima_adpcm_i16_u8(short *in, unsigned char *out, int n, ima_adpcm_state_t state)
+{
+    if (n < 2) return state;
+    int16_t *din = stage_in<int16_t>(4, in, n); uint8_t *dout = stage_out<uint8_t>(5, n / 2 + 16); int *ds = stage_in<int>(6, &state.index, 2);
+    MUST(csdr_amd_encode_ima_adpcm_i16_u8(ctx(), din, dout, 1, n, n, n / 2, ds));
+    fetch(out, dout, n / 2); fetch(&state.index, ds, 2);
+    return state;
+}
+ima_adpcm_state_t decode_ima_adpcm_u8_i16(unsigned char *in, short *out, int n, ima_adpcm_state_t state)
+{
+    if (n <= 0) return state;
+    uint8_t *din = stage_in<uint8_t>(4, in, n); int16_t *dout = stage_out<int16_t>(5, 2 * (size_t)n + 16); int *ds = stage_in<int>(6, &state.index, 2);
+    MUST(csdr_amd_decode_ima_adpcm_u8_i16(ctx(), din, dout, 1, n, n, 2 * (size_t)n, ds));
+    fetch(out, dout, 2 * (size_t)n); fetch(&state.index, ds, 2);
+    return state;
+}
+
 } // extern "C"

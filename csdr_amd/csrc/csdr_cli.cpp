@@ -386,6 +386,37 @@ struct FftCc : Stage {         // csdr.c:1569-1641 (binary output; --octave text
     { size_t used = 0; int nf = csdr_amd_fftcc_process(f, (const csdr_complexf *)i, n, (csdr_complexf *)o, &used); MUST(nf); *cons = used; return (long)nf * fft; }
 };
 
+
+// ------------------------------------------------------------------ f3 commands (csdr.c:1745-1768, 1891-1919)
+struct AdpcmEnc : Stage {
+    int *d_state;
+    AdpcmEnc(csdr_amd_ctx *c) { in_elem = 2; out_elem = 1; granule = 2; flush_partial = false; d_state = (int *)csdr_amd_malloc(c, 8); MUST(csdr_amd_memset(c, d_state, 0, 8)); }
+    int next_bufsize(int b) override { return b / 2; }               // csdr.c:1893
+    size_t out_capacity(size_t n) override { return n / 2 + 16; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { n &= ~(size_t)1; *cons = n; MUST(csdr_amd_encode_ima_adpcm_i16_u8(c, (const int16_t *)i, (uint8_t *)o, 1, n, n, n / 2, d_state)); return (long)(n / 2); }
+};
+struct AdpcmDec : Stage {
+    int *d_state;
+    AdpcmDec(csdr_amd_ctx *c) { in_elem = 1; out_elem = 2; d_state = (int *)csdr_amd_malloc(c, 8); MUST(csdr_amd_memset(c, d_state, 0, 8)); }
+    int next_bufsize(int b) override { return b * 2; }               // csdr.c:1910
+    size_t out_capacity(size_t n) override { return 2 * n + 16; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    { *cons = n; MUST(csdr_amd_decode_ima_adpcm_u8_i16(c, (const uint8_t *)i, (int16_t *)o, 1, n, n, 2 * n, d_state)); return (long)(2 * n); }
+};
+struct CompressFft : Stage {
+    int fft;
+    CompressFft(int f) : fft(f) { in_elem = 4; out_elem = 1; granule = f; flush_partial = false; }
+    int next_bufsize(int) override { return fft + 10; }              // csdr.c:1752
+    size_t out_capacity(size_t n) override { return (n / fft + 1) * (size_t)((fft + 10) / 2) + 16; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
+    {
+        const int nb = (int)(n / fft); *cons = (size_t)nb * fft;
+        if (nb) MUST(csdr_amd_compress_fft_adpcm_f_u8(c, (const float *)i, (uint8_t *)o, nb, fft));
+        return (long)nb * ((fft + 10) / 2);
+    }
+};
+
 // ------------------------------------------------------------------ wire protocol (csdr.c:325-419)
 int g_dynamic = 0, g_fixed = 1024, g_fixed_big = 16384, g_print = 0;
 void parse_env()
@@ -663,6 +694,14 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
         if (argc >= 6 && !strcmp(argv[5], "--octave")) { badsyntax("--octave text output is not offered by the MI355X back end"); return nullptr; }
         return new FftCc(c, fft, every, argc >= 5 ? window_from(argv[4]) : CSDR_WINDOW_HAMMING, block);
     }
+    if (cmd == "encode_ima_adpcm_i16_u8" || cmd == "encode_ima_adpcm_s16_u8") return new AdpcmEnc(c);
+    if (cmd == "decode_ima_adpcm_u8_i16" || cmd == "decode_ima_adpcm_u8_s16") return new AdpcmDec(c);
+    if (cmd == "compress_fft_adpcm_f_u8") {
+        if (argc <= 2) { badsyntax("need required parameters (fft_size)"); return nullptr; }
+        int fft; sscanf(argv[2], "%d", &fft);
+        if (fft <= 0 || (fft & 1)) { badsyntax("fft_size must be positive and even"); return nullptr; }
+        return new CompressFft(fft);
+    }
     if (cmd == "wfm_chain_u8_s16") { float shift = 0; if (argc > 2) sscanf(argv[2], "%g", &shift); return new WfmChain(c, shift, block); }
     fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]);
     return nullptr;
@@ -706,7 +745,7 @@ int main(int argc, char **argv)
                         "convert_f_s24 convert_s24_f shift_math_cc shift_addition_cc shift_addition_fc shift_table_cc shift_addfast_cc shift_unroll_cc "
                         "decimating_shift_addition_cc fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff "
                         "deemphasis_nfm_ff limit_ff fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c "
-                        "amdemod_cf amdemod_estimator_cf fmdemod_atan_cf dcblock_ff fastdcblock_ff agc_ff gain_ff realpart_cf logpower_cf fft_cc "
+                        "amdemod_cf amdemod_estimator_cf fmdemod_atan_cf dcblock_ff fastdcblock_ff agc_ff gain_ff realpart_cf logpower_cf fft_cc encode_ima_adpcm_i16_u8 decode_ima_adpcm_u8_i16 compress_fft_adpcm_f_u8 "
                         "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, chain \"<cmd> <args> | <cmd> <args> ...\"\n");
         return -1;
     }

@@ -188,6 +188,18 @@ csdr_amd_fftcc *csdr_amd_fftcc_create(csdr_amd_ctx *ctx, int fft_size, int every
 void csdr_amd_fftcc_destroy(csdr_amd_fftcc *f);
 int  csdr_amd_fftcc_process(csdr_amd_fftcc *f, const csdr_complexf *in, size_t n_in, csdr_complexf *out, size_t *consumed);
 
+/* ------------------------------------------------------------------ f3: IMA ADPCM (ima_adpcm.c:110-174), bit exact.
+ * A serial state machine per stream: one lane per stream.  state_io: device int32[2*n_streams] = {index, previousValue} (ima_adpcm_state_t).
+ * encode: n int16 samples per stream -> n/2 bytes (low nibble first; an odd last sample is dropped like the reference does);
+ * decode: n bytes per stream -> 2n samples. */
+int csdr_amd_encode_ima_adpcm_i16_u8(csdr_amd_ctx *ctx, const int16_t *in, uint8_t *out, int n_streams, size_t n,
+                                     size_t in_pitch, size_t out_pitch, int *state_io);
+int csdr_amd_decode_ima_adpcm_u8_i16(csdr_amd_ctx *ctx, const uint8_t *in, int16_t *out, int n_streams, size_t n,
+                                     size_t in_pitch, size_t out_pitch, int *state_io);
+/* `csdr compress_fft_adpcm_f_u8 <fft_size>` (csdr.c:1745-1768): n_blocks rows of fft_size dB values -> (fft_size+10)/2 bytes each; the
+ * encoder restarts from the zero state for every row, so rows are independent (one lane per row). */
+int csdr_amd_compress_fft_adpcm_f_u8(csdr_amd_ctx *ctx, const float *in, uint8_t *out, int n_blocks, int fft_size);
+
 /* ------------------------------------------------------------------ FFT overlap-add filter
  * bandpass_fir_fft_cc (csdr.c:1810-1886) = apply_fir_fft_cc (libcsdr.c:814-849) per block.
  * One object per (fft_size, taps); processes n_blocks blocks of input_size = fft_size-taps_length+1 samples

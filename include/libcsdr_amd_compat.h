@@ -105,6 +105,11 @@ void logpower_cf(complexf *input, float *output, int size, float add_db);
 float agc_ff(float *input, float *output, int input_size, float reference, float attack_rate, float decay_rate, float max_gain,
              short hang_time, short attack_wait_time, float gain_filter_alpha, float last_gain);
 
+/* IMA ADPCM, ima_adpcm.h:5-11 */
+typedef struct ImaState { int index; int previousValue; } ima_adpcm_state_t;
+ima_adpcm_state_t encode_ima_adpcm_i16_u8(short *input, unsigned char *output, int input_length, ima_adpcm_state_t state);
+ima_adpcm_state_t decode_ima_adpcm_u8_i16(unsigned char *input, short *output, int input_length, ima_adpcm_state_t state);
+
 /* converters, libcsdr.h:220-229 */
 void convert_u8_f(unsigned char *input, float *output, int input_size);
 void convert_f_u8(float *input, unsigned char *output, int input_size);

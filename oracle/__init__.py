@@ -49,6 +49,10 @@ class _DcBlock(C.Structure):       # libcsdr.h:110-114
     _fields_ = [("last_input", C.c_float), ("last_output", C.c_float)]
 
 
+class _Adpcm(C.Structure):         # ima_adpcm.h:5-8
+    _fields_ = [("index", C.c_int), ("previousValue", C.c_int)]
+
+
 class _FastDDC(C.Structure):        # fastddc.h:5-24
     _fields_ = [(n, C.c_int) for n in ("pre_decimation", "post_decimation", "taps_length", "taps_min_length",
                                        "overlap_length", "fft_size", "fft_inv_size", "input_size",
@@ -99,6 +103,8 @@ class Port:
         L.orc_dcblock_ff.restype = _DcBlock
         L.orc_fastdcblock_ff.restype = C.c_float
         L.orc_agc_ff.restype = C.c_float
+        L.orc_encode_ima_adpcm_i16_u8.restype = _Adpcm
+        L.orc_decode_ima_adpcm_u8_i16.restype = _Adpcm
 
     # ---- design
     def firdes_filter_len(self, tbw):
@@ -320,6 +326,24 @@ class Port:
             out.append(self.fft_c2c(win, True))
         return np.concatenate(out) if out else np.zeros(0, c64)
 
+
+    # ---- f3: IMA ADPCM
+    def encode_ima_adpcm_i16_u8(self, x, state=(0, 0)):
+        x = np.ascontiguousarray(x, np.int16); y = np.zeros(x.size // 2, np.uint8)
+        st = self.L.orc_encode_ima_adpcm_i16_u8(_p(x), _p(y), x.size, _Adpcm(*state)); return y, (st.index, st.previousValue)
+
+    def decode_ima_adpcm_u8_i16(self, x, state=(0, 0)):
+        x = np.ascontiguousarray(x, np.uint8); y = np.zeros(2 * x.size, np.int16)
+        st = self.L.orc_decode_ima_adpcm_u8_i16(_p(x), _p(y), x.size, _Adpcm(*state)); return y, (st.index, st.previousValue)
+
+    def compress_fft_adpcm_f_u8(self, x, fft_size):
+        """csdr.c:1745-1768 stream model: whole blocks of fft_size floats -> (fft_size+10)/2 bytes each."""
+        x = np.ascontiguousarray(x, f32); nb = x.size // fft_size; ob = (fft_size + 10) // 2
+        y = np.zeros(nb * ob, np.uint8)
+        for b in range(nb):
+            self.L.orc_compress_fft_adpcm_f_u8(_p(x[b * fft_size:]), _p(y[b * ob:]), fft_size)
+        return y
+
     # ---- FFT paths
     def fft_c2c(self, x, forward=True):
         x = _cf(x); y = np.zeros_like(x)
@@ -456,6 +480,8 @@ class Ref:
         for name in ("fmdemod_atan_cf", "fastdcblock_ff", "agc_ff"):
             getattr(L, name).restype = C.c_float
         L.dcblock_ff.restype = _DcBlock
+        L.encode_ima_adpcm_i16_u8.restype = _Adpcm
+        L.decode_ima_adpcm_u8_i16.restype = _Adpcm
         L.precalculate_window.restype = C.POINTER(C.c_float)
         if lib_path is None:
             L.fftwf_malloc.restype = C.c_void_p
@@ -502,6 +528,16 @@ class Ref:
     def apply_precalculated_window_c(self, x, w):
         x = _cf(x); w = np.ascontiguousarray(w, f32); y = np.zeros_like(x)
         self.L.apply_precalculated_window_c(_p(x), _p(y), x.size, _p(w)); return y
+
+
+    # ---- f3
+    def encode_ima_adpcm_i16_u8(self, x, state=(0, 0)):
+        x = np.ascontiguousarray(x, np.int16); y = np.zeros(x.size // 2, np.uint8)
+        st = self.L.encode_ima_adpcm_i16_u8(_p(x), _p(y), x.size, _Adpcm(*state)); return y, (st.index, st.previousValue)
+
+    def decode_ima_adpcm_u8_i16(self, x, state=(0, 0)):
+        x = np.ascontiguousarray(x, np.uint8); y = np.zeros(2 * x.size, np.int16)
+        st = self.L.decode_ima_adpcm_u8_i16(_p(x), _p(y), x.size, _Adpcm(*state)); return y, (st.index, st.previousValue)
 
     def nfm_taps(self, sample_rate):
         n = {48000: 201, 44100: 123, 8000: 81, 11025: 81}[sample_rate]

@@ -624,3 +624,59 @@ void orc_precalculate_window(float *windowt, int size, int window)
 
 void orc_apply_precalculated_window_c(const orc_cf *in, orc_cf *out, int size, const float *windowt)
 { for (int k = 0; k < size; k++) { out[k].i = in[k].i * windowt[k]; out[k].q = in[k].q * windowt[k]; } }   /* libcsdr.c:1269-1276 */
+
+
+/* ================================================================== f3: IMA ADPCM (ima_adpcm.c:88-174) */
+static const int adpcm_index_adjust[16] = { -1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8 };          /* ima_adpcm.c:90-95 */
+static int adpcm_step(int index)
+{   /* ima_adpcm.c:98-108: the standard IMA table, 89 entries, 7 ... 32767 */
+    static const int t[89] = { 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45, 50, 55, 60, 66, 73, 80, 88, 97, 107, 118, 130, 143,
+        157, 173, 190, 209, 230, 253, 279, 307, 337, 371, 408, 449, 494, 544, 598, 658, 724, 796, 876, 963, 1060, 1166, 1282, 1411, 1552, 1707, 1878, 2066,
+        2272, 2499, 2749, 3024, 3327, 3660, 4026, 4428, 4871, 5358, 5894, 6484, 7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500,
+        20350, 22385, 24623, 27086, 29794, 32767 };
+    return t[index];
+}
+static short adpcm_decode_one(unsigned code, orc_adpcm_t *st)
+{   /* ima_adpcm.c:110-134 */
+    const int step = adpcm_step(st->index);
+    int diff = step >> 3;
+    if (code & 1) diff += step >> 2;
+    if (code & 2) diff += step >> 1;
+    if (code & 4) diff += step;
+    if (code & 8) diff = -diff;
+    st->previousValue += diff;
+    if (st->previousValue > 32767) st->previousValue = 32767; else if (st->previousValue < -32768) st->previousValue = -32768;
+    st->index += adpcm_index_adjust[code];
+    if (st->index < 0) st->index = 0; else if (st->index > 88) st->index = 88;
+    return (short)st->previousValue;
+}
+static unsigned adpcm_encode_one(short sample, orc_adpcm_t *st)
+{   /* ima_adpcm.c:136-152 */
+    int diff = sample - st->previousValue, step = adpcm_step(st->index);
+    unsigned code = 0;
+    if (diff < 0) { code = 8; diff = -diff; }
+    if (diff >= step) { code |= 4; diff -= step; }
+    step >>= 1;
+    if (diff >= step) { code |= 2; diff -= step; }
+    step >>= 1;
+    if (diff >= step) { code |= 1; }
+    adpcm_decode_one(code, st);
+    return code;
+}
+orc_adpcm_t orc_encode_ima_adpcm_i16_u8(const short *in, unsigned char *out, int n, orc_adpcm_t st)
+{   /* ima_adpcm.c:154-163: two samples per byte, low nibble first; an odd last sample is dropped */
+    for (int k = 0; k < n / 2; k++) { unsigned lo = adpcm_encode_one(in[2 * k], &st), hi = adpcm_encode_one(in[2 * k + 1], &st); out[k] = (unsigned char)(lo | (hi << 4)); }
+    return st;
+}
+orc_adpcm_t orc_decode_ima_adpcm_u8_i16(const unsigned char *in, short *out, int n, orc_adpcm_t st)
+{   /* ima_adpcm.c:165-174 */
+    for (int k = 0; k < n; k++) { out[2 * k] = adpcm_decode_one(in[k] & 0xf, &st); out[2 * k + 1] = adpcm_decode_one((in[k] >> 4) & 0xf, &st); }
+    return st;
+}
+void orc_compress_fft_adpcm_f_u8(const float *in, unsigned char *out, int fft_size)
+{   /* csdr.c:1745-1768: the first value repeated 10 times in front, (short)(v*100), encoder restarted from the zero state for every block */
+    short tmp[fft_size + 10];
+    for (int k = 0; k < fft_size + 10; k++) { float v = (k < 10 ? in[0] : in[k - 10]) * 100; tmp[k] = (short)(int)v; }
+    orc_adpcm_t st = {0, 0};
+    orc_encode_ima_adpcm_i16_u8(tmp, out, fft_size + 10, st);
+}

@@ -107,6 +107,13 @@ void  orc_logpower_cf(const orc_cf *in, float *out, int n, float add_db);       
 void  orc_precalculate_window(float *windowt, int size, int window);                     /* :1256-1267 */
 void  orc_apply_precalculated_window_c(const orc_cf *in, orc_cf *out, int size, const float *windowt); /* :1269-1276 */
 
+/* ---- f3: IMA ADPCM codec -- integer, bit exact ---- */
+typedef struct { int index, previousValue; } orc_adpcm_t;                                 /* ima_adpcm.h:5-8 */
+orc_adpcm_t orc_encode_ima_adpcm_i16_u8(const short *in, unsigned char *out, int input_length, orc_adpcm_t state); /* ima_adpcm.c:154-163 */
+orc_adpcm_t orc_decode_ima_adpcm_u8_i16(const unsigned char *in, short *out, int input_length, orc_adpcm_t state); /* :165-174 */
+/* one block of `csdr compress_fft_adpcm_f_u8` (csdr.c:1745-1768): 10 pad values + fft_size dB values, x100 -> short, encoded from a zero state */
+void orc_compress_fft_adpcm_f_u8(const float *in, unsigned char *out, int fft_size);
+
 /* ---- whole-stream models of the csdr CLI loops (block framing included) ---- */
 /* csdr.c:877-925: 1024-sample chunks, phase threaded through; n need not be a multiple of 1024 only for the last chunk */
 float orc_stream_shift_addition_cc(const orc_cf *in, orc_cf *out, long n, float rate, float starting_phase, int chunk);

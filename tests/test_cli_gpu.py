@@ -355,3 +355,20 @@ def test_cli_am_and_ssb_chains(port):
     want = port.convert_f_s16(port.limit_ff(port.agc_ff(port.realpart_cf(bp))[0], 1.0))
     got = np.frombuffer(run(["chain", ssb % "agc_ff | "], iq, 65536), np.int16)
     assert got.size == want.size and relrms(got.astype(f32), want.astype(f32)) < 2e-2
+
+
+def test_cli_f3_adpcm(port):
+    """test_ima_adpcm.grc:721-722 round trip as CLI processes, and the waterfall compressor, byte for byte."""
+    rng = np.random.default_rng(16)
+    x = (8000 * np.sin(np.arange(50000) * 0.01) + rng.integers(-3000, 3000, 50000)).astype(np.int16)
+    enc = run(["encode_ima_adpcm_i16_u8"], x)
+    assert enc == port.encode_ima_adpcm_i16_u8(x)[0].tobytes()
+    dec = run(["decode_ima_adpcm_u8_i16"], np.frombuffer(enc, np.uint8))
+    assert dec == port.decode_ima_adpcm_u8_i16(np.frombuffer(enc, np.uint8))[0].tobytes()
+    rows = (rng.uniform(-120, 10, 9 * 1024) + 20 * np.sin(np.arange(9 * 1024) * 0.05)).astype(f32)
+    assert run(["compress_fft_adpcm_f_u8", 1024], rows, 4096) == port.compress_fft_adpcm_f_u8(rows, 1024).tobytes()
+    # waterfall path of openwebrx in one process: fft_cc | logpower_cf | compress_fft_adpcm_f_u8
+    sig = crand(rng, 40000)
+    want = port.compress_fft_adpcm_f_u8(port.logpower_cf(port.fft_cc(sig, 1024, 3000), -70), 1024)
+    got = np.frombuffer(run(["chain", "fft_cc 1024 3000 HAMMING | logpower_cf -70 | compress_fft_adpcm_f_u8 1024"], sig, 16384), np.uint8)
+    assert got.size == want.size and np.mean(got != want) < 0.02      # float dB values x100 truncated to short: a last-bit difference can flip a code

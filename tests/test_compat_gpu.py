@@ -140,3 +140,12 @@ def test_f2_dropin_symbols(ours, port):
     assert np.array_equal(ours.precalculate_window(512, "BLACKMAN"), port.precalculate_window(512, "BLACKMAN"))
     wnd = port.precalculate_window(512)
     assert np.array_equal(ours.apply_precalculated_window_c(x[:512], wnd), (x[:512].view(f32).reshape(-1, 2) * wnd[:, None]).reshape(-1).view(c64))
+
+
+def test_f3_adpcm_dropin(ours, port):
+    rng = np.random.default_rng(52)
+    x = (8000 * np.sin(np.arange(9001) * 0.01) + rng.integers(-3000, 3000, 9001)).astype(np.int16)
+    (a, sa), (b, sb) = ours.encode_ima_adpcm_i16_u8(x, (5, -100)), port.encode_ima_adpcm_i16_u8(x, (5, -100))
+    assert np.array_equal(a, b) and sa == sb
+    (c, sc), (d, sd) = ours.decode_ima_adpcm_u8_i16(a, (3, 77)), port.decode_ima_adpcm_u8_i16(a, (3, 77))
+    assert np.array_equal(c, d) and sc == sd

@@ -390,3 +390,28 @@ def test_f2_fft_cc(gpu, port, fft, every):
     for calls in (1, 3):
         got = gpu.fft_cc(x, fft, every, "HAMMING", calls=calls)
         assert got.size == want.size and relrms(got, want) <= TOL
+
+
+# ---------------------------------------------------------------- f3: IMA ADPCM, bit exact
+def test_f3_adpcm(gpu, port):
+    rng = np.random.default_rng(46)
+    x = np.stack([(8000 * np.sin(np.arange(30000) * 0.01 * (s + 1)) + rng.integers(-3000, 3000, 30000)) for s in range(5)]).astype(np.int16)
+    x[4] = rng.integers(-32768, 32768, 30000)
+    st0 = np.array([[0, 0], [5, -100], [88, 32767], [0, -32768], [40, 1]], np.int32)
+    for calls in (1, 3):
+        y, st = gpu.encode_ima_adpcm_i16_u8(x, st0, calls=calls)
+        for s in range(5):
+            w, ws = port.encode_ima_adpcm_i16_u8(x[s], tuple(st0[s]))
+            assert np.array_equal(y[s], w) and tuple(st[s]) == ws
+        z, zt = gpu.decode_ima_adpcm_u8_i16(y, st0, calls=calls)
+        for s in range(5):
+            w, ws = port.decode_ima_adpcm_u8_i16(y[s], tuple(st0[s]))
+            assert np.array_equal(z[s], w) and tuple(zt[s]) == ws
+    # encode -> decode round trip tracks the input (size-independent property at a larger size)
+    big = (12000 * np.sin(np.arange(1 << 20) * 0.002)).astype(np.int16)
+    enc, _ = gpu.encode_ima_adpcm_i16_u8(big)
+    dec, _ = gpu.decode_ima_adpcm_u8_i16(enc)
+    assert np.abs(dec.astype(np.int32) - big.astype(np.int32))[64:].max() < 400
+    fftrows = (rng.uniform(-120, 10, 37 * 2048) + 20 * np.sin(np.arange(37 * 2048) * 0.05)).astype(f32)
+    fftrows[5] = 400.0; fftrows[6] = -400.0; fftrows[7] = 3e7
+    assert np.array_equal(gpu.compress_fft_adpcm_f_u8(fftrows, 2048), port.compress_fft_adpcm_f_u8(fftrows, 2048))
