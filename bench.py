@@ -99,13 +99,20 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # CSDR_BENCH_SHARED_GPU=1: dry run of the multi-rank code path on a box with ONE GPU (all ranks on device 0, gloo for the
+    # barrier / max-over-ranks) -- a test aid for the launcher contract, never a measurement.
+    shared = os.environ.get("CSDR_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if shared else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     import csdr_amd
-    ctx = csdr_amd.Context(local_rank)           # own non-blocking HIP stream; timed with HIP events on that stream
+    ctx = csdr_amd.Context(dev_index)            # own non-blocking HIP stream; timed with HIP events on that stream
     L = ctx.L
     S, T = args.streams, args.block
     assert T % 1024 == 0
@@ -143,7 +150,7 @@ def main():
     wall = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([wall], device="cpu" if shared else "cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
     kms = C.c_double(0); kl = C.c_long(0)
