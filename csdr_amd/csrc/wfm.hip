@@ -217,6 +217,9 @@ struct csdr_amd_wfm {
     WfmMfmaDevice mfma;
     float2 *d_ctab; size_t ctab_cap;
     float2 c_prev;                   // phasor seed of the previous block's last chunk (history windows)
+    // side stream: the bounds-checked edge tiles and the history copy run beside the dominant kernel (which leaves the CUs' wave slots
+    // mostly free: 4 waves per CU), joined before the back end
+    hipStream_t side; hipEvent_t ev_fork, ev_join;
 };
 
 extern "C" {
@@ -265,6 +268,16 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
         }
     }
     w->profiling = false; w->ev_used = 0; w->prof_ms = 0; w->prof_launches = 0;
+    w->side = nullptr; w->ev_fork = nullptr; w->ev_join = nullptr;
+    {
+        const char *e = getenv("CSDR_AMD_WFM_SIDE");
+        if (w->use_mfma && e && atoi(e) == 1) {      // opt-in: measured 1.324 vs 1.301 ms per step WITH the fork/join (cross-stream events cost more than the 2 x 22 us they hide)
+            if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) w->side = nullptr;
+            if (w->side && (hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)) {
+                (void)hipStreamDestroy(w->side); w->side = nullptr;
+            }
+        }
+    }
     if (csdr_amd_wfm_reset(w)) { delete w; return nullptr; }
     return w;
 }
@@ -280,6 +293,9 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
     if (w->mfma.d_consts) (void)hipFree(w->mfma.d_consts);
     if (w->mfma.d_set_of) (void)hipFree(w->mfma.d_set_of);
     if (w->d_ctab) (void)hipFree(w->d_ctab);
+    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
+    if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+    if (w->ev_join) (void)hipEventDestroy(w->ev_join);
     delete w;
 }
 
@@ -327,6 +343,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     if (((uintptr_t)in & 15) || (in_pitch & 15)) return fail_msg(-3, "wfm: input pointer and pitch must be 16-byte aligned");
     const int T = (int)block_samples;
     int rc = 0;
+    bool hist_saved = false;
     if (w->use_mfma) {
         // 1a. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping
         //     (libcsdr_gpl.c:33-34, 48-51; chunks of 1024 per csdr.c:911-918).  ctab[0] belongs to the previous block's last chunk.
@@ -377,25 +394,37 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
                 w->ev_pool.emplace_back(a, b);
             }
             e0 = w->ev_pool[w->ev_used].first; e1 = w->ev_pool[w->ev_used].second; w->ev_used++;
-            CSDR_HIP(hipEventRecord(e0, st));
         }
+        bool forked = false;
         if (w->use_mfma) {
-            rc = wfm_mfma_launch(st, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio);
+            hipStream_t se = st;
+            if (w->side) {                                                     // fork: edge tiles + history copy beside the dominant kernel
+                CSDR_HIP(hipEventRecord(w->ev_fork, st));
+                CSDR_HIP(hipStreamWaitEvent(w->side, w->ev_fork, 0));
+                se = w->side; forked = true;
+            }
+            rc = wfm_mfma_launch(st, se, e0, e1, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio);
             if (rc) return rc;
             w->kernel_name = wfm_mfma_last_kernel();
+            if (forked) {
+                if (T >= HIST) { hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, se, in, in_pitch, T, w->d_hist); CSDR_LAUNCH_CHECK(); hist_saved = true; }
+                CSDR_HIP(hipEventRecord(w->ev_join, se));
+                CSDR_HIP(hipStreamWaitEvent(st, w->ev_join, 0));
+            }
         } else {
+            if (e0) CSDR_HIP(hipEventRecord(e0, st));
             hipLaunchKernelGGL(k_wfm_front, dim3(w->n_streams, cdiv(n_audio, TILE_A)), dim3(256), lds, st,
                                in, in_pitch, w->d_hist, w->d_rot, w->d_taps, w->d_demod, w->demod_pitch, p);
             CSDR_LAUNCH_CHECK();
+            if (e1) CSDR_HIP(hipEventRecord(e1, st));
         }
-        if (w->profiling) CSDR_HIP(hipEventRecord(e1, st));
         hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, BK_CHUNK), w->n_streams), dim3(256), 0, st,
                            w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j - 4 * (w->next_j / 4)) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
         CSDR_LAUNCH_CHECK();
         w->flip ^= 1;
     }
-    // 3. history for the next block
-    if (T >= HIST) {
+    // 3. history for the next block (already done on the side stream when that path ran)
+    if (T >= HIST && !hist_saved) {
         hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, st, in, in_pitch, T, w->d_hist);
         CSDR_LAUNCH_CHECK();
     }

@@ -480,7 +480,7 @@ namespace csdr_amd {
 static const char *g_last_kernel = "k_wfm_mfma";
 const char *wfm_mfma_last_kernel() { return g_last_kernel; }
 
-int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
+int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
                     float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio)
 {
     MfmaParams p;
@@ -495,7 +495,7 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
     const int n_sb = (n_streams + 63) / 64;
     static int target = 0;
     if (!target) { const char *e = getenv("CSDR_AMD_WFM_WAVES"); target = e ? atoi(e) : 2048; if (target < 1) target = 2048; }
-    auto launch = [&](long long first, long long last, bool edge) -> int {
+    auto launch = [&](hipStream_t ls, long long first, long long last, bool edge) -> int {
         if (last < first) return 0;
         p.tile_first = first; p.n_tiles = (int)(last - first + 1); p.tiles_per_wave = 0;
         // waves = stream blocks x phases x segments: aim at `target` waves, keep >= 4 tiles per wave
@@ -504,8 +504,8 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
         if (z > per_phase / 4) z = (int)(per_phase / 4);
         if (z < 1) z = 1;
         dim3 grid(n_sb, p.n_phases, z);
-        if (edge) hipLaunchKernelGGL((k_wfm_mfma<true>), grid, dim3(64), 0, st, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
-        else      hipLaunchKernelGGL((k_wfm_mfma<false>), grid, dim3(64), 0, st, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
+        if (edge) hipLaunchKernelGGL((k_wfm_mfma<true>), grid, dim3(64), 0, ls, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
+        else      hipLaunchKernelGGL((k_wfm_mfma<false>), grid, dim3(64), 0, ls, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
         CSDR_LAUNCH_CHECK();
         return 0;
     };
@@ -532,6 +532,7 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
         if (z < 1) z = 1;
         const size_t lds = (size_t)NBv * (4 * ((SBv * 107 + 255) / 256) * 1024) + 2 * SBv * 16 * sizeof(float);
         if (wp.row_bytes != 1712) return fail_msg(-3, "wfm: workgroup kernel is specialised for 1712-byte quad rows");
+        if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
         if (cfg == 1) {
             static bool done1 = false;
             if (!done1) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done1 = true; }
@@ -542,16 +543,19 @@ int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const ui
             hipLaunchKernelGGL((k_wfm_mfma_wg<16, 5>), dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
         }
         CSDR_LAUNCH_CHECK();
+        if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
         g_last_kernel = "k_wfm_mfma_wg";
         // leftovers around the quad range run on the per-wave kernel (bounds-checked variant: a handful of tiles)
-        rc = launch(tile_first, 4 * qa - 1, true); if (rc) return rc;
-        rc = launch(4 * (qb + 1), tile_last, true);
+        rc = launch(st_edge, tile_first, 4 * qa - 1, true); if (rc) return rc;
+        rc = launch(st_edge, 4 * (qb + 1), tile_last, true);
         return rc;
     }
     g_last_kernel = "k_wfm_mfma";
-    rc = launch(t_a, t_b, false); if (rc) return rc;                        // the bulk: no bounds logic at all
-    rc = launch(tile_first, t_a - 1 < tile_last ? t_a - 1 : tile_last, true); if (rc) return rc;      // leading tiles (history)
-    if (t_b + 1 > t_a - 1) rc = launch(t_b + 1 > t_a ? t_b + 1 : t_a, tile_last, true);               // trailing tiles (ragged end / partial tile)
+    if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
+    rc = launch(st, t_a, t_b, false); if (rc) return rc;                    // the bulk: no bounds logic at all
+    if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
+    rc = launch(st_edge, tile_first, t_a - 1 < tile_last ? t_a - 1 : tile_last, true); if (rc) return rc;      // leading tiles (history)
+    if (t_b + 1 > t_a - 1) rc = launch(st_edge, t_b + 1 > t_a ? t_b + 1 : t_a, tile_last, true);               // trailing tiles (ragged end / partial tile)
     return rc;
 }
 

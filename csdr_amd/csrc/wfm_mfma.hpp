@@ -26,7 +26,9 @@ struct WfmMfmaDevice {             // device copies
 bool wfm_mfma_supported(int D, int L, int F);
 void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *taps, WfmMfmaTable &t);
 const char *wfm_mfma_last_kernel();
-int wfm_mfma_launch(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
+// st_edge: stream for the few bounds-checked tiles around the whole-quad range (may equal st); ev_begin/ev_end (may be null) are recorded on st
+// around the dominant kernel only.
+int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
                     float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio);
 
 } // namespace csdr_amd
