@@ -126,6 +126,7 @@ struct MfmaParams {
     long long B;                      // global sample index of the block start (multiple of 1024)
     long long j_first; int n_audio;   // audio samples produced by this call: j_first .. j_first+n_audio-1
     long long tile_first; int n_tiles, tiles_per_wave;
+    long long tile_first_b; int n_tiles_b; int two_ranges;   // edge launch: blockIdx.z picks [tile_first, +n_tiles) or [tile_first_b, +n_tiles_b), no z segmentation
     long long tile_out0;              // tile whose 4 audio samples land at demod[stream][0..3]
     int tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
@@ -185,12 +186,15 @@ __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in,
     const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
     const int ph = blockIdx.y;
     // tiles of this phase inside [tile_first, tile_first + n_tiles): ti = t0 + m * n_phases, m in this segment
-    const long long t_lim = p.tile_first + p.n_tiles;
-    long long t0 = p.tile_first + (((long long)ph - p.tile_first) % p.n_phases + p.n_phases) % p.n_phases;
+    const bool rb = p.two_ranges && blockIdx.z == 1;
+    const long long r_first = rb ? p.tile_first_b : p.tile_first;
+    const long long t_lim = r_first + (rb ? p.n_tiles_b : p.n_tiles);
+    long long t0 = r_first + (((long long)ph - r_first) % p.n_phases + p.n_phases) % p.n_phases;
     if (t0 >= t_lim) return;
     const long long m_total = (t_lim - 1 - t0) / p.n_phases + 1;
-    const long long m_per = (m_total + gridDim.z - 1) / gridDim.z;
-    const long long m_begin = (long long)blockIdx.z * m_per;
+    const int zseg = p.two_ranges ? 1 : (int)gridDim.z, zidx = p.two_ranges ? 0 : (int)blockIdx.z;
+    const long long m_per = (m_total + zseg - 1) / zseg;
+    const long long m_begin = (long long)zidx * m_per;
     long long m_end = m_begin + m_per; if (m_end > m_total) m_end = m_total;
     if (m_begin >= m_end) return;
     const long long step = (long long)p.n_phases * p.tile_stride_bytes;               // bytes between this wave's consecutive windows
@@ -497,7 +501,7 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
     if (!target) { const char *e = getenv("CSDR_AMD_WFM_WAVES"); target = e ? atoi(e) : 2048; if (target < 1) target = 2048; }
     auto launch = [&](hipStream_t ls, long long first, long long last, bool edge) -> int {
         if (last < first) return 0;
-        p.tile_first = first; p.n_tiles = (int)(last - first + 1); p.tiles_per_wave = 0;
+        p.tile_first = first; p.n_tiles = (int)(last - first + 1); p.tiles_per_wave = 0; p.two_ranges = 0; p.tile_first_b = 0; p.n_tiles_b = 0;
         // waves = stream blocks x phases x segments: aim at `target` waves, keep >= 4 tiles per wave
         const long long per_phase = (p.n_tiles + p.n_phases - 1) / p.n_phases;
         int z = (int)((target + (long long)n_sb * p.n_phases - 1) / ((long long)n_sb * p.n_phases));
@@ -546,8 +550,15 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
         if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
         g_last_kernel = "k_wfm_mfma_wg";
         // leftovers around the quad range run on the per-wave kernel (bounds-checked variant: a handful of tiles)
-        rc = launch(st_edge, tile_first, 4 * qa - 1, true); if (rc) return rc;
-        rc = launch(st_edge, 4 * (qb + 1), tile_last, true);
+        const long long a0 = tile_first, a1 = 4 * qa - 1, b0 = 4 * (qb + 1), b1 = tile_last;
+        if (a1 >= a0 && b1 >= b0) {                                          // both ends in ONE launch (each is latency bound: ~22 us)
+            p.tile_first = a0; p.n_tiles = (int)(a1 - a0 + 1); p.tile_first_b = b0; p.n_tiles_b = (int)(b1 - b0 + 1); p.two_ranges = 1; p.tiles_per_wave = 0;
+            hipLaunchKernelGGL((k_wfm_mfma<true>), dim3(n_sb, p.n_phases, 2), dim3(64), 0, st_edge, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
+            CSDR_LAUNCH_CHECK();
+            return 0;
+        }
+        rc = launch(st_edge, a0, a1, true); if (rc) return rc;
+        rc = launch(st_edge, b0, b1, true);
         return rc;
     }
     g_last_kernel = "k_wfm_mfma";
