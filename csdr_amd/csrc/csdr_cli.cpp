@@ -580,6 +580,78 @@ int passthrough(bool read_preamble, int send_size)
     for (;;) { size_t got = 0; bool more = read_full(buf.data(), buf.size(), &got); if (got) write_full(buf.data(), got); if (!more) return 0; }
 }
 
+
+// ------------------------------------------------------------------ f4: the ddcd topology in one process
+// ddcd runs `csdr fastddc_fwd_cc D | nmux` once and one `csdr fastddc_inv_cc --fd <ctl> D` per client (ddcd_old.cpp:238-252, 474-492):
+// N processes re-reading the same spectrum.  Here: one forward transform per block and ONE multi-channel inverse call for all clients;
+//   csdr fastddc_bank_cc <decimation> <transition_bw> <window> <ctl | -> <out_0> <shift_rate_0> [<out_1> <shift_rate_1> ...]
+// out_k: a path (file or fifo) or fd:<n>;  ctl: a fifo path / fd:<n> carrying lines "<channel> <shift_rate>\n" (newest line per poll), or "-".
+int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
+{
+    if (argc < 8 || (argc - 6) % 2) return badsyntax("usage: fastddc_bank_cc <decimation> <transition_bw> <window> <ctl|-> <out_0> <rate_0> [<out_k> <rate_k> ...]");
+    int D = 0; float tbw = 0.05f; sscanf(argv[2], "%d", &D); sscanf(argv[3], "%g", &tbw);
+    const int window = window_from(argv[4]);
+    const int n_ch = (argc - 6) / 2;
+    auto open_fd = [](const char *spec, int flags) { int fd = -1; if (!strncmp(spec, "fd:", 3)) sscanf(spec + 3, "%d", &fd); else fd = open(spec, flags, 0644); return fd; };
+    Control ctl;
+    if (strcmp(argv[5], "-")) { ctl.fd = open_fd(argv[5], O_RDONLY | O_NONBLOCK); if (ctl.fd <= 0) return badsyntax("cannot open the control channel"); fcntl(ctl.fd, F_SETFL, fcntl(ctl.fd, F_GETFL, 0) | O_NONBLOCK); }
+    std::vector<int> out_fd(n_ch); std::vector<float> rates(n_ch);
+    for (int k = 0; k < n_ch; k++) {
+        sscanf(argv[7 + 2 * k], "%g", &rates[k]);
+        out_fd[k] = open_fd(argv[6 + 2 * k], O_WRONLY | O_CREAT | O_TRUNC);
+        if (out_fd[k] < 0) { fprintf(stderr, "csdr fastddc_bank_cc: cannot open output %s\n", argv[6 + 2 * k]); return -1; }
+    }
+    csdr_fastddc_t ddc;
+    if (csdr_amd_fastddc_init(&ddc, tbw, D, 0)) return badsyntax("error in fastddc_init()");
+    int nb_max = (int)(block / ddc.input_size); if (nb_max < 1) nb_max = 1;
+    csdr_amd_fastddc_fwd *fwd = csdr_amd_fastddc_fwd_create(c, &ddc, nb_max);
+    csdr_amd_fastddc_inv *inv = csdr_amd_fastddc_inv_create(c, tbw, D, rates.data(), n_ch, window, nb_max);
+    if (!fwd || !inv) die("fastddc_bank create");
+    const size_t pitch = (size_t)csdr_amd_fastddc_inv_max_output(inv, nb_max) + 8;
+    const size_t in_elems = (size_t)nb_max * ddc.input_size;
+    csdr_complexf *h_in = nullptr, *h_out = nullptr;
+    if (hipHostMalloc((void **)&h_in, in_elems * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&h_out, (size_t)n_ch * pitch * 8, hipHostMallocDefault) != hipSuccess) die("pinned buffers");
+    csdr_complexf *d_in = (csdr_complexf *)csdr_amd_malloc(c, in_elems * 8 + 64), *d_spec = (csdr_complexf *)csdr_amd_malloc(c, (size_t)nb_max * ddc.fft_size * 8 + 64);
+    csdr_complexf *d_out = (csdr_complexf *)csdr_amd_malloc(c, (size_t)n_ch * pitch * 8 + 64);
+    if (!d_in || !d_spec || !d_out) die("device buffers");
+    std::vector<int> counts(n_ch);
+    fprintf(stderr, "csdr fastddc_bank_cc: %d channels, fft_size = %d, input_size = %d, %d blocks per call\n", n_ch, ddc.fft_size, ddc.input_size, nb_max);
+    size_t have = 0;
+    for (bool eof = false; !eof;) {
+        size_t got = 0;
+        if (!read_full((char *)h_in + have * 8, (in_elems - have) * 8, &got)) eof = true;
+        have += got / 8;
+        if (ctl.fd) {
+            // every complete line since the last poll is applied (several clients may retune between two blocks)
+            const ssize_t r = read(ctl.fd, ctl.buf + ctl.fill, sizeof(ctl.buf) - 1 - ctl.fill);
+            if (r > 0) {
+                int end = ctl.fill + (int)r, start = 0;
+                for (int i = 0; i < end; i++) if (ctl.buf[i] == '\n') {
+                    ctl.buf[i] = 0; int ch = -1; float rate = 0;
+                    if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch) { MUST(csdr_amd_fastddc_inv_set_rate(inv, ch, rate)); fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ch, rate); }
+                    start = i + 1;
+                }
+                memmove(ctl.buf, ctl.buf + start, end - start); ctl.fill = end - start;
+            }
+        }
+        const int nb = (int)(have / ddc.input_size);
+        if (nb == 0) continue;
+        const size_t used = (size_t)nb * ddc.input_size;
+        MUST(csdr_amd_h2d(c, d_in, h_in, used * 8));
+        MUST(csdr_amd_fastddc_fwd_process(fwd, d_in, d_spec, nb));
+        MUST(csdr_amd_fastddc_inv_process(inv, d_spec, nb, d_out, pitch, counts.data()));
+        MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_ch * pitch * 8));
+        for (int k = 0; k < n_ch; k++) {
+            size_t done = 0; const size_t bytes = (size_t)counts[k] * 8; const char *src = (const char *)(h_out + (size_t)k * pitch);
+            while (done < bytes) { ssize_t r = write(out_fd[k], src + done, bytes - done); if (r < 0) { if (errno == EINTR) continue; break; } done += (size_t)r; }
+        }
+        memmove(h_in, h_in + used, (have - used) * 8);
+        have -= used;
+    }
+    for (int k = 0; k < n_ch; k++) close(out_fd[k]);
+    return 0;
+}
+
 // Build the operator for one command line.  `block` = the largest input this stage will be handed in one call.
 // ctl: opened when the command line carries --fifo/--fd (single-command mode only).  Returns nullptr after printing why.
 Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control *ctl, int the_bufsize)
@@ -746,7 +818,7 @@ int main(int argc, char **argv)
                         "decimating_shift_addition_cc fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff "
                         "deemphasis_nfm_ff limit_ff fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c "
                         "amdemod_cf amdemod_estimator_cf fmdemod_atan_cf dcblock_ff fastdcblock_ff agc_ff gain_ff realpart_cf logpower_cf fft_cc encode_ima_adpcm_i16_u8 decode_ima_adpcm_u8_i16 compress_fft_adpcm_f_u8 "
-                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, chain \"<cmd> <args> | <cmd> <args> ...\"\n");
+                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, fastddc_bank_cc <decimation> <tbw> <window> <ctl|-> <out_0> <rate_0> ..., chain \"<cmd> <args> | <cmd> <args> ...\"\n");
         return -1;
     }
     g_cmd = argv[1];
@@ -788,6 +860,7 @@ int main(int argc, char **argv)
     csdr_amd_ctx *c = csdr_amd_ctx_create(dev ? atoi(dev) : 0, nullptr);
     if (!c) { fprintf(stderr, "csdr %s: %s\n", g_cmd, csdr_amd_last_error()); return 3; }
     size_t block = block_elems();
+    if (cmd == "fastddc_bank_cc") return run_bank(c, argc, argv, block);
     std::vector<Stage *> stages; std::vector<size_t> caps;
     Control ctl;
     std::vector<std::vector<std::string>> cmds;

@@ -390,6 +390,7 @@ int csdr_amd_fastddc_fwd_process(csdr_amd_fastddc_fwd *f, const csdr_complexf *i
 // ====================================================================================== fastddc inverse (multi channel)
 struct csdr_amd_fastddc_inv {
     csdr_amd_ctx *ctx; int n_channels, max_blocks;
+    float tbw; int decimation, window;                             // kept for per-channel retunes
     std::vector<csdr_fastddc_t> geom;
     cf32 *d_H, *d_inv_in, *d_td;
     ChanGeom *d_geom; DdcChanState *d_state;
@@ -405,6 +406,7 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
     if (n_channels < 1 || max_blocks < 1) { fail_msg(-3, "fastddc_inv: bad sizes"); return nullptr; }
     csdr_amd_fastddc_inv *f = new csdr_amd_fastddc_inv();
     f->ctx = ctx; f->n_channels = n_channels; f->max_blocks = max_blocks;
+    f->tbw = transition_bw; f->decimation = decimation; f->window = window;
     f->geom.resize(n_channels);
     std::vector<ChanGeom> cg(n_channels);
     for (int c = 0; c < n_channels; c++) {
@@ -445,6 +447,32 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
         hipfftDestroy(h);
     }
     return f;
+}
+
+// Retune ONE channel: what `csdr fastddc_inv_cc --fd` does when a new rate arrives (csdr.c:2329-2376: geometry, band-pass taps, their FFT and the
+// shift status are all rebuilt), applied to one row of the multi-channel object between two process() calls.
+int csdr_amd_fastddc_inv_set_rate(csdr_amd_fastddc_inv *f, int channel, float shift_rate)
+{
+    if (!f || channel < 0 || channel >= f->n_channels) return fail_msg(-3, "fastddc_inv_set_rate: bad channel");
+    csdr_amd_ctx *ctx = f->ctx;
+    csdr_fastddc_t g;
+    if (csdr_amd_fastddc_init(&g, f->tbw, f->decimation, shift_rate)) return fail_msg(-3, "fastddc_init failed");
+    f->geom[channel] = g;
+    ChanGeom cg; cg.offsetbin = g.offsetbin; cg.sindelta = g.dsadata.sindelta; cg.cosdelta = g.dsadata.cosdelta; cg.rate2 = g.dsadata.rate;
+    const int fft = g.fft_size;
+    std::vector<cf32> taps((size_t)fft, cf32{0.f, 0.f});
+    const float half_bw = 0.5f / (float)f->decimation;
+    csdr_amd_firdes_bandpass_c((csdr_complexf *)taps.data(), g.taps_length, (-shift_rate) - half_bw, (-shift_rate) + half_bw, f->window);
+    CSDR_HIP(hipStreamSynchronize(ctx->stream));                     // the previous process() call may still read this channel's row
+    CSDR_HIP(hipMemcpy(f->d_geom + channel, &cg, sizeof(ChanGeom), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemset(f->d_state + channel, 0, sizeof(DdcChanState)));
+    cf32 *row = f->d_H + (size_t)channel * fft;
+    CSDR_HIP(hipMemcpy(row, taps.data(), sizeof(cf32) * (size_t)fft, hipMemcpyHostToDevice));
+    int rc = csdr_amd_fft_c2c(ctx, (const csdr_complexf *)row, (csdr_complexf *)row, fft, 1); if (rc) return rc;
+    hipLaunchKernelGGL(k_swap_halves, dim3(cdiv((size_t)fft / 2, 256)), dim3(256), 0, ctx->stream, row, fft, (size_t)fft);
+    CSDR_LAUNCH_CHECK();
+    CSDR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 void csdr_amd_fastddc_inv_destroy(csdr_amd_fastddc_inv *f)

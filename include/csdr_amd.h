@@ -246,6 +246,8 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
                                                   const float *host_shift_rates, int n_channels, int window,
                                                   int max_blocks);
 void csdr_amd_fastddc_inv_destroy(csdr_amd_fastddc_inv *f);
+/* retune one channel between two process() calls: geometry, taps and shift status of that channel are rebuilt (csdr.c:2329-2376) */
+int  csdr_amd_fastddc_inv_set_rate(csdr_amd_fastddc_inv *f, int channel, float shift_rate);
 int  csdr_amd_fastddc_inv_geometry(const csdr_amd_fastddc_inv *f, int channel, csdr_fastddc_t *ddc);
 int  csdr_amd_fastddc_inv_max_output(const csdr_amd_fastddc_inv *f, int n_blocks);
 int  csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *spectra, int n_blocks,

@@ -372,3 +372,51 @@ def test_cli_f3_adpcm(port):
     want = port.compress_fft_adpcm_f_u8(port.logpower_cf(port.fft_cc(sig, 1024, 3000), -70), 1024)
     got = np.frombuffer(run(["chain", "fft_cc 1024 3000 HAMMING | logpower_cf -70 | compress_fft_adpcm_f_u8 1024"], sig, 16384), np.uint8)
     assert got.size == want.size and np.mean(got != want) < 0.02      # float dB values x100 truncated to short: a last-bit difference can flip a code
+
+
+# ---------------------------------------------------------------- f4: the ddcd topology (one forward transform, N channels, per-channel retune)
+def test_cli_fastddc_bank(port, tmp_path):
+    import threading
+    import time
+    rng = np.random.default_rng(17)
+    D, tbw = 16, 0.02
+    rates = [0.11, -0.2, 0.3]
+    ddc, err = port.fastddc_init(tbw, D, rates[0])
+    assert err == 0
+    nblk = 6
+    x = crand(rng, nblk * ddc.input_size + 50)
+    outs = [str(tmp_path / ("ch%d.bin" % k)) for k in range(3)]
+    args = ["fastddc_bank_cc", D, tbw, "HAMMING", "-"]
+    for o, r in zip(outs, rates):
+        args += [o, r]
+    run(args, x, 2 * ddc.input_size)
+    spectra = port.fastddc_fwd_cc(x, ddc)
+    for k, r in enumerate(rates):
+        dk, _ = port.fastddc_init(tbw, D, r)
+        want = port.fastddc_inv_cc(spectra, dk, port.fastddc_taps_fft(dk, r, D))
+        got = np.fromfile(outs[k], c64)
+        assert got.size == want.size and relrms(got, want) <= TOL
+    # retune channel 1 through the control fifo between two calls (two blocks per call here)
+    fifo = str(tmp_path / "ctl"); os.mkfifo(fifo)
+    args[4] = fifo
+    env = dict(os.environ, CSDR_AMD_BLOCK=str(2 * ddc.input_size))
+    p = subprocess.Popen([CLI] + [str(a) for a in args], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    ctl = open(fifo, "w")
+    first = 2 * ddc.input_size
+    p.stdin.write(x[:first].tobytes()); p.stdin.flush()
+    time.sleep(2.0)
+    ctl.write("1 0.05\n"); ctl.flush()
+    time.sleep(0.3)
+    p.stdin.write(x[first:].tobytes()); p.stdin.close()
+    assert p.wait(timeout=60) == 0, p.stderr.read().decode()
+    ctl.close()
+    d1, _ = port.fastddc_init(tbw, D, rates[1])
+    part1 = port.fastddc_inv_cc(spectra[:2], d1, port.fastddc_taps_fft(d1, rates[1], D))
+    d2, _ = port.fastddc_init(tbw, D, 0.05)
+    part2 = port.fastddc_inv_cc(spectra[2:], d2, port.fastddc_taps_fft(d2, 0.05, D))       # status restarts from zero like the reference's rebuild
+    got = np.fromfile(outs[1], c64)
+    want = np.concatenate([part1, part2])
+    assert got.size == want.size and relrms(got, want) <= TOL
+    got0 = np.fromfile(outs[0], c64)                                                         # the other channels are untouched by the retune
+    d0, _ = port.fastddc_init(tbw, D, rates[0])
+    assert relrms(got0, port.fastddc_inv_cc(spectra, d0, port.fastddc_taps_fft(d0, rates[0], D))) <= TOL
