@@ -106,6 +106,55 @@ struct ChanGeom { int offsetbin; float sindelta, cosdelta, rate2; };
 // This is the channelizer's traffic: H is fft_size complexf PER CHANNEL (512 KiB at 65536; 128 MiB for 256 channels).  The reference
 // streams it once per block; here one lane owns output bin m of one channel for BT blocks at once, so each taps_fft value is
 // loaded once per call and reused from a register for all blocks of the call (lanes = consecutive m: coalesced for H and X).
+// Channel-tiled fold.  For a residue r = bin mod inv every channel needs the SAME spectrum values X[b][r + q*inv], q = 0..pre-1 (a channel's
+// offsetbin only decides which output bin the sum lands in), so a thread owns (residue r, CT channels, BT blocks): per q it loads BT spectrum
+// values and CT taps and does CT*BT complex MACs -- 4 MACs per load at CT = 8, BT = 8 against 0.94 for the per-channel kernel below, whose
+// 9 GB of L2/Infinity-Cache reads per 64-block call were what it ran at (profiles/r1_notes.md).  Index algebra (fastddc.c:106-147 with both
+// fft_swap_sides folded in): i = r + q*inv indexes the taps, (i + fft/2) mod fft the spectrum, the sum goes to output bin (r - offsetbin) mod inv.
+// Summation order over q is the reference's; products are fused (fmaf), well inside the 1e-5 gate.
+template <int CT, int BT>
+__global__ __launch_bounds__(256) void k_ddc_fold_ct(const cf32 *__restrict__ spectra, const cf32 *__restrict__ H, cf32 *__restrict__ inv_in,
+                                                     const ChanGeom *__restrict__ geom, int fft, int inv, int pre, int n_blocks, int n_channels)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= inv) return;
+    const int b0 = blockIdx.y * BT, nb = min(BT, n_blocks - b0);
+    const int c0 = blockIdx.z * CT, nc = min(CT, n_channels - c0);
+    float ai[CT][BT], aq[CT][BT];
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+        for (int k = 0; k < BT; k++) { ai[c][k] = 0.f; aq[c][k] = 0.f; }
+    const cf32 *x0 = spectra + (size_t)b0 * fft + r;
+    const cf32 *h0 = H + (size_t)c0 * fft + r;
+    const int hq = pre / 2;
+    // (explicit double buffering of the loads across q was tried: 7.2 -> 6.0 GS/s, the extra registers cost more than the overlap gains)
+    for (int q = 0; q < pre; q++) {
+        const int xq = (q + hq) & (pre - 1);                        // pre = fft / inv is a power of two
+        cf32 xv[BT];
+#pragma unroll
+        for (int k = 0; k < BT; k++) xv[k] = (k < nb) ? x0[(size_t)k * fft + (size_t)xq * inv] : cf32{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            const cf32 hv = (c < nc) ? h0[(size_t)c * fft + (size_t)q * inv] : cf32{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < BT; k++) {
+                ai[c][k] = fmaf(xv[k].i, hv.i, ai[c][k]); ai[c][k] = fmaf(-xv[k].q, hv.q, ai[c][k]);
+                aq[c][k] = fmaf(xv[k].i, hv.q, aq[c][k]); aq[c][k] = fmaf(xv[k].q, hv.i, aq[c][k]);
+            }
+        }
+    }
+    const float scale = 1.0f / (float)pre;
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        if (c >= nc) break;
+        int dst = (r - geom[c0 + c].offsetbin) % inv; if (dst < 0) dst += inv;
+#pragma unroll
+        for (int k = 0; k < BT; k++)
+            if (k < nb) inv_in[((size_t)(c0 + c) * n_blocks + b0 + k) * inv + dst] = cf32{ai[c][k] * scale, aq[c][k] * scale};
+    }
+}
+
 template <int BT>
 __global__ __launch_bounds__(256) void k_ddc_fold(const cf32 *__restrict__ spectra, const cf32 *__restrict__ H, cf32 *__restrict__ inv_in,
                                                   const ChanGeom *__restrict__ geom, int fft, int inv, int pre, int n_blocks)
@@ -512,10 +561,19 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
         CSDR_FFT(hipfftSetStream(h, st));
         f->plans[batch] = h;
     }
-    if (n_blocks >= 16)
+    const bool ct_ok = f->n_channels >= 4 && pre >= 2 && (pre & (pre - 1)) == 0 && !getenv("CSDR_AMD_DDC_FOLD_OLD");
+    // tile choice measured on config 4 (256 channels, 64 blocks per call): <4,16> 5.0, <8,8> 7.2, <6,12> 3.5, <2,16> 3.0 GS/s of wideband input
+    if (n_blocks >= 8 && ct_ok && f->n_channels >= 8) {
+        hipLaunchKernelGGL((k_ddc_fold_ct<8, 8>), dim3(cdiv(inv, 256), cdiv(n_blocks, 8), cdiv(f->n_channels, 8)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels);
+    } else if (n_blocks >= 16 && ct_ok) {
+        hipLaunchKernelGGL((k_ddc_fold_ct<4, 16>), dim3(cdiv(inv, 256), cdiv(n_blocks, 16), cdiv(f->n_channels, 4)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels);
+    } else if (ct_ok) {
+        hipLaunchKernelGGL((k_ddc_fold_ct<4, 4>), dim3(cdiv(inv, 256), cdiv(n_blocks, 4), cdiv(f->n_channels, 4)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels);
+    } else if (n_blocks >= 16) {
         hipLaunchKernelGGL((k_ddc_fold<16>), dim3(cdiv(inv, 256), cdiv(n_blocks, 16), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks);
-    else
+    } else {
         hipLaunchKernelGGL((k_ddc_fold<4>), dim3(cdiv(inv, 256), cdiv(n_blocks, 4), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks);
+    }
     CSDR_LAUNCH_CHECK();
     CSDR_FFT(hipfftExecC2C(f->plans[batch], (hipfftComplex *)f->d_inv_in, (hipfftComplex *)f->d_td, HIPFFT_BACKWARD));
     hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(f->n_channels, 64)), dim3(64), 0, st, f->d_state, f->d_geom, f->n_channels, n_blocks, g.post_input_size, g.post_decimation,

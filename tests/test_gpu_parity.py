@@ -250,6 +250,22 @@ def test_fastddc(gpu, port, D, tbw, shifts):
         assert relrms(outs[c], ref_out) < TOL
 
 
+@pytest.mark.parametrize("blocks_per_call", [20, 3])
+def test_fastddc_channel_tiled_fold(gpu, port, blocks_per_call):
+    """>= 4 channels take the channel-tiled fold kernel (8 channels x 8 blocks or 4 x 4 per thread, ragged tiles on both axes)."""
+    rng = np.random.default_rng(5)
+    D, tbw = 16, 0.05
+    shifts = [-0.4, -0.3, -0.1, 0.0, 0.07, 0.12, 0.2, 0.33, 0.41, 0.45, -0.22]      # 11 channels: full and ragged tiles of 8 (20 blocks) and of 4 (3 blocks)
+    pd, _ = port.fastddc_init(tbw, D, 0.0)
+    x = crand(rng, pd.input_size * 41)
+    pspec = port.fastddc_fwd_cc(x, pd)
+    outs = gpu.fastddc_inv_cc(pspec, tbw, D, shifts, blocks_per_call=blocks_per_call)
+    for c, sft in enumerate(shifts):
+        pdc, _ = port.fastddc_init(tbw, D, sft)
+        ref_out = port.fastddc_inv_cc(pspec, pdc, port.fastddc_taps_fft(pdc, sft, D))
+        assert outs[c].size == ref_out.size and relrms(outs[c], ref_out) < TOL
+
+
 # ---------------------------------------------------------------- the fused WFM chain (BASELINE config 2)
 def wfm_inputs(n_streams, n):
     return np.stack([to_u8(fm_signal(np.random.default_rng(1000 + s), n, offset=0.085)) for s in range(n_streams)])
