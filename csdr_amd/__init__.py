@@ -277,6 +277,13 @@ class Context:
         y = self.download(do, c64, s * n).reshape(s, n)
         return (y[0] if squeeze else y), ph.value
 
+    # the reference's own names for the five shifter variants (libcsdr.h:108, 185-207; libcsdr_gpl.h:32-35), CLI chunking included
+    def shift_addition_cc(self, x, rate, chunk=1024, phase=0.0): return self.shift_cc(x, rate, "addition", phase, chunk)
+    def shift_math_cc(self, x, rate, phase=0.0): return self.shift_cc(x, rate, "math", phase)
+    def shift_addfast_cc(self, x, rate, chunk=1024, phase=0.0): return self.shift_cc(x, rate, "addfast", phase, chunk)
+    def shift_unroll_cc(self, x, rate, size=1024, phase=0.0): return self.shift_cc(x, rate, "unroll", phase, size, size)
+    def shift_table_cc(self, x, rate, table_size=65536, phase=0.0): return self.shift_cc(x, rate, "table", phase, 1024, table_size)
+
     def shift_addition_fc(self, x, rate, phase=0.0, chunk=1024):
         x = np.ascontiguousarray(x, f32); n = x.size
         di = self.upload(x); do = self.alloc(8 * n + 64); rot = self.alloc(8 * n + 64)

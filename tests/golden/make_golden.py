@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""tests/golden/make_golden.py -- golden input/output vectors of the hot path, produced by the UNMODIFIED reference.
+
+Runs only where /root/reference is mounted: it drives oracle/_ref/libcsdr_ref.so (the reference's own sources compiled with the
+reference's own flags by oracle/Makefile, FFTW replaced by the double-precision shim) through oracle.Ref, and the reference CLI
+binary oracle/_ref/csdr for the two CLI-only loops.  Output: tests/golden/ref_vectors.npz (seeded inputs + reference outputs,
+a few hundred KB).  tests/test_golden.py replays the inputs through the CPU oracle (anywhere) and through the HIP path (GPU box,
+where neither /root/reference nor a toolchain for it is needed) and compares with these outputs.
+
+    python tests/golden/make_golden.py        # rewrites ref_vectors.npz
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+
+c64, f32 = np.complex64, np.float32
+
+
+def crand(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(c64)
+
+
+def main():
+    assert oracle.Ref.available(), "oracle/_ref/libcsdr_ref.so is missing (needs /root/reference; run `make -C oracle`)"
+    R = oracle.ref()
+    rng = np.random.default_rng(20260924)
+    g = {}
+    # ---- converters (bit exact)
+    g["u8"] = np.arange(256, dtype=np.uint8)
+    g["convert_u8_f"] = R.convert_u8_f(g["u8"])
+    g["s8"] = np.arange(-128, 128, dtype=np.int8)
+    g["convert_s8_f"] = R.convert_s8_f(g["s8"])
+    g["s16"] = rng.integers(-32768, 32768, 4096).astype(np.int16)
+    g["convert_s16_f"] = R.convert_s16_f(g["s16"])
+    fl = np.concatenate([np.linspace(-1.2, 1.2, 4001), [0.0, -0.0, 1.0, -1.0, 0.999999, 1e-30, 3.0, -3.0]]).astype(f32)
+    g["flt"] = fl
+    for name in ("convert_f_u8", "convert_f_s8", "convert_f_s16"):
+        g[name] = getattr(R, name)(fl)
+    g["convert_f_s24_le"] = R.convert_f_s24(fl, 0); g["convert_f_s24_be"] = R.convert_f_s24(fl, 1)
+    g["s24"] = rng.integers(0, 256, 3 * 1000, dtype=np.uint8)
+    g["convert_s24_f_le"] = R.convert_s24_f(g["s24"], 0); g["convert_s24_f_be"] = R.convert_s24_f(g["s24"], 1)
+    # ---- design
+    g["firdes_lowpass_79"] = R.firdes_lowpass_f(79, 0.05)
+    g["firdes_lowpass_801_blackman"] = R.firdes_lowpass_f(801, 0.01, "BLACKMAN")
+    g["firdes_bandpass_255"] = R.firdes_bandpass_c(255, -0.1, 0.2)
+    # ---- shifters with the CLI's 1024-chunk framing
+    x = crand(rng, 5 * 1024 + 300)
+    g["cx"] = x
+    for name in ("shift_addition_cc", "shift_math_cc", "shift_addfast_cc", "shift_unroll_cc"):
+        y, ph = getattr(R, name)(x, -0.085)
+        g[name] = y; g[name + "_phase"] = np.float32(ph)
+    y, ph = R.shift_table_cc(x, -0.085, 4096); g["shift_table_cc"] = y
+    g["rx"] = rng.uniform(-1, 1, 3000).astype(f32)
+    g["shift_addition_fc"] = R.shift_addition_fc(g["rx"], 0.21)[0]
+    y, st = R.decimating_shift_addition_cc(x, 0.07, 6); g["decimating_shift_addition_cc"] = y; g["dsa_status"] = np.array(st, np.float64)
+    # ---- FIR / demod / audio
+    taps = R.firdes_lowpass_f(79, 0.05)
+    g["fir_decimate_cc"] = R.fir_decimate_cc_block(x, 10, taps)
+    y, last = R.fmdemod_quadri_cf(x, (0.3, -0.2)); g["fmdemod_quadri_cf"] = y
+    y, last = R.deemphasis_wfm_ff(g["rx"], 50e-6, 48000, 0.1); g["deemphasis_wfm_ff"] = y
+    g["deemphasis_nfm_ff_48000"] = R.deemphasis_nfm_ff(g["rx"], 48000)
+    g["limit_ff"] = R.limit_ff((g["rx"] * 1.7).astype(f32), 1.0)
+    g["gain_ff"] = R.gain_ff(g["rx"], 2.5)
+    g["agc_in"] = (rng.uniform(-1, 1, 6 * 1024) * np.repeat(rng.uniform(0.01, 1, 6 * 8), 128)).astype(f32)
+    g["fastagc_ff"] = R.fastagc_ff(g["agc_in"], 1024, 0.8)
+    g["fractional_decimator_ff_5"] = R.fractional_decimator_ff(g["rx"], 5.0)
+    g["fractional_decimator_ff_2p5_4"] = R.fractional_decimator_ff(g["rx"], 2.5, 4)
+    # ---- FFT paths
+    bt = R.firdes_bandpass_c(255, -0.1, 0.2)
+    g["bandpass_fir_fft_cc_1024"] = R.bandpass_fir_fft_cc(x, bt, 1024)
+    ddc, err = R.fastddc_init(0.05, 16, 0.11)
+    g["fastddc_geometry"] = np.array([ddc.pre_decimation, ddc.post_decimation, ddc.taps_length, ddc.overlap_length, ddc.fft_size, ddc.fft_inv_size,
+                                      ddc.input_size, ddc.post_input_size, ddc.startbin, ddc.offsetbin, ddc.scrap], np.int64)
+    xd = crand(rng, 5 * ddc.input_size)
+    g["ddc_x"] = xd
+    spec = R.fastddc_fwd_cc(xd, ddc); g["fastddc_fwd_cc"] = spec
+    g["fastddc_inv_cc"] = R.fastddc_inv_cc(spec, ddc, R.fastddc_taps_fft(ddc, 0.11, 16))
+    # ---- the README.md:66 chain, stage by stage through the reference library with the CLI's framing
+    n = 60 * 1024
+    t = np.arange(n)
+    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * t) + 0.3 * rng.uniform(-1, 1, n)
+    sig = 0.7 * np.exp(1j * (2 * np.pi * np.cumsum(0.03125 * msg) + 2 * np.pi * 0.085 * t)) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    iq = np.empty(2 * n, f32); iq[0::2] = sig.real; iq[1::2] = sig.imag
+    iq = np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+    g["wfm_iq_u8"] = iq
+    s16, af = R.wfm_chain(iq, -0.085, 10, taps)
+    g["wfm_audio_f"] = af; g["wfm_audio_s16"] = s16
+    # ---- f2 blocks
+    g["amdemod_cf"] = R.amdemod_cf(x); g["amdemod_estimator_cf"] = R.amdemod_estimator_cf(x)
+    g["fmdemod_atan_cf"] = R.fmdemod_atan_cf(x, 0.3)[0]
+    g["logpower_cf"] = R.logpower_cf(x + c64(0.01), 3.0)
+    g["dc_in"] = (g["rx"] + 0.3).astype(f32)
+    g["dcblock_ff"] = R.dcblock_ff(g["dc_in"], 0, (0.1, 0.2))[0]
+    g["fastdcblock_ff"] = R.fastdcblock_ff(g["dc_in"], 1024, 0.1)[0]
+    g["agc_ff"] = R.agc_ff(g["agc_in"], 1024)[0]
+    g["window_hamming_512"] = R.precalculate_window(512, "HAMMING")
+    # ---- f3: ADPCM (bit exact); the waterfall compressor only exists as a CLI loop
+    pcm = (8000 * np.sin(np.arange(4001) * 0.01) + rng.integers(-3000, 3000, 4001)).astype(np.int16)
+    g["pcm"] = pcm
+    enc, st = R.encode_ima_adpcm_i16_u8(pcm, (5, -100)); g["adpcm_enc"] = enc; g["adpcm_enc_state"] = np.array(st, np.int64)
+    dec, st = R.decode_ima_adpcm_u8_i16(enc, (3, 77)); g["adpcm_dec"] = dec; g["adpcm_dec_state"] = np.array(st, np.int64)
+    rows = (rng.uniform(-120, 10, 3 * 256) + 20 * np.sin(np.arange(3 * 256) * 0.05)).astype(f32)
+    g["fft_rows_db"] = rows
+    cli = os.path.join(ROOT, "oracle", "_ref", "csdr")
+    out = subprocess.run([cli, "compress_fft_adpcm_f_u8", "256"], input=rows.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30).stdout
+    g["compress_fft_adpcm_f_u8_256"] = np.frombuffer(out, np.uint8)[:3 * 133].copy()     # the reference repeats its last block at EOF
+    path = os.path.join(ROOT, "tests", "golden", "ref_vectors.npz")
+    np.savez_compressed(path, **g)
+    print("wrote %s: %d arrays, %.0f KB" % (path, len(g), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
