@@ -305,7 +305,7 @@ class Context:
     def fir_decimate_cc(self, x, decimation, taps):
         x2, squeeze = self._2d(x, c64); taps = np.ascontiguousarray(taps, f32)
         s, n = x2.shape
-        opitch = n // decimation + 2
+        opitch = n // max(int(decimation), 1) + 2
         di = self.upload(x2); dt = self.upload(taps); do = self.alloc(8 * s * opitch + 64)
         no = self.check(self.L.csdr_amd_fir_decimate_cc(self.h, di.ptr, do.ptr, s, n, n, opitch, decimation, dt.ptr, taps.size), "fir_decimate_cc")
         y = self.download(do, c64, s * opitch).reshape(s, opitch)[:, :no]

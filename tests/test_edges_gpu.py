@@ -1,0 +1,127 @@
+"""Edge cases of the device batch API on the GPU: empty and one-element inputs, lengths that are not multiples of any tile,
+stream counts that do not fill a 16/64-stream group, inputs shorter than a filter, minimum block sizes, odd ADPCM lengths,
+error reporting.  Everything against the CPU oracle on identical input (tests/conftest.py::port)."""
+import numpy as np
+import pytest
+from oracle import relrms
+
+pytestmark = pytest.mark.gpu
+c64, f32 = np.complex64, np.float32
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch  # noqa: F401
+    import csdr_amd
+    ctx = csdr_amd.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def crand(rng, n):
+    return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(c64)
+
+
+def test_empty_and_single_element(gpu, port):
+    e8, ef, ec = np.zeros(0, np.uint8), np.zeros(0, f32), np.zeros(0, c64)
+    assert gpu.convert_u8_f(e8).size == 0 and gpu.convert_f_s16(ef).size == 0 and gpu.limit_ff(ef).size == 0
+    assert gpu.amdemod_cf(ec).size == 0 and gpu.logpower_cf(ec).size == 0 and gpu.realpart_cf(ec).size == 0
+    one = np.array([0.3 - 0.7j], c64)
+    assert np.array_equal(gpu.shift_addition_cc(one, 0.1)[0].view(np.uint32), port.shift_addition_cc(one, 0.1)[0].view(np.uint32))
+    assert relrms(gpu.fmdemod_quadri_cf(one, np.array([0.2 + 0.1j], c64))[0], port.fmdemod_quadri_cf(one, (0.2, 0.1))[0]) <= TOL
+    assert relrms(gpu.fmdemod_atan_cf(one)[0], port.fmdemod_atan_cf(one)[0]) <= TOL
+    r1 = np.array([0.25], f32)
+    assert relrms(gpu.dcblock_ff(r1)[0], port.dcblock_ff(r1)[0]) <= TOL
+    assert relrms(gpu.agc_ff(r1)[0], port.agc_ff(r1)[0]) <= TOL
+    assert relrms(gpu.deemphasis_wfm_ff(r1, 50e-6, 48000)[0], port.deemphasis_wfm_ff(r1, 50e-6, 48000)[0]) <= TOL
+    assert gpu.encode_ima_adpcm_i16_u8(np.array([1234], np.int16))[0].size == 0          # an odd last sample is dropped (ima_adpcm.c:157)
+    assert gpu.decode_ima_adpcm_u8_i16(e8)[0].size == 0
+
+
+@pytest.mark.parametrize("n", [1, 3, 63, 64, 65, 255, 257, 1023, 1025, 4099])
+def test_odd_lengths_elementwise(gpu, port, n):
+    rng = np.random.default_rng(n)
+    u8 = rng.integers(0, 256, n, dtype=np.uint8)
+    assert np.array_equal(gpu.convert_u8_f(u8).view(np.uint32), port.convert_u8_f(u8).view(np.uint32))
+    x = rng.uniform(-1.3, 1.3, n).astype(f32)
+    assert np.array_equal(gpu.convert_f_s16(x), port.convert_f_s16(x)) and np.array_equal(gpu.convert_f_u8(x), port.convert_f_u8(x))
+    assert np.array_equal(gpu.limit_ff(x, 0.9).view(np.uint32), port.limit_ff(x, 0.9).view(np.uint32))
+    c = crand(rng, n)
+    for name in ("shift_addition_cc", "shift_math_cc", "shift_addfast_cc", "shift_unroll_cc"):
+        m = n // 4 * 4 if name == "shift_addfast_cc" else n       # the reference's addfast loop only covers whole groups of four (libcsdr.c:406-434)
+        if m:
+            assert relrms(getattr(gpu, name)(c, 0.123)[0][:m], getattr(port, name)(c, 0.123)[0][:m]) <= TOL, name
+    assert relrms(gpu.fmdemod_quadri_cf(c)[0], port.fmdemod_quadri_cf(c)[0]) <= TOL
+    assert relrms(gpu.amdemod_cf(c), port.amdemod_cf(c)) <= TOL
+    assert relrms(gpu.dcblock_ff(x)[0], port.dcblock_ff(x)[0]) <= TOL
+    assert relrms(gpu.agc_ff(x, 64)[0], port.agc_ff(x, 64)[0]) <= TOL
+
+
+def test_fir_shorter_than_taps_and_exact_fit(gpu, port):
+    rng = np.random.default_rng(2)
+    taps = port.firdes_lowpass_f(79, 0.05)
+    assert gpu.fir_decimate_cc(crand(rng, 78), 10, taps).size == 0 and port.fir_decimate_cc(crand(rng, 78), 10, taps).size == 0
+    for n in (79, 80, 88, 89, 79 + 10 * 255, 79 + 10 * 256, 79 + 10 * 257):           # one output, tile boundaries of the polyphase kernel
+        x = crand(rng, n)
+        a, b = gpu.fir_decimate_cc(x, 10, taps), port.fir_decimate_cc(x, 10, taps)
+        assert a.size == b.size and relrms(a, b) <= TOL, n
+    # other decimations / tap counts (polyphase configurations and the generic fallback)
+    for D, nt in ((1, 31), (2, 9), (3, 101), (7, 255), (16, 127), (50, 801), (100, 1601)):
+        t = port.firdes_lowpass_f(nt, 0.4 / D)
+        x = crand(rng, nt + D * 700 + 3)
+        a, b = gpu.fir_decimate_cc(x, D, t), port.fir_decimate_cc(x, D, t)
+        assert a.size == b.size and relrms(a, b) <= TOL, (D, nt)
+
+
+def test_many_short_streams_and_pitch(gpu, port):
+    rng = np.random.default_rng(3)
+    x = np.stack([crand(rng, 300) for _ in range(130)])                # 130 streams: not a multiple of 64
+    taps = port.firdes_lowpass_f(31, 0.1)
+    y = gpu.fir_decimate_cc(x, 4, taps)
+    for s in (0, 63, 64, 129):
+        assert relrms(y[s], port.fir_decimate_cc(x[s], 4, taps)) <= TOL
+    d, _ = gpu.fmdemod_quadri_cf(x)
+    for s in (0, 129):
+        assert relrms(d[s], port.fmdemod_quadri_cf(x[s])[0]) <= TOL
+    r = rng.uniform(-1, 1, (130, 300)).astype(f32)
+    e, _ = gpu.deemphasis_wfm_ff(r, 50e-6, 48000)
+    for s in (0, 77, 129):
+        assert relrms(e[s], port.deemphasis_wfm_ff(r[s], 50e-6, 48000)[0]) <= TOL
+
+
+@pytest.mark.parametrize("n_streams", [1, 15, 17, 65])
+def test_wfm_stream_counts(gpu, port, n_streams):
+    """stream counts around the 16-stream MFMA group and the 64-stream block"""
+    from tests_helpers import wfm_signal_u8
+    taps = port.firdes_lowpass_f(79, 0.05)
+    base = [wfm_signal_u8(100 + s, 16384 * 3) for s in range(min(n_streams, 3))]
+    u8 = np.stack([base[s % len(base)] for s in range(n_streams)])
+    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps)
+    want = [port.wfm_chain(b, -0.085, 10, taps) for b in base]
+    for s in sorted({0, n_streams // 2, n_streams - 1}):
+        ps, pf = want[s % len(base)]
+        m = min(pf.size, af.shape[1])
+        assert m >= 16384 * 3 // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL
+        assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
+def test_wfm_minimum_blocks(gpu, port):
+    """1024-sample blocks (the smallest legal block): every tile straddles a block boundary, history path only"""
+    from tests_helpers import wfm_signal_u8
+    taps = port.firdes_lowpass_f(79, 0.05)
+    u8 = wfm_signal_u8(7, 1024 * 23)[None, :]
+    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=1024)
+    ps, pf = port.wfm_chain(u8[0], -0.085, 10, taps)
+    m = min(pf.size, af.shape[1])
+    assert m >= 1024 * 23 // 50 - 8 and relrms(af[0, :m], pf[:m]) <= TOL
+
+
+def test_error_reporting(gpu):
+    import csdr_amd
+    with pytest.raises(csdr_amd.CsdrAmdError):
+        gpu.fir_decimate_cc(np.zeros(100, c64), 0, np.ones(3, f32))                     # decimation 0
+    with pytest.raises(csdr_amd.CsdrAmdError):
+        gpu.fft_cc(np.zeros(100, c64), 1000, 10)                                        # not a power of two
+    f = gpu.L.csdr_amd_fftfilt_create(gpu.h, 1000, None, 3, 1, 1)                         # fft_size not a power of two
+    assert not f and gpu.err()
