@@ -377,13 +377,20 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
     // DMA cursor: the next item to fetch (stream block cs, quad cm); advances independently of the compute position
     int cs = blockIdx.y; long long cm = 0, c_issued = 0;
+    // per-lane source row of each DMA instruction for the cursor's stream block: recomputed once per stream block (M items), so the
+    // per-item address is one 64-bit add instead of a 64-bit multiply-add (VALU instructions are on every wave's serial chain)
+    const uint8_t *rowp[DMA_PW];
+    auto set_rows = [&](int sb) {
+#pragma unroll
+        for (int k = 0; k < DMA_PW; k++) rowp[k] = in + (long long)min(sb * SB + prow[k], last_stream) * (long long)in_pitch + pcol[k];
+    };
+    set_rows(cs);
     auto dma_next = [&](int buf) {
         const uint32_t ldst = __builtin_amdgcn_readfirstlane((int)(lds_in_addr + buf * quad_bytes + (w * DMA_PW) * 1024));
         const long long base = wq0 + cm * quad_step;
-        const int cs0 = cs * SB;
 #pragma unroll
         for (int k = 0; k < DMA_PW; k++) {                                          // every lane executes every instruction (fixed count per wave)
-            const uint8_t *gp = in + (long long)min(cs0 + prow[k], last_stream) * (long long)in_pitch + pcol[k] + base;
+            const uint8_t *gp = rowp[k] + base;
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + k * 1024));
             uint32_t keep;
             // nt: the input is read exactly once, by one CU (MI355X_MICROARCH.md row nt-weights; measured here 1.135 -> 1.110 ms)
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
                          : "=&s"(keep) : "v"(gp), "s"(la) : "memory");
         }
         c_issued++;
-        if (++cm == M) { cm = 0; cs += gridDim.y; }
+        if (++cm == M) { cm = 0; cs += gridDim.y; set_rows(cs); }
     };
     auto wait_newer = [&](long long newer) {                                        // all but the `newer` most recent quads have landed
         switch ((int)newer) {
@@ -425,16 +432,25 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
             const uint8_t *src = lrow + (16 * g + col) * p.row_bytes;
 #pragma unroll
             for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks) ^ (int)0x80808080;
-            v4i acc0[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, acc1[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            v4i acc0[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
             for (int ks = 0; ks < WFM_NK; ks++)
 #pragma unroll
                 for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks * 3 + l], Bf[ks], acc0[l], 0, 0, 0);
+            // the second weight set (window straddles a 1024-chunk) lives entirely inside one branch: its accumulators need no zero
+            // initialisation on the common path (they sit in AGPRs: every touch is a VALU instruction of the wave's serial chain)
+            float sI = 0.f, sQ = 0.f, tI = 0.f, tQ = 0.f;
             if (two) {
+                v4i acc1[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
                 for (int ks = 0; ks < WFM_NK; ks++)
 #pragma unroll
                     for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[ks * 3 + l], Bf[ks], acc1[l], 0, 0, 0);
+                float u1[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, k1[r]);
+                sI = C1.x * u1[0] - C1.y * u1[1]; sQ = C1.x * u1[1] + C1.y * u1[0];
+                tI = C1.x * u1[2] - C1.y * u1[3]; tQ = C1.x * u1[3] + C1.y * u1[2];
             }
             float pI, pQ, cI, cQ;
             {
@@ -444,16 +460,13 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
                 pI = C0.x * u0[0] - C0.y * u0[1]; pQ = C0.x * u0[1] + C0.y * u0[0];
                 cI = C0.x * u0[2] - C0.y * u0[3]; cQ = C0.x * u0[3] + C0.y * u0[2];
             }
-            if (two) {
-                float u1[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, k1[r]);
-                pI += C1.x * u1[0] - C1.y * u1[1]; pQ += C1.x * u1[1] + C1.y * u1[0];
-                cI += C1.x * u1[2] - C1.y * u1[3]; cQ += C1.x * u1[3] + C1.y * u1[2];
-            }
+            if (two) { pI += sI; pQ += sQ; cI += tI; cQ += tQ; }
             const float dq = cQ - pQ, di = cI - pI;
             const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
-            lout[(16 * g + col) * 16 + 4 * w + q] = (den != 0.f) ? (K * num) / den : 0.f;      // audio 4*ti+q of stream 16g+col
+            // K*num/den with a Newton-refined reciprocal (v_rcp_f32 + one step: ~1 ulp) instead of the 10-instruction IEEE division sequence
+            float rd = __builtin_amdgcn_rcpf(den);
+            rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
+            lout[(16 * g + col) * 16 + 4 * w + q] = (den != 0.f) ? (K * num) * rd : 0.f;      // audio 4*ti+q of stream 16g+col
         }
         // quad m+1 must have landed before anyone passes the barrier; quads m+2 .. m+NB-1 stay in flight.  After the barrier this
         // quad's buffer is free and takes quad m+NB: the input stream never pauses.
