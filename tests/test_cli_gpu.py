@@ -266,8 +266,6 @@ def test_cli_dynamic_bufsize_preamble(port):
 
 def test_cli_fifo_retune(port, tmp_path):
     """csdr.c:252-323, 883-921: `shift_addition_cc --fifo <path>`: first rate from the fifo, a later line retunes between blocks, phase carries on."""
-    import threading
-    import time
     rng = np.random.default_rng(13)
     x = crand(rng, 2 * 4096)
     fifo = str(tmp_path / "ctl")
@@ -276,18 +274,18 @@ def test_cli_fifo_retune(port, tmp_path):
     p = subprocess.Popen([CLI, "shift_addition_cc", "--fifo", fifo], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     ctl = open(fifo, "w")
     ctl.write("0.05\n"); ctl.flush()
-    out = []
-    t = threading.Thread(target=lambda: out.append(p.stdout.read()))
-    t.start()
     p.stdin.write(x[:4096].tobytes()); p.stdin.flush()
-    time.sleep(1.5)                                                        # block 1 is through; the process now waits for block 2
-    ctl.write("-0.2\n"); ctl.flush()
-    time.sleep(0.3)
+    first = b""
+    while len(first) < 8 * 4096:                                           # block 1 has come out: the process is now waiting for block 2
+        chunk = p.stdout.read(8 * 4096 - len(first))
+        assert chunk, p.stderr.read().decode()
+        first += chunk
+    ctl.write("-0.2\n"); ctl.flush()                                        # in the fifo before block 2 is even sent: applied to block 2
     p.stdin.write(x[4096:].tobytes()); p.stdin.close()
-    t.join(timeout=60)
+    rest = p.stdout.read()
     ctl.close()
     assert p.wait(timeout=30) == 0
-    got = np.frombuffer(out[0], c64)
+    got = np.frombuffer(first + rest, c64)
     a, ph = port.shift_addition_cc(x[:4096], 0.05)
     b, _ = port.shift_addition_cc(x[4096:], -0.2, phase=ph)
     assert got.size == x.size
@@ -376,7 +374,6 @@ def test_cli_f3_adpcm(port):
 
 # ---------------------------------------------------------------- f4: the ddcd topology (one forward transform, N channels, per-channel retune)
 def test_cli_fastddc_bank(port, tmp_path):
-    import threading
     import time
     rng = np.random.default_rng(17)
     D, tbw = 16, 0.02
@@ -404,14 +401,16 @@ def test_cli_fastddc_bank(port, tmp_path):
     ctl = open(fifo, "w")
     first = 2 * ddc.input_size
     p.stdin.write(x[:first].tobytes()); p.stdin.flush()
-    time.sleep(2.0)
+    d1, _ = port.fastddc_init(tbw, D, rates[1])
+    part1 = port.fastddc_inv_cc(spectra[:2], d1, port.fastddc_taps_fft(d1, rates[1], D))
+    deadline = time.time() + 60
+    while not (os.path.exists(outs[1]) and os.path.getsize(outs[1]) >= 8 * part1.size):    # the first call (two blocks) is through
+        assert time.time() < deadline and p.poll() is None
+        time.sleep(0.05)
     ctl.write("1 0.05\n"); ctl.flush()
-    time.sleep(0.3)
     p.stdin.write(x[first:].tobytes()); p.stdin.close()
     assert p.wait(timeout=60) == 0, p.stderr.read().decode()
     ctl.close()
-    d1, _ = port.fastddc_init(tbw, D, rates[1])
-    part1 = port.fastddc_inv_cc(spectra[:2], d1, port.fastddc_taps_fft(d1, rates[1], D))
     d2, _ = port.fastddc_init(tbw, D, 0.05)
     part2 = port.fastddc_inv_cc(spectra[2:], d2, port.fastddc_taps_fft(d2, 0.05, D))       # status restarts from zero like the reference's rebuild
     got = np.fromfile(outs[1], c64)
