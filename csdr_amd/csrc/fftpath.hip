@@ -108,7 +108,7 @@ struct ChanGeom { int offsetbin; float sindelta, cosdelta, rate2; };
 // loaded once per call and reused from a register for all blocks of the call (lanes = consecutive m: coalesced for H and X).
 // Channel-tiled fold.  For a residue r = bin mod inv every channel needs the SAME spectrum values X[b][r + q*inv], q = 0..pre-1 (a channel's
 // offsetbin only decides which output bin the sum lands in), so a thread owns (residue r, CT channels, BT blocks): per q it loads BT spectrum
-// values and CT taps and does CT*BT complex MACs -- 4 MACs per load at CT = 8, BT = 8 against 0.94 for the per-channel kernel below, whose
+// values and CT taps and does CT*BT complex MACs -- 2.7 MACs per load at CT = 8, BT = 4 against 0.94 for the per-channel kernel below, whose
 // 9 GB of L2/Infinity-Cache reads per 64-block call were what it ran at (profiles/r1_notes.md).  Index algebra (fastddc.c:106-147 with both
 // fft_swap_sides folded in): i = r + q*inv indexes the taps, (i + fft/2) mod fft the spectrum, the sum goes to output bin (r - offsetbin) mod inv.
 // Summation order over q is the reference's; products are fused (fmaf), well inside the 1e-5 gate.
@@ -562,14 +562,14 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
         f->plans[batch] = h;
     }
     const bool ct_ok = f->n_channels >= 4 && pre >= 2 && (pre & (pre - 1)) == 0 && !getenv("CSDR_AMD_DDC_FOLD_OLD");
-    // tile choice measured on config 4 (256 channels, 64 blocks per call): <4,16> 5.0, <8,8> 7.2, <6,12> 3.5, <2,16> 3.0 GS/s of wideband input
-    if (n_blocks >= 8 && ct_ok && f->n_channels >= 8) {
-        hipLaunchKernelGGL((k_ddc_fold_ct<8, 8>), dim3(cdiv(inv, 256), cdiv(n_blocks, 8), cdiv(f->n_channels, 8)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels);
-    } else if (n_blocks >= 16 && ct_ok) {
-        hipLaunchKernelGGL((k_ddc_fold_ct<4, 16>), dim3(cdiv(inv, 256), cdiv(n_blocks, 16), cdiv(f->n_channels, 4)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels);
-    } else if (ct_ok) {
-        hipLaunchKernelGGL((k_ddc_fold_ct<4, 4>), dim3(cdiv(inv, 256), cdiv(n_blocks, 4), cdiv(f->n_channels, 4)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels);
-    } else if (n_blocks >= 16) {
+    // tile choice measured on config 4 (256 channels, 64 blocks per call), GS/s of wideband input: <8,4> 8.6, <8,8> 7.1-7.2, <4,16> 5.0, <6,12> 3.5,
+    // <16,4> 3.0, <2,16> 3.0, <16,8> 2.6, <16,2> 1.9, <32,2> 1.0 -- 8 channels share every spectrum value; the 64 accumulators of <8,4> leave room for
+    // 4-5 waves per SIMD, which hides the load latency that <8,8> (2 waves per SIMD) exposes
+#define FOLD_CT(CTV, BTV) hipLaunchKernelGGL((k_ddc_fold_ct<CTV, BTV>), dim3(cdiv(inv, 256), cdiv(n_blocks, BTV), cdiv(f->n_channels, CTV)), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks, f->n_channels)
+    if (ct_ok && f->n_channels >= 8) { FOLD_CT(8, 4); }
+    else if (ct_ok) { FOLD_CT(4, 4); }
+#undef FOLD_CT
+    else if (n_blocks >= 16) {
         hipLaunchKernelGGL((k_ddc_fold<16>), dim3(cdiv(inv, 256), cdiv(n_blocks, 16), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks);
     } else {
         hipLaunchKernelGGL((k_ddc_fold<4>), dim3(cdiv(inv, 256), cdiv(n_blocks, 4), f->n_channels), dim3(256), 0, st, spectra, f->d_H, f->d_inv_in, f->d_geom, fft, inv, pre, n_blocks);
