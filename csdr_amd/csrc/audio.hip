@@ -17,7 +17,7 @@ namespace {
 __global__ __launch_bounds__(256) void k_fmdemod(const cf32 *__restrict__ in, float *__restrict__ out, size_t n,
                                                  size_t in_pitch, size_t out_pitch, const cf32 *__restrict__ last)
 {
-    const double K = 0.340447550238101026565118445432744920253753662109375;   // libcsdr.c:1021
+    const float Kf = 0.340447550238101026565118445432744920253753662109375f;   // libcsdr.c:1021
     const cf32 *src = in + (size_t)blockIdx.y * in_pitch;
     float *dst = out + (size_t)blockIdx.y * out_pitch;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256) void k_fmdemod(const cf32 *__restrict__ in, fl
         const float dq = x.q - p.q, di = x.i - p.i;
         const float num = x.i * dq - x.q * di;
         const float den = x.i * x.i + x.q * x.q;
-        dst[k] = (den != 0.f) ? (float)(K * (double)num / (double)den) : 0.f;   // double scaling/division, :1067
+        // the reference scales and divides in double (:1067) and rounds once; a float product with a Newton-refined reciprocal is within 2 ulp of
+        // that (gate: 1e-5 relative RMS) and avoids the ~25-instruction fp64 division sequence that made this kernel arithmetic bound
+        float rd = __builtin_amdgcn_rcpf(den);
+        rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
+        dst[k] = (den != 0.f) ? (Kf * num) * rd : 0.f;
     }
 }
 __global__ void k_store_last(const cf32 *__restrict__ in, size_t n, size_t in_pitch, cf32 *__restrict__ last, int n_streams)
