@@ -555,11 +555,13 @@ class Context:
         self.L.csdr_amd_fastddc_inv_destroy(f)
         return [np.concatenate(o) for o in outs]
 
-    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None):
-        """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call."""
+    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0):
+        """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call;
+        `pitch_pad` = extra bytes of row pitch (multiple of 16; a pitch that is not a multiple of 128 selects the quad kernel).
+        The front-end kernel of the last call is left in `self.last_wfm_kernel`."""
         x2, squeeze = self._2d(iq_u8, np.uint8)
         s, nbytes = x2.shape; n = nbytes // 2
-        pitch = (nbytes + 15) // 16 * 16
+        pitch = (nbytes + 15) // 16 * 16 + pitch_pad
         xx = np.zeros((s, pitch), np.uint8); xx[:, :nbytes] = x2
         taps = np.ascontiguousarray(taps, f32)
         block = n if block is None else block
@@ -576,6 +578,7 @@ class Context:
             pos += k; na += got
         s16 = self.download(ds, np.int16, s * apitch).reshape(s, apitch)[:, :na]
         af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na]
+        self.last_wfm_kernel = self.L.csdr_amd_wfm_kernel_name(w).decode()
         self.L.csdr_amd_wfm_destroy(w)
         return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())
 

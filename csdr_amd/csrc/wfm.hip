@@ -235,7 +235,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     w->shift_rate = shift_rate; w->tau = tau; w->max_block = max_block_samples;
     const float dt = (float)(1.0 / audio_rate); w->alpha = dt / (tau + dt);          // libcsdr.c:1090-1091
     const size_t max_audio = max_block_samples / ((size_t)decimation * frac_rate) + 8;
-    w->demod_pitch = (max_audio + 8 + 63) & ~(size_t)63;
+    w->demod_pitch = (max_audio + 40 + 63) & ~(size_t)63;          // + the octet-aligned start (up to 31 samples) and tile padding
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&w->d_taps, sizeof(float) * taps_length);
@@ -247,7 +247,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
     (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     w->kernel_name = "k_wfm_front";
-    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_set_of = nullptr;
+    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_kb_of = nullptr;
     {
         const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons)
         const bool want_mfma = !(force && !strcmp(force, "valu"));
@@ -258,11 +258,11 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
             w->ctab_cap = max_block_samples / 1024 + 8;
             hipError_t e2 = hipMalloc(&w->mfma.d_frags, t.frags.size());
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_consts, t.consts.size() * sizeof(float));
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_set_of, t.set_of.size() * sizeof(int));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_kb_of, t.kb_of.size() * sizeof(int));
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->d_ctab, w->ctab_cap * sizeof(float2));
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_frags, t.frags.data(), t.frags.size(), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_consts, t.consts.data(), t.consts.size() * sizeof(float), hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_set_of, t.set_of.data(), t.set_of.size() * sizeof(int), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_kb_of, t.kb_of.data(), t.kb_of.size() * sizeof(int), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) { fail(e2, "hipMalloc/hipMemcpy(wfm mfma table)", __FILE__, __LINE__); delete w; return nullptr; }
             w->use_mfma = true; w->kernel_name = "k_wfm_mfma";
         }
@@ -291,7 +291,7 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
     for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (w->mfma.d_frags) (void)hipFree(w->mfma.d_frags);
     if (w->mfma.d_consts) (void)hipFree(w->mfma.d_consts);
-    if (w->mfma.d_set_of) (void)hipFree(w->mfma.d_set_of);
+    if (w->mfma.d_kb_of) (void)hipFree(w->mfma.d_kb_of);
     if (w->d_ctab) (void)hipFree(w->d_ctab);
     if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
@@ -380,7 +380,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     }
     const long long n_audio_ll = j_hi - w->next_j + 1;
     const int n_audio = n_audio_ll > 0 ? (int)n_audio_ll : 0;
-    if ((size_t)n_audio + 8 > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
+    if ((size_t)n_audio + 40 > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
     if (n_audio > 0) {
         if ((size_t)n_audio > out_pitch) return fail_msg(-3, "wfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, n_audio);
         WfmParams p; p.D = w->D; p.L = w->L; p.F = w->F; p.T = T; p.B = w->B; p.j_first = w->next_j; p.n_audio = n_audio;
@@ -419,7 +419,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
         }
         hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, BK_CHUNK), w->n_streams), dim3(256), 0, st,
-                           w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j - 4 * (w->next_j / 4)) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
+                           w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j % 32) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
         CSDR_LAUNCH_CHECK();
         w->flip ^= 1;
     }

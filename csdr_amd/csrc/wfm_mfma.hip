@@ -46,10 +46,13 @@ bool wfm_mfma_supported(int D, int L, int F)
     return true;
 }
 
-// Builds the periodic weight table.  A window that contains a shift_addition_cc chunk boundary gets TWO weight sets
-// (samples before / after the boundary, the other side zero) so that each side can be scaled by its own chunk phasor.
-//   frags : [n_sets][WFM_NK][3 digits][64 lanes] int8x16   (lane l: row l%16, K bytes 16*(l/16) .. +15 of that K-step)
-//   set_of: [n_phases][2]                                  (weight set of each side; -1 when the window has one side only)
+// Builds the periodic weight table: ONE weight set per tile phase.  A window that contains a shift_addition_cc chunk boundary
+// (25 % of the phases) is split at K-step granularity: K-steps before the boundary belong to chunk m, K-steps after it to chunk
+// m+1, and the one K-step `kb` that contains the boundary appears twice -- its chunk-m samples in the extra fragment (index
+// WFM_NK*3 + digit), its chunk-(m+1) samples in its regular slot.  The kernels run one accumulator chain, snapshot it after the
+// extra fragment and get the two sides as (snapshot, total - snapshot): exact in int32, 27 MFMAs instead of 2 x 24.
+//   frags : [n_phases][WFM_NFRAG][64 lanes] int8x16        (lane l: row l%16, K bytes 16*(l/16) .. +15 of that K-step)
+//   kb_of : [n_phases]                                     (WFM_NK when the window lies inside one chunk)
 //   consts: [n_phases][2 sides][16 rows] float             (the +1/255 offset of u8->float through the filter)
 void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *taps, WfmMfmaTable &t)
 {
@@ -69,19 +72,18 @@ void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *ta
     if (gmax == 0) gmax = 1;
     const double qscale = 4194304.0 / gmax;                          // 2^22: three balanced base-256 digits stay inside int8
     t.scale = (float)(gmax / 4194304.0);
-    const size_t set_bytes = (size_t)WFM_FRAG_V4 * 16;
-    t.frags.clear();
+    const size_t ph_bytes = (size_t)WFM_FRAG_V4 * 16;
+    t.frags.assign((size_t)t.n_phases * ph_bytes, 0);
     t.consts.assign((size_t)t.n_phases * 32, 0.f);
-    t.set_of.assign((size_t)t.n_phases * 2, -1);
+    t.kb_of.assign((size_t)t.n_phases, WFM_NK);
     const int base_off_samples = t.win_off_bytes / 2;
-    int n_sets = 0;
     for (int ph = 0; ph < t.n_phases; ph++) {
         const long s0 = (long)4 * D * F * ph + base_off_samples;     // window base sample in the periodic frame
         const long chunk0 = s0 / 1024;
-        const bool two_sides = (chunk0 + 1) * 1024 - s0 < 32 * WFM_NK;   // a chunk boundary inside the 256-sample window
-        t.set_of[2 * ph] = n_sets++;
-        if (two_sides) t.set_of[2 * ph + 1] = n_sets++;
-        t.frags.resize((size_t)n_sets * set_bytes, 0);
+        const long bb = 2 * ((chunk0 + 1) * 1024 - s0);              // byte offset of the next chunk's first sample inside the window
+        const int kb = bb < 64 * WFM_NK ? (int)(bb / 64) : WFM_NK;
+        t.kb_of[ph] = kb;
+        int8_t *fr = t.frags.data() + (size_t)ph * ph_bytes;
         float *cst = t.consts.data() + (size_t)ph * 32;
         for (int r = 0; r < 16; r++) {
             const int q = r / 4, which = (r % 4) / 2, comp = r % 2;
@@ -92,7 +94,6 @@ void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *ta
                 const int side = (int)(g / 1024 - chunk0);
                 const std::complex<double> G = a * (double)taps[tp] * Dk[g % 1024];
                 csum[side] += (double)taps[tp] * Dk[g % 1024];
-                int8_t *fr = t.frags.data() + (size_t)t.set_of[2 * ph + side] * set_bytes;
                 for (int c = 0; c < 2; c++) {
                     // real form of (Gr + j Gi)(I + j Q): Re row takes (Gr, -Gi) on (I, Q); Im row takes (Gi, Gr)
                     const double val = comp == 0 ? (c == 0 ? G.real() : -G.imag()) : (c == 0 ? G.imag() : G.real());
@@ -104,7 +105,10 @@ void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *ta
                     const int w0 = (int)qv;
                     const int lane = 16 * (b / 16) + r, byte = b % 16;
                     const int dig[3] = {w0, w1, w2};
-                    for (int l = 0; l < 3; l++) fr[((size_t)(ks * 3 + l) * 64 + lane) * 16 + byte] = (int8_t)dig[l];
+                    // side 0 inside the boundary K-step goes to the extra fragment; everything else to its regular slot
+                    // (ks < kb is side 0 and ks > kb is side 1 by construction)
+                    const bool extra = (ks == kb && side == 0);
+                    for (int l = 0; l < 3; l++) fr[((size_t)(extra ? WFM_NK * 3 + l : ks * 3 + l) * 64 + lane) * 16 + byte] = (int8_t)dig[l];
                 }
             }
             for (int p = 0; p < 2; p++) {
@@ -135,6 +139,46 @@ struct MfmaParams {
 __device__ __forceinline__ float combine_digits(int a0, int a1, int a2)
 {   // exact integers (<= 22 bits each) recombined in float: value = a0*65536 + a1*256 + a2
     return fmaf((float)a0, 65536.0f, fmaf((float)a1, 256.0f, (float)a2));
+}
+
+// The banded product of one (tile, 16 streams): ONE accumulator chain per digit over the window's K-steps.  When the window contains
+// a 1024-chunk boundary (kb < WFM_NK, wave uniform) the boundary K-step contributes twice -- first its chunk-m samples (extra
+// fragment), then, after the chain has been snapshotted, its chunk-(m+1) samples -- so that  side 0 = snap,  side 1 = acc - snap.
+__device__ __forceinline__ void tile_product(const v4i (&A)[WFM_NFRAG], const v4i (&Bf)[WFM_NK], int kb, v4i (&acc)[3], v4i (&snap)[3])
+{
+#pragma unroll
+    for (int ks = 0; ks < WFM_NK; ks++) {
+        if (ks == kb) {
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[WFM_NK * 3 + l], Bf[ks], acc[l], 0, 0, 0);
+#pragma unroll
+            for (int l = 0; l < 3; l++) snap[l] = acc[l];
+        }
+#pragma unroll
+        for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc[l], 0, 0, 0);
+    }
+}
+
+// rows 4q..4q+3 of the tile after the chunk phasors: (Re, Im) of y[Fj+9] and of y[Fj+10];  y = C_m u0 + C_{m+1} u1
+__device__ __forceinline__ void tile_rows(const v4i (&acc)[3], const v4i (&snap)[3], bool two, float scale, const float (&k0)[4], const float (&k1)[4],
+                                          float2 C0, float2 C1, float &pI, float &pQ, float &cI, float &cQ)
+{
+    float u0[4];
+    if (two) {
+        float u1[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            u0[r] = fmaf(combine_digits(snap[0][r], snap[1][r], snap[2][r]), scale, k0[r]);
+            u1[r] = fmaf(combine_digits(acc[0][r] - snap[0][r], acc[1][r] - snap[1][r], acc[2][r] - snap[2][r]), scale, k1[r]);
+        }
+        pI = C0.x * u0[0] - C0.y * u0[1] + (C1.x * u1[0] - C1.y * u1[1]); pQ = C0.x * u0[1] + C0.y * u0[0] + (C1.x * u1[1] + C1.y * u1[0]);
+        cI = C0.x * u0[2] - C0.y * u0[3] + (C1.x * u1[2] - C1.y * u1[3]); cQ = C0.x * u0[3] + C0.y * u0[2] + (C1.x * u1[3] + C1.y * u1[2]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) u0[r] = fmaf(combine_digits(acc[0][r], acc[1][r], acc[2][r]), scale, k0[r]);
+        pI = C0.x * u0[0] - C0.y * u0[1]; pQ = C0.x * u0[1] + C0.y * u0[0];
+        cI = C0.x * u0[2] - C0.y * u0[3]; cQ = C0.x * u0[3] + C0.y * u0[2];
+    }
 }
 
 // B operand of one (tile, stream group): 8 x 16 raw bytes per lane straight from the input rows.
@@ -180,7 +224,7 @@ __device__ __forceinline__ void load_B(v4i (&Bf)[WFM_NK], const uint8_t *__restr
 //   * output : the quadrature demodulator is lane local; 4 audio samples per stream leave as one aligned 16-byte store.
 template <bool EDGE>
 __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ hist,
-                                                 const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ set_of,
+                                                 const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ kb_of,
                                                  const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, MfmaParams p)
 {
     const int lane = threadIdx.x, col = lane & 15, q = lane >> 4;
@@ -201,16 +245,13 @@ __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in,
     const long long two_T = 2LL * p.T, B2 = 2 * p.B;
     const int stream_base = blockIdx.x * 64 + col, last_stream = p.n_streams - 1;
     // ---- weights: once per wave
-    const int set0 = set_of[2 * ph], set1 = set_of[2 * ph + 1];
-    const bool two = set1 >= 0;
-    v4i A0[WFM_NK * 3], A1[WFM_NK * 3];
+    const int kb = __builtin_amdgcn_readfirstlane(kb_of[ph]);
+    const bool two = kb < WFM_NK;                                                     // the window contains a 1024-chunk boundary
+    v4i A0[WFM_NFRAG];
     {
-        const v4i *fa = frags + (size_t)set0 * WFM_FRAG_V4 + lane;
+        const v4i *fa = frags + (size_t)ph * WFM_FRAG_V4 + lane;
 #pragma unroll
-        for (int s = 0; s < WFM_NK * 3; s++) A0[s] = fa[s * 64];
-        const v4i *fb = frags + (size_t)(two ? set1 : set0) * WFM_FRAG_V4 + lane;
-#pragma unroll
-        for (int s = 0; s < WFM_NK * 3; s++) A1[s] = fb[s * 64];
+        for (int s = 0; s < WFM_NFRAG; s++) A0[s] = fa[s * 64];
     }
     const float4 k0v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 4 * q);
     const float4 k1v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 16 + 4 * q);
@@ -245,17 +286,8 @@ __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in,
         for (int g = 0; g < 4; g++) {
 #pragma unroll
             for (int ks = 0; ks < WFM_NK; ks++) Bq[g][ks] ^= (int)0x80808080;          // u8 - 128 as int8, in place
-            v4i acc0[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, acc1[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-            for (int ks = 0; ks < WFM_NK; ks++)
-#pragma unroll
-                for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks * 3 + l], Bq[g][ks], acc0[l], 0, 0, 0);
-            if (two) {
-#pragma unroll
-                for (int ks = 0; ks < WFM_NK; ks++)
-#pragma unroll
-                    for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[ks * 3 + l], Bq[g][ks], acc1[l], 0, 0, 0);
-            }
+            v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            tile_product(A0, Bq[g], kb, acc, snap);
             if (refill) {
                 if (!EDGE) {
 #pragma unroll
@@ -264,20 +296,7 @@ __global__ __launch_bounds__(64) void k_wfm_mfma(const uint8_t *__restrict__ in,
             }
             // lane (col, q): rows 4q..4q+3 = Re/Im of y[Fj+9], Re/Im of y[Fj+10] for audio j = 4*ti+q of stream col;  y = C_m u0 + C_{m+1} u1
             float pI, pQ, cI, cQ;
-            {
-                float u0[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) u0[r] = fmaf(combine_digits(acc0[0][r], acc0[1][r], acc0[2][r]), p.scale, k0[r]);
-                pI = C0.x * u0[0] - C0.y * u0[1]; pQ = C0.x * u0[1] + C0.y * u0[0];
-                cI = C0.x * u0[2] - C0.y * u0[3]; cQ = C0.x * u0[3] + C0.y * u0[2];
-            }
-            if (two) {
-                float u1[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, k1[r]);
-                pI += C1.x * u1[0] - C1.y * u1[1]; pQ += C1.x * u1[1] + C1.y * u1[0];
-                cI += C1.x * u1[2] - C1.y * u1[3]; cQ += C1.x * u1[3] + C1.y * u1[2];
-            }
+            tile_rows(acc, snap, two, p.scale, k0, k1, C0, C1, pI, pQ, cI, cQ);
             // fmdemod_quadri_cf (libcsdr.c:1040-1071) on (previous = y[Fj+9], current = y[Fj+10])
             const float dq = cQ - pQ, di = cI - pI;
             const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
@@ -310,7 +329,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // SB=16/NB=5 keeps 4 quads (110 KB per CU) in flight.
 template <int SB, int NB>
 __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__ in, size_t in_pitch,
-                                                     const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ set_of,
+                                                     const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ kb_of,
                                                      const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, WgParams p)
 {
     extern __shared__ float4 lds_raw[];
@@ -339,16 +358,13 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
     if (my_sb <= 0) return;
     const long long M = m_end - m_begin, n_items = (long long)my_sb * M;
     // ---- weights: once per wave
-    const int set0 = set_of[2 * ph], set1 = set_of[2 * ph + 1];
-    const bool two = set1 >= 0;
-    v4i A0[WFM_NK * 3], A1[WFM_NK * 3];
+    const int kb = __builtin_amdgcn_readfirstlane(kb_of[ph]);
+    const bool two = kb < WFM_NK;                                                     // the window contains a 1024-chunk boundary
+    v4i A0[WFM_NFRAG];
     {
-        const v4i *fa = frags + (size_t)set0 * WFM_FRAG_V4 + lane;
+        const v4i *fa = frags + (size_t)ph * WFM_FRAG_V4 + lane;
 #pragma unroll
-        for (int s = 0; s < WFM_NK * 3; s++) A0[s] = fa[s * 64];
-        const v4i *fb = frags + (size_t)(two ? set1 : set0) * WFM_FRAG_V4 + lane;
-#pragma unroll
-        for (int s = 0; s < WFM_NK * 3; s++) A1[s] = fb[s * 64];
+        for (int s = 0; s < WFM_NFRAG; s++) A0[s] = fa[s * 64];
     }
     const float4 k0v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 4 * q);
     const float4 k1v = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 16 + 4 * q);
@@ -432,35 +448,10 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
             const uint8_t *src = lrow + (16 * g + col) * p.row_bytes;
 #pragma unroll
             for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks) ^ (int)0x80808080;
-            v4i acc0[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-            for (int ks = 0; ks < WFM_NK; ks++)
-#pragma unroll
-                for (int l = 0; l < 3; l++) acc0[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0[ks * 3 + l], Bf[ks], acc0[l], 0, 0, 0);
-            // the second weight set (window straddles a 1024-chunk) lives entirely inside one branch: its accumulators need no zero
-            // initialisation on the common path (they sit in AGPRs: every touch is a VALU instruction of the wave's serial chain)
-            float sI = 0.f, sQ = 0.f, tI = 0.f, tQ = 0.f;
-            if (two) {
-                v4i acc1[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-                for (int ks = 0; ks < WFM_NK; ks++)
-#pragma unroll
-                    for (int l = 0; l < 3; l++) acc1[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1[ks * 3 + l], Bf[ks], acc1[l], 0, 0, 0);
-                float u1[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) u1[r] = fmaf(combine_digits(acc1[0][r], acc1[1][r], acc1[2][r]), p.scale, k1[r]);
-                sI = C1.x * u1[0] - C1.y * u1[1]; sQ = C1.x * u1[1] + C1.y * u1[0];
-                tI = C1.x * u1[2] - C1.y * u1[3]; tQ = C1.x * u1[3] + C1.y * u1[2];
-            }
+            v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            tile_product(A0, Bf, kb, acc, snap);
             float pI, pQ, cI, cQ;
-            {
-                float u0[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) u0[r] = fmaf(combine_digits(acc0[0][r], acc0[1][r], acc0[2][r]), p.scale, k0[r]);
-                pI = C0.x * u0[0] - C0.y * u0[1]; pQ = C0.x * u0[1] + C0.y * u0[0];
-                cI = C0.x * u0[2] - C0.y * u0[3]; cQ = C0.x * u0[3] + C0.y * u0[2];
-            }
-            if (two) { pI += sI; pQ += sQ; cI += tI; cQ += tQ; }
+            tile_rows(acc, snap, two, p.scale, k0, k1, C0, C1, pI, pQ, cI, cQ);
             const float dq = cQ - pQ, di = cI - pI;
             const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
             // K*num/den with a Newton-refined reciprocal (v_rcp_f32 + one step: ~1 ulp) instead of the 10-instruction IEEE division sequence
@@ -490,6 +481,187 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_wg(const uint8_t *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Octet variant: one workgroup item = 8 CONSECUTIVE tiles (32 audio samples) x 16 streams, fetched as WHOLE 128-byte lines.
+// PMC on the quad kernel above (profiles/r1_notes.md): the vector-memory request stream of each CU is the limiter and it asks
+// for 1.29 x the useful bytes -- 16.1 line requests per 1600-byte row: the 112-byte overlap between consecutive quads (7 %),
+// 16-byte-granular row starts and 1-KiB DMA instructions that straddle a line each.  Here
+//   * the item is twice as long in time (3312-byte rows, overlap 3.4 %), every wave owns TWO tile phases (w and w+4; 2 x 27
+//     weight fragments stay in registers, which the single-chain scheme of tile_product() made affordable);
+//   * every row is fetched from its line-aligned base (window base & ~127): 27 lines = 3 DMA instructions of 8 lines + one of
+//     3 lines (exec-masked to 24 lanes), 27 requests per 3200 useful bytes = 1.08 x.  Each instruction has its own M0, so rows
+//     sit in LDS at a pitch of 217 x 16 B (odd: the 16 streams of a B-fragment read hit different banks) although the fetches
+//     are line granular; the window's offset inside its first line is one scalar add on the LDS read address;
+//   * global addresses are saddr + 32-bit lane offsets: the per-item address work is scalar only;
+//   * 32 audio samples per stream leave as one whole 128-byte line.
+// Requires the input base and pitch to be multiples of 128 bytes (else the quad kernel runs).
+#ifndef WFM_OCT_DIAG
+#define WFM_OCT_DIAG 0
+#endif
+struct OctParams {
+    int n_streams; long long B2; long long oct_first; int n_octs; long long tile_out0;
+    int stride, win_off, n_phases; float scale;
+    int swap_xy;                      // grid roles: 0 = x octet phase / y stream-block slot, 1 = the reverse
+};
+constexpr int OCT_ROW_BYTES = 7 * 400 + 64 * WFM_NK;      // 3312: the kernel is specialised for D*F = 50 (tile stride 400 bytes)
+constexpr int OCT_LINES = 27;                             // (112 + 3312 + 127) / 128
+constexpr int OCT_PITCH = 217 * 16;                       // LDS row pitch: 27 lines + one 16-byte pad slot
+constexpr int OCT_UNIT = 8 * OCT_PITCH;                   // DMA ring unit: 8 streams (half an item), so that 5 units = 2.5 items fit the 160 KB of LDS
+constexpr int OCT_OUTP = 36;                              // floats per stream row of the output staging (32 + pad, 16-byte multiple)
+
+template <int NU>
+__global__ __launch_bounds__(256) void k_wfm_mfma_oct(const uint8_t *__restrict__ in, size_t in_pitch,
+                                                      const v4i *__restrict__ frags, const float *__restrict__ consts, const int *__restrict__ kb_of,
+                                                      const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, OctParams p)
+{
+    extern __shared__ float4 lds_raw[];
+    uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
+    float *lds_out = reinterpret_cast<float *>(lds_in + NU * OCT_UNIT);               // 2 x 16 x OCT_OUTP floats
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    const int n_oph = p.n_phases / 8;                                                // octet phases
+    const int oph = p.swap_xy ? blockIdx.y : blockIdx.x;
+    const int slot_y = p.swap_xy ? blockIdx.x : blockIdx.y, n_slots = p.swap_xy ? gridDim.x : gridDim.y;   // stream-block slot of this workgroup
+    const long long o_lim = p.oct_first + p.n_octs;
+    const long long o0 = p.oct_first + (((long long)oph - p.oct_first) % n_oph + n_oph) % n_oph;
+    if (o0 >= o_lim) return;
+    const long long m_total = (o_lim - 1 - o0) / n_oph + 1;
+    const long long m_per = (m_total + gridDim.z - 1) / gridDim.z;
+    const long long m_begin = (long long)blockIdx.z * m_per;
+    long long m_end = m_begin + m_per; if (m_end > m_total) m_end = m_total;
+    if (m_begin >= m_end) return;
+    const int last_stream = p.n_streams - 1;
+    const int n_wsb = (p.n_streams + 15) / 16;
+    const int my_sb = (n_wsb - slot_y + n_slots - 1) / n_slots;      // stream blocks of this (persistent) workgroup
+    if (my_sb <= 0) return;
+    const long long M = m_end - m_begin, n_items = (long long)my_sb * M;
+    // ---- weights of this wave's two tile phases: once per workgroup lifetime
+    v4i A[2][WFM_NFRAG];
+    int kb[2]; float k0[2][4], k1[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int ph = 8 * oph + w + 4 * t;
+        kb[t] = __builtin_amdgcn_readfirstlane(kb_of[ph]);
+        const v4i *fa = frags + (size_t)ph * WFM_FRAG_V4 + lane;
+#pragma unroll
+        for (int s = 0; s < WFM_NFRAG; s++) A[t][s] = fa[s * 64];
+        const float4 a = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4 *>(consts + (size_t)ph * 32 + 16 + 4 * q);
+        k0[t][0] = a.x; k0[t][1] = a.y; k0[t][2] = a.z; k0[t][3] = a.w;
+        k1[t][0] = b.x; k1[t][1] = b.y; k1[t][2] = b.z; k1[t][3] = b.w;
+    }
+    const float K = 0.340447550238101026565118445432744920253753662109375f;
+    // ---- input staging by LDS-DMA.  Ring of NU units of 8 streams: unit u = (item u/2, streams 8(u%2) .. +7) lives in slot u % NU;
+    //      wave w fetches rows 2w, 2w+1 of every unit, 4 instructions per row (8 VMEM instructions per wave per unit).
+    const long long oct_step = (long long)n_oph * 8 * p.stride;                     // bytes between this workgroup's consecutive octets
+    const long long Og0 = o0 + m_begin * n_oph;
+    const long long wo0 = Og0 * 8 * p.stride + p.win_off - p.B2;                    // first octet's window base relative to the block start
+    const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
+    int cs = slot_y, ch = 0, cslot = 0; long long cm = 0, u_issued = 0;         // DMA cursor (stream block, octet, half), its ring slot
+    const long long n_units = 2 * n_items;
+    uint32_t voff[2][2];                                                            // per-lane byte offset of (half h, row 2w+r, lane's 16-byte piece) from the stream block's base
+    auto set_rows = [&](int sb) {
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int srow = min(sb * 16 + 8 * h + 2 * w + r, last_stream) - sb * 16;   // rows past the last stream re-read it (results discarded)
+                voff[h][r] = (uint32_t)max(srow, 0) * (uint32_t)in_pitch + 16u * lane;
+            }
+    };
+    set_rows(cs);
+    auto dma_unit = [&]() {
+        const long long wa = (wo0 + cm * oct_step) & ~127LL;                        // line-aligned fetch base (same for all rows: base and pitch are line multiples)
+        const uint8_t *sbase = in + (long long)cs * 16 * (long long)in_pitch + wa;
+        const uint32_t ldst = lds_in_addr + cslot * OCT_UNIT + (2 * w) * OCT_PITCH;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const uint32_t vo = ch ? voff[1][r] : voff[0][r];
+#pragma unroll
+            for (int part = 0; part < 4; part++) {
+                const uint8_t *sb = sbase + 1024 * part;
+                const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * OCT_PITCH + 1024 * part));
+                uint32_t keep;
+                // nt: the input is read exactly once, by one CU.  Inline asm on purpose (see the quad kernel): hand-counted vmcnt.
+                if (part < 3)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(vo), "s"(sb), "s"(la) : "memory");
+                else                                                                // lines 24..26 only: lanes 0..23
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, 0xffffff\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(vo), "s"(sb), "s"(la) : "memory");
+            }
+        }
+        u_issued++;
+        cslot = (cslot + 1 == NU) ? 0 : cslot + 1;
+        ch ^= 1;
+        if (!ch && ++cm == M) { cm = 0; cs += n_slots; set_rows(cs); }
+    };
+    // every wave issues exactly 8 VMEM loads per unit and they return in order, so vmcnt(8 n) leaves at most the n newest units in
+    // flight (the demod store of waves 0/1 sits in the same queue: it can only make the wait stricter by one instruction)
+    auto wait_newer = [&](long long newer) {
+        switch ((int)newer) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<8>(); break;
+            case 2: wait_vmcnt<16>(); break;
+            default: wait_vmcnt<24>(); break;
+        }
+    };
+    for (int k = 0; k < NU; k++) if (u_issued < n_units) dma_unit();
+    { long long newer = u_issued - 2; if (newer < 0) newer = 0; if (newer > 3) newer = 3; wait_newer(newer); }     // item 0 = units 0, 1
+    __syncthreads();
+    int ua = 0;                                                                     // slot of the current item's first unit
+    int s0 = slot_y * 16; long long m = 0, Og = Og0, wo = wo0;                  // compute position
+    for (long long it = 0; it < n_items; it++) {
+        const int wbm = (int)(wo & 127);                                            // the window's offset inside its first fetched line
+        float *lout = lds_out + (int)(it & 1) * (16 * OCT_OUTP);
+        const int ub = (ua + 1 == NU) ? 0 : ua + 1;
+        const uint8_t *lrow = lds_in + (col < 8 ? ua : ub) * OCT_UNIT + (col & 7) * OCT_PITCH + 16 * q;     // this lane's stream row in the ring
+#if WFM_OCT_DIAG == 1                                                                 // experiment: DMA stream only (no LDS reads, no math)
+        if (lane == 0) { lout[w] = (float)it; }
+#else
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int jt = w + 4 * t;                                               // tile inside the octet
+            const long long wb2 = wo + p.B2 + (long long)jt * p.stride;             // global byte index of the tile's window base
+            const long long chunk_rel = (wb2 >> 11) - (p.B2 >> 11);
+            const float2 C0 = ctab[chunk_rel + 1], C1 = ctab[chunk_rel + 2];
+            const uint8_t *src = lrow + wbm + jt * p.stride;
+            v4i Bf[WFM_NK];
+#pragma unroll
+            for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks) ^ (int)0x80808080;
+            v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            tile_product(A[t], Bf, kb[t], acc, snap);
+            float pI, pQ, cI, cQ;
+            tile_rows(acc, snap, kb[t] < WFM_NK, p.scale, k0[t], k1[t], C0, C1, pI, pQ, cI, cQ);
+            const float dq = cQ - pQ, di = cI - pI;
+            const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
+            float rd = __builtin_amdgcn_rcpf(den);                                  // Newton-refined reciprocal (~1 ulp), as in the quad kernel
+            rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
+            lout[col * OCT_OUTP + 4 * jt + q] = (den != 0.f) ? (K * num) * rd : 0.f;  // audio 4*(8 Og + jt) + q of stream col
+        }
+#endif
+        {   // item it+1 = units 2it+2, 2it+3 must have landed before anyone passes the barrier; units issued beyond them stay in flight
+            long long left = u_issued - (2 * it + 4);
+            if (left < 0) left = 0;
+            if (left > 3) left = 3;
+            wait_newer(left);
+        }
+        __syncthreads();
+#if WFM_OCT_DIAG != 2                                                                 // experiment 2: math only (the ring is filled once)
+        if (u_issued < n_units) dma_unit();                                         // this item's two slots are free again
+        if (u_issued < n_units) dma_unit();
+#endif
+        if (tid < 128) {                                                            // 8 threads x 16 B = one whole 128-byte line per stream
+            const int srow = tid >> 3, part = tid & 7;
+            if (s0 + srow < p.n_streams)
+                *reinterpret_cast<float4 *>(demod + (size_t)(s0 + srow) * demod_pitch + 4 * (8 * Og - p.tile_out0) + 4 * part) =
+                    *reinterpret_cast<const float4 *>(lout + srow * OCT_OUTP + 4 * part);
+        }
+        ua += 2; if (ua >= NU) ua -= NU;
+        if (++m == M) { m = 0; Og = Og0; wo = wo0; s0 += n_slots * 16; } else { Og += n_oph; wo += oct_step; }
+    }
+}
+
 } // namespace
 
 namespace csdr_amd {
@@ -504,7 +676,7 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
     p.n_streams = n_streams; p.T = T; p.B = B; p.j_first = j_first; p.n_audio = n_audio;
     p.tile_stride_bytes = dev.tile_stride_bytes; p.win_off_bytes = dev.win_off_bytes; p.n_phases = dev.n_phases; p.scale = dev.scale;
     const long long tile_first = j_first / 4, tile_last = (j_first + n_audio - 1) / 4;
-    p.tile_out0 = tile_first;                                        // the scratch rows hold whole tiles; k_wfm_back skips j_first - 4*tile_first samples
+    p.tile_out0 = 8 * (tile_first / 8);                              // the scratch rows hold whole octets (128-byte lines); k_wfm_back skips j_first % 32 samples
     // interior tiles: window entirely inside [0, 2T) of this block (no history, no ragged end)
     long long t_a = tile_first, t_b = tile_last;
     while (t_a <= tile_last && t_a * p.tile_stride_bytes + p.win_off_bytes - 2 * B < 0) t_a++;
@@ -521,58 +693,107 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
         if (z > per_phase / 4) z = (int)(per_phase / 4);
         if (z < 1) z = 1;
         dim3 grid(n_sb, p.n_phases, z);
-        if (edge) hipLaunchKernelGGL((k_wfm_mfma<true>), grid, dim3(64), 0, ls, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
-        else      hipLaunchKernelGGL((k_wfm_mfma<false>), grid, dim3(64), 0, ls, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
+        if (edge) hipLaunchKernelGGL((k_wfm_mfma<true>), grid, dim3(64), 0, ls, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, p);
+        else      hipLaunchKernelGGL((k_wfm_mfma<false>), grid, dim3(64), 0, ls, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, p);
         CSDR_LAUNCH_CHECK();
         return 0;
     };
     static int use_wg = -1;
     if (use_wg < 0) { const char *e = getenv("CSDR_AMD_WFM_WG"); use_wg = e ? atoi(e) : 1; }
     int rc = 0;
+    static int n_cu = 0;
+    if (!n_cu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n_cu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
+    // leftovers around the workgroup kernels' range run on the per-wave kernel (bounds-checked variant: a handful of tiles), both ends in ONE launch
+    auto launch_edges = [&](long long a0, long long a1, long long b0, long long b1) -> int {
+        if (a1 >= a0 && b1 >= b0) {                                          // (each is latency bound: ~22 us)
+            p.tile_first = a0; p.n_tiles = (int)(a1 - a0 + 1); p.tile_first_b = b0; p.n_tiles_b = (int)(b1 - b0 + 1); p.two_ranges = 1; p.tiles_per_wave = 0;
+            hipLaunchKernelGGL((k_wfm_mfma<true>), dim3(n_sb, p.n_phases, 2), dim3(64), 0, st_edge, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, p);
+            CSDR_LAUNCH_CHECK();
+            return 0;
+        }
+        int r2 = launch(st_edge, a0, a1, true); if (r2) return r2;
+        return launch(st_edge, b0, b1, true);
+    };
+    // ---- octet kernel (default): 8 consecutive tiles x 16 streams per item, line-aligned fetch
+    static int use_oct = -1;
+    if (use_oct < 0) { const char *e = getenv("CSDR_AMD_WFM_OCT"); use_oct = e ? atoi(e) : 1; }
+    if (use_oct && use_wg && (p.n_phases % 8) == 0 && 7 * p.tile_stride_bytes + 64 * WFM_NK == OCT_ROW_BYTES &&
+        (((uintptr_t)in | in_pitch) & 127) == 0 && in_pitch * 16 + 4096 < ((size_t)1 << 32)) {
+        const long long oa = (t_a + 7) / 8; long long ob = (t_b + 1) / 8 - 1;            // whole octets inside the interior tile range
+        auto fetch_end = [&](long long o) { return ((o * 8 * p.tile_stride_bytes + p.win_off_bytes - 2 * B) & ~127LL) + 128LL * OCT_LINES; };
+        while (ob >= oa && fetch_end(ob) > 2LL * T) ob--;                                // the line-aligned fetch must stay inside the row
+        const int n_oph = p.n_phases / 8;
+        if (ob - oa + 1 >= 2 * n_oph) {
+            OctParams op;
+            op.n_streams = n_streams; op.B2 = 2 * B; op.oct_first = oa; op.n_octs = (int)(ob - oa + 1); op.tile_out0 = p.tile_out0;
+            op.stride = p.tile_stride_bytes; op.win_off = p.win_off_bytes; op.n_phases = p.n_phases; op.scale = p.scale;
+            static int swap = -1;
+            if (swap < 0) { const char *e = getenv("CSDR_AMD_WFM_OCT_SWAP"); swap = e ? atoi(e) != 0 : 1; }
+            op.swap_xy = swap;
+            const int n_wsb = (n_streams + 15) / 16;
+            const long long per_oph = (op.n_octs + n_oph - 1) / n_oph;
+            int gy = n_cu / n_oph; if (gy < 1) gy = 1; if (gy > n_wsb) gy = n_wsb;      // persistent: one workgroup per CU
+            int z = n_cu / (n_oph * gy); if (z < 1) z = 1;
+            if (z > per_oph / 8) z = (int)(per_oph / 8);
+            if (z < 1) z = 1;
+            static int nu = 0;                                                           // ring depth in half-item units (experiment switch; 5 = 2.5 items)
+            if (!nu) { const char *e = getenv("CSDR_AMD_WFM_OCT_UNITS"); nu = e ? atoi(e) : 5; if (nu != 4) nu = 5; }
+            const size_t lds = (size_t)nu * OCT_UNIT + 2 * 16 * OCT_OUTP * sizeof(float);
+            static bool done[2] = {false, false};
+            auto go = [&](auto kern, bool &dn) -> int {
+                if (!dn) { CSDR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); dn = true; }
+                if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
+                hipLaunchKernelGGL(kern, swap ? dim3(gy, n_oph, z) : dim3(n_oph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, op);
+                return 0;
+            };
+            const int grc = nu == 4 ? go(k_wfm_mfma_oct<4>, done[0]) : go(k_wfm_mfma_oct<5>, done[1]);
+            if (grc) return grc;
+            CSDR_LAUNCH_CHECK();
+            if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
+            g_last_kernel = "k_wfm_mfma_oct";
+            return launch_edges(tile_first, 8 * oa - 1, 8 * (ob + 1), tile_last);
+        }
+    }
     const long long qa = (t_a + 3) / 4, qb = (t_b + 1) / 4 - 1;             // whole quads inside the interior tile range
     if (use_wg && (p.n_phases % 4) == 0 && 3 * p.tile_stride_bytes + 64 * WFM_NK == 1712 && qb - qa + 1 >= 2 * (p.n_phases / 4)) {
         WgParams wp;
-        wp.n_streams = n_streams; wp.B2 = 2 * B; wp.quad_first = qa; wp.n_quads = (int)(qb - qa + 1); wp.tile_out0 = tile_first;
+        wp.n_streams = n_streams; wp.B2 = 2 * B; wp.quad_first = qa; wp.n_quads = (int)(qb - qa + 1); wp.tile_out0 = p.tile_out0;
         wp.stride = p.tile_stride_bytes; wp.win_off = p.win_off_bytes; wp.n_phases = p.n_phases; wp.scale = p.scale;
         wp.row_bytes = 3 * wp.stride + 64 * WFM_NK;                       // rows back to back (the DMA fills one contiguous run); 107 slots: odd
-        static int cfg = -1;                                             // 0: 16 streams x ring of 5 quads (default), 1: 32 streams x ring of 2
-        if (cfg < 0) { const char *e = getenv("CSDR_AMD_WFM_WGCFG"); cfg = e ? atoi(e) : 0; }
-        const int SBv = cfg == 1 ? 32 : 16, NBv = cfg == 1 ? 2 : 5;
+        // CSDR_AMD_WFM_WGCFG: 0 = 16 streams x ring of 5 quads, one workgroup per CU (default); 1 = 32 streams x ring of 2;
+        // 2 = 16 streams x ring of 2, TWO workgroups per CU (two waves per SIMD); 3 = 16 streams x ring of 3, one per CU
+        static int cfg = -1;
+        if (cfg < 0) { const char *e = getenv("CSDR_AMD_WFM_WGCFG"); cfg = e ? atoi(e) : 0; if (cfg < 0 || cfg > 3) cfg = 0; }
+        const int SBv = cfg == 1 ? 32 : 16, NBv = cfg == 0 ? 5 : (cfg == 3 ? 3 : 2), per_cu = cfg == 2 ? 2 : 1;
         const int n_qph = p.n_phases / 4, n_wsb = (n_streams + SBv - 1) / SBv;
         const long long per_qph = (wp.n_quads + n_qph - 1) / n_qph;
-        // persistent grid: one workgroup per CU (256); a workgroup owns a quad phase and walks its share of the stream blocks
-        static int n_cu = 0;
-        if (!n_cu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n_cu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
-        int gy = n_cu / n_qph; if (gy < 1) gy = 1; if (gy > n_wsb) gy = n_wsb;
-        int z = n_cu / (n_qph * gy); if (z < 1) z = 1;
+        // persistent grid: `per_cu` workgroups per CU; a workgroup owns a quad phase and walks its share of the stream blocks
+        const int slots = n_cu * per_cu;
+        int gy = slots / n_qph; if (gy < 1) gy = 1; if (gy > n_wsb) gy = n_wsb;
+        int z = slots / (n_qph * gy); if (z < 1) z = 1;
         if (z > per_qph / 8) z = (int)(per_qph / 8);
         if (z < 1) z = 1;
         const size_t lds = (size_t)NBv * (4 * ((SBv * 107 + 255) / 256) * 1024) + 2 * SBv * 16 * sizeof(float);
         if (wp.row_bytes != 1712) return fail_msg(-3, "wfm: workgroup kernel is specialised for 1712-byte quad rows");
         if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
-        if (cfg == 1) {
-            static bool done1 = false;
-            if (!done1) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done1 = true; }
-            hipLaunchKernelGGL((k_wfm_mfma_wg<32, 2>), dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
-        } else {
-            static bool done0 = false;
-            if (!done0) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_wg<16, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done0 = true; }
-            hipLaunchKernelGGL((k_wfm_mfma_wg<16, 5>), dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, wp);
+        auto go = [&](auto kern, bool &done) -> int {
+            if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+            hipLaunchKernelGGL(kern, dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, wp);
+            return 0;
+        };
+        static bool done[4] = {false, false, false, false};
+        int grc = 0;
+        switch (cfg) {
+            case 1: grc = go(k_wfm_mfma_wg<32, 2>, done[1]); break;
+            case 2: grc = go(k_wfm_mfma_wg<16, 2>, done[2]); break;
+            case 3: grc = go(k_wfm_mfma_wg<16, 3>, done[3]); break;
+            default: grc = go(k_wfm_mfma_wg<16, 5>, done[0]); break;
         }
+        if (grc) return grc;
         CSDR_LAUNCH_CHECK();
         if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
         g_last_kernel = "k_wfm_mfma_wg";
-        // leftovers around the quad range run on the per-wave kernel (bounds-checked variant: a handful of tiles)
-        const long long a0 = tile_first, a1 = 4 * qa - 1, b0 = 4 * (qb + 1), b1 = tile_last;
-        if (a1 >= a0 && b1 >= b0) {                                          // both ends in ONE launch (each is latency bound: ~22 us)
-            p.tile_first = a0; p.n_tiles = (int)(a1 - a0 + 1); p.tile_first_b = b0; p.n_tiles_b = (int)(b1 - b0 + 1); p.two_ranges = 1; p.tiles_per_wave = 0;
-            hipLaunchKernelGGL((k_wfm_mfma<true>), dim3(n_sb, p.n_phases, 2), dim3(64), 0, st_edge, in, in_pitch, hist, (const v4i *)dev.d_frags, dev.d_consts, dev.d_set_of, ctab, demod, demod_pitch, p);
-            CSDR_LAUNCH_CHECK();
-            return 0;
-        }
-        rc = launch(st_edge, a0, a1, true); if (rc) return rc;
-        rc = launch(st_edge, b0, b1, true);
-        return rc;
+        return launch_edges(tile_first, 4 * qa - 1, 4 * (qb + 1), tile_last);
     }
     g_last_kernel = "k_wfm_mfma";
     if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
@@ -600,20 +821,28 @@ extern "C" int csdr_amd_debug_wfm_mfma_tile(int D, int L, int F, float shift_rat
     if (tile_stride_bytes) *tile_stride_bytes = t.tile_stride_bytes;
     if (win_off_bytes) *win_off_bytes = t.win_off_bytes;
     if (phase < 0 || phase >= t.n_phases) return -2;
-    if (straddle) *straddle = t.set_of[2 * phase + 1] >= 0;
+    const int kb = t.kb_of[phase];
+    if (straddle) *straddle = kb < WFM_NK;
     const float *cst = t.consts.data() + (size_t)phase * 32;
-    for (int side = 0; side < 2; side++) {
-        const int set = t.set_of[2 * phase + side];
-        for (int r = 0; r < 16; r++) {
-            long acc[3] = {0, 0, 0};
-            if (set >= 0) {
-                const int8_t *fr = t.frags.data() + (size_t)set * WFM_FRAG_V4 * 16;
-                for (int ks = 0; ks < WFM_NK; ks++) for (int kg = 0; kg < 4; kg++) for (int b = 0; b < 16; b++) {
-                    const int v = (int)(int8_t)(window[64 * ks + 16 * kg + b] ^ 0x80);
-                    for (int l = 0; l < 3; l++) acc[l] += (long)fr[((size_t)(ks * 3 + l) * 64 + (16 * kg + r)) * 16 + b] * v;
-                }
-                out16[16 * side + r] = fmaf(fmaf((float)acc[0], 65536.0f, fmaf((float)acc[1], 256.0f, (float)acc[2])), t.scale, cst[side * 16 + r]);
-            } else out16[16 * side + r] = 0.f;
+    const int8_t *fr = t.frags.data() + (size_t)phase * WFM_FRAG_V4 * 16;
+    for (int r = 0; r < 16; r++) {
+        long acc[3] = {0, 0, 0}, snap[3] = {0, 0, 0};
+        auto step = [&](int frag0, int ks) {                          // one K-step of v_mfma_i32_16x16x64_i8, row r, three digit fragments
+            for (int kg = 0; kg < 4; kg++) for (int b = 0; b < 16; b++) {
+                const int v = (int)(int8_t)(window[64 * ks + 16 * kg + b] ^ 0x80);
+                for (int l = 0; l < 3; l++) acc[l] += (long)fr[((size_t)(frag0 + l) * 64 + (16 * kg + r)) * 16 + b] * v;
+            }
+        };
+        for (int ks = 0; ks < WFM_NK; ks++) {                         // same order as tile_product()
+            if (ks == kb) { step(WFM_NK * 3, ks); for (int l = 0; l < 3; l++) snap[l] = acc[l]; }
+            step(ks * 3, ks);
+        }
+        if (kb < WFM_NK) {
+            out16[r] = fmaf(fmaf((float)snap[0], 65536.0f, fmaf((float)snap[1], 256.0f, (float)snap[2])), t.scale, cst[r]);
+            out16[16 + r] = fmaf(fmaf((float)(acc[0] - snap[0]), 65536.0f, fmaf((float)(acc[1] - snap[1]), 256.0f, (float)(acc[2] - snap[2]))), t.scale, cst[16 + r]);
+        } else {
+            out16[r] = fmaf(fmaf((float)acc[0], 65536.0f, fmaf((float)acc[1], 256.0f, (float)acc[2])), t.scale, cst[r]);
+            out16[16 + r] = 0.f;
         }
     }
     float res[16];

@@ -7,20 +7,21 @@ namespace csdr_amd {
 
 constexpr int WFM_HIST = 256;      // complex samples of input history kept per stream between blocks
 constexpr int WFM_NK = 8;          // 64-byte K-steps per tile window (4 audio samples)
-constexpr int WFM_FRAG_V4 = WFM_NK * 3 * 64;   // int8x16 vectors per weight set: [K-step][digit][lane]
+constexpr int WFM_NFRAG = WFM_NK * 3 + 3;      // weight fragments per tile phase: [K-step][digit] + the boundary K-step's side-0 part [digit]
+constexpr int WFM_FRAG_V4 = WFM_NFRAG * 64;    // int8x16 vectors per tile phase: [fragment][lane]
 
 struct WfmMfmaTable {              // host side
     int D, L, F, tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
-    std::vector<int8_t> frags;     // [n_sets][WFM_NK][3][64][16]; set index from set_of
+    std::vector<int8_t> frags;     // [n_phases][WFM_NFRAG][64][16]
     std::vector<float> consts;     // [n_phases][2][16]
-    std::vector<int> set_of;       // [n_phases][2]: weight set of (phase, side of the chunk boundary); -1 = no second side
+    std::vector<int> kb_of;        // [n_phases]: K-step that contains the first sample of the NEXT 1024-chunk; WFM_NK = the window has one side only
 };
 
 struct WfmMfmaDevice {             // device copies
     int tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
-    void *d_frags; float *d_consts; int *d_set_of;
+    void *d_frags; float *d_consts; int *d_kb_of;
 };
 
 bool wfm_mfma_supported(int D, int L, int F);

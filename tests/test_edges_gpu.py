@@ -106,6 +106,27 @@ def test_wfm_stream_counts(gpu, port, n_streams):
         assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
 
 
+@pytest.mark.parametrize("pitch_pad,block,kernel", [(0, None, "k_wfm_mfma_oct"), (0, 16384 * 5, "k_wfm_mfma_oct"), (16, None, "k_wfm_mfma_wg"),
+                                                     (16, 16384 * 5, "k_wfm_mfma_wg")])
+def test_wfm_workgroup_kernels(gpu, port, pitch_pad, block, kernel):
+    """Both workgroup front ends on the same input: the octet kernel (line-aligned fetch; needs base and pitch to be multiples of
+    128 bytes) and the quad kernel (any 16-byte-aligned pitch), in one call and in blocks whose audio start is not octet aligned;
+    19 streams = one full and one ragged 16-stream block."""
+    from tests_helpers import wfm_signal_u8
+    taps = port.firdes_lowpass_f(79, 0.05)
+    n = 16384 * 15                                  # three blocks of 16384*5, each long enough for the workgroup kernels
+    base = [wfm_signal_u8(300 + s, n) for s in range(3)]
+    u8 = np.stack([base[s % 3] for s in range(19)])
+    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=block, pitch_pad=pitch_pad)
+    assert gpu.last_wfm_kernel == kernel
+    want = [port.wfm_chain(b, -0.085, 10, taps) for b in base]
+    for s in (0, 1, 2, 15, 16, 18):
+        ps, pf = want[s % 3]
+        m = min(pf.size, af.shape[1])
+        assert m >= n // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL
+        assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
 def test_wfm_minimum_blocks(gpu, port):
     """1024-sample blocks (the smallest legal block): every tile straddles a block boundary, history path only"""
     from tests_helpers import wfm_signal_u8
