@@ -136,6 +136,18 @@ def lib():
     L.csdr_amd_wfm_kernel_name.restype = C.c_char_p; L.csdr_amd_wfm_kernel_name.argtypes = [vp]
     L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
     L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.csdr_amd_ddc_create.restype = vp; L.csdr_amd_ddc_create.argtypes = [vp, i, fl, i, vp, i, sz]
+    L.csdr_amd_ddc_destroy.argtypes = [vp]
+    L.csdr_amd_ddc_reset.argtypes = [vp]
+    L.csdr_amd_ddc_process.restype = C.c_long; L.csdr_amd_ddc_process.argtypes = [vp, vp, sz, sz, vp, sz]
+    L.csdr_amd_ddc_kernel_name.restype = C.c_char_p; L.csdr_amd_ddc_kernel_name.argtypes = [vp]
+    L.csdr_amd_ddc_set_profiling.argtypes = [vp, i]
+    L.csdr_amd_ddc_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.csdr_amd_nfm_create.restype = vp; L.csdr_amd_nfm_create.argtypes = [vp, i, fl, i, vp, i, i, i, fl, fl, sz]
+    L.csdr_amd_nfm_destroy.argtypes = [vp]
+    L.csdr_amd_nfm_reset.argtypes = [vp]
+    L.csdr_amd_nfm_process.restype = C.c_long; L.csdr_amd_nfm_process.argtypes = [vp, vp, sz, sz, vp, vp, sz]
+    L.csdr_amd_nfm_front_end.restype = vp; L.csdr_amd_nfm_front_end.argtypes = [vp]
     _lib = L
     return L
 
@@ -582,7 +594,61 @@ class Context:
         self.L.csdr_amd_wfm_destroy(w)
         return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())
 
-    def nfm_chain(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024):
+    def ddc_u8(self, iq_u8, shift_rate, decimation, taps, block=None, pitch_pad=0):
+        """Fused front end convert_u8_f | shift_addition_cc | fir_decimate_cc (csdr_amd_ddc_*): iq_u8 [2n] or [streams, 2n] uint8 ->
+        complex64 [streams, n_out].  `block` = samples per call; `pitch_pad` = extra bytes of row pitch (a pitch that is not a multiple of
+        128 selects the plain kernel).  The kernel of the last call is left in `self.last_ddc_kernel`, all kernels used in `self.ddc_kernels`."""
+        x2, squeeze = self._2d(iq_u8, np.uint8)
+        s, nbytes = x2.shape; n = nbytes // 2
+        pitch = (nbytes + 127) // 128 * 128 + pitch_pad
+        xx = np.full((s, pitch), 0x80, np.uint8); xx[:, :nbytes] = x2
+        taps = np.ascontiguousarray(taps, f32)
+        block = n if block is None else block
+        d = self.L.csdr_amd_ddc_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, max(block, 1024))
+        if not d:
+            raise CsdrAmdError(self.err())
+        di = self.upload(xx)
+        opitch = n // decimation + 64
+        do = self.alloc(8 * s * opitch)
+        pos = 0; no = 0; self.ddc_kernels = set()
+        while pos < n:
+            k = min(block, n - pos)
+            got = self.check(self.L.csdr_amd_ddc_process(d, di.at(2 * pos), pitch, k, do.at(8 * no), opitch), "ddc_process")
+            self.ddc_kernels.add(self.L.csdr_amd_ddc_kernel_name(d).decode())
+            pos += k; no += got
+        y = self.download(do, c64, s * opitch).reshape(s, opitch)[:, :no]
+        self.last_ddc_kernel = self.L.csdr_amd_ddc_kernel_name(d).decode()
+        self.L.csdr_amd_ddc_destroy(d)
+        return y[0].copy() if squeeze else y.copy()
+
+    def nfm_chain(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024, block=None):
+        """BASELINE config 5 / README.md:87 through the chain object csdr_amd_nfm_* (matrix-core front end + audio-rate back end):
+        iq_u8 [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call."""
+        x2, squeeze = self._2d(iq_u8, np.uint8)
+        S, nbytes = x2.shape; n = nbytes // 2
+        pitch = (nbytes + 127) // 128 * 128
+        xx = np.full((S, pitch), 0x80, np.uint8); xx[:, :nbytes] = x2
+        nt = self.firdes_filter_len(tbw)
+        taps = np.ascontiguousarray(self.firdes_lowpass_f(nt, 0.5 / decimation), f32)
+        block = n if block is None else block
+        w = self.L.csdr_amd_nfm_create(self.h, S, shift_rate, decimation, _hp(taps), taps.size, audio_rate, agc_block, 1.0, 1.0, max(block, 1024))
+        if not w:
+            raise CsdrAmdError(self.err())
+        di = self.upload(xx)
+        apitch = n // decimation + 64
+        ds = self.alloc(2 * S * apitch); df = self.alloc(4 * S * apitch)
+        pos = 0; na = 0
+        while pos < n:
+            k = min(block, n - pos)
+            got = self.check(self.L.csdr_amd_nfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na), apitch), "nfm_process")
+            pos += k; na += got
+        pcm = self.download(ds, np.int16, S * apitch).reshape(S, apitch)[:, :na]
+        af = self.download(df, f32, S * apitch).reshape(S, apitch)[:, :na]
+        self.last_ddc_kernel = self.L.csdr_amd_ddc_kernel_name(self.L.csdr_amd_nfm_front_end(w)).decode()
+        self.L.csdr_amd_nfm_destroy(w)
+        return (pcm[0].copy(), af[0].copy()) if squeeze else (pcm.copy(), af.copy())
+
+    def nfm_chain_unfused(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024):
         """BASELINE config 5 / README.md:87, stage by stage through the device batch API with the data resident on the GPU between
         stages: convert_u8_f | shift_addition_cc | fir_decimate_cc D tbw HAMMING | fmdemod_quadri_cf | limit_ff | deemphasis_nfm_ff |
         fastagc_ff | convert_f_s16.   iq_u8: [streams, 2n] uint8  ->  (s16 [streams, na], float audio [streams, na])."""

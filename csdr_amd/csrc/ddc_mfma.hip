@@ -1,0 +1,697 @@
+// ddc_mfma.hip -- fused receiver front end on the matrix cores:
+//
+//        convert_u8_f | shift_addition_cc <rate> | fir_decimate_cc <D> <tbw> <window>
+//
+// (libcsdr.c:2363-2368, libcsdr_gpl.c:27-52 with the CLI's 1024-sample chunks csdr.c:911-918, libcsdr.c:528-549 with the CLI's
+// re-feed loop csdr.c:1160-1176) for N independent u8 IQ streams: the head of the reference's NFM, AM and SSB receive chains
+// (README.md:87, 95, 110 -- D = 50, 801 taps).  Stream model:   y[k] = sum_t h[t] x'[D k + t],   x'[n] = u8_to_float(iq[n]) R[n].
+//
+// Like the WFM front end (wfm_mfma.hip) the whole thing is LINEAR in the input bytes, and u8 - 128 is exactly an int8:
+//
+//        y[k] = sum_n  a h[n - D k] R[n] (v_n - 128)  +  const ,          a = 2/255
+//
+// so conversion, rotation and FIR are one banded int8 product on v_mfma_i32_16x16x64_i8 with exact int32 accumulation and
+// 23-bit weights (three base-256 digits).  What is new here:
+//
+//  * ONE weight set for every tile.  shift_addition_cc's phasor inside a 1024-chunk is R[n] = C_m D^(n - 1024 m) (C_m = float
+//    (cos, sin) of the chunk's float starting phase, D = (cos d, sin d) rounded to float), so relative to a tile's first sample n0
+//    R[n0 + t] = [C_m D^(n0 - 1024 m)] D^t: the weights a h[t - D o] D^t do not depend on the tile, the bracket is a complex
+//    scalar per (tile, chunk) applied AFTER the product.  (The WFM kernel keeps 128 phase-specific weight sets and therefore has to
+//    give every wave a fixed tile phase and jump through the input; here a workgroup can walk through time contiguously.)
+//  * 16 rows = {Re, Im} x 8 consecutive outputs; the 8 D + L - 1 sample window (1151 samples = 36 K-steps for D = 50, L = 801) is
+//    split over the 4 waves of a workgroup (9 K-steps = 27 weight fragments per wave, register resident for the whole launch),
+//    partial sums are reduced through LDS.  The band is 70 % dense (WFM: 31 %).
+//  * A 1024-chunk boundary inside a wave's K-range is handled without a second weight set: the accumulator chain is snapshotted
+//    at the boundary (side 0 = snapshot, side 1 = total - snapshot); when the boundary falls in the middle of a K-step (it is
+//    32-byte granular) that K-step is multiplied twice with the other half of the B operand zeroed.
+//  * Input: a workgroup owns 16 streams x a contiguous run of tiles and slides over the input: every byte is fetched ONCE, as
+//    whole 1-KiB runs of 128-byte lines, by LDS-DMA (global_load_lds_dwordx4, per-instruction M0) into a per-stream ring.
+//  * Outputs that need the previous block's tail (history) or do not fill a tile run on k_ddc_direct, a plain one-thread-per-
+//    output evaluation of the same model, which is also the fallback for shapes the matrix-core kernel does not cover.
+#include "common.hpp"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <complex>
+#include <string>
+#include <vector>
+using namespace csdr_amd;
+
+namespace {
+
+constexpr int DDC_NKT = 36;                 // 64-byte K-steps per tile window (8 outputs): 2*(7 D + L) <= 2304 bytes
+constexpr int DDC_NKW = 9;                  // K-steps per wave
+constexpr int DDC_WIN = 64 * DDC_NKT;       // 2304 bytes
+constexpr int DDC_HIST = 1024;              // complex samples of input history kept per stream between blocks (>= L - 1; one chunk, so that history has ONE phasor seed)
+constexpr int DDC_DTAB = 3072;              // D^k for k in [-2048, 1024)
+constexpr int DDC_NGRAN = 2 * DDC_NKT + 1;  // prefix sums of the weights at 32-byte granules
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct DdcTable {
+    int D, L; float scale;
+    std::vector<int8_t> frags;              // [DDC_NKT][3 digits][64 lanes][16]  (lane l: row l%16, K bytes 16*(l/16) .. +15 of that K-step)
+    std::vector<float> cum;                 // [DDC_NGRAN][16 rows]: 0.5 * sum of the (unquantised) weights of row r over bytes < 32 g
+    std::vector<float2> dtab;               // D^(i - 2048)
+};
+
+bool ddc_mfma_supported(int D, int L)
+{
+    // D even: tile starts stay 32-byte granular (chunk boundaries fall on half K-steps); 16 D <= 3584: the 8 KiB ring holds the current window plus the next tile's bytes
+    return D >= 2 && D <= 224 && (D % 2) == 0 && 2 * (7 * D + L) <= DDC_WIN && L - 1 <= DDC_HIST;
+}
+
+// shift_addition_init libcsdr_gpl.c:81-89: the per-sample phasor D as the reference's floats
+std::complex<double> ddc_step_phasor(float shift_rate)
+{
+    const float rate2 = shift_rate * 2, inc = rate2 * PI_F;
+    return std::complex<double>((double)(float)cos((double)inc), (double)(float)sin((double)inc));
+}
+
+void ddc_build_dtab(float shift_rate, std::vector<float2> &dtab)
+{
+    const std::complex<double> d = ddc_step_phasor(shift_rate);
+    const double mag = std::abs(d), ang = std::arg(d);
+    dtab.resize(DDC_DTAB);
+    for (int i = 0; i < DDC_DTAB; i++) {
+        const int k = i - 2048;
+        const std::complex<double> v = std::polar(pow(mag, k), ang * k);
+        dtab[i] = make_float2((float)v.real(), (float)v.imag());
+    }
+}
+
+void ddc_build_table(int D, int L, float shift_rate, const float *taps, DdcTable &t)
+{
+    t.D = D; t.L = L;
+    const std::complex<double> d = ddc_step_phasor(shift_rate);
+    const double mag = std::abs(d), ang = std::arg(d);
+    ddc_build_dtab(shift_rate, t.dtab);
+    const double a = 2.0 / 255.0;
+    const int span = 7 * D + L;                                       // samples of the tile window
+    double gmax = 0, dmax = fmax(1.0, pow(mag, span));
+    for (int k = 0; k < L; k++) gmax = fmax(gmax, fabs(a * (double)taps[k]));
+    gmax *= dmax * 1.0001;
+    if (gmax == 0) gmax = 1;
+    const double qscale = 4194304.0 / gmax;                           // 2^22: three balanced base-256 digits stay inside int8
+    t.scale = (float)(gmax / 4194304.0);
+    t.frags.assign((size_t)DDC_NKT * 3 * 64 * 16, 0);
+    std::vector<double> gsum((size_t)(DDC_NGRAN - 1) * 16, 0.0);
+    for (int r = 0; r < 16; r++) {
+        const int o = r / 2, comp = r % 2;                            // row = (output o of the tile, Re / Im)
+        for (int tp = 0; tp < L; tp++) {
+            const int ts = D * o + tp;                                // sample relative to the tile's first sample
+            const std::complex<double> G = a * (double)taps[tp] * std::polar(pow(mag, ts), ang * ts);
+            for (int c = 0; c < 2; c++) {
+                // real form of (Gr + j Gi)(I + j Q): Re row takes (Gr, -Gi) on (I, Q); Im row takes (Gi, Gr)
+                const double val = comp == 0 ? (c == 0 ? G.real() : -G.imag()) : (c == 0 ? G.imag() : G.real());
+                const int colb = 2 * ts + c, ks = colb / 64, b = colb % 64;
+                long qv = lrint(val * qscale);
+                const int w2 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w2) / 256;
+                const int w1 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w1) / 256;
+                const int w0 = (int)qv;
+                const int lane = 16 * (b / 16) + r, byte = b % 16;
+                const int dig[3] = {w0, w1, w2};
+                for (int l = 0; l < 3; l++) t.frags[((size_t)(ks * 3 + l) * 64 + lane) * 16 + byte] = (int8_t)dig[l];
+                gsum[(size_t)(colb / 32) * 16 + r] += val;
+            }
+        }
+    }
+    // u8 -> float is a (v - 128) + 1/255 = a (v - 128 + 0.5): the offset's way through the filter is 0.5 * (sum of the weights)
+    t.cum.assign((size_t)DDC_NGRAN * 16, 0.f);
+    for (int r = 0; r < 16; r++) {
+        double run = 0;
+        for (int g = 0; g < DDC_NGRAN; g++) { t.cum[(size_t)g * 16 + r] = (float)(0.5 * run); if (g + 1 < DDC_NGRAN) run += gsum[(size_t)g * 16 + r]; }
+    }
+}
+
+__host__ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// How well does R[n] = C_m D^k describe the reference's float32 phasor recurrence (libcsdr_gpl.c:44-45) for this rate?  For most rates the
+// recurrence's rounding errors average out (relative RMS deviation ~8e-7); for rates whose orbit is short (0.05, 0.25, ...) they repeat and
+// accumulate to a systematic drift of 1e-5 .. 4e-5 over a chunk.  Returns the RMS deviation over a chunk, averaged over a few seeds.
+double ddc_rotator_model_rms(float shift_rate)
+{
+    const float rate2 = shift_rate * 2, inc = rate2 * PI_F;
+    const float cd = (float)cos((double)inc), sd = (float)sin((double)inc);
+    const std::complex<double> d((double)cd, (double)sd);
+    const double mag = std::abs(d), ang = std::arg(d);
+    double acc = 0; int cnt = 0;
+    for (int seed = 0; seed < 12; seed++) {
+        const float ph = -3.0f + 0.53f * seed;
+        float c = (float)cos((double)ph), s = (float)sin((double)ph);
+        const std::complex<double> C((double)c, (double)s);
+        for (int k = 0; k < 1024; k++) {
+            if (k >= 256 && (k & 63) == 0) {
+                const std::complex<double> e = std::complex<double>(c, s) / (C * std::polar(pow(mag, k), ang * k)) - 1.0;
+                acc += std::norm(e); cnt++;
+            }
+            const float c2 = c * cd - s * sd, s2 = s * cd + c * sd;   // -ffp-contract=off: separate products and sums, as the reference's SSE code
+            c = c2; s = s2;
+        }
+    }
+    return sqrt(acc / cnt);
+}
+
+// corr[m][j] = (float recurrence started at C_m, after k = 32 j + 16 steps) / (C_m D^k): the slowly varying factor by which the reference's
+// phasor deviates from the model inside chunk m.  One lane per chunk replays the chunk (data independent, shared by all streams).
+__global__ __launch_bounds__(64) void k_ddc_corr(const float2 *__restrict__ ctab, const float2 *__restrict__ dtab, float2 *__restrict__ corr, int n_rows, float cd, float sd)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= n_rows) return;
+    const float2 C = ctab[m];
+    float c = C.x, s = C.y;
+    for (int k = 0; k < 1024; k++) {
+        if ((k & 31) == 16) {
+            const float2 ref = cmulf(C, dtab[k + 2048]);
+            const float inv = 1.0f / (ref.x * ref.x + ref.y * ref.y);
+            corr[(size_t)m * 32 + (k >> 5)] = make_float2((c * ref.x + s * ref.y) * inv, (s * ref.x - c * ref.y) * inv);
+        }
+        const float c2 = c * cd - s * sd, s2 = s * cd + c * sd;       // libcsdr_gpl.c:44-45
+        c = c2; s = s2;
+    }
+}
+
+// ---- geometry of one wave's K-range, shared by the kernel and the CPU evaluation (csdr_amd_debug_ddc_mfma_tile)
+struct WaveGeom {
+    int two;          // the K-range contains a 1024-chunk boundary
+    int kb, half;     // boundary K-step (0..8) and whether it falls in the middle (32 bytes in) of that K-step
+    int gb;           // boundary granule (32-byte units from the window start)
+    int e0;           // exponent of the post factor of side 0: P0 = C_m D^e0 ; side 1: C_{m+1} D^(e0 - 1024)
+    long long chunk;  // absolute chunk index of side 0
+};
+__host__ __device__ __forceinline__ WaveGeom ddc_wave_geom(long long n0, int w)
+{
+    WaveGeom g;
+    const long long s = n0 + 32LL * DDC_NKW * w;                      // first sample of the wave's K-range
+    const int off = (int)(s & 1023);
+    g.chunk = s >> 10;
+    g.e0 = (int)(n0 - (s & ~1023LL));
+    g.two = off + 32 * DDC_NKW > 1024;
+    const int bo = 2 * (1024 - off);                                  // byte offset of the next chunk's first sample inside the K-range
+    g.kb = g.two ? (bo >> 6) : DDC_NKW;
+    g.half = g.two ? ((bo >> 5) & 1) : 0;
+    g.gb = 2 * DDC_NKW * w + (bo >> 5);
+    return g;
+}
+
+__device__ __forceinline__ float combine_digits(int a0, int a1, int a2)
+{   // exact integers (<= 23 bits each) recombined in float: value = a0*65536 + a1*256 + a2
+    return fmaf((float)a0, 65536.0f, fmaf((float)a1, 256.0f, (float)a2));
+}
+__device__ __forceinline__ float u8_to_f(uint32_t v) { return fmaf((float)v, 0x1.010102p-7f, -1.0f); }   // v/127.5 - 1 (<= 1 ulp of the reference's double expression)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+struct DdcParams {
+    int n_streams;
+    long long B;                      // global sample index of the block start (multiple of 1024)
+    long long tile_first; int n_tiles, tiles_per_seg;
+    long long k_out0;                 // output index stored at out[stream][0]
+    int D, nk_used;                   // decimation; K-steps of the window that hold weights at all
+    float scale;
+};
+
+// One workgroup = 16 streams x the tiles [t0, t1) of its segment, walked in time order.
+//   LDS: 16 ring buffers of RB bytes (pitch RB + 16: the 16 streams of a B-fragment read hit different banks) + the reduction buffer.
+//   DMA: a "row-step" fetches the next 1 KiB of all 16 streams (wave w: streams 4w .. 4w+3, one instruction each).
+template <int RBL>
+__global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
+                                                  const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
+                                                  const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p)
+{
+    constexpr int RB = 1 << RBL, RP = RB + 16;
+    extern __shared__ float4 lds_raw[];
+    uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
+    float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][4 waves][64 lanes]
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    const int sb = blockIdx.x;
+    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
+    long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
+    if (t0 >= t1) return;
+    const int n_it = (int)(t1 - t0);
+    const int last_stream = p.n_streams - 1;
+    // ---- weights of this wave's K-range: once per workgroup
+    v4i A[DDC_NKW * 3];
+    {
+        const v4i *fa = frags + (size_t)(DDC_NKW * w) * 3 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < DDC_NKW * 3; s++) A[s] = fa[s * 64];
+    }
+    int nact = p.nk_used - DDC_NKW * w; if (nact > DDC_NKW) nact = DDC_NKW; if (nact < 0) nact = 0;    // K-steps of this wave that hold weights
+    nact = __builtin_amdgcn_readfirstlane(nact);
+    const int g0 = 2 * DDC_NKW * w;
+    float cfull[4], cg0[4], cg1[4];                                                   // offset constants of rows 4q .. 4q+3: whole K-range, and the prefix values at its ends
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(cum + (size_t)g0 * 16 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4 *>(cum + (size_t)(g0 + 2 * DDC_NKW) * 16 + 4 * q);
+        cg0[0] = a.x; cg0[1] = a.y; cg0[2] = a.z; cg0[3] = a.w; cg1[0] = b.x; cg1[1] = b.y; cg1[2] = b.z; cg1[3] = b.w;
+#pragma unroll
+        for (int r = 0; r < 4; r++) cfull[r] = cg1[r] - cg0[r];
+    }
+    // ---- DMA state
+    const int tstride = 16 * p.D;                                                    // bytes of input per tile
+    long long ws = t0 * tstride - 2 * p.B;                                           // window start of the current tile, bytes from the block start
+    const long long F0 = ws & ~1023LL;
+    const long long F_end = ((t1 - 1) * tstride - 2 * p.B + DDC_WIN + 1023) & ~1023LL;
+    long long F = F0;                                                                // next row-step
+    const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
+    uint32_t voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int srow = min(sb * 16 + 4 * w + r, last_stream) - sb * 16;            // rows past the last stream re-read it (results discarded)
+        voff[r] = (uint32_t)max(srow, 0) * (uint32_t)in_pitch + 16u * lane;
+    }
+    const uint8_t *sblock = in + (long long)sb * 16 * (long long)in_pitch;
+    auto row_step = [&]() {
+        const uint8_t *sbase = sblock + F;
+        const uint32_t ldst = lds_in_addr + (4 * w) * RP + (uint32_t)(F & (RB - 1));
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
+            uint32_t keep;
+            // nt: the input is read exactly once.  Inline asm with hand-counted vmcnt (see wfm_mfma.hip: the builtin form makes the
+            // compiler serialise the DMA with the LDS reads of the other ring positions).
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff[r]), "s"(sbase), "s"(la) : "memory");
+        }
+        F += 1024;
+    };
+    // every wave issues exactly 4 VMEM loads per row-step and they return in order: vmcnt(4 n) leaves at most the n newest row-steps in flight
+    auto wait_newer = [&](long long newer) {
+        switch ((int)newer) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<4>(); break;
+            case 2: wait_vmcnt<8>(); break;
+            case 3: wait_vmcnt<12>(); break;
+            case 4: wait_vmcnt<16>(); break;
+            case 5: wait_vmcnt<20>(); break;
+            case 6: wait_vmcnt<24>(); break;
+            default: wait_vmcnt<28>(); break;
+        }
+    };
+    auto wait_for = [&](long long wstart) {                                          // everything below wstart + DDC_WIN has landed
+        const long long need_end = (wstart + DDC_WIN + 1023) & ~1023LL;
+        long long newer = (F - need_end) >> 10;                                      // row-steps issued beyond what this tile needs
+        if (newer < 0) newer = 0;
+        if (newer > 7) newer = 7;
+        wait_newer(newer);
+    };
+    while (F < F_end && F + 1024 <= ws + RB) row_step();
+    wait_for(ws);
+    __syncthreads();
+    const uint8_t *lrow = lds_in + col * RP;
+    long long ti = t0;
+    for (int it = 0; it < n_it; it++, ti++, ws += tstride) {
+        const long long n0 = p.B + (ws >> 1);                                        // global index of the tile's first sample
+        const WaveGeom g = ddc_wave_geom(n0, w);
+        const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
+        const long long chunk_rel = g.chunk - (p.B >> 10);
+        // ---- B fragments of this wave's K-range from the ring
+        const int base = (int)(ws & (RB - 1)) + 64 * DDC_NKW * w + 16 * q;
+        v4i Bf[DDC_NKW];
+#pragma unroll
+        for (int ks = 0; ks < DDC_NKW; ks++)
+            if (ks < nact) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
+        // ---- one accumulator chain per digit; snapshot at the chunk boundary
+        v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int ks = 0; ks < DDC_NKW; ks++) {
+            if (ks < nact) {
+                if (ks == kb) {
+                    const v4i z = {0, 0, 0, 0};
+                    if (half) {                                                      // bytes 0..31 of the K-step (lanes q < 2) still belong to chunk m
+                        const v4i lo = q < 2 ? Bf[ks] : z;
+#pragma unroll
+                        for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], lo, acc[l], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int l = 0; l < 3; l++) snap[l] = acc[l];
+                    const v4i hi = half ? (q < 2 ? z : Bf[ks]) : Bf[ks];
+#pragma unroll
+                    for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], hi, acc[l], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc[l], 0, 0, 0);
+                }
+            }
+        }
+        // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
+        float4 part;
+        {
+            float2 P0 = cmulf(ctab[chunk_rel + 1], dtab[g.e0 + 2048]);
+            // optional per-chunk correction (rates for which the reference's float recurrence drifts away from C_m D^k): sampled at the
+            // centre of the K-range's part in each chunk
+            const int off = (int)((n0 + 32LL * DDC_NKW * w) & 1023);
+            if (corr) P0 = cmulf(P0, corr[(chunk_rel + 1) * 32 + ((off + (g.two ? (1024 - off) / 2 : 16 * DDC_NKW)) >> 5)]);
+            float u[4];
+            if (g.two && kb < nact) {
+                const float4 cb = *reinterpret_cast<const float4 *>(cum + (size_t)g.gb * 16 + 4 * q);
+                const float cbv[4] = {cb.x, cb.y, cb.z, cb.w};
+                float2 P1 = cmulf(ctab[chunk_rel + 2], dtab[g.e0 - 1024 + 2048]);
+                if (corr) P1 = cmulf(P1, corr[(chunk_rel + 2) * 32 + (((off + 32 * DDC_NKW - 1024) / 2) >> 5)]);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    u[r] = fmaf(combine_digits(snap[0][r], snap[1][r], snap[2][r]), p.scale, cbv[r] - cg0[r]);
+                    v[r] = fmaf(combine_digits(acc[0][r] - snap[0][r], acc[1][r] - snap[1][r], acc[2][r] - snap[2][r]), p.scale, cg1[r] - cbv[r]);
+                }
+                part.x = P0.x * u[0] - P0.y * u[1] + (P1.x * v[0] - P1.y * v[1]); part.y = P0.x * u[1] + P0.y * u[0] + (P1.x * v[1] + P1.y * v[0]);
+                part.z = P0.x * u[2] - P0.y * u[3] + (P1.x * v[2] - P1.y * v[3]); part.w = P0.x * u[3] + P0.y * u[2] + (P1.x * v[3] + P1.y * v[2]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) u[r] = fmaf(combine_digits(acc[0][r], acc[1][r], acc[2][r]), p.scale, cfull[r]);
+                part.x = P0.x * u[0] - P0.y * u[1]; part.y = P0.x * u[1] + P0.y * u[0];
+                part.z = P0.x * u[2] - P0.y * u[3]; part.w = P0.x * u[3] + P0.y * u[2];
+            }
+        }
+        float4 *rbuf = red + (it & 1) * 256;
+        rbuf[w * 64 + lane] = part;
+        // ---- the next tile's window must have landed before anyone passes the barrier; the ring space behind it is refilled right after
+        const long long ws_n = ws + tstride;
+        if (it + 1 < n_it) wait_for(ws_n);
+        __syncthreads();
+        if (it + 1 < n_it) { while (F < F_end && F + 1024 <= ws_n + RB) row_step(); }
+        // ---- reduction of the four K-range shares and store: the waves take turns
+        if (w == (it & 3)) {
+            const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
+            const int stream = sb * 16 + col;
+            if (stream < p.n_streams) {
+                float2 *dst = out + (size_t)stream * out_pitch + (8 * ti - p.k_out0) + 2 * q;
+                dst[0] = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
+                dst[1] = make_float2((a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+            }
+        }
+    }
+}
+
+// Plain evaluation of the same model, one thread per output: outputs [ka0, ka0 + na) and [kb0, kb0 + nb) of every stream.
+// Samples before the block come from the history buffer (the previous blocks' last DDC_HIST samples).
+struct DirectParams { int n_streams; long long B; int T, D, L; long long k_out0, ka0, kb0; int na, nb; };
+
+__global__ __launch_bounds__(256) void k_ddc_direct(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ hist,
+                                                    const float *__restrict__ taps, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
+                                                    const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DirectParams p)
+{
+    const int s = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.na + p.nb) return;
+    const long long k = idx < p.na ? p.ka0 + idx : p.kb0 + (idx - p.na);
+    const uint8_t *row = in + (size_t)s * in_pitch;
+    const uint8_t *hrow = hist + (size_t)s * (2 * DDC_HIST);
+    const long long c0 = p.B >> 10;
+    float ai = 0.f, aq = 0.f;
+    long long n = (long long)p.D * k;
+    for (int t = 0; t < p.L; t++, n++) {
+        const long long rel = n - p.B;
+        uint32_t vi, vq;
+        if (rel < 0) { vi = hrow[2 * (rel + DDC_HIST)]; vq = hrow[2 * (rel + DDC_HIST) + 1]; }
+        else { vi = row[2 * rel]; vq = row[2 * rel + 1]; }
+        float2 R = cmulf(ctab[(n >> 10) - c0 + 1], dtab[(int)(n & 1023) + 2048]);
+        if (corr) R = cmulf(R, corr[((n >> 10) - c0 + 1) * 32 + ((int)(n & 1023) >> 5)]);
+        const float xi = u8_to_f(vi), xq = u8_to_f(vq);
+        const float h = taps[t];
+        ai = fmaf(h, xi * R.x - xq * R.y, ai);
+        aq = fmaf(h, xq * R.x + xi * R.y, aq);
+    }
+    out[(size_t)s * out_pitch + (k - p.k_out0)] = make_float2(ai, aq);
+}
+
+// new_hist = last DDC_HIST samples of (old_hist ++ block)
+__global__ __launch_bounds__(256) void k_ddc_save_hist(const uint8_t *__restrict__ in, size_t in_pitch, int T, const uint8_t *__restrict__ old_hist,
+                                                       uint8_t *__restrict__ new_hist)
+{
+    const int s = blockIdx.x;
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(in + (size_t)s * in_pitch);
+    const uint16_t *oh = reinterpret_cast<const uint16_t *>(old_hist + (size_t)s * (2 * DDC_HIST));
+    uint16_t *nh = reinterpret_cast<uint16_t *>(new_hist + (size_t)s * (2 * DDC_HIST));
+    for (int i = threadIdx.x; i < DDC_HIST; i += 256) {
+        const long long rel = (long long)T - DDC_HIST + i;
+        nh[i] = rel >= 0 ? src[rel] : oh[rel + DDC_HIST];
+    }
+}
+
+} // namespace
+
+struct csdr_amd_ddc {
+    csdr_amd_ctx *ctx;
+    int n_streams, D, L;
+    float shift_rate;
+    size_t max_block;
+    float *d_taps; uint8_t *d_hist[2]; int hflip;
+    void *d_frags; float *d_cum; float2 *d_dtab, *d_ctab, *d_corr; size_t ctab_cap; bool need_corr;
+    float scale; int nk_used;
+    bool use_mfma, ended;
+    float phase; float2 c_prev;
+    long long B, next_k;
+    std::string kernel_name;
+    bool profiling; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used; double prof_ms; long prof_launches;
+};
+
+extern "C" {
+
+csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
+                                  size_t max_block_samples)
+{
+    if (!ctx || n_streams < 1 || decimation < 1 || taps_length < 1 || !host_taps) { fail_msg(-3, "ddc_create: bad arguments"); return nullptr; }
+    if (taps_length - 1 > DDC_HIST) { fail_msg(-3, "ddc_create: %d taps exceed the %d-sample history", taps_length, DDC_HIST + 1); return nullptr; }
+    if (max_block_samples < 1024) max_block_samples = 1024;
+    csdr_amd_ddc *d = new csdr_amd_ddc();
+    d->ctx = ctx; d->n_streams = n_streams; d->D = decimation; d->L = taps_length; d->shift_rate = shift_rate; d->max_block = max_block_samples;
+    d->d_taps = nullptr; d->d_hist[0] = d->d_hist[1] = nullptr; d->d_frags = nullptr; d->d_cum = nullptr; d->d_dtab = nullptr; d->d_ctab = nullptr; d->d_corr = nullptr;
+    d->profiling = false; d->ev_used = 0; d->prof_ms = 0; d->prof_launches = 0;
+    d->ctab_cap = max_block_samples / 1024 + 8;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    alloc((void **)&d->d_taps, sizeof(float) * taps_length);
+    alloc((void **)&d->d_hist[0], (size_t)2 * DDC_HIST * n_streams);
+    alloc((void **)&d->d_hist[1], (size_t)2 * DDC_HIST * n_streams);
+    alloc((void **)&d->d_dtab, sizeof(float2) * DDC_DTAB);
+    alloc((void **)&d->d_ctab, sizeof(float2) * d->ctab_cap);
+    {   // CSDR_AMD_DDC_CORR: 0 = never, 1 = always, default = only for rates whose float recurrence drifts (model deviation > 2e-6 RMS)
+        const char *ce = getenv("CSDR_AMD_DDC_CORR");
+        d->need_corr = ce ? atoi(ce) != 0 : ddc_rotator_model_rms(shift_rate) > 2e-6;
+        if (d->need_corr) alloc((void **)&d->d_corr, sizeof(float2) * d->ctab_cap * 32);
+    }
+    if (e == hipSuccess) e = hipMemcpy(d->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
+    const char *force = getenv("CSDR_AMD_DDC_PATH");                  // "direct" forces the plain kernel (A/B comparisons)
+    d->use_mfma = ddc_mfma_supported(decimation, taps_length) && !(force && !strcmp(force, "direct"));
+    d->scale = 0; d->nk_used = 0;
+    if (d->use_mfma) {
+        DdcTable t;
+        ddc_build_table(decimation, taps_length, shift_rate, host_taps, t);
+        d->scale = t.scale; d->nk_used = (2 * (7 * decimation + taps_length) + 63) / 64;
+        alloc(&d->d_frags, t.frags.size());
+        alloc((void **)&d->d_cum, t.cum.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(d->d_frags, t.frags.data(), t.frags.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d->d_cum, t.cum.data(), t.cum.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d->d_dtab, t.dtab.data(), sizeof(float2) * DDC_DTAB, hipMemcpyHostToDevice);
+    } else {
+        std::vector<float2> dt; ddc_build_dtab(shift_rate, dt);
+        if (e == hipSuccess) e = hipMemcpy(d->d_dtab, dt.data(), sizeof(float2) * DDC_DTAB, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { fail(e, "hipMalloc/hipMemcpy(ddc state)", __FILE__, __LINE__); csdr_amd_ddc_destroy(d); return nullptr; }
+    d->kernel_name = d->use_mfma ? "k_ddc_mfma" : "k_ddc_direct";
+    if (csdr_amd_ddc_reset(d)) { csdr_amd_ddc_destroy(d); return nullptr; }
+    return d;
+}
+
+void csdr_amd_ddc_destroy(csdr_amd_ddc *d)
+{
+    if (!d) return;
+    (void)hipStreamSynchronize(d->ctx->stream);
+    (void)hipFree(d->d_taps); (void)hipFree(d->d_hist[0]); (void)hipFree(d->d_hist[1]); (void)hipFree(d->d_frags); (void)hipFree(d->d_cum);
+    (void)hipFree(d->d_dtab); (void)hipFree(d->d_ctab); (void)hipFree(d->d_corr);
+    for (auto &pr : d->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete d;
+}
+
+int csdr_amd_ddc_reset(csdr_amd_ddc *d)
+{
+    d->phase = 0.f; d->c_prev = make_float2(1.f, 0.f); d->B = 0; d->next_k = 0; d->ended = false; d->hflip = 0;
+    CSDR_HIP(hipMemsetAsync(d->d_hist[0], 0x80, (size_t)2 * DDC_HIST * d->n_streams, d->ctx->stream));
+    CSDR_HIP(hipMemsetAsync(d->d_hist[1], 0x80, (size_t)2 * DDC_HIST * d->n_streams, d->ctx->stream));
+    return 0;
+}
+
+const char *csdr_amd_ddc_kernel_name(const csdr_amd_ddc *d) { return d->kernel_name.c_str(); }
+
+int csdr_amd_ddc_set_profiling(csdr_amd_ddc *d, int on)
+{
+    d->profiling = on != 0; d->ev_used = 0; d->prof_ms = 0; d->prof_launches = 0;
+    return 0;
+}
+
+int csdr_amd_ddc_kernel_time(csdr_amd_ddc *d, double *total_ms, long *launches)
+{
+    CSDR_HIP(hipStreamSynchronize(d->ctx->stream));
+    for (size_t i = 0; i < d->ev_used; i++) {
+        float ms = 0; CSDR_HIP(hipEventElapsedTime(&ms, d->ev_pool[i].first, d->ev_pool[i].second));
+        d->prof_ms += ms; d->prof_launches++;
+    }
+    d->ev_used = 0;
+    if (total_ms) *total_ms = d->prof_ms;
+    if (launches) *launches = d->prof_launches;
+    return 0;
+}
+
+long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, size_t block_samples, csdr_complexf *out, size_t out_pitch)
+{
+    csdr_amd_ctx *c = d->ctx; hipStream_t st = c->stream;
+    if (d->ended) return fail_msg(-3, "ddc: stream already ended by a block that was not a multiple of 1024 samples; reset first");
+    if (block_samples == 0) return 0;
+    if (block_samples > d->max_block) return fail_msg(-3, "ddc: block of %zu samples exceeds max_block_samples %zu", block_samples, d->max_block);
+    if (((uintptr_t)in & 1) || (in_pitch & 1)) return fail_msg(-3, "ddc: input pointer and pitch must be 2-byte aligned");
+    if (in_pitch < 2 * block_samples && d->n_streams > 1) return fail_msg(-3, "ddc: in_pitch smaller than the block");
+    const int T = (int)block_samples;
+    // 1. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping (libcsdr_gpl.c:33-34, 48-51;
+    //    chunks of 1024 per csdr.c:911-918).  ctab[0] belongs to the previous block's last chunk.
+    const size_t nch = ((size_t)T + 1023) / 1024;
+    if (nch + 3 > d->ctab_cap) return fail_msg(-3, "ddc: chunk table too small");
+    float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * (nch + 3));
+    if (!hc) return -2;
+    {
+        const float inc = (d->shift_rate * 2) * PI_F;
+        float ph = d->phase;
+        hc[0] = d->c_prev;
+        for (size_t m = 0; m <= nch + 1; m++) {
+            hc[1 + m] = make_float2((float)cos((double)ph), (float)sin((double)ph));
+            if (m + 1 == nch) d->c_prev = hc[1 + m];
+            const int len = (m < nch && (size_t)T - m * 1024 < 1024) ? (int)((size_t)T - m * 1024) : 1024;
+            float nx = ph + inc * (float)len;
+            while (nx > PI_F) nx -= 2 * PI_F;
+            while (nx < -PI_F) nx += 2 * PI_F;
+            if (m + 1 == nch) d->phase = nx;
+            ph = nx;
+        }
+    }
+    int rc = c->pinned_upload(d->d_ctab, sizeof(float2) * (nch + 3)); if (rc) return rc;
+    if (d->need_corr) {
+        const float inc = (d->shift_rate * 2) * PI_F;
+        hipLaunchKernelGGL(k_ddc_corr, dim3(cdiv(nch + 2, 64)), dim3(64), 0, st, d->d_ctab, d->d_dtab, d->d_corr, (int)(nch + 2), (float)cos((double)inc), (float)sin((double)inc));
+        CSDR_LAUNCH_CHECK();
+    }
+    // 2. outputs that become computable with this block: y[k] needs input up to D k + L - 1
+    const long long avail_last = d->B + T - 1;
+    long long k_hi = -1;
+    if (avail_last - (d->L - 1) >= 0) k_hi = (avail_last - (d->L - 1)) / d->D;
+    const long long n_out_ll = k_hi - d->next_k + 1;
+    const long n_out = n_out_ll > 0 ? (long)n_out_ll : 0;
+    if (n_out > 0) {
+        if ((size_t)n_out > out_pitch && d->n_streams > 1) return fail_msg(-3, "ddc: out_pitch %zu smaller than the %ld outputs of this block", out_pitch, n_out);
+        const long long k_first = d->next_k;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (d->profiling) {
+            if (d->ev_used == d->ev_pool.size()) { hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b)); d->ev_pool.emplace_back(a, b); }
+            e0 = d->ev_pool[d->ev_used].first; e1 = d->ev_pool[d->ev_used].second; d->ev_used++;
+        }
+        // whole tiles (8 outputs) whose window lies inside this block, fetched as 1-KiB runs of whole lines
+        long long ta = 0, tb = -1;
+        const long long tstride = 16LL * d->D;
+        if (d->use_mfma && (((uintptr_t)in | in_pitch) & 127) == 0 && in_pitch * 16 + 4096 < ((size_t)1 << 32)) {
+            ta = (k_first + 7) / 8; tb = (k_hi + 1) / 8 - 1;
+            while (ta <= tb && ta * tstride - 2 * d->B < 0) ta++;
+            while (tb >= ta && ((tb * tstride - 2 * d->B + DDC_WIN + 1023) & ~1023LL) > 2LL * T) tb--;
+            if (tb - ta + 1 < 4) { ta = 0; tb = -1; }
+        }
+        static int n_cu = 0;
+        if (!n_cu) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); n_cu = (hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
+        if (tb >= ta) {
+            DdcParams p;
+            p.n_streams = d->n_streams; p.B = d->B; p.tile_first = ta; p.n_tiles = (int)(tb - ta + 1); p.k_out0 = k_first; p.D = d->D; p.nk_used = d->nk_used; p.scale = d->scale;
+            const int n_wsb = (d->n_streams + 15) / 16;
+            // 8 KiB ring per stream (window 2304 B + the next tile's bytes + 1-KiB fetch granularity on both sides need > 4 KiB), one workgroup per CU
+            constexpr int rbl = 13;
+            int n_seg = (n_cu + n_wsb - 1) / n_wsb; if (n_seg < 1) n_seg = 1;
+            if (n_seg > p.n_tiles / 16) n_seg = p.n_tiles / 16;
+            if (n_seg < 1) n_seg = 1;
+            p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
+            n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
+            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + 2 * 4 * 64 * sizeof(float4);
+            static bool done = false;
+            if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+            if (e0) CSDR_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL((k_ddc_mfma<rbl>), dim3(n_wsb, n_seg), dim3(256), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,
+                               reinterpret_cast<float2 *>(out), out_pitch, p);
+            CSDR_LAUNCH_CHECK();
+            if (e1) CSDR_HIP(hipEventRecord(e1, st));
+            d->kernel_name = "k_ddc_mfma";
+        } else d->kernel_name = "k_ddc_direct";
+        // everything else: leading outputs (history), trailing outputs of the last partial tile, or the whole block
+        DirectParams q;
+        q.n_streams = d->n_streams; q.B = d->B; q.T = T; q.D = d->D; q.L = d->L; q.k_out0 = k_first;
+        if (tb >= ta) { q.ka0 = k_first; q.na = (int)(8 * ta - k_first); q.kb0 = 8 * (tb + 1); q.nb = (int)(k_hi - q.kb0 + 1); }
+        else { q.ka0 = k_first; q.na = (int)n_out; q.kb0 = 0; q.nb = 0; }
+        if (q.na + q.nb > 0) {
+            if (tb < ta && e0) CSDR_HIP(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(k_ddc_direct, dim3(cdiv(q.na + q.nb, 256), d->n_streams), dim3(256), 0, st, in, in_pitch, d->d_hist[d->hflip], d->d_taps, d->d_dtab, d->d_ctab, d->d_corr,
+                               reinterpret_cast<float2 *>(out), out_pitch, q);
+            CSDR_LAUNCH_CHECK();
+            if (tb < ta && e1) CSDR_HIP(hipEventRecord(e1, st));
+        }
+    }
+    // 3. history for the next block
+    hipLaunchKernelGGL(k_ddc_save_hist, dim3(d->n_streams), dim3(256), 0, st, in, in_pitch, T, d->d_hist[d->hflip], d->d_hist[d->hflip ^ 1]);
+    CSDR_LAUNCH_CHECK();
+    d->hflip ^= 1;
+    if (T % 1024) d->ended = true;
+    d->B += T; d->next_k += n_out;
+    return n_out;
+}
+
+// Test hook (tests/test_ddc_table_cpu.py): evaluates ONE tile on the CPU exactly the way k_ddc_mfma does -- same table, same lane/byte
+// layout, same K-range split over four waves, same snapshot / half-K-step handling of chunk boundaries, same post factors -- so the
+// table builder and the index arithmetic are validated without a GPU.
+//   n0: global index of the tile's first sample (multiple of 16); window: DDC_WIN raw u8 bytes starting at sample n0;
+//   ctab: (cos, sin) pairs of the chunks n0 >> 10, +1, +2;  out16: (Re, Im) of the tile's 8 outputs.
+int csdr_amd_debug_ddc_mfma_tile(int D, int L, float shift_rate, const float *taps, long long n0, const uint8_t *window, const float *ctab3, float *out16)
+{
+    if (!ddc_mfma_supported(D, L) || (n0 & 15)) return -1;
+    static DdcTable t; static int cD = 0, cL = 0; static float crate = 0; static std::vector<float> ctaps;
+    if (cD != D || cL != L || crate != shift_rate || ctaps != std::vector<float>(taps, taps + L)) {
+        ddc_build_table(D, L, shift_rate, taps, t); cD = D; cL = L; crate = shift_rate; ctaps.assign(taps, taps + L);
+    }
+    const int nk_used = (2 * (7 * D + L) + 63) / 64;
+    for (int r = 0; r < 16; r++) out16[r] = 0.f;
+    for (int w = 0; w < 4; w++) {
+        const WaveGeom g = ddc_wave_geom(n0, w);
+        int nact = nk_used - DDC_NKW * w; if (nact > DDC_NKW) nact = DDC_NKW; if (nact < 0) nact = 0;
+        const long long chunk_rel = g.chunk - (n0 >> 10);
+        const float2 C0 = make_float2(ctab3[2 * chunk_rel], ctab3[2 * chunk_rel + 1]), C1 = make_float2(ctab3[2 * chunk_rel + 2], ctab3[2 * chunk_rel + 3]);
+        const float2 P0 = cmulf(C0, t.dtab[g.e0 + 2048]);
+        const float2 P1 = g.two ? cmulf(C1, t.dtab[g.e0 - 1024 + 2048]) : make_float2(0.f, 0.f);
+        float u[16], v[16];
+        for (int r = 0; r < 16; r++) {
+            long acc[3] = {0, 0, 0}, snap[3] = {0, 0, 0};
+            auto step = [&](int ks, int kg_lo, int kg_hi) {           // K-step ks of this wave, k-groups (16-byte lane groups) [kg_lo, kg_hi)
+                const int K = DDC_NKW * w + ks;
+                for (int kg = kg_lo; kg < kg_hi; kg++) for (int b = 0; b < 16; b++) {
+                    const int x = (int)(int8_t)(window[64 * K + 16 * kg + b] ^ 0x80);
+                    for (int l = 0; l < 3; l++) acc[l] += (long)t.frags[((size_t)(K * 3 + l) * 64 + (16 * kg + r)) * 16 + b] * x;
+                }
+            };
+            for (int ks = 0; ks < nact; ks++) {
+                if (ks == g.kb) {
+                    if (g.half) step(ks, 0, 2);
+                    for (int l = 0; l < 3; l++) snap[l] = acc[l];
+                    if (g.half) step(ks, 2, 4); else step(ks, 0, 4);
+                } else step(ks, 0, 4);
+            }
+            const float cg0 = t.cum[(size_t)(2 * DDC_NKW * w) * 16 + r], cg1 = t.cum[(size_t)(2 * DDC_NKW * (w + 1)) * 16 + r];
+            if (g.two && g.kb < nact) {
+                const float cb = t.cum[(size_t)g.gb * 16 + r];
+                u[r] = fmaf(fmaf((float)snap[0], 65536.0f, fmaf((float)snap[1], 256.0f, (float)snap[2])), t.scale, cb - cg0);
+                v[r] = fmaf(fmaf((float)(acc[0] - snap[0]), 65536.0f, fmaf((float)(acc[1] - snap[1]), 256.0f, (float)(acc[2] - snap[2]))), t.scale, cg1 - cb);
+            } else {
+                u[r] = fmaf(fmaf((float)acc[0], 65536.0f, fmaf((float)acc[1], 256.0f, (float)acc[2])), t.scale, cg1 - cg0);
+                v[r] = 0.f;
+            }
+        }
+        for (int o = 0; o < 8; o++) {
+            out16[2 * o] += P0.x * u[2 * o] - P0.y * u[2 * o + 1] + (P1.x * v[2 * o] - P1.y * v[2 * o + 1]);
+            out16[2 * o + 1] += P0.x * u[2 * o + 1] + P0.y * u[2 * o] + (P1.x * v[2 * o + 1] + P1.y * v[2 * o]);
+        }
+    }
+    return 0;
+}
+
+} // extern "C"

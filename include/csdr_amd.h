@@ -282,6 +282,48 @@ const char *csdr_amd_wfm_kernel_name(const csdr_amd_wfm *w);
 int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on);
 int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches);
 
+/* ------------------------------------------------------------------ fused receiver front end (head of the NFM / AM / SSB chains, BASELINE config 5)
+ * README.md:87, 95, 110:  convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw window
+ * (libcsdr.c:2363-2368, libcsdr_gpl.c:27-52 in the CLI's 1024-sample chunks csdr.c:911-918, libcsdr.c:528-549 with the CLI's re-feed loop
+ * csdr.c:1160-1176) for n_streams independent u8 IQ streams in one pass:  y[k] = sum_t taps[t] x'[D k + t].  Each input byte is read from HBM
+ * once; the decimated complex stream is written once.  Streaming: consecutive blocks, all cross-block state (shift phase, FIR history,
+ * output index) lives in the object.  taps_length <= 1025. */
+typedef struct csdr_amd_ddc csdr_amd_ddc;
+csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation,
+                                  const float *host_taps, int taps_length, size_t max_block_samples);
+void csdr_amd_ddc_destroy(csdr_amd_ddc *d);
+int  csdr_amd_ddc_reset(csdr_amd_ddc *d);
+/* in: u8 IQ, [n_streams][in_pitch bytes], block_samples complex samples per stream (multiple of 1024 except for the last block of a
+ * stream).  out: [n_streams][out_pitch] complexf.  Returns the number of outputs written per stream (all k with D k + taps <= samples so far). */
+long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, size_t block_samples,
+                          csdr_complexf *out, size_t out_pitch);
+const char *csdr_amd_ddc_kernel_name(const csdr_amd_ddc *d);
+int csdr_amd_ddc_set_profiling(csdr_amd_ddc *d, int on);
+int csdr_amd_ddc_kernel_time(csdr_amd_ddc *d, double *total_ms, long *launches);
+/* Test hook: CPU evaluation of one tile of the front end's matrix-core kernel with its own weight table, K-range split and chunk-boundary
+ * handling (no GPU needed).  window: 2304 raw bytes from sample n0 (multiple of 16); ctab3: (cos, sin) of chunks n0>>10, +1, +2; out16: 8 x (Re, Im). */
+int csdr_amd_debug_ddc_mfma_tile(int D, int L, float shift_rate, const float *taps, long long n0, const uint8_t *window,
+                                 const float *ctab3, float *out16);
+
+/* ------------------------------------------------------------------ NFM receive chain (BASELINE config 5)
+ * README.md:87:  convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw HAMMING | fmdemod_quadri_cf | limit_ff [max] |
+ *                deemphasis_nfm_ff fs | fastagc_ff [block [reference]] | convert_f_s16
+ * for n_streams independent u8 IQ streams: front end = csdr_amd_ddc (one pass over the input), back end at the audio rate.  Streaming as the
+ * CLI pipeline does it: the de-emphasis FIR re-feeds its unconsumed input (csdr.c:1083), fastagc_ff works on whole blocks with its two-block
+ * latency and zero-initialised state (csdr.c:1393-1394); a call returns the whole AGC blocks that became available (a multiple of agc_block,
+ * possibly 0).  audio_rate selects the de-emphasis table (48000, 44100, 8000, 11025; libcsdr.c:1115-1119). */
+typedef struct csdr_amd_nfm csdr_amd_nfm;
+csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
+                                  int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples);
+void csdr_amd_nfm_destroy(csdr_amd_nfm *w);
+int  csdr_amd_nfm_reset(csdr_amd_nfm *w);
+/* in: u8 IQ as for csdr_amd_ddc_process.  audio_s16: [n_streams][out_pitch]; audio_f (optional, may be NULL): the float audio before
+ * convert_f_s16 (parity tap).  Returns audio samples written per stream. */
+long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, size_t block_samples,
+                          int16_t *audio_s16, float *audio_f, size_t out_pitch);
+/* the chain's front end object (kernel name / profiling: csdr_amd_ddc_kernel_name, csdr_amd_ddc_set_profiling, csdr_amd_ddc_kernel_time) */
+csdr_amd_ddc *csdr_amd_nfm_front_end(csdr_amd_nfm *w);
+
 /* Test hook: CPU evaluation of one matrix-core tile with the kernel's own weight table and layout (no GPU needed);
  * out16 must hold 32 floats (16 results + scratch).  See csdr_amd/csrc/wfm_mfma.hip. */
 int csdr_amd_debug_wfm_mfma_tile(int D, int L, int F, float shift_rate, const float *taps, int phase, const uint8_t *window,

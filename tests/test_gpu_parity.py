@@ -335,15 +335,23 @@ def test_dropin_client_binary(gpu):
     assert abs(float(m.group(4)) / float(g.group(2)) - 1) < 1e-4
 
 
-def test_nfm_chain_device_resident(gpu, port):
-    """BASELINE config 5 shape (README.md:87) at reduced size: 3 channels x 0.25 s, every stage a device batch call."""
-    n = 600000
+@pytest.mark.parametrize("mode", ["chain", "chain_blocks", "chain_small_blocks", "unfused"])
+def test_nfm_chain_device_resident(gpu, port, mode):
+    """BASELINE config 5 shape (README.md:87) at reduced size: 3 channels x 0.25 s.  chain = the csdr_amd_nfm object (matrix-core front end,
+    audio-rate back end) in one call / in blocks that split AGC blocks and filter history / in blocks too small for the matrix-core kernel;
+    unfused = every stage a device batch call."""
+    n = 600000 if mode != "chain_small_blocks" else 1024 * 150
     u8 = np.stack([to_u8(fm_signal(np.random.default_rng(5000 + s), n, dev=5e3 / 2.4e6, offset=0.05)) for s in range(3)])
-    pcm, af = gpu.nfm_chain(u8, -0.05)
+    if mode == "unfused":
+        pcm, af = gpu.nfm_chain_unfused(u8, -0.05)
+    else:
+        pcm, af = gpu.nfm_chain(u8, -0.05, block={"chain": None, "chain_blocks": 1024 * 150, "chain_small_blocks": 1024 * 5}[mode])
+        if mode != "chain_small_blocks":
+            assert gpu.last_ddc_kernel == "k_ddc_mfma" or mode == "chain_blocks"
     taps = gpu.nfm_taps(48000)
     for s in range(3):
         ps, pf = port.nfm_chain(u8[s], -0.05, taps)
-        assert pf.size == af.shape[1] and pf.size >= 10 * 1024
+        assert pf.size == af.shape[1] and pf.size >= 2 * 1024
         assert np.all(af[s, :2048] == 0)                               # fastagc's two-block latency
         assert relrms(af[s], pf) < TOL
         d = np.abs(pcm[s].astype(np.int32) - ps.astype(np.int32))
