@@ -202,6 +202,35 @@ __device__ __forceinline__ float u8_to_f(uint32_t v) { return fmaf((float)v, 0x1
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// The accumulator chains of one wave's K-range with the chunk boundary at K-step KB (compile time; KB = DDC_NKW: no boundary), so that every
+// variant is straight-line code (run-time `if (ks == kb)` branches inside the unrolled chain made the compiler shuffle the accumulators through
+// AGPR copies at every merge point: 700 v_accvgpr moves per tile, 4x the kernel time).  half: the boundary lies 32 bytes into K-step KB: lanes
+// q < 2 hold its chunk-m bytes.  Handled branch free: the K-step is multiplied twice with complementary halves of B zeroed (with half = 0 the
+// first product is a product with zero).
+template <int KB>
+__device__ __forceinline__ void ddc_chain(const v4i (&A)[DDC_NKW * 3], const v4i (&Bf)[DDC_NKW], bool lo_lane, v4i (&acc)[3], v4i (&snap)[3])
+{
+    const v4i z = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < DDC_NKW; ks++) {
+        if (ks == KB) {
+            const v4i lo = lo_lane ? Bf[ks] : z, hi = lo_lane ? z : Bf[ks];
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], lo, acc[l], 0, 0, 0);
+#pragma unroll
+            for (int l = 0; l < 3; l++) snap[l] = acc[l];
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], hi, acc[l], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc[l], 0, 0, 0);
+        }
+    }
+}
+
+#ifndef DDC_DIAG
+#define DDC_DIAG 0          // experiments: 1 = DMA ring + barriers only (no LDS reads / math), 2 = math only (ring filled once)
+#endif
 struct DdcParams {
     int n_streams;
     long long B;                      // global sample index of the block start (multiple of 1024)
@@ -223,7 +252,10 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
     float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][4 waves][64 lanes]
+    float *lcum = reinterpret_cast<float *>(red + 512);                               // the prefix-sum table: a vector load from global memory inside the tile
+                                                                                      // loop would need vmcnt(0), i.e. drain the whole DMA ring
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    for (int i = tid; i < DDC_NGRAN * 16; i += 256) lcum[i] = cum[i];                 // (visible after the barrier that ends the prologue)
     const int sb = blockIdx.x;
     const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
@@ -306,37 +338,32 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
         const WaveGeom g = ddc_wave_geom(n0, w);
         const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
         const long long chunk_rel = g.chunk - (p.B >> 10);
+#if DDC_DIAG == 1
+        float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
+#else
         // ---- B fragments of this wave's K-range from the ring
         const int base = (int)(ws & (RB - 1)) + 64 * DDC_NKW * w + 16 * q;
+        float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nact > 0) {                                                              // (loop invariant: waves beyond a short window have nothing to add)
         v4i Bf[DDC_NKW];
 #pragma unroll
-        for (int ks = 0; ks < DDC_NKW; ks++)
-            if (ks < nact) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
+        for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
         // ---- one accumulator chain per digit; snapshot at the chunk boundary
         v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int ks = 0; ks < DDC_NKW; ks++) {
-            if (ks < nact) {
-                if (ks == kb) {
-                    const v4i z = {0, 0, 0, 0};
-                    if (half) {                                                      // bytes 0..31 of the K-step (lanes q < 2) still belong to chunk m
-                        const v4i lo = q < 2 ? Bf[ks] : z;
-#pragma unroll
-                        for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], lo, acc[l], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int l = 0; l < 3; l++) snap[l] = acc[l];
-                    const v4i hi = half ? (q < 2 ? z : Bf[ks]) : Bf[ks];
-#pragma unroll
-                    for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], hi, acc[l], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc[l], 0, 0, 0);
-                }
-            }
+        const bool lo_lane = half && q < 2;
+        switch (kb) {
+            case 0: ddc_chain<0>(A, Bf, lo_lane, acc, snap); break;
+            case 1: ddc_chain<1>(A, Bf, lo_lane, acc, snap); break;
+            case 2: ddc_chain<2>(A, Bf, lo_lane, acc, snap); break;
+            case 3: ddc_chain<3>(A, Bf, lo_lane, acc, snap); break;
+            case 4: ddc_chain<4>(A, Bf, lo_lane, acc, snap); break;
+            case 5: ddc_chain<5>(A, Bf, lo_lane, acc, snap); break;
+            case 6: ddc_chain<6>(A, Bf, lo_lane, acc, snap); break;
+            case 7: ddc_chain<7>(A, Bf, lo_lane, acc, snap); break;
+            case 8: ddc_chain<8>(A, Bf, lo_lane, acc, snap); break;
+            default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
         }
         // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
-        float4 part;
         {
             float2 P0 = cmulf(ctab[chunk_rel + 1], dtab[g.e0 + 2048]);
             // optional per-chunk correction (rates for which the reference's float recurrence drifts away from C_m D^k): sampled at the
@@ -344,8 +371,8 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
             const int off = (int)((n0 + 32LL * DDC_NKW * w) & 1023);
             if (corr) P0 = cmulf(P0, corr[(chunk_rel + 1) * 32 + ((off + (g.two ? (1024 - off) / 2 : 16 * DDC_NKW)) >> 5)]);
             float u[4];
-            if (g.two && kb < nact) {
-                const float4 cb = *reinterpret_cast<const float4 *>(cum + (size_t)g.gb * 16 + 4 * q);
+            if (g.two) {
+                const float4 cb = *reinterpret_cast<const float4 *>(lcum + g.gb * 16 + 4 * q);
                 const float cbv[4] = {cb.x, cb.y, cb.z, cb.w};
                 float2 P1 = cmulf(ctab[chunk_rel + 2], dtab[g.e0 - 1024 + 2048]);
                 if (corr) P1 = cmulf(P1, corr[(chunk_rel + 2) * 32 + (((off + 32 * DDC_NKW - 1024) / 2) >> 5)]);
@@ -364,13 +391,19 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
                 part.z = P0.x * u[2] - P0.y * u[3]; part.w = P0.x * u[3] + P0.y * u[2];
             }
         }
+        }
+#endif
         float4 *rbuf = red + (it & 1) * 256;
         rbuf[w * 64 + lane] = part;
         // ---- the next tile's window must have landed before anyone passes the barrier; the ring space behind it is refilled right after
         const long long ws_n = ws + tstride;
+#if DDC_DIAG != 2
         if (it + 1 < n_it) wait_for(ws_n);
+#endif
         __syncthreads();
+#if DDC_DIAG != 2
         if (it + 1 < n_it) { while (F < F_end && F + 1024 <= ws_n + RB) row_step(); }
+#endif
         // ---- reduction of the four K-range shares and store: the waves take turns
         if (w == (it & 3)) {
             const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
@@ -606,7 +639,7 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
             if (n_seg < 1) n_seg = 1;
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
-            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + 2 * 4 * 64 * sizeof(float4);
+            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + 2 * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float);
             static bool done = false;
             if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
             if (e0) CSDR_HIP(hipEventRecord(e0, st));
