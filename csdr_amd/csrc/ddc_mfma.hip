@@ -240,27 +240,30 @@ struct DdcParams {
     float scale;
 };
 
-// One workgroup = 16 streams x the tiles [t0, t1) of its segment, walked in time order.
-//   LDS: 16 ring buffers of RB bytes (pitch RB + 16: the 16 streams of a B-fragment read hit different banks) + the reduction buffer.
-//   DMA: a "row-step" fetches the next 1 KiB of all 16 streams (wave w: streams 4w .. 4w+3, one instruction each).
-template <int RBL>
-__global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
-                                                  const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
-                                                  const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p)
+// One workgroup = 16 streams x the tiles [t0, t1) of its segment, walked in time order, NT tiles at a time: the workgroup has NT teams of
+// 4 waves; team j computes tile NT*g + j of group g (wave w of a team: K-range w), all teams read the same input ring.  NT = 2 puts two waves
+// on every SIMD, so that one tile's LDS reads / epilogue overlap the other tile's matrix products (the per-tile chain is serial inside a wave).
+//   LDS: 16 ring buffers of RB bytes (pitch RB + 16: the 16 streams of a B-fragment read hit different banks) + reduction buffer + prefix table.
+//   DMA: a "row-step" fetches the next 1 KiB of all 16 streams (16 / (4 NT) instructions per wave).
+template <int RBL, int NT>
+__global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
+                                                       const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
+                                                       const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p)
 {
-    constexpr int RB = 1 << RBL, RP = RB + 16;
+    constexpr int RB = 1 << RBL, RP = RB + 16, SPW = 16 / (4 * NT);                   // SPW: streams fetched per wave in a row-step
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
-    float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][4 waves][64 lanes]
-    float *lcum = reinterpret_cast<float *>(red + 512);                               // the prefix-sum table: a vector load from global memory inside the tile
+    float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][4 waves][64 lanes]
+    float *lcum = reinterpret_cast<float *>(red + 2 * NT * 256);                      // the prefix-sum table: a vector load from global memory inside the tile
                                                                                       // loop would need vmcnt(0), i.e. drain the whole DMA ring
-    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
-    for (int i = tid; i < DDC_NGRAN * 16; i += 256) lcum[i] = cum[i];                 // (visible after the barrier that ends the prologue)
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    const int team = wv >> 2, w = wv & 3;
+    for (int i = tid; i < DDC_NGRAN * 16; i += 256 * NT) lcum[i] = cum[i];            // (visible after the barrier that ends the prologue)
     const int sb = blockIdx.x;
     const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
     if (t0 >= t1) return;
-    const int n_it = (int)(t1 - t0);
+    const int n_it = (int)(t1 - t0), n_grp = (n_it + NT - 1) / NT;
     const int last_stream = p.n_streams - 1;
     // ---- weights of this wave's K-range: once per workgroup
     v4i A[DDC_NKW * 3];
@@ -282,23 +285,23 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
     }
     // ---- DMA state
     const int tstride = 16 * p.D;                                                    // bytes of input per tile
-    long long ws = t0 * tstride - 2 * p.B;                                           // window start of the current tile, bytes from the block start
-    const long long F0 = ws & ~1023LL;
+    long long wg = t0 * tstride - 2 * p.B;                                           // window start of the current GROUP's first tile, bytes from the block start
+    const long long F0 = wg & ~1023LL;
     const long long F_end = ((t1 - 1) * tstride - 2 * p.B + DDC_WIN + 1023) & ~1023LL;
     long long F = F0;                                                                // next row-step
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
-    uint32_t voff[4];
+    uint32_t voff[SPW];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int srow = min(sb * 16 + 4 * w + r, last_stream) - sb * 16;            // rows past the last stream re-read it (results discarded)
+    for (int r = 0; r < SPW; r++) {
+        const int srow = min(sb * 16 + SPW * wv + r, last_stream) - sb * 16;         // rows past the last stream re-read it (results discarded)
         voff[r] = (uint32_t)max(srow, 0) * (uint32_t)in_pitch + 16u * lane;
     }
     const uint8_t *sblock = in + (long long)sb * 16 * (long long)in_pitch;
     auto row_step = [&]() {
         const uint8_t *sbase = sblock + F;
-        const uint32_t ldst = lds_in_addr + (4 * w) * RP + (uint32_t)(F & (RB - 1));
+        const uint32_t ldst = lds_in_addr + (SPW * wv) * RP + (uint32_t)(F & (RB - 1));
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < SPW; r++) {
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
             uint32_t keep;
             // nt: the input is read exactly once.  Inline asm with hand-counted vmcnt (see wfm_mfma.hip: the builtin form makes the
@@ -308,63 +311,65 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
         }
         F += 1024;
     };
-    // every wave issues exactly 4 VMEM loads per row-step and they return in order: vmcnt(4 n) leaves at most the n newest row-steps in flight
+    // every wave issues exactly SPW VMEM loads per row-step and they return in order: vmcnt(SPW n) leaves at most the n newest row-steps in flight
     auto wait_newer = [&](long long newer) {
         switch ((int)newer) {
             case 0: wait_vmcnt<0>(); break;
-            case 1: wait_vmcnt<4>(); break;
-            case 2: wait_vmcnt<8>(); break;
-            case 3: wait_vmcnt<12>(); break;
-            case 4: wait_vmcnt<16>(); break;
-            case 5: wait_vmcnt<20>(); break;
-            case 6: wait_vmcnt<24>(); break;
-            default: wait_vmcnt<28>(); break;
+            case 1: wait_vmcnt<SPW>(); break;
+            case 2: wait_vmcnt<SPW * 2>(); break;
+            case 3: wait_vmcnt<SPW * 3>(); break;
+            case 4: wait_vmcnt<SPW * 4>(); break;
+            case 5: wait_vmcnt<SPW * 5>(); break;
+            case 6: wait_vmcnt<SPW * 6>(); break;
+            default: wait_vmcnt<SPW * 7>(); break;
         }
     };
-    auto wait_for = [&](long long wstart) {                                          // everything below wstart + DDC_WIN has landed
-        const long long need_end = (wstart + DDC_WIN + 1023) & ~1023LL;
-        long long newer = (F - need_end) >> 10;                                      // row-steps issued beyond what this tile needs
+    auto wait_for = [&](long long last_window_start) {                               // everything below last_window_start + DDC_WIN has landed
+        const long long need_end = (last_window_start + DDC_WIN + 1023) & ~1023LL;
+        long long newer = (F - need_end) >> 10;                                      // row-steps issued beyond what the group needs
         if (newer < 0) newer = 0;
         if (newer > 7) newer = 7;
         wait_newer(newer);
     };
-    while (F < F_end && F + 1024 <= ws + RB) row_step();
-    wait_for(ws);
+    while (F < F_end && F + 1024 <= wg + RB) row_step();
+    wait_for(wg + (long long)(NT - 1) * tstride);
     __syncthreads();
     const uint8_t *lrow = lds_in + col * RP;
-    long long ti = t0;
-    for (int it = 0; it < n_it; it++, ti++, ws += tstride) {
-        const long long n0 = p.B + (ws >> 1);                                        // global index of the tile's first sample
-        const WaveGeom g = ddc_wave_geom(n0, w);
-        const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
-        const long long chunk_rel = g.chunk - (p.B >> 10);
+    for (int gi = 0; gi < n_grp; gi++, wg += (long long)NT * tstride) {
+        const int it = gi * NT + team;                                               // this team's tile of the group
+        const bool active = it < n_it;
+        const long long ti = t0 + it;
+        const long long ws = wg + (long long)team * tstride;                         // window start of this team's tile
 #if DDC_DIAG == 1
         float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
 #else
-        // ---- B fragments of this wave's K-range from the ring
-        const int base = (int)(ws & (RB - 1)) + 64 * DDC_NKW * w + 16 * q;
         float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nact > 0) {                                                              // (loop invariant: waves beyond a short window have nothing to add)
-        v4i Bf[DDC_NKW];
+        if (active && nact > 0) {                                                    // (nact is loop invariant: waves beyond a short window have nothing to add)
+            const long long n0 = p.B + (ws >> 1);                                    // global index of the tile's first sample
+            const WaveGeom g = ddc_wave_geom(n0, w);
+            const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
+            const long long chunk_rel = g.chunk - (p.B >> 10);
+            // ---- B fragments of this wave's K-range from the ring
+            const int base = (int)(ws & (RB - 1)) + 64 * DDC_NKW * w + 16 * q;
+            v4i Bf[DDC_NKW];
 #pragma unroll
-        for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
-        // ---- one accumulator chain per digit; snapshot at the chunk boundary
-        v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        const bool lo_lane = half && q < 2;
-        switch (kb) {
-            case 0: ddc_chain<0>(A, Bf, lo_lane, acc, snap); break;
-            case 1: ddc_chain<1>(A, Bf, lo_lane, acc, snap); break;
-            case 2: ddc_chain<2>(A, Bf, lo_lane, acc, snap); break;
-            case 3: ddc_chain<3>(A, Bf, lo_lane, acc, snap); break;
-            case 4: ddc_chain<4>(A, Bf, lo_lane, acc, snap); break;
-            case 5: ddc_chain<5>(A, Bf, lo_lane, acc, snap); break;
-            case 6: ddc_chain<6>(A, Bf, lo_lane, acc, snap); break;
-            case 7: ddc_chain<7>(A, Bf, lo_lane, acc, snap); break;
-            case 8: ddc_chain<8>(A, Bf, lo_lane, acc, snap); break;
-            default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
-        }
-        // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
-        {
+            for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
+            // ---- one accumulator chain per digit; snapshot at the chunk boundary
+            v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const bool lo_lane = half && q < 2;
+            switch (kb) {
+                case 0: ddc_chain<0>(A, Bf, lo_lane, acc, snap); break;
+                case 1: ddc_chain<1>(A, Bf, lo_lane, acc, snap); break;
+                case 2: ddc_chain<2>(A, Bf, lo_lane, acc, snap); break;
+                case 3: ddc_chain<3>(A, Bf, lo_lane, acc, snap); break;
+                case 4: ddc_chain<4>(A, Bf, lo_lane, acc, snap); break;
+                case 5: ddc_chain<5>(A, Bf, lo_lane, acc, snap); break;
+                case 6: ddc_chain<6>(A, Bf, lo_lane, acc, snap); break;
+                case 7: ddc_chain<7>(A, Bf, lo_lane, acc, snap); break;
+                case 8: ddc_chain<8>(A, Bf, lo_lane, acc, snap); break;
+                default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
+            }
+            // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
             float2 P0 = cmulf(ctab[chunk_rel + 1], dtab[g.e0 + 2048]);
             // optional per-chunk correction (rates for which the reference's float recurrence drifts away from C_m D^k): sampled at the
             // centre of the K-range's part in each chunk
@@ -391,21 +396,20 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
                 part.z = P0.x * u[2] - P0.y * u[3]; part.w = P0.x * u[3] + P0.y * u[2];
             }
         }
-        }
 #endif
-        float4 *rbuf = red + (it & 1) * 256;
+        float4 *rbuf = red + ((gi & 1) * NT + team) * 256;
         rbuf[w * 64 + lane] = part;
-        // ---- the next tile's window must have landed before anyone passes the barrier; the ring space behind it is refilled right after
-        const long long ws_n = ws + tstride;
+        // ---- the next group's windows must have landed before anyone passes the barrier; the ring space behind them is refilled right after
+        const long long wg_n = wg + (long long)NT * tstride;
 #if DDC_DIAG != 2
-        if (it + 1 < n_it) wait_for(ws_n);
+        if (gi + 1 < n_grp) wait_for(wg_n + (long long)(NT - 1) * tstride);
 #endif
         __syncthreads();
 #if DDC_DIAG != 2
-        if (it + 1 < n_it) { while (F < F_end && F + 1024 <= ws_n + RB) row_step(); }
+        if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + RB) row_step(); }
 #endif
-        // ---- reduction of the four K-range shares and store: the waves take turns
-        if (w == (it & 3)) {
+        // ---- reduction of the four K-range shares and store: the waves of a team take turns
+        if (active && w == (gi & 3)) {
             const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
             const int stream = sb * 16 + col;
             if (stream < p.n_streams) {
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256) void k_ddc_mfma(const uint8_t *__restrict__ in
     }
 }
 
-// Plain evaluation of the same model, one thread per output: outputs [ka0, ka0 + na) and [kb0, kb0 + nb) of every stream.
+// Plain evaluation of the same model, one WAVE per output (lanes split the taps): outputs [ka0, ka0 + na) and [kb0, kb0 + nb) of every stream.
 // Samples before the block come from the history buffer (the previous blocks' last DDC_HIST samples).
 struct DirectParams { int n_streams; long long B; int T, D, L; long long k_out0, ka0, kb0; int na, nb; };
 
@@ -425,17 +429,16 @@ __global__ __launch_bounds__(256) void k_ddc_direct(const uint8_t *__restrict__ 
                                                     const float *__restrict__ taps, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
                                                     const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DirectParams p)
 {
-    const int s = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y, lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= p.na + p.nb) return;
     const long long k = idx < p.na ? p.ka0 + idx : p.kb0 + (idx - p.na);
     const uint8_t *row = in + (size_t)s * in_pitch;
     const uint8_t *hrow = hist + (size_t)s * (2 * DDC_HIST);
     const long long c0 = p.B >> 10;
     float ai = 0.f, aq = 0.f;
-    long long n = (long long)p.D * k;
-    for (int t = 0; t < p.L; t++, n++) {
-        const long long rel = n - p.B;
+    for (int t = lane; t < p.L; t += 64) {
+        const long long n = (long long)p.D * k + t, rel = n - p.B;
         uint32_t vi, vq;
         if (rel < 0) { vi = hrow[2 * (rel + DDC_HIST)]; vq = hrow[2 * (rel + DDC_HIST) + 1]; }
         else { vi = row[2 * rel]; vq = row[2 * rel + 1]; }
@@ -446,7 +449,9 @@ __global__ __launch_bounds__(256) void k_ddc_direct(const uint8_t *__restrict__ 
         ai = fmaf(h, xi * R.x - xq * R.y, ai);
         aq = fmaf(h, xq * R.x + xi * R.y, aq);
     }
-    out[(size_t)s * out_pitch + (k - p.k_out0)] = make_float2(ai, aq);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ai += __shfl_xor(ai, o, 64); aq += __shfl_xor(aq, o, 64); }
+    if (lane == 0) out[(size_t)s * out_pitch + (k - p.k_out0)] = make_float2(ai, aq);
 }
 
 // new_hist = last DDC_HIST samples of (old_hist ++ block)
@@ -632,19 +637,31 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
             DdcParams p;
             p.n_streams = d->n_streams; p.B = d->B; p.tile_first = ta; p.n_tiles = (int)(tb - ta + 1); p.k_out0 = k_first; p.D = d->D; p.nk_used = d->nk_used; p.scale = d->scale;
             const int n_wsb = (d->n_streams + 15) / 16;
-            // 8 KiB ring per stream (window 2304 B + the next tile's bytes + 1-KiB fetch granularity on both sides need > 4 KiB), one workgroup per CU
+            // 8 KiB ring per stream (window 2304 B + the next group's bytes + 1-KiB fetch granularity on both sides need > 4 KiB), one workgroup per CU.
+            // Two teams (512 threads, two waves per SIMD) when the ring also holds a second tile per group: 3 * 16 D <= 3842.
             constexpr int rbl = 13;
+            static int teams_env = -1;
+            if (teams_env < 0) { const char *e = getenv("CSDR_AMD_DDC_TEAMS"); teams_env = e ? atoi(e) : 2; if (teams_env != 1) teams_env = 2; }
+            const int nt = (teams_env == 2 && 3 * 16 * d->D <= 3842) ? 2 : 1;
             int n_seg = (n_cu + n_wsb - 1) / n_wsb; if (n_seg < 1) n_seg = 1;
             if (n_seg > p.n_tiles / 16) n_seg = p.n_tiles / 16;
             if (n_seg < 1) n_seg = 1;
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
-            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + 2 * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float);
-            static bool done = false;
-            if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float);
+            static bool done[2] = {false, false};
+            if (!done[nt - 1]) {
+                if (nt == 2) CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                else CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                done[nt - 1] = true;
+            }
             if (e0) CSDR_HIP(hipEventRecord(e0, st));
-            hipLaunchKernelGGL((k_ddc_mfma<rbl>), dim3(n_wsb, n_seg), dim3(256), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,
-                               reinterpret_cast<float2 *>(out), out_pitch, p);
+            if (nt == 2)
+                hipLaunchKernelGGL((k_ddc_mfma<rbl, 2>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,
+                                   reinterpret_cast<float2 *>(out), out_pitch, p);
+            else
+                hipLaunchKernelGGL((k_ddc_mfma<rbl, 1>), dim3(n_wsb, n_seg), dim3(256), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,
+                                   reinterpret_cast<float2 *>(out), out_pitch, p);
             CSDR_LAUNCH_CHECK();
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
             d->kernel_name = "k_ddc_mfma";
@@ -656,7 +673,7 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
         else { q.ka0 = k_first; q.na = (int)n_out; q.kb0 = 0; q.nb = 0; }
         if (q.na + q.nb > 0) {
             if (tb < ta && e0) CSDR_HIP(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(k_ddc_direct, dim3(cdiv(q.na + q.nb, 256), d->n_streams), dim3(256), 0, st, in, in_pitch, d->d_hist[d->hflip], d->d_taps, d->d_dtab, d->d_ctab, d->d_corr,
+            hipLaunchKernelGGL(k_ddc_direct, dim3(cdiv(q.na + q.nb, 4), d->n_streams), dim3(256), 0, st, in, in_pitch, d->d_hist[d->hflip], d->d_taps, d->d_dtab, d->d_ctab, d->d_corr,
                                reinterpret_cast<float2 *>(out), out_pitch, q);
             CSDR_LAUNCH_CHECK();
             if (tb < ta && e1) CSDR_HIP(hipEventRecord(e1, st));
