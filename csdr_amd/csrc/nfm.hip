@@ -5,19 +5,30 @@
 //   front end (2.4 MS/s -> 48 kS/s): csdr_amd_ddc (ddc_mfma.hip), one pass over the input on the matrix cores;
 //   back end  (48 kS/s, 1/50 of the input rate): k_nfm_demod_limit (fmdemod_quadri_cf libcsdr.c:1040-1071 + limit_ff :1130-1137 in one
 //   pass, appended behind the de-emphasis filter's unconsumed input), the fixed de-emphasis FIR (libcsdr.c:1101-1128, the CLI's re-feed
-//   loop csdr.c:1083), fastagc_ff (libcsdr.c:946-991) over whole blocks and convert_f_s16 (:2397) -- the device-batch operators of this
-//   library.  The de-emphasis filter is run for whole AGC blocks only (its remaining input waits in the carry buffer), so nothing else
-//   needs a carry.
+//   loop csdr.c:1083), fastagc_ff (libcsdr.c:946-991) over whole blocks and convert_f_s16 (:2397).  The de-emphasis filter is run for whole
+//   AGC blocks only (its remaining input waits in the carry buffer), so nothing else needs a carry.
+//
+//   The 201-tap de-emphasis FIR was 80 % of the back end as a float VALU kernel (0.53 ms of 0.66 ms for 512 channels x 1 s: 18 TFLOP/s).  Its
+//   input is the LIMITED demodulator output, |x| <= max_amplitude, so 24-bit fixed point represents it to 6e-8 of full scale: the demodulator
+//   kernel writes three int8 digit planes instead of floats, and the FIR becomes a banded int8 product on v_mfma_i32_16x16x64_i8 (16 consecutive
+//   outputs x 16 channels x 256 inputs per tile, band 93 % dense, one resident weight set): k_nfm_deemph_mfma.  Digit pairs of equal weight
+//   share an accumulator; only the (low x low) pair is dropped (2^-31 of full scale).
 #include "common.hpp"
 #include <math.h>
 #include <string.h>
 #include <string>
+#include <vector>
 using namespace csdr_amd;
 
 namespace {
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr float NFM_XQ = 8355711.0f;       // 127*65536 + 127*256 + 127: full scale of three balanced base-256 digits
+constexpr int NFM_FIR_NK = 4;              // 64-input K-steps per tile of 16 outputs: taps <= 241
+
+// planes: [3][n_streams][dl_pitch] int8 -- digit j of round(v / max_amp * NFM_XQ) = d0 * 65536 + d1 * 256 + d2
 __global__ __launch_bounds__(256) void k_nfm_demod_limit(const cf32 *__restrict__ y, size_t y_pitch, int n, const cf32 *__restrict__ last,
-                                                         float *__restrict__ dl, size_t dl_pitch, int dl_fill, float max_amp)
+                                                         int8_t *__restrict__ planes, size_t plane_bytes, size_t dl_pitch, int dl_fill, float max_amp, float q_per_amp)
 {
     const float Kf = 0.340447550238101026565118445432744920253753662109375f;   // libcsdr.c:1021
     const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
@@ -31,25 +42,74 @@ __global__ __launch_bounds__(256) void k_nfm_demod_limit(const cf32 *__restrict_
     rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
     float v = (den != 0.f) ? (Kf * num) * rd : 0.f;
     v = (max_amp < v) ? max_amp : v; v = (-max_amp > v) ? -max_amp : v;        // limit_ff libcsdr.c:1133-1136
-    dl[(size_t)s * dl_pitch + dl_fill + k] = v;
+    int qv = __float2int_rn(v * q_per_amp);                                    // |qv| <= NFM_XQ
+    const int d2 = ((qv + 128) & 255) - 128; qv = (qv - d2) >> 8;
+    const int d1 = ((qv + 128) & 255) - 128; qv = (qv - d1) >> 8;
+    int8_t *dst = planes + (size_t)s * dl_pitch + dl_fill + k;
+    dst[0] = (int8_t)qv; dst[plane_bytes] = (int8_t)d1; dst[2 * plane_bytes] = (int8_t)d2;
+}
+
+// out[s][i] = sum_t taps[t] x[s][i + t] for i < n_tiles * 16, x given as digit planes.  One wave = 16 channels x a strided set of tiles; the 12
+// weight fragments (4 K-steps x 3 digits of the Toeplitz band) stay in registers; B operands are 16 consecutive digit bytes of a channel,
+// loaded straight from the planes (consecutive tiles overlap by 240 of 256 inputs: L1 / L2 traffic, the planes are 3 bytes per sample in HBM).
+// MFMA result layout: lane (col, q) holds outputs 4q .. 4q+3 of channel col.
+__global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restrict__ planes, size_t plane_bytes, size_t dl_pitch, const v4i *__restrict__ frags,
+                                                         float scale, float *__restrict__ out, size_t out_pitch, int n_tiles, int n_streams)
+{
+    const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = gridDim.x * 4;
+    v4i A[NFM_FIR_NK * 3];
+#pragma unroll
+    for (int i = 0; i < NFM_FIR_NK * 3; i++) A[i] = frags[i * 64 + lane];
+    const int stream = min((int)blockIdx.y * 16 + col, n_streams - 1);
+    const int8_t *row = planes + (size_t)stream * dl_pitch + 16 * q;
+    for (int tile = wv; tile < n_tiles; tile += n_wv) {
+        const int8_t *src = row + 16 * tile;
+        v4i acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (int ks = 0; ks < NFM_FIR_NK; ks++) {
+            const v4i x0 = *reinterpret_cast<const v4i *>(src + 64 * ks), x1 = *reinterpret_cast<const v4i *>(src + 64 * ks + plane_bytes),
+                      x2 = *reinterpret_cast<const v4i *>(src + 64 * ks + 2 * plane_bytes);
+            const v4i w0 = A[ks * 3], w1 = A[ks * 3 + 1], w2 = A[ks * 3 + 2];
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x0, acc[0], 0, 0, 0);          // 2^32
+            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x1, acc[1], 0, 0, 0);          // 2^24
+            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x0, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x2, acc[2], 0, 0, 0);          // 2^16
+            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x1, acc[2], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, x0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x2, acc[3], 0, 0, 0);          // 2^8
+            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, x1, acc[3], 0, 0, 0);
+        }
+        float4 r;
+        float *rv = reinterpret_cast<float *>(&r);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float t = fmaf((float)acc[0][j], 256.0f, (float)acc[1][j]);
+            t = fmaf(t, 256.0f, (float)acc[2][j]);
+            t = fmaf(t, 256.0f, (float)acc[3][j]);
+            rv[j] = t * scale;
+        }
+        if ((int)blockIdx.y * 16 + col < n_streams)
+            *reinterpret_cast<float4 *>(out + (size_t)stream * out_pitch + 16 * tile + 4 * q) = r;
+    }
+}
+
+// bytes: buf[s][0 .. count) = buf[s][src_off .. src_off + count) on each of the three planes (ranges may overlap; count <= 2048)
+__global__ __launch_bounds__(256) void k_nfm_move_front_planes(int8_t *__restrict__ planes, size_t plane_bytes, size_t pitch, int src_off, int count)
+{
+    int8_t *row = planes + (size_t)blockIdx.y * plane_bytes + (size_t)blockIdx.x * pitch;
+    int8_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int i = threadIdx.x + 256 * j; v[j] = i < count ? row[src_off + i] : (int8_t)0; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int i = threadIdx.x + 256 * j; if (i < count) row[i] = v[j]; }
 }
 
 __global__ void k_nfm_store_last(const cf32 *__restrict__ y, size_t y_pitch, int n, cf32 *__restrict__ last, int n_streams)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n_streams) last[s] = y[(size_t)s * y_pitch + n - 1];
-}
-
-// buf[s][0 .. count) = buf[s][src_off .. src_off + count)   (ranges may overlap: staged through registers; count <= 256 * 8)
-__global__ __launch_bounds__(256) void k_nfm_move_front(float *__restrict__ buf, size_t pitch, int src_off, int count)
-{
-    float *row = buf + (size_t)blockIdx.x * pitch;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const int i = threadIdx.x + 256 * j; v[j] = i < count ? row[src_off + i] : 0.f; }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; j++) { const int i = threadIdx.x + 256 * j; if (i < count) row[i] = v[j]; }
 }
 
 // convert_f_s16 (libcsdr.c:2397: (short)(int)(x*32767), x86 truncation semantics) of the AGC output into the caller's buffers
@@ -72,9 +132,10 @@ struct csdr_amd_nfm {
     float limit, agc_ref;
     csdr_amd_ddc *ddc;
     cf32 *d_y; size_t y_pitch; cf32 *d_last;
-    float *d_dl; size_t dl_pitch; int dl_fill;      // limited demodulator output waiting for the de-emphasis filter
+    int8_t *d_planes; size_t plane_bytes; size_t dl_pitch; int dl_fill;   // limited demodulator output (three digit planes) waiting for the de-emphasis filter
+    void *d_fir_frags; float fir_scale;             // de-emphasis taps as int8 digit fragments; scale of the recombined product
     float *d_de, *d_agc; size_t a_pitch;            // de-emphasised blocks, AGC output
-    float *d_dtaps, *d_agc_state;
+    float *d_agc_state;
     size_t max_y;
 };
 
@@ -83,10 +144,11 @@ extern "C" {
 csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
                                   int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples)
 {
-    if (!ctx || n_streams < 1 || agc_block < 1 || agc_block > 2048 - 512) { fail_msg(-3, "nfm_create: bad arguments (agc_block 1..1536)"); return nullptr; }
+    if (!ctx || n_streams < 1 || agc_block < 1 || agc_block > 2048 - 512 || (agc_block % 16) || !(limit_max > 0)) { fail_msg(-3, "nfm_create: bad arguments (agc_block: multiple of 16 up to 1536; limit > 0)"); return nullptr; }
     const float *dt = nullptr;
     const int Ld = csdr_amd_nfm_deemph_taps(audio_rate, &dt);
     if (!Ld) { fail_msg(-3, "nfm_create: no de-emphasis table for sample rate %d (libcsdr.c:1115-1119)", audio_rate); return nullptr; }
+    if (Ld + 15 > 64 * NFM_FIR_NK) { fail_msg(-3, "nfm_create: %d de-emphasis taps exceed the matrix-core tile", Ld); return nullptr; }
     if (max_block_samples < 1024) max_block_samples = 1024;
     csdr_amd_nfm *w = new csdr_amd_nfm();
     memset(w, 0, sizeof(*w));
@@ -95,18 +157,36 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (!w->ddc) { delete w; return nullptr; }
     w->max_y = max_block_samples / decimation + 2;
     w->y_pitch = (w->max_y + 15) & ~(size_t)15;
-    w->dl_pitch = (w->max_y + Ld + agc_block + 15) & ~(size_t)15;
+    w->dl_pitch = (w->max_y + Ld + agc_block + 64 * NFM_FIR_NK + 63) & ~(size_t)63;   // + the last tile's window beyond the valid samples (zero weights)
     w->a_pitch = (w->max_y + Ld + agc_block + 15) & ~(size_t)15;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&w->d_y, sizeof(cf32) * w->y_pitch * n_streams);
     alloc((void **)&w->d_last, sizeof(cf32) * n_streams);
-    alloc((void **)&w->d_dl, sizeof(float) * w->dl_pitch * n_streams);
+    w->plane_bytes = w->dl_pitch * n_streams;
+    alloc((void **)&w->d_planes, 3 * w->plane_bytes);
+    alloc(&w->d_fir_frags, (size_t)NFM_FIR_NK * 3 * 64 * 16);
     alloc((void **)&w->d_de, sizeof(float) * w->a_pitch * n_streams);
     alloc((void **)&w->d_agc, sizeof(float) * w->a_pitch * n_streams);
-    alloc((void **)&w->d_dtaps, sizeof(float) * Ld);
     alloc((void **)&w->d_agc_state, sizeof(float) * (size_t)n_streams * (2 * agc_block + 4));
-    if (e == hipSuccess) e = hipMemcpy(w->d_dtaps, dt, sizeof(float) * Ld, hipMemcpyHostToDevice);
+    {   // Toeplitz band of the de-emphasis taps as three base-256 digits: row o (output), column t (input): taps[t - o]
+        std::vector<int8_t> fr((size_t)NFM_FIR_NK * 3 * 64 * 16, 0);
+        double gmax = 0;
+        for (int k = 0; k < Ld; k++) gmax = fmax(gmax, fabs((double)dt[k]));
+        gmax *= 1.0001; if (gmax == 0) gmax = 1;
+        const double qscale = 4194304.0 / gmax;
+        for (int o = 0; o < 16; o++) for (int tp = 0; tp < Ld; tp++) {
+            const int t = o + tp, ks = t / 64, b = t % 64;
+            long qv = lrint((double)dt[tp] * qscale);
+            const int w2 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w2) / 256;
+            const int w1 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w1) / 256;
+            const int dig[3] = {(int)qv, w1, w2};
+            for (int l = 0; l < 3; l++) fr[((size_t)(ks * 3 + l) * 64 + (16 * (b / 16) + o)) * 16 + b % 16] = (int8_t)dig[l];
+        }
+        // value = (a0 2^24 + a1 2^16 + a2 2^8 + a3) * 2^8 * (gmax / 2^22) * (max_amp / NFM_XQ)
+        w->fir_scale = (float)(256.0 * (gmax / 4194304.0) * ((double)limit_max / (double)NFM_XQ));
+        if (e == hipSuccess) e = hipMemcpy(w->d_fir_frags, fr.data(), fr.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { fail(e, "hipMalloc/hipMemcpy(nfm state)", __FILE__, __LINE__); csdr_amd_nfm_destroy(w); return nullptr; }
     if (csdr_amd_nfm_reset(w)) { csdr_amd_nfm_destroy(w); return nullptr; }
     return w;
@@ -117,8 +197,8 @@ void csdr_amd_nfm_destroy(csdr_amd_nfm *w)
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     if (w->ddc) csdr_amd_ddc_destroy(w->ddc);
-    (void)hipFree(w->d_y); (void)hipFree(w->d_last); (void)hipFree(w->d_dl); (void)hipFree(w->d_de); (void)hipFree(w->d_agc);
-    (void)hipFree(w->d_dtaps); (void)hipFree(w->d_agc_state);
+    (void)hipFree(w->d_y); (void)hipFree(w->d_last); (void)hipFree(w->d_planes); (void)hipFree(w->d_fir_frags); (void)hipFree(w->d_de); (void)hipFree(w->d_agc);
+    (void)hipFree(w->d_agc_state);
     delete w;
 }
 
@@ -126,6 +206,7 @@ int csdr_amd_nfm_reset(csdr_amd_nfm *w)
 {
     hipStream_t st = w->ctx->stream;
     w->dl_fill = 0;
+    CSDR_HIP(hipMemsetAsync(w->d_planes, 0, 3 * w->plane_bytes, st));                                          // bytes behind the valid samples meet zero weights, but must be initialised
     CSDR_HIP(hipMemsetAsync(w->d_last, 0, sizeof(cf32) * w->n_streams, st));                                   // the CLI starts fmdemod from (0, 0) (csdr.c:1044)
     CSDR_HIP(hipMemsetAsync(w->d_agc_state, 0, sizeof(float) * (size_t)w->n_streams * (2 * w->agc_block + 4), st));   // calloc'ed fastagc state (csdr.c:1393-1394)
     return csdr_amd_ddc_reset(w->ddc);
@@ -142,7 +223,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
     if (n_y == 0) return 0;
     if ((size_t)n_y > w->max_y) return fail_msg(-3, "nfm: front end produced more than the planned %zu samples", w->max_y);
     // fmdemod_quadri_cf | limit_ff, appended behind the filter's unconsumed input
-    hipLaunchKernelGGL(k_nfm_demod_limit, dim3(cdiv(n_y, 256), S), dim3(256), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, w->d_dl, w->dl_pitch, w->dl_fill, w->limit);
+    hipLaunchKernelGGL(k_nfm_demod_limit, dim3(cdiv(n_y, 256), S), dim3(256), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, w->d_planes, w->plane_bytes, w->dl_pitch, w->dl_fill, w->limit, NFM_XQ / w->limit);
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_nfm_store_last, dim3(cdiv(S, 64)), dim3(64), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, S);
     CSDR_LAUNCH_CHECK();
@@ -153,8 +234,13 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
     const int ne = nb * w->agc_block;
     if (nb > 0) {
         if ((size_t)ne > out_pitch && S > 1) return fail_msg(-3, "nfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, ne);
-        const int got = csdr_amd_fir_ff(c, w->d_dl, w->d_de, S, ne + w->Ld, w->dl_pitch, w->a_pitch, w->d_dtaps, w->Ld);
-        if (got != ne) return got < 0 ? got : fail_msg(-3, "nfm: de-emphasis filter produced %d of %d samples", got, ne);
+        {
+            const int n_tiles = ne / 16, n_sb = (S + 15) / 16;
+            int gx = (n_tiles + 3) / 4; const int want = (256 * 8 + n_sb - 1) / n_sb; if (gx > want) gx = want; if (gx < 1) gx = 1;
+            hipLaunchKernelGGL(k_nfm_deemph_mfma, dim3(gx, n_sb), dim3(256), 0, st, w->d_planes, w->plane_bytes, w->dl_pitch, (const v4i *)w->d_fir_frags, w->fir_scale,
+                               w->d_de, w->a_pitch, n_tiles, S);
+            CSDR_LAUNCH_CHECK();
+        }
         int rc = csdr_amd_fastagc_ff(c, w->d_de, w->d_agc, S, nb, w->agc_block, w->a_pitch, w->a_pitch, w->agc_ref, w->d_agc_state);
         if (rc) return rc;
         hipLaunchKernelGGL(k_nfm_out, dim3(cdiv(ne, 256), S), dim3(256), 0, st, w->d_agc, w->a_pitch, ne, audio_s16, audio_f, out_pitch);
@@ -164,7 +250,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
     const int rem = n_in - ne;
     if (ne > 0 && rem > 0) {
         if (rem > 2048) return fail_msg(-3, "nfm: internal carry of %d samples", rem);
-        hipLaunchKernelGGL(k_nfm_move_front, dim3(S), dim3(256), 0, st, w->d_dl, w->dl_pitch, ne, rem);
+        hipLaunchKernelGGL(k_nfm_move_front_planes, dim3(S, 3), dim3(256), 0, st, w->d_planes, w->plane_bytes, w->dl_pitch, ne, rem);
         CSDR_LAUNCH_CHECK();
     }
     w->dl_fill = rem;
