@@ -135,6 +135,7 @@ def lib():
     L.csdr_amd_wfm_process.restype = C.c_long; L.csdr_amd_wfm_process.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.csdr_amd_wfm_kernel_name.restype = C.c_char_p; L.csdr_amd_wfm_kernel_name.argtypes = [vp]
     L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
+    L.csdr_amd_debug_wfm_select.restype = None; L.csdr_amd_debug_wfm_select.argtypes = [i]
     L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.csdr_amd_ddc_create.restype = vp; L.csdr_amd_ddc_create.argtypes = [vp, i, fl, i, vp, i, sz]
     L.csdr_amd_ddc_destroy.argtypes = [vp]

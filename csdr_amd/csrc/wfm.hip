@@ -247,7 +247,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
     (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     w->kernel_name = "k_wfm_front";
-    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_kb_of = nullptr;
+    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_kb_of = nullptr; w->mfma.d_seq_frags = nullptr; w->mfma.d_seq_cum = nullptr; w->mfma.d_dtab = nullptr;
     {
         const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons)
         const bool want_mfma = !(force && !strcmp(force, "valu"));
@@ -263,6 +263,13 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_frags, t.frags.data(), t.frags.size(), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_consts, t.consts.data(), t.consts.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_kb_of, t.kb_of.data(), t.kb_of.size() * sizeof(int), hipMemcpyHostToDevice);
+            w->mfma.seq_scale = t.seq_scale;
+            if (e2 == hipSuccess) e2 = hipMalloc(&w->mfma.d_seq_frags, t.seq_frags.size());
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_seq_cum, t.seq_cum.size() * sizeof(float));
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_dtab, t.dtab.size() * sizeof(float2));
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_seq_frags, t.seq_frags.data(), t.seq_frags.size(), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_seq_cum, t.seq_cum.data(), t.seq_cum.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_dtab, t.dtab.data(), t.dtab.size() * sizeof(float2), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) { fail(e2, "hipMalloc/hipMemcpy(wfm mfma table)", __FILE__, __LINE__); delete w; return nullptr; }
             w->use_mfma = true; w->kernel_name = "k_wfm_mfma";
         }
@@ -292,6 +299,9 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
     if (w->mfma.d_frags) (void)hipFree(w->mfma.d_frags);
     if (w->mfma.d_consts) (void)hipFree(w->mfma.d_consts);
     if (w->mfma.d_kb_of) (void)hipFree(w->mfma.d_kb_of);
+    if (w->mfma.d_seq_frags) (void)hipFree(w->mfma.d_seq_frags);
+    if (w->mfma.d_seq_cum) (void)hipFree(w->mfma.d_seq_cum);
+    if (w->mfma.d_dtab) (void)hipFree(w->mfma.d_dtab);
     if (w->d_ctab) (void)hipFree(w->d_ctab);
     if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
     if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);

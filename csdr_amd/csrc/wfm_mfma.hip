@@ -117,6 +117,44 @@ void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *ta
             }
         }
     }
+    // ---- phase-independent form (k_wfm_mfma_seq): R[n0 + t] = [C_m D^(n0 - 1024 m)] D^t, so the weights a h D^t are the same for every tile
+    {
+        t.dtab.resize(3072);
+        for (int i = 0; i < 3072; i++) { const std::complex<double> v = std::polar(pow(mag, i - 2048), ang * (i - 2048)); t.dtab[i] = make_float2((float)v.real(), (float)v.imag()); }
+        const double dmax = fmax(1.0, pow(mag, 32 * WFM_NK));
+        double g2 = 0;
+        for (int k = 0; k < L; k++) g2 = fmax(g2, fabs(a * (double)taps[k]));
+        g2 *= dmax * 1.0001; if (g2 == 0) g2 = 1;
+        const double qs = 4194304.0 / g2;
+        t.seq_scale = (float)(g2 / 4194304.0);
+        t.seq_frags.assign((size_t)WFM_NK * 3 * 64 * 16, 0);
+        const int ngr = 4 * WFM_NK;                                   // 16-byte granules of the window
+        std::vector<double> gsum((size_t)ngr * 16, 0.0);
+        for (int r = 0; r < 16; r++) {
+            const int q = r / 4, which = (r % 4) / 2, comp = r % 2;
+            const long off = (long)D * (F * q + 9 + which) - base_off_samples;
+            for (int tp = 0; tp < L; tp++) {
+                const long ts = off + tp;
+                const std::complex<double> G = a * (double)taps[tp] * std::polar(pow(mag, (double)ts), ang * (double)ts);
+                for (int c = 0; c < 2; c++) {
+                    const double val = comp == 0 ? (c == 0 ? G.real() : -G.imag()) : (c == 0 ? G.imag() : G.real());
+                    const long colb = 2 * ts + c;
+                    const int ks = (int)(colb / 64), b = (int)(colb % 64);
+                    long qv = lrint(val * qs);
+                    const int w2 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w2) / 256;
+                    const int w1 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w1) / 256;
+                    const int dig[3] = {(int)qv, w1, w2};
+                    for (int l = 0; l < 3; l++) t.seq_frags[((size_t)(ks * 3 + l) * 64 + (16 * (b / 16) + r)) * 16 + b % 16] = (int8_t)dig[l];
+                    gsum[(size_t)(colb / 16) * 16 + r] += val;
+                }
+            }
+        }
+        t.seq_cum.assign((size_t)(ngr + 1) * 16, 0.f);
+        for (int r = 0; r < 16; r++) {
+            double run = 0;
+            for (int g = 0; g <= ngr; g++) { t.seq_cum[(size_t)g * 16 + r] = (float)(0.5 * run); if (g < ngr) run += gsum[(size_t)g * 16 + r]; }
+        }
+    }
 }
 
 } // namespace csdr_amd
@@ -662,11 +700,203 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_oct(const uint8_t *__restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sequential variant (default): ONE phase-independent weight set, a workgroup walks through time.
+// shift_addition_cc's phasor inside a 1024-chunk is R[n] = C_m D^(n - 1024 m), so relative to a tile's window base n0
+// R[n0 + t] = [C_m D^(n0 - 1024 m)] D^t: the weights a h D^t are the same for every tile and the bracket is a complex scalar per (tile, chunk)
+// applied after the product (the same idea as ddc_mfma.hip).  Without phase-specific weights a wave no longer has to own a tile phase and
+// jump through the input in steps of 128 tiles: a workgroup owns 16 streams x a contiguous run of tiles, its 8 waves take 8 consecutive tiles
+// per step, and the input slides through a per-stream LDS ring filled by LDS-DMA in whole 1-KiB runs of lines -- every input byte is fetched
+// exactly once (quad kernel: 1.29 x, octet kernel: 1.08 x requested / useful bytes), in long sequential runs per stream.
+// A chunk boundary inside the 256-sample window is 16-byte granular here (window bases are multiples of 8 samples): the boundary K-step is
+// multiplied twice with complementary lane groups of the B operand zeroed, the accumulator chain is snapshotted in between.
+struct SeqParams {
+    int n_streams; long long B2; long long tile_first; int n_tiles, tiles_per_seg; long long tile_out0;
+    int stride, win_off; float scale;
+};
+
+template <int KB>
+__device__ __forceinline__ void wfm_chain(const v4i (&A)[WFM_NK * 3], const v4i (&Bf)[WFM_NK], bool lo_lane, v4i (&acc)[3], v4i (&snap)[3])
+{   // straight-line code per boundary position (see ddc_mfma.hip: run-time branches inside the unrolled chain cost hundreds of AGPR moves)
+    const v4i z = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < WFM_NK; ks++) {
+        if (ks == KB) {
+            const v4i lo = lo_lane ? Bf[ks] : z, hi = lo_lane ? z : Bf[ks];
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], lo, acc[l], 0, 0, 0);
+#pragma unroll
+            for (int l = 0; l < 3; l++) snap[l] = acc[l];
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], hi, acc[l], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc[l], 0, 0, 0);
+        }
+    }
+}
+
+constexpr int SEQ_RB = 9216;               // ring bytes per stream: 9 x 1 KiB (the 8-tile step's window 3312 B + the next step's 3200 B + fetch granularity)
+constexpr int SEQ_RP = SEQ_RB + 16;        // LDS pitch: odd multiple of 16 bytes
+constexpr int SEQ_NGR = 4 * WFM_NK;        // 16-byte granules per window
+
+template <int NT>
+__global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags, const float *__restrict__ cum,
+                                                           const float2 *__restrict__ dtab, const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, SeqParams p)
+{
+    constexpr int TPG = 4 * NT, SPW = 16 / (4 * NT);                                 // tiles per step; streams fetched per wave in a row-step
+    extern __shared__ float4 lds_raw[];
+    uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
+    float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 2 x 16 x OCT_OUTP floats
+    float *lcum = lds_out + 2 * 16 * OCT_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    for (int i = tid; i < (SEQ_NGR + 1) * 16; i += 256 * NT) lcum[i] = cum[i];
+    const int sb = blockIdx.x;
+    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
+    long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
+    if (t0 >= t1) return;
+    const int n_it = (int)(t1 - t0), n_grp = (n_it + TPG - 1) / TPG;
+    const int last_stream = p.n_streams - 1;
+    v4i A[WFM_NK * 3];
+#pragma unroll
+    for (int s = 0; s < WFM_NK * 3; s++) A[s] = frags[s * 64 + lane];
+    float c_lo[4], c_hi[4];                                                          // prefix values at the window's ends, rows 4q .. 4q+3
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(cum + 4 * q), b = *reinterpret_cast<const float4 *>(cum + (size_t)SEQ_NGR * 16 + 4 * q);
+        c_lo[0] = a.x; c_lo[1] = a.y; c_lo[2] = a.z; c_lo[3] = a.w; c_hi[0] = b.x; c_hi[1] = b.y; c_hi[2] = b.z; c_hi[3] = b.w;
+    }
+    const float K = 0.340447550238101026565118445432744920253753662109375f;
+    // ---- DMA ring
+    const int tstride = p.stride;
+    long long wg = t0 * tstride + p.win_off - p.B2;                                  // window start of the step's first tile, bytes from the block start
+    const long long F0 = wg & ~1023LL;
+    const long long F_end = ((t1 - 1) * tstride + p.win_off - p.B2 + 64 * WFM_NK + 1023) & ~1023LL;
+    long long F = F0;
+    int fslot = (int)(F0 % SEQ_RB), wslot = (int)(wg % SEQ_RB);                      // ring positions of F and of wg
+    const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
+    uint32_t voff[SPW];
+#pragma unroll
+    for (int r = 0; r < SPW; r++) {
+        const int srow = min(sb * 16 + SPW * wv + r, last_stream) - sb * 16;
+        voff[r] = (uint32_t)max(srow, 0) * (uint32_t)in_pitch + 16u * lane;
+    }
+    const uint8_t *sblock = in + (long long)sb * 16 * (long long)in_pitch;
+    auto row_step = [&]() {
+        const uint8_t *sbase = sblock + F;
+        const uint32_t ldst = lds_in_addr + (SPW * wv) * SEQ_RP + (uint32_t)fslot;
+#pragma unroll
+        for (int r = 0; r < SPW; r++) {
+            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * SEQ_RP));
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff[r]), "s"(sbase), "s"(la) : "memory");
+        }
+        F += 1024; fslot += 1024; if (fslot >= SEQ_RB) fslot -= SEQ_RB;
+    };
+    auto wait_newer = [&](long long newer) {                                         // SPW loads per wave per row-step, returned in order
+        switch ((int)newer) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<SPW>(); break;
+            case 2: wait_vmcnt<SPW * 2>(); break;
+            case 3: wait_vmcnt<SPW * 3>(); break;
+            case 4: wait_vmcnt<SPW * 4>(); break;
+            case 5: wait_vmcnt<SPW * 5>(); break;
+            case 6: wait_vmcnt<SPW * 6>(); break;
+            default: wait_vmcnt<SPW * 7>(); break;
+        }
+    };
+    auto wait_for = [&](long long last_window_start) {
+        const long long need_end = (last_window_start + 64 * WFM_NK + 1023) & ~1023LL;
+        long long newer = (F - need_end) >> 10;
+        if (newer < 0) newer = 0;
+        if (newer > 7) newer = 7;
+        wait_newer(newer);
+    };
+    while (F < F_end && F + 1024 <= wg + SEQ_RB) row_step();
+    wait_for(wg + (long long)(TPG - 1) * tstride);
+    __syncthreads();
+    const uint8_t *lrow = lds_in + col * SEQ_RP;
+    int s0 = sb * 16;
+    for (int gi = 0; gi < n_grp; gi++) {
+        const int it = gi * TPG + wv;
+        float *lout = lds_out + (gi & 1) * (16 * OCT_OUTP);
+        if (it < n_it) {
+            const long long ws = wg + (long long)wv * tstride;
+            const long long n0 = (ws + p.B2) >> 1;                                   // global index of the window's first sample
+            const int off = (int)(n0 & 1023);
+            const bool two = off + 32 * WFM_NK > 1024;
+            const int bo = 2 * (1024 - off);                                         // byte offset of the next chunk's first sample inside the window
+            const int kb = __builtin_amdgcn_readfirstlane(two ? (bo >> 6) : WFM_NK), hq = __builtin_amdgcn_readfirstlane((bo >> 4) & 3);
+            const long long chunk_rel = (n0 >> 10) - (p.B2 >> 11);
+            // ---- B fragments from the ring
+            unsigned a0 = (unsigned)(wslot + wv * tstride + 16 * q);
+            a0 = min(a0, a0 - (unsigned)SEQ_RB);                                     // wrap (at most once: wslot < RB, the rest < RB)
+            v4i Bf[WFM_NK];
+#pragma unroll
+            for (int ks = 0; ks < WFM_NK; ks++) {
+                unsigned a = a0 + 64u * ks; a = min(a, a - (unsigned)SEQ_RB);
+                Bf[ks] = *reinterpret_cast<const v4i *>(lrow + a) ^ (int)0x80808080;
+            }
+            v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            const bool lo_lane = q < hq;
+            switch (kb) {
+                case 0: wfm_chain<0>(A, Bf, lo_lane, acc, snap); break;
+                case 1: wfm_chain<1>(A, Bf, lo_lane, acc, snap); break;
+                case 2: wfm_chain<2>(A, Bf, lo_lane, acc, snap); break;
+                case 3: wfm_chain<3>(A, Bf, lo_lane, acc, snap); break;
+                case 4: wfm_chain<4>(A, Bf, lo_lane, acc, snap); break;
+                case 5: wfm_chain<5>(A, Bf, lo_lane, acc, snap); break;
+                case 6: wfm_chain<6>(A, Bf, lo_lane, acc, snap); break;
+                case 7: wfm_chain<7>(A, Bf, lo_lane, acc, snap); break;
+                default: wfm_chain<WFM_NK>(A, Bf, lo_lane, acc, snap); break;
+            }
+            // ---- post factors and offset constants of the window's part(s)
+            const float2 C0 = ctab[chunk_rel + 1], D0 = dtab[off + 2048];
+            const float2 P0 = make_float2(C0.x * D0.x - C0.y * D0.y, C0.x * D0.y + C0.y * D0.x);
+            float2 P1 = make_float2(0.f, 0.f);
+            float k0[4], k1[4];
+            if (two) {
+                const float2 C1 = ctab[chunk_rel + 2], D1 = dtab[off - 1024 + 2048];
+                P1 = make_float2(C1.x * D1.x - C1.y * D1.y, C1.x * D1.y + C1.y * D1.x);
+                const float4 cb = *reinterpret_cast<const float4 *>(lcum + (bo >> 4) * 16 + 4 * q);
+                k0[0] = cb.x - c_lo[0]; k0[1] = cb.y - c_lo[1]; k0[2] = cb.z - c_lo[2]; k0[3] = cb.w - c_lo[3];
+                k1[0] = c_hi[0] - cb.x; k1[1] = c_hi[1] - cb.y; k1[2] = c_hi[2] - cb.z; k1[3] = c_hi[3] - cb.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) { k0[r] = c_hi[r] - c_lo[r]; k1[r] = 0.f; }
+            }
+            float pI, pQ, cI, cQ;
+            tile_rows(acc, snap, two, p.scale, k0, k1, P0, P1, pI, pQ, cI, cQ);
+            const float dq = cQ - pQ, di = cI - pI;
+            const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
+            float rd = __builtin_amdgcn_rcpf(den);
+            rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
+            lout[col * OCT_OUTP + 4 * wv + q] = (den != 0.f) ? (K * num) * rd : 0.f;   // audio 4 * tile + q of stream col
+        }
+        const long long wg_n = wg + (long long)TPG * tstride;
+        if (gi + 1 < n_grp) wait_for(wg_n + (long long)(TPG - 1) * tstride);
+        __syncthreads();
+        if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
+        {   // TPG tiles x 4 audio samples per stream leave as one run of 16-byte pieces (a whole 128-byte line for 8 tiles)
+            const int vt = min(TPG, n_it - gi * TPG);
+            if (tid < 16 * TPG) {
+                const int srow = tid / TPG, part = tid % TPG;
+                if (part < vt && s0 + srow < p.n_streams)
+                    *reinterpret_cast<float4 *>(demod + (size_t)(s0 + srow) * demod_pitch + 4 * (t0 + (long long)gi * TPG - p.tile_out0) + 4 * part) =
+                        *reinterpret_cast<const float4 *>(lout + srow * OCT_OUTP + 4 * part);
+            }
+        }
+        wg = wg_n; wslot += TPG * tstride; if (wslot >= SEQ_RB) wslot -= SEQ_RB;
+    }
+}
+
 } // namespace
 
 namespace csdr_amd {
 
 static const char *g_last_kernel = "k_wfm_mfma";
+static int g_wfm_select = -1;      // test hook csdr_amd_debug_wfm_select: -1 = environment / default, 0 = sequential, 1 = octet, 2 = quad, 3 = per-wave kernel
 const char *wfm_mfma_last_kernel() { return g_last_kernel; }
 
 int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
@@ -698,8 +928,15 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
         CSDR_LAUNCH_CHECK();
         return 0;
     };
-    static int use_wg = -1;
-    if (use_wg < 0) { const char *e = getenv("CSDR_AMD_WFM_WG"); use_wg = e ? atoi(e) : 1; }
+    static int env_wg = -1, env_seq = -1, env_oct = -1;
+    if (env_wg < 0) {
+        const char *e = getenv("CSDR_AMD_WFM_WG"); env_wg = e ? atoi(e) : 1;
+        e = getenv("CSDR_AMD_WFM_SEQ"); env_seq = e ? atoi(e) : 1;
+        e = getenv("CSDR_AMD_WFM_OCT"); env_oct = e ? atoi(e) : 1;
+    }
+    const int use_wg = g_wfm_select >= 0 ? g_wfm_select <= 2 : env_wg;
+    const int use_seq = g_wfm_select >= 0 ? g_wfm_select == 0 : env_seq;
+    const int use_oct = g_wfm_select >= 0 ? g_wfm_select <= 1 : env_oct;
     int rc = 0;
     static int n_cu = 0;
     if (!n_cu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n_cu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
@@ -714,9 +951,32 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
         int r2 = launch(st_edge, a0, a1, true); if (r2) return r2;
         return launch(st_edge, b0, b1, true);
     };
-    // ---- octet kernel (default): 8 consecutive tiles x 16 streams per item, line-aligned fetch
-    static int use_oct = -1;
-    if (use_oct < 0) { const char *e = getenv("CSDR_AMD_WFM_OCT"); use_oct = e ? atoi(e) : 1; }
+    // ---- sequential kernel (default): one weight set, a workgroup walks its 16 streams through time, every byte fetched once
+    if (use_seq && use_wg && dev.d_seq_frags && p.tile_stride_bytes == 400 && (((uintptr_t)in | in_pitch) & 127) == 0 && in_pitch * 16 + 4096 < ((size_t)1 << 32)) {
+        long long sa = (t_a + 7) / 8 * 8, sb_ = t_b;                                     // first tile: multiple of 8, so that every step writes one whole output line
+        while (sb_ >= sa && ((sb_ * p.tile_stride_bytes + p.win_off_bytes - 2 * B + 64 * WFM_NK + 1023) & ~1023LL) > 2LL * T) sb_--;   // 1-KiB fetch granularity
+        if (sb_ - sa + 1 >= 64) {
+            SeqParams sp;
+            sp.n_streams = n_streams; sp.B2 = 2 * B; sp.tile_first = sa; sp.n_tiles = (int)(sb_ - sa + 1); sp.tile_out0 = p.tile_out0;
+            sp.stride = p.tile_stride_bytes; sp.win_off = p.win_off_bytes; sp.scale = dev.seq_scale;
+            const int n_wsb = (n_streams + 15) / 16;
+            int n_seg = (n_cu + n_wsb - 1) / n_wsb; if (n_seg < 1) n_seg = 1;
+            if (n_seg > sp.n_tiles / 64) n_seg = sp.n_tiles / 64;
+            if (n_seg < 1) n_seg = 1;
+            sp.tiles_per_seg = ((sp.n_tiles + n_seg - 1) / n_seg + 7) / 8 * 8;
+            n_seg = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
+            const size_t lds = (size_t)16 * SEQ_RP + 2 * 16 * OCT_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
+            static bool done = false;
+            if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_seq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+            if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
+            hipLaunchKernelGGL((k_wfm_mfma_seq<2>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp);
+            CSDR_LAUNCH_CHECK();
+            if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
+            g_last_kernel = "k_wfm_mfma_seq";
+            return launch_edges(tile_first, sa - 1, sb_ + 1, tile_last);
+        }
+    }
+    // ---- octet kernel: 8 consecutive tiles x 16 streams per item, line-aligned fetch
     if (use_oct && use_wg && (p.n_phases % 8) == 0 && 7 * p.tile_stride_bytes + 64 * WFM_NK == OCT_ROW_BYTES &&
         (((uintptr_t)in | in_pitch) & 127) == 0 && in_pitch * 16 + 4096 < ((size_t)1 << 32)) {
         const long long oa = (t_a + 7) / 8; long long ob = (t_b + 1) / 8 - 1;            // whole octets inside the interior tile range
@@ -805,6 +1065,10 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
 }
 
 } // namespace csdr_amd
+
+// Test hook: which front-end kernel the following csdr_amd_wfm_process calls use for the bulk of a block (-1 = default order: sequential,
+// octet, quad, per-wave -- the first one whose preconditions hold).
+extern "C" void csdr_amd_debug_wfm_select(int kernel) { csdr_amd::g_wfm_select = kernel; }
 
 // Test hook (tests/test_mfma_table_cpu.py): evaluates ONE tile on the CPU exactly the way the kernel does -- same table,
 // same lane/byte layout, same digit recombination -- so the table builder and the indexing are validated without a GPU.

@@ -16,12 +16,18 @@ struct WfmMfmaTable {              // host side
     std::vector<int8_t> frags;     // [n_phases][WFM_NFRAG][64][16]
     std::vector<float> consts;     // [n_phases][2][16]
     std::vector<int> kb_of;        // [n_phases]: K-step that contains the first sample of the NEXT 1024-chunk; WFM_NK = the window has one side only
+    // phase-independent form for the sequential kernel (k_wfm_mfma_seq): weights a h D^t relative to the window base, post factors C_m D^e
+    std::vector<int8_t> seq_frags; // [WFM_NK][3][64][16]
+    std::vector<float> seq_cum;    // [2 * 4 * WFM_NK + 1][16]: 0.5 * sum of the weights of row r over bytes < 16 g
+    std::vector<float2> dtab;      // D^(i - 2048), i in [0, 3072)
+    float seq_scale;
 };
 
 struct WfmMfmaDevice {             // device copies
     int tile_stride_bytes, win_off_bytes, n_phases;
     float scale;
     void *d_frags; float *d_consts; int *d_kb_of;
+    void *d_seq_frags; float *d_seq_cum; float2 *d_dtab; float seq_scale;
 };
 
 bool wfm_mfma_supported(int D, int L, int F);

@@ -324,6 +324,9 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
 /* the chain's front end object (kernel name / profiling: csdr_amd_ddc_kernel_name, csdr_amd_ddc_set_profiling, csdr_amd_ddc_kernel_time) */
 csdr_amd_ddc *csdr_amd_nfm_front_end(csdr_amd_nfm *w);
 
+/* Test hook: front-end kernel of the following csdr_amd_wfm_process calls: -1 = default (the first whose preconditions hold of:) 0 = sequential
+ * (k_wfm_mfma_seq), 1 = octet (k_wfm_mfma_oct), 2 = quad (k_wfm_mfma_wg), 3 = per-wave (k_wfm_mfma). */
+void csdr_amd_debug_wfm_select(int kernel);
 /* Test hook: CPU evaluation of one matrix-core tile with the kernel's own weight table and layout (no GPU needed);
  * out16 must hold 32 floats (16 results + scratch).  See csdr_amd/csrc/wfm_mfma.hip. */
 int csdr_amd_debug_wfm_mfma_tile(int D, int L, int F, float shift_rate, const float *taps, int phase, const uint8_t *window,

@@ -106,18 +106,23 @@ def test_wfm_stream_counts(gpu, port, n_streams):
         assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
 
 
-@pytest.mark.parametrize("pitch_pad,block,kernel", [(0, None, "k_wfm_mfma_oct"), (0, 16384 * 5, "k_wfm_mfma_oct"), (16, None, "k_wfm_mfma_wg"),
-                                                     (16, 16384 * 5, "k_wfm_mfma_wg")])
-def test_wfm_workgroup_kernels(gpu, port, pitch_pad, block, kernel):
-    """Both workgroup front ends on the same input: the octet kernel (line-aligned fetch; needs base and pitch to be multiples of
-    128 bytes) and the quad kernel (any 16-byte-aligned pitch), in one call and in blocks whose audio start is not octet aligned;
-    19 streams = one full and one ragged 16-stream block."""
+@pytest.mark.parametrize("pitch_pad,block,select,kernel", [
+    (0, None, -1, "k_wfm_mfma_seq"), (0, 16384 * 5, -1, "k_wfm_mfma_seq"), (0, None, 1, "k_wfm_mfma_oct"), (0, 16384 * 5, 1, "k_wfm_mfma_oct"),
+    (16, None, -1, "k_wfm_mfma_wg"), (16, 16384 * 5, -1, "k_wfm_mfma_wg"), (0, None, 2, "k_wfm_mfma_wg"), (0, 16384 * 5, 3, "k_wfm_mfma")])
+def test_wfm_workgroup_kernels(gpu, port, pitch_pad, block, select, kernel):
+    """All front-end kernels on the same input: the sequential kernel (one weight set, time-contiguous walk; needs base and pitch to be
+    multiples of 128 bytes), the octet kernel (same precondition), the quad kernel (any 16-byte-aligned pitch) and the per-wave kernel, in one
+    call and in blocks whose audio start is not octet aligned; 19 streams = one full and one ragged 16-stream block."""
     from tests_helpers import wfm_signal_u8
     taps = port.firdes_lowpass_f(79, 0.05)
     n = 16384 * 15                                  # three blocks of 16384*5, each long enough for the workgroup kernels
     base = [wfm_signal_u8(300 + s, n) for s in range(3)]
     u8 = np.stack([base[s % 3] for s in range(19)])
-    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=block, pitch_pad=pitch_pad)
+    gpu.L.csdr_amd_debug_wfm_select(select)
+    try:
+        s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=block, pitch_pad=pitch_pad)
+    finally:
+        gpu.L.csdr_amd_debug_wfm_select(-1)
     assert gpu.last_wfm_kernel == kernel
     want = [port.wfm_chain(b, -0.085, 10, taps) for b in base]
     for s in (0, 1, 2, 15, 16, 18):
@@ -125,6 +130,22 @@ def test_wfm_workgroup_kernels(gpu, port, pitch_pad, block, kernel):
         m = min(pf.size, af.shape[1])
         assert m >= n // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL
         assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
+@pytest.mark.parametrize("rate", [0.25, 0.05, -0.3141])
+def test_wfm_other_shift_rates(gpu, port, rate):
+    """Shift rates other than the benchmark's, including 0.25 and 0.05 for which the reference's float phasor recurrence drifts by up to
+    4e-5 per chunk away from C_m D^k: the FM demodulator is insensitive to that common-mode error (both FIR outputs of a pair share it)."""
+    from tests_helpers import wfm_signal_u8
+    taps = port.firdes_lowpass_f(79, 0.05)
+    n = 16384 * 8
+    u8 = np.stack([wfm_signal_u8(350 + s, n, offset=-rate) for s in range(2)])
+    s16, af = gpu.wfm_chain(u8, rate, 10, taps)
+    assert gpu.last_wfm_kernel == "k_wfm_mfma_seq"
+    for s in range(2):
+        ps, pf = port.wfm_chain(u8[s], rate, 10, taps)
+        m = min(pf.size, af.shape[1])
+        assert m >= n // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL
 
 
 def test_wfm_minimum_blocks(gpu, port):
