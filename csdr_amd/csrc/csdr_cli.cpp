@@ -292,6 +292,36 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
     { *cons = n; long na = csdr_amd_wfm_process(w, (const uint8_t *)i, 2 * n, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
 };
 
+struct DdcFront : Stage {   // convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw window as ONE command (extension): the head of the NFM / AM / SSB chains
+    csdr_amd_ddc *d; int dec;
+    DdcFront(csdr_amd_ctx *c, float shift, int D, float tbw, int window, size_t block) : dec(D)
+    {
+        in_elem = 2; out_elem = 8; granule = 1024;
+        const int nt = csdr_amd_firdes_filter_len(tbw);
+        std::vector<float> t(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.5f / (float)D, window);       // csdr.c:1144-1158
+        d = csdr_amd_ddc_create(c, 1, shift, D, t.data(), nt, block + 1024); if (!d) die("ddc_create");
+    }
+    size_t out_capacity(size_t n) override { return n / dec + 64; }
+    int next_bufsize(int b) override { return b / dec; }
+    long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
+    { *cons = n; long no = csdr_amd_ddc_process(d, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (csdr_complexf *)o, cap); MUST(no); return no; }
+};
+
+struct NfmChain : Stage {   // the README.md:87 chain as ONE command (extension)
+    csdr_amd_nfm *w; int dec;
+    NfmChain(csdr_amd_ctx *c, float shift, int D, float tbw, size_t block) : dec(D)
+    {
+        in_elem = 2; out_elem = 2; granule = 1024;
+        const int nt = csdr_amd_firdes_filter_len(tbw);
+        std::vector<float> t(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.5f / (float)D, CSDR_WINDOW_HAMMING);
+        w = csdr_amd_nfm_create(c, 1, shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024); if (!w) die("nfm_create");   // fastagc_ff defaults csdr.c:1379-1391
+    }
+    size_t out_capacity(size_t n) override { return n / dec + 4096; }
+    int next_bufsize(int b) override { return b / dec; }
+    long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
+    { *cons = n; long na = csdr_amd_nfm_process(w, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
+};
+
 struct DecimatingShift : Stage {   // csdr.c:851-875: one libcsdr call per the_bufsize samples, status carried between calls
     int dec, bufsize; float dsa[3]; void *d_dsa, *d_status;
     DecimatingShift(csdr_amd_ctx *c, float rate, int decimation, int the_bufsize) : dec(decimation), bufsize(the_bufsize)
@@ -774,6 +804,21 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
         if (fft <= 0 || (fft & 1)) { badsyntax("fft_size must be positive and even"); return nullptr; }
         return new CompressFft(fft);
     }
+    if (cmd == "ddc_u8_cc") {
+        if (argc <= 3) { badsyntax("need required parameters (shift rate, decimation factor)"); return nullptr; }
+        float shift = 0, tbw = 0.05f; int factor = 0; sscanf(argv[2], "%g", &shift); sscanf(argv[3], "%d", &factor);
+        if (factor < 1) { badsyntax("decimation factor must be >= 1"); return nullptr; }
+        if (argc >= 5) sscanf(argv[4], "%g", &tbw);
+        const int window = argc >= 6 ? window_from(argv[5]) : CSDR_WINDOW_HAMMING;
+        return new DdcFront(c, shift, factor, tbw, window, block);
+    }
+    if (cmd == "nfm_chain_u8_s16") {
+        float shift = 0, tbw = 0.005f; int factor = 50;
+        if (argc > 2) sscanf(argv[2], "%g", &shift);
+        if (argc > 3) sscanf(argv[3], "%d", &factor);
+        if (argc > 4) sscanf(argv[4], "%g", &tbw);
+        return new NfmChain(c, shift, factor, tbw, block);
+    }
     if (cmd == "wfm_chain_u8_s16") { float shift = 0; if (argc > 2) sscanf(argv[2], "%g", &shift); return new WfmChain(c, shift, block); }
     fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]);
     return nullptr;
@@ -807,6 +852,34 @@ bool is_wfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *sh
     return sscanf(cmds[1][2].c_str(), "%g", shift) == 1;
 }
 
+bool is_nfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *shift)
+{   // README.md:87 exactly: the shape csdr_amd_nfm implements
+    if (cmds.size() != 8) return false;
+    auto is = [&](size_t k, std::initializer_list<const char *> want) {
+        if (cmds[k].size() != want.size() + 1) return false;
+        size_t j = 1; for (const char *w : want) { if (w[0] != '*' && cmds[k][j] != w) return false; j++; }
+        return true;
+    };
+    if (!is(0, {"convert_u8_f"}) || !is(1, {"shift_addition_cc", "*"}) || !is(2, {"fir_decimate_cc", "50", "0.005", "HAMMING"}) || !is(3, {"fmdemod_quadri_cf"}) ||
+        !is(4, {"limit_ff"}) || !is(5, {"deemphasis_nfm_ff", "48000"}) || !is(6, {"fastagc_ff"}) || !is(7, {"convert_f_s16"})) return false;
+    return sscanf(cmds[1][2].c_str(), "%g", shift) == 1;
+}
+
+// convert_u8_f | shift_addition_cc r | fir_decimate_cc D [tbw [window]] at the head of a chain -> one ddc_u8_cc command
+bool fuse_front_end(std::vector<std::vector<std::string>> &cmds)
+{
+    if (cmds.size() < 3 || cmds[0].size() != 2 || cmds[0][1] != "convert_u8_f") return false;
+    if (cmds[1].size() != 3 || cmds[1][1] != "shift_addition_cc") return false;
+    if (cmds[2].size() < 3 || cmds[2].size() > 5 || cmds[2][1] != "fir_decimate_cc") return false;
+    float r; int d;
+    if (sscanf(cmds[1][2].c_str(), "%g", &r) != 1 || sscanf(cmds[2][2].c_str(), "%d", &d) != 1 || d < 1) return false;
+    std::vector<std::string> fused = {"csdr", "ddc_u8_cc", cmds[1][2], cmds[2][2]};
+    for (size_t k = 3; k < cmds[2].size(); k++) fused.push_back(cmds[2][k]);
+    cmds.erase(cmds.begin(), cmds.begin() + 3);
+    cmds.insert(cmds.begin(), fused);
+    return true;
+}
+
 } // namespace
 
 int main(int argc, char **argv)
@@ -818,7 +891,7 @@ int main(int argc, char **argv)
                         "decimating_shift_addition_cc fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff "
                         "deemphasis_nfm_ff limit_ff fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c "
                         "amdemod_cf amdemod_estimator_cf fmdemod_atan_cf dcblock_ff fastdcblock_ff agc_ff gain_ff realpart_cf logpower_cf fft_cc encode_ima_adpcm_i16_u8 decode_ima_adpcm_u8_i16 compress_fft_adpcm_f_u8 "
-                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, fastddc_bank_cc <decimation> <tbw> <window> <ctl|-> <out_0> <rate_0> ..., chain \"<cmd> <args> | <cmd> <args> ...\"\n");
+                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, nfm_chain_u8_s16 <shift_rate> [decimation [transition_bw]], ddc_u8_cc <shift_rate> <decimation> [transition_bw [window]], fastddc_bank_cc <decimation> <tbw> <window> <ctl|-> <out_0> <rate_0> ..., chain \"<cmd> <args> | <cmd> <args> ...\"\n");
         return -1;
     }
     g_cmd = argv[1];
@@ -872,6 +945,12 @@ int main(int argc, char **argv)
             fprintf(stderr, "csdr chain: WFM receive pattern recognised -> fused matrix-core kernel\n");
             char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
             cmds.assign(1, {"csdr", "wfm_chain_u8_s16", sh});
+        } else if (is_nfm_pattern(cmds, &shift)) {
+            fprintf(stderr, "csdr chain: NFM receive pattern recognised -> fused chain (matrix-core front end and de-emphasis)\n");
+            char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
+            cmds.assign(1, {"csdr", "nfm_chain_u8_s16", sh});
+        } else if (fuse_front_end(cmds)) {
+            fprintf(stderr, "csdr chain: convert_u8_f | shift_addition_cc | fir_decimate_cc recognised -> fused matrix-core front end\n");
         }
     } else {
         cmds.assign(1, std::vector<std::string>(argv, argv + argc));

@@ -1066,6 +1066,56 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
 
 } // namespace csdr_amd
 
+// Test hook (tests/test_mfma_table_cpu.py): ONE tile of the sequential kernel on the CPU -- the phase-independent weight set, the
+// snapshot / lane-group masking at a chunk boundary, the post factors C_m D^e and the prefix-sum offset constants, exactly as
+// k_wfm_mfma_seq evaluates them.  n0: global index of the window's first sample (multiple of 8); window: 64*WFM_NK raw u8 bytes from n0;
+// ctab2: (cos, sin) of the chunks n0>>10 and +1;  out16: the 16 rows (Re, Im of y[Fj+9], y[Fj+10] for the tile's 4 audio samples).
+extern "C" int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const float *taps, long long n0, const uint8_t *window,
+                                           const float *ctab2, float *out16)
+{
+    if (!wfm_mfma_supported(D, L, F) || (n0 & 7)) return -1;
+    static WfmMfmaTable t; static int cD = 0, cL = 0, cF = 0; static float crate = 0; static std::vector<float> ctaps;
+    if (cD != D || cL != L || cF != F || crate != shift_rate || ctaps != std::vector<float>(taps, taps + L)) {
+        wfm_mfma_build_table(D, L, F, shift_rate, taps, t); cD = D; cL = L; cF = F; crate = shift_rate; ctaps.assign(taps, taps + L);
+    }
+    const int off = (int)(n0 & 1023);
+    const bool two = off + 32 * WFM_NK > 1024;
+    const int bo = 2 * (1024 - off), kb = two ? (bo >> 6) : WFM_NK, hq = (bo >> 4) & 3, gb = bo >> 4;
+    const float2 D0 = t.dtab[off + 2048], C0 = make_float2(ctab2[0], ctab2[1]);
+    const float2 P0 = make_float2(C0.x * D0.x - C0.y * D0.y, C0.x * D0.y + C0.y * D0.x);
+    float2 P1 = make_float2(0.f, 0.f);
+    if (two) { const float2 D1 = t.dtab[off - 1024 + 2048], C1 = make_float2(ctab2[2], ctab2[3]); P1 = make_float2(C1.x * D1.x - C1.y * D1.y, C1.x * D1.y + C1.y * D1.x); }
+    const int ngr = 4 * WFM_NK;
+    float u[16], v[16];
+    for (int r = 0; r < 16; r++) {
+        long acc[3] = {0, 0, 0}, snap[3] = {0, 0, 0};
+        auto step = [&](int ks, int kg_lo, int kg_hi) {
+            for (int kg = kg_lo; kg < kg_hi; kg++) for (int b = 0; b < 16; b++) {
+                const int x = (int)(int8_t)(window[64 * ks + 16 * kg + b] ^ 0x80);
+                for (int l = 0; l < 3; l++) acc[l] += (long)t.seq_frags[((size_t)(ks * 3 + l) * 64 + (16 * kg + r)) * 16 + b] * x;
+            }
+        };
+        for (int ks = 0; ks < WFM_NK; ks++) {
+            if (ks == kb) { step(ks, 0, hq); for (int l = 0; l < 3; l++) snap[l] = acc[l]; step(ks, hq, 4); }
+            else step(ks, 0, 4);
+        }
+        const float clo = t.seq_cum[r], chi = t.seq_cum[(size_t)ngr * 16 + r];
+        if (two) {
+            const float cb = t.seq_cum[(size_t)gb * 16 + r];
+            u[r] = fmaf(fmaf((float)snap[0], 65536.0f, fmaf((float)snap[1], 256.0f, (float)snap[2])), t.seq_scale, cb - clo);
+            v[r] = fmaf(fmaf((float)(acc[0] - snap[0]), 65536.0f, fmaf((float)(acc[1] - snap[1]), 256.0f, (float)(acc[2] - snap[2]))), t.seq_scale, chi - cb);
+        } else {
+            u[r] = fmaf(fmaf((float)acc[0], 65536.0f, fmaf((float)acc[1], 256.0f, (float)acc[2])), t.seq_scale, chi - clo);
+            v[r] = 0.f;
+        }
+    }
+    for (int k = 0; k < 8; k++) {
+        out16[2 * k] = P0.x * u[2 * k] - P0.y * u[2 * k + 1] + (P1.x * v[2 * k] - P1.y * v[2 * k + 1]);
+        out16[2 * k + 1] = P0.x * u[2 * k + 1] + P0.y * u[2 * k] + (P1.x * v[2 * k + 1] + P1.y * v[2 * k]);
+    }
+    return 0;
+}
+
 // Test hook: which front-end kernel the following csdr_amd_wfm_process calls use for the bulk of a block (-1 = default order: sequential,
 // octet, quad, per-wave -- the first one whose preconditions hold).
 extern "C" void csdr_amd_debug_wfm_select(int kernel) { csdr_amd::g_wfm_select = kernel; }

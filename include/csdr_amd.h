@@ -324,6 +324,10 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
 /* the chain's front end object (kernel name / profiling: csdr_amd_ddc_kernel_name, csdr_amd_ddc_set_profiling, csdr_amd_ddc_kernel_time) */
 csdr_amd_ddc *csdr_amd_nfm_front_end(csdr_amd_nfm *w);
 
+/* Test hook: one tile of the SEQUENTIAL WFM kernel (phase-independent weight set, post factors, chunk-boundary handling) on the CPU.
+ * n0: window base sample (multiple of 8); window: 512 raw bytes; ctab2: (cos, sin) of chunks n0>>10, +1; out16: 16 rows. */
+int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const float *taps, long long n0, const uint8_t *window,
+                                const float *ctab2, float *out16);
 /* Test hook: front-end kernel of the following csdr_amd_wfm_process calls: -1 = default (the first whose preconditions hold of:) 0 = sequential
  * (k_wfm_mfma_seq), 1 = octet (k_wfm_mfma_oct), 2 = quad (k_wfm_mfma_wg), 3 = per-wave (k_wfm_mfma). */
 void csdr_amd_debug_wfm_select(int kernel);

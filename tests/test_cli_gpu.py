@@ -235,6 +235,32 @@ def test_cli_chain_equals_pipeline(port):
     assert d.max() <= 1 and np.mean(d != 0) < 0.01
 
 
+def test_cli_fused_front_end_and_nfm_commands(port):
+    """Extensions: `csdr ddc_u8_cc r D tbw window` (= convert_u8_f | shift_addition_cc | fir_decimate_cc in one pass on the matrix cores) and
+    `csdr nfm_chain_u8_s16 r` (README.md:87 in one process), streaming in several host blocks; a chain that merely starts with the three
+    front-end commands gets them fused."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests_helpers import nfm_signal_u8
+    n = 1024 * 330 + 517
+    iq = nfm_signal_u8(77, n, offset=-0.11)
+    taps = port.firdes_lowpass_f(port.firdes_filter_len(0.005), 0.5 / 50)
+    want_y = port.fir_decimate_cc(port.shift_addition_cc(port.convert_u8_f(iq).view(c64), 0.11)[0], 50, taps)
+    got_y = np.frombuffer(run(["ddc_u8_cc", 0.11, 50, 0.005, "HAMMING"], iq, 1024 * 100), c64)
+    assert got_y.size == want_y.size and relrms(got_y, want_y) <= TOL
+    dtaps = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    want, _ = port.nfm_chain(iq, 0.11, dtaps)
+    got = np.frombuffer(run(["nfm_chain_u8_s16", 0.11], iq, 1024 * 100), np.int16)
+    assert got.size == want.size
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.01
+    am = "convert_u8_f | shift_addition_cc 0.11 | fir_decimate_cc 50 0.005 HAMMING | amdemod_cf | fastdcblock_ff | agc_ff | limit_ff | convert_f_s16"
+    env = dict(os.environ, CSDR_AMD_BLOCK=str(1024 * 100))
+    p = subprocess.run([CLI, "chain", am], input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0 and b"fused matrix-core front end" in p.stderr, p.stderr.decode()
+    assert len(p.stdout) // 2 >= want_y.size - 2048
+
+
 def test_cli_dynamic_bufsize_preamble(port):
     """csdr.c:330-391: with CSDR_DYNAMIC_BUFSIZE_ON=1 every command eats the "csdr"+int preamble and sends its own (size rule per command)."""
     import struct
