@@ -198,7 +198,7 @@ struct csdr_amd_wfm {
     int n_streams, D, L, F, audio_rate;
     float shift_rate, tau, alpha;
     size_t max_block;
-    float *d_taps, *d_demod, *d_last[2];
+    float *d_taps, *d_demod, *d_last[2], *d_seg_state;
     float phase;                     // shift_addition_cc starting_phase (host float, like the reference's by-value state)
     cf32 *d_rot;
     uint8_t *d_hist;
@@ -242,6 +242,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     alloc((void **)&w->d_demod, sizeof(float) * w->demod_pitch * n_streams);
     alloc((void **)&w->d_last[0], sizeof(float) * n_streams);
     alloc((void **)&w->d_last[1], sizeof(float) * n_streams);
+    alloc((void **)&w->d_seg_state, sizeof(float) * n_streams);
     alloc((void **)&w->d_rot, sizeof(cf32) * (HIST + max_block_samples + 64));
     alloc((void **)&w->d_hist, (size_t)2 * HIST * n_streams);
     if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
@@ -293,7 +294,7 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
 {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
-    (void)hipFree(w->d_taps); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]);
+    (void)hipFree(w->d_taps); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]); (void)hipFree(w->d_seg_state);
     (void)hipFree(w->d_rot); (void)hipFree(w->d_hist);
     for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (w->mfma.d_frags) (void)hipFree(w->mfma.d_frags);
@@ -405,7 +406,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
             }
             e0 = w->ev_pool[w->ev_used].first; e1 = w->ev_pool[w->ev_used].second; w->ev_used++;
         }
-        bool forked = false;
+        bool forked = false, back_done = false;
         if (w->use_mfma) {
             hipStream_t se = st;
             if (w->side) {                                                     // fork: edge tiles + history copy beside the dominant kernel
@@ -413,8 +414,12 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
                 CSDR_HIP(hipStreamWaitEvent(w->side, w->ev_fork, 0));
                 se = w->side; forked = true;
             }
-            rc = wfm_mfma_launch(st, se, e0, e1, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio);
+            WfmBackArgs back;
+            back.alpha = w->alpha; back.last_in = w->d_last[w->flip]; back.last_out = w->d_last[w->flip ^ 1]; back.seg_state = w->d_seg_state;
+            back.s16 = audio_s16; back.af = audio_f; back.out_pitch = out_pitch; back.skip = (int)(w->next_j % 32); back.done = false;
+            rc = wfm_mfma_launch(st, se, e0, e1, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio, &back);
             if (rc) return rc;
+            back_done = back.done;
             w->kernel_name = wfm_mfma_last_kernel();
             if (forked) {
                 if (T >= HIST) { hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, se, in, in_pitch, T, w->d_hist); CSDR_LAUNCH_CHECK(); hist_saved = true; }
@@ -428,9 +433,11 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
             CSDR_LAUNCH_CHECK();
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
         }
-        hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, BK_CHUNK), w->n_streams), dim3(256), 0, st,
-                           w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j % 32) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
-        CSDR_LAUNCH_CHECK();
+        if (!back_done) {                                                  // (the sequential front end does the back end itself)
+            hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, BK_CHUNK), w->n_streams), dim3(256), 0, st,
+                               w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j % 32) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
+            CSDR_LAUNCH_CHECK();
+        }
         w->flip ^= 1;
     }
     // 3. history for the next block (already done on the side stream when that path ran)

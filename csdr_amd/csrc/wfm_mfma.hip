@@ -714,6 +714,8 @@ __global__ __launch_bounds__(256) void k_wfm_mfma_oct(const uint8_t *__restrict_
 struct SeqParams {
     int n_streams; long long B2; long long tile_first; int n_tiles, tiles_per_seg; long long tile_out0;
     int stride, win_off; float scale;
+    // fused back end (FUSE): de-emphasis + convert_f_s16 inside the kernel
+    float alpha; const float *last_in; float *seg_state; int16_t *s16; float *af; size_t out_pitch; long long j_first; int skip;
 };
 
 template <int KB>
@@ -741,15 +743,23 @@ constexpr int SEQ_RB = 9216;               // ring bytes per stream: 9 x 1 KiB (
 constexpr int SEQ_RP = SEQ_RB + 16;        // LDS pitch: odd multiple of 16 bytes
 constexpr int SEQ_NGR = 4 * WFM_NK;        // 16-byte granules per window
 
-template <int NT>
+// FUSE: the back end of the chain inside this kernel.  The workgroup produces its streams' audio in time order, so the one-pole de-emphasis
+// (libcsdr.c:1081-1097) is a state carried in 16 lanes of wave 0 from step to step, and convert_f_s16 + the stores are done by all threads one
+// step later (one sample per thread, three staging buffers so that nobody waits): the demodulated audio never goes to HBM as floats
+// (0.2 GB written + read per step), and k_wfm_back (0.077 ms of a 1.08 ms step) disappears.  A segment that starts in the middle of a stream
+// demodulates two steps (64 audio samples) ahead of its range from zero state without storing them -- the filter forgets as 0.706^k --,
+// the first segment starts from the exact carried state and first walks through the leading edge tiles' samples (computed by the per-wave
+// edge kernel, launched before); the last segment exports its state for the trailing edge tiles (k_wfm_tail).
+template <int NT, bool FUSE>
 __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags, const float *__restrict__ cum,
                                                            const float2 *__restrict__ dtab, const float2 *__restrict__ ctab, float *__restrict__ demod, size_t demod_pitch, SeqParams p)
 {
     constexpr int TPG = 4 * NT, SPW = 16 / (4 * NT);                                 // tiles per step; streams fetched per wave in a row-step
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
-    float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 2 x 16 x OCT_OUTP floats
-    float *lcum = lds_out + 2 * 16 * OCT_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
+    constexpr int NOUT = FUSE ? 3 : 2;
+    float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // NOUT x 16 x OCT_OUTP floats
+    float *lcum = lds_out + NOUT * 16 * OCT_OUTP;                                    // prefix table (a global vector load inside the loop would drain the DMA ring)
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     for (int i = tid; i < (SEQ_NGR + 1) * 16; i += 256 * NT) lcum[i] = cum[i];
     const int sb = blockIdx.x;
@@ -757,6 +767,7 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
     if (t0 >= t1) return;
     const int n_it = (int)(t1 - t0), n_grp = (n_it + TPG - 1) / TPG;
+    const int n_warm = (FUSE && blockIdx.y > 0) ? 2 : 0;                             // steps demodulated ahead of the segment to warm the de-emphasis up
     const int last_stream = p.n_streams - 1;
     v4i A[WFM_NK * 3];
 #pragma unroll
@@ -769,11 +780,11 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
     const float K = 0.340447550238101026565118445432744920253753662109375f;
     // ---- DMA ring
     const int tstride = p.stride;
-    long long wg = t0 * tstride + p.win_off - p.B2;                                  // window start of the step's first tile, bytes from the block start
+    long long wg = (t0 - (long long)n_warm * TPG) * tstride + p.win_off - p.B2;      // window start of the step's first tile, bytes from the block start
     const long long F0 = wg & ~1023LL;
     const long long F_end = ((t1 - 1) * tstride + p.win_off - p.B2 + 64 * WFM_NK + 1023) & ~1023LL;
     long long F = F0;
-    int fslot = (int)(F0 % SEQ_RB), wslot = (int)(wg % SEQ_RB);                      // ring positions of F and of wg
+    int fslot = (int)(F0 % SEQ_RB), wslot = (int)(wg % SEQ_RB);                      // ring positions of F and of wg (wg already includes the warm-up steps)
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
     uint32_t voff[SPW];
 #pragma unroll
@@ -818,9 +829,50 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
     __syncthreads();
     const uint8_t *lrow = lds_in + col * SEQ_RP;
     int s0 = sb * 16;
-    for (int gi = 0; gi < n_grp; gi++) {
+    // ---- fused back end: de-emphasis state of stream s0 + lane (wave 0, lanes 0..15)
+    // The recurrence y_k = alpha x_k + b y_{k-1} (b = 1 - alpha) over a step's 32 samples of a stream is split over 4 lanes (wave 0: lane =
+    // stream + 16 * quarter): each lane runs its 8 samples from zero state, the quarters' end values are combined with b^8, b^16, b^24 (three
+    // shuffles), and every output gets its share b^(j+1) of its quarter's start state -- a dependent chain of ~12 instead of 32 steps on the
+    // one wave that all others wait for at the next barrier.  (Rounding differs from the sequential recurrence by a few 1e-8.)
+    float yst = 0.f;                                                                 // state after the last sample processed so far (same value in the stream's 4 lanes)
+    const float one_minus = 1 - p.alpha;
+    const bool iir_lane = FUSE && wv == 0 && lane < 16;
+    const bool iir_wave = FUSE && wv == 0;
+    float bp[9];                                                                     // b^0 .. b^8
+    bp[0] = 1.f;
+#pragma unroll
+    for (int j = 1; j <= 8; j++) bp[j] = bp[j - 1] * one_minus;
+    const float b16 = bp[8] * bp[8], b24 = b16 * bp[8];
+    if (FUSE && iir_lane && blockIdx.y == 0 && s0 + lane < p.n_streams) {
+        // first segment: exact carried state (NaN reset as libcsdr.c:1092), then the leading edge tiles' samples in order
+        yst = p.last_in[s0 + lane]; if (yst != yst) yst = 0.f;
+        const int n_lead = (int)(4 * p.tile_first - p.j_first);
+        const float *row = demod + (size_t)(s0 + lane) * demod_pitch + p.skip;
+        for (int i = 0; i < n_lead; i++) {
+            yst = p.alpha * row[i] + one_minus * yst;
+            const float scaled = yst * 32767.0f;
+            const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
+            p.s16[(size_t)(s0 + lane) * p.out_pitch + i] = (int16_t)iv;
+            if (p.af) p.af[(size_t)(s0 + lane) * p.out_pitch + i] = yst;
+        }
+    }
+    if (iir_wave) yst = __shfl(yst, col, 64);                                        // the stream's state into all four of its lanes
+    auto emit = [&](int g) {                                                         // convert_f_s16 + store of step g's 16 x 32 samples, one per thread
+        if (g < 0) return;
+        const int vt = min(TPG, n_it - g * TPG);
+        const int srow = tid >> 5, k = tid & 31;
+        if (tid < 16 * 4 * TPG && (k >> 2) < vt && s0 + srow < p.n_streams) {
+            const float e = lds_out[(g % 3) * (16 * OCT_OUTP) + srow * OCT_OUTP + k];
+            const long long idx = 4 * (t0 + (long long)g * TPG) + k - p.j_first;
+            const float scaled = e * 32767.0f;                                       // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
+            const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
+            p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)iv;
+            if (p.af) p.af[(size_t)(s0 + srow) * p.out_pitch + idx] = e;
+        }
+    };
+    for (int gi = -n_warm; gi < n_grp; gi++) {
         const int it = gi * TPG + wv;
-        float *lout = lds_out + (gi & 1) * (16 * OCT_OUTP);
+        float *lout = lds_out + (FUSE ? ((gi + 3) % 3) : (gi & 1)) * (16 * OCT_OUTP);
         if (it < n_it) {
             const long long ws = wg + (long long)wv * tstride;
             const long long n0 = (ws + p.B2) >> 1;                                   // global index of the window's first sample
@@ -878,7 +930,36 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
         if (gi + 1 < n_grp) wait_for(wg_n + (long long)(TPG - 1) * tstride);
         __syncthreads();
         if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
-        {   // TPG tiles x 4 audio samples per stream leave as one run of 16-byte pieces (a whole 128-byte line for 8 tiles)
+        if (FUSE) {
+            emit(gi - 1);                                                            // the previous step's audio: filtered by wave 0 before it came to this barrier
+            if (iir_wave) {                                                          // this step's 32 samples of stream s0 + col through the de-emphasis, in place
+                float *row = lout + col * OCT_OUTP + 8 * q;                          // this lane's quarter: samples 8q .. 8q+7
+                const int nv = 4 * min(TPG, n_it - gi * TPG);                        // valid samples of the step (a multiple of 4; 32 except in a segment's last step)
+                float4 xa = *reinterpret_cast<const float4 *>(row), xb = *reinterpret_cast<const float4 *>(row + 4);
+                float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, z[8];
+                if (8 * q + 4 >= nv) { x[4] = x[5] = x[6] = x[7] = 0.f; }            // samples behind the valid ones do not exist: feed zeros (their outputs are not stored)
+                if (8 * q >= nv) { x[0] = x[1] = x[2] = x[3] = 0.f; }
+                z[0] = p.alpha * x[0];
+#pragma unroll
+                for (int j = 1; j < 8; j++) z[j] = p.alpha * x[j] + one_minus * z[j - 1];
+                // start state of this quarter: S_q = b^(8q) y_prev + sum_{i<q} b^(8(q-1-i)) z7(i)
+                const float z7_0 = __shfl(z[7], col, 64), z7_1 = __shfl(z[7], col + 16, 64), z7_2 = __shfl(z[7], col + 32, 64);
+                float S = yst;
+                if (q == 1) S = bp[8] * yst + z7_0;
+                else if (q == 2) S = b16 * yst + (bp[8] * z7_0 + z7_1);
+                else if (q == 3) S = b24 * yst + (b16 * z7_0 + (bp[8] * z7_1 + z7_2));
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) y[j] = z[j] + bp[j + 1] * S;
+                *reinterpret_cast<float4 *>(row) = make_float4(y[0], y[1], y[2], y[3]);
+                *reinterpret_cast<float4 *>(row + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                // new carried state = the value after the last VALID sample (nv - 1): it lives in quarter (nv - 1) / 8 at position (nv - 1) % 8
+                const int lq = (nv - 1) >> 3, lj = (nv - 1) & 7;
+                float ylast = y[7];
+                if (lj == 3) ylast = y[3];
+                yst = __shfl(ylast, col + 16 * lq, 64);
+            }
+        } else {   // TPG tiles x 4 audio samples per stream leave as one run of 16-byte pieces (a whole 128-byte line for 8 tiles)
             const int vt = min(TPG, n_it - gi * TPG);
             if (tid < 16 * TPG) {
                 const int srow = tid / TPG, part = tid % TPG;
@@ -889,6 +970,31 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
         }
         wg = wg_n; wslot += TPG * tstride; if (wslot >= SEQ_RB) wslot -= SEQ_RB;
     }
+    if (FUSE) {
+        __syncthreads();
+        emit(n_grp - 1);
+        if (iir_lane && blockIdx.y + 1 == gridDim.y && s0 + lane < p.n_streams) p.seg_state[s0 + lane] = yst;   // for the trailing edge tiles (lanes 0..15: quarter 0 holds the state too)
+    }
+}
+
+// trailing samples of a call (the edge tiles behind the sequential kernel's range): one lane per stream continues the de-emphasis
+__global__ __launch_bounds__(64) void k_wfm_tail(const float *__restrict__ demod, size_t demod_pitch, int skip, int first, int n_audio, float alpha,
+                                                 const float *__restrict__ state_in, float *__restrict__ last_out, int16_t *__restrict__ s16, float *__restrict__ af,
+                                                 size_t out_pitch, int n_streams)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_streams) return;
+    float y = state_in[s];
+    const float one_minus = 1 - alpha;
+    const float *row = demod + (size_t)s * demod_pitch + skip;
+    for (int i = first; i < n_audio; i++) {
+        y = alpha * row[i] + one_minus * y;
+        const float scaled = y * 32767.0f;
+        const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
+        s16[(size_t)s * out_pitch + i] = (int16_t)iv;
+        if (af) af[(size_t)s * out_pitch + i] = y;
+    }
+    last_out[s] = y;
 }
 
 } // namespace
@@ -900,9 +1006,10 @@ static int g_wfm_select = -1;      // test hook csdr_amd_debug_wfm_select: -1 = 
 const char *wfm_mfma_last_kernel() { return g_last_kernel; }
 
 int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
-                    float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio)
+                    float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio, WfmBackArgs *back)
 {
     MfmaParams p;
+    if (back) back->done = false;
     p.n_streams = n_streams; p.T = T; p.B = B; p.j_first = j_first; p.n_audio = n_audio;
     p.tile_stride_bytes = dev.tile_stride_bytes; p.win_off_bytes = dev.win_off_bytes; p.n_phases = dev.n_phases; p.scale = dev.scale;
     const long long tile_first = j_first / 4, tile_last = (j_first + n_audio - 1) / 4;
@@ -965,15 +1072,33 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
             if (n_seg < 1) n_seg = 1;
             sp.tiles_per_seg = ((sp.n_tiles + n_seg - 1) / n_seg + 7) / 8 * 8;
             n_seg = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
-            const size_t lds = (size_t)16 * SEQ_RP + 2 * 16 * OCT_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
-            static bool done = false;
-            if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_seq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+            static int env_fuse = -1;
+            if (env_fuse < 0) { const char *e = getenv("CSDR_AMD_WFM_FUSE_BACK"); env_fuse = e ? atoi(e) : 1; }
+            const bool fuse = back && env_fuse && sp.tiles_per_seg >= 64 && st_edge == st;       // (edge tiles on a side stream would not be ordered before the first segment)
+            sp.alpha = 0; sp.last_in = nullptr; sp.seg_state = nullptr; sp.s16 = nullptr; sp.af = nullptr; sp.out_pitch = 0; sp.j_first = j_first; sp.skip = 0;
+            if (fuse) { sp.alpha = back->alpha; sp.last_in = back->last_in; sp.seg_state = back->seg_state; sp.s16 = back->s16; sp.af = back->af; sp.out_pitch = back->out_pitch; sp.skip = back->skip; }
+            const size_t lds = (size_t)16 * SEQ_RP + (fuse ? 3 : 2) * 16 * OCT_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
+            static bool done[2] = {false, false};
+            if (!done[fuse]) {
+                if (fuse) CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_seq<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                else CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_seq<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                done[fuse] = true;
+            }
+            // the edge tiles first: the fused back end of the first segment walks through the leading ones' samples
+            rc = launch_edges(tile_first, sa - 1, sb_ + 1, tile_last); if (rc) return rc;
             if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
-            hipLaunchKernelGGL((k_wfm_mfma_seq<2>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp);
+            if (fuse) hipLaunchKernelGGL((k_wfm_mfma_seq<2, true>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp);
+            else hipLaunchKernelGGL((k_wfm_mfma_seq<2, false>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp);
             CSDR_LAUNCH_CHECK();
             if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
+            if (fuse) {
+                hipLaunchKernelGGL(k_wfm_tail, dim3((n_streams + 63) / 64), dim3(64), 0, st, demod, demod_pitch, back->skip, (int)(4 * (sb_ + 1) - j_first), n_audio, back->alpha,
+                                   back->seg_state, back->last_out, back->s16, back->af, back->out_pitch, n_streams);
+                CSDR_LAUNCH_CHECK();
+                back->done = true;
+            }
             g_last_kernel = "k_wfm_mfma_seq";
-            return launch_edges(tile_first, sa - 1, sb_ + 1, tile_last);
+            return 0;
         }
     }
     // ---- octet kernel: 8 consecutive tiles x 16 streams per item, line-aligned fetch

@@ -30,12 +30,17 @@ struct WfmMfmaDevice {             // device copies
     void *d_seq_frags; float *d_seq_cum; float2 *d_dtab; float seq_scale;
 };
 
+// back end (de-emphasis + convert_f_s16) the sequential kernel can take over; `done` is set when it did (the caller then skips k_wfm_back)
+struct WfmBackArgs {
+    float alpha; const float *last_in; float *last_out; float *seg_state; int16_t *s16; float *af; size_t out_pitch; int skip; bool done;
+};
+
 bool wfm_mfma_supported(int D, int L, int F);
 void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *taps, WfmMfmaTable &t);
 const char *wfm_mfma_last_kernel();
 // st_edge: stream for the few bounds-checked tiles around the whole-quad range (may equal st); ev_begin/ev_end (may be null) are recorded on st
 // around the dominant kernel only.
 int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const uint8_t *hist, const WfmMfmaDevice &dev, const float2 *ctab,
-                    float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio);
+                    float *demod, size_t demod_pitch, int n_streams, int T, long long B, long long j_first, int n_audio, WfmBackArgs *back);
 
 } // namespace csdr_amd
