@@ -49,27 +49,43 @@ __global__ __launch_bounds__(256) void k_nfm_demod_limit(const cf32 *__restrict_
     dst[0] = (int8_t)qv; dst[plane_bytes] = (int8_t)d1; dst[2 * plane_bytes] = (int8_t)d2;
 }
 
-// out[s][i] = sum_t taps[t] x[s][i + t] for i < n_tiles * 16, x given as digit planes.  One wave = 16 channels x a strided set of tiles; the 12
-// weight fragments (4 K-steps x 3 digits of the Toeplitz band) stay in registers; B operands are 16 consecutive digit bytes of a channel,
-// loaded straight from the planes (consecutive tiles overlap by 240 of 256 inputs: L1 / L2 traffic, the planes are 3 bytes per sample in HBM).
+// out[s][i] = sum_t taps[t] x[s][i + t] for i < n_tiles * 16, x given as digit planes.  One workgroup = 16 channels x NFM_FIR_SPAN consecutive
+// tiles: the three planes' bytes of that span (+ the 240-sample window tail) are staged in LDS once (consecutive tiles overlap by 240 of
+// their 256 inputs; reading the B operands straight from global memory made this kernel L2-bandwidth bound: 1.2 GB of L2 reads for 74 MB of
+// planes, 0.16 ms); the 12 weight fragments (4 K-steps x 3 digits of the Toeplitz band) stay in registers; each wave takes every fourth tile.
 // MFMA result layout: lane (col, q) holds outputs 4q .. 4q+3 of channel col.
+constexpr int NFM_FIR_SPAN = 64;                                   // tiles per workgroup (1024 outputs)
+constexpr int NFM_FIR_ROW = 16 * NFM_FIR_SPAN + 64 * NFM_FIR_NK;   // staged bytes per channel and plane (1280)
+constexpr int NFM_FIR_RP = NFM_FIR_ROW + 16;                       // LDS pitch: odd multiple of 16 bytes (the 16 channels of a B read hit different banks)
+
 __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restrict__ planes, size_t plane_bytes, size_t dl_pitch, const v4i *__restrict__ frags,
                                                          float scale, float *__restrict__ out, size_t out_pitch, int n_tiles, int n_streams)
 {
-    const int lane = threadIdx.x & 63, col = lane & 15, q = lane >> 4;
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), n_wv = gridDim.x * 4;
+    __shared__ __attribute__((aligned(16))) int8_t lds[3 * 16 * NFM_FIR_RP];
+    const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, q = lane >> 4, wv = tid >> 6;
     v4i A[NFM_FIR_NK * 3];
 #pragma unroll
     for (int i = 0; i < NFM_FIR_NK * 3; i++) A[i] = frags[i * 64 + lane];
-    const int stream = min((int)blockIdx.y * 16 + col, n_streams - 1);
-    const int8_t *row = planes + (size_t)stream * dl_pitch + 16 * q;
-    for (int tile = wv; tile < n_tiles; tile += n_wv) {
-        const int8_t *src = row + 16 * tile;
+    const int tile0 = blockIdx.x * NFM_FIR_SPAN;
+    const int nt = min(NFM_FIR_SPAN, n_tiles - tile0);
+    // stage [3 planes][16 channels][NFM_FIR_ROW] (rows of channels past the last one re-read it; bytes behind the valid samples meet zero weights)
+    const int last = n_streams - 1;
+    for (int i = tid; i < 3 * 16 * (NFM_FIR_ROW / 16); i += 256) {
+        const int piece = i % (NFM_FIR_ROW / 16), r = (i / (NFM_FIR_ROW / 16)) % 16, pl = i / (16 * (NFM_FIR_ROW / 16));
+        const int stream = min((int)blockIdx.y * 16 + r, last);
+        *reinterpret_cast<v4i *>(lds + (pl * 16 + r) * NFM_FIR_RP + 16 * piece) =
+            *reinterpret_cast<const v4i *>(planes + (size_t)pl * plane_bytes + (size_t)stream * dl_pitch + (size_t)tile0 * 16 + 16 * piece);
+    }
+    __syncthreads();
+    const int stream = (int)blockIdx.y * 16 + col;
+    const int8_t *row = lds + col * NFM_FIR_RP + 16 * q;
+    for (int t = wv; t < nt; t += 4) {
+        const int8_t *src = row + 16 * t;
         v4i acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
         for (int ks = 0; ks < NFM_FIR_NK; ks++) {
-            const v4i x0 = *reinterpret_cast<const v4i *>(src + 64 * ks), x1 = *reinterpret_cast<const v4i *>(src + 64 * ks + plane_bytes),
-                      x2 = *reinterpret_cast<const v4i *>(src + 64 * ks + 2 * plane_bytes);
+            const v4i x0 = *reinterpret_cast<const v4i *>(src + 64 * ks), x1 = *reinterpret_cast<const v4i *>(src + 64 * ks + 16 * NFM_FIR_RP),
+                      x2 = *reinterpret_cast<const v4i *>(src + 64 * ks + 32 * NFM_FIR_RP);
             const v4i w0 = A[ks * 3], w1 = A[ks * 3 + 1], w2 = A[ks * 3 + 2];
             acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x0, acc[0], 0, 0, 0);          // 2^32
             acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x1, acc[1], 0, 0, 0);          // 2^24
@@ -84,13 +100,13 @@ __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restric
         float *rv = reinterpret_cast<float *>(&r);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            float t = fmaf((float)acc[0][j], 256.0f, (float)acc[1][j]);
-            t = fmaf(t, 256.0f, (float)acc[2][j]);
-            t = fmaf(t, 256.0f, (float)acc[3][j]);
-            rv[j] = t * scale;
+            float v = fmaf((float)acc[0][j], 256.0f, (float)acc[1][j]);
+            v = fmaf(v, 256.0f, (float)acc[2][j]);
+            v = fmaf(v, 256.0f, (float)acc[3][j]);
+            rv[j] = v * scale;
         }
-        if ((int)blockIdx.y * 16 + col < n_streams)
-            *reinterpret_cast<float4 *>(out + (size_t)stream * out_pitch + 16 * tile + 4 * q) = r;
+        if (stream < n_streams)
+            *reinterpret_cast<float4 *>(out + (size_t)stream * out_pitch + 16 * (size_t)(tile0 + t) + 4 * q) = r;
     }
 }
 
@@ -157,7 +173,7 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (!w->ddc) { delete w; return nullptr; }
     w->max_y = max_block_samples / decimation + 2;
     w->y_pitch = (w->max_y + 15) & ~(size_t)15;
-    w->dl_pitch = (w->max_y + Ld + agc_block + 64 * NFM_FIR_NK + 63) & ~(size_t)63;   // + the last tile's window beyond the valid samples (zero weights)
+    w->dl_pitch = (w->max_y + Ld + agc_block + NFM_FIR_ROW + 63) & ~(size_t)63;        // + the last workgroup's staged span beyond the valid samples (zero weights)
     w->a_pitch = (w->max_y + Ld + agc_block + 15) & ~(size_t)15;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
@@ -236,7 +252,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
         if ((size_t)ne > out_pitch && S > 1) return fail_msg(-3, "nfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, ne);
         {
             const int n_tiles = ne / 16, n_sb = (S + 15) / 16;
-            int gx = (n_tiles + 3) / 4; const int want = (256 * 8 + n_sb - 1) / n_sb; if (gx > want) gx = want; if (gx < 1) gx = 1;
+            const int gx = (n_tiles + NFM_FIR_SPAN - 1) / NFM_FIR_SPAN;
             hipLaunchKernelGGL(k_nfm_deemph_mfma, dim3(gx, n_sb), dim3(256), 0, st, w->d_planes, w->plane_bytes, w->dl_pitch, (const v4i *)w->d_fir_frags, w->fir_scale,
                                w->d_de, w->a_pitch, n_tiles, S);
             CSDR_LAUNCH_CHECK();
