@@ -7,6 +7,7 @@ missing, everything raises.
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 import numpy as np
 
@@ -58,6 +59,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise CsdrAmdError("%s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` first" % LIB_PATH)
+    # One HIP runtime per process: libcsdr_amd.so links the system libamdhip64, torch ships its own copy.  Loaded torch-first, the library
+    # resolves to the copy torch brought (both share devices and streams); loaded the other way round, torch's runtime finds the devices taken
+    # ("no ROCm-capable device").  So if torch is going to be used in this process at all, it has to come first.
+    if "torch" not in sys.modules and not os.environ.get("CSDR_AMD_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, sz, i, fl = C.c_void_p, C.c_size_t, C.c_int, C.c_float
     L.csdr_amd_ctx_create.restype = vp; L.csdr_amd_ctx_create.argtypes = [i, vp]
