@@ -292,9 +292,19 @@ struct csdr_amd_fftfilt {
     csdr_amd_ctx *ctx;
     int fft, taps_len, inp, ovl, n_streams, max_blocks;
     cf32 *d_taps_fft, *d_pad, *d_td, *d_carry[2];
+    cf32 *d_taps_fft_t; float2 *d_tw;      // fft_size 65536: taps spectrum in [k1][k2] order and the twiddle tables of the three-pass transform (fft64k.hip)
     int flip;
     hipfftHandle plan_one, plan_batch; int plan_batch_n;
 };
+
+namespace csdr_amd {
+int fft64k_upload_tables(float2 *d_tw);
+int fft64k_transpose_taps(hipStream_t st, const cf32 *d_taps_fft, cf32 *d_taps_fft_t);
+int fft64k_filter(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int n_blocks, int n_streams, cf32 *d_work, const cf32 *d_taps_fft_t,
+                  const float2 *d_tw, cf32 *d_td);
+int fft64k_filter_oa(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int ovl, int n_blocks, int n_streams, cf32 *d_work, const cf32 *d_taps_fft_t,
+                     const float2 *d_tw, cf32 *d_tails, const cf32 *d_carry_in, cf32 *d_carry_out, cf32 *out, size_t out_pitch);
+}
 
 static int fftfilt_make_batch_plan(csdr_amd_fftfilt *f, int batch)
 {
@@ -317,6 +327,7 @@ int csdr_amd_fftfilt_set_taps(csdr_amd_fftfilt *f, const csdr_complexf *host_tap
     CSDR_HIP(hipStreamSynchronize(f->ctx->stream));
     CSDR_HIP(hipMemcpy(f->d_taps_fft, pad.data(), sizeof(cf32) * f->fft, hipMemcpyHostToDevice));
     CSDR_FFT(hipfftExecC2C(f->plan_one, (hipfftComplex *)f->d_taps_fft, (hipfftComplex *)f->d_taps_fft, HIPFFT_FORWARD));
+    if (f->d_taps_fft_t) return fft64k_transpose_taps(f->ctx->stream, f->d_taps_fft, f->d_taps_fft_t);
     return 0;
 }
 
@@ -333,6 +344,12 @@ csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_td, sizeof(cf32) * tot);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_carry[0], sizeof(cf32) * (size_t)n_streams * (f->ovl + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_carry[1], sizeof(cf32) * (size_t)n_streams * (f->ovl + 1));
+    f->d_taps_fft_t = nullptr; f->d_tw = nullptr;
+    if (fft_size == 65536 && !getenv("CSDR_AMD_FFT64K_OFF")) {          // config 3: the three-pass transform of fft64k.hip instead of hipFFT
+        if (e == hipSuccess) e = hipMalloc((void **)&f->d_taps_fft_t, sizeof(cf32) * fft_size);
+        if (e == hipSuccess) e = hipMalloc((void **)&f->d_tw, sizeof(float2) * 512);
+        if (e == hipSuccess && fft64k_upload_tables(f->d_tw)) e = hipErrorUnknown;
+    }
     if (e != hipSuccess) { fail(e, "hipMalloc(fftfilt)", __FILE__, __LINE__); delete f; return nullptr; }
     if (hipfftPlan1d(&f->plan_one, fft_size, HIPFFT_C2C, 1) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlan1d(%d) failed", fft_size); delete f; return nullptr; }
     hipfftSetStream(f->plan_one, ctx->stream);
@@ -346,6 +363,7 @@ void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f)
     (void)hipStreamSynchronize(f->ctx->stream);
     hipfftDestroy(f->plan_one); if (f->plan_batch_n) hipfftDestroy(f->plan_batch);
     (void)hipFree(f->d_taps_fft); (void)hipFree(f->d_pad); (void)hipFree(f->d_td); (void)hipFree(f->d_carry[0]); (void)hipFree(f->d_carry[1]);
+    (void)hipFree(f->d_taps_fft_t); (void)hipFree(f->d_tw);
     delete f;
 }
 
@@ -365,12 +383,24 @@ int csdr_amd_fftfilt_process(csdr_amd_fftfilt *f, const csdr_complexf *in, csdr_
     if (n_blocks > f->max_blocks) return fail_msg(-3, "fftfilt: %d blocks exceed max_blocks %d", n_blocks, f->max_blocks);
     hipStream_t st = f->ctx->stream;
     const int batch = f->n_streams * n_blocks;
-    int rc = fftfilt_make_batch_plan(f, batch); if (rc) return rc;
+    int rc = 0;
+    if (f->d_taps_fft_t && f->ovl <= f->inp) {
+        // three passes + a pass over the overlap regions only; the inverse pass writes the output itself (d_td only holds the blocks' tails)
+        rc = fft64k_filter_oa(st, in, in_pitch, f->inp, f->ovl, n_blocks, f->n_streams, f->d_pad, f->d_taps_fft_t, f->d_tw, f->d_td, f->d_carry[f->flip], f->d_carry[f->flip ^ 1], out, out_pitch);
+        if (rc) return rc;
+        if (f->ovl > 0) f->flip ^= 1;
+        return 0;
+    }
+    if (f->d_taps_fft_t) {
+        rc = fft64k_filter(st, in, in_pitch, f->inp, n_blocks, f->n_streams, f->d_pad, f->d_taps_fft_t, f->d_tw, f->d_td); if (rc) return rc;
+    } else {
+    rc = fftfilt_make_batch_plan(f, batch); if (rc) return rc;
     hipLaunchKernelGGL(k_oa_frame, dim3(cdiv(f->fft, 256), n_blocks, f->n_streams), dim3(256), 0, st, in, in_pitch, f->d_pad, f->fft, f->inp, n_blocks); CSDR_LAUNCH_CHECK();
     CSDR_FFT(hipfftExecC2C(f->plan_batch, (hipfftComplex *)f->d_pad, (hipfftComplex *)f->d_pad, HIPFFT_FORWARD));
     const size_t total = (size_t)batch * f->fft;
     hipLaunchKernelGGL(k_bin_product, dim3(cdiv(total, 256)), dim3(256), 0, st, f->d_pad, f->d_taps_fft, f->fft, total); CSDR_LAUNCH_CHECK();
     CSDR_FFT(hipfftExecC2C(f->plan_batch, (hipfftComplex *)f->d_pad, (hipfftComplex *)f->d_td, HIPFFT_BACKWARD));
+    }
     const float inv_n = 1.0f / (float)f->fft;
     hipLaunchKernelGGL(k_oa_stitch, dim3(cdiv(f->inp, 256), n_blocks, f->n_streams), dim3(256), 0, st, f->d_td, f->d_carry[f->flip], out, out_pitch,
                        f->fft, f->inp, f->ovl, n_blocks, inv_n); CSDR_LAUNCH_CHECK();

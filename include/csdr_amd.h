@@ -328,6 +328,8 @@ csdr_amd_ddc *csdr_amd_nfm_front_end(csdr_amd_nfm *w);
  * n0: window base sample (multiple of 8); window: 512 raw bytes; ctab2: (cos, sin) of chunks n0>>10, +1; out16: 16 rows. */
 int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const float *taps, long long n0, const uint8_t *window,
                                 const float *ctab2, float *out16);
+/* Test hook: the register-level 16-point butterfly of the three-pass 65536-point transform (fft64k.hip) on the CPU; 16 interleaved complex floats */
+void csdr_amd_debug_dft16(const float *in32, float *out32, int inverse);
 /* Test hook: front-end kernel of the following csdr_amd_wfm_process calls: -1 = default (the first whose preconditions hold of:) 0 = sequential
  * (k_wfm_mfma_seq), 1 = octet (k_wfm_mfma_oct), 2 = quad (k_wfm_mfma_wg), 3 = per-wave (k_wfm_mfma). */
 void csdr_amd_debug_wfm_select(int kernel);

@@ -113,3 +113,21 @@ def test_reference_client_links_against_our_library(libpath, tmp_path):
     assert r.returncode == 0, r.stderr
     import shutil
     shutil.copy(exe, os.path.join(ROOT, "tests", "data", "dropin_client.bin"))      # travels to the GPU box for the -m gpu run
+
+
+def test_dft16_butterfly():
+    """The register-level 16-point butterfly of the three-pass 65536-point transform (csdr_amd/csrc/fft64k.hip), forward and inverse, against numpy."""
+    import ctypes as C
+    import numpy as np
+    import csdr_amd
+    L = csdr_amd.lib()
+    L.csdr_amd_debug_dft16.restype = None
+    L.csdr_amd_debug_dft16.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(16)
+    for _ in range(8):
+        x = (rng.uniform(-1, 1, 16) + 1j * rng.uniform(-1, 1, 16)).astype(np.complex64)
+        y = np.zeros(16, np.complex64)
+        L.csdr_amd_debug_dft16(x.ctypes.data, y.ctypes.data, 0)
+        assert np.abs(y - np.fft.fft(x.astype(np.complex128))).max() < 2e-6
+        L.csdr_amd_debug_dft16(x.ctypes.data, y.ctypes.data, 1)
+        assert np.abs(y - 16 * np.fft.ifft(x.astype(np.complex128))).max() < 2e-6

@@ -220,6 +220,20 @@ def test_bandpass_fir_fft_c3(gpu, port, ntaps):
     assert relrms(a[:20000], direct) < TOL
 
 
+def test_bandpass_fir_fft_c3_streams(gpu, port):
+    """fft 65536 (the three-pass transform of fft64k.hip) on several streams, blocks split over calls; the hipFFT path gives the same result."""
+    rng = np.random.default_rng(33)
+    fft, ntaps = 65536, 1023
+    inp = fft - ntaps + 1
+    x = np.stack([crand(rng, inp * 3) for _ in range(3)])
+    taps = port.firdes_bandpass_c(ntaps, -0.3, 0.05)
+    a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=2)
+    for s in range(3):
+        want = np.convolve(x[s, :30000].astype(np.complex128), taps.astype(np.complex128))[:30000]
+        assert relrms(a[s, :30000], want) < TOL
+    assert relrms(a[1], port.bandpass_fir_fft_cc(x[1], taps, fft)) < TOL
+
+
 def test_bandpass_small_and_chained_overlap(gpu, port):
     rng = np.random.default_rng(5)
     for ntaps, fft in [(79, 256), (601, 1024)]:                        # second case: input_size (424) < overlap (600)
