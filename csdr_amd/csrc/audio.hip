@@ -131,16 +131,24 @@ __global__ void k_agc_gains(float *__restrict__ peaks, float *__restrict__ gains
     }
 }
 __global__ __launch_bounds__(256) void k_agc_apply(const float *__restrict__ in, float *__restrict__ out, size_t in_pitch, size_t out_pitch,
-                                                   int block, int n_blocks, const float *__restrict__ state, const float *__restrict__ gains)
-{   // grid (n_blocks, n_streams): output block j = sequence block j with the gain ramped from g[j] to g[j+1] (:973-978)
+                                                   int block, int n_blocks, const float *__restrict__ state, const float *__restrict__ gains,
+                                                   int16_t *__restrict__ out_s16, size_t s16_pitch)
+{   // grid (n_blocks, n_streams): output block j = sequence block j with the gain ramped from g[j] to g[j+1] (:973-978);
+    // optionally convert_f_s16 (libcsdr.c:2397, x86 truncation semantics) of the result in the same pass (chains that end in `| convert_f_s16`)
     const int j = blockIdx.x; const size_t s = blockIdx.y;
     const float *x = agc_seq_block(state + s * (2 * block + 4), in + s * in_pitch, block, j);
     const float g0 = gains[s * (n_blocks + 1) + j], g1 = gains[s * (n_blocks + 1) + j + 1];
-    float *y = out + s * out_pitch + (size_t)j * block;
+    float *y = out ? out + s * out_pitch + (size_t)j * block : nullptr;
+    int16_t *z = out_s16 ? out_s16 + s * s16_pitch + (size_t)j * block : nullptr;
     for (int k = threadIdx.x; k < block; k += 256) {
         const float r = (float)k / (float)block;
         const float g = (float)((double)g0 * (1.0 - (double)r) + (double)(g1 * r));
-        y[k] = x[k] * g;
+        const float v = x[k] * g;
+        if (y) y[k] = v;
+        if (z) {
+            const float scaled = v * 32767.0f;
+            z[k] = (int16_t)((scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000);
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_agc_update(const float *__restrict__ in, size_t in_pitch, int block, int n_blocks,
@@ -236,16 +244,27 @@ int csdr_amd_deemphasis_wfm_ff(csdr_amd_ctx *c, const float *in, float *out, int
 int csdr_amd_fastagc_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams, int n_blocks, int block,
                         size_t in_pitch, size_t out_pitch, float reference, float *state_io)
 {
+    return csdr_amd::fastagc_ff_s16(c, in, out, nullptr, n_streams, n_blocks, block, in_pitch, out_pitch, 0, reference, state_io);
+}
+
+} // extern "C"
+
+// fastagc_ff with an optional second output: the same samples through convert_f_s16 (used by the NFM chain object; out may be null)
+int csdr_amd::fastagc_ff_s16(csdr_amd_ctx *c, const float *in, float *out, int16_t *out_s16, int n_streams, int n_blocks, int block,
+                             size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io)
+{
     if (n_blocks <= 0 || n_streams <= 0) return 0;
     float *peaks = (float *)c->get_scratch(3, sizeof(float) * (size_t)n_streams * (2 * n_blocks + 3));
     if (!peaks) return -2;
     float *gains = peaks + (size_t)n_streams * (n_blocks + 2);
     hipLaunchKernelGGL(k_agc_peaks, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, peaks); CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_agc_gains, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, peaks, gains, state_io, block, n_blocks, n_streams, reference); CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_agc_apply, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, out, in_pitch, out_pitch, block, n_blocks, state_io, gains); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_agc_apply, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, out, in_pitch, out_pitch, block, n_blocks, state_io, gains, out_s16, s16_pitch); CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_agc_update, dim3(1, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, state_io, peaks, gains); CSDR_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" {
 
 csdr_amd_fracdec *csdr_amd_fracdec_create(float rate, int num_poly_points, const float *host_taps, int taps_length)
 {   // fractional_decimator_ff_init libcsdr.c:715-748

@@ -24,6 +24,10 @@ static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) 
 
 enum { SCRATCH_SLOTS = 8 };
 
+// fastagc_ff (audio.hip) with an optional convert_f_s16 output written in the same pass; `out` may be null
+int fastagc_ff_s16(struct ::csdr_amd_ctx *c, const float *in, float *out, int16_t *out_s16, int n_streams, int n_blocks, int block,
+                   size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io);
+
 } // namespace csdr_amd
 
 struct csdr_amd_ctx {

@@ -128,18 +128,6 @@ __global__ void k_nfm_store_last(const cf32 *__restrict__ y, size_t y_pitch, int
     if (s < n_streams) last[s] = y[(size_t)s * y_pitch + n - 1];
 }
 
-// convert_f_s16 (libcsdr.c:2397: (short)(int)(x*32767), x86 truncation semantics) of the AGC output into the caller's buffers
-__global__ __launch_bounds__(256) void k_nfm_out(const float *__restrict__ agc, size_t agc_pitch, int n, int16_t *__restrict__ s16, float *__restrict__ af, size_t out_pitch)
-{
-    const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
-    const float x = agc[(size_t)s * agc_pitch + k];
-    const float scaled = x * 32767.0f;
-    const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
-    s16[(size_t)s * out_pitch + k] = (int16_t)iv;
-    if (af) af[(size_t)s * out_pitch + k] = x;
-}
-
 } // namespace
 
 struct csdr_amd_nfm {
@@ -150,7 +138,7 @@ struct csdr_amd_nfm {
     cf32 *d_y; size_t y_pitch; cf32 *d_last;
     int8_t *d_planes; size_t plane_bytes; size_t dl_pitch; int dl_fill;   // limited demodulator output (three digit planes) waiting for the de-emphasis filter
     void *d_fir_frags; float fir_scale;             // de-emphasis taps as int8 digit fragments; scale of the recombined product
-    float *d_de, *d_agc; size_t a_pitch;            // de-emphasised blocks, AGC output
+    float *d_de; size_t a_pitch;                    // de-emphasised blocks
     float *d_agc_state;
     size_t max_y;
 };
@@ -183,7 +171,6 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     alloc((void **)&w->d_planes, 3 * w->plane_bytes);
     alloc(&w->d_fir_frags, (size_t)NFM_FIR_NK * 3 * 64 * 16);
     alloc((void **)&w->d_de, sizeof(float) * w->a_pitch * n_streams);
-    alloc((void **)&w->d_agc, sizeof(float) * w->a_pitch * n_streams);
     alloc((void **)&w->d_agc_state, sizeof(float) * (size_t)n_streams * (2 * agc_block + 4));
     {   // Toeplitz band of the de-emphasis taps as three base-256 digits: row o (output), column t (input): taps[t - o]
         std::vector<int8_t> fr((size_t)NFM_FIR_NK * 3 * 64 * 16, 0);
@@ -213,7 +200,7 @@ void csdr_amd_nfm_destroy(csdr_amd_nfm *w)
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     if (w->ddc) csdr_amd_ddc_destroy(w->ddc);
-    (void)hipFree(w->d_y); (void)hipFree(w->d_last); (void)hipFree(w->d_planes); (void)hipFree(w->d_fir_frags); (void)hipFree(w->d_de); (void)hipFree(w->d_agc);
+    (void)hipFree(w->d_y); (void)hipFree(w->d_last); (void)hipFree(w->d_planes); (void)hipFree(w->d_fir_frags); (void)hipFree(w->d_de);
     (void)hipFree(w->d_agc_state);
     delete w;
 }
@@ -257,10 +244,9 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
                                w->d_de, w->a_pitch, n_tiles, S);
             CSDR_LAUNCH_CHECK();
         }
-        int rc = csdr_amd_fastagc_ff(c, w->d_de, w->d_agc, S, nb, w->agc_block, w->a_pitch, w->a_pitch, w->agc_ref, w->d_agc_state);
+        // fastagc_ff | convert_f_s16 in one pass (the float audio is written only when the caller wants the parity tap)
+        int rc = fastagc_ff_s16(c, w->d_de, audio_f, audio_s16, S, nb, w->agc_block, w->a_pitch, out_pitch, out_pitch, w->agc_ref, w->d_agc_state);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_nfm_out, dim3(cdiv(ne, 256), S), dim3(256), 0, st, w->d_agc, w->a_pitch, ne, audio_s16, audio_f, out_pitch);
-        CSDR_LAUNCH_CHECK();
     }
     // keep the unconsumed filter input in front
     const int rem = n_in - ne;
