@@ -98,6 +98,16 @@ def main():
     L.csdr_amd_ddc_kernel_time(fe, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_ddc_kernel_name(fe).decode()
     if rank == 0:
+        traffic = None; traffic_src = None
+        for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):       # committed rocprofv3 PMC summary of the same kernel and workload, if any
+            if f.endswith("_pmc_traffic.json") and "nfm" in f:
+                try:
+                    d = json.load(open(os.path.join(ROOT, "profiles", f)))
+                    w = d.get("workload", {})
+                    if d.get("kernel", "").startswith(kname) and w.get("channels_per_gpu") == S and w.get("block_samples_per_channel") == T and "FRONT END ONLY" not in w.get("workload", ""):
+                        traffic = d["traffic_bytes_per_launch"]; traffic_src = "profiles/" + f + " (rocprofv3 PMC passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                except Exception:  # noqa: BLE001
+                    pass
         samples = S * T * args.steps * world
         k_avg_ms = kms.value / max(kl.value, 1)
         algo = (2.0 + 8.0 / D) * S * T                      # front-end kernel: 2 B of u8 IQ in + one complexf per D samples out
@@ -109,7 +119,7 @@ def main():
                           "channels_per_gpu": S, "block_samples_per_channel": T, "channel_rate_sps": 2400000,
                           "realtime_channels_equivalent": round(samples / wall / 2.4e6, 1), "parallelism": "channels sharded, no data-path collective"},
                "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(algo / (k_avg_ms * 1e-3) / 1e9, 1) if k_avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_avg_ms else None, "traffic": None,
+                            "frac": round(algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_avg_ms else None, "traffic": traffic, "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": algo, "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches_timed": kl.value,
                             "hip_event_ms_per_step_all_kernels": round(ev_ms / args.steps, 4)},
                "outputs_per_step_per_channel": produced // max(args.steps, 1)}
