@@ -838,11 +838,12 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
     const float one_minus = 1 - p.alpha;
     const bool iir_lane = FUSE && wv == 0 && lane < 16;
     const bool iir_wave = FUSE && wv == 0;
-    float bp[9];                                                                     // b^0 .. b^8
+    constexpr int QL = TPG, SPS = 4 * TPG;                                           // samples per lane of the scan (a quarter of a step), samples per step and stream
+    float bp[QL + 1];                                                                // b^0 .. b^QL
     bp[0] = 1.f;
 #pragma unroll
-    for (int j = 1; j <= 8; j++) bp[j] = bp[j - 1] * one_minus;
-    const float b16 = bp[8] * bp[8], b24 = b16 * bp[8];
+    for (int j = 1; j <= QL; j++) bp[j] = bp[j - 1] * one_minus;
+    const float b2q = bp[QL] * bp[QL], b3q = b2q * bp[QL];
     if (FUSE && iir_lane && blockIdx.y == 0 && s0 + lane < p.n_streams) {
         // first segment: exact carried state (NaN reset as libcsdr.c:1092), then the leading edge tiles' samples in order
         yst = p.last_in[s0 + lane]; if (yst != yst) yst = 0.f;
@@ -860,8 +861,8 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
     auto emit = [&](int g) {                                                         // convert_f_s16 + store of step g's 16 x 32 samples, one per thread
         if (g < 0) return;
         const int vt = min(TPG, n_it - g * TPG);
-        const int srow = tid >> 5, k = tid & 31;
-        if (tid < 16 * 4 * TPG && (k >> 2) < vt && s0 + srow < p.n_streams) {
+        const int srow = tid / SPS, k = tid % SPS;
+        if (tid < 16 * SPS && (k >> 2) < vt && s0 + srow < p.n_streams) {
             const float e = lds_out[(g % 3) * (16 * OCT_OUTP) + srow * OCT_OUTP + k];
             const long long idx = 4 * (t0 + (long long)g * TPG) + k - p.j_first;
             const float scaled = e * 32767.0f;                                       // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
@@ -933,29 +934,31 @@ __global__ __launch_bounds__(256 * NT) void k_wfm_mfma_seq(const uint8_t *__rest
         if (FUSE) {
             emit(gi - 1);                                                            // the previous step's audio: filtered by wave 0 before it came to this barrier
             if (iir_wave) {                                                          // this step's 32 samples of stream s0 + col through the de-emphasis, in place
-                float *row = lout + col * OCT_OUTP + 8 * q;                          // this lane's quarter: samples 8q .. 8q+7
-                const int nv = 4 * min(TPG, n_it - gi * TPG);                        // valid samples of the step (a multiple of 4; 32 except in a segment's last step)
-                float4 xa = *reinterpret_cast<const float4 *>(row), xb = *reinterpret_cast<const float4 *>(row + 4);
-                float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w}, z[8];
-                if (8 * q + 4 >= nv) { x[4] = x[5] = x[6] = x[7] = 0.f; }            // samples behind the valid ones do not exist: feed zeros (their outputs are not stored)
-                if (8 * q >= nv) { x[0] = x[1] = x[2] = x[3] = 0.f; }
+                float *row = lout + col * OCT_OUTP + QL * q;                         // this lane's quarter: samples QL q .. QL q + QL - 1
+                const int nv = 4 * min(TPG, n_it - gi * TPG);                        // valid samples of the step (a multiple of 4; all except in a segment's last step)
+                float x[QL], z[QL], y[QL];
+#pragma unroll
+                for (int j = 0; j < QL; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row + j);
+                    const bool ok = QL * q + j < nv;                                 // samples behind the valid ones do not exist: feed zeros (their outputs are not stored)
+                    x[j] = ok ? v.x : 0.f; x[j + 1] = ok ? v.y : 0.f; x[j + 2] = ok ? v.z : 0.f; x[j + 3] = ok ? v.w : 0.f;
+                }
                 z[0] = p.alpha * x[0];
 #pragma unroll
-                for (int j = 1; j < 8; j++) z[j] = p.alpha * x[j] + one_minus * z[j - 1];
-                // start state of this quarter: S_q = b^(8q) y_prev + sum_{i<q} b^(8(q-1-i)) z7(i)
-                const float z7_0 = __shfl(z[7], col, 64), z7_1 = __shfl(z[7], col + 16, 64), z7_2 = __shfl(z[7], col + 32, 64);
+                for (int j = 1; j < QL; j++) z[j] = p.alpha * x[j] + one_minus * z[j - 1];
+                // start state of this quarter: S_q = b^(QL q) y_prev + sum_{i<q} b^(QL (q-1-i)) z_end(i)
+                const float ze_0 = __shfl(z[QL - 1], col, 64), ze_1 = __shfl(z[QL - 1], col + 16, 64), ze_2 = __shfl(z[QL - 1], col + 32, 64);
                 float S = yst;
-                if (q == 1) S = bp[8] * yst + z7_0;
-                else if (q == 2) S = b16 * yst + (bp[8] * z7_0 + z7_1);
-                else if (q == 3) S = b24 * yst + (b16 * z7_0 + (bp[8] * z7_1 + z7_2));
-                float y[8];
+                if (q == 1) S = bp[QL] * yst + ze_0;
+                else if (q == 2) S = b2q * yst + (bp[QL] * ze_0 + ze_1);
+                else if (q == 3) S = b3q * yst + (b2q * ze_0 + (bp[QL] * ze_1 + ze_2));
 #pragma unroll
-                for (int j = 0; j < 8; j++) y[j] = z[j] + bp[j + 1] * S;
-                *reinterpret_cast<float4 *>(row) = make_float4(y[0], y[1], y[2], y[3]);
-                *reinterpret_cast<float4 *>(row + 4) = make_float4(y[4], y[5], y[6], y[7]);
-                // new carried state = the value after the last VALID sample (nv - 1): it lives in quarter (nv - 1) / 8 at position (nv - 1) % 8
-                const int lq = (nv - 1) >> 3, lj = (nv - 1) & 7;
-                float ylast = y[7];
+                for (int j = 0; j < QL; j++) y[j] = z[j] + bp[j + 1] * S;
+#pragma unroll
+                for (int j = 0; j < QL; j += 4) *reinterpret_cast<float4 *>(row + j) = make_float4(y[j], y[j + 1], y[j + 2], y[j + 3]);
+                // new carried state = the value after the last VALID sample (nv - 1): it lives in quarter (nv - 1) / QL at position (nv - 1) % QL
+                const int lq = (nv - 1) / QL, lj = (nv - 1) % QL;
+                float ylast = y[QL - 1];
                 if (lj == 3) ylast = y[3];
                 yst = __shfl(ylast, col + 16 * lq, 64);
             }
@@ -1078,17 +1081,23 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
             sp.alpha = 0; sp.last_in = nullptr; sp.seg_state = nullptr; sp.s16 = nullptr; sp.af = nullptr; sp.out_pitch = 0; sp.j_first = j_first; sp.skip = 0;
             if (fuse) { sp.alpha = back->alpha; sp.last_in = back->last_in; sp.seg_state = back->seg_state; sp.s16 = back->s16; sp.af = back->af; sp.out_pitch = back->out_pitch; sp.skip = back->skip; }
             const size_t lds = (size_t)16 * SEQ_RP + (fuse ? 3 : 2) * 16 * OCT_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
-            static bool done[2] = {false, false};
-            if (!done[fuse]) {
-                if (fuse) CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_seq<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                else CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_mfma_seq<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                done[fuse] = true;
+            static int env_nt = 0;                                                       // CSDR_AMD_WFM_SEQ_NT: 2 = 8 waves take 8 tiles per step (default), 1 = 4 waves x 4 tiles (deeper look-ahead in the same ring)
+            if (!env_nt) { const char *e = getenv("CSDR_AMD_WFM_SEQ_NT"); env_nt = (e && atoi(e) == 1) ? 1 : 2; }
+            const int nt = env_nt;
+            static bool done[4] = {false, false, false, false};
+            if (!done[2 * (nt - 1) + fuse]) {
+                const void *fn = nt == 2 ? (fuse ? (const void *)k_wfm_mfma_seq<2, true> : (const void *)k_wfm_mfma_seq<2, false>)
+                                         : (fuse ? (const void *)k_wfm_mfma_seq<1, true> : (const void *)k_wfm_mfma_seq<1, false>);
+                CSDR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                done[2 * (nt - 1) + fuse] = true;
             }
             // the edge tiles first: the fused back end of the first segment walks through the leading ones' samples
             rc = launch_edges(tile_first, sa - 1, sb_ + 1, tile_last); if (rc) return rc;
             if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
-            if (fuse) hipLaunchKernelGGL((k_wfm_mfma_seq<2, true>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp);
-            else hipLaunchKernelGGL((k_wfm_mfma_seq<2, false>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp);
+#define SEQ_LAUNCH(NTV, FV) hipLaunchKernelGGL((k_wfm_mfma_seq<NTV, FV>), dim3(n_wsb, n_seg), dim3(256 * NTV), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, demod, demod_pitch, sp)
+            if (nt == 2) { if (fuse) SEQ_LAUNCH(2, true); else SEQ_LAUNCH(2, false); }
+            else         { if (fuse) SEQ_LAUNCH(1, true); else SEQ_LAUNCH(1, false); }
+#undef SEQ_LAUNCH
             CSDR_LAUNCH_CHECK();
             if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
             if (fuse) {
