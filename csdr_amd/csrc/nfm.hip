@@ -110,6 +110,36 @@ __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restric
     }
 }
 
+// Toeplitz band of the de-emphasis taps as three base-256 digits: row o (output), column t (input): taps[t - o]; lane / byte layout of the A
+// operand of v_mfma_i32_16x16x64_i8.  Returns the scale of the recombined product:
+//   value = (a0 2^24 + a1 2^16 + a2 2^8 + a3) * 2^8 * (gmax / 2^22) * (max_amp / NFM_XQ)
+float nfm_fir_table(const float *taps, int Ld, float limit_max, std::vector<int8_t> &fr)
+{
+    fr.assign((size_t)NFM_FIR_NK * 3 * 64 * 16, 0);
+    double gmax = 0;
+    for (int k = 0; k < Ld; k++) gmax = fmax(gmax, fabs((double)taps[k]));
+    gmax *= 1.0001; if (gmax == 0) gmax = 1;
+    const double qscale = 4194304.0 / gmax;
+    for (int o = 0; o < 16; o++) for (int tp = 0; tp < Ld; tp++) {
+        const int t = o + tp, ks = t / 64, b = t % 64;
+        long qv = lrint((double)taps[tp] * qscale);
+        const int w2 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w2) / 256;
+        const int w1 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w1) / 256;
+        const int dig[3] = {(int)qv, w1, w2};
+        for (int l = 0; l < 3; l++) fr[((size_t)(ks * 3 + l) * 64 + (16 * (b / 16) + o)) * 16 + b % 16] = (int8_t)dig[l];
+    }
+    return (float)(256.0 * (gmax / 4194304.0) * ((double)limit_max / (double)NFM_XQ));
+}
+
+// the digits k_nfm_demod_limit stores for a limited sample v (|v| <= max_amp)
+inline void nfm_sample_digits(float v, float q_per_amp, int (&d)[3])
+{
+    int qv = (int)lrintf(v * q_per_amp);
+    d[2] = ((qv + 128) & 255) - 128; qv = (qv - d[2]) >> 8;
+    d[1] = ((qv + 128) & 255) - 128; qv = (qv - d[1]) >> 8;
+    d[0] = qv;
+}
+
 // bytes: buf[s][0 .. count) = buf[s][src_off .. src_off + count) on each of the three planes (ranges may overlap; count <= 2048)
 __global__ __launch_bounds__(256) void k_nfm_move_front_planes(int8_t *__restrict__ planes, size_t plane_bytes, size_t pitch, int src_off, int count)
 {
@@ -172,22 +202,9 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     alloc(&w->d_fir_frags, (size_t)NFM_FIR_NK * 3 * 64 * 16);
     alloc((void **)&w->d_de, sizeof(float) * w->a_pitch * n_streams);
     alloc((void **)&w->d_agc_state, sizeof(float) * (size_t)n_streams * (2 * agc_block + 4));
-    {   // Toeplitz band of the de-emphasis taps as three base-256 digits: row o (output), column t (input): taps[t - o]
-        std::vector<int8_t> fr((size_t)NFM_FIR_NK * 3 * 64 * 16, 0);
-        double gmax = 0;
-        for (int k = 0; k < Ld; k++) gmax = fmax(gmax, fabs((double)dt[k]));
-        gmax *= 1.0001; if (gmax == 0) gmax = 1;
-        const double qscale = 4194304.0 / gmax;
-        for (int o = 0; o < 16; o++) for (int tp = 0; tp < Ld; tp++) {
-            const int t = o + tp, ks = t / 64, b = t % 64;
-            long qv = lrint((double)dt[tp] * qscale);
-            const int w2 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w2) / 256;
-            const int w1 = (int)(((qv + 128) % 256 + 256) % 256) - 128; qv = (qv - w1) / 256;
-            const int dig[3] = {(int)qv, w1, w2};
-            for (int l = 0; l < 3; l++) fr[((size_t)(ks * 3 + l) * 64 + (16 * (b / 16) + o)) * 16 + b % 16] = (int8_t)dig[l];
-        }
-        // value = (a0 2^24 + a1 2^16 + a2 2^8 + a3) * 2^8 * (gmax / 2^22) * (max_amp / NFM_XQ)
-        w->fir_scale = (float)(256.0 * (gmax / 4194304.0) * ((double)limit_max / (double)NFM_XQ));
+    {
+        std::vector<int8_t> fr;
+        w->fir_scale = nfm_fir_table(dt, Ld, limit_max, fr);
         if (e == hipSuccess) e = hipMemcpy(w->d_fir_frags, fr.data(), fr.size(), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) { fail(e, "hipMalloc/hipMemcpy(nfm state)", __FILE__, __LINE__); csdr_amd_nfm_destroy(w); return nullptr; }
@@ -260,3 +277,36 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
 }
 
 } // extern "C"
+
+// Test hook (tests/test_abi_cpu.py): ONE tile of k_nfm_deemph_mfma on the CPU -- the digit planes of 256 limited samples (as k_nfm_demod_limit
+// stores them), the Toeplitz digit table and the four accumulator classes, exactly as the kernel combines them.  x: 256 floats, |x| <= max_amp;
+// out16: the 16 outputs out[i] = sum_t taps[t] x[i + t].
+extern "C" int csdr_amd_debug_nfm_deemph_tile(int audio_rate, float max_amp, const float *x, float *out16)
+{
+    const float *dt = nullptr;
+    const int Ld = csdr_amd_nfm_deemph_taps(audio_rate, &dt);
+    if (!Ld || Ld + 15 > 64 * NFM_FIR_NK || !(max_amp > 0)) return -1;
+    std::vector<int8_t> fr;
+    const float scale = nfm_fir_table(dt, Ld, max_amp, fr);
+    const float q_per_amp = NFM_XQ / max_amp;
+    int xd[256][3];
+    for (int t = 0; t < 256; t++) nfm_sample_digits(x[t], q_per_amp, xd[t]);
+    for (int o = 0; o < 16; o++) {
+        long acc[4] = {0, 0, 0, 0};
+        for (int ks = 0; ks < NFM_FIR_NK; ks++) for (int b = 0; b < 64; b++) {
+            const int t = 64 * ks + b;
+            int w[3];
+            for (int l = 0; l < 3; l++) w[l] = fr[((size_t)(ks * 3 + l) * 64 + (16 * (b / 16) + o)) * 16 + b % 16];
+            acc[0] += (long)w[0] * xd[t][0];
+            acc[1] += (long)w[0] * xd[t][1] + (long)w[1] * xd[t][0];
+            acc[2] += (long)w[0] * xd[t][2] + (long)w[1] * xd[t][1] + (long)w[2] * xd[t][0];
+            acc[3] += (long)w[1] * xd[t][2] + (long)w[2] * xd[t][1];
+        }
+        float v = fmaf((float)acc[0], 256.0f, (float)acc[1]);
+        v = fmaf(v, 256.0f, (float)acc[2]);
+        v = fmaf(v, 256.0f, (float)acc[3]);
+        out16[o] = v * scale;
+    }
+    return 0;
+}
+

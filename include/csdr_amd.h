@@ -330,6 +330,9 @@ int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const flo
                                 const float *ctab2, float *out16);
 /* Test hook: the register-level 16-point butterfly of the three-pass 65536-point transform (fft64k.hip) on the CPU; 16 interleaved complex floats */
 void csdr_amd_debug_dft16(const float *in32, float *out32, int inverse);
+/* Test hook: one tile (16 outputs from 256 limited samples) of the NFM chain's matrix-core de-emphasis FIR on the CPU: digit planes,
+ * Toeplitz digit table and accumulator classes as k_nfm_deemph_mfma combines them. */
+int csdr_amd_debug_nfm_deemph_tile(int audio_rate, float max_amp, const float *x, float *out16);
 /* Test hook: front-end kernel of the following csdr_amd_wfm_process calls: -1 = default (the first whose preconditions hold of:) 0 = sequential
  * (k_wfm_mfma_seq), 1 = octet (k_wfm_mfma_oct), 2 = quad (k_wfm_mfma_wg), 3 = per-wave (k_wfm_mfma). */
 void csdr_amd_debug_wfm_select(int kernel);

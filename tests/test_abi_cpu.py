@@ -131,3 +131,29 @@ def test_dft16_butterfly():
         assert np.abs(y - np.fft.fft(x.astype(np.complex128))).max() < 2e-6
         L.csdr_amd_debug_dft16(x.ctypes.data, y.ctypes.data, 1)
         assert np.abs(y - 16 * np.fft.ifft(x.astype(np.complex128))).max() < 2e-6
+
+
+def test_nfm_deemph_digit_planes():
+    """The NFM chain's de-emphasis FIR on int8 digit planes (csdr_amd/csrc/nfm.hip): 24-bit fixed-point samples x 23-bit taps with the
+    low x low digit pair dropped must reproduce the float64 convolution to ~1e-7 of full scale."""
+    import ctypes as C
+    import os
+    import numpy as np
+    import csdr_amd
+    L = csdr_amd.lib()
+    fn = L.csdr_amd_debug_nfm_deemph_tile
+    fn.argtypes = [C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tabs = np.load(os.path.join(root, "tests", "golden", "nfm_deemph_taps.npz"))
+    rng = np.random.default_rng(21)
+    out = np.zeros(16, np.float32)
+    for sr, amp in ((48000, 1.0), (44100, 0.5), (8000, 2.0), (11025, 1.0)):
+        taps = tabs["sr%d" % sr].astype(np.float64)
+        for trial in range(4):
+            x = rng.uniform(-amp, amp, 256).astype(np.float32)
+            if trial == 0:
+                x[:8] = [amp, -amp, 0.0, amp * 1e-6, -amp * 1e-6, amp / 3, -amp / 3, amp]     # full scale, zero and tiny values
+            assert fn(sr, amp, x.ctypes.data, out.ctypes.data) == 0
+            want = np.array([np.dot(taps, x[i:i + taps.size].astype(np.float64)) for i in range(16)])
+            assert np.abs(out - want).max() < 4e-7 * amp * np.abs(taps).sum(), (sr, np.abs(out - want).max())
+    assert fn(12345, 1.0, x.ctypes.data, out.ctypes.data) == -1
