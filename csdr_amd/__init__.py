@@ -645,7 +645,7 @@ class Context:
         if not w:
             raise CsdrAmdError(self.err())
         di = self.upload(xx)
-        apitch = n // decimation + 64
+        apitch = n // decimation + 1024 + 64
         ds = self.alloc(2 * S * apitch); df = self.alloc(4 * S * apitch)
         pos = 0; na = 0
         while pos < n:
@@ -678,19 +678,23 @@ class Context:
         nd = self.check(L.csdr_amd_fir_decimate_cc(self.h, d_sh.ptr, d_dec.ptr, S, n, n, pd, decimation, taps.ptr, nt), "fir_decimate_cc")
         d_dem = self.alloc(4 * S * pd + 64); d_last = self.upload(np.zeros(S, c64))
         self.check(L.csdr_amd_fmdemod_quadri_cf(self.h, d_dec.ptr, d_dem.ptr, S, nd, pd, pd, d_last.ptr), "fmdemod")
-        d_lim = self.alloc(4 * S * pd + 64)
-        self.check(L.csdr_amd_limit_ff(self.h, d_dem.ptr, d_lim.ptr, S * pd, 1.0), "limit")
+        pre = 1024                         # `csdr deemphasis_nfm_ff` filters  the_bufsize zeros ++ stream  (csdr.c:1076-1081)
+        pd2 = pd + pre
+        d_lim0 = self.alloc(4 * S * pd + 64)
+        self.check(L.csdr_amd_limit_ff(self.h, d_dem.ptr, d_lim0.ptr, S * pd, 1.0), "limit")
+        lim = np.zeros((S, pd2), f32); lim[:, pre:] = self.download(d_lim0, f32, S * pd).reshape(S, pd)
+        d_lim = self.upload(lim)
         dtaps_h = self.nfm_taps(audio_rate)
         d_dt = self.upload(dtaps_h)
-        d_de = self.alloc(4 * S * pd + 64)
-        ne = self.check(L.csdr_amd_fir_ff(self.h, d_lim.ptr, d_de.ptr, S, nd, pd, pd, d_dt.ptr, dtaps_h.size), "deemphasis_nfm")
+        d_de = self.alloc(4 * S * pd2 + 64)
+        ne = self.check(L.csdr_amd_fir_ff(self.h, d_lim.ptr, d_de.ptr, S, nd + pre, pd2, pd2, d_dt.ptr, dtaps_h.size), "deemphasis_nfm")
         nb = ne // agc_block
-        d_agc = self.alloc(4 * S * pd + 64)
+        d_agc = self.alloc(4 * S * pd2 + 64)
         d_st = self.upload(np.zeros(S * (2 * agc_block + 4), f32))
-        self.check(L.csdr_amd_fastagc_ff(self.h, d_de.ptr, d_agc.ptr, S, nb, agc_block, pd, pd, 1.0, d_st.ptr), "fastagc")
+        self.check(L.csdr_amd_fastagc_ff(self.h, d_de.ptr, d_agc.ptr, S, nb, agc_block, pd2, pd2, 1.0, d_st.ptr), "fastagc")
         na = nb * agc_block
-        d_pcm = self.alloc(2 * S * pd + 64)
-        self.check(L.csdr_amd_convert_f_s16(self.h, d_agc.ptr, d_pcm.ptr, S * pd), "convert_f_s16")
-        af = self.download(d_agc, f32, S * pd).reshape(S, pd)[:, :na]
-        pcm = self.download(d_pcm, np.int16, S * pd).reshape(S, pd)[:, :na]
+        d_pcm = self.alloc(2 * S * pd2 + 64)
+        self.check(L.csdr_amd_convert_f_s16(self.h, d_agc.ptr, d_pcm.ptr, S * pd2), "convert_f_s16")
+        af = self.download(d_agc, f32, S * pd2).reshape(S, pd2)[:, :na]
+        pcm = self.download(d_pcm, np.int16, S * pd2).reshape(S, pd2)[:, :na]
         return (pcm[0].copy(), af[0].copy()) if squeeze else (pcm.copy(), af.copy())

@@ -150,17 +150,31 @@ struct DeemphWfm : Stage {   // csdr.c:1014-1032
 };
 
 struct DeemphNfm : Stage {   // csdr.c:1068-1087
-    int ntaps; float *d_taps;
-    DeemphNfm(csdr_amd_ctx *c, int rate)
+    // The reference's loop runs its FIR over the freshly allocated input buffer BEFORE it reads anything (`processed` starts at 0, so the
+    // first fread is empty, csdr.c:1076-1081): its output is the FIR of  the_bufsize zeros ++ stream.  `pre` = zeros not yet consumed.
+    int ntaps; float *d_taps; size_t pre; float *d_tmp; size_t tmp_cap;
+    DeemphNfm(csdr_amd_ctx *c, int rate, int the_bufsize) : pre((size_t)the_bufsize), d_tmp(nullptr), tmp_cap(0)
     {
         const float *t = nullptr; ntaps = csdr_amd_nfm_deemph_taps(rate, &t); min_block = ntaps;
         if (!ntaps) { badsyntax("deemphasis_nfm_ff: invalid sample rate (this function works only with specific sample rates)."); exit(255); }
         d_taps = (float *)csdr_amd_malloc(c, 4 * ntaps); MUST(csdr_amd_h2d(c, d_taps, t, 4 * ntaps));
     }
+    size_t out_capacity(size_t n) override { return n + pre + 16; }
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
     {
-        long no = csdr_amd_fir_ff(c, (const float *)i, (float *)o, 1, (int)n, n, cap, d_taps, ntaps);
-        MUST(no); *cons = (size_t)no; return no;
+        if (!pre) {
+            long no = csdr_amd_fir_ff(c, (const float *)i, (float *)o, 1, (int)n, n, cap, d_taps, ntaps);
+            MUST(no); *cons = (size_t)no; return no;
+        }
+        const size_t tot = pre + n;
+        if (tot > tmp_cap) { if (d_tmp) csdr_amd_free(c, d_tmp); tmp_cap = tot + 64; d_tmp = (float *)csdr_amd_malloc(c, 4 * tmp_cap); if (!d_tmp) die("malloc"); }
+        MUST(csdr_amd_memset(c, d_tmp, 0, 4 * pre));
+        if (n) MUST(csdr_amd_d2d(c, d_tmp + pre, i, 4 * n));
+        long no = csdr_amd_fir_ff(c, d_tmp, (float *)o, 1, (int)tot, tot, cap, d_taps, ntaps);
+        MUST(no);
+        const size_t from_zeros = (size_t)no < pre ? (size_t)no : pre;
+        pre -= from_zeros; *cons = (size_t)no - from_zeros;
+        return no;
     }
 };
 
@@ -731,7 +745,7 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
         fprintf(stderr, "csdr deemphasis_wfm_ff: tau = %g, sample_rate = %d\n", tau, rate);
         return new DeemphWfm(c, rate, tau);
     }
-    if (cmd == "deemphasis_nfm_ff") { if (argc <= 2) { badsyntax("need required parameter (sample rate)"); return nullptr; } int rate; sscanf(argv[2], "%d", &rate); return new DeemphNfm(c, rate); }
+    if (cmd == "deemphasis_nfm_ff") { if (argc <= 2) { badsyntax("need required parameter (sample rate)"); return nullptr; } int rate; sscanf(argv[2], "%d", &rate); return new DeemphNfm(c, rate, g_dynamic ? the_bufsize : unitround(g_fixed)); }   // without the preamble protocol every reference process has its default buffer
     if (cmd == "fastagc_ff") { int b = 1024; float ref = 1.0f; if (argc >= 3) sscanf(argv[2], "%d", &b); if (argc >= 4) sscanf(argv[3], "%g", &ref); return new FastAgc(c, b, ref); }
     if (cmd == "fractional_decimator_ff") {
         if (argc <= 2) { badsyntax("need required parameters (rate)"); return nullptr; }

@@ -162,7 +162,7 @@ __global__ void k_nfm_store_last(const cf32 *__restrict__ y, size_t y_pitch, int
 
 struct csdr_amd_nfm {
     csdr_amd_ctx *ctx;
-    int n_streams, D, Ld, agc_block;
+    int n_streams, D, Ld, agc_block, cli_prefix;
     float limit, agc_ref;
     csdr_amd_ddc *ddc;
     cf32 *d_y; size_t y_pitch; cf32 *d_last;
@@ -191,8 +191,12 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (!w->ddc) { delete w; return nullptr; }
     w->max_y = max_block_samples / decimation + 2;
     w->y_pitch = (w->max_y + 15) & ~(size_t)15;
-    w->dl_pitch = (w->max_y + Ld + agc_block + NFM_FIR_ROW + 63) & ~(size_t)63;        // + the last workgroup's staged span beyond the valid samples (zero weights)
-    w->a_pitch = (w->max_y + Ld + agc_block + 15) & ~(size_t)15;
+    // The reference's `csdr deemphasis_nfm_ff` runs its FIR over its freshly allocated buffer before it reads anything (csdr.c:1076-1081: `processed`
+    // starts at 0, the first fread is empty): its output is the FIR of  the_bufsize zeros ++ stream.  The chain object reproduces the pipeline
+    // at the default buffer size (1024, csdr.c:189).
+    w->cli_prefix = 1024;
+    w->dl_pitch = (w->max_y + Ld + agc_block + w->cli_prefix + NFM_FIR_ROW + 63) & ~(size_t)63;        // + the last workgroup's staged span beyond the valid samples (zero weights)
+    w->a_pitch = (w->max_y + Ld + agc_block + 1024 + 15) & ~(size_t)15;
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&w->d_y, sizeof(cf32) * w->y_pitch * n_streams);
@@ -225,7 +229,7 @@ void csdr_amd_nfm_destroy(csdr_amd_nfm *w)
 int csdr_amd_nfm_reset(csdr_amd_nfm *w)
 {
     hipStream_t st = w->ctx->stream;
-    w->dl_fill = 0;
+    w->dl_fill = w->cli_prefix;                                                                                // zeros (the planes are cleared below): see csdr_amd_nfm_create
     CSDR_HIP(hipMemsetAsync(w->d_planes, 0, 3 * w->plane_bytes, st));                                          // bytes behind the valid samples meet zero weights, but must be initialised
     CSDR_HIP(hipMemsetAsync(w->d_last, 0, sizeof(cf32) * w->n_streams, st));                                   // the CLI starts fmdemod from (0, 0) (csdr.c:1044)
     CSDR_HIP(hipMemsetAsync(w->d_agc_state, 0, sizeof(float) * (size_t)w->n_streams * (2 * w->agc_block + 4), st));   // calloc'ed fastagc state (csdr.c:1393-1394)

@@ -224,6 +224,12 @@ class Port:
         n = self.L.orc_deemphasis_nfm_ff(_p(x), _p(y), x.size, _p(taps), taps.size)
         return y[:max(n, 0)].copy()
 
+    def deemphasis_nfm_ff_cli(self, x, taps, bufsize=1024):
+        """Stream model of `csdr deemphasis_nfm_ff` (csdr.c:1068-1087): the loop runs the FIR over its freshly allocated (zero) buffer before it
+        reads anything -- `processed` starts at 0, so the first fread is empty -- i.e. the output is the FIR of  bufsize zeros ++ stream
+        (verified against the reference binary: tests/test_oracle_vs_ref.py::test_nfm_chain_vs_reference_cli)."""
+        return self.deemphasis_nfm_ff(np.concatenate([np.zeros(bufsize, f32), np.ascontiguousarray(x, f32)]), taps)
+
     def limit_ff(self, x, m=1.0):
         x = np.ascontiguousarray(x, f32); y = np.zeros_like(x)
         self.L.orc_limit_ff(_p(x), _p(y), x.size, C.c_float(m)); return y
@@ -422,7 +428,7 @@ class Port:
         nt = self.firdes_filter_len(tbw)
         dec = self.fir_decimate_cc(sh, decimation, self.firdes_lowpass_f(nt, 0.5 / decimation))
         dem, _ = self.fmdemod_quadri_cf(dec)
-        de = self.deemphasis_nfm_ff(self.limit_ff(dem, 1.0), nfm_taps)
+        de = self.deemphasis_nfm_ff_cli(self.limit_ff(dem, 1.0), nfm_taps)
         agc = self.fastagc_ff(de, agc_block, 1.0)
         return self.convert_f_s16(agc), agc
 

@@ -262,6 +262,33 @@ def test_wfm_chain(port, ref):
     assert d.max() <= 1 and (d > 0).mean() < 0.05
 
 
+def test_nfm_chain_vs_reference_cli(port):
+    """BASELINE config 5 / README.md:87 as EIGHT processes of the unmodified reference binary connected by real pipes, against the oracle's
+    stage-by-stage stream model (port.nfm_chain) that the GPU parity tests of the NFM chain use."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "oracle", "_ref", "csdr")
+    if not os.path.exists(cli):
+        pytest.skip("oracle/_ref/csdr not built")
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from tests_helpers import nfm_signal_u8
+    n = 1024 * 400
+    iq = nfm_signal_u8(91, n, offset=-0.11)
+    pipe = " | ".join("%s %s" % (cli, c) for c in ("convert_u8_f", "shift_addition_cc 0.11", "fir_decimate_cc 50 0.005 HAMMING", "fmdemod_quadri_cf", "limit_ff",
+                                                    "deemphasis_nfm_ff 48000", "fastagc_ff", "convert_f_s16"))
+    p = subprocess.run(pipe, shell=True, input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+    got = np.frombuffer(p.stdout[:len(p.stdout) // 2 * 2], np.int16)
+    taps = np.load(os.path.join(root, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    want, _ = port.nfm_chain(iq, 0.11, taps)
+    m = min(got.size, want.size)
+    assert m >= 4 * 1024 and want.size - m <= 2048            # the process pipeline may hold back / repeat its last blocks at EOF (SURVEY.md 3.1)
+    assert np.any(got[2048:4096] != 0)                        # (fastagc's two zero blocks, then audio)
+    d = np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.02, (d.max(), np.mean(d != 0))
+
+
 # ---------------------------------------------------------------- f2 blocks (SURVEY.md section 8 row f2)
 def test_f2_elementwise(port, ref):
     rng = np.random.default_rng(31)
