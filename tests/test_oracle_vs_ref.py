@@ -289,6 +289,76 @@ def test_nfm_chain_vs_reference_cli(port):
     assert d.max() <= 1 and np.mean(d != 0) < 0.02, (d.max(), np.mean(d != 0))
 
 
+def _ref_pipeline(cmds, data):
+    """The commands as separate processes of the unmodified reference binary connected by pipes (skips when it was not built)."""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "csdr")
+    if not os.path.exists(cli):
+        pytest.skip("oracle/_ref/csdr not built")
+    pipe = " | ".join("%s %s" % (cli, c) for c in cmds)
+    return subprocess.run(pipe, shell=True, input=np.ascontiguousarray(data).tobytes(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout
+
+
+def _prefix(out, dtype, want):
+    """The reference processes repeat / hold back their last blocks at EOF: compare the common prefix, which must cover
+    the oracle's output up to a few buffers."""
+    isz = np.dtype(dtype).itemsize
+    got = np.frombuffer(out[:len(out) // isz * isz], dtype)
+    m = min(got.size, want.size)
+    assert m > 0 and want.size - m <= 4096, (got.size, want.size)
+    return got[:m], want[:m]
+
+
+def test_am_and_ssb_chains_vs_reference_cli(port):
+    """README.md:95 (AM) and :110 (SSB) as process pipelines of the reference binary against the oracle's stage-by-stage stream models
+    (the ones the GPU tests of the CLI chains and of the fused front end are compared with)."""
+    rng = np.random.default_rng(15)
+    n = 400000
+    t = np.arange(n)
+    audio = 0.5 * np.sin(2 * np.pi * 700 / 2.4e6 * t)
+    am = 0.5 * (1 + audio) * np.exp(2j * np.pi * 0.25 * t) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+    iq = np.empty(2 * n, f32); iq[0::2] = am.real; iq[1::2] = am.imag
+    iq = np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
+    front = ["convert_u8_f", "shift_addition_cc -0.25", "fir_decimate_cc 50 0.005 HAMMING"]
+    xf = port.convert_u8_f(iq).view(c64)
+    sh, _ = port.shift_addition_cc(xf, -0.25)
+    dec = port.fir_decimate_cc(sh, 50, port.firdes_lowpass_f(port.firdes_filter_len(0.005), 0.5 / 50))
+    g, w = _prefix(_ref_pipeline(front, iq), c64, dec)
+    assert relrms(g, w) < 1e-5
+    d, _ = port.fastdcblock_ff(port.amdemod_cf(dec))
+    g, w = _prefix(_ref_pipeline(front + ["amdemod_cf", "fastdcblock_ff"], iq), f32, d)
+    assert relrms(g, w) < 1e-5
+    want = port.convert_f_s16(port.limit_ff(port.agc_ff(d)[0], 1.0))
+    g, w = _prefix(_ref_pipeline(front + ["amdemod_cf", "fastdcblock_ff", "agc_ff", "limit_ff", "convert_f_s16"], iq), np.int16, want)
+    dd = np.abs(g.astype(np.int32) - w.astype(np.int32))
+    assert dd.max() <= 2 and np.mean(dd != 0) < 0.03
+    nt = port.firdes_filter_len(0.05); fft = port.next_pow2(nt)
+    if fft - nt < 200:
+        fft *= 2                                                # csdr.c:1834-1836
+    bp = port.bandpass_fir_fft_cc(dec, port.firdes_bandpass_c(nt, 0.0, 0.1), fft)
+    g, w = _prefix(_ref_pipeline(front + ["bandpass_fir_fft_cc 0 0.1 0.05"], iq), c64, bp)
+    assert relrms(g, w) < 1e-5
+    want = port.convert_f_s16(port.limit_ff(port.gain_ff(port.realpart_cf(bp), 3.0), 1.0))
+    g, w = _prefix(_ref_pipeline(front + ["bandpass_fir_fft_cc 0 0.1 0.05", "realpart_cf", "gain_ff 3", "limit_ff", "convert_f_s16"], iq), np.int16, want)
+    dd = np.abs(g.astype(np.int32) - w.astype(np.int32))
+    assert dd.max() <= 1 and np.mean(dd != 0) < 0.03
+
+
+@pytest.mark.parametrize("D,tbw,shift", [(16, 0.05, 0.2), (8, 0.05, -0.31)])
+def test_fastddc_vs_reference_cli(port, D, tbw, shift):
+    """`csdr fastddc_fwd_cc | csdr fastddc_inv_cc` (csdr.c:2255-2378) as two reference processes against the oracle's stream model."""
+    rng = np.random.default_rng(44)
+    x = crand(rng, 300000)
+    pd, _ = port.fastddc_init(tbw, D, shift)
+    spec = port.fastddc_fwd_cc(x, pd)
+    g, w = _prefix(_ref_pipeline(["fastddc_fwd_cc %d %g" % (D, tbw)], x), c64, spec.reshape(-1))
+    assert relrms(g, w) < 1e-5
+    y = port.fastddc_inv_cc(spec, pd, port.fastddc_taps_fft(pd, shift, D))
+    g, w = _prefix(_ref_pipeline(["fastddc_fwd_cc %d %g" % (D, tbw), "fastddc_inv_cc %g %d %g" % (shift, D, tbw)], x), c64, y)
+    assert relrms(g, w) < 1e-5
+
+
 # ---------------------------------------------------------------- f2 blocks (SURVEY.md section 8 row f2)
 def test_f2_elementwise(port, ref):
     rng = np.random.default_rng(31)
