@@ -8,6 +8,7 @@ a few hundred KB).  tests/test_golden.py replays the inputs through the CPU orac
 where neither /root/reference nor a toolchain for it is needed) and compares with these outputs.
 
     python tests/golden/make_golden.py        # rewrites ref_vectors.npz
+    python tests/golden/make_golden.py nfm    # rewrites nfm_cli_vectors.npz (the NFM chain as a process pipeline of the reference binary)
 """
 import os
 import subprocess
@@ -26,7 +27,27 @@ def crand(rng, n):
     return (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(c64)
 
 
+def make_nfm_cli():
+    """tests/golden/nfm_cli_vectors.npz: README.md:87 (NFM, BASELINE config 5) as EIGHT processes of the reference binary connected by pipes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests_helpers import nfm_signal_u8
+    cli = os.path.join(ROOT, "oracle", "_ref", "csdr")
+    assert os.path.exists(cli), "oracle/_ref/csdr is missing"
+    iq = nfm_signal_u8(2026, 1024 * 200, offset=-0.11)
+    cmds = ("convert_u8_f", "shift_addition_cc 0.11", "fir_decimate_cc 50 0.005 HAMMING", "fmdemod_quadri_cf", "limit_ff", "deemphasis_nfm_ff 48000", "fastagc_ff", "convert_f_s16")
+    pipe = " | ".join("%s %s" % (cli, c) for c in cmds)
+    out = subprocess.run(pipe, shell=True, input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout
+    s16 = np.frombuffer(out[:len(out) // 2 * 2], np.int16)
+    # the processes repeat / hold back their last blocks at EOF (SURVEY.md 3.1): keep the part every complete run agrees on
+    keep = ((1024 * 200 - 801) // 50 + 1 + 1024 - 201) // 1024 * 1024
+    assert s16.size >= keep
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "nfm_cli_vectors.npz"), nfm_iq_u8=iq, nfm_cli_s16=s16[:keep].copy(), shift_rate=np.float32(0.11))
+    print("wrote nfm_cli_vectors.npz: %d input samples, %d audio samples" % (iq.size // 2, keep))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "nfm":
+        return make_nfm_cli()
     assert oracle.Ref.available(), "oracle/_ref/libcsdr_ref.so is missing (needs /root/reference; run `make -C oracle`)"
     R = oracle.ref()
     rng = np.random.default_rng(20260924)

@@ -125,3 +125,38 @@ def test_hip_path_against_golden(G):
         check_wfm(s16[0], af[0], G)
     finally:
         gpu.close()
+
+
+# ---------------------------------------------------------------- the NFM chain (BASELINE config 5) as run by the reference CLI pipeline
+def _nfm_golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "nfm_cli_vectors.npz"))
+
+
+def _check_nfm(pcm, N):
+    want = N["nfm_cli_s16"]
+    assert pcm.size == want.size
+    assert np.all(want[:2048] == 0) and np.any(want[2048:] != 0)          # fastagc's two-block latency, then audio
+    d = np.abs(pcm.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.02
+
+
+def test_oracle_nfm_chain_against_reference_pipeline(port):
+    N = _nfm_golden()
+    taps48 = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    pcm, _ = port.nfm_chain(N["nfm_iq_u8"], float(N["shift_rate"]), taps48)
+    _check_nfm(pcm, N)
+
+
+@pytest.mark.gpu
+def test_hip_nfm_chain_against_reference_pipeline():
+    import torch  # noqa: F401
+    import csdr_amd
+    N = _nfm_golden()
+    gpu = csdr_amd.Context(0)
+    try:
+        for block in (None, 1024 * 70):
+            pcm, _ = gpu.nfm_chain(N["nfm_iq_u8"][None, :], float(N["shift_rate"]), block=block)
+            _check_nfm(pcm[0], N)
+    finally:
+        gpu.close()
+
