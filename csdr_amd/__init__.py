@@ -123,6 +123,7 @@ def lib():
     L.csdr_amd_fracdec_create.restype = vp; L.csdr_amd_fracdec_create.argtypes = [fl, i, vp, i]
     L.csdr_amd_fracdec_destroy.argtypes = [vp]
     L.csdr_amd_fractional_decimator_ff.argtypes = [vp, vp, vp, vp, i, i, sz, sz, C.POINTER(i)]
+    L.csdr_amd_fracdec_set_cli_bufsize.restype = None; L.csdr_amd_fracdec_set_cli_bufsize.argtypes = [vp, i]
     L.csdr_amd_fftfilt_create.restype = vp; L.csdr_amd_fftfilt_create.argtypes = [vp, i, vp, i, i, i]
     L.csdr_amd_fftfilt_destroy.argtypes = [vp]
     L.csdr_amd_fftfilt_input_size.argtypes = [vp]
@@ -498,13 +499,15 @@ class Context:
         y = self.download(do, f32, s * n).reshape(s, n)[:, :nb * block]
         return y[0].copy() if squeeze else y.copy()
 
-    def fractional_decimator_ff(self, x, rate, num_poly_points=12, taps=None):
+    def fractional_decimator_ff(self, x, rate, num_poly_points=12, taps=None, bufsize=None):
         x2, squeeze = self._2d(x, f32)
         s, n = x2.shape
         tp = None if taps is None else np.ascontiguousarray(taps, f32)
         d = self.L.csdr_amd_fracdec_create(rate, num_poly_points, None if tp is None else _hp(tp), 0 if tp is None else tp.size)
         if not d:
             raise CsdrAmdError(self.err())
+        if bufsize:                                   # the CLI's window loop (csdr.c:1511-1524) instead of one call over the whole array
+            self.L.csdr_amd_fracdec_set_cli_bufsize(d, bufsize)
         di = self.upload(x2); do = self.alloc(4 * s * n + 64); proc = C.c_int(0)
         no = self.check(self.L.csdr_amd_fractional_decimator_ff(self.h, d, di.ptr, do.ptr, s, n, n, n, C.byref(proc)), "fracdec")
         self.sync(); self.L.csdr_amd_fracdec_destroy(d)

@@ -195,6 +195,7 @@ struct csdr_amd_fracdec {
     std::vector<float> denom, taps;
     // cached plan
     float plan_where; int plan_n; bool plan_valid; int plan_outputs, plan_processed; float plan_where_after;
+    int cli_bufsize, plan_bufsize;   // > 0: replay the CLI's loop over the_bufsize-sample windows (csdr.c:1511-1524) instead of one call over the whole array
     std::vector<int> lo; std::vector<float> coef;
     int *d_lo; float *d_coef; float *d_taps; size_t d_cap;
 };
@@ -280,11 +281,12 @@ csdr_amd_fracdec *csdr_amd_fracdec_create(float rate, int num_poly_points, const
     d->where = (float)(-d->xifirst); d->rate = rate; d->input_processed = 0;
     d->taps_length = host_taps ? taps_length : 0;
     if (d->taps_length) d->taps.assign(host_taps, host_taps + taps_length);
-    d->plan_valid = false; d->d_lo = nullptr; d->d_coef = nullptr; d->d_taps = nullptr; d->d_cap = 0;
+    d->plan_valid = false; d->d_lo = nullptr; d->d_coef = nullptr; d->d_taps = nullptr; d->d_cap = 0; d->cli_bufsize = 0; d->plan_bufsize = 0;
     return d;
 }
 
 void  csdr_amd_fracdec_set_where(csdr_amd_fracdec *d, float where) { d->where = where; }
+void  csdr_amd_fracdec_set_cli_bufsize(csdr_amd_fracdec *d, int the_bufsize) { d->cli_bufsize = the_bufsize > 0 ? the_bufsize : 0; d->plan_valid = false; }
 float csdr_amd_fracdec_get_where(const csdr_amd_fracdec *d) { return d->where; }
 
 void csdr_amd_fracdec_destroy(csdr_amd_fracdec *d)
@@ -300,24 +302,44 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
                                      size_t in_pitch, size_t out_pitch, int *input_processed)
 {
     const int P = d->num_poly_points;
-    if (!(d->plan_valid && d->plan_where == d->where && d->plan_n == input_size)) {
+    if (!(d->plan_valid && d->plan_where == d->where && d->plan_n == input_size && d->plan_bufsize == d->cli_bufsize)) {
         // Replay the reference's float position bookkeeping (libcsdr.c:762-792) on the host: it does not depend
         // on the samples, only on (where, rate, input_size).
         d->lo.clear(); d->coef.clear();
-        float where = d->where; int hi;
-        for (; (hi = (int)ceilf(where)) + P + d->taps_length < input_size; where += d->rate) {
-            const int lo = hi - 1;
-            const float x = where - lo;
-            d->lo.push_back(lo);
-            int idx = 0;
-            for (int a = d->xifirst; a <= d->xilast; a++, idx++) {
-                float prod = 1;
-                for (int b = d->xifirst; b <= d->xilast; b++) if (a != b) prod *= (x - b);
-                d->coef.push_back(prod / d->denom[idx]);
+        float where = d->where; int hi = 0;
+        auto one_call = [&](int base, int size) {                       // fractional_decimator_ff over in[base .. base + size)
+            for (; (hi = (int)ceilf(where)) + P + d->taps_length < size; where += d->rate) {
+                const int lo = hi - 1;
+                const float x = where - lo;
+                d->lo.push_back(base + lo);
+                int idx = 0;
+                for (int a = d->xifirst; a <= d->xilast; a++, idx++) {
+                    float prod = 1;
+                    for (int b = d->xifirst; b <= d->xilast; b++) if (a != b) prod *= (x - b);
+                    d->coef.push_back(prod / d->denom[idx]);
+                }
             }
+            const int processed = (hi - 1) + d->xifirst;                // libcsdr.c:790-791
+            where -= processed;
+            return processed;
+        };
+        if (d->cli_bufsize > 0 && input_size >= d->cli_bufsize) {          // (a shorter input = the stream's tail at EOF: one call, as without the switch)
+            // `csdr fractional_decimator_ff` calls the function on the_bufsize-sample windows and re-presents the unprocessed tail
+            // (csdr.c:1511-1524): `where` stays small, so for rates that are not exact in float the positions differ from one call over
+            // the whole array (whose `where` loses precision as it grows).  Same windows, same float arithmetic, one gather kernel.
+            int base = 0;
+            while (base + d->cli_bufsize <= input_size) {
+                const int processed = one_call(base, d->cli_bufsize);
+                if (processed <= 0) break;
+                base += processed;
+            }
+            d->plan_processed = base;
+            d->plan_where_after = where;
+        } else {
+            d->plan_processed = one_call(0, input_size);
+            d->plan_where_after = where;
         }
-        d->plan_processed = (hi - 1) + d->xifirst;
-        d->plan_where_after = where - d->plan_processed;
+        d->plan_bufsize = d->cli_bufsize;
         d->plan_outputs = (int)d->lo.size();
         d->plan_where = d->where; d->plan_n = input_size;
         const size_t need = d->lo.size() + 1;

@@ -199,7 +199,12 @@ struct FastAgc : Stage {   // csdr.c:1377-1406
 
 struct FracDec : Stage {   // csdr.c:1465-1525
     csdr_amd_fracdec *d; float rate;
-    FracDec(float r, int points, const float *taps, int ntaps) : rate(r) { d = csdr_amd_fracdec_create(r, points, taps, ntaps); if (!d) { badsyntax(csdr_amd_last_error()); exit(255); } }
+    FracDec(float r, int points, const float *taps, int ntaps, int the_bufsize) : rate(r)
+    {
+        d = csdr_amd_fracdec_create(r, points, taps, ntaps); if (!d) { badsyntax(csdr_amd_last_error()); exit(255); }
+        csdr_amd_fracdec_set_cli_bufsize(d, the_bufsize);                           // the reference's window loop: positions of inexact rates depend on it
+        min_block = (size_t)the_bufsize;
+    }
     size_t out_capacity(size_t n) override { return (size_t)(n / rate) + 64; }
     int next_bufsize(int b) override { return (int)(b / rate); }     // csdr.c:1497
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
@@ -567,14 +572,20 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
     void *d_out = csdr_amd_malloc(c, cap_out * last->out_elem + 256);
     if (!d_out) die("device buffers");
     size_t have0 = 0;                                              // elements at the front of h_in: the unconsumed tail of the previous block
-    for (bool eof = false; !eof;) {
+    // After EOF the pass is repeated (a few times at most) while some stage still consumes input: an operator that works through its input in
+    // windows (fractional_decimator_ff) leaves a tail shorter than its window, which only the next call takes as the end of the stream.
+    int extra_passes = 0;
+    for (bool eof = false, again = true; again;) {
         size_t got = 0;
-        if (!read_full((char *)h_in + have0 * first->in_elem, (block - have0) * first->in_elem, &got)) eof = true;
-        have0 += got / first->in_elem;
+        if (!eof) {
+            if (!read_full((char *)h_in + have0 * first->in_elem, (block - have0) * first->in_elem, &got)) eof = true;
+            have0 += got / first->in_elem;
+        }
+        bool progressed = false;
         if (ctl && ctl->fd && first->ctl_format()) { float a, b; if (ctl->poll(first->ctl_format(), &a, &b)) first->retune(c, a, b); }
         size_t n = have0;
         if (!(eof && first->flush_partial)) n -= n % first->granule;
-        if (n == 0 && !(eof && n_st > 1)) continue;                 // at EOF a chain still flushes what its later stages carry
+        if (n == 0 && !(eof && n_st > 1)) { again = !eof; continue; }   // at EOF a chain still flushes what its later stages carry
         if (n) MUST(csdr_amd_h2d(c, L[0].d_in[0], h_in, n * first->in_elem));
         // stage 0 consumes from the host-staged block; stages k > 0 consume [carry | new] from their own device buffer
         size_t n_in = n; const char *d_src = L[0].d_in[0];
@@ -592,6 +603,7 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             }
             size_t consumed = 0;
             n_out = n_in ? s->process(c, d_src, n_in, dst, dst_cap, &consumed) : 0;
+            if (consumed) progressed = true;
             if (k == 0) {
                 if (consumed > have0) consumed = have0;
                 if (consumed == 0 && have0 == block && !eof) { fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); return 1; }
@@ -612,6 +624,9 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             d_src = nx.d_in[nx.cur];
         }
         if (n_out > 0) { MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_out * last->out_elem)); write_full(h_out, (size_t)n_out * last->out_elem); }
+        bool leftover = have0 > 0;
+        for (size_t k = 1; k < n_st; k++) if (L[k].have_b) leftover = true;
+        again = !eof || (progressed && leftover && extra_passes++ < 4);
     }
     return 0;
 }
@@ -759,7 +774,7 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
             const int nt = csdr_amd_firdes_filter_len(tbw); taps.resize(nt);
             csdr_amd_firdes_lowpass_f(taps.data(), nt, 0.5f / (rate - tbw), CSDR_WINDOW_HAMMING);
         }
-        return new FracDec(rate, points, taps.empty() ? nullptr : taps.data(), (int)taps.size());
+        return new FracDec(rate, points, taps.empty() ? nullptr : taps.data(), (int)taps.size(), g_dynamic ? the_bufsize : unitround(g_fixed));
     }
     if (cmd == "bandpass_fir_fft_cc") {
         float lo = 0, hi = 0, tbw = 0;

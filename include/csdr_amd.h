@@ -157,6 +157,9 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *ctx, csdr_amd_fracdec *d, con
                                      int n_streams, int input_size, size_t in_pitch, size_t out_pitch,
                                      int *input_processed);
 void  csdr_amd_fracdec_set_where(csdr_amd_fracdec *d, float where);   /* fractional_decimator_ff_t.where */
+/* the_bufsize > 0: csdr_amd_fractional_decimator_ff replays the CLI's loop (csdr.c:1511-1524: the function is called on the_bufsize-sample windows,
+ * the unprocessed tail is re-presented) over the given input instead of one call over the whole array; 0 (default) = one call = the library function */
+void  csdr_amd_fracdec_set_cli_bufsize(csdr_amd_fracdec *d, int the_bufsize);
 float csdr_amd_fracdec_get_where(const csdr_amd_fracdec *d);
 
 /* ------------------------------------------------------------------ f2: the remaining simple blocks

@@ -255,8 +255,9 @@ class Port:
             y[b * block:(b + 1) * block] = ob
         return y
 
-    def fractional_decimator_ff(self, x, rate, num_poly_points=12, taps=None):
-        """One call over the whole array (stream model)."""
+    def fractional_decimator_ff(self, x, rate, num_poly_points=12, taps=None, bufsize=None):
+        """bufsize=None: one call over the whole array (the library function); else the CLI loop (csdr.c:1511-1524): the function is called on
+        bufsize-sample windows and the unprocessed tail is re-presented -- for rates that are not exact in float the positions differ."""
         class D(C.Structure):
             _fields_ = [("where", C.c_float), ("input_processed", C.c_int), ("output_size", C.c_int),
                         ("num_poly_points", C.c_int), ("denom", C.c_float * 64), ("xifirst", C.c_int),
@@ -268,9 +269,19 @@ class Port:
             self.L.orc_fractional_decimator_ff_init(C.byref(d), C.c_float(rate), num_poly_points, _p(taps), taps.size)
         else:
             self.L.orc_fractional_decimator_ff_init(C.byref(d), C.c_float(rate), num_poly_points, None, 0)
-        y = np.zeros(int(x.size / rate) + 4, f32)
-        self.L.orc_fractional_decimator_ff(_p(x), _p(y), x.size, C.byref(d))
-        return y[:d.output_size].copy()
+        if bufsize is None:
+            y = np.zeros(int(x.size / rate) + 4, f32)
+            self.L.orc_fractional_decimator_ff(_p(x), _p(y), x.size, C.byref(d))
+            return y[:d.output_size].copy()
+        ob = np.zeros(bufsize, f32); outs = []; base = 0
+        while base + bufsize <= x.size:                      # window = the stream from the first unprocessed sample on
+            win = np.ascontiguousarray(x[base:base + bufsize])
+            self.L.orc_fractional_decimator_ff(_p(win), _p(ob), bufsize, C.byref(d))
+            outs.append(ob[:d.output_size].copy())
+            if d.input_processed <= 0:
+                break
+            base += d.input_processed
+        return np.concatenate(outs) if outs else np.zeros(0, f32)
 
 
     # ---- f2 blocks (AM/SSB chains, waterfall path)

@@ -165,6 +165,9 @@ def test_fractional_decimator(gpu, port):
     taps = port.firdes_lowpass_f(133, 0.5 / (2.5 - 0.03))
     a, b = gpu.fractional_decimator_ff(x, 2.5, taps=taps), port.fractional_decimator_ff(x, 2.5, taps=taps)
     assert a.size == b.size and relrms(a, b) < TOL
+    for rate in (3.3, 4.17):                          # the CLI's window loop replayed by the device operator (csdr_amd_fracdec_set_cli_bufsize)
+        a, b = gpu.fractional_decimator_ff(x, rate, bufsize=1024), port.fractional_decimator_ff(x, rate, bufsize=1024)
+        assert a.size == b.size and relrms(a, b) <= TOL
 
 
 def test_deemphasis_limit_gain(gpu, port):

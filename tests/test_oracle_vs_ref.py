@@ -169,6 +169,15 @@ def test_fractional_decimator(port, ref):
     taps = ref.firdes_lowpass_f(133, 0.5 / (2.5 - 0.03))
     a = port.fractional_decimator_ff(x, 2.5, taps=taps); b = ref.fractional_decimator_ff(x, 2.5, taps=taps)
     assert a.size == b.size and relrms(a, b) < 1e-5
+    # the CLI's window loop (csdr.c:1511-1524): for rates that are not exact in float its positions differ from one call over the whole array
+    for rate in [3.3, 4.17, 2.5]:
+        a = port.fractional_decimator_ff(x, rate, bufsize=1024); b = ref.fractional_decimator_ff(x, rate, bufsize=1024)
+        m = min(a.size, b.size)
+        assert m >= b.size - 1024 and relrms(a[:m], b[:m]) < 1e-5
+    a = port.fractional_decimator_ff(x, 3.3, bufsize=1024); one = port.fractional_decimator_ff(x, 3.3)
+    assert relrms(a[:200], one[:200]) < 1e-4 and relrms(a, one[:a.size]) > 1e-2                                # the two models start together and drift apart
+    g, w = _prefix(_ref_pipeline(["fractional_decimator_ff 3.3"], x), f32, a)                                 # ... and the reference binary follows the window loop
+    assert relrms(g, w) < 1e-5
 
 
 def test_deemphasis_limit_gain_agc(port, ref):
