@@ -974,7 +974,7 @@ int main(int argc, char **argv)
             fprintf(stderr, "csdr chain: WFM receive pattern recognised -> fused matrix-core kernel\n");
             char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
             cmds.assign(1, {"csdr", "wfm_chain_u8_s16", sh});
-        } else if (is_nfm_pattern(cmds, &shift)) {
+        } else if (is_nfm_pattern(cmds, &shift) && !g_dynamic && unitround(g_fixed) == 1024) {    // (the chain object models the pipeline at the default buffer size)
             fprintf(stderr, "csdr chain: NFM receive pattern recognised -> fused chain (matrix-core front end and de-emphasis)\n");
             char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
             cmds.assign(1, {"csdr", "nfm_chain_u8_s16", sh});
