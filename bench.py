@@ -9,7 +9,7 @@ on 1024 parallel 2.4 MS/s u8 IQ streams per GPU, synthetic i.i.d. uniform u8 (SU
 signal"), inputs resident in HBM before the timed region.  One step = one block of 2344*1024 = 2 400 256 complex
 samples (1.0001 s of signal) of every stream through the whole chain (state carried from step to step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--block T] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--block T] [--no-cpu-baseline] [--verify]
 
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are independent, so ranks share nothing on
 the data path (replicas of the per-GPU workload, "scaling": "weak"); barrier + max-over-ranks timing over RCCL.
@@ -26,66 +26,35 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import bench_common as bc
+
 ALGO_BYTES_PER_SAMPLE = 2.0 + 2.0 / 50.0      # u8 IQ in + s16 audio out per complex input sample
-HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = bc.HBM_PEAK_GBS                 # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
-def cpu_baseline(seconds_of_signal=1500.0):
-    """Reference CPU path on the host cores, bounded sample (rank 0, N=1 only)."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "cpu_bench_ref")
-    port = os.path.join(ROOT, "oracle", "cpu_bench_port")
-    exe = ref if os.path.exists(ref) else port
-    if not os.path.exists(exe):
-        return None
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    quota = None
-    try:                                              # a container CPU quota caps what `cores` threads can deliver
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q == "max" else round(float(q) / float(per), 2)
-    except Exception:  # noqa: BLE001
-        pass
-    out = {}
-    try:
-        one = json.loads(subprocess.run([exe, "1", str(seconds_of_signal)], capture_output=True, text=True, timeout=300, check=True).stdout)
-        # all host threads, each on its own stream, sized for ~15 s of wall at the measured aggregate rate of a short probe
-        probe = json.loads(subprocess.run([exe, str(cores), "4"], capture_output=True, text=True, timeout=300, check=True).stdout)
-        per_thread = max(4.0, min(seconds_of_signal, 15.0 * probe["msps"] * 1e6 / 2.4e6 / cores))
-        allc = json.loads(subprocess.run([exe, str(cores), str(per_thread)], capture_output=True, text=True, timeout=600, check=True).stdout)
-    except Exception as e:  # noqa: BLE001
-        return {"error": str(e)}
-    out = {"value": round(allc["msps"], 3), "unit": "complex MS/s", "cores": cores, "kind": one["kind"],
-           "sample": "%d threads x %.0f s of 2.4 MS/s u8 IQ signal each (%.2e complex samples in total, %.1f s wall) through the 7-stage "
-                     "chain in process with the CLI's block framing; 1 thread alone on %.0f s of signal: %.1f MS/s (%.1f s wall)"
-                     % (cores, per_thread, allc["samples"], allc["wall_s"], seconds_of_signal, one["msps"], one["wall_s"]),
-           "single_core_value": round(one["msps"], 3), "cgroup_cpu_quota_cores": quota}
-    return out
+def cpu_baseline():
+    """Reference CPU path on the host cores, bounded sample (rank 0, N=1 only): the unmodified reference (oracle/_ref/cpu_bench_ref), one
+    2.4 MS/s u8 IQ stream per thread through the 7-stage chain in process with the CLI's block framing; `cores` = threads used =
+    min(CPU affinity, cgroup quota)."""
+    return bc.cpu_baseline("wfm", unit="complex MS/s", single_amount=300.0, probe_amount=4.0, target_wall_s=12.0,
+                           describe="config 2 WFM chain, one 2.4 MS/s u8 IQ stream per thread, in process with the CLI's block framing")
 
 
 def pmc_traffic(kernel_name, streams, block):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
-    produced by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).  bench.py cannot
-    read PMCs itself; the value is reported only when the summary was taken on the same kernel and workload, else null."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:  # noqa: BLE001
-            continue
-        w = d.get("workload", {})
-        if d.get("kernel", "").startswith(kernel_name) and w.get("streams_per_gpu") == streams and w.get("block_samples_per_stream") == block:
-            best = (d["traffic_bytes_per_launch"], os.path.basename(f))
-    return best
+    return bc.pmc_traffic(kernel_name, {"streams_per_gpu": streams, "block_samples_per_stream": block})
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)        # ~0.5 s of timed work at ~1 ms per step
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=1024)
     ap.add_argument("--block", type=int, default=2344 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: reset, one more pass over all streams with the same object / buffers, 16 full audio rows "
+                         "spread over all stream blocks against the CPU oracle on the same bytes (tests/verify_configs.py)")
     args = ap.parse_args()
 
     import numpy as np
@@ -183,10 +152,17 @@ def main():
         tr = pmc_traffic(kernel_name, S, T)
         if tr:
             res["roofline"]["traffic"] = tr[0]
-            res["roofline"]["traffic_source"] = "profiles/" + tr[1] + " (rocprofv3 PMC passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+            res["roofline"]["traffic_source"] = tr[1]
+        if args.verify:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import verify_configs as vc
+            L.csdr_amd_wfm_set_profiling(w, 0)
+            res["verify"] = vc.verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
+        if args.verify and not res["verify"]["ok"]:
+            raise SystemExit("bench.py --verify: output of the timed configuration does not match the oracle: %s" % json.dumps(res["verify"]))
     L.csdr_amd_wfm_destroy(w)
     ctx.close()
     if world > 1:

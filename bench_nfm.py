@@ -20,17 +20,22 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-HBM_PEAK_GBS = 8000.0
+import bench_common as bc  # noqa: E402
+HBM_PEAK_GBS = bc.HBM_PEAK_GBS
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=300)        # ~0.3 s of timed work
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=512)
     ap.add_argument("--block", type=int, default=2344 * 1024)
     ap.add_argument("--front-end-only", action="store_true", help="time csdr_amd_ddc_process alone (convert | shift | fir_decimate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: reset, one more pass over all channels with the same object / buffers, 16 full s16 rows spread "
+                         "over all channel blocks against the CPU oracle's stage-by-stage chain on the same bytes")
     args = ap.parse_args()
 
     import numpy as np
@@ -98,16 +103,8 @@ def main():
     L.csdr_amd_ddc_kernel_time(fe, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_ddc_kernel_name(fe).decode()
     if rank == 0:
-        traffic = None; traffic_src = None
-        for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):       # committed rocprofv3 PMC summary of the same kernel and workload, if any
-            if f.endswith("_pmc_traffic.json") and "nfm" in f:
-                try:
-                    d = json.load(open(os.path.join(ROOT, "profiles", f)))
-                    w = d.get("workload", {})
-                    if d.get("kernel", "").startswith(kname) and w.get("channels_per_gpu") == S and w.get("block_samples_per_channel") == T and "FRONT END ONLY" not in w.get("workload", ""):
-                        traffic = d["traffic_bytes_per_launch"]; traffic_src = "profiles/" + f + " (rocprofv3 PMC passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
-                except Exception:  # noqa: BLE001
-                    pass
+        tr = bc.pmc_traffic(kname, {"channels_per_gpu": S, "block_samples_per_channel": T})
+        traffic, traffic_src = tr if tr else (None, None)
         samples = S * T * args.steps * world
         k_avg_ms = kms.value / max(kl.value, 1)
         algo = (2.0 + 8.0 / D) * S * T                      # front-end kernel: 2 B of u8 IQ in + one complexf per D samples out
@@ -121,9 +118,22 @@ def main():
                "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(algo / (k_avg_ms * 1e-3) / 1e9, 1) if k_avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_avg_ms else None, "traffic": traffic, "traffic_source": traffic_src,
                             "algorithmic_bytes_per_launch": algo, "kernel_avg_ms": round(k_avg_ms, 4), "kernel_launches_timed": kl.value,
-                            "hip_event_ms_per_step_all_kernels": round(ev_ms / args.steps, 4)},
+                            "hip_event_ms_per_step_all_kernels": round(ev_ms / args.steps, 4),
+                            "whole_chain": {"algorithmic_bytes_per_step": (2.0 + 2.0 / D) * S * T,
+                                            "achieved": round((2.0 + 2.0 / D) * S * T / (ev_ms / args.steps * 1e-3) / 1e9, 1),
+                                            "frac": round((2.0 + 2.0 / D) * S * T / (ev_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
                "outputs_per_step_per_channel": produced // max(args.steps, 1)}
+        if args.verify and not args.front_end_only:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import verify_configs as vc
+            L.csdr_amd_ddc_set_profiling(fe, 0)
+            res["verify"] = vc.verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max)
+        if world == 1 and not args.no_cpu_baseline and not args.front_end_only:
+            res["cpu_baseline"] = bc.cpu_baseline("nfm", unit="complex MS/s", single_amount=100.0, probe_amount=4.0, target_wall_s=8.0,
+                                                  describe="config 5 NFM chain (README.md:87), one 2.4 MS/s u8 IQ channel per thread, in process with the CLI's block framing")
         print(json.dumps(res))
+        if "verify" in res and not res["verify"]["ok"]:
+            raise SystemExit("bench_nfm.py --verify failed: %s" % json.dumps(res["verify"]))
     if args.front_end_only:
         L.csdr_amd_ddc_destroy(obj)
     else:

@@ -1,0 +1,121 @@
+"""Parity at the EXACT BASELINE.json shapes that the benches time (these were timed but never checked):
+  config 4  fastddc D = 256, transition_bw 0.001 -> fft 65536 / inverse 512, 256 channels at -0.5 + (c + 0.5)/256
+  config 2  WFM chain at 1024 streams x 2 400 256 samples (64 stream blocks x 4 time segments, > 2^31 byte offsets)
+  config 5  NFM chain at 512 channels x 2 400 256 samples
+plus the FFT plan layer's real transforms (fft_fftw.c:16-35), which nothing referenced."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import verify_configs as vc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+c64 = np.complex64
+f32 = np.float32
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch  # noqa: F401
+    import csdr_amd
+    ctx = csdr_amd.Context(0)
+    assert ctx.arch().startswith("gfx950")
+    yield ctx
+    ctx.close()
+
+
+def test_c4_exact_shape(gpu, port):
+    """fastddc.c:106-166 / csdr.c:2255-2378 at config 4's geometry: all 256 channels folded, 18 compared (band edges c = 0, 255, the
+    middle pair 127 / 128, tile edges of the fold kernels), 5 blocks in calls of 3 + 2 (state carried between calls)."""
+    tbw, D, nch, nb = 0.001, 256, 256, 5
+    ddc, err = gpu.fastddc_init(tbw, D, 0.0)
+    assert err == 0 and (ddc.fft_size, ddc.fft_inv_size, ddc.taps_length, ddc.input_size, ddc.pre_decimation, ddc.post_decimation) == (65536, 512, 8193, 57344, 128, 2)
+    rng = np.random.default_rng(4)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = vc.c4_rates(nch)
+    check = [0, 1, 7, 8, 31, 32, 63, 64, 100, 126, 127, 128, 129, 191, 192, 200, 254, 255]
+    pspec, want = vc.fastddc_oracle_channels(x, tbw, D, rates, check)
+    spec = gpu.fastddc_fwd_cc(x, ddc, blocks_per_call=3)
+    assert vc.relrms(spec, pspec) < TOL                                     # the fft-65536 forward stream
+    outs = gpu.fastddc_inv_cc(spec, tbw, D, rates, blocks_per_call=3)
+    assert len(outs) == nch
+    for c in check:
+        assert outs[c].size == want[c].size and want[c].size >= nb * (ddc.post_input_size // ddc.post_decimation) - 1, "channel %d" % c
+        assert vc.relrms(outs[c], want[c]) < TOL, "channel %d" % c
+    sizes = {o.size for o in outs}
+    assert len(sizes) <= 2 and max(sizes) - min(sizes) <= 1                  # +-1 sample between channels (decimation_remain chain)
+
+
+def test_c2_wfm_at_1024_streams(gpu):
+    """bench.py's timed configuration: 1024 streams x 2 400 256 samples (4.9 GB of u8 IQ), 16 full audio rows vs the oracle."""
+    import torch
+    S, T = 1024, 2344 * 1024
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.05), 0.5 / 10, "HAMMING")
+    g = torch.Generator(device="cuda"); g.manual_seed(42)
+    x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda", generator=g)
+    n_audio_max = (T // 50 + 64 + 63) // 64 * 64
+    out = torch.zeros((S, n_audio_max), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+    assert w, gpu.err()
+    try:
+        res = vc.verify_wfm(gpu, w, x, out, S, T, 2 * T, n_audio_max, taps)
+    finally:
+        L.csdr_amd_wfm_destroy(w)
+    assert res["kernel"] == "k_wfm_mfma_seq"
+    assert res["rows_got_len"] == res["rows_expected_len"] >= 48000 and res["ok"], res
+
+
+def test_c5_nfm_at_512_channels(gpu):
+    """bench_nfm.py's timed configuration: 512 channels x 2 400 256 samples, 16 full s16 rows vs the oracle's stage-by-stage chain."""
+    import torch
+    S, T, D = 512, 2344 * 1024, 50
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.005), 0.5 / D, "HAMMING")
+    g = torch.Generator(device="cuda"); g.manual_seed(5000)
+    x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda", generator=g)
+    n_out_max = (T // D + 2048 + 63) // 64 * 64
+    out = torch.zeros((S, n_out_max), dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    obj = L.csdr_amd_nfm_create(gpu.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
+    assert obj, gpu.err()
+    try:
+        res = vc.verify_nfm(gpu, obj, x, out, S, T, 2 * T, n_out_max)
+    finally:
+        L.csdr_amd_nfm_destroy(obj)
+    assert res["kernel"] == "k_ddc_mfma"
+    assert res["ok"], res
+
+
+class _Plan(C.Structure):        # fft_fftw.h:14-20
+    _fields_ = [("size", C.c_int), ("input", C.c_void_p), ("output", C.c_void_p), ("plan", C.c_void_p)]
+
+
+@pytest.mark.parametrize("n", [16, 1024, 4096])
+def test_fft_plan_layer_real_transforms(gpu, n):
+    """make_fft_r2c / make_fft_c2r (fft_fftw.c:16-35: FFTW's r2c half spectrum of n/2+1 bins, c2r unnormalised inverse) through the drop-in symbols."""
+    import csdr_amd
+    L = C.CDLL(csdr_amd.LIB_PATH)
+    L.make_fft_r2c.restype = C.POINTER(_Plan); L.make_fft_r2c.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.make_fft_c2r.restype = C.POINTER(_Plan); L.make_fft_c2r.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.fft_execute.argtypes = [C.POINTER(_Plan)]; L.fft_destroy.argtypes = [C.POINTER(_Plan)]
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, n).astype(f32)
+    X = np.zeros(n // 2 + 1, c64)
+    p = L.make_fft_r2c(n, x.ctypes.data, X.ctypes.data, 0)
+    assert p.contents.size == n and p.contents.input == x.ctypes.data and p.contents.output == X.ctypes.data
+    L.fft_execute(p)
+    want = np.fft.rfft(x.astype(np.float64))
+    assert vc.relrms(X, want) < TOL
+    y = np.zeros(n, f32)
+    Xin = want.astype(c64)
+    q = L.make_fft_c2r(n, Xin.ctypes.data, y.ctypes.data, 0)
+    L.fft_execute(q)
+    assert vc.relrms(y, np.fft.irfft(want, n) * n) < TOL                      # FFTW's c2r is unnormalised
+    L.fft_destroy(p); L.fft_destroy(q)

@@ -1,0 +1,118 @@
+"""Checker side of the `--verify` legs of bench.py / bench_nfm.py / bench_fastddc.py and of tests/test_configs_gpu.py: the outputs the
+HIP path produced at the FULL BASELINE.json sizes (1024 WFM streams x 2 400 256 samples, 512 NFM channels, 256 fastddc channels at
+fft 65536) against the CPU oracle on the same bytes.  TEST INFRASTRUCTURE: imports oracle/, never on the timed path (the benches call
+it after the timed region; nothing here is measured)."""
+import ctypes as C
+import numpy as np
+
+f32 = np.float32
+c64 = np.complex64
+
+
+def pick_rows(n_rows, group=16, want=16):
+    """Rows spread over every region of the batch: first / last row of the first, middle and last `group`-row stream block, the very
+    last row, and evenly spaced rows in between (each lands in a different stream block when n_rows / want >= group)."""
+    if n_rows <= want:
+        return list(range(n_rows))
+    rows = {0, group - 1, group, n_rows // 2 - 1, n_rows // 2, n_rows - group, n_rows - 1}
+    k = 1
+    while len(rows) < want:
+        rows.add(min(n_rows - 1, (k * n_rows) // want + (k * 5) % group))
+        k += 1
+    return sorted(r for r in rows if 0 <= r < n_rows)[:want]
+
+
+def s16_diff(a, b):
+    """Difference modulo 2^16 (convert_f_s16 wraps out-of-range values, libcsdr.c:2378-2381: a +-1 LSB difference next to the wrap
+    point is a 65535 difference of the int16 values)."""
+    d = (a.astype(np.int64) - b.astype(np.int64) + 32768) % 65536 - 32768
+    return np.abs(d)
+
+
+def summarize(diffs, n_expected, n_got):
+    d = np.concatenate(diffs) if diffs else np.zeros(0, np.int64)
+    return {"samples_compared": int(d.size), "max_abs_diff_lsb": int(d.max()) if d.size else 0,
+            "frac_nonzero": float((d > 0).mean()) if d.size else 0.0, "frac_over_1_lsb": float((d > 1).mean()) if d.size else 0.0,
+            "rows_expected_len": int(n_expected), "rows_got_len": int(n_got)}
+
+
+def verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, shift_rate=-0.085, decimation=10, rows=None):
+    """Fresh-state pass of the SAME object / buffers / launch configuration as the timed steps (csdr_amd_wfm_reset, one
+    csdr_amd_wfm_process over all S streams x T samples), then `rows` full audio rows against oracle.port().wfm_chain on the same bytes.
+    Gate: every row has the oracle's length, >= 99.99 % of the s16 samples within +-1 LSB, < 5 % differing at all.  (On i.i.d. uniform u8
+    input the demodulator's denominator I^2+Q^2 comes arbitrarily close to zero about once per 10^6 samples, where 1e-7 relative
+    differences of the FIR output are amplified past one LSB: hence 99.99 % and not 100 %; the FM-signal parity tests use max <= 1.)"""
+    import oracle
+    port = oracle.port()
+    L = ctx.L
+    rc = L.csdr_amd_wfm_reset(w)
+    assert rc == 0, ctx.err()
+    n = L.csdr_amd_wfm_process(w, x.data_ptr(), pitch, T, out_s16.data_ptr(), None, n_audio_max)
+    assert n >= 0, ctx.err()
+    ctx.sync()
+    rows = pick_rows(S) if rows is None else rows
+    diffs = []; n_ref = -1
+    for r in rows:
+        u8 = x[r, :2 * T].cpu().numpy()
+        ps, _ = port.wfm_chain(u8, shift_rate, decimation, taps)
+        got = out_s16[r, :n].cpu().numpy()
+        n_ref = ps.size
+        m = min(ps.size, got.size)
+        diffs.append(s16_diff(got[:m], ps[:m]))
+    res = summarize(diffs, n_ref, n)
+    res["rows"] = rows
+    res["kernel"] = L.csdr_amd_wfm_kernel_name(w).decode()
+    res["ok"] = bool(n == n_ref and res["frac_over_1_lsb"] <= 1e-4 and res["frac_nonzero"] < 0.05)
+    return res
+
+
+def verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, shift_rate=-0.05, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024, rows=None):
+    """Same for the NFM chain object: reset, one pass over all S channels, `rows` full s16 rows against oracle.port().nfm_chain."""
+    import oracle
+    port = oracle.port()
+    L = ctx.L
+    rc = L.csdr_amd_nfm_reset(obj)
+    assert rc == 0, ctx.err()
+    n = L.csdr_amd_nfm_process(obj, x.data_ptr(), pitch, T, out_s16.data_ptr(), None, n_out_max)
+    assert n >= 0, ctx.err()
+    ctx.sync()
+    rows = pick_rows(S) if rows is None else rows
+    nfm_taps = ctx.nfm_taps(audio_rate)
+    diffs = []; n_ref = -1
+    for r in rows:
+        u8 = x[r, :2 * T].cpu().numpy()
+        ps, _ = port.nfm_chain(u8, shift_rate, nfm_taps, decimation, tbw, agc_block)
+        n_ref = ps.size
+        got = out_s16[r, :n].cpu().numpy()
+        m = min(ps.size, got.size)
+        diffs.append(s16_diff(got[:m], ps[:m]))
+    res = summarize(diffs, n_ref, n)
+    res["rows"] = rows
+    res["kernel"] = L.csdr_amd_ddc_kernel_name(L.csdr_amd_nfm_front_end(obj)).decode()
+    res["ok"] = bool(n == n_ref and n > 0 and res["frac_over_1_lsb"] <= 1e-4 and res["frac_nonzero"] < 0.05)
+    return res
+
+
+def c4_rates(n_channels=256):
+    """channel c at shift_rate = -0.5 + (c + 0.5)/C"""
+    return (-0.5 + (np.arange(n_channels) + 0.5) / n_channels).astype(f32)
+
+
+def fastddc_oracle_channels(x, tbw, decimation, rates, channels):
+    """Oracle outputs of the listed channels for the wideband input x (whole blocks only): (spectra, {channel: samples})."""
+    import oracle
+    port = oracle.port()
+    pd, err = port.fastddc_init(tbw, decimation, 0.0)
+    assert err == 0
+    spec = port.fastddc_fwd_cc(x, pd)
+    outs = {}
+    for c in channels:
+        pdc, _ = port.fastddc_init(tbw, decimation, float(rates[c]))
+        outs[c] = port.fastddc_inv_cc(spec, pdc, port.fastddc_taps_fft(pdc, float(rates[c]), decimation))
+    return spec, outs
+
+
+def relrms(a, b):
+    a = np.asarray(a).astype(np.complex128).ravel(); b = np.asarray(b).astype(np.complex128).ravel()
+    den = np.sqrt((np.abs(b) ** 2).sum())
+    return float(np.sqrt((np.abs(a - b) ** 2).sum()) / den) if den else float(np.abs(a).max() if a.size else 0.0)
