@@ -24,6 +24,13 @@ static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) 
 
 enum { SCRATCH_SLOTS = 8 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (current device, kernel): the attribute is per device, contexts may live on several
+// devices and be created from several threads (thread safe).  Returns 0 or a negative error.
+int lds_attr_once(const void *kernel, size_t lds_bytes);
+// multiProcessorCount of the CURRENT device (cached per device)
+int current_device_cu_count();
+void drop_fft_plans(hipStream_t st);      // fftpath.hip
+
 // fastagc_ff (audio.hip) with an optional convert_f_s16 output written in the same pass; `out` may be null
 int fastagc_ff_s16(struct ::csdr_amd_ctx *c, const float *in, float *out, int16_t *out_s16, int n_streams, int n_blocks, int block,
                    size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io);

@@ -10,25 +10,31 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <unistd.h>
+#include <sys/syscall.h>
 #include <vector>
 
 using namespace csdr_amd;
 
 namespace {
 
-csdr_amd_ctx *g_ctx = nullptr;
-std::mutex g_mu;
+// One device context PER HOST THREAD (own HIP stream, own scratch / staging buffers): the reference's functions are stateless and
+// re-entrant (SURVEY.md section 8b "Threading"), so two threads may call any of them concurrently; with a context each they neither share
+// staging buffers nor serialise on one stream.  A thread's context is destroyed when the thread ends; the main thread's lives until the
+// process exits (the HIP runtime may already be unloading when its thread-local destructors run).
+struct ThreadCtx {
+    csdr_amd_ctx *c = nullptr;
+    ~ThreadCtx() { if (c && (long)syscall(SYS_gettid) != (long)getpid()) csdr_amd_ctx_destroy(c); }
+};
+thread_local ThreadCtx t_ctx;
 
 csdr_amd_ctx *ctx()
 {
-    if (g_ctx) return g_ctx;
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_ctx) {
-        const char *dev = getenv("CSDR_AMD_DEVICE");
-        g_ctx = csdr_amd_ctx_create(dev ? atoi(dev) : 0, nullptr);
-        if (!g_ctx) { fprintf(stderr, "libcsdr_amd: cannot open the MI355X device: %s\n", csdr_amd_last_error()); abort(); }
-    }
-    return g_ctx;
+    if (t_ctx.c) return t_ctx.c;
+    const char *dev = getenv("CSDR_AMD_DEVICE");
+    t_ctx.c = csdr_amd_ctx_create(dev ? atoi(dev) : 0, nullptr);
+    if (!t_ctx.c) { fprintf(stderr, "libcsdr_amd: cannot open the MI355X device: %s\n", csdr_amd_last_error()); abort(); }
+    return t_ctx.c;
 }
 
 void die(const char *where, int rc)

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <map>
+#include <mutex>
 
 namespace csdr_amd {
 static thread_local char g_err[512] = "";
@@ -16,6 +18,32 @@ int fail_msg(int code, const char *fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
     return code;
+}
+static std::mutex g_attr_mu;
+static std::map<std::pair<int, const void *>, size_t> g_attr_done;
+static int g_cu_count[64];
+
+int lds_attr_once(const void *kernel, size_t lds_bytes)
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    auto key = std::make_pair(dev, kernel);
+    auto it = g_attr_done.find(key);
+    if (it != g_attr_done.end() && it->second >= lds_bytes) return 0;
+    CSDR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    g_attr_done[key] = lds_bytes;
+    return 0;
+}
+
+int current_device_cu_count()
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (dev >= 0 && dev < 64 && g_cu_count[dev]) return g_cu_count[dev];
+    hipDeviceProp_t pr; int n = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+    if (n < 1) n = 256;
+    if (dev >= 0 && dev < 64) g_cu_count[dev] = n;
+    return n;
 }
 } // namespace csdr_amd
 using namespace csdr_amd;
@@ -91,6 +119,7 @@ void csdr_amd_ctx_destroy(csdr_amd_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    drop_fft_plans(c->stream);
     for (int i = 0; i < SCRATCH_SLOTS; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->pinned_ev);
     if (c->pinned) (void)hipHostFree(c->pinned);

@@ -2,8 +2,9 @@
 //
 // Same argv grammar, same raw native-endian sample streams on stdin/stdout as the reference CLI (csdr.c:56-181 usage string;
 // per-command loops cited below), so a shell pipeline keeps working when `csdr` is replaced by this binary.  What differs, on purpose:
-//   * each process moves LARGE blocks (CSDR_AMD_BLOCK elements, default 262144; 65536 when a control channel is open) through the GPU
-//     per iteration instead of 1024/16384-sample blocks per libcsdr call; the sample VALUES follow the reference's block semantics
+//   * each process moves whatever has arrived -- at least the reference's the_bufsize (1024 / 16384 samples, csdr.c:189-193, 332), at most
+//     CSDR_AMD_BLOCK elements (default 1048576; 65536 when a control channel is open) -- through the GPU per iteration: a live stream sees the
+//     reference's latency, a file or a fast producer large blocks (CSDR_AMD_MIN_READ overrides the minimum); the sample VALUES follow the reference's block semantics
 //     exactly where they are observable (shift_* re-seed every 1024 samples like csdr.c:785,836,911-918; fastagc_ff works on its own
 //     block size; decimating_shift_addition_cc restarts its recurrence every the_bufsize samples) and the stream models verified against
 //     the reference (fir_decimate_cc refeed, fractional_decimator_ff refeed, overlap-add, fastddc);
@@ -28,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <poll.h>
+#include <pthread.h>
 #include <string>
 #include <vector>
 
@@ -41,7 +44,7 @@ int badsyntax(const char *why) { fprintf(stderr, "csdr %s: %s\n", g_cmd, why); r
 size_t block_elems()
 {
     const char *e = getenv("CSDR_AMD_BLOCK");
-    long v = e ? atol(e) : 262144;
+    long v = e ? atol(e) : 1048576;
     if (v < 4096) v = 4096;
     return (size_t)(v / 1024 * 1024);
 }
@@ -91,8 +94,8 @@ struct Convert : Stage {
 struct Shift : Stage {   // csdr.c:703-925
     int variant; float rate; float phase = 0; int aux; bool real_in = false; csdr_complexf *rot = nullptr; size_t rot_cap = 0;
     Shift(int v, float r, int a) : variant(v), rate(r), aux(a) { in_elem = 8; out_elem = 8; granule = 1024; }
-    const char *ctl_format() override { return variant == CSDR_SHIFT_ADDITION && !real_in ? "%g\n" : nullptr; }
-    void retune(csdr_amd_ctx *, float r, float) override { rate = r; fprintf(stderr, "csdr shift_addition_cc: reinitialized to %g\n", r); }   // phase carries on (csdr.c:896-921)
+    const char *ctl_format() override { return (variant == CSDR_SHIFT_ADDITION || variant == CSDR_SHIFT_ADDFAST || variant == CSDR_SHIFT_UNROLL) ? "%g\n" : nullptr; }   // csdr.c:757-792, 808-843, 881-923, 3373-3407
+    void retune(csdr_amd_ctx *, float r, float) override { rate = r; fprintf(stderr, "csdr %s: reinitialized to %g\n", g_cmd, r); }   // phase carries on (csdr.c:896-921)
     long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t, size_t *cons) override
     {
         *cons = n;
@@ -481,7 +484,7 @@ bool read_full(void *buf, size_t bytes, size_t *got)
     size_t have = 0;
     while (have < bytes) {
         ssize_t r = read(STDIN_FILENO, (char *)buf + have, bytes - have);
-        if (r < 0) { if (errno == EINTR) continue; break; }
+        if (r < 0) { if (errno == EINTR) continue; fprintf(stderr, "csdr %s: read error on stdin (%s), treating it as the end of the stream\n", g_cmd, strerror(errno)); *got = have; return false; }
         if (r == 0) { *got = have; return false; }
         have += (size_t)r;
     }
@@ -551,44 +554,132 @@ struct Control {
 };
 
 // ------------------------------------------------------------------ the streaming loop: one or more stages, intermediates in HBM
+// Host side = three threads around the GPU work so that read(), PCIe and write() overlap (the reference overlaps them with one process per
+// command): a READER fills pinned buffers from stdin, the main thread queues H2D -> kernels -> D2H on the context's stream without waiting,
+// a WRITER waits for each block's completion event and writes it to stdout.
+// Latency: the reader hands a block on as soon as `min_elems` elements have arrived (the reference's the_bufsize, csdr.c:232-247, 332, rounded up to
+// the operator's granule) and only takes more when more is ALREADY waiting in the pipe, up to CSDR_AMD_BLOCK elements: a live 2.4 MS/s or 48 kS/s
+// stream moves in the reference's own block sizes (6.8 ms / 21 ms), a file or a fast producer in large blocks.
+struct HostBuf { char *p = nullptr; size_t cap = 0, bytes = 0; bool eof = false; hipEvent_t ev = nullptr; bool pending = false; };
+struct BufQueue {
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cv = PTHREAD_COND_INITIALIZER; std::vector<HostBuf *> q;
+    void push(HostBuf *b) { pthread_mutex_lock(&mu); q.push_back(b); pthread_cond_signal(&cv); pthread_mutex_unlock(&mu); }
+    HostBuf *pop() { pthread_mutex_lock(&mu); while (q.empty()) pthread_cond_wait(&cv, &mu); HostBuf *b = q.front(); q.erase(q.begin()); pthread_mutex_unlock(&mu); return b; }
+};
+struct IoThreads {
+    int device = 0; size_t min_bytes = 0, max_bytes = 0;
+    BufQueue free_in, full_in, free_out, full_out;
+};
+
+// blocks until min_bytes have arrived (or EOF / error), then keeps reading only while more is immediately available
+void read_some(char *buf, size_t min_bytes, size_t max_bytes, size_t *got, bool *eof)
+{
+    size_t have = 0; *eof = false;
+    while (have < max_bytes) {
+        if (have >= min_bytes) {
+            struct pollfd pf = {STDIN_FILENO, POLLIN, 0};
+            if (poll(&pf, 1, 0) <= 0 || !(pf.revents & (POLLIN | POLLHUP))) break;
+        }
+        ssize_t r = read(STDIN_FILENO, buf + have, max_bytes - have);
+        if (r < 0) { if (errno == EINTR) continue; fprintf(stderr, "csdr %s: read error on stdin (%s), treating it as the end of the stream\n", g_cmd, strerror(errno)); *eof = true; break; }
+        if (r == 0) { *eof = true; break; }
+        have += (size_t)r;
+    }
+    *got = have;
+}
+void *reader_main(void *arg)
+{
+    IoThreads *io = (IoThreads *)arg;
+    (void)hipSetDevice(io->device);
+    for (;;) {
+        HostBuf *b = io->free_in.pop();
+        if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }      // its previous upload has left the buffer
+        read_some(b->p, io->min_bytes, io->max_bytes, &b->bytes, &b->eof);
+        const bool eof = b->eof;
+        io->full_in.push(b);
+        if (eof) return nullptr;
+    }
+}
+void *writer_main(void *arg)
+{
+    IoThreads *io = (IoThreads *)arg;
+    (void)hipSetDevice(io->device);
+    for (;;) {
+        HostBuf *b = io->full_out.pop();
+        if (b->eof) return nullptr;
+        if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }
+        size_t done = 0;
+        while (done < b->bytes) {
+            ssize_t r = write(STDOUT_FILENO, b->p + done, b->bytes - done);
+            if (r < 0) { if (errno == EINTR) continue; _exit(0); }                  // downstream closed: end quietly like SIGPIPE would
+            done += (size_t)r;
+        }
+        io->free_out.push(b);
+    }
+}
+
 struct Link { Stage *s; char *d_in[2] = {nullptr, nullptr}; char *d_stage = nullptr; int cur = 0; size_t cap_b = 0, have_b = 0; };   // byte counts: a pipe carries bytes,
                                                                                                                // the reader picks the element size
-int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps, Control *ctl)
+int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps, Control *ctl, int in_bufsize, int device)
 {
     const size_t n_st = stages.size();
     std::vector<Link> L(n_st);
-    for (size_t k = 0; k < n_st; k++) {
-        L[k].s = stages[k]; L[k].cap_b = caps[k] * stages[k]->in_elem;
-        for (int b = 0; b < (k == 0 ? 1 : 2); b++) { L[k].d_in[b] = (char *)csdr_amd_malloc(c, L[k].cap_b + 256); if (!L[k].d_in[b]) die("device buffers"); }
-        if (k) { L[k].d_stage = (char *)csdr_amd_malloc(c, L[k].cap_b + 256); if (!L[k].d_stage) die("device buffers"); }
-    }
     Stage *first = stages[0], *last = stages[n_st - 1];
     const size_t block = caps[0];
-    const size_t cap_out = last->out_capacity(caps[n_st - 1]) + 64;
-    void *h_in = nullptr, *h_out = nullptr;
-    if (hipHostMalloc(&h_in, (block + 64) * first->in_elem, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&h_out, cap_out * last->out_elem, hipHostMallocDefault) != hipSuccess) {
-        fprintf(stderr, "csdr %s: cannot allocate pinned host buffers\n", g_cmd); exit(3);
+    for (size_t k = 0; k < n_st; k++) {
+        L[k].s = stages[k]; L[k].cap_b = (k == 0 ? 2 * block + 64 : caps[k]) * stages[k]->in_elem;      // stage 0: unconsumed tail + one new block
+        for (int b = 0; b < 2; b++) { L[k].d_in[b] = (char *)csdr_amd_malloc(c, L[k].cap_b + 256); if (!L[k].d_in[b]) die("device buffers"); }
+        if (k) { L[k].d_stage = (char *)csdr_amd_malloc(c, L[k].cap_b + 256); if (!L[k].d_stage) die("device buffers"); }
     }
+    const size_t cap_out = last->out_capacity(caps[n_st - 1]) + 64;
+    hipStream_t st = (hipStream_t)csdr_amd_ctx_stream(c);
+    enum { NBUF = 3 };
+    HostBuf hin[NBUF], hout[NBUF + 1];
+    IoThreads io; io.device = device;
+    size_t min_elems = (size_t)(in_bufsize > 0 ? in_bufsize : 1024);
+    if (const char *e = getenv("CSDR_AMD_MIN_READ")) { long v = atol(e); if (v > 0) min_elems = (size_t)v; }
+    if (min_elems % first->granule) min_elems += first->granule - min_elems % first->granule;
+    if (min_elems > block) min_elems = block;
+    io.min_bytes = min_elems * first->in_elem; io.max_bytes = block * first->in_elem;
+    for (int k = 0; k < NBUF; k++) {
+        hin[k].cap = io.max_bytes + 64; hout[k].cap = cap_out * last->out_elem;
+        if (hipHostMalloc((void **)&hin[k].p, hin[k].cap, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&hout[k].p, hout[k].cap, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&hin[k].ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&hout[k].ev, hipEventDisableTiming) != hipSuccess) {
+            fprintf(stderr, "csdr %s: cannot allocate pinned host buffers\n", g_cmd); exit(3);
+        }
+        io.free_in.push(&hin[k]); io.free_out.push(&hout[k]);
+    }
+#ifdef F_SETPIPE_SZ
+    (void)fcntl(STDIN_FILENO, F_SETPIPE_SZ, 1 << 20); (void)fcntl(STDOUT_FILENO, F_SETPIPE_SZ, 1 << 20);      // fewer, larger pipe transfers (ignored for files)
+#endif
+    pthread_t th_r, th_w;
+    if (pthread_create(&th_r, nullptr, reader_main, &io) || pthread_create(&th_w, nullptr, writer_main, &io)) { fprintf(stderr, "csdr %s: cannot start the I/O threads\n", g_cmd); exit(3); }
     void *d_out = csdr_amd_malloc(c, cap_out * last->out_elem + 256);
     if (!d_out) die("device buffers");
-    size_t have0 = 0;                                              // elements at the front of h_in: the unconsumed tail of the previous block
     // After EOF the pass is repeated (a few times at most) while some stage still consumes input: an operator that works through its input in
     // windows (fractional_decimator_ff) leaves a tail shorter than its window, which only the next call takes as the end of the stream.
-    int extra_passes = 0;
+    int extra_passes = 0, rc = 0;
     for (bool eof = false, again = true; again;) {
-        size_t got = 0;
         if (!eof) {
-            if (!read_full((char *)h_in + have0 * first->in_elem, (block - have0) * first->in_elem, &got)) eof = true;
-            have0 += got / first->in_elem;
+            HostBuf *b = io.full_in.pop();
+            eof = b->eof;
+            Link &l0 = L[0];
+            if (l0.have_b + b->bytes > l0.cap_b) { fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); rc = 1; break; }
+            if (b->bytes) {
+                if (hipMemcpyAsync(l0.d_in[l0.cur] + l0.have_b, b->p, b->bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(b->ev, st) != hipSuccess) die("upload");
+                b->pending = true; l0.have_b += b->bytes;
+            }
+            if (!eof) io.free_in.push(b);
         }
         bool progressed = false;
-        if (ctl && ctl->fd && first->ctl_format()) { float a, b; if (ctl->poll(first->ctl_format(), &a, &b)) first->retune(c, a, b); }
-        size_t n = have0;
-        if (!(eof && first->flush_partial)) n -= n % first->granule;
-        if (n == 0 && !(eof && n_st > 1)) { again = !eof; continue; }   // at EOF a chain still flushes what its later stages carry
-        if (n) MUST(csdr_amd_h2d(c, L[0].d_in[0], h_in, n * first->in_elem));
-        // stage 0 consumes from the host-staged block; stages k > 0 consume [carry | new] from their own device buffer
-        size_t n_in = n; const char *d_src = L[0].d_in[0];
+        if (ctl && ctl->fd && first->ctl_format()) { float a, b2; if (ctl->poll(first->ctl_format(), &a, &b2)) first->retune(c, a, b2); }
+        // a pass hands the first operator at most `block` elements (what the operators were sized for); what is left waits for the next pass
+        size_t n_in = L[0].have_b / first->in_elem;
+        const bool all_of_it = n_in <= block;
+        if (!all_of_it) n_in = block;                                 // block is a multiple of the granule
+        if (!(eof && all_of_it && first->flush_partial)) n_in -= n_in % first->granule;
+        if (n_in == 0 && !(eof && n_st > 1)) { again = !eof; continue; }   // at EOF a chain still flushes what its later stages carry
+        const char *d_src = L[0].d_in[L[0].cur];
         long n_out = 0;
         for (size_t k = 0; k < n_st; k++) {
             Stage *s = stages[k];
@@ -604,16 +695,16 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             size_t consumed = 0;
             n_out = n_in ? s->process(c, d_src, n_in, dst, dst_cap, &consumed) : 0;
             if (consumed) progressed = true;
-            if (k == 0) {
-                if (consumed > have0) consumed = have0;
-                if (consumed == 0 && have0 == block && !eof) { fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); return 1; }
-                memmove(h_in, (char *)h_in + consumed * first->in_elem, (have0 - consumed) * first->in_elem);
-                have0 -= consumed;
-            } else {
+            {
                 Link &lk = L[k];
+                if (consumed * s->in_elem > lk.have_b) consumed = lk.have_b / s->in_elem;
+                if (k == 0 && consumed == 0 && lk.have_b >= block * s->in_elem && !eof) {
+                    fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); return 1; }
                 const size_t rest_b = lk.have_b - consumed * s->in_elem;
-                if (rest_b) MUST(csdr_amd_d2d(c, lk.d_in[lk.cur ^ 1], lk.d_in[lk.cur] + consumed * s->in_elem, rest_b));
-                lk.cur ^= 1; lk.have_b = rest_b;
+                if (consumed) {
+                    if (rest_b) MUST(csdr_amd_d2d(c, lk.d_in[lk.cur ^ 1], lk.d_in[lk.cur] + consumed * s->in_elem, rest_b));
+                    lk.cur ^= 1; lk.have_b = rest_b;
+                }
             }
             if (k + 1 == n_st) break;
             Link &nx = L[k + 1];
@@ -623,12 +714,22 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             if (!(eof && stages[k + 1]->flush_partial)) n_in -= n_in % stages[k + 1]->granule;
             d_src = nx.d_in[nx.cur];
         }
-        if (n_out > 0) { MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_out * last->out_elem)); write_full(h_out, (size_t)n_out * last->out_elem); }
-        bool leftover = have0 > 0;
-        for (size_t k = 1; k < n_st; k++) if (L[k].have_b) leftover = true;
+        if (n_out > 0) {
+            HostBuf *ob = io.free_out.pop();
+            ob->bytes = (size_t)n_out * last->out_elem;
+            if (ob->bytes > ob->cap) { fprintf(stderr, "csdr %s: output block larger than its staging buffer\n", g_cmd); return 1; }
+            if (hipMemcpyAsync(ob->p, d_out, ob->bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(ob->ev, st) != hipSuccess) die("download");
+            ob->pending = true;
+            // d_out is reused by the next pass: the download is ordered before the next kernels on the same stream
+            io.full_out.push(ob);
+        }
+        bool leftover = false;
+        for (size_t k = 0; k < n_st; k++) if (L[k].have_b) leftover = true;
         again = !eof || (progressed && leftover && extra_passes++ < 4);
     }
-    return 0;
+    hout[NBUF].eof = true; io.full_out.push(&hout[NBUF]);
+    pthread_join(th_w, nullptr);
+    return rc;
 }
 
 int passthrough(bool read_preamble, int send_size)
@@ -728,7 +829,8 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
     if (cmd == "convert_s24_f") { Convert *cv = new Convert(7, 3, 4); cv->bigendian = argc > 2 && !strcmp(argv[2], "--bigendian"); cv->granule = 4; return cv; }
     if (cmd == "shift_math_cc" || cmd == "shift_addition_cc" || cmd == "shift_table_cc" || cmd == "shift_addfast_cc" || cmd == "shift_unroll_cc" || cmd == "shift_addition_fc") {
         float rate = 0;
-        if (has_ctl && cmd == "shift_addition_cc") { float d; ctl->wait_first("%g\n", &rate, &d); }
+        const bool ctl_cmd = cmd == "shift_addition_cc" || cmd == "shift_addition_fc" || cmd == "shift_addfast_cc" || cmd == "shift_unroll_cc";
+        if (has_ctl && ctl_cmd) { float d; ctl->wait_first("%g\n", &rate, &d); }
         else { if (argc <= 2) { badsyntax("need required parameter (rate)"); return nullptr; } sscanf(argv[2], "%g", &rate); }
         int variant = CSDR_SHIFT_ADDITION, aux = 0;
         if (cmd == "shift_math_cc") variant = CSDR_SHIFT_MATH;
@@ -747,8 +849,10 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
     }
     if (cmd == "fir_decimate_cc") {
         if (argc <= 2) { badsyntax("need required parameter (decimation factor)"); return nullptr; }
-        int factor; sscanf(argv[2], "%d", &factor);
+        int factor = 0;
+        if (sscanf(argv[2], "%d", &factor) != 1 || factor < 1) { badsyntax("decimation factor must be an integer >= 1"); return nullptr; }
         float tbw = 0.05f; if (argc >= 4) sscanf(argv[3], "%g", &tbw);
+        if (!(tbw > 0)) { badsyntax("transition_bw must be positive"); return nullptr; }
         int window = CSDR_WINDOW_HAMMING; if (argc >= 5) window = window_from(argv[4]); else fprintf(stderr, "csdr fir_decimate_cc: window = HAMMING\n");
         return new FirDecimate(c, factor, tbw, window);
     }
@@ -761,7 +865,7 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
         return new DeemphWfm(c, rate, tau);
     }
     if (cmd == "deemphasis_nfm_ff") { if (argc <= 2) { badsyntax("need required parameter (sample rate)"); return nullptr; } int rate; sscanf(argv[2], "%d", &rate); return new DeemphNfm(c, rate, g_dynamic ? the_bufsize : unitround(g_fixed)); }   // without the preamble protocol every reference process has its default buffer
-    if (cmd == "fastagc_ff") { int b = 1024; float ref = 1.0f; if (argc >= 3) sscanf(argv[2], "%d", &b); if (argc >= 4) sscanf(argv[3], "%g", &ref); return new FastAgc(c, b, ref); }
+    if (cmd == "fastagc_ff") { int b = 1024; float ref = 1.0f; if (argc >= 3) sscanf(argv[2], "%d", &b); if (argc >= 4) sscanf(argv[3], "%g", &ref); if (b <= 0) { badsyntax("block size must be positive"); return nullptr; } return new FastAgc(c, b, ref); }
     if (cmd == "fractional_decimator_ff") {
         if (argc <= 2) { badsyntax("need required parameters (rate)"); return nullptr; }
         float rate; sscanf(argv[2], "%g", &rate);
@@ -990,6 +1094,7 @@ int main(int argc, char **argv)
     for (size_t k = 0; k < cmds.size(); k++) {
         std::vector<char *> av; for (auto &t : cmds[k]) av.push_back(const_cast<char *>(t.c_str()));
         if (av.size() < 2) return badsyntax("empty command in chain");
+        if (cmds.size() > 1 || cmd == "chain") for (auto &t : cmds[k]) if (t == "--fifo" || t == "--fd") return badsyntax("--fifo / --fd control channels are not available inside `chain` (run the command as its own process)");
         // element size of the next command is only known once it is built; size its block for the worst case (1-byte elements) first
         Stage *s = make_stage(c, (int)av.size(), av.data(), cap, cmds.size() == 1 ? &ctl : nullptr, out_bufsize);
         if (!s) return -1;
@@ -1005,7 +1110,7 @@ int main(int argc, char **argv)
     }
     g_cmd = argv[1];
     send_bufsize(out_bufsize);
-    const int rc = run(c, stages, caps, &ctl);
+    const int rc = run(c, stages, caps, &ctl, in_bufsize, dev ? atoi(dev) : 0);
     (void)csdr_amd_ctx_sync(c);
     return rc;
 }

@@ -631,8 +631,7 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
             while (tb >= ta && ((tb * tstride - 2 * d->B + DDC_WIN + 1023) & ~1023LL) > 2LL * T) tb--;
             if (tb - ta + 1 < 4) { ta = 0; tb = -1; }
         }
-        static int n_cu = 0;
-        if (!n_cu) { hipDeviceProp_t pr; int dv = 0; (void)hipGetDevice(&dv); n_cu = (hipGetDeviceProperties(&pr, dv) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
+        const int n_cu = current_device_cu_count();
         if (tb >= ta) {
             DdcParams p;
             p.n_streams = d->n_streams; p.B = d->B; p.tile_first = ta; p.n_tiles = (int)(tb - ta + 1); p.k_out0 = k_first; p.D = d->D; p.nk_used = d->nk_used; p.scale = d->scale;
@@ -649,12 +648,7 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
             const size_t lds = (size_t)16 * ((1u << rbl) + 16) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float);
-            static bool done[2] = {false, false};
-            if (!done[nt - 1]) {
-                if (nt == 2) CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                else CSDR_HIP(hipFuncSetAttribute((const void *)k_ddc_mfma<rbl, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                done[nt - 1] = true;
-            }
+            { const int arc = lds_attr_once(nt == 2 ? (const void *)k_ddc_mfma<rbl, 2> : (const void *)k_ddc_mfma<rbl, 1>, lds); if (arc) return arc; }
             if (e0) CSDR_HIP(hipEventRecord(e0, st));
             if (nt == 2)
                 hipLaunchKernelGGL((k_ddc_mfma<rbl, 2>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,

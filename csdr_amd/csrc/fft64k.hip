@@ -238,13 +238,7 @@ int fft64k_filter(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int 
                   const float2 *d_tw, cf32 *d_td)
 {
     const int batch = n_blocks * n_streams;
-    static bool attr = false;
-    if (!attr) {
-        CSDR_HIP(hipFuncSetAttribute((const void *)k_f64_cols_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64_LDS_BYTES));
-        CSDR_HIP(hipFuncSetAttribute((const void *)k_f64_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64_LDS_BYTES));
-        CSDR_HIP(hipFuncSetAttribute((const void *)k_f64_cols_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64_LDS_BYTES));
-        attr = true;
-    }
+    if (lds_attr_once((const void *)k_f64_cols_fwd, F64_LDS_BYTES) || lds_attr_once((const void *)k_f64_rows, F64_LDS_BYTES) || lds_attr_once((const void *)k_f64_cols_inv, F64_LDS_BYTES)) return -1;
     hipLaunchKernelGGL(k_f64_cols_fwd, dim3(16, n_blocks, n_streams), dim3(256), F64_LDS_BYTES, st, in, in_pitch, inp, n_blocks, reinterpret_cast<float2 *>(d_work), d_tw);
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_f64_rows, dim3(16, batch), dim3(256), F64_LDS_BYTES, st, reinterpret_cast<float2 *>(d_work), reinterpret_cast<const float2 *>(d_taps_fft_t), d_tw);
@@ -259,13 +253,7 @@ int fft64k_filter_oa(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, i
                      const float2 *d_tw, cf32 *d_tails, const cf32 *d_carry_in, cf32 *d_carry_out, cf32 *out, size_t out_pitch)
 {
     const int batch = n_blocks * n_streams;
-    static bool attr = false;
-    if (!attr) {
-        CSDR_HIP(hipFuncSetAttribute((const void *)k_f64_cols_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64_LDS_BYTES));
-        CSDR_HIP(hipFuncSetAttribute((const void *)k_f64_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64_LDS_BYTES));
-        CSDR_HIP(hipFuncSetAttribute((const void *)k_f64_cols_inv_oa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F64_LDS_BYTES));
-        attr = true;
-    }
+    if (lds_attr_once((const void *)k_f64_cols_fwd, F64_LDS_BYTES) || lds_attr_once((const void *)k_f64_rows, F64_LDS_BYTES) || lds_attr_once((const void *)k_f64_cols_inv_oa, F64_LDS_BYTES)) return -1;
     hipLaunchKernelGGL(k_f64_cols_fwd, dim3(16, n_blocks, n_streams), dim3(256), F64_LDS_BYTES, st, in, in_pitch, inp, n_blocks, reinterpret_cast<float2 *>(d_work), d_tw);
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_f64_rows, dim3(16, batch), dim3(256), F64_LDS_BYTES, st, reinterpret_cast<float2 *>(d_work), reinterpret_cast<const float2 *>(d_taps_fft_t), d_tw);

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <vector>
 #include <map>
+#include <mutex>
 #include <string.h>
 using namespace csdr_amd;
 
@@ -257,19 +258,36 @@ __global__ __launch_bounds__(256) void k_scale_add(cf32 *__restrict__ io, size_t
 
 // cached single-transform plans for the drop-in FFT layer
 static std::map<std::pair<int, long>, hipfftHandle> g_c2c_plans;
+static std::mutex g_c2c_mu;      // the map is shared by every context (the drop-in layer has one context per host thread)
+
+namespace csdr_amd {
+// called by csdr_amd_ctx_destroy: the cached single-transform plans of a context die with its stream
+void drop_fft_plans(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_c2c_mu);
+    for (auto it = g_c2c_plans.begin(); it != g_c2c_plans.end();) {
+        if (it->first.second == (long)(uintptr_t)st) { hipfftDestroy(it->second); it = g_c2c_plans.erase(it); } else ++it;
+    }
+}
+}
 
 extern "C" {
 
 int csdr_amd_fft_c2c(csdr_amd_ctx *c, const csdr_complexf *in, csdr_complexf *out, int n, int forward)
 {
     auto key = std::make_pair(n, (long)(uintptr_t)c->stream);
-    if (!g_c2c_plans.count(key)) {
-        hipfftHandle h;
-        CSDR_FFT(hipfftPlan1d(&h, n, HIPFFT_C2C, 1));
-        CSDR_FFT(hipfftSetStream(h, c->stream));
-        g_c2c_plans[key] = h;
+    hipfftHandle plan;
+    {
+        std::lock_guard<std::mutex> lk(g_c2c_mu);
+        if (!g_c2c_plans.count(key)) {
+            hipfftHandle h;
+            CSDR_FFT(hipfftPlan1d(&h, n, HIPFFT_C2C, 1));
+            CSDR_FFT(hipfftSetStream(h, c->stream));
+            g_c2c_plans[key] = h;
+        }
+        plan = g_c2c_plans[key];
     }
-    CSDR_FFT(hipfftExecC2C(g_c2c_plans[key], (hipfftComplex *)in, (hipfftComplex *)out, forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
+    CSDR_FFT(hipfftExecC2C(plan, (hipfftComplex *)in, (hipfftComplex *)out, forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD));
     return 0;
 }
 int csdr_amd_bin_product(csdr_amd_ctx *c, const csdr_complexf *a, const csdr_complexf *b, csdr_complexf *out, size_t n)

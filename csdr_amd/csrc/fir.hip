@@ -265,7 +265,7 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     const int to = pick_tile(decimation, taps_length, 2, n_out);
     const size_t win_bytes = ((size_t)(to - 1) * decimation + taps_length) * 8;
     if (win_bytes > 160 * 1024 - 256) return fail_msg(-3, "fir_decimate_cc: %d taps exceed the LDS window (use the FFT path)", taps_length);
-    if (win_bytes > 64 * 1024) CSDR_HIP(hipFuncSetAttribute((const void *)k_fir_generic<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+    if (win_bytes > 64 * 1024) { const int arc = lds_attr_once((const void *)k_fir_generic<true>, win_bytes + 16); if (arc) return arc; }
     dim3 grid(cdiv(n_out, to), (unsigned)n_streams);
     hipLaunchKernelGGL((k_fir_generic<true>), grid, dim3(256), win_bytes + 16, c->stream, (const float *)in, (float *)out, n_out, to,
                        in_pitch, out_pitch, decimation, taps, taps_length);

@@ -397,7 +397,7 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
         WfmParams p; p.D = w->D; p.L = w->L; p.F = w->F; p.T = T; p.B = w->B; p.j_first = w->next_j; p.n_audio = n_audio;
         const int span = w->D * (w->F * (TILE_A - 1) + 1) + w->L + 16;          // samples per tile window (+alignment slack)
         const size_t lds = (size_t)((span + 7) / 8 * 8 + 2 * TILE_A) * sizeof(float2) + 64;
-        if (lds > 64 * 1024) CSDR_HIP(hipFuncSetAttribute((const void *)k_wfm_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_wfm_front, lds); if (arc) return arc; }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (w->profiling) {
             if (w->ev_used == w->ev_pool.size()) {

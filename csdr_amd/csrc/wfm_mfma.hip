@@ -1048,8 +1048,7 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
     const int use_seq = g_wfm_select >= 0 ? g_wfm_select == 0 : env_seq;
     const int use_oct = g_wfm_select >= 0 ? g_wfm_select <= 1 : env_oct;
     int rc = 0;
-    static int n_cu = 0;
-    if (!n_cu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); n_cu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; if (n_cu < 1) n_cu = 256; }
+    const int n_cu = current_device_cu_count();
     // leftovers around the workgroup kernels' range run on the per-wave kernel (bounds-checked variant: a handful of tiles), both ends in ONE launch
     auto launch_edges = [&](long long a0, long long a1, long long b0, long long b1) -> int {
         if (a1 >= a0 && b1 >= b0) {                                          // (each is latency bound: ~22 us)
@@ -1084,12 +1083,10 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
             static int env_nt = 0;                                                       // CSDR_AMD_WFM_SEQ_NT: 2 = 8 waves take 8 tiles per step (default), 1 = 4 waves x 4 tiles (deeper look-ahead in the same ring)
             if (!env_nt) { const char *e = getenv("CSDR_AMD_WFM_SEQ_NT"); env_nt = (e && atoi(e) == 1) ? 1 : 2; }
             const int nt = env_nt;
-            static bool done[4] = {false, false, false, false};
-            if (!done[2 * (nt - 1) + fuse]) {
+            {
                 const void *fn = nt == 2 ? (fuse ? (const void *)k_wfm_mfma_seq<2, true> : (const void *)k_wfm_mfma_seq<2, false>)
                                          : (fuse ? (const void *)k_wfm_mfma_seq<1, true> : (const void *)k_wfm_mfma_seq<1, false>);
-                CSDR_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                done[2 * (nt - 1) + fuse] = true;
+                const int arc = lds_attr_once(fn, lds); if (arc) return arc;
             }
             // the edge tiles first: the fused back end of the first segment walks through the leading ones' samples
             rc = launch_edges(tile_first, sa - 1, sb_ + 1, tile_last); if (rc) return rc;
@@ -1135,7 +1132,7 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
             const size_t lds = (size_t)nu * OCT_UNIT + 2 * 16 * OCT_OUTP * sizeof(float);
             static bool done[2] = {false, false};
             auto go = [&](auto kern, bool &dn) -> int {
-                if (!dn) { CSDR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); dn = true; }
+                (void)dn; { const int arc = lds_attr_once((const void *)kern, lds); if (arc) return arc; }
                 if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
                 hipLaunchKernelGGL(kern, swap ? dim3(gy, n_oph, z) : dim3(n_oph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, op);
                 return 0;
@@ -1171,7 +1168,7 @@ int wfm_mfma_launch(hipStream_t st, hipStream_t st_edge, hipEvent_t ev_begin, hi
         if (wp.row_bytes != 1712) return fail_msg(-3, "wfm: workgroup kernel is specialised for 1712-byte quad rows");
         if (ev_begin) CSDR_HIP(hipEventRecord(ev_begin, st));
         auto go = [&](auto kern, bool &done) -> int {
-            if (!done) { CSDR_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+            (void)done; { const int arc = lds_attr_once((const void *)kern, lds); if (arc) return arc; }
             hipLaunchKernelGGL(kern, dim3(n_qph, gy, z), dim3(256), lds, st, in, in_pitch, (const v4i *)dev.d_frags, dev.d_consts, dev.d_kb_of, ctab, demod, demod_pitch, wp);
             return 0;
         };

@@ -330,6 +330,89 @@ def test_cli_fifo_retune(port, tmp_path):
     assert relrms(got[:4096], a) <= TOL and relrms(got[4096:], b) <= TOL
 
 
+@pytest.mark.parametrize("cmd,fn", [("shift_addfast_cc", "shift_addfast_cc"), ("shift_unroll_cc", "shift_unroll_cc"), ("shift_addition_fc", "shift_addition_fc")])
+def test_cli_fifo_retune_other_shifters(port, tmp_path, cmd, fn):
+    """csdr.c:757-792 (shift_addfast_cc), 808-843 (shift_unroll_cc), 3373-3407 (shift_addition_fc): the same --fifo protocol as shift_addition_cc --
+    the rate comes from the control channel, a later line re-initialises the shifter between blocks, the phase carries on."""
+    rng = np.random.default_rng(14)
+    real = cmd.endswith("_fc")
+    x = rng.uniform(-1, 1, 2 * 4096).astype(f32) if real else crand(rng, 2 * 4096)
+    esz = 4 if real else 8
+    fifo = str(tmp_path / "ctl"); os.mkfifo(fifo)
+    env = dict(os.environ, CSDR_AMD_BLOCK="4096")
+    p = subprocess.Popen([CLI, cmd, "--fifo", fifo], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    ctl = open(fifo, "w")
+    ctl.write("0.05\n"); ctl.flush()
+    p.stdin.write(x[:4096].tobytes()); p.stdin.flush()
+    first = b""
+    while len(first) < 8 * 4096:
+        chunk = p.stdout.read(8 * 4096 - len(first))
+        assert chunk, p.stderr.read().decode()
+        first += chunk
+    ctl.write("-0.2\n"); ctl.flush()
+    p.stdin.write(x[4096:].tobytes()); p.stdin.close()
+    rest = p.stdout.read()
+    ctl.close()
+    assert p.wait(timeout=30) == 0
+    got = np.frombuffer(first + rest, c64)
+    a, ph = getattr(port, fn)(x[:4096], 0.05)
+    b, _ = getattr(port, fn)(x[4096:], -0.2, phase=ph)
+    assert got.size == x.size and esz
+    assert relrms(got[:4096], a) <= TOL and relrms(got[4096:], b) <= TOL
+
+
+def test_cli_ddcd_time_domain_command_line(port):
+    """ddcd's per-client pipeline, exactly as it launches it (ddcd_old.h:51-57, ddcd_old.cpp:474-492): `csdr shift_unroll_cc --fd <n> | csdr fir_decimate_cc
+    <D> <tbw>` with the shift rate arriving on an inherited pipe fd."""
+    rng = np.random.default_rng(15)
+    D, tbw = 8, 0.05
+    x = crand(rng, 40000)
+    r, w = os.pipe()
+    os.set_inheritable(r, True)
+    env = dict(os.environ, CSDR_AMD_BLOCK="8192")
+    p1 = subprocess.Popen([CLI, "shift_unroll_cc", "--fd", str(r)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, pass_fds=(r,))
+    p2 = subprocess.Popen([CLI, "fir_decimate_cc", str(D), str(tbw)], stdin=p1.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    p1.stdout.close(); os.close(r)
+    os.write(w, b"0.1234\n")
+    p1.stdin.write(x.tobytes()); p1.stdin.close()
+    out = p2.stdout.read()
+    os.close(w)
+    assert p1.wait(timeout=60) == 0 and p2.wait(timeout=60) == 0, (p1.stderr.read().decode(), p2.stderr.read().decode())
+    sh, _ = port.shift_unroll_cc(x, 0.1234)
+    want = port.fir_decimate_cc(sh, D, port.firdes_lowpass_f(port.firdes_filter_len(tbw), 0.5 / D))
+    got = np.frombuffer(out, c64)
+    assert got.size == want.size and relrms(got, want) <= TOL
+
+
+def test_cli_live_stream_latency_and_ragged_writes(port):
+    """The reader hands on whatever has arrived once the reference's the_bufsize is there (csdr.c:232-247, 332) instead of waiting for a
+    whole CSDR_AMD_BLOCK: with the default (1 Mi element) block, the output of the first 1024 floats must come back while stdin stays open;
+    writes that end in the middle of a sample are reassembled."""
+    rng = np.random.default_rng(16)
+    x = rng.uniform(-1.5, 1.5, 1024 * 3 + 100).astype(f32)
+    env = dict(os.environ); env.pop("CSDR_AMD_BLOCK", None)
+    p = subprocess.Popen([CLI, "limit_ff", "0.7"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    raw = x.tobytes()
+    p.stdin.write(raw[:4096 + 3]); p.stdin.flush()                          # 1024 floats and 3 bytes of the next one
+    first = b""
+    while len(first) < 4096:                                              # must arrive without EOF: a blocking full-block read would hang here
+        chunk = p.stdout.read(4096 - len(first))
+        assert chunk, p.stderr.read().decode()
+        first += chunk
+    p.stdin.write(raw[4096 + 3:]); p.stdin.close()
+    rest = p.stdout.read()
+    assert p.wait(timeout=30) == 0
+    got = np.frombuffer(first + rest, f32)
+    assert np.array_equal(got, port.limit_ff(x, 0.7))
+
+
+def test_cli_argument_validation():
+    """bad arguments end with the reference's badsyntax exit status instead of a crash (SIGFPE on a zero block / decimation)"""
+    for args in (["fastagc_ff", "0"], ["fir_decimate_cc", "0"], ["fir_decimate_cc", "x"], ["chain", "shift_addition_cc --fifo /tmp/x | fir_decimate_cc 10"]):
+        p = subprocess.run([CLI] + args, input=b"", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert p.returncode == 255 and p.stderr, args
+
+
 # ---------------------------------------------------------------- f2 commands
 def test_cli_f2_commands(port):
     rng = np.random.default_rng(14)

@@ -11,9 +11,11 @@ for name, reps in (("/tmp/iq_a.u8", 20), ("/tmp/iq_b.u8", 80)):
     with open(name, "wb") as f:
         for _ in range(reps): f.write(blk)
 PY
-run() { local s=$(date +%s.%N); "$@" > /dev/null 2>/dev/null; local e=$(date +%s.%N); python -c "print($e - $s)"; }
+# best of three runs (the first process on a cold box pays the HIP start-up of the whole image: that is not a streaming rate)
+run() { local best=1e9; for i in 1 2 3; do local s=$(date +%s.%N); "$@" > /dev/null 2>/dev/null; local e=$(date +%s.%N); best=$(python -c "print(min($best, $e - $s))"); done; echo $best; }
+csdr_amd/csdr wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8 > /dev/null 2>&1    # warm the box
 WFM='convert_u8_f | shift_addition_cc -0.085 | fir_decimate_cc 10 0.05 HAMMING | fmdemod_quadri_cf | fractional_decimator_ff 5.5 | deemphasis_wfm_ff 48000 50e-6 | convert_f_s16'
-for b in 1048576 4194304; do
+for b in 262144 1048576 4194304; do
   export CSDR_AMD_BLOCK=$b
   ta=$(run sh -c 'csdr_amd/csdr wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8'); tb=$(run sh -c 'csdr_amd/csdr wfm_chain_u8_s16 -0.085 < /tmp/iq_b.u8')
   python -c "ta, tb = $ta, $tb; r = (1920e6 - 480e6) / (tb - ta); print('wfm_chain_u8_s16 block=$b: %.0f MS/s streaming, start-up %.2f s (480 M samples %.2f s, 1920 M samples %.2f s)' % (r / 1e6, ta - 480e6 / r, ta, tb))"

@@ -8,6 +8,7 @@ import os
 import sys
 
 run, tag, kern = sys.argv[1], sys.argv[2], sys.argv[3]
+cmdline = sys.argv[4] if len(sys.argv) > 4 else "bench.py"
 out = {}
 for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     f = [x for x in os.listdir(os.path.join(run, name)) if x.endswith("counter_collection.csv")][0]
@@ -21,13 +22,19 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
         out.setdefault(k, {})[ctr + "_KiB_mean"] = sum(v) / len(v)
         out[k][ctr + "_launches"] = len(v)
 bench = json.load(open(os.path.join(run, "bench.json")))
-key = [k for k in out if kern in k and "<true>" not in k][0]
-fetch = out[key]["FETCH_SIZE_KiB_mean"] * 1024
-write = out[key]["WRITE_SIZE_KiB_mean"] * 1024
+keys = [k for k in out if kern in k and "<true>" not in k]
+key = keys[0]
+if len(keys) > 1 and kern.endswith("*"):
+    pass
+# several kernels of one step (e.g. the three passes of fft64k.hip): per-step traffic = sum over the matching kernels of mean bytes x launches per step
+steps = max(bench.get("steps_profiled", 0), 1)
+fetch = sum(out[k].get("FETCH_SIZE_KiB_mean", 0) * 1024 for k in keys)
+write = sum(out[k].get("WRITE_SIZE_KiB_mean", 0) * 1024 for k in keys)
+key = " + ".join(keys)
 algo = bench["roofline"]["algorithmic_bytes_per_launch"]
 summary = {
     "tag": tag,
-    "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / WRITE_SIZE (pass 2) --kernel-trace --output-format csv -- python %s --steps 2 --warmup 1 --no-cpu-baseline" % cmdline,
     "workload": bench["config"], "kernel": key,
     "FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
     "correction": "FETCH_SIZE x2 (MI355X_MICROARCH.md section HBM: gfx950 rocprofv3 reports 1/2 of coalesced streaming reads; cross-checked on k_wfm_back, "
