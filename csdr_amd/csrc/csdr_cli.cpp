@@ -3,7 +3,7 @@
 // Same argv grammar, same raw native-endian sample streams on stdin/stdout as the reference CLI (csdr.c:56-181 usage string;
 // per-command loops cited below), so a shell pipeline keeps working when `csdr` is replaced by this binary.  What differs, on purpose:
 //   * each process moves whatever has arrived -- at least the reference's the_bufsize (1024 / 16384 samples, csdr.c:189-193, 332), at most
-//     CSDR_AMD_BLOCK elements (default 1048576; 65536 when a control channel is open) -- through the GPU per iteration: a live stream sees the
+//     CSDR_AMD_BLOCK elements (default 4194304; 65536 when a control channel is open) -- through the GPU per iteration: a live stream sees the
 //     reference's latency, a file or a fast producer large blocks (CSDR_AMD_MIN_READ overrides the minimum); the sample VALUES follow the reference's block semantics
 //     exactly where they are observable (shift_* re-seed every 1024 samples like csdr.c:785,836,911-918; fastagc_ff works on its own
 //     block size; decimating_shift_addition_cc restarts its recurrence every the_bufsize samples) and the stream models verified against
@@ -44,7 +44,7 @@ int badsyntax(const char *why) { fprintf(stderr, "csdr %s: %s\n", g_cmd, why); r
 size_t block_elems()
 {
     const char *e = getenv("CSDR_AMD_BLOCK");
-    long v = e ? atol(e) : 1048576;
+    long v = e ? atol(e) : 4194304;
     if (v < 4096) v = 4096;
     return (size_t)(v / 1024 * 1024);
 }

@@ -12,6 +12,7 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import verify_configs as vc  # noqa: E402
+from tests_helpers import wfm_signal_u8, nfm_signal_u8  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 c64 = np.complex64
@@ -52,7 +53,9 @@ def test_c4_exact_shape(gpu, port):
 
 
 def test_c2_wfm_at_1024_streams(gpu):
-    """bench.py's timed configuration: 1024 streams x 2 400 256 samples (4.9 GB of u8 IQ), 16 full audio rows vs the oracle."""
+    """bench.py's timed configuration: 1024 streams x 2 400 256 samples (4.9 GB of u8 IQ), 16 full audio rows of the bench's noise input vs
+    the oracle (statistical gate, see verify_configs.verify_wfm) and 6 rows carrying a real FM signal, spread over other stream blocks,
+    held to +-1 LSB on every one of their 48 001 samples."""
     import torch
     S, T = 1024, 2344 * 1024
     L = gpu.L
@@ -61,15 +64,18 @@ def test_c2_wfm_at_1024_streams(gpu):
     x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda", generator=g)
     n_audio_max = (T // 50 + 64 + 63) // 64 * 64
     out = torch.zeros((S, n_audio_max), dtype=torch.int16, device="cuda")
+    strict = [3, 17, 300, 515, 777, 1022]
+    for k, r in enumerate(strict):
+        x[r] = torch.from_numpy(wfm_signal_u8(2000 + k, T)).cuda()
     torch.cuda.synchronize()
     w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
     assert w, gpu.err()
     try:
-        res = vc.verify_wfm(gpu, w, x, out, S, T, 2 * T, n_audio_max, taps)
+        res = vc.verify_wfm(gpu, w, x, out, S, T, 2 * T, n_audio_max, taps, strict_rows=strict)
     finally:
         L.csdr_amd_wfm_destroy(w)
     assert res["kernel"] == "k_wfm_mfma_seq"
-    assert res["rows_got_len"] == res["rows_expected_len"] >= 48000 and res["ok"], res
+    assert res["rows_expected_len"] >= 48000 and res["ok"], res
 
 
 def test_c5_nfm_at_512_channels(gpu):
@@ -82,11 +88,14 @@ def test_c5_nfm_at_512_channels(gpu):
     x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda", generator=g)
     n_out_max = (T // D + 2048 + 63) // 64 * 64
     out = torch.zeros((S, n_out_max), dtype=torch.int16, device="cuda")
+    strict = [5, 18, 250, 400, 510]
+    for k, r in enumerate(strict):
+        x[r] = torch.from_numpy(nfm_signal_u8(3000 + k, T, offset=0.05)).cuda()
     torch.cuda.synchronize()
     obj = L.csdr_amd_nfm_create(gpu.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
     assert obj, gpu.err()
     try:
-        res = vc.verify_nfm(gpu, obj, x, out, S, T, 2 * T, n_out_max)
+        res = vc.verify_nfm(gpu, obj, x, out, S, T, 2 * T, n_out_max, strict_rows=strict)
     finally:
         L.csdr_amd_nfm_destroy(obj)
     assert res["kernel"] == "k_ddc_mfma"
