@@ -6,9 +6,13 @@ One step = `--blocks` consecutive overlap-save blocks (input_size = 57344 sample
 taps 8193, fft_inv 512): rank 0 frames + FFTs the new input once, the [blocks, 65536] spectrum is broadcast over xGMI,
 every rank folds/IFFTs/post-shifts its slice of the channels.  Reports wideband INPUT MS/s (whole job) and aggregate output MS/s.
 
-    python bench_fastddc.py [--gpus N] [--steps K] [--warmup W] [--channels 256] [--blocks 16]
+    python bench_fastddc.py [--gpus N] [--steps K] [--warmup W] [--channels 256] [--blocks 64] [--no-cpu-baseline] [--verify]
 N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench_fastddc.py --gpus N ...
-Not part of the driver's bench contract (that is bench.py); same timing discipline (barrier + synchronize, max over ranks).
+Same line format and timing discipline as bench.py (barrier + synchronize, max over ranks).  Roofline of the dominant kernel, the alias fold
+(fastddc.c:126-141 for all channels and blocks of a step): 8 flop per (bin, channel, block) against the fp32 matrix-core peak -- the fold is COMPUTE
+bound (51 flop per byte of its compulsory traffic: the per-channel taps spectra once, the spectra once, the folded bins once; both figures are in
+the line).  CPU baseline: the unmodified reference in process (oracle/cpu_bench.c mode fastddc: one forward transform per block, fastddc_inv_cc per
+channel, channels spread over the host threads), FFTs by MKL when present.
 """
 import argparse
 import ctypes as C
@@ -19,17 +23,51 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import bench_common as bc  # noqa: E402
+
+
+def verify(ctx, L, ddc, args, x, rates, first, count, nb):
+    """Fresh forward / inverse objects, ONE call over the same `nb` blocks of the same input as a timed step (same kernels and tile shapes),
+    16 of this rank's channels against the CPU oracle (tests/verify_configs.py)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import verify_configs as vc
+    import torch
+    my_rates = np.ascontiguousarray(rates[first:first + count])
+    inv = L.csdr_amd_fastddc_inv_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
+    fwd = L.csdr_amd_fastddc_fwd_create(ctx.h, C.byref(ddc), nb)
+    pitch = L.csdr_amd_fastddc_inv_max_output(inv, nb) + 8
+    out = torch.zeros((count, pitch, 2), dtype=torch.float32, device=x.device)
+    spectra = torch.empty((nb, ddc.fft_size, 2), dtype=torch.float32, device=x.device)
+    counts = np.zeros(count, np.int32)
+    assert L.csdr_amd_fastddc_fwd_process(fwd, x.data_ptr(), spectra.data_ptr(), nb) >= 0, ctx.err()
+    assert L.csdr_amd_fastddc_inv_process(inv, spectra.data_ptr(), nb, out.data_ptr(), pitch, counts.ctypes.data_as(C.c_void_p)) >= 0, ctx.err()
+    ctx.sync()
+    xh = x.cpu().numpy().view(np.complex64).ravel()
+    chans = vc.pick_rows(count)
+    pspec, want = vc.fastddc_oracle_channels(xh, args.tbw, args.decimation, my_rates, chans)
+    worst = vc.relrms(spectra.cpu().numpy().view(np.complex64).reshape(nb, -1), pspec)
+    ok = worst < 1e-5
+    for c in chans:
+        got = out[c, :counts[c]].cpu().numpy().view(np.complex64).ravel()
+        ok = ok and got.size == want[c].size
+        worst = max(worst, vc.relrms(got[:want[c].size], want[c]))
+    kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
+    L.csdr_amd_fastddc_inv_destroy(inv); L.csdr_amd_fastddc_fwd_destroy(fwd)
+    return {"channels": chans, "blocks": nb, "max_rel_rms": worst, "tolerance": 1e-5, "kernel": kname, "ok": bool(ok and worst < 1e-5)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--channels", type=int, default=256)
     ap.add_argument("--decimation", type=int, default=256)
     ap.add_argument("--tbw", type=float, default=0.001)
-    ap.add_argument("--blocks", type=int, default=16)
+    ap.add_argument("--blocks", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,11 +116,15 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); cd.barrier()
+    L.csdr_amd_fastddc_inv_set_profiling(inv, 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    kms = C.c_double(0); kl = C.c_long(0)
+    L.csdr_amd_fastddc_inv_kernel_time(inv, C.byref(kms), C.byref(kl))
+    kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
     cd.barrier()
     wall = cd.max_over_ranks(wall, dev if world > 1 else "cpu")
     if rank == 0:
@@ -97,7 +139,32 @@ def main():
                "aggregate_output_msps": round(in_samples / args.decimation * args.channels / wall / 1e6, 2),
                "realtime_factor_at_61p44_msps": round(in_samples / wall / 61.44e6, 3),
                "taps_fft_bytes_per_step": h_bytes}
+        k_avg_ms = kms.value / max(kl.value, 1)
+        flops = 8.0 * ddc.fft_size * count * nb                       # complex MAC per (bin, channel, block) of this rank's channel slice
+        hbm_min = 8.0 * ddc.fft_size * count + 8.0 * ddc.fft_size * nb + 8.0 * ddc.fft_inv_size * count * nb      # taps spectra + spectra in, folded bins out
+        if k_avg_ms > 0:
+            tf = flops / (k_avg_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": bc.FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / bc.FP32_PEAK_TFLOPS, 4),
+                               "traffic": None, "traffic_source": None, "algorithmic_flops_per_launch": flops, "kernel_avg_ms": round(k_avg_ms, 4),
+                               "kernel_launches_timed": kl.value,
+                               "hbm_bound_alternative": {"algorithmic_bytes_per_launch": hbm_min, "achieved_GBps": round(hbm_min / (k_avg_ms * 1e-3) / 1e9, 1),
+                                                         "frac_of_8TBps": round(hbm_min / (k_avg_ms * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4),
+                                                         "note": "51 flop per compulsory byte > the fp32 ridge of 19.7: the fp32 matrix-core peak is the roofline, not HBM"}}
+            tr = bc.pmc_traffic(kname, {"channels": args.channels, "blocks_per_step": nb})
+            if tr:
+                res["roofline"]["traffic"], res["roofline"]["traffic_source"] = tr
+        else:
+            res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": None, "peak": bc.FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "note": "general kernels (geometry outside the matrix-core path): no per-kernel timing"}
+        if args.verify:
+            res["verify"] = verify(ctx, L, ddc, args, x, rates, first, count, nb)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = bc.cpu_baseline("fastddc", (args.channels, args.tbw), unit="complex MS/s (input)", single_amount=1, probe_amount=4, target_wall_s=10.0,
+                                                  fast_fft=True, describe="config 4 in process: fastddc_fwd_cc framing + FFT once per block, fastddc_inv_cc for %d channels "
+                                                  "spread over the threads (every thread transforms the block itself)" % args.channels)
         print(json.dumps(res))
+        if args.verify and not res["verify"]["ok"]:
+            raise SystemExit("bench_fastddc.py --verify failed: %s" % json.dumps(res["verify"]))
     L.csdr_amd_fastddc_inv_destroy(inv)
     if fwd:
         L.csdr_amd_fastddc_fwd_destroy(fwd)

@@ -1,0 +1,368 @@
+// fastddc_mfma.hip -- the fastddc inverse (fastddc.c:106-166 x N channels, csdr.c:2302-2378) at BASELINE config 4's geometry
+// (fft_size 65536, fft_inv_size 512, pre_decimation 128, 256 channels, tens of blocks per call) on the fp32 matrix cores.
+//
+// Per bin residue r = i mod fft_inv_size the alias fold of all channels and blocks is ONE complex matrix product
+//     C_r[channel][block] = sum_q  H[channel][r + q inv] * Xs[block][r + q inv]          q = 0 .. pre-1      (fastddc.c:126-141, Xs = swapped spectrum)
+// i.e. per residue a (channels x pre) . (pre x blocks) contraction: 8 flop per (bin, channel, block) = 8.6 GFLOP per 64-block call against
+// 128 MiB of taps spectra: 51 flop per byte, above the fp32 ridge (157 TF / 8 TB/s = 20): COMPUTE bound on v_mfma_f32_32x32x2_f32 (exact fp32
+// fma chains, MI355X_MICROARCH.md: 64 cycles per instruction per SIMD = the fp32 vector rate, but without the VALU's operand traffic).
+// The general kernel k_ddc_fold_ct (fftpath.hip) re-read every taps value 16 times per call from L2 / Infinity Cache and ran at 13 % of that peak.
+//
+// Layouts (all private to this path; built once per retune / once per call):
+//   Ht[r][g][channel][8]   the taps spectra, 8 floats = (re, im) of q = 4g .. 4g+3: a wave's A operand for one k-group of all its 32 channels
+//                          is ONE contiguous KiB, fetched exactly once per call straight into registers (no LDS), prefetched 4 groups ahead;
+//   Xt[r][block][q]        the spectra with the first fft_swap_sides folded into q (q' = (q + pre/2) mod pre): 64 KiB contiguous per residue,
+//                          staged once per workgroup in LDS (row pitch + 16 B: the 16 lanes of a ds_read_b128 group hit 16 different bank quads);
+//   Ct[m][channel][block]  the folded bins, m = (r - offsetbin_channel) mod inv = the IFFT input bin after the second fft_swap_sides
+//                          (fastddc.c:129, 150): 32 blocks x 8 B = 256-byte runs per store instruction.
+// Complex product on real MFMAs: rows = channels, k' = (q, re/im of H) = the natural interleaved order of H, columns = (block, re/im of C):
+//   C_re = [H_re | H_im] . [X_re ; -X_im],  C_im = [H_re | H_im] . [X_im ; X_re]: the SAME A registers feed both, B is the loaded complex value with
+//   a swap / sign flip.  A lane's k pair inside a group is (float j of its half, j = 0..3): lanes 0-31 hold q = 4g, 4g+1, lanes 32-63 q = 4g+2, 4g+3,
+//   so one 16-byte A load and one 16-byte B read feed 4 MFMA steps x 2 output tiles (the summation order over q differs from the reference's
+//   sequential one: fp32 rounding noise, well inside the 1e-5 gate).
+// Then, per (channel, 16 blocks): 512-point inverse transforms in LDS (radix 8 x 8 x 8, one wave per transform, in place), scrap,
+// decimating_shift_addition_cc with the reference's float32 phasor recurrence REPLAYED (k_ddc_rot: one lane per (channel, block) chain, data
+// independent) -- the folded bins are read once, the output written once; no hipFFT plan, no [channel][block][inv] round trips.
+#include "fastddc.hpp"
+#include "fft_butterflies.hpp"
+#include <math.h>
+#include <vector>
+
+namespace csdr_amd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DdcMfma {
+    csdr_amd_ctx *ctx;
+    int fft, inv, pre, G, C, Cpad, nbp, scrap, post_in, post_dec, kmax, rpitch, max_blocks;
+    float *d_Ht; cf32 *d_Xt, *d_Ct; float2 *d_R, *d_tw;
+    // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
+    bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ layout builders
+// Ht[((r G + q/4) Cpad + c) 8 + 2 (q%4)] = H[c][r + q inv]
+__global__ __launch_bounds__(256) void k_ddc_ht(const float2 *__restrict__ H, float *__restrict__ Ht, int fft, int inv, int G, int Cpad, int c_first)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= inv) return;
+    const int q = blockIdx.y, c = c_first + blockIdx.z;
+    const float2 v = H[(size_t)c * fft + r + (size_t)q * inv];
+    *reinterpret_cast<float2 *>(Ht + (((size_t)r * G + (q >> 2)) * Cpad + c) * 8 + 2 * (q & 3)) = v;
+}
+
+// Xt[(r nbp + b) pre + q] = X[b][r + q' inv],  q' = (q + pre/2) mod pre     (32 x 32 tiles through LDS: both sides move 256-byte runs)
+__global__ __launch_bounds__(256) void k_ddc_xt(const float2 *__restrict__ X, float2 *__restrict__ Xt, int fft, int inv, int pre, int nbp)
+{
+    __shared__ float2 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 32, qp0 = blockIdx.y * 32; const size_t b = blockIdx.z;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int qp = qp0 + ty + 8 * j, r = r0 + tx;
+        if (qp < pre && r < inv) tile[ty + 8 * j][tx] = X[b * fft + (size_t)qp * inv + r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = r0 + ty + 8 * j, qp = qp0 + tx;
+        if (qp < pre && r < inv) Xt[((size_t)r * nbp + b) * pre + ((qp - pre / 2) & (pre - 1))] = tile[tx][ty + 8 * j];
+    }
+}
+
+// ------------------------------------------------------------------ the fold as a matrix product
+// grid (inv residues, ceil(Cpad / 256) channel groups, ceil(n_blocks / (32 NBT)) block groups); 512 threads: wave w owns channels 32 w .. 32 w + 31 of
+// the group, all 32 NBT blocks of the group and both output parts: 2 NBT accumulator tiles of 32 x 32.
+template <int NBT>
+__global__ __launch_bounds__(512) void k_ddc_gemm(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
+                                                  const ChanGeom *__restrict__ geom, int inv, int pre, int Cpad, int n_channels, int nbp, int n_blocks, float scale)
+{
+    extern __shared__ float4 xs[];                                  // [32 NBT rows][pre / 2 + 1] float4
+    const int r = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c_base = blockIdx.y * 256 + wave * 32, b_base = blockIdx.z * 32 * NBT;
+    const int G = pre >> 2, P4 = (pre >> 1) + 1, rows = 32 * NBT, row4 = pre >> 1;
+    {   // stage this residue's spectra: rows are contiguous in Xt (pre complex = pre / 2 float4 each)
+        const float4 *src = reinterpret_cast<const float4 *>(Xt + ((size_t)r * nbp + b_base) * pre);
+        for (int idx = threadIdx.x; idx < rows * row4; idx += 512) {
+            const int row = idx / row4, col = idx - row * row4;
+            xs[row * P4 + col] = (b_base + row < n_blocks) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    if (c_base >= Cpad) return;
+    const int i = lane & 31, hi = lane >> 5;
+    const size_t gstride = (size_t)Cpad * 2;                          // float4 per k-group
+    const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_base + i) * 2 + hi;
+    f32x16 acc[NBT][2];
+#pragma unroll
+    for (int bt = 0; bt < NBT; bt++)
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[bt][p][e] = 0.f;
+    // four k-groups in flight (indices clamped: a short K loop re-loads its last group instead of branching)
+    float4 a0 = ap[0], a1 = ap[(size_t)min(1, G - 1) * gstride], a2 = ap[(size_t)min(2, G - 1) * gstride], a3 = ap[(size_t)min(3, G - 1) * gstride];
+    const float4 *xrow = xs + i * P4 + hi;
+#define DDC_STEP(AV, GG)                                                                                                   \
+    {                                                                                                                      \
+        _Pragma("unroll") for (int bt = 0; bt < NBT; bt++) {                                                               \
+            const float4 xv = xrow[bt * 32 * P4 + 2 * (GG)];                                                               \
+            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.x, acc[bt][0], 0, 0, 0);                          \
+            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.y, acc[bt][1], 0, 0, 0);                          \
+            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, -xv.y, acc[bt][0], 0, 0, 0);                         \
+            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, xv.x, acc[bt][1], 0, 0, 0);                          \
+            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.z, acc[bt][0], 0, 0, 0);                          \
+            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.w, acc[bt][1], 0, 0, 0);                          \
+            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, -xv.w, acc[bt][0], 0, 0, 0);                         \
+            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, xv.z, acc[bt][1], 0, 0, 0);                          \
+        }                                                                                                                  \
+    }
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {                                      // straight-line body: the loads stay four groups ahead of their use
+        { const float4 av = a0; a0 = ap[(size_t)min(g + 4, G - 1) * gstride]; DDC_STEP(av, g); }
+        { const float4 av = a1; a1 = ap[(size_t)min(g + 5, G - 1) * gstride]; DDC_STEP(av, g + 1); }
+        { const float4 av = a2; a2 = ap[(size_t)min(g + 6, G - 1) * gstride]; DDC_STEP(av, g + 2); }
+        { const float4 av = a3; a3 = ap[(size_t)min(g + 7, G - 1) * gstride]; DDC_STEP(av, g + 3); }
+    }
+    if (g < G) { DDC_STEP(a0, g); }                                   // pre_decimation = 8 ... (G not a multiple of 4)
+    if (g + 1 < G) { DDC_STEP(a1, g + 1); }
+    if (g + 2 < G) { DDC_STEP(a2, g + 2); }
+#undef DDC_STEP
+    // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (c >= n_channels) continue;
+        int m = (r - geom[c].offsetbin) % inv; if (m < 0) m += inv;
+        float2 *dst = Ct + ((size_t)m * Cpad + c) * nbp + b_base + i;
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++)
+            if (b_base + bt * 32 + i < n_blocks) dst[bt * 32] = make_float2(acc[bt][0][e] * scale, acc[bt][1][e] * scale);
+    }
+}
+
+// ------------------------------------------------------------------ the residual shift's phasor chains (libcsdr_gpl.c:131-160), replayed in float32
+// R[(c n_blocks + b) rpitch + k] = (cos, sin) after k steps of (c, s) <- (c cd - s sd, s cd + c sd) from (cos, sin)(starting_phase of the block)
+__global__ __launch_bounds__(64) void k_ddc_rot(const ChanGeom *__restrict__ geom, const float *__restrict__ blk_phase, float2 *__restrict__ R,
+                                                int n_chains, int n_blocks, int kmax, int rpitch)
+{
+    __shared__ float2 tile[64][33];
+    const int lane = threadIdx.x, cb0 = blockIdx.x * 64, cb = cb0 + lane;
+    float co = 1.f, sn = 0.f, cd = 1.f, sd = 0.f;
+    if (cb < n_chains) {
+        const ChanGeom g = geom[cb / n_blocks];
+        cd = g.cosdelta; sd = g.sindelta;
+        const float ph = blk_phase[cb];
+        co = (float)cos((double)ph); sn = (float)sin((double)ph);
+    }
+    for (int k0 = 0; k0 < kmax; k0 += 32) {
+#pragma unroll 4
+        for (int kk = 0; kk < 32; kk++) {
+            tile[lane][kk] = make_float2(co, sn);
+            const float c1 = co * cd - sn * sd, s1 = sn * cd + co * sd;
+            co = c1; sn = s1;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < 32; rr++) {
+            const int row = 2 * rr + (lane >> 5), col = lane & 31;
+            if (cb0 + row < n_chains && k0 + col < rpitch) R[(size_t)(cb0 + row) * rpitch + k0 + col] = tile[row][col];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ 512-point inverse transforms + scrap + residual shift
+// grid (ceil(n_blocks / 16), n_channels), 256 threads.  LDS: 16 transforms x (512 + one pad cell per 8) float2, row pitch 580; the 512 twiddles.
+constexpr int I512_PITCH = 580;
+__device__ __forceinline__ int pad8(int idx) { return idx + (idx >> 3); }
+
+__global__ __launch_bounds__(256) void k_ddc_ifft512_post(const float2 *__restrict__ Ct, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ R,
+                                                          const float2 *__restrict__ g_tw, const int *__restrict__ blk_remain, const int *__restrict__ blk_off,
+                                                          int Cpad, int nbp, int n_blocks, int scrap, int post_in, int post_dec, int rpitch)
+{
+    extern __shared__ float4 lds_raw[];
+    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + 16 * I512_PITCH;
+    const int t = threadIdx.x, c = blockIdx.y, b0 = blockIdx.x * 16;
+    tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
+    {   // bins m of 16 blocks: 128-byte runs per bin
+        const int bl = t & 15, mrow = t >> 4;
+        const bool ok = b0 + bl < n_blocks;
+        const float2 *src = Ct + (size_t)c * nbp + b0 + bl;
+#pragma unroll 8
+        for (int p = 0; p < 32; p++) {
+            const int m = 16 * p + mrow;
+            data[bl * I512_PITCH + pad8(m)] = ok ? src[(size_t)m * Cpad * nbp] : make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63;
+    // N = 512: n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3; W^(nk) = W8^(n1 k1) W512^((8 n2 + n3) k1) W8^(n2 k2) W64^(n3 k2) W8^(n3 k3)
+    for (int round = 0; round < 4; round++) {
+        float2 *row = data + (4 * round + wave) * I512_PITCH;
+        float2 v[8];
+        // stage 1: lane = 8 n2 + n3, over n1; in place (a lane reads and writes the same cells)
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) v[n1] = row[pad8(64 * n1 + lane)];
+        dft8<true>(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++) { float2 w = tw[(k1 * lane) & 511]; w.y = -w.y; row[pad8(64 * k1 + lane)] = cmul(v[k1], w); }
+        __syncthreads();
+        // stage 2: lane = (k1, n3), over n2; in place
+        const int hi3 = lane >> 3, lo3 = lane & 7;
+#pragma unroll
+        for (int n2 = 0; n2 < 8; n2++) v[n2] = row[pad8(64 * hi3 + 8 * n2 + lo3)];
+        dft8<true>(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { float2 w = tw[(8 * k2 * lo3) & 511]; w.y = -w.y; row[pad8(64 * hi3 + 8 * k2 + lo3)] = cmul(v[k2], w); }
+        __syncthreads();
+        // stage 3: lane = (k1, k2), over n3; results go to natural positions k1 + 8 k2 + 64 k3 (other lanes' inputs: barrier first)
+#pragma unroll
+        for (int n3 = 0; n3 < 8; n3++) v[n3] = row[pad8(64 * hi3 + 8 * lo3 + n3)];
+        dft8<true>(v);
+        __syncthreads();
+#pragma unroll
+        for (int k3 = 0; k3 < 8; k3++) row[pad8(hi3 + 8 * lo3 + 64 * k3)] = v[k3];
+    }
+    __syncthreads();
+    // fastddc.c:153-162: /size, drop `scrap` samples, rotate every post_dec-th sample from decimation_remain on
+    const float inv_n = 1.0f / 512.0f;
+    for (int bl = 0; bl < 16; bl++) {
+        const int b = b0 + bl;
+        if (b >= n_blocks) break;
+        const size_t cb = (size_t)c * n_blocks + b;
+        const int rem = blk_remain[cb];
+        const int cnt = rem < post_in ? (post_in - 1 - rem) / post_dec + 1 : 0;
+        float2 *dst = out + (size_t)c * out_pitch + blk_off[cb];
+        const float2 *rot = R + cb * rpitch;
+        for (int k = t; k < cnt; k += 256) {
+            const float2 x = data[bl * I512_PITCH + pad8(scrap + rem + post_dec * k)];
+            const float vi = x.x * inv_n, vq = x.y * inv_n;
+            const float2 w = rot[k];
+            dst[k] = make_float2(w.x * vi - w.y * vq, w.y * vi + w.x * vq);
+        }
+    }
+}
+
+} // namespace
+
+// ====================================================================================== host side
+DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec)
+{
+    if (getenv("CSDR_AMD_DDC_MFMA_OFF")) return nullptr;
+    if (inv != 512 || pre < 8 || (pre & (pre - 1)) || fft != inv * pre || post_dec < 1 || scrap + post_in > inv) return nullptr;
+    DdcMfma *m = new DdcMfma();
+    m->ctx = ctx; m->fft = fft; m->inv = inv; m->pre = pre; m->G = pre / 4; m->C = n_channels; m->Cpad = (n_channels + 31) / 32 * 32;
+    m->max_blocks = max_blocks; m->nbp = (max_blocks + 31) / 32 * 32; m->scrap = scrap; m->post_in = post_in; m->post_dec = post_dec;
+    m->kmax = (post_in - 1) / post_dec + 1; m->rpitch = (m->kmax + 31) / 32 * 32;
+    m->d_Ht = nullptr; m->d_Xt = nullptr; m->d_Ct = nullptr; m->d_R = nullptr; m->d_tw = nullptr;
+    hipError_t e = hipMalloc((void **)&m->d_Ht, sizeof(float) * 2 * (size_t)m->Cpad * fft);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_Xt, sizeof(cf32) * (size_t)fft * m->nbp);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_Ct, sizeof(cf32) * (size_t)inv * m->Cpad * m->nbp);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_R, sizeof(float2) * (size_t)n_channels * max_blocks * m->rpitch);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_tw, sizeof(float2) * 512);
+    if (e == hipSuccess) e = hipMemsetAsync(m->d_Ht, 0, sizeof(float) * 2 * (size_t)m->Cpad * fft, ctx->stream);      // padded channel rows stay zero
+    if (e != hipSuccess) { fail(e, "hipMalloc(fastddc matrix-core path)", __FILE__, __LINE__); ddc_mfma_destroy(m); return nullptr; }
+    std::vector<float2> tw(512);
+    for (int k = 0; k < 512; k++) { const double a = -2.0 * M_PI * k / 512.0; tw[k] = make_float2((float)cos(a), (float)sin(a)); }
+    if (hipMemcpy(m->d_tw, tw.data(), sizeof(float2) * 512, hipMemcpyHostToDevice) != hipSuccess) { ddc_mfma_destroy(m); return nullptr; }
+    return m;
+}
+
+void ddc_mfma_destroy(DdcMfma *m)
+{
+    if (!m) return;
+    (void)hipFree(m->d_Ht); (void)hipFree(m->d_Xt); (void)hipFree(m->d_Ct); (void)hipFree(m->d_R); (void)hipFree(m->d_tw);
+    for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    delete m;
+}
+
+int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, int c_count)
+{
+    if (c_count <= 0) return 0;
+    hipLaunchKernelGGL(k_ddc_ht, dim3(cdiv(m->inv, 256), m->pre, c_count), dim3(256), 0, st, reinterpret_cast<const float2 *>(d_H), m->d_Ht, m->fft, m->inv, m->G, m->Cpad, c_first);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int ddc_mfma_load_spectra(DdcMfma *m, hipStream_t st, const cf32 *spectra, int n_blocks)
+{
+    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
+    hipLaunchKernelGGL(k_ddc_xt, dim3(cdiv(m->inv, 32), cdiv(m->pre, 32), n_blocks), dim3(256), 0, st, reinterpret_cast<const float2 *>(spectra),
+                       reinterpret_cast<float2 *>(m->d_Xt), m->fft, m->inv, m->pre, m->nbp);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+int ddc_mfma_set_profiling(DdcMfma *m, int on) { m->profiling = on != 0; m->ev_used = 0; m->prof_ms = 0; m->prof_launches = 0; return 0; }
+int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches)
+{
+    for (size_t k = 0; k < m->ev_used; k++) {
+        CSDR_HIP(hipEventSynchronize(m->ev_pool[k].second));
+        float ms = 0; CSDR_HIP(hipEventElapsedTime(&ms, m->ev_pool[k].first, m->ev_pool[k].second));
+        m->prof_ms += ms; m->prof_launches++;
+    }
+    m->ev_used = 0;
+    *total_ms = m->prof_ms; *launches = m->prof_launches;
+    return 0;
+}
+
+cf32 *ddc_mfma_xt(DdcMfma *m, size_t *bytes, int *block_pitch)
+{
+    if (bytes) *bytes = sizeof(cf32) * (size_t)m->fft * m->nbp;
+    if (block_pitch) *block_pitch = m->nbp;
+    return m->d_Xt;
+}
+
+int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d_geom, const int *d_blk_remain, const float *d_blk_phase,
+                     const int *d_blk_off, cf32 *out, size_t out_pitch)
+{
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
+    const int n_chains = m->C * n_blocks;
+    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, st, d_geom, d_blk_phase, m->d_R, n_chains, n_blocks, m->kmax, m->rpitch);
+    CSDR_LAUNCH_CHECK();
+    const float scale = 1.0f / (float)m->pre;                              // fastddc.c:144-148 (a power of two: exact)
+    const int nbt = n_blocks > 32 ? 2 : 1;
+    const size_t lds = (size_t)32 * nbt * (m->pre / 2 + 1) * sizeof(float4);
+    const dim3 grid(m->inv, cdiv(m->Cpad, 256), cdiv(n_blocks, 32 * nbt));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (m->profiling) {
+        if (m->ev_used == m->ev_pool.size()) {
+            hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b));
+            m->ev_pool.emplace_back(a, b);
+        }
+        e0 = m->ev_pool[m->ev_used].first; e1 = m->ev_pool[m->ev_used].second; m->ev_used++;
+        CSDR_HIP(hipEventRecord(e0, st));
+    }
+    if (nbt == 2) {
+        if (lds > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<2>, lds); if (rc) return rc; }
+        hipLaunchKernelGGL((k_ddc_gemm<2>), grid, dim3(512), lds, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt), reinterpret_cast<float2 *>(m->d_Ct), d_geom,
+                           m->inv, m->pre, m->Cpad, m->C, m->nbp, n_blocks, scale);
+    } else {
+        if (lds > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<1>, lds); if (rc) return rc; }
+        hipLaunchKernelGGL((k_ddc_gemm<1>), grid, dim3(512), lds, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt), reinterpret_cast<float2 *>(m->d_Ct), d_geom,
+                           m->inv, m->pre, m->Cpad, m->C, m->nbp, n_blocks, scale);
+    }
+    CSDR_LAUNCH_CHECK();
+    if (e1) CSDR_HIP(hipEventRecord(e1, st));
+    const size_t lds2 = (size_t)(16 * I512_PITCH + 512) * sizeof(float2);
+    { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post, lds2); if (rc) return rc; }
+    hipLaunchKernelGGL(k_ddc_ifft512_post, dim3(cdiv(n_blocks, 16), m->C), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,
+                       m->d_R, m->d_tw, d_blk_remain, d_blk_off, m->Cpad, m->nbp, n_blocks, m->scrap, m->post_in, m->post_dec, m->rpitch);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace csdr_amd
+
+// Test hook: the 8-point butterfly of the 512-point transform on the CPU; 8 interleaved complex floats
+extern "C" void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse)
+{
+    float2 v[8];
+    for (int k = 0; k < 8; k++) v[k] = make_float2(in16[2 * k], in16[2 * k + 1]);
+    if (inverse) dft8<true>(v); else dft8<false>(v);
+    for (int k = 0; k < 8; k++) { out16[2 * k] = v[k].x; out16[2 * k + 1] = v[k].y; }
+}

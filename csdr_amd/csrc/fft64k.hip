@@ -16,6 +16,7 @@
 // ([k1][n2] layout, pitch 17, conflict free); a workgroup of 256 threads transforms 16 columns (K1, K3: 128-byte global segments per
 // row) or 16 rows (K2) at once.
 #include "common.hpp"
+#include "fft_butterflies.hpp"
 #include <math.h>
 #include <vector>
 using namespace csdr_amd;
@@ -24,41 +25,6 @@ namespace {
 
 constexpr int F64_N = 65536;
 constexpr int F64_P = 273;                 // LDS pitch of one 256-point transform (>= 17 * 16, odd: column-major fills are conflict free)
-
-__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiplication by -j (forward) / +j (inverse)
-template <bool INV> __host__ __device__ __forceinline__ float2 rot90(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
-
-template <bool INV>
-__host__ __device__ __forceinline__ void dft4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
-{
-    const float2 s02 = cadd(x0, x2), d02 = csub(x0, x2), s13 = cadd(x1, x3), d13 = rot90<INV>(csub(x1, x3));
-    x0 = cadd(s02, s13); x2 = csub(s02, s13); x1 = cadd(d02, d13); x3 = csub(d02, d13);
-}
-
-// 16-point DFT in registers, natural order in and out:  n = 4 n1 + n2, k = k1 + 4 k2
-template <bool INV>
-__host__ __device__ __forceinline__ void dft16(float2 (&v)[16])
-{
-    const float c1 = 0.92387953251128673848f, s1 = 0.38268343236508978178f, r2 = 0.70710678118654752440f;   // cos, sin of pi/8; sqrt(1/2)
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);       // over n1: v[4 k1 + n2]
-    // twiddles W16^(n2 k1), W16 = exp(-+ 2 pi i / 16)
-    const float sg = INV ? 1.f : -1.f;
-    const float2 w1 = make_float2(c1, sg * s1), w2 = make_float2(r2, sg * r2), w3 = make_float2(s1, sg * c1);
-    const float2 w4 = make_float2(0.f, sg), w6 = make_float2(-r2, sg * r2), w9 = make_float2(-c1, -sg * s1);
-    v[4 + 1] = cmul(v[4 + 1], w1); v[4 + 2] = cmul(v[4 + 2], w2); v[4 + 3] = cmul(v[4 + 3], w3);          // k1 = 1
-    v[8 + 1] = cmul(v[8 + 1], w2); v[8 + 2] = cmul(v[8 + 2], w4); v[8 + 3] = cmul(v[8 + 3], w6);          // k1 = 2
-    v[12 + 1] = cmul(v[12 + 1], w3); v[12 + 2] = cmul(v[12 + 2], w6); v[12 + 3] = cmul(v[12 + 3], w9);    // k1 = 3
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);    // over n2: v[4 k1 + k2]
-    // v[4 k1 + k2] holds X[k1 + 4 k2]: transpose to natural order
-    float2 t;
-    t = v[1]; v[1] = v[4]; v[4] = t;   t = v[2]; v[2] = v[8]; v[8] = t;   t = v[3]; v[3] = v[12]; v[12] = t;
-    t = v[6]; v[6] = v[9]; v[9] = t;   t = v[7]; v[7] = v[13]; v[13] = t; t = v[11]; v[11] = v[14]; v[14] = t;
-}
 
 // 256-point transform of transform f (of 16 in the workgroup) by its 16 threads j = 0..15, in place in buf ([16][F64_P], natural order in
 // and out; the exchange between the two radix-16 stages uses the same rows in [k1][n2] layout with pitch 17).  tw256: exp(-2 pi i m / 256) in

@@ -9,6 +9,7 @@
 // block-to-block dependency of the reference (previous block's tail) becomes a gather from the neighbouring
 // block of the batch plus a small carry buffer between calls.
 #include "common.hpp"
+#include "fastddc.hpp"
 #include <hipfft/hipfft.h>
 #include <math.h>
 #include <vector>
@@ -100,7 +101,6 @@ __global__ __launch_bounds__(256) void k_swap_halves(cf32 *__restrict__ a, int n
     const cf32 t = p[k]; p[k] = p[k + half]; p[k + half] = t;
 }
 
-struct ChanGeom { int offsetbin; float sindelta, cosdelta, rate2; };
 
 // alias fold: inv_in[c][b][(m + inv/2) % inv] = (1/pre) * sum_q Xs[i0 + q*inv] * H[c][i0 + q*inv],  i0 = (m + offsetbin - inv/2) mod inv
 // (fastddc.c:123-150; Xs = fft_swap_sides(X), the final index shift is the second fft_swap_sides).
@@ -193,7 +193,6 @@ __global__ __launch_bounds__(256) void k_ddc_fold(const cf32 *__restrict__ spect
         if (k < nb) inv_in[((size_t)c * n_blocks + b0 + k) * inv + dst] = cf32{ai[k] * scale, aq[k] * scale};
 }
 
-struct DdcChanState { int remain; float phase; };
 // per channel: the (remain, phase, output offset) chain over the blocks of this call -- data independent
 __global__ void k_ddc_chain(DdcChanState *__restrict__ state, const ChanGeom *__restrict__ geom, int n_channels, int n_blocks,
                             int post_in, int post_dec, int *__restrict__ blk_remain, float *__restrict__ blk_phase, int *__restrict__ blk_off, int *__restrict__ counts)
@@ -490,6 +489,7 @@ struct csdr_amd_fastddc_inv {
     float tbw; int decimation, window;                             // kept for per-channel retunes
     std::vector<csdr_fastddc_t> geom;
     cf32 *d_H, *d_inv_in, *d_td;
+    DdcMfma *mf;                                                    // matrix-core path (fastddc_mfma.hip) when the geometry is config 4's, else nullptr
     ChanGeom *d_geom; DdcChanState *d_state;
     int *d_blk_remain, *d_blk_off, *d_counts; float *d_blk_phase;
     std::map<int, hipfftHandle> plans;
@@ -512,9 +512,13 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
     }
     const csdr_fastddc_t &g = f->geom[0];
     const int fft = g.fft_size, inv = g.fft_inv_size;
+    f->d_inv_in = nullptr; f->d_td = nullptr;
+    f->mf = ddc_mfma_create(ctx, fft, inv, g.pre_decimation, n_channels, max_blocks, g.scrap, g.post_input_size, g.post_decimation);
     hipError_t e = hipMalloc((void **)&f->d_H, sizeof(cf32) * (size_t)n_channels * fft);
-    if (e == hipSuccess) e = hipMalloc((void **)&f->d_inv_in, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
-    if (e == hipSuccess) e = hipMalloc((void **)&f->d_td, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
+    if (!f->mf) {                                                  // the general path's [channel][block][inv] intermediates
+        if (e == hipSuccess) e = hipMalloc((void **)&f->d_inv_in, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
+        if (e == hipSuccess) e = hipMalloc((void **)&f->d_td, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_geom, sizeof(ChanGeom) * n_channels);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_state, sizeof(DdcChanState) * n_channels);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_blk_remain, sizeof(int) * (size_t)n_channels * max_blocks);
@@ -540,6 +544,7 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
         hipfftExecC2C(h, (hipfftComplex *)f->d_H, (hipfftComplex *)f->d_H, HIPFFT_FORWARD);
         const size_t total = (size_t)n_channels * fft;
         hipLaunchKernelGGL(k_swap_halves, dim3(cdiv(total / 2, 256)), dim3(256), 0, ctx->stream, f->d_H, fft, total);
+        if (f->mf && ddc_mfma_set_taps(f->mf, ctx->stream, f->d_H, 0, n_channels)) { delete f; return nullptr; }
         (void)hipStreamSynchronize(ctx->stream);
         hipfftDestroy(h);
     }
@@ -568,6 +573,7 @@ int csdr_amd_fastddc_inv_set_rate(csdr_amd_fastddc_inv *f, int channel, float sh
     int rc = csdr_amd_fft_c2c(ctx, (const csdr_complexf *)row, (csdr_complexf *)row, fft, 1); if (rc) return rc;
     hipLaunchKernelGGL(k_swap_halves, dim3(cdiv((size_t)fft / 2, 256)), dim3(256), 0, ctx->stream, row, fft, (size_t)fft);
     CSDR_LAUNCH_CHECK();
+    if (f->mf) { rc = ddc_mfma_set_taps(f->mf, ctx->stream, f->d_H, channel, 1); if (rc) return rc; }
     CSDR_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -577,9 +583,18 @@ void csdr_amd_fastddc_inv_destroy(csdr_amd_fastddc_inv *f)
     if (!f) return;
     (void)hipStreamSynchronize(f->ctx->stream);
     for (auto &kv : f->plans) hipfftDestroy(kv.second);
+    ddc_mfma_destroy(f->mf);
     (void)hipFree(f->d_H); (void)hipFree(f->d_inv_in); (void)hipFree(f->d_td); (void)hipFree(f->d_geom); (void)hipFree(f->d_state);
     (void)hipFree(f->d_blk_remain); (void)hipFree(f->d_blk_off); (void)hipFree(f->d_blk_phase); (void)hipFree(f->d_counts);
     delete f;
+}
+
+const char *csdr_amd_fastddc_inv_kernel_name(const csdr_amd_fastddc_inv *f) { return f->mf ? "k_ddc_gemm" : "k_ddc_fold_ct"; }
+int csdr_amd_fastddc_inv_set_profiling(csdr_amd_fastddc_inv *f, int on) { return f->mf ? ddc_mfma_set_profiling(f->mf, on) : 0; }
+int csdr_amd_fastddc_inv_kernel_time(csdr_amd_fastddc_inv *f, double *total_ms, long *launches)
+{
+    *total_ms = 0; *launches = 0;
+    return f->mf ? ddc_mfma_kernel_time(f->mf, total_ms, launches) : 0;
 }
 
 int csdr_amd_fastddc_inv_geometry(const csdr_amd_fastddc_inv *f, int channel, csdr_fastddc_t *ddc)
@@ -602,6 +617,17 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
     const csdr_fastddc_t &g = f->geom[0];
     const int fft = g.fft_size, inv = g.fft_inv_size, pre = g.pre_decimation;
     if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_inv: out_pitch too small");
+    if (f->mf) {   // config 4's geometry: fold on the matrix cores, own 512-point inverse transforms fused with scrap + residual shift
+        hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(f->n_channels, 64)), dim3(64), 0, st, f->d_state, f->d_geom, f->n_channels, n_blocks, g.post_input_size, g.post_decimation,
+                           f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); CSDR_LAUNCH_CHECK();
+        int rc = ddc_mfma_load_spectra(f->mf, st, spectra, n_blocks); if (rc) return rc;
+        rc = ddc_mfma_process(f->mf, st, n_blocks, f->d_geom, f->d_blk_remain, f->d_blk_phase, f->d_blk_off, out, out_pitch); if (rc) return rc;
+        if (out_counts) {
+            CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
+            CSDR_HIP(hipStreamSynchronize(st));
+        }
+        return 0;
+    }
     const int batch = f->n_channels * n_blocks;
     if (!f->plans.count(batch)) {
         hipfftHandle h; int n[1] = {inv};

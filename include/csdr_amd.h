@@ -255,6 +255,11 @@ int  csdr_amd_fastddc_inv_geometry(const csdr_amd_fastddc_inv *f, int channel, c
 int  csdr_amd_fastddc_inv_max_output(const csdr_amd_fastddc_inv *f, int n_blocks);
 int  csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *spectra, int n_blocks,
                                   csdr_complexf *out, size_t out_pitch, int *out_counts);
+/* name of the dominant kernel ("k_ddc_gemm": the alias fold as an fp32 matrix-core product, taken at fft_inv_size 512 = BASELINE config 4;
+ * "k_ddc_fold_ct": the general kernel) and HIP-event timing of it on the context's stream (bench_fastddc.py's roofline leg) */
+const char *csdr_amd_fastddc_inv_kernel_name(const csdr_amd_fastddc_inv *f);
+int  csdr_amd_fastddc_inv_set_profiling(csdr_amd_fastddc_inv *f, int on);
+int  csdr_amd_fastddc_inv_kernel_time(csdr_amd_fastddc_inv *f, double *total_ms, long *launches);
 /* one channel, one block, explicit taps_fft and status = fastddc_inv_cc itself (fastddc.c:106-166).
  * status_io: HOST {decimation_remain, float starting_phase, output_size} (decimating_shift_addition_status_t).
  * d_inv_in / d_td: device scratch of fft_inv_size complexf (folded bins after the second swap / IFFT output, unnormalised). */
@@ -333,6 +338,8 @@ int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const flo
                                 const float *ctab2, float *out16);
 /* Test hook: the register-level 16-point butterfly of the three-pass 65536-point transform (fft64k.hip) on the CPU; 16 interleaved complex floats */
 void csdr_amd_debug_dft16(const float *in32, float *out32, int inverse);
+/* Test hook: the 8-point butterfly of the channelizer's 512-point inverse transforms (fastddc_mfma.hip) on the CPU; 8 interleaved complex floats */
+void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse);
 /* Test hook: one tile (16 outputs from 256 limited samples) of the NFM chain's matrix-core de-emphasis FIR on the CPU: digit planes,
  * Toeplitz digit table and accumulator classes as k_nfm_deemph_mfma combines them. */
 int csdr_amd_debug_nfm_deemph_tile(int audio_rate, float max_amp, const float *x, float *out16);

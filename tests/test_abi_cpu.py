@@ -133,6 +133,24 @@ def test_dft16_butterfly():
         assert np.abs(y - 16 * np.fft.ifft(x.astype(np.complex128))).max() < 2e-6
 
 
+def test_dft8_butterfly():
+    """The 8-point butterfly of the channelizer's 512 = 8 x 8 x 8 inverse transforms (csdr_amd/csrc/fft_butterflies.hpp) against numpy."""
+    import ctypes as C
+    import numpy as np
+    import csdr_amd
+    L = csdr_amd.lib()
+    L.csdr_amd_debug_dft8.restype = None
+    L.csdr_amd_debug_dft8.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(8)
+    for _ in range(8):
+        x = (rng.uniform(-1, 1, 8) + 1j * rng.uniform(-1, 1, 8)).astype(np.complex64)
+        y = np.zeros(8, np.complex64)
+        L.csdr_amd_debug_dft8(x.ctypes.data, y.ctypes.data, 0)
+        assert np.abs(y - np.fft.fft(x.astype(np.complex128))).max() < 1e-6
+        L.csdr_amd_debug_dft8(x.ctypes.data, y.ctypes.data, 1)
+        assert np.abs(y - 8 * np.fft.ifft(x.astype(np.complex128))).max() < 1e-6
+
+
 def test_nfm_deemph_digit_planes():
     """The NFM chain's de-emphasis FIR on int8 digit planes (csdr_amd/csrc/nfm.hip): 24-bit fixed-point samples x 23-bit taps with the
     low x low digit pair dropped must reproduce the float64 convolution to ~1e-7 of full scale."""

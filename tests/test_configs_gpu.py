@@ -52,6 +52,30 @@ def test_c4_exact_shape(gpu, port):
     assert len(sizes) <= 2 and max(sizes) - min(sizes) <= 1                  # +-1 sample between channels (decimation_remain chain)
 
 
+def test_c4_matrix_core_fold_ragged(gpu, port):
+    """the matrix-core path of the fastddc inverse (fastddc_mfma.hip) with ragged tiles on both axes: 37 channels (two channel waves, the second
+    partly empty), 40 blocks in ONE call (two 32-block accumulator tiles, the second partly empty) followed by a 3-block call (single tile,
+    state carried), every channel compared; and the same call sequence through the general kernels (CSDR_AMD_DDC_MFMA_OFF) gives the same stream."""
+    tbw, D, nch, nb = 0.001, 256, 37, 43
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(44)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = np.concatenate([vc.c4_rates(256)[::8][:32], np.array([0.0, 0.1234, -0.3711, 0.25, -0.4999], f32)])
+    assert rates.size == nch
+    pspec, want = vc.fastddc_oracle_channels(x, tbw, D, rates, range(nch))
+    outs = gpu.fastddc_inv_cc(pspec, tbw, D, rates, blocks_per_call=40)
+    for c in range(nch):
+        assert outs[c].size == want[c].size, "channel %d" % c
+        assert vc.relrms(outs[c], want[c]) < TOL, "channel %d" % c
+    os.environ["CSDR_AMD_DDC_MFMA_OFF"] = "1"
+    try:
+        general = gpu.fastddc_inv_cc(pspec, tbw, D, rates[:5], blocks_per_call=40)
+    finally:
+        del os.environ["CSDR_AMD_DDC_MFMA_OFF"]
+    for c in range(5):
+        assert general[c].size == outs[c].size and vc.relrms(general[c], outs[c]) < TOL
+
+
 def test_c2_wfm_at_1024_streams(gpu):
     """bench.py's timed configuration: 1024 streams x 2 400 256 samples (4.9 GB of u8 IQ), 16 full audio rows of the bench's noise input vs
     the oracle (statistical gate, see verify_configs.verify_wfm) and 6 rows carrying a real FM signal, spread over other stream blocks,
