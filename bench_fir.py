@@ -114,9 +114,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = bc.cpu_baseline("fir", (D, args.tbw), single_amount=100.0, probe_amount=4.0, target_wall_s=8.0,
                                                   describe="fir_decimate_cc %d %g on one 2.4 MS/s complexf stream per thread, 16384-sample blocks + refeed (csdr.c:1160-1176)" % (D, args.tbw))
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
         if args.verify and not res["verify"]["ok"]:
             raise SystemExit("bench_fir.py --verify failed")
+    taps.free()                                                       # device buffers go before their context
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -180,9 +180,9 @@ class DevBuf:
             raise CsdrAmdError(ctx.err())
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:                  # a buffer that outlives its (closed) context is gone with the process
             lib().csdr_amd_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:

@@ -517,6 +517,8 @@ def test_cli_fastddc_bank(port, tmp_path):
     # retune channel 1 through the control fifo between two calls (two blocks per call here)
     fifo = str(tmp_path / "ctl"); os.mkfifo(fifo)
     args[4] = fifo
+    for o in outs:
+        os.remove(o)                                                  # the wait below must not see the first run's files
     env = dict(os.environ, CSDR_AMD_BLOCK=str(2 * ddc.input_size))
     p = subprocess.Popen([CLI] + [str(a) for a in args], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     ctl = open(fifo, "w")
@@ -536,7 +538,9 @@ def test_cli_fastddc_bank(port, tmp_path):
     part2 = port.fastddc_inv_cc(spectra[2:], d2, port.fastddc_taps_fft(d2, 0.05, D))       # status restarts from zero like the reference's rebuild
     got = np.fromfile(outs[1], c64)
     want = np.concatenate([part1, part2])
-    assert got.size == want.size and relrms(got, want) <= TOL
+    assert got.size == want.size
+    assert relrms(got[:part1.size], part1) <= TOL, "before the retune"
+    assert relrms(got[part1.size:], part2) <= TOL, "after the retune"
     got0 = np.fromfile(outs[0], c64)                                                         # the other channels are untouched by the retune
     d0, _ = port.fastddc_init(tbw, D, rates[0])
     assert relrms(got0, port.fastddc_inv_cc(spectra, d0, port.fastddc_taps_fft(d0, rates[0], D))) <= TOL
