@@ -34,26 +34,24 @@ def verify(ctx, L, ddc, args, x, rates, first, count, nb):
     import verify_configs as vc
     import torch
     my_rates = np.ascontiguousarray(rates[first:first + count])
-    inv = L.csdr_amd_fastddc_inv_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
-    fwd = L.csdr_amd_fastddc_fwd_create(ctx.h, C.byref(ddc), nb)
+    bank = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
+    inv = L.csdr_amd_fastddc_bank_inverse(bank)
     pitch = L.csdr_amd_fastddc_inv_max_output(inv, nb) + 8
     out = torch.zeros((count, pitch, 2), dtype=torch.float32, device=x.device)
-    spectra = torch.empty((nb, ddc.fft_size, 2), dtype=torch.float32, device=x.device)
     counts = np.zeros(count, np.int32)
-    assert L.csdr_amd_fastddc_fwd_process(fwd, x.data_ptr(), spectra.data_ptr(), nb) >= 0, ctx.err()
-    assert L.csdr_amd_fastddc_inv_process(inv, spectra.data_ptr(), nb, out.data_ptr(), pitch, counts.ctypes.data_as(C.c_void_p)) >= 0, ctx.err()
+    assert L.csdr_amd_fastddc_bank_process(bank, x.data_ptr(), nb, out.data_ptr(), pitch, counts.ctypes.data_as(C.c_void_p)) >= 0, ctx.err()
     ctx.sync()
     xh = x.cpu().numpy().view(np.complex64).ravel()
     chans = vc.pick_rows(count)
     pspec, want = vc.fastddc_oracle_channels(xh, args.tbw, args.decimation, my_rates, chans)
-    worst = vc.relrms(spectra.cpu().numpy().view(np.complex64).reshape(nb, -1), pspec)
-    ok = worst < 1e-5
+    worst = 0.0
+    ok = True
     for c in chans:
         got = out[c, :counts[c]].cpu().numpy().view(np.complex64).ravel()
         ok = ok and got.size == want[c].size
         worst = max(worst, vc.relrms(got[:want[c].size], want[c]))
     kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
-    L.csdr_amd_fastddc_inv_destroy(inv); L.csdr_amd_fastddc_fwd_destroy(fwd)
+    L.csdr_amd_fastddc_bank_destroy(bank)
     return {"channels": chans, "blocks": nb, "max_rel_rms": worst, "tolerance": 1e-5, "kernel": kname, "ok": bool(ok and worst < 1e-5)}
 
 
@@ -90,7 +88,16 @@ def main():
     rates = (-0.5 + (np.arange(args.channels) + 0.5) / args.channels).astype(np.float32)
     first, count = cd.shard(args.channels, rank, world)
     my_rates = np.ascontiguousarray(rates[first:first + count])
-    inv = L.csdr_amd_fastddc_inv_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
+    # one GPU: the bank object (forward + inverse in one call; at this geometry the forward transform writes the fold's layout directly).
+    # several GPUs: rank 0 transforms, the spectrum is broadcast, every rank inverts its channel slice.
+    bank = None
+    if world == 1:
+        bank = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
+        if not bank:
+            raise SystemExit("fastddc_bank_create: " + ctx.err())
+        inv = L.csdr_amd_fastddc_bank_inverse(bank)
+    else:
+        inv = L.csdr_amd_fastddc_inv_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
     if not inv:
         raise SystemExit("fastddc_inv_create: " + ctx.err())
     pitch = L.csdr_amd_fastddc_inv_max_output(inv, nb) + 8
@@ -98,12 +105,18 @@ def main():
     spectra = torch.empty((nb, ddc.fft_size, 2), dtype=torch.float32, device=dev)
     fwd = None
     if rank == 0:
-        fwd = L.csdr_amd_fastddc_fwd_create(ctx.h, C.byref(ddc), nb)
+        if world > 1:
+            fwd = L.csdr_amd_fastddc_fwd_create(ctx.h, C.byref(ddc), nb)
         g = torch.Generator(device=dev); g.manual_seed(4)
         x = (torch.rand((nb * ddc.input_size, 2), device=dev, generator=g) * 2 - 1).contiguous()
     torch.cuda.synchronize()
 
     def step():
+        if bank:
+            rc = L.csdr_amd_fastddc_bank_process(bank, x.data_ptr(), nb, out.data_ptr(), pitch, None)
+            if rc < 0:
+                raise SystemExit(ctx.err())
+            return
         if rank == 0:
             rc = L.csdr_amd_fastddc_fwd_process(fwd, x.data_ptr(), spectra.data_ptr(), nb)
             if rc < 0:
@@ -165,7 +178,10 @@ def main():
         print(json.dumps(res))
         if args.verify and not res["verify"]["ok"]:
             raise SystemExit("bench_fastddc.py --verify failed: %s" % json.dumps(res["verify"]))
-    L.csdr_amd_fastddc_inv_destroy(inv)
+    if bank:
+        L.csdr_amd_fastddc_bank_destroy(bank)
+    else:
+        L.csdr_amd_fastddc_inv_destroy(inv)
     if fwd:
         L.csdr_amd_fastddc_fwd_destroy(fwd)
     ctx.close()

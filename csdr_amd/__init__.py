@@ -139,6 +139,13 @@ def lib():
     L.csdr_amd_fastddc_inv_geometry.argtypes = [vp, i, vp]
     L.csdr_amd_fastddc_inv_max_output.argtypes = [vp, i]
     L.csdr_amd_fastddc_inv_process.argtypes = [vp, vp, i, vp, sz, vp]
+    L.csdr_amd_fastddc_bank_create.restype = vp; L.csdr_amd_fastddc_bank_create.argtypes = [vp, fl, i, vp, i, i, i]
+    L.csdr_amd_fastddc_bank_destroy.argtypes = [vp]; L.csdr_amd_fastddc_bank_destroy.restype = None
+    L.csdr_amd_fastddc_bank_set_rate.argtypes = [vp, i, fl]
+    L.csdr_amd_fastddc_bank_input_size.argtypes = [vp]
+    L.csdr_amd_fastddc_bank_max_output.argtypes = [vp, i]
+    L.csdr_amd_fastddc_bank_process.argtypes = [vp, vp, i, vp, sz, vp]
+    L.csdr_amd_fastddc_bank_inverse.restype = vp; L.csdr_amd_fastddc_bank_inverse.argtypes = [vp]
     L.csdr_amd_fastddc_inv_kernel_name.restype = C.c_char_p; L.csdr_amd_fastddc_inv_kernel_name.argtypes = [vp]
     L.csdr_amd_fastddc_inv_set_profiling.argtypes = [vp, i]
     L.csdr_amd_fastddc_inv_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
@@ -581,6 +588,36 @@ class Context:
                 outs[c].append(y[c, :counts[c]].copy())
             b += k
         self.L.csdr_amd_fastddc_inv_destroy(f)
+        return [np.concatenate(o) for o in outs]
+
+    def fastddc_bank(self, x, tbw, decimation, shift_rates, window="HAMMING", blocks_per_call=None, retune=None):
+        """forward + inverse in one object (csdr_amd_fastddc_bank_*): x = wideband samples -> list of per-channel outputs.
+        retune = (call_index, channel, rate): applied before that call."""
+        x = np.ascontiguousarray(x, c64)
+        rates = np.ascontiguousarray(shift_rates, f32); nc = rates.size
+        ddc, _ = self.fastddc_init(tbw, decimation, 0.0)
+        nb = x.size // ddc.input_size
+        per = nb if not blocks_per_call else blocks_per_call
+        bk = self.L.csdr_amd_fastddc_bank_create(self.h, tbw, decimation, _hp(rates), nc, WINDOWS[window], max(per, 1))
+        if not bk:
+            raise CsdrAmdError(self.err())
+        di = self.upload(x)
+        outs = [[] for _ in range(nc)]
+        b = 0; call = 0
+        while b < nb:
+            k = min(per, nb - b)
+            if retune and retune[0] == call:
+                self.check(self.L.csdr_amd_fastddc_bank_set_rate(bk, retune[1], retune[2]), "bank_set_rate")
+            pitch = self.L.csdr_amd_fastddc_bank_max_output(bk, k) + 8
+            do = self.alloc(8 * nc * pitch)
+            counts = np.zeros(nc, np.int32)
+            self.check(self.L.csdr_amd_fastddc_bank_process(bk, di.at(8 * b * ddc.input_size), k, do.ptr, pitch, _hp(counts)), "fastddc_bank")
+            y = self.download(do, c64, nc * pitch).reshape(nc, pitch)
+            for c in range(nc):
+                outs[c].append(y[c, :counts[c]].copy())
+            b += k; call += 1
+        self.last_ddc_kernel = self.L.csdr_amd_fastddc_inv_kernel_name(self.L.csdr_amd_fastddc_bank_inverse(bk)).decode()
+        self.L.csdr_amd_fastddc_bank_destroy(bk)
         return [np.concatenate(o) for o in outs]
 
     def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0):

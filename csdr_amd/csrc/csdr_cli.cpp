@@ -764,16 +764,15 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
     csdr_fastddc_t ddc;
     if (csdr_amd_fastddc_init(&ddc, tbw, D, 0)) return badsyntax("error in fastddc_init()");
     int nb_max = (int)(block / ddc.input_size); if (nb_max < 1) nb_max = 1;
-    csdr_amd_fastddc_fwd *fwd = csdr_amd_fastddc_fwd_create(c, &ddc, nb_max);
-    csdr_amd_fastddc_inv *inv = csdr_amd_fastddc_inv_create(c, tbw, D, rates.data(), n_ch, window, nb_max);
-    if (!fwd || !inv) die("fastddc_bank create");
-    const size_t pitch = (size_t)csdr_amd_fastddc_inv_max_output(inv, nb_max) + 8;
+    csdr_amd_fastddc_bank *bank = csdr_amd_fastddc_bank_create(c, tbw, D, rates.data(), n_ch, window, nb_max);
+    if (!bank) die("fastddc_bank create");
+    const size_t pitch = (size_t)csdr_amd_fastddc_bank_max_output(bank, nb_max) + 8;
     const size_t in_elems = (size_t)nb_max * ddc.input_size;
     csdr_complexf *h_in = nullptr, *h_out = nullptr;
     if (hipHostMalloc((void **)&h_in, in_elems * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&h_out, (size_t)n_ch * pitch * 8, hipHostMallocDefault) != hipSuccess) die("pinned buffers");
-    csdr_complexf *d_in = (csdr_complexf *)csdr_amd_malloc(c, in_elems * 8 + 64), *d_spec = (csdr_complexf *)csdr_amd_malloc(c, (size_t)nb_max * ddc.fft_size * 8 + 64);
+    csdr_complexf *d_in = (csdr_complexf *)csdr_amd_malloc(c, in_elems * 8 + 64);
     csdr_complexf *d_out = (csdr_complexf *)csdr_amd_malloc(c, (size_t)n_ch * pitch * 8 + 64);
-    if (!d_in || !d_spec || !d_out) die("device buffers");
+    if (!d_in || !d_out) die("device buffers");
     std::vector<int> counts(n_ch);
     fprintf(stderr, "csdr fastddc_bank_cc: %d channels, fft_size = %d, input_size = %d, %d blocks per call\n", n_ch, ddc.fft_size, ddc.input_size, nb_max);
     size_t have = 0;
@@ -788,7 +787,7 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
                 int end = ctl.fill + (int)r, start = 0;
                 for (int i = 0; i < end; i++) if (ctl.buf[i] == '\n') {
                     ctl.buf[i] = 0; int ch = -1; float rate = 0;
-                    if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch) { MUST(csdr_amd_fastddc_inv_set_rate(inv, ch, rate)); fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ch, rate); }
+                    if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch) { MUST(csdr_amd_fastddc_bank_set_rate(bank, ch, rate)); fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ch, rate); }
                     start = i + 1;
                 }
                 memmove(ctl.buf, ctl.buf + start, end - start); ctl.fill = end - start;
@@ -798,8 +797,7 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
         if (nb == 0) continue;
         const size_t used = (size_t)nb * ddc.input_size;
         MUST(csdr_amd_h2d(c, d_in, h_in, used * 8));
-        MUST(csdr_amd_fastddc_fwd_process(fwd, d_in, d_spec, nb));
-        MUST(csdr_amd_fastddc_inv_process(inv, d_spec, nb, d_out, pitch, counts.data()));
+        MUST(csdr_amd_fastddc_bank_process(bank, d_in, nb, d_out, pitch, counts.data()));
         MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_ch * pitch * 8));
         for (int k = 0; k < n_ch; k++) {
             size_t done = 0; const size_t bytes = (size_t)counts[k] * 8; const char *src = (const char *)(h_out + (size_t)k * pitch);

@@ -10,19 +10,26 @@ struct DdcChanState { int remain; float phase; };                     // decimat
 
 struct DdcMfma;   // device-side plan of the matrix-core path
 
+// k_ddc_chain (fftpath.hip): per channel the (decimation_remain, starting_phase, output offset) of every block of a call, and the samples produced
+int ddc_launch_chain(hipStream_t st, DdcChanState *d_state, const ChanGeom *d_geom, int n_channels, int n_blocks, int post_in, int post_dec,
+                     int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts);
+
 // nullptr when the geometry is not the one this path implements (the caller keeps the general kernels)
-DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec);
+DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec, int input_size, int overlap);
 void ddc_mfma_destroy(DdcMfma *m);
 // (re)build the kernel-side layout of the taps spectra of channels [c_first, c_first + c_count) from the natural [channel][fft] array
 int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, int c_count);
-// natural [n_blocks][fft] spectra -> the transposed layout the fold reads (also done by the fused forward transform, which skips the natural array)
+// One call = ddc_mfma_begin_chains, then EITHER ddc_mfma_load_spectra (natural [n_blocks][fft] spectra, the wire format between fastddc_fwd_cc and
+// fastddc_inv_cc) OR ddc_mfma_forward (new input samples; overlap-save framing + own 65536-point transform straight into the fold's layout), then
+// ddc_mfma_process (fold + inverse transforms + scrap + residual shift).
+int ddc_mfma_begin_chains(DdcMfma *m, hipStream_t st, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts);
 int ddc_mfma_load_spectra(DdcMfma *m, hipStream_t st, const cf32 *spectra, int n_blocks);
-// fold + inverse transform + scrap + residual shift of the loaded spectra; blk_* = the per-(channel, block) chain computed by k_ddc_chain
-int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d_geom, const int *d_blk_remain, const float *d_blk_phase,
-                     const int *d_blk_off, cf32 *out, size_t out_pitch);
+bool ddc_mfma_can_forward(const DdcMfma *m);
+int ddc_mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, int n_blocks);
+int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d_geom, const int *d_blk_remain, const int *d_blk_off, cf32 *out, size_t out_pitch);
 int ddc_mfma_set_profiling(DdcMfma *m, int on);
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches);
-// device pointer / pitches of the transposed spectrum buffer Xt[residue][block][q] (for the fused forward transform and the multi-GPU exchange)
+// device pointer / pitches of the transposed spectrum buffer Xt[residue][block][q] (for the multi-GPU exchange)
 cf32 *ddc_mfma_xt(DdcMfma *m, size_t *bytes, int *block_pitch);
 
 } // namespace csdr_amd

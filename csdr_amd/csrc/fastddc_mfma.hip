@@ -36,6 +36,10 @@ struct DdcMfma {
     csdr_amd_ctx *ctx;
     int fft, inv, pre, G, C, Cpad, nbp, scrap, post_in, post_dec, kmax, rpitch, max_blocks;
     float *d_Ht; cf32 *d_Xt, *d_Ct; float2 *d_R, *d_tw;
+    // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
+    cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
+    // the per-(channel, block) state chain and phasor chains are data independent: they run on a side stream beside the transforms and the fold
+    hipStream_t side; hipEvent_t ev_fork, ev_join;
     // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
     bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -174,59 +178,150 @@ __global__ __launch_bounds__(64) void k_ddc_rot(const ChanGeom *__restrict__ geo
     }
 }
 
-// ------------------------------------------------------------------ 512-point inverse transforms + scrap + residual shift
-// grid (ceil(n_blocks / 16), n_channels), 256 threads.  LDS: 16 transforms x (512 + one pad cell per 8) float2, row pitch 580; the 512 twiddles.
+// ------------------------------------------------------------------ 512-point transforms in LDS: N = 512 = 8 x 8 x 8
+// n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3;  W^(nk) = W8^(n1 k1) W512^((8 n2 + n3) k1) W8^(n2 k2) W64^(n3 k2) W8^(n3 k3).
+// A workgroup of 256 threads holds 16 transforms (rows of I512_PITCH cells, one pad cell per 8: every stage's accesses are conflict free or 2-way).
+// Stage 1 works on values straight from global memory: thread (j = t & 15: transform, i = t >> 4) loads x_j[64 a + tp], a = 0..7, for its four
+// tp = i + 16 s, so the 16 lanes j of one load instruction read one 128-byte run; stages 2 and 3 are done by one wave per transform, in place.
 constexpr int I512_PITCH = 580;
 __device__ __forceinline__ int pad8(int idx) { return idx + (idx >> 3); }
 
+template <bool INV>
+__device__ __forceinline__ void fft512_stage1_store(float2 (&v)[8], float2 *row, int tp, const float2 *tw)
+{
+    dft8<INV>(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) { float2 w = tw[(k1 * tp) & 511]; if (INV) w.y = -w.y; row[pad8(64 * k1 + tp)] = cmul(v[k1], w); }
+}
+// stages 2 and 3 of the 16 rows: wave w takes rows w, w + 4, w + 8, w + 12; all 256 threads must call it (barriers inside)
+template <bool INV>
+__device__ __forceinline__ void fft512_stages23(float2 *data, int t, const float2 *tw)
+{
+    const int wave = t >> 6, lane = t & 63, hi3 = lane >> 3, lo3 = lane & 7;
+    for (int round = 0; round < 4; round++) {
+        float2 *row = data + (4 * round + wave) * I512_PITCH;
+        float2 v[8];
+#pragma unroll
+        for (int n2 = 0; n2 < 8; n2++) v[n2] = row[pad8(64 * hi3 + 8 * n2 + lo3)];            // lane = (k1, n3), over n2; in place
+        dft8<INV>(v);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) { float2 w = tw[(8 * k2 * lo3) & 511]; if (INV) w.y = -w.y; row[pad8(64 * hi3 + 8 * k2 + lo3)] = cmul(v[k2], w); }
+        __syncthreads();
+#pragma unroll
+        for (int n3 = 0; n3 < 8; n3++) v[n3] = row[pad8(64 * hi3 + 8 * lo3 + n3)];            // lane = (k1, k2), over n3
+        dft8<INV>(v);
+        __syncthreads();                                                                      // results land on other lanes' inputs
+#pragma unroll
+        for (int k3 = 0; k3 < 8; k3++) row[pad8(hi3 + 8 * lo3 + 64 * k3)] = v[k3];            // natural position k1 + 8 k2 + 64 k3
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ fused forward transform, 65536 = 512 (k1 = bin residue) x 128 (k2 = q')
+//   X[k1 + 512 k2] = sum_n2 W_N^(n2 k1) W_128^(n2 k2) [ sum_n1 x[128 n1 + n2] W_512^(n1 k1) ]          (csdr.c:2289-2299: window b = stream[b inp - ovl ..))
+// pass 1: 512-point transforms over n1 for 16 consecutive n2 per workgroup (128-byte runs on both sides), times W_N^(n2 k1), to Y[block][k1][n2];
+// pass 2: 128-point transforms over n2 -- one per (residue, block), input and output 1 KiB contiguous -- written straight in the fold's layout
+// Xt[residue][block][q] (q = q' with the first fft_swap_sides folded in).  The natural-order spectrum never exists; no framing copy.
+__global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ Y,
+                                                    const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl)
+{
+    extern __shared__ float4 lds_raw[];
+    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + 16 * I512_PITCH, *twb = tw + 512;
+    const int t = threadIdx.x, j = t & 15, i = t >> 4;
+    const int n2 = 16 * blockIdx.x + j; const long long b = blockIdx.y;
+    tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
+    if (t < 128) twb[t] = g_twb[t];
+    const long long base = b * inp - ovl + n2;
+    float2 v[4][8];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const long long pos = base + 128LL * (64 * a + i + 16 * s);
+            v[s][a] = pos < 0 ? tail[ovl + pos] : in[pos];
+        }
+    __syncthreads();                                                  // twiddle tables
+#pragma unroll
+    for (int s = 0; s < 4; s++) fft512_stage1_store<false>(v[s], data + j * I512_PITCH, i + 16 * s, tw);
+    __syncthreads();
+    fft512_stages23<false>(data, t, tw);
+    float2 *dst = Y + (size_t)b * 65536 + n2;
+#pragma unroll 8
+    for (int p = 0; p < 32; p++) {
+        const int k1 = i + 16 * p, m = n2 * k1;                        // W_65536^m = W_512^(m >> 7) W_65536^(m & 127)
+        dst[(size_t)k1 * 128] = cmul(data[j * I512_PITCH + pad8(k1)], cmul(tw[m >> 7], twb[m & 127]));
+    }
+}
+
+// 128 = 16 (a) x 8 (c): n2 = 8 a + c, k2 = ka + 16 kc; W128^(n2 k2) = W16^(a ka) W128^(c ka) W8^(c kc).  8 lanes per transform, 32 transforms per workgroup.
+__global__ __launch_bounds__(256) void k_ddc_fwd128(const float2 *__restrict__ Y, float2 *__restrict__ Xt, const float2 *__restrict__ g_tw, int nbp, int n_blocks)
+{
+    __shared__ __attribute__((aligned(16))) float2 ex[32 * 144];       // [transform][c][18]: ka fastest, pitch 18
+    const int t = threadIdx.x, tr = t >> 3, c = t & 7, r = blockIdx.x, b = blockIdx.y * 32 + tr;
+    const bool ok = b < n_blocks;
+    const float2 *src = Y + ((size_t)(ok ? b : 0) * 512 + r) * 128;
+    float2 v[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) v[a] = src[8 * a + c];
+    dft16<false>(v);
+#pragma unroll
+    for (int ka = 0; ka < 16; ka++) ex[tr * 144 + c * 18 + ka] = cmul(v[ka], g_tw[(4 * c * ka) & 511]);
+    __syncthreads();
+    float2 e[8], o[8];
+#pragma unroll
+    for (int cc = 0; cc < 8; cc++) {
+        const float4 two = *reinterpret_cast<const float4 *>(&ex[tr * 144 + cc * 18 + 2 * c]);
+        e[cc] = make_float2(two.x, two.y); o[cc] = make_float2(two.z, two.w);
+    }
+    dft8<false>(e); dft8<false>(o);
+    if (!ok) return;
+    float2 *dst = Xt + ((size_t)r * nbp + b) * 128;
+#pragma unroll
+    for (int kc = 0; kc < 8; kc++) {
+        const int q = (2 * c + 16 * kc + 64) & 127;                   // q' = ka + 16 kc with ka = 2 c (and 2 c + 1); q = (q' - pre/2) mod pre
+        *reinterpret_cast<float4 *>(dst + q) = make_float4(e[kc].x, e[kc].y, o[kc].x, o[kc].y);
+    }
+}
+
+// the last `ovl` samples of the stream so far = the next call's overlap (csdr.c:2292)
+__global__ __launch_bounds__(256) void k_ddc_fwd_tail(const float2 *__restrict__ in, const float2 *__restrict__ tail_in, float2 *__restrict__ tail_out, int inp, int ovl, int n_blocks)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ovl) return;
+    const long long pos = (long long)n_blocks * inp - ovl + k;
+    tail_out[k] = pos < 0 ? tail_in[ovl + pos] : in[pos];
+}
+
+// ------------------------------------------------------------------ 512-point inverse transforms + scrap + residual shift
+// grid (ceil(n_blocks / 16), n_channels), 256 threads: the bins of 16 blocks of one channel (128-byte runs per bin) are transformed, the first `scrap`
+// samples dropped (overlap & scrap, fastddc.c:153), every post_dec-th sample from decimation_remain on rotated by the replayed phasor and written.
 __global__ __launch_bounds__(256) void k_ddc_ifft512_post(const float2 *__restrict__ Ct, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ R,
                                                           const float2 *__restrict__ g_tw, const int *__restrict__ blk_remain, const int *__restrict__ blk_off,
                                                           int Cpad, int nbp, int n_blocks, int scrap, int post_in, int post_dec, int rpitch)
 {
     extern __shared__ float4 lds_raw[];
     float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + 16 * I512_PITCH;
-    const int t = threadIdx.x, c = blockIdx.y, b0 = blockIdx.x * 16;
+    const int t = threadIdx.x, c = blockIdx.y, b0 = blockIdx.x * 16, j = t & 15, i = t >> 4;
     tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
-    {   // bins m of 16 blocks: 128-byte runs per bin
-        const int bl = t & 15, mrow = t >> 4;
-        const bool ok = b0 + bl < n_blocks;
-        const float2 *src = Ct + (size_t)c * nbp + b0 + bl;
-#pragma unroll 8
-        for (int p = 0; p < 32; p++) {
-            const int m = 16 * p + mrow;
-            data[bl * I512_PITCH + pad8(m)] = ok ? src[(size_t)m * Cpad * nbp] : make_float2(0.f, 0.f);
+    const bool ok = b0 + j < n_blocks;
+    const float2 *src = Ct + (size_t)c * nbp + b0 + (ok ? j : 0);
+    const size_t mstride = (size_t)Cpad * nbp;
+    float2 v[4][8];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[s][a] = src[(size_t)(64 * a + i + 16 * s) * mstride];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (!ok) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) v[s][a] = make_float2(0.f, 0.f);
         }
+        fft512_stage1_store<true>(v[s], data + j * I512_PITCH, i + 16 * s, tw);
     }
     __syncthreads();
-    const int wave = t >> 6, lane = t & 63;
-    // N = 512: n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3; W^(nk) = W8^(n1 k1) W512^((8 n2 + n3) k1) W8^(n2 k2) W64^(n3 k2) W8^(n3 k3)
-    for (int round = 0; round < 4; round++) {
-        float2 *row = data + (4 * round + wave) * I512_PITCH;
-        float2 v[8];
-        // stage 1: lane = 8 n2 + n3, over n1; in place (a lane reads and writes the same cells)
-#pragma unroll
-        for (int n1 = 0; n1 < 8; n1++) v[n1] = row[pad8(64 * n1 + lane)];
-        dft8<true>(v);
-#pragma unroll
-        for (int k1 = 0; k1 < 8; k1++) { float2 w = tw[(k1 * lane) & 511]; w.y = -w.y; row[pad8(64 * k1 + lane)] = cmul(v[k1], w); }
-        __syncthreads();
-        // stage 2: lane = (k1, n3), over n2; in place
-        const int hi3 = lane >> 3, lo3 = lane & 7;
-#pragma unroll
-        for (int n2 = 0; n2 < 8; n2++) v[n2] = row[pad8(64 * hi3 + 8 * n2 + lo3)];
-        dft8<true>(v);
-#pragma unroll
-        for (int k2 = 0; k2 < 8; k2++) { float2 w = tw[(8 * k2 * lo3) & 511]; w.y = -w.y; row[pad8(64 * hi3 + 8 * k2 + lo3)] = cmul(v[k2], w); }
-        __syncthreads();
-        // stage 3: lane = (k1, k2), over n3; results go to natural positions k1 + 8 k2 + 64 k3 (other lanes' inputs: barrier first)
-#pragma unroll
-        for (int n3 = 0; n3 < 8; n3++) v[n3] = row[pad8(64 * hi3 + 8 * lo3 + n3)];
-        dft8<true>(v);
-        __syncthreads();
-#pragma unroll
-        for (int k3 = 0; k3 < 8; k3++) row[pad8(hi3 + 8 * lo3 + 64 * k3)] = v[k3];
-    }
-    __syncthreads();
+    fft512_stages23<true>(data, t, tw);
     // fastddc.c:153-162: /size, drop `scrap` samples, rotate every post_dec-th sample from decimation_remain on
     const float inv_n = 1.0f / 512.0f;
     for (int bl = 0; bl < 16; bl++) {
@@ -249,7 +344,7 @@ __global__ __launch_bounds__(256) void k_ddc_ifft512_post(const float2 *__restri
 } // namespace
 
 // ====================================================================================== host side
-DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec)
+DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec, int input_size, int overlap)
 {
     if (getenv("CSDR_AMD_DDC_MFMA_OFF")) return nullptr;
     if (inv != 512 || pre < 8 || (pre & (pre - 1)) || fft != inv * pre || post_dec < 1 || scrap + post_in > inv) return nullptr;
@@ -257,24 +352,36 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
     m->ctx = ctx; m->fft = fft; m->inv = inv; m->pre = pre; m->G = pre / 4; m->C = n_channels; m->Cpad = (n_channels + 31) / 32 * 32;
     m->max_blocks = max_blocks; m->nbp = (max_blocks + 31) / 32 * 32; m->scrap = scrap; m->post_in = post_in; m->post_dec = post_dec;
     m->kmax = (post_in - 1) / post_dec + 1; m->rpitch = (m->kmax + 31) / 32 * 32;
-    m->d_Ht = nullptr; m->d_Xt = nullptr; m->d_Ct = nullptr; m->d_R = nullptr; m->d_tw = nullptr;
+    m->input_size = input_size; m->overlap = overlap; m->flip = 0;
+    m->d_Ht = nullptr; m->d_Xt = nullptr; m->d_Ct = nullptr; m->d_R = nullptr; m->d_tw = nullptr; m->d_Y = nullptr; m->d_tail[0] = m->d_tail[1] = nullptr; m->d_twb = nullptr;
+    m->side = nullptr; m->ev_fork = nullptr; m->ev_join = nullptr;
     hipError_t e = hipMalloc((void **)&m->d_Ht, sizeof(float) * 2 * (size_t)m->Cpad * fft);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Xt, sizeof(cf32) * (size_t)fft * m->nbp);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Ct, sizeof(cf32) * (size_t)inv * m->Cpad * m->nbp);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_R, sizeof(float2) * (size_t)n_channels * max_blocks * m->rpitch);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_tw, sizeof(float2) * 512);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_twb, sizeof(float2) * 128);
     if (e == hipSuccess) e = hipMemsetAsync(m->d_Ht, 0, sizeof(float) * 2 * (size_t)m->Cpad * fft, ctx->stream);      // padded channel rows stay zero
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { fail(e, "hipMalloc(fastddc matrix-core path)", __FILE__, __LINE__); ddc_mfma_destroy(m); return nullptr; }
-    std::vector<float2> tw(512);
+    std::vector<float2> tw(512), twb(128);
     for (int k = 0; k < 512; k++) { const double a = -2.0 * M_PI * k / 512.0; tw[k] = make_float2((float)cos(a), (float)sin(a)); }
-    if (hipMemcpy(m->d_tw, tw.data(), sizeof(float2) * 512, hipMemcpyHostToDevice) != hipSuccess) { ddc_mfma_destroy(m); return nullptr; }
+    for (int k = 0; k < 128; k++) { const double a = -2.0 * M_PI * k / 65536.0; twb[k] = make_float2((float)cos(a), (float)sin(a)); }
+    if (hipMemcpy(m->d_tw, tw.data(), sizeof(float2) * 512, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_twb, twb.data(), sizeof(float2) * 128, hipMemcpyHostToDevice) != hipSuccess) { ddc_mfma_destroy(m); return nullptr; }
     return m;
 }
 
 void ddc_mfma_destroy(DdcMfma *m)
 {
     if (!m) return;
-    (void)hipFree(m->d_Ht); (void)hipFree(m->d_Xt); (void)hipFree(m->d_Ct); (void)hipFree(m->d_R); (void)hipFree(m->d_tw);
+    if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    (void)hipFree(m->d_Ht); (void)hipFree(m->d_Xt); (void)hipFree(m->d_Ct); (void)hipFree(m->d_R); (void)hipFree(m->d_tw); (void)hipFree(m->d_twb);
+    (void)hipFree(m->d_Y); (void)hipFree(m->d_tail[0]); (void)hipFree(m->d_tail[1]);
     for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete m;
 }
@@ -293,6 +400,36 @@ int ddc_mfma_load_spectra(DdcMfma *m, hipStream_t st, const cf32 *spectra, int n
     hipLaunchKernelGGL(k_ddc_xt, dim3(cdiv(m->inv, 32), cdiv(m->pre, 32), n_blocks), dim3(256), 0, st, reinterpret_cast<const float2 *>(spectra),
                        reinterpret_cast<float2 *>(m->d_Xt), m->fft, m->inv, m->pre, m->nbp);
     CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->pre == 128 && !getenv("CSDR_AMD_DDC_FWD_OFF"); }
+
+// fastddc_fwd_cc's overlap-save framing + forward transform of n_blocks x input_size NEW samples (csdr.c:2289-2299), result in the fold's own layout
+int ddc_mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, int n_blocks)
+{
+    if (!ddc_mfma_can_forward(m)) return fail_msg(-3, "fastddc: the fused forward transform covers fft_size 65536 / pre_decimation 128 only");
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
+    if (!m->d_Y) {
+        hipError_t e = hipMalloc((void **)&m->d_Y, sizeof(cf32) * (size_t)m->max_blocks * m->fft);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipMalloc((void **)&m->d_tail[k], sizeof(cf32) * (size_t)(m->overlap + 1));
+            if (e == hipSuccess) e = hipMemsetAsync(m->d_tail[k], 0, sizeof(cf32) * (size_t)(m->overlap + 1), st);        // csdr.c:2279: the first window starts with zeros
+        }
+        if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
+    }
+    const size_t lds = (size_t)(16 * I512_PITCH + 512 + 128) * sizeof(float2);
+    { const int rc = lds_attr_once((const void *)k_ddc_fwd512, lds); if (rc) return rc; }
+    hipLaunchKernelGGL(k_ddc_fwd512, dim3(8, n_blocks), dim3(256), lds, st, reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]),
+                       reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap);
+    CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_blocks, 32)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(m->d_Xt), m->d_tw, m->nbp, n_blocks);
+    CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ddc_fwd_tail, dim3(cdiv(m->overlap, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]),
+                       reinterpret_cast<float2 *>(m->d_tail[m->flip ^ 1]), m->input_size, m->overlap, n_blocks);
+    CSDR_LAUNCH_CHECK();
+    m->flip ^= 1;
     return 0;
 }
 
@@ -316,14 +453,27 @@ cf32 *ddc_mfma_xt(DdcMfma *m, size_t *bytes, int *block_pitch)
     return m->d_Xt;
 }
 
-int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d_geom, const int *d_blk_remain, const float *d_blk_phase,
-                     const int *d_blk_off, cf32 *out, size_t out_pitch)
+// The per-channel state chain over the blocks of this call and the phasor chains of every (channel, block) do not depend on the samples: they are
+// queued on the side stream (ordered after everything already on `st`, e.g. the previous call's readers of the same tables) while `st` carries the
+// transforms and the fold; `st` waits for them just before the inverse transforms.  Call BEFORE the forward transform / ddc_mfma_load_spectra.
+int ddc_mfma_begin_chains(DdcMfma *m, hipStream_t st, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts)
 {
     if (n_blocks <= 0) return 0;
     if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
+    CSDR_HIP(hipEventRecord(m->ev_fork, st));
+    CSDR_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    int rc = ddc_launch_chain(m->side, d_state, d_geom, m->C, n_blocks, m->post_in, m->post_dec, d_blk_remain, d_blk_phase, d_blk_off, d_counts); if (rc) return rc;
     const int n_chains = m->C * n_blocks;
-    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, st, d_geom, d_blk_phase, m->d_R, n_chains, n_blocks, m->kmax, m->rpitch);
+    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, m->side, d_geom, d_blk_phase, m->d_R, n_chains, n_blocks, m->kmax, m->rpitch);
     CSDR_LAUNCH_CHECK();
+    CSDR_HIP(hipEventRecord(m->ev_join, m->side));
+    return 0;
+}
+
+int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d_geom, const int *d_blk_remain, const int *d_blk_off, cf32 *out, size_t out_pitch)
+{
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
     const float scale = 1.0f / (float)m->pre;                              // fastddc.c:144-148 (a power of two: exact)
     const int nbt = n_blocks > 32 ? 2 : 1;
     const size_t lds = (size_t)32 * nbt * (m->pre / 2 + 1) * sizeof(float4);
@@ -348,6 +498,7 @@ int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d
     }
     CSDR_LAUNCH_CHECK();
     if (e1) CSDR_HIP(hipEventRecord(e1, st));
+    CSDR_HIP(hipStreamWaitEvent(st, m->ev_join, 0));                      // the chains of ddc_mfma_begin_chains
     const size_t lds2 = (size_t)(16 * I512_PITCH + 512) * sizeof(float2);
     { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post, lds2); if (rc) return rc; }
     hipLaunchKernelGGL(k_ddc_ifft512_post, dim3(cdiv(n_blocks, 16), m->C), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,

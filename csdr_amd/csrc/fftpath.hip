@@ -255,6 +255,16 @@ __global__ __launch_bounds__(256) void k_scale_add(cf32 *__restrict__ io, size_t
 
 } // namespace
 
+namespace csdr_amd {
+int ddc_launch_chain(hipStream_t st, DdcChanState *d_state, const ChanGeom *d_geom, int n_channels, int n_blocks, int post_in, int post_dec,
+                     int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts)
+{
+    hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(n_channels, 64)), dim3(64), 0, st, d_state, d_geom, n_channels, n_blocks, post_in, post_dec, d_blk_remain, d_blk_phase, d_blk_off, d_counts);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+}
+
 // cached single-transform plans for the drop-in FFT layer
 static std::map<std::pair<int, long>, hipfftHandle> g_c2c_plans;
 static std::mutex g_c2c_mu;      // the map is shared by every context (the drop-in layer has one context per host thread)
@@ -513,7 +523,7 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
     const csdr_fastddc_t &g = f->geom[0];
     const int fft = g.fft_size, inv = g.fft_inv_size;
     f->d_inv_in = nullptr; f->d_td = nullptr;
-    f->mf = ddc_mfma_create(ctx, fft, inv, g.pre_decimation, n_channels, max_blocks, g.scrap, g.post_input_size, g.post_decimation);
+    f->mf = ddc_mfma_create(ctx, fft, inv, g.pre_decimation, n_channels, max_blocks, g.scrap, g.post_input_size, g.post_decimation, g.input_size, g.overlap_length);
     hipError_t e = hipMalloc((void **)&f->d_H, sizeof(cf32) * (size_t)n_channels * fft);
     if (!f->mf) {                                                  // the general path's [channel][block][inv] intermediates
         if (e == hipSuccess) e = hipMalloc((void **)&f->d_inv_in, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
@@ -618,10 +628,9 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
     const int fft = g.fft_size, inv = g.fft_inv_size, pre = g.pre_decimation;
     if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_inv: out_pitch too small");
     if (f->mf) {   // config 4's geometry: fold on the matrix cores, own 512-point inverse transforms fused with scrap + residual shift
-        hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(f->n_channels, 64)), dim3(64), 0, st, f->d_state, f->d_geom, f->n_channels, n_blocks, g.post_input_size, g.post_decimation,
-                           f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); CSDR_LAUNCH_CHECK();
-        int rc = ddc_mfma_load_spectra(f->mf, st, spectra, n_blocks); if (rc) return rc;
-        rc = ddc_mfma_process(f->mf, st, n_blocks, f->d_geom, f->d_blk_remain, f->d_blk_phase, f->d_blk_off, out, out_pitch); if (rc) return rc;
+        int rc = ddc_mfma_begin_chains(f->mf, st, n_blocks, f->d_state, f->d_geom, f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); if (rc) return rc;
+        rc = ddc_mfma_load_spectra(f->mf, st, spectra, n_blocks); if (rc) return rc;
+        rc = ddc_mfma_process(f->mf, st, n_blocks, f->d_geom, f->d_blk_remain, f->d_blk_off, out, out_pitch); if (rc) return rc;
         if (out_counts) {
             CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
             CSDR_HIP(hipStreamSynchronize(st));
@@ -654,6 +663,70 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
                        f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ddc_post, dim3(cdiv((size_t)batch, 64)), dim3(64), 0, st, f->d_td, out, out_pitch, f->d_geom, f->n_channels, n_blocks, inv, g.scrap,
                        g.post_input_size, g.post_decimation, f->d_blk_remain, f->d_blk_phase, f->d_blk_off); CSDR_LAUNCH_CHECK();
+    if (out_counts) {
+        CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
+        CSDR_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+} // extern "C"
+
+// ====================================================================================== fastddc bank: forward + multi-channel inverse in one object
+// The ddcd topology (ddcd_old.cpp:238-252, 474-492: one `csdr fastddc_fwd_cc` feeding N `csdr fastddc_inv_cc --fd` clients) as ONE call per block
+// batch: new wideband samples in, every channel's decimated samples out.  At config 4's geometry the forward transform writes the fold's own
+// layout directly (fastddc_mfma.hip: no natural-order spectrum, no framing copy); other geometries chain the two halves through a spectrum buffer.
+struct csdr_amd_fastddc_bank {
+    csdr_amd_ctx *ctx; csdr_amd_fastddc_inv *inv; csdr_amd_fastddc_fwd *fwd; cf32 *d_spec; int max_blocks; bool fused;
+};
+
+extern "C" {
+
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
+                                                    int window, int max_blocks)
+{
+    csdr_amd_fastddc_bank *b = new csdr_amd_fastddc_bank();
+    b->ctx = ctx; b->max_blocks = max_blocks; b->fwd = nullptr; b->d_spec = nullptr;
+    b->inv = csdr_amd_fastddc_inv_create(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, max_blocks);
+    if (!b->inv) { delete b; return nullptr; }
+    b->fused = ddc_mfma_can_forward(b->inv->mf);
+    if (!b->fused) {
+        csdr_fastddc_t g = b->inv->geom[0];
+        b->fwd = csdr_amd_fastddc_fwd_create(ctx, &g, max_blocks);
+        if (!b->fwd || hipMalloc((void **)&b->d_spec, sizeof(cf32) * (size_t)max_blocks * g.fft_size) != hipSuccess) {
+            fail_msg(-2, "fastddc_bank: cannot allocate the spectrum buffer"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
+    }
+    return b;
+}
+
+void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
+{
+    if (!b) return;
+    if (b->fwd) csdr_amd_fastddc_fwd_destroy(b->fwd);
+    if (b->inv) csdr_amd_fastddc_inv_destroy(b->inv);
+    (void)hipFree(b->d_spec);
+    delete b;
+}
+
+int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate) { return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate); }
+int csdr_amd_fastddc_bank_input_size(const csdr_amd_fastddc_bank *b) { return b->inv->geom[0].input_size; }
+int csdr_amd_fastddc_bank_max_output(const csdr_amd_fastddc_bank *b, int n_blocks) { return csdr_amd_fastddc_inv_max_output(b->inv, n_blocks); }
+csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b) { return b->inv; }
+
+int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{
+    if (n_blocks <= 0) return 0;
+    if (n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks exceed max_blocks %d", n_blocks, b->max_blocks);
+    if (!b->fused) {
+        int rc = csdr_amd_fastddc_fwd_process(b->fwd, in, b->d_spec, n_blocks); if (rc) return rc;
+        return csdr_amd_fastddc_inv_process(b->inv, b->d_spec, n_blocks, out, out_pitch, out_counts);
+    }
+    csdr_amd_fastddc_inv *f = b->inv;
+    hipStream_t st = f->ctx->stream;
+    if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
+    int rc = ddc_mfma_begin_chains(f->mf, st, n_blocks, f->d_state, f->d_geom, f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); if (rc) return rc;
+    rc = ddc_mfma_forward(f->mf, st, in, n_blocks); if (rc) return rc;
+    rc = ddc_mfma_process(f->mf, st, n_blocks, f->d_geom, f->d_blk_remain, f->d_blk_off, out, out_pitch); if (rc) return rc;
     if (out_counts) {
         CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
         CSDR_HIP(hipStreamSynchronize(st));

@@ -260,6 +260,21 @@ int  csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *
 const char *csdr_amd_fastddc_inv_kernel_name(const csdr_amd_fastddc_inv *f);
 int  csdr_amd_fastddc_inv_set_profiling(csdr_amd_fastddc_inv *f, int on);
 int  csdr_amd_fastddc_inv_kernel_time(csdr_amd_fastddc_inv *f, double *total_ms, long *launches);
+/* Both halves in one object = the ddcd topology (ddcd_old.cpp:238-252, 474-492: one `csdr fastddc_fwd_cc` feeding N `csdr fastddc_inv_cc --fd` clients)
+ * as one call per batch of blocks: in = n_blocks * input_size NEW wideband samples (the overlap is kept inside), out / out_counts as for
+ * csdr_amd_fastddc_inv_process.  At BASELINE config 4's geometry (fft_size 65536, fft_inv_size 512) the forward transform writes the fold's own layout
+ * directly (no natural-order spectrum, no framing copy). */
+typedef struct csdr_amd_fastddc_bank csdr_amd_fastddc_bank;
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
+                                                    int window, int max_blocks);
+void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b);
+int  csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate);   /* csdr.c:2329-2376 for one client */
+int  csdr_amd_fastddc_bank_input_size(const csdr_amd_fastddc_bank *b);
+int  csdr_amd_fastddc_bank_max_output(const csdr_amd_fastddc_bank *b, int n_blocks);
+int  csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts);
+/* the bank's inverse half (kernel name / profiling: csdr_amd_fastddc_inv_kernel_name, _set_profiling, _kernel_time) */
+csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b);
+
 /* one channel, one block, explicit taps_fft and status = fastddc_inv_cc itself (fastddc.c:106-166).
  * status_io: HOST {decimation_remain, float starting_phase, output_size} (decimating_shift_addition_status_t).
  * d_inv_in / d_td: device scratch of fft_inv_size complexf (folded bins after the second swap / IFFT output, unnormalised). */

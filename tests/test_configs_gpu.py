@@ -76,6 +76,42 @@ def test_c4_matrix_core_fold_ragged(gpu, port):
         assert general[c].size == outs[c].size and vc.relrms(general[c], outs[c]) < TOL
 
 
+def test_c4_bank_fused_forward(gpu, port):
+    """csdr_amd_fastddc_bank_* at config 4's geometry: new samples in -> own 65536 = 512 x 128 forward transform straight into the fold's layout
+    (no natural-order spectrum) -> matrix-core fold -> 512-point inverse transforms; 37 channels, 43 blocks in calls of 40 + 3 (overlap tail and
+    channel state carried), channel 35 retuned before the second call (csdr.c:2329-2376: status restarts), against the oracle's two-process model."""
+    tbw, D, nch, nb = 0.001, 256, 37, 43
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(45)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb + 100) + 1j * rng.uniform(-1, 1, ddc.input_size * nb + 100)).astype(c64)
+    rates = np.concatenate([vc.c4_rates(256)[3::8][:32], np.array([0.0, -0.2222, 0.3711, 0.125, 0.4999], f32)])
+    outs = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=40, retune=(1, 35, 0.0517))
+    assert gpu.last_ddc_kernel == "k_ddc_gemm"
+    pspec, want = vc.fastddc_oracle_channels(x, tbw, D, rates, [c for c in range(nch) if c != 35])
+    for c, w in want.items():
+        assert outs[c].size == w.size, "channel %d" % c
+        assert vc.relrms(outs[c], w) < TOL, "channel %d" % c
+    pd_a, _ = port.fastddc_init(tbw, D, float(rates[35])); pd_b, _ = port.fastddc_init(tbw, D, 0.0517)
+    part_a = port.fastddc_inv_cc(pspec[:40], pd_a, port.fastddc_taps_fft(pd_a, float(rates[35]), D))
+    part_b = port.fastddc_inv_cc(pspec[40:], pd_b, port.fastddc_taps_fft(pd_b, 0.0517, D))
+    w35 = np.concatenate([part_a, part_b])
+    assert outs[35].size == w35.size and vc.relrms(outs[35], w35) < TOL
+
+
+def test_bank_general_geometry(gpu, port):
+    """the same object where the matrix-core path does not apply (fft_inv_size 128): forward and inverse halves chained through a spectrum buffer"""
+    tbw, D = 0.05, 16
+    rates = [-0.1, 0.2, 0.33, 0.05, -0.41]
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(46)
+    x = (rng.uniform(-1, 1, ddc.input_size * 23) + 1j * rng.uniform(-1, 1, ddc.input_size * 23)).astype(c64)
+    outs = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=7)
+    assert gpu.last_ddc_kernel == "k_ddc_fold_ct"
+    _, want = vc.fastddc_oracle_channels(x, tbw, D, np.array(rates, f32), range(len(rates)))
+    for c in range(len(rates)):
+        assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < TOL
+
+
 def test_c2_wfm_at_1024_streams(gpu):
     """bench.py's timed configuration: 1024 streams x 2 400 256 samples (4.9 GB of u8 IQ), 16 full audio rows of the bench's noise input vs
     the oracle (statistical gate, see verify_configs.verify_wfm) and 6 rows carrying a real FM signal, spread over other stream blocks,
