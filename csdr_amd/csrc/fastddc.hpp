@@ -10,10 +10,6 @@ struct DdcChanState { int remain; float phase; };                     // decimat
 
 struct DdcMfma;   // device-side plan of the matrix-core path
 
-// k_ddc_chain (fftpath.hip): per channel the (decimation_remain, starting_phase, output offset) of every block of a call, and the samples produced
-int ddc_launch_chain(hipStream_t st, DdcChanState *d_state, const ChanGeom *d_geom, int n_channels, int n_blocks, int post_in, int post_dec,
-                     int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts);
-
 // nullptr when the geometry is not the one this path implements (the caller keeps the general kernels)
 DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec, int input_size, int overlap);
 void ddc_mfma_destroy(DdcMfma *m);

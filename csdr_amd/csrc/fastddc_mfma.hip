@@ -26,6 +26,8 @@
 #include "fastddc.hpp"
 #include "fft_butterflies.hpp"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 namespace csdr_amd {
@@ -38,8 +40,6 @@ struct DdcMfma {
     float *d_Ht; cf32 *d_Xt, *d_Ct; float2 *d_R, *d_tw;
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
-    // the per-(channel, block) state chain and phasor chains are data independent: they run on a side stream beside the transforms and the fold
-    hipStream_t side; hipEvent_t ev_fork, ev_join;
     // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
     bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -78,103 +78,150 @@ __global__ __launch_bounds__(256) void k_ddc_xt(const float2 *__restrict__ X, fl
 }
 
 // ------------------------------------------------------------------ the fold as a matrix product
-// grid (inv residues, ceil(Cpad / 256) channel groups, ceil(n_blocks / (32 NBT)) block groups); 512 threads: wave w owns channels 32 w .. 32 w + 31 of
+// grid (residue slots, ceil(Cpad / 256) channel groups, ceil(n_blocks / (32 NBT)) block groups); 512 threads: wave w owns channels 32 w .. 32 w + 31 of
 // the group, all 32 NBT blocks of the group and both output parts: 2 NBT accumulator tiles of 32 x 32.
-template <int NBT>
-__global__ __launch_bounds__(512) void k_ddc_gemm(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
+// A workgroup walks the residues r = blockIdx.x, blockIdx.x + gridDim.x, ...  One residue per workgroup (gridDim.x = inv) is the simple form: but then
+// all workgroups of the launch load their spectra, multiply, and store their bins in lockstep, and the matrix cores idle during the first and the last phase
+// (64 KiB in and 128 KiB out per workgroup).  PERSIST (gridDim.x = one workgroup per CU, two LDS buffers): the next residue's spectra are fetched into
+// registers while the current one is multiplied and go to the other buffer afterwards; the bins' stores drain under the next residue's product.
+template <int NBT, bool PERSIST>
+__global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
                                                   const ChanGeom *__restrict__ geom, int inv, int pre, int Cpad, int n_channels, int nbp, int n_blocks, float scale)
 {
-    extern __shared__ float4 xs[];                                  // [32 NBT rows][pre / 2 + 1] float4
-    const int r = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ float4 xs_all[];                              // (PERSIST ? 2 : 1) x [32 NBT rows][pre / 2 + 1] float4
+    constexpr int NX = 4 * NBT;                                     // float4 per thread of one residue's spectra (PERSIST: pre <= 128)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c_base = blockIdx.y * 256 + wave * 32, b_base = blockIdx.z * 32 * NBT;
-    const int G = pre >> 2, P4 = (pre >> 1) + 1, rows = 32 * NBT, row4 = pre >> 1;
-    {   // stage this residue's spectra: rows are contiguous in Xt (pre complex = pre / 2 float4 each)
-        const float4 *src = reinterpret_cast<const float4 *>(Xt + ((size_t)r * nbp + b_base) * pre);
+    const int G = pre >> 2, P4 = (pre >> 1) + 1, rows = 32 * NBT, row4 = pre >> 1, BUF = rows * P4;
+    const int i = lane & 31, hi = lane >> 5;
+    const size_t gstride = (size_t)Cpad * 2;                          // float4 per k-group
+    const bool active = c_base < Cpad;
+    auto xt_src = [&](int r) { return reinterpret_cast<const float4 *>(Xt + ((size_t)r * nbp + b_base) * pre); };
+    {   // stage the first residue's spectra: rows are contiguous in Xt (pre complex = pre / 2 float4 each)
+        const float4 *src = xt_src(blockIdx.x);
         for (int idx = threadIdx.x; idx < rows * row4; idx += 512) {
             const int row = idx / row4, col = idx - row * row4;
-            xs[row * P4 + col] = (b_base + row < n_blocks) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xs_all[row * P4 + col] = (b_base + row < n_blocks) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
-    if (c_base >= Cpad) return;
-    const int i = lane & 31, hi = lane >> 5;
-    const size_t gstride = (size_t)Cpad * 2;                          // float4 per k-group
-    const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_base + i) * 2 + hi;
-    f32x16 acc[NBT][2];
+    int cur = 0;
+    for (int r = blockIdx.x; r < inv; r += gridDim.x) {
+        const int rn = r + gridDim.x;
+        float4 nx[NX];
+        if (PERSIST && rn < inv) {
+            const float4 *src = xt_src(rn);
 #pragma unroll
-    for (int bt = 0; bt < NBT; bt++)
+            for (int k = 0; k < NX; k++) {
+                const int idx = threadIdx.x + 512 * k, row = idx / row4;
+                nx[k] = (idx < rows * row4 && b_base + row < n_blocks) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (active) {
+            const float4 *xs = xs_all + cur * BUF;
+            const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_base + i) * 2 + hi;
+            f32x16 acc[NBT][2];
 #pragma unroll
-        for (int p = 0; p < 2; p++)
+            for (int bt = 0; bt < NBT; bt++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc[bt][p][e] = 0.f;
-    // four k-groups in flight (indices clamped: a short K loop re-loads its last group instead of branching)
-    float4 a0 = ap[0], a1 = ap[(size_t)min(1, G - 1) * gstride], a2 = ap[(size_t)min(2, G - 1) * gstride], a3 = ap[(size_t)min(3, G - 1) * gstride];
-    const float4 *xrow = xs + i * P4 + hi;
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[bt][p][e] = 0.f;
+            // four k-groups in flight (indices clamped: a short K loop re-loads its last group instead of branching)
+            float4 a0 = ap[0], a1 = ap[(size_t)min(1, G - 1) * gstride], a2 = ap[(size_t)min(2, G - 1) * gstride], a3 = ap[(size_t)min(3, G - 1) * gstride];
+            const float4 *xrow = xs + i * P4 + hi;
 #define DDC_STEP(AV, GG)                                                                                                   \
-    {                                                                                                                      \
-        _Pragma("unroll") for (int bt = 0; bt < NBT; bt++) {                                                               \
-            const float4 xv = xrow[bt * 32 * P4 + 2 * (GG)];                                                               \
-            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.x, acc[bt][0], 0, 0, 0);                          \
-            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.y, acc[bt][1], 0, 0, 0);                          \
-            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, -xv.y, acc[bt][0], 0, 0, 0);                         \
-            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, xv.x, acc[bt][1], 0, 0, 0);                          \
-            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.z, acc[bt][0], 0, 0, 0);                          \
-            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.w, acc[bt][1], 0, 0, 0);                          \
-            acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, -xv.w, acc[bt][0], 0, 0, 0);                         \
-            acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, xv.z, acc[bt][1], 0, 0, 0);                          \
-        }                                                                                                                  \
-    }
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {                                      // straight-line body: the loads stay four groups ahead of their use
-        { const float4 av = a0; a0 = ap[(size_t)min(g + 4, G - 1) * gstride]; DDC_STEP(av, g); }
-        { const float4 av = a1; a1 = ap[(size_t)min(g + 5, G - 1) * gstride]; DDC_STEP(av, g + 1); }
-        { const float4 av = a2; a2 = ap[(size_t)min(g + 6, G - 1) * gstride]; DDC_STEP(av, g + 2); }
-        { const float4 av = a3; a3 = ap[(size_t)min(g + 7, G - 1) * gstride]; DDC_STEP(av, g + 3); }
-    }
-    if (g < G) { DDC_STEP(a0, g); }                                   // pre_decimation = 8 ... (G not a multiple of 4)
-    if (g + 1 < G) { DDC_STEP(a1, g + 1); }
-    if (g + 2 < G) { DDC_STEP(a2, g + 2); }
+            {                                                                                                              \
+                _Pragma("unroll") for (int bt = 0; bt < NBT; bt++) {                                                       \
+                    const float4 xv = xrow[bt * 32 * P4 + 2 * (GG)];                                                       \
+                    acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.x, acc[bt][0], 0, 0, 0);                  \
+                    acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.y, acc[bt][1], 0, 0, 0);                  \
+                    acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, -xv.y, acc[bt][0], 0, 0, 0);                 \
+                    acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, xv.x, acc[bt][1], 0, 0, 0);                  \
+                    acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.z, acc[bt][0], 0, 0, 0);                  \
+                    acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.w, acc[bt][1], 0, 0, 0);                  \
+                    acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, -xv.w, acc[bt][0], 0, 0, 0);                 \
+                    acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, xv.z, acc[bt][1], 0, 0, 0);                  \
+                }                                                                                                          \
+            }
+            int g = 0;
+            for (; g + 4 <= G; g += 4) {                              // straight-line body: the loads stay four groups ahead of their use
+                { const float4 av = a0; a0 = ap[(size_t)min(g + 4, G - 1) * gstride]; DDC_STEP(av, g); }
+                { const float4 av = a1; a1 = ap[(size_t)min(g + 5, G - 1) * gstride]; DDC_STEP(av, g + 1); }
+                { const float4 av = a2; a2 = ap[(size_t)min(g + 6, G - 1) * gstride]; DDC_STEP(av, g + 2); }
+                { const float4 av = a3; a3 = ap[(size_t)min(g + 7, G - 1) * gstride]; DDC_STEP(av, g + 3); }
+            }
+            if (g < G) { DDC_STEP(a0, g); }                           // pre_decimation = 8 ... (G not a multiple of 4)
+            if (g + 1 < G) { DDC_STEP(a1, g + 1); }
+            if (g + 2 < G) { DDC_STEP(a2, g + 2); }
 #undef DDC_STEP
-    // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+            // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        if (c >= n_channels) continue;
-        int m = (r - geom[c].offsetbin) % inv; if (m < 0) m += inv;
-        float2 *dst = Ct + ((size_t)m * Cpad + c) * nbp + b_base + i;
+            for (int e = 0; e < 16; e++) {
+                const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (c >= n_channels) continue;
+                int m = (r - geom[c].offsetbin) % inv; if (m < 0) m += inv;
+                float2 *dst = Ct + ((size_t)m * Cpad + c) * nbp + b_base + i;
 #pragma unroll
-        for (int bt = 0; bt < NBT; bt++)
-            if (b_base + bt * 32 + i < n_blocks) dst[bt * 32] = make_float2(acc[bt][0][e] * scale, acc[bt][1][e] * scale);
+                for (int bt = 0; bt < NBT; bt++)
+                    if (b_base + bt * 32 + i < n_blocks) dst[bt * 32] = make_float2(acc[bt][0][e] * scale, acc[bt][1][e] * scale);
+            }
+        }
+        if (PERSIST && rn < inv) {
+            float4 *nxt = xs_all + (cur ^ 1) * BUF;
+#pragma unroll
+            for (int k = 0; k < NX; k++) {
+                const int idx = threadIdx.x + 512 * k, row = idx / row4, col = idx - row * row4;
+                if (idx < rows * row4) nxt[row * P4 + col] = nx[k];
+            }
+            __syncthreads();                                          // the other buffer is complete; nobody reads this one any more
+            cur ^= 1;
+        }
     }
 }
 
-// ------------------------------------------------------------------ the residual shift's phasor chains (libcsdr_gpl.c:131-160), replayed in float32
-// R[(c n_blocks + b) rpitch + k] = (cos, sin) after k steps of (c, s) <- (c cd - s sd, s cd + c sd) from (cos, sin)(starting_phase of the block)
-__global__ __launch_bounds__(64) void k_ddc_rot(const ChanGeom *__restrict__ geom, const float *__restrict__ blk_phase, float2 *__restrict__ R,
-                                                int n_chains, int n_blocks, int kmax, int rpitch)
+// ------------------------------------------------------------------ the residual shift: data-independent bookkeeping
+// Both tables are BLOCK-MAJOR (index b * n_channels + c): a wave's lanes are consecutive channels, so every access below is coalesced (the general
+// path's [channel][block] arrays cost one scattered 4-byte store per lane and step: 20 us for 256 x 64 entries).
+// k_ddc_chain_t: per channel, the (decimation_remain, starting_phase, output offset) of every block of the call (libcsdr_gpl.c:153-158, float32 phase
+// bookkeeping exactly as decimating_shift_addition_cc returns it) and the samples produced.
+__global__ __launch_bounds__(64) void k_ddc_chain_t(DdcChanState *__restrict__ state, const ChanGeom *__restrict__ geom, int n_channels, int n_blocks,
+                                                    int post_in, int post_dec, int *__restrict__ blk_remain, float *__restrict__ blk_phase, int *__restrict__ blk_off,
+                                                    int *__restrict__ counts)
 {
-    __shared__ float2 tile[64][33];
-    const int lane = threadIdx.x, cb0 = blockIdx.x * 64, cb = cb0 + lane;
-    float co = 1.f, sn = 0.f, cd = 1.f, sd = 0.f;
-    if (cb < n_chains) {
-        const ChanGeom g = geom[cb / n_blocks];
-        cd = g.cosdelta; sd = g.sindelta;
-        const float ph = blk_phase[cb];
-        co = (float)cos((double)ph); sn = (float)sin((double)ph);
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= n_channels) return;
+    DdcChanState s = state[c];
+    const float r = geom[c].rate2;
+    int off = 0;
+    for (int b = 0; b < n_blocks; b++) {
+        const size_t id = (size_t)b * n_channels + c;
+        blk_remain[id] = s.remain; blk_phase[id] = s.phase; blk_off[id] = off;
+        int k = 0, pos = s.remain;
+        if (pos < post_in) { k = (post_in - 1 - pos) / post_dec + 1; pos += k * post_dec; }
+        s.remain = pos - post_in;
+        float p = s.phase + r * PI_F * (float)k;                       // libcsdr_gpl.c:155
+        while (p > PI_F) p -= 2 * PI_F;
+        while (p < -PI_F) p += 2 * PI_F;
+        s.phase = p; off += k;
     }
-    for (int k0 = 0; k0 < kmax; k0 += 32) {
-#pragma unroll 4
-        for (int kk = 0; kk < 32; kk++) {
-            tile[lane][kk] = make_float2(co, sn);
-            const float c1 = co * cd - sn * sd, s1 = sn * cd + co * sd;
-            co = c1; sn = s1;
-        }
-        __syncthreads();
-        for (int rr = 0; rr < 32; rr++) {
-            const int row = 2 * rr + (lane >> 5), col = lane & 31;
-            if (cb0 + row < n_chains && k0 + col < rpitch) R[(size_t)(cb0 + row) * rpitch + k0 + col] = tile[row][col];
-        }
-        __syncthreads();
+    state[c] = s; counts[c] = off;
+}
+// k_ddc_rot: the phasor recurrence (c, s) <- (c cd - s sd, s cd + c sd) of every (block, channel) chain from (cos, sin)(its starting phase), replayed in
+// float32 like libcsdr_gpl.c:141-152; every ROT_CK-th state is kept (R[kc * n_chains + id]), the consumer replays the < ROT_CK steps in between itself.
+constexpr int ROT_CK = 16;
+__global__ __launch_bounds__(64) void k_ddc_rot(const ChanGeom *__restrict__ geom, const float *__restrict__ blk_phase, float2 *__restrict__ R,
+                                                int n_chains, int n_channels, int kmax)
+{
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id >= n_chains) return;
+    const ChanGeom g = geom[id % n_channels];
+    const float cd = g.cosdelta, sd = g.sindelta, ph = blk_phase[id];
+    float co = (float)cos((double)ph), sn = (float)sin((double)ph);
+    for (int k0 = 0; k0 < kmax; k0 += ROT_CK) {
+        R[(size_t)(k0 / ROT_CK) * n_chains + id] = make_float2(co, sn);
+#pragma unroll
+        for (int kk = 0; kk < ROT_CK; kk++) { const float c1 = co * cd - sn * sd, s1 = sn * cd + co * sd; co = c1; sn = s1; }
     }
 }
 
@@ -185,6 +232,9 @@ __global__ __launch_bounds__(64) void k_ddc_rot(const ChanGeom *__restrict__ geo
 // tp = i + 16 s, so the 16 lanes j of one load instruction read one 128-byte run; stages 2 and 3 are done by one wave per transform, in place.
 constexpr int I512_PITCH = 580;
 __device__ __forceinline__ int pad8(int idx) { return idx + (idx >> 3); }
+// row pitch for NT transforms per workgroup: the NT lanes of one global-load instruction (one per transform) then write NT rows: 580 (16 rows) and
+// 578 (8 rows) spread them over the banks (2-way at worst)
+template <int NT> struct I512 { static constexpr int pitch = NT == 16 ? 580 : 578; static constexpr int tw_n = NT == 16 ? 512 : 448; };   // twiddle indices stay below 7 * 63 + 1
 
 template <bool INV>
 __device__ __forceinline__ void fft512_stage1_store(float2 (&v)[8], float2 *row, int tp, const float2 *tw)
@@ -193,13 +243,13 @@ __device__ __forceinline__ void fft512_stage1_store(float2 (&v)[8], float2 *row,
 #pragma unroll
     for (int k1 = 0; k1 < 8; k1++) { float2 w = tw[(k1 * tp) & 511]; if (INV) w.y = -w.y; row[pad8(64 * k1 + tp)] = cmul(v[k1], w); }
 }
-// stages 2 and 3 of the 16 rows: wave w takes rows w, w + 4, w + 8, w + 12; all 256 threads must call it (barriers inside)
-template <bool INV>
+// stages 2 and 3 of the NT rows: wave w takes rows w, w + 4, ...; all 256 threads must call it (barriers inside)
+template <bool INV, int NT>
 __device__ __forceinline__ void fft512_stages23(float2 *data, int t, const float2 *tw)
 {
     const int wave = t >> 6, lane = t & 63, hi3 = lane >> 3, lo3 = lane & 7;
-    for (int round = 0; round < 4; round++) {
-        float2 *row = data + (4 * round + wave) * I512_PITCH;
+    for (int round = 0; round < NT / 4; round++) {
+        float2 *row = data + (4 * round + wave) * I512<NT>::pitch;
         float2 v[8];
 #pragma unroll
         for (int n2 = 0; n2 < 8; n2++) v[n2] = row[pad8(64 * hi3 + 8 * n2 + lo3)];            // lane = (k1, n3), over n2; in place
@@ -222,8 +272,8 @@ __device__ __forceinline__ void fft512_stages23(float2 *data, int t, const float
 // pass 1: 512-point transforms over n1 for 16 consecutive n2 per workgroup (128-byte runs on both sides), times W_N^(n2 k1), to Y[block][k1][n2];
 // pass 2: 128-point transforms over n2 -- one per (residue, block), input and output 1 KiB contiguous -- written straight in the fold's layout
 // Xt[residue][block][q] (q = q' with the first fft_swap_sides folded in).  The natural-order spectrum never exists; no framing copy.
-__global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ Y,
-                                                    const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl)
+__global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ tail_out, float2 *__restrict__ Y,
+                                                    const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl, int n_blocks)
 {
     extern __shared__ float4 lds_raw[];
     float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + 16 * I512_PITCH, *twb = tw + 512;
@@ -231,7 +281,7 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
     const int n2 = 16 * blockIdx.x + j; const long long b = blockIdx.y;
     tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
     if (t < 128) twb[t] = g_twb[t];
-    const long long base = b * inp - ovl + n2;
+    const long long base = b * inp - ovl + n2, tail_first = (long long)n_blocks * inp - ovl;
     float2 v[4][8];
 #pragma unroll
     for (int s = 0; s < 4; s++)
@@ -239,12 +289,14 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
         for (int a = 0; a < 8; a++) {
             const long long pos = base + 128LL * (64 * a + i + 16 * s);
             v[s][a] = pos < 0 ? tail[ovl + pos] : in[pos];
+            // the last window ends with the stream's newest `ovl` samples = the next call's overlap (csdr.c:2292)
+            if (b == n_blocks - 1 && pos >= tail_first) tail_out[pos - tail_first] = v[s][a];
         }
     __syncthreads();                                                  // twiddle tables
 #pragma unroll
     for (int s = 0; s < 4; s++) fft512_stage1_store<false>(v[s], data + j * I512_PITCH, i + 16 * s, tw);
     __syncthreads();
-    fft512_stages23<false>(data, t, tw);
+    fft512_stages23<false, 16>(data, t, tw);
     float2 *dst = Y + (size_t)b * 65536 + n2;
 #pragma unroll 8
     for (int p = 0; p < 32; p++) {
@@ -283,59 +335,66 @@ __global__ __launch_bounds__(256) void k_ddc_fwd128(const float2 *__restrict__ Y
     }
 }
 
-// the last `ovl` samples of the stream so far = the next call's overlap (csdr.c:2292)
-__global__ __launch_bounds__(256) void k_ddc_fwd_tail(const float2 *__restrict__ in, const float2 *__restrict__ tail_in, float2 *__restrict__ tail_out, int inp, int ovl, int n_blocks)
-{
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= ovl) return;
-    const long long pos = (long long)n_blocks * inp - ovl + k;
-    tail_out[k] = pos < 0 ? tail_in[ovl + pos] : in[pos];
-}
-
 // ------------------------------------------------------------------ 512-point inverse transforms + scrap + residual shift
-// grid (ceil(n_blocks / 16), n_channels), 256 threads: the bins of 16 blocks of one channel (128-byte runs per bin) are transformed, the first `scrap`
-// samples dropped (overlap & scrap, fastddc.c:153), every post_dec-th sample from decimation_remain on rotated by the replayed phasor and written.
+// One workgroup (256 threads) = one channel x NT consecutive blocks: the bins of those blocks (runs of NT x 8 bytes per bin) are transformed, the first
+// `scrap` samples dropped (overlap & scrap, fastddc.c:153), every post_dec-th sample from decimation_remain on rotated by the replayed phasor and written.
+// NT = 8: 40 KiB of LDS, four workgroups per CU (the load, transform and store phases of different workgroups overlap); its two halves of a 128-byte
+// bin line are workgroup ids 8 apart = the same XCD (same L2), dispatched together.  NT = 16: whole lines per workgroup, two workgroups per CU.
+template <int NT>
 __global__ __launch_bounds__(256) void k_ddc_ifft512_post(const float2 *__restrict__ Ct, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ R,
                                                           const float2 *__restrict__ g_tw, const int *__restrict__ blk_remain, const int *__restrict__ blk_off,
-                                                          int Cpad, int nbp, int n_blocks, int scrap, int post_in, int post_dec, int rpitch)
+                                                          const ChanGeom *__restrict__ geom, int Cpad, int nbp, int n_blocks, int n_channels, int scrap, int post_in, int post_dec)
 {
     extern __shared__ float4 lds_raw[];
-    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + 16 * I512_PITCH;
-    const int t = threadIdx.x, c = blockIdx.y, b0 = blockIdx.x * 16, j = t & 15, i = t >> 4;
-    tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
+    constexpr int PITCH = I512<NT>::pitch, TWN = I512<NT>::tw_n, NS = NT / 4, IW = 256 / NT;       // NS sets of 8 loads per thread; IW threads per transform
+    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + NT * PITCH;
+    const int t = threadIdx.x, j = t & (NT - 1), i = t / NT;
+    int c, b0;
+    if (NT == 16) { c = blockIdx.y; b0 = blockIdx.x * 16; }
+    else {   // linear id L = 16 g + 8 h + u: (channel, line) pair P = 8 g + u, half h
+        const int L = blockIdx.x, h = (L >> 3) & 1, P = (L >> 4) * 8 + (L & 7), nl = (n_blocks + 15) / 16;
+        c = P / nl; b0 = (P - c * nl) * 16 + 8 * h;
+        if (c >= n_channels) return;
+    }
+    for (int k = t; k < TWN; k += 256) tw[k] = g_tw[k];
     const bool ok = b0 + j < n_blocks;
     const float2 *src = Ct + (size_t)c * nbp + b0 + (ok ? j : 0);
     const size_t mstride = (size_t)Cpad * nbp;
-    float2 v[4][8];
+    float2 v[NS][8];
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < NS; s++)
 #pragma unroll
-        for (int a = 0; a < 8; a++) v[s][a] = src[(size_t)(64 * a + i + 16 * s) * mstride];
+        for (int a = 0; a < 8; a++) v[s][a] = src[(size_t)(64 * a + i + IW * s) * mstride];
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < NS; s++) {
         if (!ok) {
 #pragma unroll
             for (int a = 0; a < 8; a++) v[s][a] = make_float2(0.f, 0.f);
         }
-        fft512_stage1_store<true>(v[s], data + j * I512_PITCH, i + 16 * s, tw);
+        fft512_stage1_store<true>(v[s], data + j * PITCH, i + IW * s, tw);
     }
     __syncthreads();
-    fft512_stages23<true>(data, t, tw);
+    fft512_stages23<true, NT>(data, t, tw);
     // fastddc.c:153-162: /size, drop `scrap` samples, rotate every post_dec-th sample from decimation_remain on
     const float inv_n = 1.0f / 512.0f;
-    for (int bl = 0; bl < 16; bl++) {
+    const float cd = geom[c].cosdelta, sd = geom[c].sindelta;
+    const size_t n_chains = (size_t)n_blocks * n_channels;
+    for (int bl = 0; bl < NT; bl++) {
         const int b = b0 + bl;
         if (b >= n_blocks) break;
-        const size_t cb = (size_t)c * n_blocks + b;
-        const int rem = blk_remain[cb];
+        const size_t id = (size_t)b * n_channels + c;
+        const int rem = blk_remain[id];
         const int cnt = rem < post_in ? (post_in - 1 - rem) / post_dec + 1 : 0;
-        float2 *dst = out + (size_t)c * out_pitch + blk_off[cb];
-        const float2 *rot = R + cb * rpitch;
+        float2 *dst = out + (size_t)c * out_pitch + blk_off[id];
         for (int k = t; k < cnt; k += 256) {
-            const float2 x = data[bl * I512_PITCH + pad8(scrap + rem + post_dec * k)];
+            const float2 x = data[bl * PITCH + pad8(scrap + rem + post_dec * k)];
             const float vi = x.x * inv_n, vq = x.y * inv_n;
-            const float2 w = rot[k];
+            float2 w = R[(size_t)(k / ROT_CK) * n_chains + id];            // the chain's state at the checkpoint below k, then the steps in between
+            const int steps = k % ROT_CK;
+#pragma unroll
+            for (int s2 = 0; s2 < ROT_CK - 1; s2++)
+                if (s2 < steps) { const float c1 = w.x * cd - w.y * sd, s1 = w.y * cd + w.x * sd; w.x = c1; w.y = s1; }
             dst[k] = make_float2(w.x * vi - w.y * vq, w.y * vi + w.x * vq);
         }
     }
@@ -351,10 +410,9 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
     DdcMfma *m = new DdcMfma();
     m->ctx = ctx; m->fft = fft; m->inv = inv; m->pre = pre; m->G = pre / 4; m->C = n_channels; m->Cpad = (n_channels + 31) / 32 * 32;
     m->max_blocks = max_blocks; m->nbp = (max_blocks + 31) / 32 * 32; m->scrap = scrap; m->post_in = post_in; m->post_dec = post_dec;
-    m->kmax = (post_in - 1) / post_dec + 1; m->rpitch = (m->kmax + 31) / 32 * 32;
+    m->kmax = (post_in - 1) / post_dec + 1; m->rpitch = (m->kmax + ROT_CK - 1) / ROT_CK;      // checkpoints per chain
     m->input_size = input_size; m->overlap = overlap; m->flip = 0;
     m->d_Ht = nullptr; m->d_Xt = nullptr; m->d_Ct = nullptr; m->d_R = nullptr; m->d_tw = nullptr; m->d_Y = nullptr; m->d_tail[0] = m->d_tail[1] = nullptr; m->d_twb = nullptr;
-    m->side = nullptr; m->ev_fork = nullptr; m->ev_join = nullptr;
     hipError_t e = hipMalloc((void **)&m->d_Ht, sizeof(float) * 2 * (size_t)m->Cpad * fft);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Xt, sizeof(cf32) * (size_t)fft * m->nbp);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Ct, sizeof(cf32) * (size_t)inv * m->Cpad * m->nbp);
@@ -362,9 +420,6 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_tw, sizeof(float2) * 512);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_twb, sizeof(float2) * 128);
     if (e == hipSuccess) e = hipMemsetAsync(m->d_Ht, 0, sizeof(float) * 2 * (size_t)m->Cpad * fft, ctx->stream);      // padded channel rows stay zero
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) { fail(e, "hipMalloc(fastddc matrix-core path)", __FILE__, __LINE__); ddc_mfma_destroy(m); return nullptr; }
     std::vector<float2> tw(512), twb(128);
     for (int k = 0; k < 512; k++) { const double a = -2.0 * M_PI * k / 512.0; tw[k] = make_float2((float)cos(a), (float)sin(a)); }
@@ -377,9 +432,6 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
 void ddc_mfma_destroy(DdcMfma *m)
 {
     if (!m) return;
-    if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     (void)hipFree(m->d_Ht); (void)hipFree(m->d_Xt); (void)hipFree(m->d_Ct); (void)hipFree(m->d_R); (void)hipFree(m->d_tw); (void)hipFree(m->d_twb);
     (void)hipFree(m->d_Y); (void)hipFree(m->d_tail[0]); (void)hipFree(m->d_tail[1]);
     for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -419,15 +471,12 @@ int ddc_mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, int n_blocks)
         }
         if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
     }
-    const size_t lds = (size_t)(16 * I512_PITCH + 512 + 128) * sizeof(float2);
+    const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
     { const int rc = lds_attr_once((const void *)k_ddc_fwd512, lds); if (rc) return rc; }
     hipLaunchKernelGGL(k_ddc_fwd512, dim3(8, n_blocks), dim3(256), lds, st, reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]),
-                       reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap);
+                       reinterpret_cast<float2 *>(m->d_tail[m->flip ^ 1]), reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_blocks);
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_blocks, 32)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(m->d_Xt), m->d_tw, m->nbp, n_blocks);
-    CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ddc_fwd_tail, dim3(cdiv(m->overlap, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]),
-                       reinterpret_cast<float2 *>(m->d_tail[m->flip ^ 1]), m->input_size, m->overlap, n_blocks);
     CSDR_LAUNCH_CHECK();
     m->flip ^= 1;
     return 0;
@@ -453,20 +502,17 @@ cf32 *ddc_mfma_xt(DdcMfma *m, size_t *bytes, int *block_pitch)
     return m->d_Xt;
 }
 
-// The per-channel state chain over the blocks of this call and the phasor chains of every (channel, block) do not depend on the samples: they are
-// queued on the side stream (ordered after everything already on `st`, e.g. the previous call's readers of the same tables) while `st` carries the
-// transforms and the fold; `st` waits for them just before the inverse transforms.  Call BEFORE the forward transform / ddc_mfma_load_spectra.
+// The per-channel state chain over the blocks of this call and the phasor checkpoints of every (block, channel): data independent, a few microseconds,
+// queued first.  The blk_* arrays are filled BLOCK-MAJOR (b * n_channels + c) on this path.
 int ddc_mfma_begin_chains(DdcMfma *m, hipStream_t st, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts)
 {
     if (n_blocks <= 0) return 0;
     if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
-    CSDR_HIP(hipEventRecord(m->ev_fork, st));
-    CSDR_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-    int rc = ddc_launch_chain(m->side, d_state, d_geom, m->C, n_blocks, m->post_in, m->post_dec, d_blk_remain, d_blk_phase, d_blk_off, d_counts); if (rc) return rc;
-    const int n_chains = m->C * n_blocks;
-    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, m->side, d_geom, d_blk_phase, m->d_R, n_chains, n_blocks, m->kmax, m->rpitch);
+    hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, st, d_state, d_geom, m->C, n_blocks, m->post_in, m->post_dec, d_blk_remain, d_blk_phase, d_blk_off, d_counts);
     CSDR_LAUNCH_CHECK();
-    CSDR_HIP(hipEventRecord(m->ev_join, m->side));
+    const int n_chains = m->C * n_blocks;
+    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, st, d_geom, d_blk_phase, m->d_R, n_chains, m->C, m->kmax);
+    CSDR_LAUNCH_CHECK();
     return 0;
 }
 
@@ -487,22 +533,37 @@ int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d
         e0 = m->ev_pool[m->ev_used].first; e1 = m->ev_pool[m->ev_used].second; m->ev_used++;
         CSDR_HIP(hipEventRecord(e0, st));
     }
-    if (nbt == 2) {
-        if (lds > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<2>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL((k_ddc_gemm<2>), grid, dim3(512), lds, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt), reinterpret_cast<float2 *>(m->d_Ct), d_geom,
-                           m->inv, m->pre, m->Cpad, m->C, m->nbp, n_blocks, scale);
-    } else {
-        if (lds > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<1>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL((k_ddc_gemm<1>), grid, dim3(512), lds, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt), reinterpret_cast<float2 *>(m->d_Ct), d_geom,
-                           m->inv, m->pre, m->Cpad, m->C, m->nbp, n_blocks, scale);
-    }
+    // persistent form (one workgroup per CU walks several residues, double-buffered spectra) when a residue's spectra fit the register staging
+    // and there are at least two residues per workgroup; CSDR_AMD_DDC_GEMM=simple / persist overrides
+    const int n_cu = current_device_cu_count();
+    const int per_res = (int)(grid.y * grid.z);
+    int slots = n_cu / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
+    bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
+    if (const char *e = getenv("CSDR_AMD_DDC_GEMM")) { if (!strcmp(e, "simple")) persist = false; else if (!strcmp(e, "persist") && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true; }
+    const size_t lds_use = persist ? 2 * lds : lds;
+    const dim3 grid_use(persist ? (unsigned)slots : grid.x, grid.y, grid.z);
+#define DDC_GEMM_LAUNCH(NBTV, PV) do {                                                                                                               \
+        if (lds_use > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<NBTV, PV>, lds_use); if (rc) return rc; }                    \
+        hipLaunchKernelGGL((k_ddc_gemm<NBTV, PV>), grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt),              \
+                           reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, n_blocks, scale); } while (0)
+    if (nbt == 2) { if (persist) DDC_GEMM_LAUNCH(2, true); else DDC_GEMM_LAUNCH(2, false); }
+    else          { if (persist) DDC_GEMM_LAUNCH(1, true); else DDC_GEMM_LAUNCH(1, false); }
+#undef DDC_GEMM_LAUNCH
     CSDR_LAUNCH_CHECK();
     if (e1) CSDR_HIP(hipEventRecord(e1, st));
-    CSDR_HIP(hipStreamWaitEvent(st, m->ev_join, 0));                      // the chains of ddc_mfma_begin_chains
-    const size_t lds2 = (size_t)(16 * I512_PITCH + 512) * sizeof(float2);
-    { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post, lds2); if (rc) return rc; }
-    hipLaunchKernelGGL(k_ddc_ifft512_post, dim3(cdiv(n_blocks, 16), m->C), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,
-                       m->d_R, m->d_tw, d_blk_remain, d_blk_off, m->Cpad, m->nbp, n_blocks, m->scrap, m->post_in, m->post_dec, m->rpitch);
+    // inverse transforms: 8 blocks per workgroup (four workgroups per CU) unless CSDR_AMD_DDC_IFFT=16
+    const char *iv = getenv("CSDR_AMD_DDC_IFFT");
+    if (iv && atoi(iv) == 16) {
+        const size_t lds2 = (size_t)(16 * I512<16>::pitch + I512<16>::tw_n) * sizeof(float2);
+        { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post<16>, lds2); if (rc) return rc; }
+        hipLaunchKernelGGL(k_ddc_ifft512_post<16>, dim3(cdiv(n_blocks, 16), m->C), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,
+                           m->d_R, m->d_tw, d_blk_remain, d_blk_off, d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in, m->post_dec);
+    } else {
+        const size_t lds2 = (size_t)(8 * I512<8>::pitch + I512<8>::tw_n) * sizeof(float2);
+        const int pairs = m->C * cdiv(n_blocks, 16);
+        hipLaunchKernelGGL(k_ddc_ifft512_post<8>, dim3(cdiv(pairs, 8) * 16), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,
+                           m->d_R, m->d_tw, d_blk_remain, d_blk_off, d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in, m->post_dec);
+    }
     CSDR_LAUNCH_CHECK();
     return 0;
 }

@@ -255,16 +255,6 @@ __global__ __launch_bounds__(256) void k_scale_add(cf32 *__restrict__ io, size_t
 
 } // namespace
 
-namespace csdr_amd {
-int ddc_launch_chain(hipStream_t st, DdcChanState *d_state, const ChanGeom *d_geom, int n_channels, int n_blocks, int post_in, int post_dec,
-                     int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts)
-{
-    hipLaunchKernelGGL(k_ddc_chain, dim3(cdiv(n_channels, 64)), dim3(64), 0, st, d_state, d_geom, n_channels, n_blocks, post_in, post_dec, d_blk_remain, d_blk_phase, d_blk_off, d_counts);
-    CSDR_LAUNCH_CHECK();
-    return 0;
-}
-}
-
 // cached single-transform plans for the drop-in FFT layer
 static std::map<std::pair<int, long>, hipfftHandle> g_c2c_plans;
 static std::mutex g_c2c_mu;      // the map is shared by every context (the drop-in layer has one context per host thread)
