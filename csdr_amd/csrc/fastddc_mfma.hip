@@ -193,12 +193,13 @@ __global__ __launch_bounds__(64) void k_ddc_chain_t(DdcChanState *__restrict__ s
     if (c >= n_channels) return;
     DdcChanState s = state[c];
     const float r = geom[c].rate2;
+    const int sh = (post_dec & (post_dec - 1)) == 0 ? __ffs(post_dec) - 1 : -1;    // post_decimation is 2 for every power-of-two decimation: a shift, not a division
     int off = 0;
-    for (int b = 0; b < n_blocks; b++) {
+    for (int b = 0; b < n_blocks; b++) {                              // 64 strictly sequential steps on 4 waves: every dependent instruction counts
         const size_t id = (size_t)b * n_channels + c;
         blk_remain[id] = s.remain; blk_phase[id] = s.phase; blk_off[id] = off;
         int k = 0, pos = s.remain;
-        if (pos < post_in) { k = (post_in - 1 - pos) / post_dec + 1; pos += k * post_dec; }
+        if (pos < post_in) { k = (sh >= 0 ? (post_in - 1 - pos) >> sh : (post_in - 1 - pos) / post_dec) + 1; pos += k * post_dec; }
         s.remain = pos - post_in;
         float p = s.phase + r * PI_F * (float)k;                       // libcsdr_gpl.c:155
         while (p > PI_F) p -= 2 * PI_F;
@@ -272,36 +273,38 @@ __device__ __forceinline__ void fft512_stages23(float2 *data, int t, const float
 // pass 1: 512-point transforms over n1 for 16 consecutive n2 per workgroup (128-byte runs on both sides), times W_N^(n2 k1), to Y[block][k1][n2];
 // pass 2: 128-point transforms over n2 -- one per (residue, block), input and output 1 KiB contiguous -- written straight in the fold's layout
 // Xt[residue][block][q] (q = q' with the first fft_swap_sides folded in).  The natural-order spectrum never exists; no framing copy.
+template <int NT>
 __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ tail_out, float2 *__restrict__ Y,
                                                     const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl, int n_blocks)
 {
     extern __shared__ float4 lds_raw[];
-    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + 16 * I512_PITCH, *twb = tw + 512;
-    const int t = threadIdx.x, j = t & 15, i = t >> 4;
-    const int n2 = 16 * blockIdx.x + j; const long long b = blockIdx.y;
+    constexpr int PITCH = I512<NT>::pitch, NS = NT / 4, IW = 256 / NT;
+    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + NT * PITCH, *twb = tw + 512;
+    const int t = threadIdx.x, j = t & (NT - 1), i = t / NT;
+    const int n2 = NT * blockIdx.x + j; const long long b = blockIdx.y;
     tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
     if (t < 128) twb[t] = g_twb[t];
     const long long base = b * inp - ovl + n2, tail_first = (long long)n_blocks * inp - ovl;
-    float2 v[4][8];
+    float2 v[NS][8];
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < NS; s++)
 #pragma unroll
         for (int a = 0; a < 8; a++) {
-            const long long pos = base + 128LL * (64 * a + i + 16 * s);
+            const long long pos = base + 128LL * (64 * a + i + IW * s);
             v[s][a] = pos < 0 ? tail[ovl + pos] : in[pos];
             // the last window ends with the stream's newest `ovl` samples = the next call's overlap (csdr.c:2292)
             if (b == n_blocks - 1 && pos >= tail_first) tail_out[pos - tail_first] = v[s][a];
         }
     __syncthreads();                                                  // twiddle tables
 #pragma unroll
-    for (int s = 0; s < 4; s++) fft512_stage1_store<false>(v[s], data + j * I512_PITCH, i + 16 * s, tw);
+    for (int s = 0; s < NS; s++) fft512_stage1_store<false>(v[s], data + j * PITCH, i + IW * s, tw);
     __syncthreads();
-    fft512_stages23<false, 16>(data, t, tw);
+    fft512_stages23<false, NT>(data, t, tw);
     float2 *dst = Y + (size_t)b * 65536 + n2;
 #pragma unroll 8
-    for (int p = 0; p < 32; p++) {
-        const int k1 = i + 16 * p, m = n2 * k1;                        // W_65536^m = W_512^(m >> 7) W_65536^(m & 127)
-        dst[(size_t)k1 * 128] = cmul(data[j * I512_PITCH + pad8(k1)], cmul(tw[m >> 7], twb[m & 127]));
+    for (int p = 0; p < 512 / IW; p++) {
+        const int k1 = i + IW * p, m = n2 * k1;                        // W_65536^m = W_512^(m >> 7) W_65536^(m & 127)
+        dst[(size_t)k1 * 128] = cmul(data[j * PITCH + pad8(k1)], cmul(tw[m >> 7], twb[m & 127]));
     }
 }
 
@@ -400,6 +403,105 @@ __global__ __launch_bounds__(256) void k_ddc_ifft512_post(const float2 *__restri
     }
 }
 
+// ------------------------------------------------------------------ the same for post_decimation = 2: HALF-size inverse transforms
+// Only every second output sample survives decimating_shift_addition_cc (libcsdr_gpl.c:141: i += decimation), and decimating the OUTPUT of an inverse
+// transform by two is aliasing its INPUT: with n = 2k + rho,
+//     x[2k + rho] = sum_{m < 256} (X[m] + (-1)^rho X[m + 256]) e^(2 pi i m rho / 512) . e^(2 pi i m k / 256)
+// i.e. ONE 256-point inverse transform of the folded, phase-ramped bins Z[m] -- half the butterflies, half the LDS traffic, and the parity rho of the
+// first kept sample (scrap + decimation_remain) is known per (block, channel) before the data exists.  Every power-of-two decimation has post_decimation 2
+// (fastddc.c:44-48).  256 = 4 x 8 x 8: m = 64 a + 8 n2 + n3, k = k1 + 4 k2 + 32 k3;  W^(mk) = W4^(a k1) W256^((8 n2 + n3) k1) W8^(n2 k2) W64^(n3 k2) W8^(n3 k3).
+template <int NT> struct I256 { static constexpr int pitch = NT == 16 ? 292 : 290; };     // 256 cells + one pad per 8 (+ row stagger)
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_ddc_ifft256d_post(const float2 *__restrict__ Ct, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ R,
+                                                           const float2 *__restrict__ g_tw, const int *__restrict__ blk_remain, const int *__restrict__ blk_off,
+                                                           const ChanGeom *__restrict__ geom, int Cpad, int nbp, int n_blocks, int n_channels, int scrap, int post_in)
+{
+    extern __shared__ float4 lds_raw[];
+    constexpr int PITCH = I256<NT>::pitch, NS = NT / 4, IW = 256 / NT;
+    float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + NT * PITCH;
+    const int t = threadIdx.x, j = t & (NT - 1), i = t / NT;
+    int c, b0;
+    if (NT == 16) { c = blockIdx.y; b0 = blockIdx.x * 16; }
+    else {   // linear id L = 16 g + 8 h + u: (channel, line) pair P = 8 g + u, half h: the two halves of a 128-byte bin line share an XCD
+        const int L = blockIdx.x, h = (L >> 3) & 1, P = (L >> 4) * 8 + (L & 7), nl = (n_blocks + 15) / 16;
+        c = P / nl; b0 = (P - c * nl) * 16 + 8 * h;
+        if (c >= n_channels) return;
+    }
+    tw[t] = g_tw[t]; tw[t + 256] = g_tw[t + 256];
+    const bool ok = b0 + j < n_blocks;
+    const size_t idj = (size_t)(ok ? b0 + j : 0) * n_channels + c;
+    const int remj = blk_remain[idj], rho = (scrap + remj) & 1;
+    const float2 *src = Ct + (size_t)c * nbp + b0 + (ok ? j : 0);
+    const size_t mstride = (size_t)Cpad * nbp;
+    float2 v[NS][8];
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[s][a] = src[(size_t)(64 * a + i + IW * s) * mstride];
+    __syncthreads();
+    float2 *row = data + j * PITCH;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int tp = i + IW * s;
+        float2 z[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            float2 lo = v[s][a], hi = v[s][a + 4];
+            if (!ok) { lo = make_float2(0.f, 0.f); hi = lo; }
+            float2 sum = rho ? csub(lo, hi) : cadd(lo, hi);
+            if (rho) { float2 w = tw[64 * a + tp]; w.y = -w.y; sum = cmul(sum, w); }
+            z[a] = sum;
+        }
+        dft4<true>(z[0], z[1], z[2], z[3]);
+#pragma unroll
+        for (int k1 = 0; k1 < 4; k1++) { float2 w = tw[(2 * k1 * tp) & 511]; w.y = -w.y; row[pad8(64 * k1 + tp)] = cmul(z[k1], w); }
+    }
+    __syncthreads();
+    {   // stages 2 and 3: 32 lanes per transform, a wave takes two rows per round
+        const int wave = t >> 6, lane = t & 63, half = lane >> 5, l5 = lane & 31, k1 = l5 >> 3, lo3 = l5 & 7;
+        for (int round = 0; round < NT / 8; round++) {
+            float2 *rw = data + (8 * round + 2 * wave + half) * PITCH;
+            float2 u[8];
+#pragma unroll
+            for (int n2 = 0; n2 < 8; n2++) u[n2] = rw[pad8(64 * k1 + 8 * n2 + lo3)];            // lane = (k1, n3), over n2; in place
+            dft8<true>(u);
+#pragma unroll
+            for (int k2 = 0; k2 < 8; k2++) { float2 w = tw[(8 * k2 * lo3) & 511]; w.y = -w.y; rw[pad8(64 * k1 + 8 * k2 + lo3)] = cmul(u[k2], w); }
+            __syncthreads();
+#pragma unroll
+            for (int n3 = 0; n3 < 8; n3++) u[n3] = rw[pad8(64 * k1 + 8 * lo3 + n3)];            // lane = (k1, k2), over n3
+            dft8<true>(u);
+            __syncthreads();
+#pragma unroll
+            for (int k3 = 0; k3 < 8; k3++) rw[pad8(k1 + 4 * lo3 + 32 * k3)] = u[k3];            // natural position k1 + 4 k2 + 32 k3
+        }
+        __syncthreads();
+    }
+    const float inv_n = 1.0f / 512.0f;
+    const float cd = geom[c].cosdelta, sd = geom[c].sindelta;
+    const size_t n_chains = (size_t)n_blocks * n_channels;
+    for (int bl = 0; bl < NT; bl++) {
+        const int b = b0 + bl;
+        if (b >= n_blocks) break;
+        const size_t id = (size_t)b * n_channels + c;
+        const int rem = blk_remain[id];
+        const int cnt = rem < post_in ? (post_in - 1 - rem) / 2 + 1 : 0;
+        const int kbase = (scrap + rem) >> 1;                            // sample scrap + rem + 2 k of the full transform = sample kbase + k of the half-size one
+        float2 *dst = out + (size_t)c * out_pitch + blk_off[id];
+        for (int k = t; k < cnt; k += 256) {
+            const float2 x = data[bl * PITCH + pad8(kbase + k)];
+            const float vi = x.x * inv_n, vq = x.y * inv_n;
+            float2 w = R[(size_t)(k / ROT_CK) * n_chains + id];
+            const int steps = k % ROT_CK;
+#pragma unroll
+            for (int s2 = 0; s2 < ROT_CK - 1; s2++)
+                if (s2 < steps) { const float c1 = w.x * cd - w.y * sd, s1 = w.y * cd + w.x * sd; w.x = c1; w.y = s1; }
+            dst[k] = make_float2(w.x * vi - w.y * vq, w.y * vi + w.x * vq);
+        }
+    }
+}
+
 } // namespace
 
 // ====================================================================================== host side
@@ -471,10 +573,19 @@ int ddc_mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, int n_blocks)
         }
         if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
     }
-    const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
-    { const int rc = lds_attr_once((const void *)k_ddc_fwd512, lds); if (rc) return rc; }
-    hipLaunchKernelGGL(k_ddc_fwd512, dim3(8, n_blocks), dim3(256), lds, st, reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]),
-                       reinterpret_cast<float2 *>(m->d_tail[m->flip ^ 1]), reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_blocks);
+    // pass 1: 8 columns n2 per workgroup (64-byte runs, 42 KiB of LDS: three workgroups per CU) unless CSDR_AMD_DDC_FWD=16 (128-byte runs, two per CU)
+    const char *fv = getenv("CSDR_AMD_DDC_FWD");
+#define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]), reinterpret_cast<float2 *>(m->d_tail[m->flip ^ 1]), \
+                     reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_blocks
+    if (fv && atoi(fv) == 16) {
+        const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
+        { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16>, lds); if (rc) return rc; }
+        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_blocks), dim3(256), lds, st, DDC_FWD_ARGS);
+    } else {
+        const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
+        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_blocks), dim3(256), lds, st, DDC_FWD_ARGS);
+    }
+#undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_blocks, 32)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(m->d_Xt), m->d_tw, m->nbp, n_blocks);
     CSDR_LAUNCH_CHECK();
@@ -551,19 +662,26 @@ int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d
 #undef DDC_GEMM_LAUNCH
     CSDR_LAUNCH_CHECK();
     if (e1) CSDR_HIP(hipEventRecord(e1, st));
-    // inverse transforms: 8 blocks per workgroup (four workgroups per CU) unless CSDR_AMD_DDC_IFFT=16
+    // inverse transforms.  post_decimation 2 (every power-of-two decimation): half-size transforms of the aliased bins; CSDR_AMD_DDC_IFFT = 512 keeps
+    // the full-size form, "16" whole 128-byte bin lines per workgroup (16 blocks) instead of half lines (8 blocks, more workgroups per CU)
     const char *iv = getenv("CSDR_AMD_DDC_IFFT");
-    if (iv && atoi(iv) == 16) {
+    const bool full = m->post_dec != 2 || (iv && strstr(iv, "512"));
+    const bool nt16 = iv && strstr(iv, "16");
+    const int pairs = m->C * cdiv(n_blocks, 16);
+    const dim3 g16(cdiv(n_blocks, 16), m->C), g8(cdiv(pairs, 8) * 16);
+#define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R, m->d_tw, d_blk_remain, d_blk_off, d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in
+    if (full && nt16) {
         const size_t lds2 = (size_t)(16 * I512<16>::pitch + I512<16>::tw_n) * sizeof(float2);
         { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post<16>, lds2); if (rc) return rc; }
-        hipLaunchKernelGGL(k_ddc_ifft512_post<16>, dim3(cdiv(n_blocks, 16), m->C), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,
-                           m->d_R, m->d_tw, d_blk_remain, d_blk_off, d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in, m->post_dec);
+        hipLaunchKernelGGL(k_ddc_ifft512_post<16>, g16, dim3(256), lds2, st, DDC_IFFT_ARGS, m->post_dec);
+    } else if (full) {
+        hipLaunchKernelGGL(k_ddc_ifft512_post<8>, g8, dim3(256), (size_t)(8 * I512<8>::pitch + I512<8>::tw_n) * sizeof(float2), st, DDC_IFFT_ARGS, m->post_dec);
+    } else if (nt16) {
+        hipLaunchKernelGGL(k_ddc_ifft256d_post<16>, g16, dim3(256), (size_t)(16 * I256<16>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS);
     } else {
-        const size_t lds2 = (size_t)(8 * I512<8>::pitch + I512<8>::tw_n) * sizeof(float2);
-        const int pairs = m->C * cdiv(n_blocks, 16);
-        hipLaunchKernelGGL(k_ddc_ifft512_post<8>, dim3(cdiv(pairs, 8) * 16), dim3(256), lds2, st, reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch,
-                           m->d_R, m->d_tw, d_blk_remain, d_blk_off, d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in, m->post_dec);
+        hipLaunchKernelGGL(k_ddc_ifft256d_post<8>, g8, dim3(256), (size_t)(8 * I256<8>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS);
     }
+#undef DDC_IFFT_ARGS
     CSDR_LAUNCH_CHECK();
     return 0;
 }
