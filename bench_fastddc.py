@@ -75,11 +75,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench_fastddc.py needs an MI355X; there is no CPU fallback")
-    rank, local_rank, world = cd.init()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CSDR_BENCH_SHARED_GPU=1: dry run of the multi-rank launcher contract on a box with ONE GPU (all ranks on device 0, gloo; RCCL refuses two ranks on
+    # one device, so the exchange is a gloo broadcast of the natural-order spectrum through the two-object API) -- a test aid, never a measurement.
+    shared = os.environ.get("CSDR_BENCH_SHARED_GPU") == "1"
+    rank, local_rank, world = cd.init("gloo" if shared else None)
+    dev_index = 0 if shared else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     stream = torch.cuda.current_stream()
-    ctx = csdr_amd.Context(local_rank, hip_stream=stream.cuda_stream)      # same stream as torch/RCCL: ordering is implicit
+    ctx = csdr_amd.Context(dev_index, hip_stream=stream.cuda_stream)       # the context's stream = torch's current stream: ordering with torch is implicit
     L = ctx.L
     ddc, err = ctx.fastddc_init(args.tbw, args.decimation, 0.0)
     assert err == 0
@@ -88,44 +92,68 @@ def main():
     rates = (-0.5 + (np.arange(args.channels) + 0.5) / args.channels).astype(np.float32)
     first, count = cd.shard(args.channels, rank, world)
     my_rates = np.ascontiguousarray(rates[first:first + count])
-    # one GPU: the bank object (forward + inverse in one call; at this geometry the forward transform writes the fold's layout directly).
-    # several GPUs: rank 0 transforms, the spectrum is broadcast, every rank inverts its channel slice.
-    bank = None
-    if world == 1:
-        bank = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
+    bank = None; comm = None; inv = None; fwd = None
+    if world == 1 or not shared:
+        # the bank object: forward + inverse; over N GPUs the library's own RCCL communicator (the 128-byte id travels over torch.distributed) shards the
+        # channels, splits the forward transform by blocks and all-gathers the transposed spectra (csdr_amd/csrc/comm.cpp)
+        if world > 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idb = (C.c_char * 128)()
+                if L.csdr_amd_comm_unique_id(idb) < 0:
+                    raise SystemExit("comm_unique_id: " + ctx.err())
+                idt.copy_(torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8))
+            torch.distributed.broadcast(idt, 0)
+            idb = (C.c_char * 128).from_buffer_copy(bytes(idt.cpu().numpy().tobytes()))
+            comm = L.csdr_amd_comm_create(ctx.h, idb, rank, world)
+            if not comm:
+                raise SystemExit("comm_create: " + ctx.err())
+            bank = L.csdr_amd_fastddc_bank_create_sharded(ctx.h, args.tbw, args.decimation, rates.ctypes.data_as(C.c_void_p), args.channels, 2, nb, comm)
+        else:
+            bank = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
         if not bank:
             raise SystemExit("fastddc_bank_create: " + ctx.err())
         inv = L.csdr_amd_fastddc_bank_inverse(bank)
+        if world > 1:
+            f0 = C.c_int(); c0 = C.c_int(); L.csdr_amd_fastddc_bank_channel_slice(bank, C.byref(f0), C.byref(c0))
+            assert (f0.value, c0.value) == (first, count)
     else:
         inv = L.csdr_amd_fastddc_inv_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
-    if not inv:
-        raise SystemExit("fastddc_inv_create: " + ctx.err())
+        if not inv:
+            raise SystemExit("fastddc_inv_create: " + ctx.err())
     pitch = L.csdr_amd_fastddc_inv_max_output(inv, nb) + 8
     out = torch.empty((count, pitch, 2), dtype=torch.float32, device=dev)
-    spectra = torch.empty((nb, ddc.fft_size, 2), dtype=torch.float32, device=dev)
-    fwd = None
+    spectra = None if bank else torch.empty((nb, ddc.fft_size, 2), dtype=torch.float32, device=dev)
+    x = None
     if rank == 0:
-        if world > 1:
+        if not bank:
             fwd = L.csdr_amd_fastddc_fwd_create(ctx.h, C.byref(ddc), nb)
         g = torch.Generator(device=dev); g.manual_seed(4)
         x = (torch.rand((nb * ddc.input_size, 2), device=dev, generator=g) * 2 - 1).contiguous()
+    xp = x.data_ptr() if x is not None else None
     torch.cuda.synchronize()
 
+    # One step = one batch of `nb` blocks through the whole channelizer.  With the bank, batches are software-pipelined the way a stream is processed:
+    # batch N+1 is staged (chains, exchange, forward transform: side stream) while batch N is folded -- every step still does one submit and one collect.
     def step():
         if bank:
-            rc = L.csdr_amd_fastddc_bank_process(bank, x.data_ptr(), nb, out.data_ptr(), pitch, None)
-            if rc < 0:
+            if L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
                 raise SystemExit(ctx.err())
             return
         if rank == 0:
             rc = L.csdr_amd_fastddc_fwd_process(fwd, x.data_ptr(), spectra.data_ptr(), nb)
             if rc < 0:
                 raise SystemExit(ctx.err())
-        cd.broadcast_spectra(spectra, 0)                                   # the one exchange step (RCCL over xGMI)
+        if shared:                                                       # gloo moves host tensors
+            sp = spectra.cpu(); cd.broadcast_spectra(sp, 0); spectra.copy_(sp)
+        else:
+            cd.broadcast_spectra(spectra, 0)
         rc = L.csdr_amd_fastddc_inv_process(inv, spectra.data_ptr(), nb, out.data_ptr(), pitch, None)
         if rc < 0:
             raise SystemExit(ctx.err())
 
+    if bank and L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0:          # prime the pipeline: from here on one batch is always staged
+        raise SystemExit(ctx.err())
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); cd.barrier()
@@ -139,7 +167,7 @@ def main():
     L.csdr_amd_fastddc_inv_kernel_time(inv, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
     cd.barrier()
-    wall = cd.max_over_ranks(wall, dev if world > 1 else "cpu")
+    wall = cd.max_over_ranks(wall, dev if (world > 1 and not shared) else "cpu")
     if rank == 0:
         in_samples = nb * ddc.input_size * args.steps
         h_bytes = args.channels * ddc.fft_size * 8                         # per-channel taps_fft, read once per CALL (not per block)
@@ -148,7 +176,8 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[3]: fastddc_fwd_cc + fastddc_inv_cc", "channels": args.channels, "decimation": args.decimation,
                           "transition_bw": args.tbw, "fft_size": ddc.fft_size, "fft_inv_size": ddc.fft_inv_size, "blocks_per_step": nb,
-                          "parallelism": "channels sharded over ranks, spectrum broadcast (RCCL)"},
+                          "parallelism": "channels sharded over ranks; forward transform split by blocks, input scattered point-to-point, transposed spectra all-gathered (RCCL, from libcsdr_amd.so)",
+                          "pipelining": "batch N+1 staged (exchange + forward transform, side stream) under the fold of batch N"},
                "aggregate_output_msps": round(in_samples / args.decimation * args.channels / wall / 1e6, 2),
                "realtime_factor_at_61p44_msps": round(in_samples / wall / 61.44e6, 3),
                "taps_fft_bytes_per_step": h_bytes}
@@ -179,7 +208,11 @@ def main():
         if args.verify and not res["verify"]["ok"]:
             raise SystemExit("bench_fastddc.py --verify failed: %s" % json.dumps(res["verify"]))
     if bank:
+        L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)       # drain the staged batch
+        ctx.sync(); torch.cuda.synchronize()
         L.csdr_amd_fastddc_bank_destroy(bank)
+        if comm:
+            L.csdr_amd_comm_destroy(comm)
     else:
         L.csdr_amd_fastddc_inv_destroy(inv)
     if fwd:

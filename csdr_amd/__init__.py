@@ -146,6 +146,15 @@ def lib():
     L.csdr_amd_fastddc_bank_max_output.argtypes = [vp, i]
     L.csdr_amd_fastddc_bank_process.argtypes = [vp, vp, i, vp, sz, vp]
     L.csdr_amd_fastddc_bank_inverse.restype = vp; L.csdr_amd_fastddc_bank_inverse.argtypes = [vp]
+    L.csdr_amd_fastddc_bank_submit.argtypes = [vp, vp, i]
+    L.csdr_amd_fastddc_bank_collect.argtypes = [vp, vp, sz, vp]
+    L.csdr_amd_comm_unique_id.argtypes = [vp]
+    L.csdr_amd_comm_create.restype = vp; L.csdr_amd_comm_create.argtypes = [vp, vp, i, i]
+    L.csdr_amd_comm_destroy.argtypes = [vp]; L.csdr_amd_comm_destroy.restype = None
+    L.csdr_amd_comm_rank.argtypes = [vp]; L.csdr_amd_comm_world.argtypes = [vp]
+    L.csdr_amd_comm_broadcast.argtypes = [vp, vp, sz, i]
+    L.csdr_amd_fastddc_bank_create_sharded.restype = vp; L.csdr_amd_fastddc_bank_create_sharded.argtypes = [vp, fl, i, vp, i, i, i, vp]
+    L.csdr_amd_fastddc_bank_channel_slice.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.csdr_amd_fastddc_inv_kernel_name.restype = C.c_char_p; L.csdr_amd_fastddc_inv_kernel_name.argtypes = [vp]
     L.csdr_amd_fastddc_inv_set_profiling.argtypes = [vp, i]
     L.csdr_amd_fastddc_inv_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]

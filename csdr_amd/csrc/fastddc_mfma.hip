@@ -26,6 +26,7 @@
 #include "fastddc.hpp"
 #include "fft_butterflies.hpp"
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -37,7 +38,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct DdcMfma {
     csdr_amd_ctx *ctx;
     int fft, inv, pre, G, C, Cpad, nbp, scrap, post_in, post_dec, kmax, rpitch, max_blocks;
-    float *d_Ht; cf32 *d_Xt, *d_Ct; float2 *d_R, *d_tw;
+    float *d_Ht; cf32 *d_Ct; float2 *d_tw;
+    // sharding (a bank over several GPUs): this rank's channels [C] of all, the forward transform split by blocks (nbl per rank), Xt = one chunk per rank
+    int rank, world, nbl; const DdcComm *comm; cf32 *d_in_local;
+    // Two sets of everything a call produces before the fold (transposed spectra, chain tables, phasor checkpoints): submit() fills one set on the side
+    // stream -- exchange + forward transform + chains -- while collect() folds the other on the context's stream.
+    cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
+    int pending_blocks[2]; int fill, drain;                            // set being filled next / folded next
+    hipStream_t side; hipEvent_t ev_ready[2], ev_free[2], ev_fork; bool free_recorded[2];
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
     // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256) void k_ddc_xt(const float2 *__restrict__ X, fl
 // registers while the current one is multiplied and go to the other buffer afterwards; the bins' stores drain under the next residue's product.
 template <int NBT, bool PERSIST>
 __global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
-                                                  const ChanGeom *__restrict__ geom, int inv, int pre, int Cpad, int n_channels, int nbp, int n_blocks, float scale)
+                                                  const ChanGeom *__restrict__ geom, int inv, int pre, int Cpad, int n_channels, int nbp, int nbl, int n_blocks, float scale)
 {
     extern __shared__ float4 xs_all[];                              // (PERSIST ? 2 : 1) x [32 NBT rows][pre / 2 + 1] float4
     constexpr int NX = 4 * NBT;                                     // float4 per thread of one residue's spectra (PERSIST: pre <= 128)
@@ -96,12 +104,13 @@ __global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *
     const int i = lane & 31, hi = lane >> 5;
     const size_t gstride = (size_t)Cpad * 2;                          // float4 per k-group
     const bool active = c_base < Cpad;
-    auto xt_src = [&](int r) { return reinterpret_cast<const float4 *>(Xt + ((size_t)r * nbp + b_base) * pre); };
-    {   // stage the first residue's spectra: rows are contiguous in Xt (pre complex = pre / 2 float4 each)
-        const float4 *src = xt_src(blockIdx.x);
+    // Xt is kept in chunks of nbl blocks (one chunk per rank of a sharded bank: the all-gather's receive layout; a single chunk otherwise):
+    // row (r, b) = Xt[((b / nbl) inv + r) nbl + b % nbl][0 .. pre)
+    auto xt_row = [&](int r, int b) { return reinterpret_cast<const float4 *>(Xt + (((size_t)(b / nbl) * inv + r) * nbl + (b % nbl)) * pre); };
+    {   // stage the first residue's spectra (pre complex = pre / 2 float4 per block row)
         for (int idx = threadIdx.x; idx < rows * row4; idx += 512) {
-            const int row = idx / row4, col = idx - row * row4;
-            xs_all[row * P4 + col] = (b_base + row < n_blocks) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int row = idx / row4, col = idx - row * row4, b = b_base + row;
+            xs_all[row * P4 + col] = (b < n_blocks) ? xt_row(blockIdx.x, b)[col] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
@@ -110,11 +119,10 @@ __global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *
         const int rn = r + gridDim.x;
         float4 nx[NX];
         if (PERSIST && rn < inv) {
-            const float4 *src = xt_src(rn);
 #pragma unroll
             for (int k = 0; k < NX; k++) {
-                const int idx = threadIdx.x + 512 * k, row = idx / row4;
-                nx[k] = (idx < rows * row4 && b_base + row < n_blocks) ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int idx = threadIdx.x + 512 * k, row = idx / row4, col = idx - row * row4, b = b_base + row;
+                nx[k] = (idx < rows * row4 && b < n_blocks) ? xt_row(rn, b)[col] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if (active) {
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
             const long long pos = base + 128LL * (64 * a + i + IW * s);
             v[s][a] = pos < 0 ? tail[ovl + pos] : in[pos];
             // the last window ends with the stream's newest `ovl` samples = the next call's overlap (csdr.c:2292)
-            if (b == n_blocks - 1 && pos >= tail_first) tail_out[pos - tail_first] = v[s][a];
+            if (tail_out && b == n_blocks - 1 && pos >= tail_first) tail_out[pos - tail_first] = v[s][a];
         }
     __syncthreads();                                                  // twiddle tables
 #pragma unroll
@@ -505,7 +513,8 @@ __global__ __launch_bounds__(256) void k_ddc_ifft256d_post(const float2 *__restr
 } // namespace
 
 // ====================================================================================== host side
-DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec, int input_size, int overlap)
+DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_channels, int max_blocks, int scrap, int post_in, int post_dec, int input_size, int overlap,
+                         const DdcComm *comm)
 {
     if (getenv("CSDR_AMD_DDC_MFMA_OFF")) return nullptr;
     if (inv != 512 || pre < 8 || (pre & (pre - 1)) || fft != inv * pre || post_dec < 1 || scrap + post_in > inv) return nullptr;
@@ -513,14 +522,27 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
     m->ctx = ctx; m->fft = fft; m->inv = inv; m->pre = pre; m->G = pre / 4; m->C = n_channels; m->Cpad = (n_channels + 31) / 32 * 32;
     m->max_blocks = max_blocks; m->nbp = (max_blocks + 31) / 32 * 32; m->scrap = scrap; m->post_in = post_in; m->post_dec = post_dec;
     m->kmax = (post_in - 1) / post_dec + 1; m->rpitch = (m->kmax + ROT_CK - 1) / ROT_CK;      // checkpoints per chain
-    m->input_size = input_size; m->overlap = overlap; m->flip = 0;
-    m->d_Ht = nullptr; m->d_Xt = nullptr; m->d_Ct = nullptr; m->d_R = nullptr; m->d_tw = nullptr; m->d_Y = nullptr; m->d_tail[0] = m->d_tail[1] = nullptr; m->d_twb = nullptr;
+    m->input_size = input_size; m->overlap = overlap;
+    m->comm = comm; m->rank = comm ? comm->rank : 0; m->world = comm ? comm->world : 1;
+    m->nbl = m->world > 1 ? (max_blocks + m->world - 1) / m->world : m->nbp;
+    const size_t xt_elems = (size_t)m->world * inv * m->nbl * pre;
     hipError_t e = hipMalloc((void **)&m->d_Ht, sizeof(float) * 2 * (size_t)m->Cpad * fft);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_Xt, sizeof(cf32) * (size_t)fft * m->nbp);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_Ct, sizeof(cf32) * (size_t)inv * m->Cpad * m->nbp);
-    if (e == hipSuccess) e = hipMalloc((void **)&m->d_R, sizeof(float2) * (size_t)n_channels * max_blocks * m->rpitch);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_tw, sizeof(float2) * 512);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_twb, sizeof(float2) * 128);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+        const size_t n_tab = (size_t)n_channels * max_blocks;
+        e = hipMalloc((void **)&m->d_Xt[k], sizeof(cf32) * xt_elems);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->d_R[k], sizeof(float2) * n_tab * m->rpitch);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->d_blk_remain[k], sizeof(int) * n_tab);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->d_blk_off[k], sizeof(int) * n_tab);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->d_blk_phase[k], sizeof(float) * n_tab);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->d_counts[k], sizeof(int) * n_channels);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_free[k], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(m->d_Ht, 0, sizeof(float) * 2 * (size_t)m->Cpad * fft, ctx->stream);      // padded channel rows stay zero
     if (e != hipSuccess) { fail(e, "hipMalloc(fastddc matrix-core path)", __FILE__, __LINE__); ddc_mfma_destroy(m); return nullptr; }
     std::vector<float2> tw(512), twb(128);
@@ -534,11 +556,21 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
 void ddc_mfma_destroy(DdcMfma *m)
 {
     if (!m) return;
-    (void)hipFree(m->d_Ht); (void)hipFree(m->d_Xt); (void)hipFree(m->d_Ct); (void)hipFree(m->d_R); (void)hipFree(m->d_tw); (void)hipFree(m->d_twb);
-    (void)hipFree(m->d_Y); (void)hipFree(m->d_tail[0]); (void)hipFree(m->d_tail[1]);
+    if (m->side) { (void)hipStreamSynchronize(m->side); (void)hipStreamDestroy(m->side); }
+    (void)hipFree(m->d_Ht); (void)hipFree(m->d_Ct); (void)hipFree(m->d_tw); (void)hipFree(m->d_twb);
+    (void)hipFree(m->d_Y); (void)hipFree(m->d_tail[0]); (void)hipFree(m->d_tail[1]); (void)hipFree(m->d_in_local);
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(m->d_Xt[k]); (void)hipFree(m->d_R[k]); (void)hipFree(m->d_blk_remain[k]); (void)hipFree(m->d_blk_off[k]); (void)hipFree(m->d_blk_phase[k]); (void)hipFree(m->d_counts[k]);
+        if (m->ev_ready[k]) (void)hipEventDestroy(m->ev_ready[k]);
+        if (m->ev_free[k]) (void)hipEventDestroy(m->ev_free[k]);
+    }
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete m;
 }
+
+// everything queued by submit / collect has finished (retunes and destruction)
+int ddc_mfma_quiesce(DdcMfma *m) { CSDR_HIP(hipStreamSynchronize(m->side)); CSDR_HIP(hipStreamSynchronize(m->ctx->stream)); return 0; }
 
 int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, int c_count)
 {
@@ -548,48 +580,103 @@ int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, 
     return 0;
 }
 
-int ddc_mfma_load_spectra(DdcMfma *m, hipStream_t st, const cf32 *spectra, int n_blocks)
+bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->pre == 128 && !getenv("CSDR_AMD_DDC_FWD_OFF"); }
+
+// chain tables + phasor checkpoints of one call into set k (data independent)
+static int mfma_chains(DdcMfma *m, hipStream_t st, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
 {
-    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
-    hipLaunchKernelGGL(k_ddc_xt, dim3(cdiv(m->inv, 32), cdiv(m->pre, 32), n_blocks), dim3(256), 0, st, reinterpret_cast<const float2 *>(spectra),
-                       reinterpret_cast<float2 *>(m->d_Xt), m->fft, m->inv, m->pre, m->nbp);
+    hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, st, d_state, d_geom, m->C, n_blocks, m->post_in, m->post_dec,
+                       m->d_blk_remain[k], m->d_blk_phase[k], m->d_blk_off[k], m->d_counts[k]);
+    CSDR_LAUNCH_CHECK();
+    const int n_chains = m->C * n_blocks;
+    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, st, d_geom, m->d_blk_phase[k], m->d_R[k], n_chains, m->C, m->kmax);
     CSDR_LAUNCH_CHECK();
     return 0;
 }
 
-bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->pre == 128 && !getenv("CSDR_AMD_DDC_FWD_OFF"); }
-
-// fastddc_fwd_cc's overlap-save framing + forward transform of n_blocks x input_size NEW samples (csdr.c:2289-2299), result in the fold's own layout
-int ddc_mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, int n_blocks)
+// forward transform of n_loc windows: window b starts at in[b inp - ovl] (positions < 0 come from `tail`); the result goes to Xt chunk `xt` with block pitch nbl
+static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt)
 {
-    if (!ddc_mfma_can_forward(m)) return fail_msg(-3, "fastddc: the fused forward transform covers fft_size 65536 / pre_decimation 128 only");
-    if (n_blocks <= 0) return 0;
-    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
-    if (!m->d_Y) {
-        hipError_t e = hipMalloc((void **)&m->d_Y, sizeof(cf32) * (size_t)m->max_blocks * m->fft);
-        for (int k = 0; k < 2 && e == hipSuccess; k++) {
-            e = hipMalloc((void **)&m->d_tail[k], sizeof(cf32) * (size_t)(m->overlap + 1));
-            if (e == hipSuccess) e = hipMemsetAsync(m->d_tail[k], 0, sizeof(cf32) * (size_t)(m->overlap + 1), st);        // csdr.c:2279: the first window starts with zeros
-        }
-        if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
-    }
-    // pass 1: 8 columns n2 per workgroup (64-byte runs, 42 KiB of LDS: three workgroups per CU) unless CSDR_AMD_DDC_FWD=16 (128-byte runs, two per CU)
-    const char *fv = getenv("CSDR_AMD_DDC_FWD");
-#define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(m->d_tail[m->flip]), reinterpret_cast<float2 *>(m->d_tail[m->flip ^ 1]), \
-                     reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_blocks
-    if (fv && atoi(fv) == 16) {
+    if (n_loc <= 0) return 0;
+    const char *fv = getenv("CSDR_AMD_DDC_FWD");                      // pass 1: 16 columns n2 per workgroup (128-byte runs); "8": 64-byte runs, more workgroups per CU
+#define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
+                     reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc
+    if (fv && atoi(fv) == 8) {
+        const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
+        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc), dim3(256), lds, st, DDC_FWD_ARGS);
+    } else {
         const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
         { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_blocks), dim3(256), lds, st, DDC_FWD_ARGS);
-    } else {
-        const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
-        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_blocks), dim3(256), lds, st, DDC_FWD_ARGS);
+        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_loc), dim3(256), lds, st, DDC_FWD_ARGS);
     }
 #undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_blocks, 32)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(m->d_Xt), m->d_tw, m->nbp, n_blocks);
+    hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_loc, 32)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(xt), m->d_tw, m->nbl, n_loc);
     CSDR_LAUNCH_CHECK();
-    m->flip ^= 1;
+    return 0;
+}
+
+// Stage one call: `in` = n_blocks x input_size NEW wideband samples (on rank 0 of a sharded bank; ignored elsewhere), or `spectra` = the natural
+// [n_blocks][fft] spectra of csdr fastddc_fwd_cc (single GPU only).  Runs on the side stream: chains, [scatter of the input windows by blocks -> local
+// forward transforms -> all-gather of the transposed spectra], into the set that collect() folds next.  At most two calls may be staged.
+int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
+{
+    if (n_blocks <= 0) return fail_msg(-3, "fastddc: nothing to submit");
+    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
+    const int k = m->fill;
+    if (m->pending_blocks[k]) return fail_msg(-3, "fastddc: two calls are already staged; collect one first");
+    hipStream_t st = m->side, mainst = m->ctx->stream;
+    CSDR_HIP(hipEventRecord(m->ev_fork, mainst));                       // the producers of `in` queued so far, and (single set reuse) nothing else
+    CSDR_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
+    if (m->free_recorded[k]) CSDR_HIP(hipStreamWaitEvent(st, m->ev_free[k], 0));      // the fold that read this set two calls ago
+    int rc = mfma_chains(m, st, k, n_blocks, d_state, d_geom); if (rc) return rc;
+    if (spectra) {
+        if (m->world > 1) return fail_msg(-3, "fastddc: natural-order spectra cannot feed a sharded bank");
+        hipLaunchKernelGGL(k_ddc_xt, dim3(cdiv(m->inv, 32), cdiv(m->pre, 32), n_blocks), dim3(256), 0, st, reinterpret_cast<const float2 *>(spectra),
+                           reinterpret_cast<float2 *>(m->d_Xt[k]), m->fft, m->inv, m->pre, m->nbl);
+        CSDR_LAUNCH_CHECK();
+    } else {
+        if (!ddc_mfma_can_forward(m)) return fail_msg(-3, "fastddc: the fused forward transform covers fft_size 65536 / pre_decimation 128 only");
+        const int inp = m->input_size, ovl = m->overlap;
+        if (!m->d_Y) {
+            const int y_blocks = m->world > 1 ? m->nbl : m->max_blocks;
+            hipError_t e = hipMalloc((void **)&m->d_Y, sizeof(cf32) * (size_t)y_blocks * m->fft);
+            for (int t = 0; t < 2 && e == hipSuccess; t++) {
+                e = hipMalloc((void **)&m->d_tail[t], sizeof(cf32) * (size_t)(ovl + 1));
+                if (e == hipSuccess) e = hipMemsetAsync(m->d_tail[t], 0, sizeof(cf32) * (size_t)(ovl + 1), st);        // csdr.c:2279: the first window starts with zeros
+            }
+            if (e == hipSuccess && m->world > 1) e = hipMalloc((void **)&m->d_in_local, sizeof(cf32) * ((size_t)m->nbl * inp + ovl));
+            if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
+        }
+        if (m->world == 1) {
+            rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k]); if (rc) return rc;
+            m->flip ^= 1;
+        } else {
+            // rank g transforms blocks [g nbl, (g + 1) nbl): the root sends it the samples of its windows, stream[g nbl inp - ovl, min((g + 1) nbl, n) inp),
+            // over its own link (seven transfers in flight from the root), then the chunks are all-gathered over the full mesh
+            const DdcComm *cm = m->comm;
+            auto first_of = [&](int g) { return g * m->nbl < n_blocks ? g * m->nbl : n_blocks; };
+            const int b0 = first_of(m->rank), b1 = first_of(m->rank + 1), n_loc = b1 - b0;
+            rc = cm->group_start(cm); if (rc) return rc;
+            if (m->rank == 0) {
+                for (int g = 1; g < m->world; g++) {
+                    const int g0 = first_of(g), g1 = first_of(g + 1);
+                    if (g1 > g0) { rc = cm->send(cm, in + (size_t)g0 * inp - ovl, 2 * ((size_t)(g1 - g0) * inp + ovl), g, st); if (rc) return rc; }
+                }
+            } else if (n_loc > 0) { rc = cm->recv(cm, m->d_in_local, 2 * ((size_t)n_loc * inp + ovl), 0, st); if (rc) return rc; }
+            rc = cm->group_end(cm); if (rc) return rc;
+            cf32 *chunk = m->d_Xt[k] + (size_t)m->rank * m->inv * m->nbl * m->pre;
+            if (m->rank == 0) {
+                rc = mfma_forward(m, st, in, m->d_tail[m->flip], nullptr, n_loc, chunk); if (rc) return rc;
+                // the next call's overlap = the newest ovl samples of the stream (input_size >= overlap_length at this geometry)
+                CSDR_HIP(hipMemcpyAsync(m->d_tail[m->flip ^ 1], in + (size_t)n_blocks * inp - ovl, sizeof(cf32) * (size_t)ovl, hipMemcpyDeviceToDevice, st));
+                m->flip ^= 1;
+            } else { rc = mfma_forward(m, st, m->d_in_local + ovl, m->d_in_local, nullptr, n_loc, chunk); if (rc) return rc; }
+            rc = cm->all_gather(cm, m->d_Xt[k], 2 * (size_t)m->inv * m->nbl * m->pre, st); if (rc) return rc;      // in place: every rank's chunk sits at its offset
+        }
+    }
+    CSDR_HIP(hipEventRecord(m->ev_ready[k], st));
+    m->pending_blocks[k] = n_blocks; m->fill ^= 1;
     return 0;
 }
 
@@ -606,31 +693,14 @@ int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches)
     return 0;
 }
 
-cf32 *ddc_mfma_xt(DdcMfma *m, size_t *bytes, int *block_pitch)
+// Fold + inverse transforms + scrap + residual shift of the oldest staged call, on the context's stream.  Returns its block count (or < 0);
+// *d_counts receives the device array of samples written per channel.
+int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts)
 {
-    if (bytes) *bytes = sizeof(cf32) * (size_t)m->fft * m->nbp;
-    if (block_pitch) *block_pitch = m->nbp;
-    return m->d_Xt;
-}
-
-// The per-channel state chain over the blocks of this call and the phasor checkpoints of every (block, channel): data independent, a few microseconds,
-// queued first.  The blk_* arrays are filled BLOCK-MAJOR (b * n_channels + c) on this path.
-int ddc_mfma_begin_chains(DdcMfma *m, hipStream_t st, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, int *d_blk_remain, float *d_blk_phase, int *d_blk_off, int *d_counts)
-{
-    if (n_blocks <= 0) return 0;
-    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
-    hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, st, d_state, d_geom, m->C, n_blocks, m->post_in, m->post_dec, d_blk_remain, d_blk_phase, d_blk_off, d_counts);
-    CSDR_LAUNCH_CHECK();
-    const int n_chains = m->C * n_blocks;
-    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, st, d_geom, d_blk_phase, m->d_R, n_chains, m->C, m->kmax);
-    CSDR_LAUNCH_CHECK();
-    return 0;
-}
-
-int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d_geom, const int *d_blk_remain, const int *d_blk_off, cf32 *out, size_t out_pitch)
-{
-    if (n_blocks <= 0) return 0;
-    if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
+    const int k = m->drain, n_blocks = m->pending_blocks[k];
+    if (!n_blocks) return fail_msg(-3, "fastddc: nothing staged to collect");
+    hipStream_t st = m->ctx->stream;
+    CSDR_HIP(hipStreamWaitEvent(st, m->ev_ready[k], 0));
     const float scale = 1.0f / (float)m->pre;                              // fastddc.c:144-148 (a power of two: exact)
     const int nbt = n_blocks > 32 ? 2 : 1;
     const size_t lds = (size_t)32 * nbt * (m->pre / 2 + 1) * sizeof(float4);
@@ -655,8 +725,8 @@ int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d
     const dim3 grid_use(persist ? (unsigned)slots : grid.x, grid.y, grid.z);
 #define DDC_GEMM_LAUNCH(NBTV, PV) do {                                                                                                               \
         if (lds_use > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<NBTV, PV>, lds_use); if (rc) return rc; }                    \
-        hipLaunchKernelGGL((k_ddc_gemm<NBTV, PV>), grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt),              \
-                           reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, n_blocks, scale); } while (0)
+        hipLaunchKernelGGL((k_ddc_gemm<NBTV, PV>), grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]),           \
+                           reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); } while (0)
     if (nbt == 2) { if (persist) DDC_GEMM_LAUNCH(2, true); else DDC_GEMM_LAUNCH(2, false); }
     else          { if (persist) DDC_GEMM_LAUNCH(1, true); else DDC_GEMM_LAUNCH(1, false); }
 #undef DDC_GEMM_LAUNCH
@@ -669,7 +739,7 @@ int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d
     const bool nt16 = iv && strstr(iv, "16");
     const int pairs = m->C * cdiv(n_blocks, 16);
     const dim3 g16(cdiv(n_blocks, 16), m->C), g8(cdiv(pairs, 8) * 16);
-#define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R, m->d_tw, d_blk_remain, d_blk_off, d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in
+#define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R[k], m->d_tw, m->d_blk_remain[k], m->d_blk_off[k], d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in
     if (full && nt16) {
         const size_t lds2 = (size_t)(16 * I512<16>::pitch + I512<16>::tw_n) * sizeof(float2);
         { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post<16>, lds2); if (rc) return rc; }
@@ -683,7 +753,10 @@ int ddc_mfma_process(DdcMfma *m, hipStream_t st, int n_blocks, const ChanGeom *d
     }
 #undef DDC_IFFT_ARGS
     CSDR_LAUNCH_CHECK();
-    return 0;
+    CSDR_HIP(hipEventRecord(m->ev_free[k], st)); m->free_recorded[k] = true;
+    if (d_counts) *d_counts = m->d_counts[k];
+    m->pending_blocks[k] = 0; m->drain ^= 1;
+    return n_blocks;
 }
 
 } // namespace csdr_amd

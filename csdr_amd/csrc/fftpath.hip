@@ -11,6 +11,9 @@
 #include "common.hpp"
 #include "fastddc.hpp"
 #include <hipfft/hipfft.h>
+
+struct csdr_amd_comm;
+namespace csdr_amd { const DdcComm *csdr_amd_comm_ddc(csdr_amd_comm *c); }   // comm.cpp
 #include <math.h>
 #include <vector>
 #include <map>
@@ -497,8 +500,15 @@ struct csdr_amd_fastddc_inv {
 
 extern "C" {
 
+static csdr_amd_fastddc_inv *fastddc_inv_create_comm(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *shift_rates,
+                                                     int n_channels, int window, int max_blocks, const DdcComm *comm);
 csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *shift_rates,
                                                   int n_channels, int window, int max_blocks)
+{
+    return fastddc_inv_create_comm(ctx, transition_bw, decimation, shift_rates, n_channels, window, max_blocks, nullptr);
+}
+static csdr_amd_fastddc_inv *fastddc_inv_create_comm(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *shift_rates,
+                                                     int n_channels, int window, int max_blocks, const DdcComm *comm)
 {
     if (n_channels < 1 || max_blocks < 1) { fail_msg(-3, "fastddc_inv: bad sizes"); return nullptr; }
     csdr_amd_fastddc_inv *f = new csdr_amd_fastddc_inv();
@@ -513,7 +523,7 @@ csdr_amd_fastddc_inv *csdr_amd_fastddc_inv_create(csdr_amd_ctx *ctx, float trans
     const csdr_fastddc_t &g = f->geom[0];
     const int fft = g.fft_size, inv = g.fft_inv_size;
     f->d_inv_in = nullptr; f->d_td = nullptr;
-    f->mf = ddc_mfma_create(ctx, fft, inv, g.pre_decimation, n_channels, max_blocks, g.scrap, g.post_input_size, g.post_decimation, g.input_size, g.overlap_length);
+    f->mf = ddc_mfma_create(ctx, fft, inv, g.pre_decimation, n_channels, max_blocks, g.scrap, g.post_input_size, g.post_decimation, g.input_size, g.overlap_length, comm);
     hipError_t e = hipMalloc((void **)&f->d_H, sizeof(cf32) * (size_t)n_channels * fft);
     if (!f->mf) {                                                  // the general path's [channel][block][inv] intermediates
         if (e == hipSuccess) e = hipMalloc((void **)&f->d_inv_in, sizeof(cf32) * (size_t)n_channels * max_blocks * inv);
@@ -565,6 +575,7 @@ int csdr_amd_fastddc_inv_set_rate(csdr_amd_fastddc_inv *f, int channel, float sh
     std::vector<cf32> taps((size_t)fft, cf32{0.f, 0.f});
     const float half_bw = 0.5f / (float)f->decimation;
     csdr_amd_firdes_bandpass_c((csdr_complexf *)taps.data(), g.taps_length, (-shift_rate) - half_bw, (-shift_rate) + half_bw, f->window);
+    if (f->mf) { const int qrc = ddc_mfma_quiesce(f->mf); if (qrc) return qrc; }   // staged calls read the tables on a side stream
     CSDR_HIP(hipStreamSynchronize(ctx->stream));                     // the previous process() call may still read this channel's row
     CSDR_HIP(hipMemcpy(f->d_geom + channel, &cg, sizeof(ChanGeom), hipMemcpyHostToDevice));
     CSDR_HIP(hipMemset(f->d_state + channel, 0, sizeof(DdcChanState)));
@@ -617,12 +628,12 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
     const csdr_fastddc_t &g = f->geom[0];
     const int fft = g.fft_size, inv = g.fft_inv_size, pre = g.pre_decimation;
     if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_inv: out_pitch too small");
-    if (f->mf) {   // config 4's geometry: fold on the matrix cores, own 512-point inverse transforms fused with scrap + residual shift
-        int rc = ddc_mfma_begin_chains(f->mf, st, n_blocks, f->d_state, f->d_geom, f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); if (rc) return rc;
-        rc = ddc_mfma_load_spectra(f->mf, st, spectra, n_blocks); if (rc) return rc;
-        rc = ddc_mfma_process(f->mf, st, n_blocks, f->d_geom, f->d_blk_remain, f->d_blk_off, out, out_pitch); if (rc) return rc;
+    if (f->mf) {   // config 4's geometry: fold on the matrix cores, own inverse transforms fused with scrap + residual shift
+        int rc = ddc_mfma_submit(f->mf, nullptr, spectra, n_blocks, f->d_state, f->d_geom); if (rc) return rc;
+        const int *d_cnt = nullptr;
+        rc = ddc_mfma_collect(f->mf, f->d_geom, out, out_pitch, &d_cnt); if (rc < 0) return rc;
         if (out_counts) {
-            CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
+            CSDR_HIP(hipMemcpyAsync(out_counts, d_cnt, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
             CSDR_HIP(hipStreamSynchronize(st));
         }
         return 0;
@@ -666,20 +677,30 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
 // The ddcd topology (ddcd_old.cpp:238-252, 474-492: one `csdr fastddc_fwd_cc` feeding N `csdr fastddc_inv_cc --fd` clients) as ONE call per block
 // batch: new wideband samples in, every channel's decimated samples out.  At config 4's geometry the forward transform writes the fold's own
 // layout directly (fastddc_mfma.hip: no natural-order spectrum, no framing copy); other geometries chain the two halves through a spectrum buffer.
+// Sharded over several GPUs (csdr_amd_fastddc_bank_create_sharded): every rank owns a slice of the channels; the wideband input lives on rank 0, the
+// forward transform is split by blocks over the ranks and the transposed spectra are all-gathered (fastddc_mfma.hip: ddc_mfma_submit).
 struct csdr_amd_fastddc_bank {
     csdr_amd_ctx *ctx; csdr_amd_fastddc_inv *inv; csdr_amd_fastddc_fwd *fwd; cf32 *d_spec; int max_blocks; bool fused;
+    csdr_amd_comm *comm; int first_channel, n_channels_total; int staged[2], n_staged;      // general path: block counts of the staged calls
 };
 
-extern "C" {
-
-csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
-                                                    int window, int max_blocks)
+static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
+                                          int window, int max_blocks, csdr_amd_comm *comm)
 {
     csdr_amd_fastddc_bank *b = new csdr_amd_fastddc_bank();
-    b->ctx = ctx; b->max_blocks = max_blocks; b->fwd = nullptr; b->d_spec = nullptr;
-    b->inv = csdr_amd_fastddc_inv_create(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, max_blocks);
+    b->ctx = ctx; b->max_blocks = max_blocks; b->fwd = nullptr; b->d_spec = nullptr; b->comm = comm; b->n_staged = 0;
+    b->first_channel = 0; b->n_channels_total = n_channels;
+    int count = n_channels;
+    const DdcComm *dc = comm ? csdr_amd_comm_ddc(comm) : nullptr;
+    if (dc && dc->world > 1) {   // block distribution of the channels, counts differ by at most one (csdr_amd/dist.py: shard)
+        const int base = n_channels / dc->world, extra = n_channels % dc->world;
+        count = base + (dc->rank < extra ? 1 : 0); b->first_channel = dc->rank * base + (dc->rank < extra ? dc->rank : extra);
+        if (count < 1) { fail_msg(-3, "fastddc_bank: fewer channels than ranks"); delete b; return nullptr; }
+    }
+    b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates + b->first_channel, count, window, max_blocks, dc && dc->world > 1 ? dc : nullptr);
     if (!b->inv) { delete b; return nullptr; }
     b->fused = ddc_mfma_can_forward(b->inv->mf);
+    if (dc && dc->world > 1 && !b->fused) { fail_msg(-3, "fastddc_bank: sharding needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512)"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
     if (!b->fused) {
         csdr_fastddc_t g = b->inv->geom[0];
         b->fwd = csdr_amd_fastddc_fwd_create(ctx, &g, max_blocks);
@@ -688,6 +709,16 @@ csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create(csdr_amd_ctx *ctx, float tra
     }
     return b;
 }
+
+extern "C" {
+
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
+                                                    int window, int max_blocks)
+{ return bank_create(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, max_blocks, nullptr); }
+
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
+                                                            int window, int max_blocks, csdr_amd_comm *comm)
+{ return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm); }
 
 void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
 {
@@ -698,30 +729,47 @@ void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
     delete b;
 }
 
+int csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count) { *first = b->first_channel; *count = b->inv->n_channels; return 0; }
 int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate) { return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate); }
 int csdr_amd_fastddc_bank_input_size(const csdr_amd_fastddc_bank *b) { return b->inv->geom[0].input_size; }
 int csdr_amd_fastddc_bank_max_output(const csdr_amd_fastddc_bank *b, int n_blocks) { return csdr_amd_fastddc_inv_max_output(b->inv, n_blocks); }
 csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b) { return b->inv; }
 
-int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+int csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks)
 {
-    if (n_blocks <= 0) return 0;
-    if (n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks exceed max_blocks %d", n_blocks, b->max_blocks);
-    if (!b->fused) {
-        int rc = csdr_amd_fastddc_fwd_process(b->fwd, in, b->d_spec, n_blocks); if (rc) return rc;
-        return csdr_amd_fastddc_inv_process(b->inv, b->d_spec, n_blocks, out, out_pitch, out_counts);
-    }
+    if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
+    if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom);
+    if (b->n_staged) return fail_msg(-3, "fastddc_bank: this geometry stages one call at a time");
+    int rc = csdr_amd_fastddc_fwd_process(b->fwd, in, b->d_spec, n_blocks); if (rc) return rc;
+    b->staged[0] = n_blocks; b->n_staged = 1;
+    return 0;
+}
+
+int csdr_amd_fastddc_bank_collect(csdr_amd_fastddc_bank *b, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{
     csdr_amd_fastddc_inv *f = b->inv;
+    if (!b->fused) {
+        if (!b->n_staged) return fail_msg(-3, "fastddc_bank: nothing staged to collect");
+        b->n_staged = 0;
+        return csdr_amd_fastddc_inv_process(f, b->d_spec, b->staged[0], out, out_pitch, out_counts);
+    }
     hipStream_t st = f->ctx->stream;
-    if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
-    int rc = ddc_mfma_begin_chains(f->mf, st, n_blocks, f->d_state, f->d_geom, f->d_blk_remain, f->d_blk_phase, f->d_blk_off, f->d_counts); if (rc) return rc;
-    rc = ddc_mfma_forward(f->mf, st, in, n_blocks); if (rc) return rc;
-    rc = ddc_mfma_process(f->mf, st, n_blocks, f->d_geom, f->d_blk_remain, f->d_blk_off, out, out_pitch); if (rc) return rc;
+    const int *d_cnt = nullptr;
+    const int rc = ddc_mfma_collect(f->mf, f->d_geom, out, out_pitch, &d_cnt); if (rc < 0) return rc;
+    if ((size_t)csdr_amd_fastddc_inv_max_output(f, rc) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
     if (out_counts) {
-        CSDR_HIP(hipMemcpyAsync(out_counts, f->d_counts, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
+        CSDR_HIP(hipMemcpyAsync(out_counts, d_cnt, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
         CSDR_HIP(hipStreamSynchronize(st));
     }
     return 0;
+}
+
+int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{
+    if (n_blocks <= 0) return 0;
+    if ((size_t)csdr_amd_fastddc_inv_max_output(b->inv, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
+    const int rc = csdr_amd_fastddc_bank_submit(b, in, n_blocks); if (rc) return rc;
+    return csdr_amd_fastddc_bank_collect(b, out, out_pitch, out_counts);
 }
 
 } // extern "C"

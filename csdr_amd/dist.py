@@ -78,3 +78,50 @@ def fastddc_sharded(x_or_none, n_samples, ddc_fft_size, ddc_input_size, shift_ra
     broadcast_spectra(spectra, 0)
     first, count = shard(len(shift_rates), rank, world)
     return first, inverse_fn(spectra, shift_rates[first:first + count])
+
+
+def bank_block_ranges(n_blocks, max_blocks, world, input_size, overlap):
+    """The block split of a sharded fastddc bank (csdr_amd/csrc/fastddc_mfma.hip, ddc_mfma_submit): rank g transforms blocks [b0, b1) and needs
+    the stream samples [s0, s1) = its windows (overlap in front included; s0 < 0 on rank 0 = the kept tail of the previous call).
+    Returns (nbl, [(b0, b1, s0, s1) per rank]); nbl = blocks per chunk of the all-gathered transposed spectra."""
+    nbl = (max_blocks + world - 1) // world if world > 1 else max_blocks
+    out = []
+    for g in range(world):
+        b0 = min(g * nbl, n_blocks); b1 = min((g + 1) * nbl, n_blocks)
+        out.append((b0, b1, b0 * input_size - overlap, b1 * input_size))
+    return nbl, out
+
+
+def bank_exchange(x_or_none, n_blocks, max_blocks, input_size, overlap, fft_size, forward_window_fn, rank, world):
+    """The exchange of one batch as the C library schedules it, on torch.distributed (the CPU model of comm.cpp used by tests/test_dist_cpu.py):
+    scatter of each rank's window samples from rank 0 (point to point), local forward transforms, all-gather of the per-rank chunks.
+    forward_window_fn(samples [n_loc * input_size + overlap] complex64 numpy) -> [n_loc, fft_size] complex64 spectra of those windows.
+    Returns the gathered spectra in CHUNK order: [world, nbl, fft_size] complex64 (rows beyond a rank's blocks are zero)."""
+    import numpy as np
+    nbl, ranges = bank_block_ranges(n_blocks, max_blocks, world, input_size, overlap)
+    b0, b1, s0, s1 = ranges[rank]
+    if rank == 0:
+        xin = np.concatenate([np.zeros(overlap, np.complex64), np.asarray(x_or_none, np.complex64)])      # first call: the kept tail is zero
+        reqs = []
+        for g in range(1, world):
+            g0, g1, t0, t1 = ranges[g]
+            if g1 > g0:
+                reqs.append(dist.isend(torch.from_numpy(xin[overlap + t0:overlap + t1].view(np.float32).copy()), g))
+        mine = xin[overlap + s0:overlap + s1]
+        for r in reqs:
+            r.wait()
+    elif b1 > b0:
+        buf = torch.empty(2 * (s1 - s0), dtype=torch.float32)
+        dist.recv(buf, 0)
+        mine = buf.numpy().view(np.complex64)
+    else:
+        mine = np.zeros(0, np.complex64)
+    chunk = np.zeros((nbl, fft_size), np.complex64)
+    if b1 > b0:
+        chunk[:b1 - b0] = forward_window_fn(mine)
+    gathered = [torch.empty(2 * nbl * fft_size, dtype=torch.float32) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(gathered, torch.from_numpy(chunk.view(np.float32).reshape(-1).copy()))
+    else:
+        gathered[0] = torch.from_numpy(chunk.view(np.float32).reshape(-1).copy())
+    return nbl, np.stack([t.numpy().view(np.complex64).reshape(nbl, fft_size) for t in gathered])

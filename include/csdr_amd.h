@@ -272,6 +272,30 @@ int  csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float
 int  csdr_amd_fastddc_bank_input_size(const csdr_amd_fastddc_bank *b);
 int  csdr_amd_fastddc_bank_max_output(const csdr_amd_fastddc_bank *b, int n_blocks);
 int  csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts);
+/* The same in two halves, so that consecutive batches overlap: submit() stages a batch (state chains, forward transform -- and, for a sharded bank, the
+ * exchange -- on a side stream; `in` must stay untouched until the matching collect() has been queued); collect() folds / inverse-transforms the oldest staged
+ * batch on the context's stream.  Two batches may be staged: submit(N + 1) runs under collect(N).  process() = submit() + collect(). */
+int  csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks);
+int  csdr_amd_fastddc_bank_collect(csdr_amd_fastddc_bank *b, csdr_complexf *out, size_t out_pitch, int *out_counts);
+
+/* ------------------------------------------------------------------ multi-GPU: one process per GPU, RCCL over xGMI
+ * The communicator belongs to the library (RCCL is loaded on demand, librccl.so.1).  Rank 0 calls csdr_amd_comm_unique_id and ships the 128 bytes to
+ * the other ranks by any means (torch.distributed / MPI / a file); every rank then calls csdr_amd_comm_create (collective, ncclCommInitRank). */
+typedef struct csdr_amd_comm csdr_amd_comm;
+int  csdr_amd_comm_unique_id(char id128[128]);
+csdr_amd_comm *csdr_amd_comm_create(csdr_amd_ctx *ctx, const char id128[128], int rank, int world);
+void csdr_amd_comm_destroy(csdr_amd_comm *c);
+int  csdr_amd_comm_rank(const csdr_amd_comm *c);
+int  csdr_amd_comm_world(const csdr_amd_comm *c);
+int  csdr_amd_comm_broadcast(csdr_amd_comm *c, void *dev_buf, size_t bytes, int root);        /* on the context's stream (test / bench plumbing) */
+/* fastddc bank sharded over the communicator (BASELINE config 4 at 2 / 4 / 8 GPUs): host_shift_rates_all = ALL channels on every rank; rank r keeps the
+ * block-distributed slice csdr_amd_fastddc_bank_channel_slice reports (out rows = that slice).  `in` of submit / process is read on rank 0 only (the
+ * wideband input lives there, like ddcd's single fastddc_fwd_cc: ddcd_old.cpp:238-252): per batch the root sends every rank the samples of ITS blocks'
+ * windows (point to point, one link each), every rank transforms its blocks, the transposed spectra are all-gathered over the full mesh, every rank
+ * folds its channels.  Needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512).  All ranks make the same calls in the same order. */
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
+                                                            int window, int max_blocks, csdr_amd_comm *comm);
+int  csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count);
 /* the bank's inverse half (kernel name / profiling: csdr_amd_fastddc_inv_kernel_name, _set_profiling, _kernel_time) */
 csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b);
 

@@ -98,6 +98,49 @@ def test_c4_bank_fused_forward(gpu, port):
     assert outs[35].size == w35.size and vc.relrms(outs[35], w35) < TOL
 
 
+def test_bank_pipelined_single_rank_communicator(gpu):
+    """submit(N + 1) before collect(N) (two batches staged: the second one's chains and forward transform run on the side stream under the first one's
+    fold) gives the stream process() gives; the bank is created through the sharded entry point on a ONE-rank RCCL communicator of the library's own
+    (csdr_amd_comm_*: the dlopen of librccl and ncclCommInitRank are exercised; with one rank the slice is everything and nothing moves)."""
+    L = gpu.L
+    tbw, D, nch, per, calls = 0.001, 256, 20, 9, 4
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(47)
+    x = (rng.uniform(-1, 1, ddc.input_size * per * calls) + 1j * rng.uniform(-1, 1, ddc.input_size * per * calls)).astype(c64)
+    rates = np.ascontiguousarray(vc.c4_rates(256)[5::13][:nch])
+    want = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=per)
+    idb = (C.c_char * 128)()
+    assert L.csdr_amd_comm_unique_id(idb) == 0, gpu.err()
+    comm = L.csdr_amd_comm_create(gpu.h, idb, 0, 1)
+    assert comm, gpu.err()
+    assert (L.csdr_amd_comm_rank(comm), L.csdr_amd_comm_world(comm)) == (0, 1)
+    bank = L.csdr_amd_fastddc_bank_create_sharded(gpu.h, tbw, D, rates.ctypes.data_as(C.c_void_p), nch, 2, per, comm)
+    assert bank, gpu.err()
+    f0 = C.c_int(); c0 = C.c_int(); L.csdr_amd_fastddc_bank_channel_slice(bank, C.byref(f0), C.byref(c0))
+    assert (f0.value, c0.value) == (0, nch)
+    di = gpu.upload(x)
+    pitch = L.csdr_amd_fastddc_bank_max_output(bank, per) + 8
+    outs = [[] for _ in range(nch)]
+    step = 8 * per * ddc.input_size
+    assert L.csdr_amd_fastddc_bank_submit(bank, di.at(0), per) == 0, gpu.err()
+    for k in range(calls):
+        if k + 1 < calls:
+            assert L.csdr_amd_fastddc_bank_submit(bank, di.at((k + 1) * step), per) == 0, gpu.err()
+        if k == 0:
+            assert L.csdr_amd_fastddc_bank_submit(bank, di.at(0), per) < 0            # a third staged batch is refused
+        do = gpu.alloc(8 * nch * pitch)
+        counts = np.zeros(nch, np.int32)
+        assert L.csdr_amd_fastddc_bank_collect(bank, do.ptr, pitch, counts.ctypes.data_as(C.c_void_p)) == 0, gpu.err()
+        y = gpu.download(do, c64, nch * pitch).reshape(nch, pitch)
+        for c in range(nch):
+            outs[c].append(y[c, :counts[c]].copy())
+    assert L.csdr_amd_fastddc_bank_collect(bank, do.ptr, pitch, None) < 0                  # nothing staged any more
+    L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm)
+    for c in range(nch):
+        got = np.concatenate(outs[c])
+        assert got.size == want[c].size and np.array_equal(got, want[c]), "channel %d" % c
+
+
 def test_bank_general_geometry(gpu, port):
     """the same object where the matrix-core path does not apply (fft_inv_size 128): forward and inverse halves chained through a spectrum buffer"""
     tbw, D = 0.05, 16

@@ -81,3 +81,71 @@ def test_gloo_world2_sharding_broadcast_and_timing():
         d, _ = po.fastddc_init(tbw, D, rate)
         ref = po.fastddc_inv_cc(spec, d, po.fastddc_taps_fft(d, rate, D))
         assert np.array_equal(got[c], ref)
+
+
+def _bank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from csdr_amd import dist as cd
+    import oracle
+    cd.init("gloo")
+    po = oracle.port()
+    D, tbw = 16, 0.05
+    rates = [-0.1, 0.2, 0.33, -0.4, 0.05]
+    ddc, _ = po.fastddc_init(tbw, D, 0.0)
+    n_blocks, max_blocks = 7, 8                                     # 3 ranks x 3 blocks per chunk: the last rank holds one block, n_blocks < max_blocks
+    rng = np.random.default_rng(14)
+    x = (rng.uniform(-1, 1, ddc.input_size * n_blocks) + 1j * rng.uniform(-1, 1, ddc.input_size * n_blocks)).astype(np.complex64)
+
+    def fwd_windows(samples):                                       # samples = overlap ++ n_loc * input_size: one overlap-save window per block (csdr.c:2292-2296)
+        n_loc = (samples.size - ddc.overlap_length) // ddc.input_size
+        return np.stack([po.fft_c2c(samples[b * ddc.input_size:b * ddc.input_size + ddc.fft_size], True) for b in range(n_loc)])
+
+    nbl, chunks = cd.bank_exchange(x if rank == 0 else None, n_blocks, max_blocks, ddc.input_size, ddc.overlap_length, ddc.fft_size, fwd_windows, rank, world)
+    # every rank now holds all spectra in chunk order: block b = chunks[b // nbl][b % nbl]; fold this rank's channel slice
+    spec = np.stack([chunks[b // nbl][b % nbl] for b in range(n_blocks)])
+    first, count = cd.shard(len(rates), rank, world)
+    outs = []
+    for rate in rates[first:first + count]:
+        d, _ = po.fastddc_init(tbw, D, rate)
+        outs.append(po.fastddc_inv_cc(spec, d, po.fastddc_taps_fft(d, rate, D)).tolist())
+    cd.barrier()
+    q.put((rank, first, nbl, outs))
+
+
+def test_gloo_world3_bank_schedule():
+    """The sharded bank's batch schedule (comm.cpp / fastddc_mfma.hip ddc_mfma_submit) on gloo with three ranks: the root scatters every rank the samples of
+    its blocks' windows point to point, the ranks transform their blocks, the chunks are all-gathered, every rank folds its channels -- bit-identical
+    to the unsharded oracle (same arithmetic, different owner)."""
+    import oracle
+    from csdr_amd import dist as cd
+    nbl, rg = cd.bank_block_ranges(64, 64, 8, 57344, 8192)
+    assert nbl == 8 and rg[0] == (0, 8, -8192, 8 * 57344) and rg[7] == (56, 64, 56 * 57344 - 8192, 64 * 57344)
+    nbl, rg = cd.bank_block_ranges(5, 64, 8, 57344, 8192)            # a short batch: later ranks idle
+    assert [r[1] - r[0] for r in rg] == [5, 0, 0, 0, 0, 0, 0, 0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bank_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    po = oracle.port()
+    D, tbw = 16, 0.05
+    rates = [-0.1, 0.2, 0.33, -0.4, 0.05]
+    ddc, _ = po.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(14)
+    x = (rng.uniform(-1, 1, ddc.input_size * 7) + 1j * rng.uniform(-1, 1, ddc.input_size * 7)).astype(np.complex64)
+    spec = po.fastddc_fwd_cc(x, ddc)
+    got = {}
+    for rank, first, nbl, outs in res:
+        assert nbl == 3
+        for k, o in enumerate(outs):
+            got[first + k] = np.array(o, dtype=np.complex64)
+    assert sorted(got) == list(range(len(rates)))
+    for c, rate in enumerate(rates):
+        d, _ = po.fastddc_init(tbw, D, rate)
+        assert np.array_equal(got[c], po.fastddc_inv_cc(spec, d, po.fastddc_taps_fft(d, rate, D)))
