@@ -133,11 +133,19 @@ def main():
     xp = x.data_ptr() if x is not None else None
     torch.cuda.synchronize()
 
-    # One step = one batch of `nb` blocks through the whole channelizer.  With the bank, batches are software-pipelined the way a stream is processed:
-    # batch N+1 is staged (chains, exchange, forward transform: side stream) while batch N is folded -- every step still does one submit and one collect.
+    # One step = one batch of `nb` blocks through the whole channelizer.  Over several GPUs the batches are software-pipelined the way a stream is
+    # processed: batch N+1 is staged (chains, exchange, forward transform: side stream) while batch N is folded -- every step still does one submit and one
+    # collect.  On one GPU there is nothing to hide the transforms under (the fold's workgroups hold the whole LDS of every CU; measured: 0.184 ms
+    # pipelined vs 0.179 ms in order, profiles/r2f_*), so a step is one process() call.
+    pipelined = bank is not None and world > 1
+
     def step():
-        if bank:
+        if pipelined:
             if L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
+                raise SystemExit(ctx.err())
+            return
+        if bank:
+            if L.csdr_amd_fastddc_bank_process(bank, xp, nb, out.data_ptr(), pitch, None) < 0:
                 raise SystemExit(ctx.err())
             return
         if rank == 0:
@@ -152,7 +160,7 @@ def main():
         if rc < 0:
             raise SystemExit(ctx.err())
 
-    if bank and L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0:          # prime the pipeline: from here on one batch is always staged
+    if pipelined and L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0:      # prime the pipeline: from here on one batch is always staged
         raise SystemExit(ctx.err())
     for _ in range(args.warmup):
         step()
@@ -177,7 +185,7 @@ def main():
                "config": {"workload": "configs[3]: fastddc_fwd_cc + fastddc_inv_cc", "channels": args.channels, "decimation": args.decimation,
                           "transition_bw": args.tbw, "fft_size": ddc.fft_size, "fft_inv_size": ddc.fft_inv_size, "blocks_per_step": nb,
                           "parallelism": "channels sharded over ranks; forward transform split by blocks, input scattered point-to-point, transposed spectra all-gathered (RCCL, from libcsdr_amd.so)",
-                          "pipelining": "batch N+1 staged (exchange + forward transform, side stream) under the fold of batch N"},
+                          "pipelining": "batch N+1 staged (exchange + forward transform, side stream) under the fold of batch N" if world > 1 else "none (one process() per step)"},
                "aggregate_output_msps": round(in_samples / args.decimation * args.channels / wall / 1e6, 2),
                "realtime_factor_at_61p44_msps": round(in_samples / wall / 61.44e6, 3),
                "taps_fft_bytes_per_step": h_bytes}
@@ -208,7 +216,8 @@ def main():
         if args.verify and not res["verify"]["ok"]:
             raise SystemExit("bench_fastddc.py --verify failed: %s" % json.dumps(res["verify"]))
     if bank:
-        L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)       # drain the staged batch
+        if pipelined:
+            L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)   # drain the staged batch
         ctx.sync(); torch.cuda.synchronize()
         L.csdr_amd_fastddc_bank_destroy(bank)
         if comm:

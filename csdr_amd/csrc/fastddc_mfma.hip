@@ -45,6 +45,7 @@ struct DdcMfma {
     // stream -- exchange + forward transform + chains -- while collect() folds the other on the context's stream.
     cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
     int pending_blocks[2]; int fill, drain;                            // set being filled next / folded next
+    bool inline_set[2], chains_on_side[2];
     hipStream_t side; hipEvent_t ev_ready[2], ev_free[2], ev_fork; bool free_recorded[2];
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
@@ -619,17 +620,28 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *
 // Stage one call: `in` = n_blocks x input_size NEW wideband samples (on rank 0 of a sharded bank; ignored elsewhere), or `spectra` = the natural
 // [n_blocks][fft] spectra of csdr fastddc_fwd_cc (single GPU only).  Runs on the side stream: chains, [scatter of the input windows by blocks -> local
 // forward transforms -> all-gather of the transposed spectra], into the set that collect() folds next.  At most two calls may be staged.
-int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
+// inline = true (process(): submit immediately followed by collect, nothing else staged): the transforms go on the context's stream itself and only the
+// chains use the side stream, beside them -- on one GPU the forward transforms cannot overlap the previous batch's fold anyway (the fold's workgroups
+// hold the whole LDS of every CU), and a stream hand-off per kernel group costs more than it hides.
+int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call)
 {
     if (n_blocks <= 0) return fail_msg(-3, "fastddc: nothing to submit");
     if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
     const int k = m->fill;
     if (m->pending_blocks[k]) return fail_msg(-3, "fastddc: two calls are already staged; collect one first");
-    hipStream_t st = m->side, mainst = m->ctx->stream;
-    CSDR_HIP(hipEventRecord(m->ev_fork, mainst));                       // the producers of `in` queued so far, and (single set reuse) nothing else
-    CSDR_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
-    if (m->free_recorded[k]) CSDR_HIP(hipStreamWaitEvent(st, m->ev_free[k], 0));      // the fold that read this set two calls ago
-    int rc = mfma_chains(m, st, k, n_blocks, d_state, d_geom); if (rc) return rc;
+    hipStream_t mainst = m->ctx->stream;
+    const bool inl = inline_call && m->world == 1 && !m->pending_blocks[k ^ 1];
+    static const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 1;      // 0: chains on the context's stream too
+    hipStream_t st = inl ? mainst : m->side;
+    int rc = 0;
+    if (inl && !chains_side) {
+        rc = mfma_chains(m, mainst, k, n_blocks, d_state, d_geom); if (rc) return rc;
+    } else {
+        CSDR_HIP(hipEventRecord(m->ev_fork, mainst));                   // the producers of `in` queued so far; the readers of this set's tables (inline: same stream order)
+        CSDR_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+        if (!inl && m->free_recorded[k]) CSDR_HIP(hipStreamWaitEvent(m->side, m->ev_free[k], 0));      // the fold that read this set two calls ago
+        rc = mfma_chains(m, m->side, k, n_blocks, d_state, d_geom); if (rc) return rc;
+    }
     if (spectra) {
         if (m->world > 1) return fail_msg(-3, "fastddc: natural-order spectra cannot feed a sharded bank");
         hipLaunchKernelGGL(k_ddc_xt, dim3(cdiv(m->inv, 32), cdiv(m->pre, 32), n_blocks), dim3(256), 0, st, reinterpret_cast<const float2 *>(spectra),
@@ -675,7 +687,8 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             rc = cm->all_gather(cm, m->d_Xt[k], 2 * (size_t)m->inv * m->nbl * m->pre, st); if (rc) return rc;      // in place: every rank's chunk sits at its offset
         }
     }
-    CSDR_HIP(hipEventRecord(m->ev_ready[k], st));
+    if (!(inl && !chains_side)) CSDR_HIP(hipEventRecord(m->ev_ready[k], m->side));      // inline: the side stream carries only the chains
+    m->inline_set[k] = inl; m->chains_on_side[k] = !(inl && !chains_side);
     m->pending_blocks[k] = n_blocks; m->fill ^= 1;
     return 0;
 }
@@ -700,7 +713,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     const int k = m->drain, n_blocks = m->pending_blocks[k];
     if (!n_blocks) return fail_msg(-3, "fastddc: nothing staged to collect");
     hipStream_t st = m->ctx->stream;
-    CSDR_HIP(hipStreamWaitEvent(st, m->ev_ready[k], 0));
+    if (m->chains_on_side[k]) CSDR_HIP(hipStreamWaitEvent(st, m->ev_ready[k], 0));
     const float scale = 1.0f / (float)m->pre;                              // fastddc.c:144-148 (a power of two: exact)
     const int nbt = n_blocks > 32 ? 2 : 1;
     const size_t lds = (size_t)32 * nbt * (m->pre / 2 + 1) * sizeof(float4);

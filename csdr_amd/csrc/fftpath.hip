@@ -629,7 +629,7 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
     const int fft = g.fft_size, inv = g.fft_inv_size, pre = g.pre_decimation;
     if ((size_t)csdr_amd_fastddc_inv_max_output(f, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_inv: out_pitch too small");
     if (f->mf) {   // config 4's geometry: fold on the matrix cores, own inverse transforms fused with scrap + residual shift
-        int rc = ddc_mfma_submit(f->mf, nullptr, spectra, n_blocks, f->d_state, f->d_geom); if (rc) return rc;
+        int rc = ddc_mfma_submit(f->mf, nullptr, spectra, n_blocks, f->d_state, f->d_geom, true); if (rc) return rc;
         const int *d_cnt = nullptr;
         rc = ddc_mfma_collect(f->mf, f->d_geom, out, out_pitch, &d_cnt); if (rc < 0) return rc;
         if (out_counts) {
@@ -735,15 +735,16 @@ int csdr_amd_fastddc_bank_input_size(const csdr_amd_fastddc_bank *b) { return b-
 int csdr_amd_fastddc_bank_max_output(const csdr_amd_fastddc_bank *b, int n_blocks) { return csdr_amd_fastddc_inv_max_output(b->inv, n_blocks); }
 csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b) { return b->inv; }
 
-int csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks)
+static int bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, bool inline_call)
 {
     if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
-    if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom);
+    if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom, inline_call);
     if (b->n_staged) return fail_msg(-3, "fastddc_bank: this geometry stages one call at a time");
     int rc = csdr_amd_fastddc_fwd_process(b->fwd, in, b->d_spec, n_blocks); if (rc) return rc;
     b->staged[0] = n_blocks; b->n_staged = 1;
     return 0;
 }
+int csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks) { return bank_submit(b, in, n_blocks, false); }
 
 int csdr_amd_fastddc_bank_collect(csdr_amd_fastddc_bank *b, csdr_complexf *out, size_t out_pitch, int *out_counts)
 {
@@ -768,7 +769,7 @@ int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf 
 {
     if (n_blocks <= 0) return 0;
     if ((size_t)csdr_amd_fastddc_inv_max_output(b->inv, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
-    const int rc = csdr_amd_fastddc_bank_submit(b, in, n_blocks); if (rc) return rc;
+    const int rc = bank_submit(b, in, n_blocks, true); if (rc) return rc;
     return csdr_amd_fastddc_bank_collect(b, out, out_pitch, out_counts);
 }
 
