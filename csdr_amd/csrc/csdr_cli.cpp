@@ -810,6 +810,72 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
     return 0;
 }
 
+// ------------------------------------------------------------------ f4, first half: N-stream host ingest into the batch API
+// nmux / ddcd fan one source out to N clients, each client = one `csdr ... | csdr ...` pipeline of processes (nmux.cpp:177-283, ddcd_old.cpp:474-492).
+// The device batch API wants the opposite shape: N streams side by side in ONE call.  These commands are that producer:
+//   csdr wfm_bank_u8_s16 <shift_rate> <in_0> <out_0> [<in_1> <out_1> ...]      N u8 IQ streams -> N s16 audio streams through ONE fused WFM chain object
+//   csdr nfm_bank_u8_s16 <shift_rate> <in_0> <out_0> [<in_1> <out_1> ...]      the same through the NFM chain object (README.md:87 defaults)
+// in_k / out_k: a path (file or fifo) or fd:<n>.  Every pass reads one block of CSDR_AMD_BANK_BLOCK samples (default 262144, a multiple of 1024) from
+// EVERY input (the streams advance in lockstep, like the clients of one nmux), uploads them as the rows of one batch, runs the chain once and writes
+// each row's audio to its output.  The pass in which the first stream ends is the last one (lockstep streams end together).
+int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
+{
+    if (argc < 5 || (argc - 3) % 2) return badsyntax("usage: <shift_rate> <in_0> <out_0> [<in_k> <out_k> ...]   (paths, fifos or fd:<n>)");
+    float shift = 0; if (sscanf(argv[2], "%g", &shift) != 1) return badsyntax("shift_rate must be a number");
+    const int S = (argc - 3) / 2;
+    auto open_fd = [](const char *spec, int flags) { int fd = -1; if (!strncmp(spec, "fd:", 3)) sscanf(spec + 3, "%d", &fd); else fd = open(spec, flags, 0644); return fd; };
+    std::vector<int> in_fd(S), out_fd(S);
+    for (int k = 0; k < S; k++) {
+        in_fd[k] = open_fd(argv[3 + 2 * k], O_RDONLY); out_fd[k] = open_fd(argv[4 + 2 * k], O_WRONLY | O_CREAT | O_TRUNC);
+        if (in_fd[k] < 0 || out_fd[k] < 0) { fprintf(stderr, "csdr %s: cannot open %s / %s\n", g_cmd, argv[3 + 2 * k], argv[4 + 2 * k]); return -1; }
+    }
+    size_t T = 262144; if (const char *e = getenv("CSDR_AMD_BANK_BLOCK")) { long v = atol(e); if (v >= 1024) T = (size_t)v; }
+    T -= T % 1024;
+    const int D = nfm ? 50 : 10; const float tbw = nfm ? 0.005f : 0.05f;
+    const int nt = csdr_amd_firdes_filter_len(tbw);
+    std::vector<float> taps(nt); csdr_amd_firdes_lowpass_f(taps.data(), nt, 0.5f / (float)D, CSDR_WINDOW_HAMMING);
+    csdr_amd_wfm *w = nullptr; csdr_amd_nfm *n = nullptr;
+    if (nfm) n = csdr_amd_nfm_create(c, S, shift, D, taps.data(), nt, 48000, 1024, 1.0f, 1.0f, T);
+    else w = csdr_amd_wfm_create(c, S, shift, D, taps.data(), nt, 5, 50e-6f, 48000, T);
+    if (!w && !n) die("bank create");
+    const size_t in_pitch = 2 * T, out_pitch = ((T / 50 + 4096 + 63) / 64) * 64;
+    uint8_t *h_in = nullptr; int16_t *h_out = nullptr;
+    if (hipHostMalloc((void **)&h_in, (size_t)S * in_pitch, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&h_out, (size_t)S * out_pitch * 2, hipHostMallocDefault) != hipSuccess) die("pinned buffers");
+    uint8_t *d_in = (uint8_t *)csdr_amd_malloc(c, (size_t)S * in_pitch + 256); int16_t *d_out = (int16_t *)csdr_amd_malloc(c, (size_t)S * out_pitch * 2 + 256);
+    if (!d_in || !d_out) die("device buffers");
+    fprintf(stderr, "csdr %s: %d streams, %zu samples per stream and pass\n", g_cmd, S, T);
+    std::vector<bool> alive(S, true);
+    for (int n_alive = S; n_alive > 0;) {
+        size_t got_min = T; bool any = false;
+        for (int k = 0; k < S; k++) {
+            if (!alive[k]) { memset(h_in + (size_t)k * in_pitch, 0x80, in_pitch); continue; }
+            size_t have = 0;
+            while (have < in_pitch) { ssize_t r = read(in_fd[k], h_in + (size_t)k * in_pitch + have, in_pitch - have); if (r < 0 && errno == EINTR) continue; if (r <= 0) break; have += (size_t)r; }
+            const size_t samples = have / 2;
+            if (samples < T) { alive[k] = false; n_alive--; memset(h_in + (size_t)k * in_pitch + have, 0x80, in_pitch - have); }
+            if (samples) any = true;
+            if (samples && samples < got_min) got_min = samples;
+        }
+        if (!any) break;
+        // a short final block: whole 1024-sample chunks of the shortest live stream (the chain objects take a ragged LAST block only)
+        size_t nproc = got_min < T ? got_min : T;
+        MUST(csdr_amd_h2d(c, d_in, h_in, (size_t)S * in_pitch));
+        long na = nfm ? csdr_amd_nfm_process(n, d_in, in_pitch, nproc, d_out, nullptr, out_pitch) : csdr_amd_wfm_process(w, d_in, in_pitch, nproc, d_out, nullptr, out_pitch);
+        MUST(na);
+        if (na > 0) {
+            MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)S * out_pitch * 2));
+            for (int k = 0; k < S; k++) {
+                if (out_fd[k] < 0) continue;
+                size_t done = 0; const size_t bytes = (size_t)na * 2; const char *src = (const char *)(h_out + (size_t)k * out_pitch);
+                while (done < bytes) { ssize_t r = write(out_fd[k], src + done, bytes - done); if (r < 0) { if (errno == EINTR) continue; close(out_fd[k]); out_fd[k] = -1; break; } done += (size_t)r; }
+            }
+        }
+        if (nproc < T) break;                                        // ragged block = the end of the lockstep streams
+    }
+    for (int k = 0; k < S; k++) { if (out_fd[k] >= 0) close(out_fd[k]); close(in_fd[k]); }
+    return 0;
+}
+
 // Build the operator for one command line.  `block` = the largest input this stage will be handed in one call.
 // ctl: opened when the command line carries --fifo/--fd (single-command mode only).  Returns nullptr after printing why.
 Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control *ctl, int the_bufsize)
@@ -1022,7 +1088,7 @@ int main(int argc, char **argv)
                         "decimating_shift_addition_cc fir_decimate_cc fmdemod_quadri_cf fmdemod_quadri_novect_cf fractional_decimator_ff deemphasis_wfm_ff "
                         "deemphasis_nfm_ff limit_ff fastagc_ff bandpass_fir_fft_cc fastddc_fwd_cc fastddc_inv_cc firdes_lowpass_f firdes_bandpass_c "
                         "amdemod_cf amdemod_estimator_cf fmdemod_atan_cf dcblock_ff fastdcblock_ff agc_ff gain_ff realpart_cf logpower_cf fft_cc encode_ima_adpcm_i16_u8 decode_ima_adpcm_u8_i16 compress_fft_adpcm_f_u8 "
-                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, nfm_chain_u8_s16 <shift_rate> [decimation [transition_bw]], ddc_u8_cc <shift_rate> <decimation> [transition_bw [window]], fastddc_bank_cc <decimation> <tbw> <window> <ctl|-> <out_0> <rate_0> ..., chain \"<cmd> <args> | <cmd> <args> ...\"\n");
+                        "setbuf clone through | extensions: wfm_chain_u8_s16 <shift_rate>, nfm_chain_u8_s16 <shift_rate> [decimation [transition_bw]], ddc_u8_cc <shift_rate> <decimation> [transition_bw [window]], fastddc_bank_cc <decimation> <tbw> <window> <ctl|-> <out_0> <rate_0> ..., wfm_bank_u8_s16 / nfm_bank_u8_s16 <shift_rate> <in_0> <out_0> [<in_k> <out_k> ...], chain \"<cmd> <args> | <cmd> <args> ...\"\n");
         return -1;
     }
     g_cmd = argv[1];
@@ -1065,6 +1131,7 @@ int main(int argc, char **argv)
     if (!c) { fprintf(stderr, "csdr %s: %s\n", g_cmd, csdr_amd_last_error()); return 3; }
     size_t block = block_elems();
     if (cmd == "fastddc_bank_cc") return run_bank(c, argc, argv, block);
+    if (cmd == "wfm_bank_u8_s16" || cmd == "nfm_bank_u8_s16") return run_stream_bank(c, argc, argv, cmd[0] == 'n');
     std::vector<Stage *> stages; std::vector<size_t> caps;
     Control ctl;
     std::vector<std::vector<std::string>> cmds;

@@ -631,7 +631,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     if (m->pending_blocks[k]) return fail_msg(-3, "fastddc: two calls are already staged; collect one first");
     hipStream_t mainst = m->ctx->stream;
     const bool inl = inline_call && m->world == 1 && !m->pending_blocks[k ^ 1];
-    static const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 1;      // 0: chains on the context's stream too
+    static const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
     hipStream_t st = inl ? mainst : m->side;
     int rc = 0;
     if (inl && !chains_side) {

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "fft_butterflies.hpp"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 using namespace csdr_amd;
 
@@ -26,18 +27,15 @@ namespace {
 constexpr int F64_N = 65536;
 constexpr int F64_P = 273;                 // LDS pitch of one 256-point transform (>= 17 * 16, odd: column-major fills are conflict free)
 
-// 256-point transform of transform f (of 16 in the workgroup) by its 16 threads j = 0..15, in place in buf ([16][F64_P], natural order in
-// and out; the exchange between the two radix-16 stages uses the same rows in [k1][n2] layout with pitch 17).  tw256: exp(-2 pi i m / 256) in
-// LDS.  All 256 threads of the workgroup must call it (barriers).  One buffer instead of two: 39 KB of LDS per workgroup = 4 workgroups per CU
-// (with a separate exchange buffer: 2 per CU, and the global-memory latency of a workgroup's load / store phases was not hidden: 2.9 TB/s).
+// 256-point transform of transform f (of 16 in the workgroup) by its 16 threads j = 0..15: n = 16 n1 + n2, k = k1 + 16 k2.
+// The caller hands thread j the 16 values x[16 n1 + j] (n1 = 0..15) IN REGISTERS -- every kernel below loads exactly that set from global memory, 16 lanes
+// (j) of a load instruction reading one 128-byte run -- and gets back X[j + 16 k2] (k2 = 0..15), again the set its stores want: the only trip through LDS
+// is the exchange between the two radix-16 stages ([k1][n2] layout, pitch 17; one write and one read per element instead of three each when the tile
+// was first parked in LDS, transformed in place and read back).  tw256: exp(-2 pi i m / 256) in LDS.  All 256 threads of the workgroup must call it.
 template <bool INV>
-__device__ __forceinline__ void fft256(float2 *buf, int f, int j, const float2 *tw256)
+__device__ __forceinline__ void fft256_regs(float2 (&v)[16], float2 *buf, int f, int j, const float2 *tw256)
 {
-    float2 v[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; n1++) v[n1] = buf[f * F64_P + 16 * n1 + j];                     // n = 16 n1 + n2, thread j = n2
-    dft16<INV>(v);
-    __syncthreads();
+    dft16<INV>(v);                                                                             // over n1: v[k1], this thread's n2 = j
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         float2 w = tw256[(j * k1) & 255]; if (INV) w.y = -w.y;
@@ -45,12 +43,8 @@ __device__ __forceinline__ void fft256(float2 *buf, int f, int j, const float2 *
     }
     __syncthreads();
 #pragma unroll
-    for (int n2 = 0; n2 < 16; n2++) v[n2] = buf[f * F64_P + 17 * j + n2];                     // thread j = k1
-    dft16<INV>(v);
-    __syncthreads();
-#pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) buf[f * F64_P + j + 16 * k2] = v[k2];                     // k = k1 + 16 k2
-    __syncthreads();
+    for (int n2 = 0; n2 < 16; n2++) v[n2] = buf[f * F64_P + 17 * j + n2];                      // thread j = k1
+    dft16<INV>(v);                                                                             // v[k2] = X[j + 16 k2]
 }
 
 // W_65536^m = tw256[m >> 8] * twlo[m & 255]
@@ -61,7 +55,7 @@ __device__ __forceinline__ float2 twiddle_n(const float2 *tw256, const float2 *t
     return w;
 }
 
-// dynamic LDS: buf, the two twiddle tables
+// dynamic LDS: the exchange buffer, the two twiddle tables
 #define F64_LDS extern __shared__ float4 f64_lds_raw[]; float2 *buf = reinterpret_cast<float2 *>(f64_lds_raw), *tw256 = buf + 16 * F64_P, *twlo = tw256 + 256
 constexpr size_t F64_LDS_BYTES = (size_t)(16 * F64_P + 512) * sizeof(float2);
 
@@ -70,47 +64,54 @@ __device__ __forceinline__ void load_tables(float2 *tw256, float2 *twlo, const f
     tw256[threadIdx.x] = g_tw[threadIdx.x]; twlo[threadIdx.x] = g_tw[256 + threadIdx.x];
 }
 
-// K1: grid (16 column blocks, n_blocks, n_streams); block 256
+// K1: grid (16 column blocks, n_blocks, n_streams); block 256: thread (c = column of the block, j): rows 16 n1 + j of column 16 cb + c
 __global__ __launch_bounds__(256) void k_f64_cols_fwd(const cf32 *__restrict__ in, size_t in_pitch, int inp, int n_blocks, float2 *__restrict__ T, const float2 *__restrict__ g_tw)
 {
     F64_LDS;
     load_tables(tw256, twlo, g_tw);
-    const int t = threadIdx.x, c = t & 15, r0 = t >> 4;
+    const int t = threadIdx.x, c = t & 15, j = t >> 4;
     const int cb = blockIdx.x; const size_t s = blockIdx.z, b = blockIdx.y;
     const float2 *x = reinterpret_cast<const float2 *>(in) + s * in_pitch + b * (size_t)inp;
+    const int n2 = 16 * cb + c;
+    float2 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int r = r0 + 16 * i, n = 256 * r + 16 * cb + c;
-        buf[c * F64_P + r] = n < inp ? x[n] : make_float2(0.f, 0.f);                           // csdr.c:1864: the block is zero padded to fft_size
+    for (int n1 = 0; n1 < 16; n1++) {
+        const int n = 256 * (16 * n1 + j) + n2;
+        v[n1] = n < inp ? x[n] : make_float2(0.f, 0.f);                                        // csdr.c:1864: the block is zero padded to fft_size
     }
-    __syncthreads();
-    fft256<false>(buf, t >> 4, t & 15, tw256);
-    float2 *dst = T + (s * n_blocks + b) * (size_t)F64_N;
+    __syncthreads();                                                                           // twiddle tables
+    fft256_regs<false>(v, buf, c, j, tw256);
+    float2 *dst = T + (s * n_blocks + b) * (size_t)F64_N + n2;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int k1 = r0 + 16 * i, n2 = 16 * cb + c;
-        dst[256 * k1 + n2] = cmul(buf[c * F64_P + k1], twiddle_n(tw256, twlo, n2 * k1, false));
+    for (int k2 = 0; k2 < 16; k2++) {
+        const int k1 = j + 16 * k2;
+        dst[256 * k1] = cmul(v[k2], twiddle_n(tw256, twlo, n2 * k1, false));
     }
 }
 
-// K2: grid (16 row blocks, batch); rows k1 = 16 rb .. +15
+// K2: grid (16 row blocks, batch); rows k1 = 16 rb .. +15: thread (j, f = row of the block): elements 16 n1 + j of row f (128-byte runs per 16 lanes)
 __global__ __launch_bounds__(256) void k_f64_rows(float2 *__restrict__ T, const float2 *__restrict__ Ht, const float2 *__restrict__ g_tw)
 {
     F64_LDS;
     load_tables(tw256, twlo, g_tw);
-    const int t = threadIdx.x, rb = blockIdx.x;
-    float2 *base = T + (size_t)blockIdx.y * F64_N + (size_t)(16 * rb) * 256;
+    const int t = threadIdx.x, j = t & 15, f = t >> 4, rb = blockIdx.x;
+    float2 *row = T + (size_t)blockIdx.y * F64_N + (size_t)(16 * rb + f) * 256 + j;
+    const float2 *h = Ht + (size_t)(16 * rb + f) * 256 + j;
+    float2 v[16], hv[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) buf[i * F64_P + t] = base[256 * i + t];
+    for (int n1 = 0; n1 < 16; n1++) v[n1] = row[16 * n1];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++) hv[k2] = h[16 * k2];                                       // taps_fft[k1 + 256 (j + 16 k2)], needed after the forward transform
     __syncthreads();
-    fft256<false>(buf, t >> 4, t & 15, tw256);
-    const float2 *h = Ht + (size_t)(16 * rb) * 256;
+    fft256_regs<false>(v, buf, f, j, tw256);                                                   // v[k2] = X[k1 + 256 (j + 16 k2)]
 #pragma unroll
-    for (int i = 0; i < 16; i++) buf[i * F64_P + t] = cmul(buf[i * F64_P + t], h[256 * i + t]);   // X[k1 + 256 k2] * taps_fft[k1 + 256 k2], libcsdr.c:826-830
-    __syncthreads();
-    fft256<true>(buf, t >> 4, t & 15, tw256);
+    for (int k2 = 0; k2 < 16; k2++) v[k2] = cmul(v[k2], hv[k2]);                               // libcsdr.c:826-830
+    __syncthreads();                                                                           // the exchange buffer is reused
+    // the inverse transform's input index 16 n1 + n2 with n2 = j, n1 = k2: exactly what this thread holds
+    fft256_regs<true>(v, buf, f, j, tw256);
+    const int k1 = 16 * rb + f;
 #pragma unroll
-    for (int i = 0; i < 16; i++) base[256 * i + t] = cmul(buf[i * F64_P + t], twiddle_n(tw256, twlo, t * (16 * rb + i), true));
+    for (int k2 = 0; k2 < 16; k2++) { const int n2 = j + 16 * k2; row[16 * k2] = cmul(v[k2], twiddle_n(tw256, twlo, n2 * k1, true)); }
 }
 
 // K3 with the overlap-add fused (overlap <= input_size: every output position has at most two contributions): the block's own samples go
@@ -121,20 +122,20 @@ __global__ __launch_bounds__(256) void k_f64_cols_inv_oa(const float2 *__restric
 {
     F64_LDS;
     load_tables(tw256, twlo, g_tw);
-    const int t = threadIdx.x, c = t & 15, r0 = t >> 4, cb = blockIdx.x;
+    const int t = threadIdx.x, c = t & 15, j = t >> 4, cb = blockIdx.x;
     const size_t batch = blockIdx.y, s = batch / n_blocks, b = batch % n_blocks;
-    const float2 *src = U + batch * F64_N;
+    const float2 *src = U + batch * F64_N + 16 * cb + c;
+    float2 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const int k1 = r0 + 16 * i; buf[c * F64_P + k1] = src[256 * k1 + 16 * cb + c]; }
+    for (int n1 = 0; n1 < 16; n1++) v[n1] = src[256 * (16 * n1 + j)];
     __syncthreads();
-    fft256<true>(buf, t >> 4, t & 15, tw256);
+    fft256_regs<true>(v, buf, c, j, tw256);
     float2 *o = out + s * out_pitch + b * (size_t)inp;
     float2 *tl = tails + batch * (size_t)ovl;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int n1 = r0 + 16 * i, n = 256 * n1 + 16 * cb + c;
-        const float2 v = buf[c * F64_P + n1];
-        const float2 w = make_float2(v.x * inv_n, v.y * inv_n);
+    for (int k2 = 0; k2 < 16; k2++) {
+        const int n = 256 * (j + 16 * k2) + 16 * cb + c;
+        const float2 w = make_float2(v[k2].x * inv_n, v[k2].y * inv_n);
         if (n < inp) o[n] = w; else tl[n - inp] = w;
     }
 }
@@ -158,15 +159,16 @@ __global__ __launch_bounds__(256) void k_f64_cols_inv(const float2 *__restrict__
 {
     F64_LDS;
     load_tables(tw256, twlo, g_tw);
-    const int t = threadIdx.x, c = t & 15, r0 = t >> 4, cb = blockIdx.x;
-    const float2 *src = U + (size_t)blockIdx.y * F64_N;
+    const int t = threadIdx.x, c = t & 15, j = t >> 4, cb = blockIdx.x;
+    const float2 *src = U + (size_t)blockIdx.y * F64_N + 16 * cb + c;
+    float2 v[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const int k1 = r0 + 16 * i; buf[c * F64_P + k1] = src[256 * k1 + 16 * cb + c]; }
+    for (int n1 = 0; n1 < 16; n1++) v[n1] = src[256 * (16 * n1 + j)];
     __syncthreads();
-    fft256<true>(buf, t >> 4, t & 15, tw256);
-    float2 *dst = y + (size_t)blockIdx.y * F64_N;
+    fft256_regs<true>(v, buf, c, j, tw256);
+    float2 *dst = y + (size_t)blockIdx.y * F64_N + 16 * cb + c;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const int n1 = r0 + 16 * i; dst[256 * n1 + 16 * cb + c] = buf[c * F64_P + n1]; }
+    for (int k2 = 0; k2 < 16; k2++) dst[256 * (j + 16 * k2)] = v[k2];
 }
 
 // Ht[k1][k2] = H[k1 + 256 k2]
@@ -218,15 +220,24 @@ int fft64k_filter(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int 
 int fft64k_filter_oa(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int ovl, int n_blocks, int n_streams, cf32 *d_work, const cf32 *d_taps_fft_t,
                      const float2 *d_tw, cf32 *d_tails, const cf32 *d_carry_in, cf32 *d_carry_out, cf32 *out, size_t out_pitch)
 {
-    const int batch = n_blocks * n_streams;
     if (lds_attr_once((const void *)k_f64_cols_fwd, F64_LDS_BYTES) || lds_attr_once((const void *)k_f64_rows, F64_LDS_BYTES) || lds_attr_once((const void *)k_f64_cols_inv_oa, F64_LDS_BYTES)) return -1;
-    hipLaunchKernelGGL(k_f64_cols_fwd, dim3(16, n_blocks, n_streams), dim3(256), F64_LDS_BYTES, st, in, in_pitch, inp, n_blocks, reinterpret_cast<float2 *>(d_work), d_tw);
-    CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_f64_rows, dim3(16, batch), dim3(256), F64_LDS_BYTES, st, reinterpret_cast<float2 *>(d_work), reinterpret_cast<const float2 *>(d_taps_fft_t), d_tw);
-    CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_f64_cols_inv_oa, dim3(16, batch), dim3(256), F64_LDS_BYTES, st, reinterpret_cast<const float2 *>(d_work), reinterpret_cast<float2 *>(out), out_pitch,
-                       reinterpret_cast<float2 *>(d_tails), inp, ovl, n_blocks, 1.0f / (float)F64_N, d_tw);
-    CSDR_LAUNCH_CHECK();
+    // The three passes of a group of streams run back to back, one group after the other: the [256][256] intermediates of a group (0.5 MiB per
+    // transform, written by one pass and read by the next) then stay inside the 256 MiB Infinity Cache instead of making two round trips to HBM.
+    // CSDR_AMD_FFT64K_GROUP = transforms per group (default 256 = 128 MiB of intermediates: measured best, profiles/r2h; 0 = the whole call at once).
+    static const long group_env = getenv("CSDR_AMD_FFT64K_GROUP") ? atol(getenv("CSDR_AMD_FFT64K_GROUP")) : 256;
+    int sg = n_streams;
+    if (group_env > 0) { sg = (int)(group_env / n_blocks); if (sg < 1) sg = 1; if (sg > n_streams) sg = n_streams; }
+    for (int s0 = 0; s0 < n_streams; s0 += sg) {
+        const int ns = (n_streams - s0 < sg) ? n_streams - s0 : sg, batch = n_blocks * ns;
+        float2 *work = reinterpret_cast<float2 *>(d_work) + (size_t)s0 * n_blocks * F64_N;
+        hipLaunchKernelGGL(k_f64_cols_fwd, dim3(16, n_blocks, ns), dim3(256), F64_LDS_BYTES, st, in + (size_t)s0 * in_pitch, in_pitch, inp, n_blocks, work, d_tw);
+        CSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_f64_rows, dim3(16, batch), dim3(256), F64_LDS_BYTES, st, work, reinterpret_cast<const float2 *>(d_taps_fft_t), d_tw);
+        CSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_f64_cols_inv_oa, dim3(16, batch), dim3(256), F64_LDS_BYTES, st, work, reinterpret_cast<float2 *>(out) + (size_t)s0 * out_pitch, out_pitch,
+                           reinterpret_cast<float2 *>(d_tails) + (size_t)s0 * n_blocks * ovl, inp, ovl, n_blocks, 1.0f / (float)F64_N, d_tw);
+        CSDR_LAUNCH_CHECK();
+    }
     if (ovl > 0) {
         hipLaunchKernelGGL(k_f64_tail_add, dim3((ovl + 255) / 256, n_blocks, n_streams), dim3(256), 0, st, reinterpret_cast<float2 *>(out), out_pitch,
                            reinterpret_cast<const float2 *>(d_tails), reinterpret_cast<const float2 *>(d_carry_in), reinterpret_cast<float2 *>(d_carry_out), inp, ovl, n_blocks);

@@ -544,3 +544,33 @@ def test_cli_fastddc_bank(port, tmp_path):
     got0 = np.fromfile(outs[0], c64)                                                         # the other channels are untouched by the retune
     d0, _ = port.fastddc_init(tbw, D, rates[0])
     assert relrms(got0, port.fastddc_inv_cc(spectra, d0, port.fastddc_taps_fft(d0, rates[0], D))) <= TOL
+
+
+# ---------------------------------------------------------------- f4, first half: N-stream ingest into the batch API
+@pytest.mark.parametrize("cmd", ["wfm_bank_u8_s16", "nfm_bank_u8_s16"])
+def test_cli_stream_bank(port, tmp_path, cmd):
+    """nmux-style producer for the batch API (nmux.cpp:177-283 fans one source out to N single-stream pipelines; here N streams enter ONE chain object):
+    three u8 IQ files -> one process -> three audio files, each equal to the oracle's single-stream chain."""
+    from tests_helpers import wfm_signal_u8, nfm_signal_u8
+    nfm = cmd.startswith("nfm")
+    n = 3 * 65536 + 7 * 1024
+    sig = [(nfm_signal_u8(900 + k, n, offset=0.05) if nfm else wfm_signal_u8(900 + k, n)) for k in range(3)]
+    args = [cmd, "-0.05" if nfm else "-0.085"]
+    outs = []
+    for k in range(3):
+        fi = tmp_path / ("in%d.u8" % k); fo = tmp_path / ("out%d.s16" % k)
+        sig[k].tofile(fi); outs.append(fo); args += [str(fi), str(fo)]
+    env = dict(os.environ, CSDR_AMD_BANK_BLOCK="65536")
+    p = subprocess.run([CLI] + args, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    taps48 = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    for k in range(3):
+        got = np.fromfile(outs[k], np.int16)
+        if nfm:
+            want, _ = port.nfm_chain(sig[k], -0.05, taps48)
+        else:
+            want, _ = port.wfm_chain(sig[k], -0.085, 10, port.firdes_lowpass_f(79, 0.05))
+        m = min(got.size, want.size)
+        assert m > 0 and abs(got.size - want.size) <= (1024 if nfm else 2)
+        d = np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.05, "stream %d" % k
