@@ -35,9 +35,10 @@ __device__ __forceinline__ float sin_like_libm(float x) { return (float)sin((dou
 // The phase SEQUENCES (chunk start phases; per-sample phases of shift_math/table; shift_unroll's table angles) are
 // pure float32 recurrences p <- wrap(p + c): strictly sequential, data independent, a few thousand to a few
 // million steps.  One GPU lane needs ~1.8 us per step for them (measured: 4.3 ms per 2344 chunks, 38 % of the
-// round-1 WFM step), a host core ~1 ns, so they are computed on the host in the reference's float arithmetic
-// (SSE float add/compare = IEEE binary32, identical results) and uploaded through pinned staging; the device
-// does the parallel part (libm-grade sin/cos, the per-chunk phasor replay, the mixing).
+// round-1 WFM step), a host core ~1 ns, so the sequential scan runs on the host in the reference's float arithmetic
+// (SSE float add/compare = IEEE binary32, identical results); only its per-chunk / per-tile start values are
+// uploaded (pinned staging), the device replays the steps in between and does the parallel part (libm-grade
+// sin/cos, the per-chunk phasor replay, the mixing).
 static inline float h_wrap_pm_pi(float p) { while (p > PI_F) p -= 2 * PI_F; while (p < -PI_F) p += 2 * PI_F; return p; }
 static inline float h_wrap_0_2pi(float p) { while (p > 2 * PI_F) p -= 2 * PI_F; while (p < 0) p += 2 * PI_F; return p; }
 
@@ -90,23 +91,35 @@ __global__ __launch_bounds__(256) void k_fill_unroll(cf32 *__restrict__ rot, con
     rot[k] = cf32{c0 * dcos[off] - s0 * dsin[off], s0 * dcos[off] + c0 * dsin[off]};
 }
 
-// ---- shift_math_cc / shift_table_cc: float phase advanced and wrapped PER SAMPLE (libcsdr.c:202-204, 260-262);
-// the phase of every sample arrives from the host scan
-__global__ __launch_bounds__(256) void k_fill_math(cf32 *__restrict__ rot, const float *__restrict__ ph, size_t n)
+// ---- shift_math_cc / shift_table_cc: float phase advanced and wrapped PER SAMPLE (libcsdr.c:202-204, 260-262): p <- wrap(p + inc), a strictly
+// sequential float32 recurrence (no closed form: every step rounds).  The host runs it but keeps only every SHIFT_TILE-th value (one float per tile
+// over PCIe instead of one per sample); a lane replays the <= SHIFT_TILE - 1 steps from its tile's start phase to its own sample: same operations
+// in the same order = the same bits.
+constexpr int SHIFT_TILE = 64;
+__device__ __forceinline__ float phase_of_sample(const float *__restrict__ ph_tile, size_t k, float inc)
+{
+    float p = ph_tile[k / SHIFT_TILE];
+    const int steps = (int)(k % SHIFT_TILE);
+    for (int s = 0; s < steps; s++) p = wrap_0_2pi(p + inc);
+    return p;
+}
+__global__ __launch_bounds__(256) void k_fill_math(cf32 *__restrict__ rot, const float *__restrict__ ph_tile, float inc, size_t n)
 {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) rot[k] = cf32{cos_like_libm(ph[k]), sin_like_libm(ph[k])};
+    if (k >= n) return;
+    const float p = phase_of_sample(ph_tile, k, inc);
+    rot[k] = cf32{cos_like_libm(p), sin_like_libm(p)};
 }
 __global__ __launch_bounds__(256) void k_quarter_table(float *__restrict__ table, int size)
 {   // libcsdr.c:211-222
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < size) table[k] = sin_like_libm(((float)k / (float)size) * (PI_F / 2));
 }
-__global__ __launch_bounds__(256) void k_fill_table(cf32 *__restrict__ rot, const float *__restrict__ ph, const float *__restrict__ table, int size, size_t n)
+__global__ __launch_bounds__(256) void k_fill_table(cf32 *__restrict__ rot, const float *__restrict__ ph_tile, float inc, const float *__restrict__ table, int size, size_t n)
 {   // libcsdr.c:236-253: quadrant folding, truncated index
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const float q90 = PI_F / 2, p = ph[k];
+    const float q90 = PI_F / 2, p = phase_of_sample(ph_tile, k, inc);
     const int quadrant = (int)(p / q90);
     const float within = p - (float)quadrant * q90;
     int si = (int)((within / q90) * (float)size), ci = size - 1 - si;
@@ -229,19 +242,20 @@ int csdr_amd_rotator_generate(csdr_amd_ctx *c, int variant, float rate, float *p
         return 0;
     }
     if (variant == CSDR_SHIFT_MATH || variant == CSDR_SHIFT_TABLE) {
-        float *hp = (float *)c->pinned_acquire(sizeof(float) * n);
-        float *ph = (float *)c->get_scratch(0, sizeof(float) * n);
+        const size_t n_tiles = (n + SHIFT_TILE - 1) / SHIFT_TILE;
+        float *hp = (float *)c->pinned_acquire(sizeof(float) * n_tiles);
+        float *ph = (float *)c->get_scratch(0, sizeof(float) * n_tiles);
         if (!hp || !ph) return -2;
-        for (size_t k = 0; k < n; k++) { hp[k] = p; p = h_wrap_0_2pi(p + inc); }        // libcsdr.c:202-204
-        int rc = c->pinned_upload(ph, sizeof(float) * n); if (rc) return rc;
+        for (size_t k = 0; k < n; k++) { if (k % SHIFT_TILE == 0) hp[k / SHIFT_TILE] = p; p = h_wrap_0_2pi(p + inc); }        // libcsdr.c:202-204
+        int rc = c->pinned_upload(ph, sizeof(float) * n_tiles); if (rc) return rc;
         if (variant == CSDR_SHIFT_MATH) {
-            hipLaunchKernelGGL(k_fill_math, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, n); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_fill_math, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, inc, n); CSDR_LAUNCH_CHECK();
         } else {
             const int size = aux > 0 ? aux : 65536;     // csdr.c:731
             float *table = (float *)c->get_scratch(1, sizeof(float) * (size_t)size);
             if (!table) return -2;
             hipLaunchKernelGGL(k_quarter_table, dim3(cdiv(size, 256)), dim3(256), 0, st, table, size); CSDR_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_fill_table, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, table, size, n); CSDR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_fill_table, dim3(cdiv(n, 256)), dim3(256), 0, st, rot, ph, inc, table, size, n); CSDR_LAUNCH_CHECK();
         }
         *phase_io = p;
         return 0;

@@ -65,6 +65,9 @@ xin = xf[:2 * S * n]; yout = yf[:2 * S * n]
 ph = C.c_float(0.0)
 report("shift_addition_cc (64 streams x 2M, gen+mix)", timeit(lambda: L.csdr_amd_shift_cc(ctx.h, 0, -0.085, C.byref(ph), xin.data_ptr(), yout.data_ptr(), S, n, n, n, 1024, 0)),
        16 * S * n, S * n)
+for vname, variant, aux in (("shift_math_cc", 1, 0), ("shift_table_cc", 2, 65536), ("shift_unroll_cc", 3, 1024), ("shift_addfast_cc", 4, 0)):
+    report("%s (64 streams x 2M, gen+mix; the host's sequential float phase scan is inside the timed region)" % vname,
+           timeit(lambda: L.csdr_amd_shift_cc(ctx.h, variant, -0.085, C.byref(ph), xin.data_ptr(), yout.data_ptr(), S, n, n, n, 1024, aux), reps=5, warm=1), 16 * S * n, S * n)
 rot = torch.empty(2 * n + 16, dtype=torch.float32, device="cuda")
 L.csdr_amd_rotator_generate(ctx.h, 0, -0.085, C.byref(ph), rot.data_ptr(), n, 1024, 0)
 report("mix_cc only (64 streams x 2M)", timeit(lambda: L.csdr_amd_mix_cc(ctx.h, xin.data_ptr(), yout.data_ptr(), rot.data_ptr(), S, n, n, n)), 16 * S * n, S * n)
