@@ -13,6 +13,7 @@
 // Algorithmic traffic: 8 B in + 8/D B out per input sample => HBM bound on paper (3.6 flop/B).
 // k_fir_generic: natural-layout fallback for shapes whose polyphase tile does not fit in LDS.
 #include "common.hpp"
+#include <stdlib.h>
 using namespace csdr_amd;
 
 // Buffer loads with the hardware range check (out-of-window lanes read 0).  Declared as the LLVM intrinsics directly: hipcc 7.2's
@@ -237,6 +238,58 @@ static void launch_poly(csdr_amd_ctx *c, const PolyCfg &g, const T *in, T *out, 
 #undef POLY
 }
 
+// ------------------------------------------------------------------ long filters on complexf: the FIR as a banded product on the fp32 matrix cores
+// fir_decimate_cc 50 / 801 taps (the head of the NFM / AM / SSB chains when they start from complexf, README.md:87, 95, 110) reads 16 inputs per
+// output tap: k_fir_generic is LDS-read bound at 18 % of the HBM roofline (one 8-byte ds_read per two FMAs).  On v_mfma_f32_16x16x4_f32
+// (exact fp32 FMA chains, MI355X_MICROARCH.md) the same window costs two 4-byte ds_reads per 2048 flops:
+//   C[i][n] = sum_k A[i][k] B[k][n],   i = output within a group of 16,   n = (group g of NT consecutive groups, re / im),
+//   A[i][k] = h[k - D i]  (Toeplitz band of the taps, zero outside [0, L): read from a zero-padded copy in LDS; the band is 52 % dense at D = 50 / L = 801),
+//   B[k][n] = x[16 D g + k].part   (the staged input window, natural interleaved order).
+// One workgroup = (stream, 16 NT consecutive outputs): its (16 NT - 1) D + L input samples are staged ONCE (8 in + 8 / D out bytes per sample of HBM
+// traffic: every input is fetched by exactly one tile plus the L - 1 overlap); the K range (15 D + L) is split over the four waves, the partial tiles are
+// reduced through LDS.  Summation order differs from the reference's t = 0 .. L-1: fp32 rounding noise, parity gate 1e-5.
+typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_size, size_t in_pitch, size_t out_pitch,
+                                                  int D, const float *__restrict__ taps, int L)
+{
+    extern __shared__ float4 lds_raw[];
+    const int TO = 16 * NT, o0 = blockIdx.x * TO, W = (TO - 1) * D + L, PAD = 15 * D, KT = 15 * D + L, steps = (KT + 3) / 4;
+    float *xw = reinterpret_cast<float *>(lds_raw);                 // 2 (W + 8) floats: the window, interleaved, zero tail
+    float *hz = xw + 2 * (W + 8);                                     // PAD + 4 steps + 4 floats: the taps with PAD zeros in front
+    float *red = hz + PAD + 4 * steps + 4;                            // 4 x 256 partial results
+    const size_t s = blockIdx.y;
+    const int t = threadIdx.x;
+    const float2 *src = in + s * in_pitch + (size_t)o0 * D;
+    const int avail = input_size - o0 * D;                            // samples of this stream from the window's start on
+    for (int k = t; k < W + 8; k += 256) {
+        const float2 v = (k < W && k < avail) ? src[k] : make_float2(0.f, 0.f);
+        xw[2 * k] = v.x; xw[2 * k + 1] = v.y;
+    }
+    for (int k = t; k < PAD + 4 * steps + 4; k += 256) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63, i = lane & 15, kk = lane >> 4;
+    const int s_lo = wave * steps / 4, s_hi = (wave + 1) * steps / 4;
+    const int n = lane & 15, g = n >> 1, part = n & 1;
+    const float *ap = hz + PAD + kk - D * i;                          // + 4 step
+    // columns of groups g >= NT (NT < 8) are unused: they read group 0's window and are multiplied by zero (no divergence around the MFMAs)
+    const float bm = g < NT ? 1.f : 0.f;
+    const float *bp = xw + 2 * (16 * D * (g < NT ? g : 0) + kk) + part;   // + 8 step
+    f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int st = s_lo; st < s_hi; st++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? bp[8 * st] : bp[8 * st] * bm, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+    __syncthreads();
+    {   // C layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (i)
+        const int r = t >> 6, ln = t & 63;
+        const float v = red[t] + red[256 + t] + red[512 + t] + red[768 + t];
+        const int nn = ln & 15, gg = nn >> 1, pp = nn & 1, ii = 4 * (ln >> 4) + r;
+        const int o = o0 + 16 * gg + ii;
+        if (gg < NT && o < n_out) reinterpret_cast<float *>(out + s * out_pitch + o)[pp] = v;
+    }
+}
+
 } // namespace
 
 static int pick_tile(int D, int ntaps, int floats_per_sample, int n_out)
@@ -261,6 +314,21 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
         launch_poly<float2>(c, g, (const float2 *)in, (float2 *)out, n_out, n_streams, in_pitch, out_pitch, decimation, taps, taps_length);
         CSDR_LAUNCH_CHECK();
         return n_out;
+    }
+    if (!getenv("CSDR_AMD_FIR_MFMA_OFF")) {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
+        for (int nt = 8; nt >= 1; nt >>= 1) {
+            const int W = (16 * nt - 1) * decimation + taps_length, steps = (15 * decimation + taps_length + 3) / 4;
+            const size_t lds = sizeof(float) * (2 * (size_t)(W + 8) + 15 * (size_t)decimation + 4 * (size_t)steps + 4 + 1024);
+            if (lds > 76 * 1024) continue;                           // two workgroups per CU
+            const dim3 grid(cdiv(n_out, 16 * nt), (unsigned)n_streams);
+#define FIR_MFMA(NTV) do { if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_fir_mfma<NTV>, lds); if (arc) return arc; }                       \
+            hipLaunchKernelGGL((k_fir_mfma<NTV>), grid, dim3(256), lds, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,     \
+                               decimation, taps, taps_length); } while (0)
+            if (nt == 8) FIR_MFMA(8); else if (nt == 4) FIR_MFMA(4); else if (nt == 2) FIR_MFMA(2); else FIR_MFMA(1);
+#undef FIR_MFMA
+            CSDR_LAUNCH_CHECK();
+            return n_out;
+        }
     }
     const int to = pick_tile(decimation, taps_length, 2, n_out);
     const size_t win_bytes = ((size_t)(to - 1) * decimation + taps_length) * 8;
