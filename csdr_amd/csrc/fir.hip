@@ -256,15 +256,23 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
     extern __shared__ float4 lds_raw[];
     const int TO = 16 * NT, o0 = blockIdx.x * TO, W = (TO - 1) * D + L, PAD = 15 * D, KT = 15 * D + L, steps = (KT + 3) / 4;
     float *xw = reinterpret_cast<float *>(lds_raw);                 // 2 (W + 8) floats: the window, interleaved, zero tail
-    float *hz = xw + 2 * (W + 8);                                     // PAD + 4 steps + 4 floats: the taps with PAD zeros in front
+    float *hz = xw + ((2 * (W + 8) + 31) & ~31);                      // PAD + 4 steps + 4 floats: the taps with PAD zeros in front (the swizzle stays inside 32-float rows)
     float *red = hz + PAD + 4 * steps + 4;                            // 4 x 256 partial results
     const size_t s = blockIdx.y;
     const int t = threadIdx.x;
     const float2 *src = in + s * in_pitch + (size_t)o0 * D;
     const int avail = input_size - o0 * D;                            // samples of this stream from the window's start on
-    for (int k = t; k < W + 8; k += 256) {
-        const float2 v = (k < W && k < avail) ? src[k] : make_float2(0.f, 0.f);
-        xw[2 * k] = v.x; xw[2 * k + 1] = v.y;
+    // staging, eight loads in flight per thread.  The window's floats are XOR-swizzled (float address a lives at a ^ ((a >> 5) & 31)): the B operands of
+    // the 8 groups sit 16 D samples = a multiple of 32 floats apart, i.e. in ONE bank without it (8-way conflicts on every read)
+    for (int k0 = 0; k0 < W + 8; k0 += 8 * 256) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int k = k0 + 256 * u + t; v[u] = (k < W && k < avail) ? src[k] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + 256 * u + t;
+            if (k < W + 8) { const int a = 2 * k; *reinterpret_cast<float2 *>(xw + (a ^ ((a >> 5) & 30))) = v[u]; }      // even mask: the (re, im) pair stays together
+        }
     }
     for (int k = t; k < PAD + 4 * steps + 4; k += 256) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
     __syncthreads();
@@ -274,10 +282,14 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
     const float *ap = hz + PAD + kk - D * i;                          // + 4 step
     // columns of groups g >= NT (NT < 8) are unused: they read group 0's window and are multiplied by zero (no divergence around the MFMAs)
     const float bm = g < NT ? 1.f : 0.f;
-    const float *bp = xw + 2 * (16 * D * (g < NT ? g : 0) + kk) + part;   // + 8 step
+    const int b0 = 2 * (16 * D * (g < NT ? g : 0) + kk) + part;       // + 8 step, then the swizzle
     f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int st = s_lo; st < s_hi; st++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? bp[8 * st] : bp[8 * st] * bm, acc, 0, 0, 0);
+    for (int st = s_lo; st < s_hi; st++) {
+        const int a = b0 + 8 * st;
+        const float b = xw[a ^ ((a >> 5) & 30)];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? b : b * bm, acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
     __syncthreads();
@@ -318,7 +330,7 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     if (!getenv("CSDR_AMD_FIR_MFMA_OFF")) {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
         for (int nt = 8; nt >= 1; nt >>= 1) {
             const int W = (16 * nt - 1) * decimation + taps_length, steps = (15 * decimation + taps_length + 3) / 4;
-            const size_t lds = sizeof(float) * (2 * (size_t)(W + 8) + 15 * (size_t)decimation + 4 * (size_t)steps + 4 + 1024);
+            const size_t lds = sizeof(float) * (2 * (size_t)(W + 8) + 32 + 15 * (size_t)decimation + 4 * (size_t)steps + 4 + 1024);
             if (lds > 76 * 1024) continue;                           // two workgroups per CU
             const dim3 grid(cdiv(n_out, 16 * nt), (unsigned)n_streams);
 #define FIR_MFMA(NTV) do { if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_fir_mfma<NTV>, lds); if (arc) return arc; }                       \
