@@ -249,33 +249,30 @@ static void launch_poly(csdr_amd_ctx *c, const PolyCfg &g, const T *in, T *out, 
 // traffic: every input is fetched by exactly one tile plus the L - 1 overlap); the K range (15 D + L) is split over the four waves, the partial tiles are
 // reduced through LDS.  Summation order differs from the reference's t = 0 .. L-1: fp32 rounding noise, parity gate 1e-5.
 typedef float f32x4_mfma __attribute__((ext_vector_type(4)));
-template <int NT>
+// A workgroup walks `tiles_per_wg` consecutive tiles of its stream: the NEXT tile's window is fetched into registers (NS x 256 float2 per workgroup) while
+// the matrix cores work on the current one, so the global-memory latency of a tile is hidden behind the previous tile's arithmetic.
+template <int NT, int NS>
 __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_size, size_t in_pitch, size_t out_pitch,
-                                                  int D, const float *__restrict__ taps, int L)
+                                                  int D, const float *__restrict__ taps, int L, int tiles_per_wg)
 {
     extern __shared__ float4 lds_raw[];
-    const int TO = 16 * NT, o0 = blockIdx.x * TO, W = (TO - 1) * D + L, PAD = 15 * D, KT = 15 * D + L, steps = (KT + 3) / 4;
-    float *xw = reinterpret_cast<float *>(lds_raw);                 // 2 (W + 8) floats: the window, interleaved, zero tail
-    float *hz = xw + ((2 * (W + 8) + 31) & ~31);                      // PAD + 4 steps + 4 floats: the taps with PAD zeros in front (the swizzle stays inside 32-float rows)
+    const int TO = 16 * NT, W = (TO - 1) * D + L, PAD = 15 * D, KT = 15 * D + L, steps = (KT + 3) / 4;
+    float *xw = reinterpret_cast<float *>(lds_raw);                 // 2 (W + 8) floats: the window, interleaved, zero tail, XOR-swizzled (below)
+    float *hz = xw + ((2 * (W + 8) + 31) & ~31);                      // PAD + 4 steps + 4 floats: the taps with PAD zeros in front
     float *red = hz + PAD + 4 * steps + 4;                            // 4 x 256 partial results
     const size_t s = blockIdx.y;
     const int t = threadIdx.x;
-    const float2 *src = in + s * in_pitch + (size_t)o0 * D;
-    const int avail = input_size - o0 * D;                            // samples of this stream from the window's start on
-    // staging, eight loads in flight per thread.  The window's floats are XOR-swizzled (float address a lives at a ^ ((a >> 5) & 31)): the B operands of
-    // the 8 groups sit 16 D samples = a multiple of 32 floats apart, i.e. in ONE bank without it (8-way conflicts on every read)
-    for (int k0 = 0; k0 < W + 8; k0 += 8 * 256) {
-        float2 v[8];
+    const int n_tiles = (n_out + TO - 1) / TO, tile0 = blockIdx.x * tiles_per_wg, tile1 = min(tile0 + tiles_per_wg, n_tiles);
+    if (tile0 >= n_tiles) return;
+    const float2 *base = in + s * in_pitch;
+    float2 v[NS];
+    auto fetch = [&](int tile) {
+        const int first = tile * TO * D;
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int k = k0 + 256 * u + t; v[u] = (k < W && k < avail) ? src[k] : make_float2(0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int k = k0 + 256 * u + t;
-            if (k < W + 8) { const int a = 2 * k; *reinterpret_cast<float2 *>(xw + (a ^ ((a >> 5) & 30))) = v[u]; }      // even mask: the (re, im) pair stays together
-        }
-    }
+        for (int u = 0; u < NS; u++) { const int k = 256 * u + t; v[u] = (k < W && first + k < input_size) ? base[(size_t)first + k] : make_float2(0.f, 0.f); }
+    };
+    fetch(tile0);
     for (int k = t; k < PAD + 4 * steps + 4; k += 256) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
-    __syncthreads();
     const int wave = t >> 6, lane = t & 63, i = lane & 15, kk = lane >> 4;
     const int s_lo = wave * steps / 4, s_hi = (wave + 1) * steps / 4;
     const int n = lane & 15, g = n >> 1, part = n & 1;
@@ -283,22 +280,35 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
     // columns of groups g >= NT (NT < 8) are unused: they read group 0's window and are multiplied by zero (no divergence around the MFMAs)
     const float bm = g < NT ? 1.f : 0.f;
     const int b0 = 2 * (16 * D * (g < NT ? g : 0) + kk) + part;       // + 8 step, then the swizzle
-    f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int st = s_lo; st < s_hi; st++) {
-        const int a = b0 + 8 * st;
-        const float b = xw[a ^ ((a >> 5) & 30)];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? b : b * bm, acc, 0, 0, 0);
-    }
+    for (int tile = tile0; tile < tile1; tile++) {
+        // The window's floats are XOR-swizzled (float address a lives at a ^ ((a >> 5) & 30)): the B operands of the 8 groups sit 16 D samples = a
+        // multiple of 32 floats apart, i.e. in ONE bank without it (8-way conflicts on every read); the even mask keeps a (re, im) pair together
 #pragma unroll
-    for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
-    __syncthreads();
-    {   // C layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (i)
-        const int r = t >> 6, ln = t & 63;
-        const float v = red[t] + red[256 + t] + red[512 + t] + red[768 + t];
-        const int nn = ln & 15, gg = nn >> 1, pp = nn & 1, ii = 4 * (ln >> 4) + r;
-        const int o = o0 + 16 * gg + ii;
-        if (gg < NT && o < n_out) reinterpret_cast<float *>(out + s * out_pitch + o)[pp] = v;
+        for (int u = 0; u < NS; u++) {
+            const int k = 256 * u + t;
+            if (k < W + 8) { const int a = 2 * k; *reinterpret_cast<float2 *>(xw + (a ^ ((a >> 5) & 30))) = v[u]; }
+        }
+        __syncthreads();
+        if (tile + 1 < tile1) fetch(tile + 1);                        // in flight during the product
+        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int st = s_lo; st < s_hi; st++) {
+            const int a = b0 + 8 * st;
+            const float b = xw[a ^ ((a >> 5) & 30)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? b : b * bm, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+        __syncthreads();
+        {   // C layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (i)
+            const int r = t >> 6, ln = t & 63;
+            const float sum = red[t] + red[256 + t] + red[512 + t] + red[768 + t];
+            const int nn = ln & 15, gg = nn >> 1, pp = nn & 1, ii = 4 * (ln >> 4) + r;
+            const int o = tile * TO + 16 * gg + ii;
+            if (gg < NT && o < n_out) reinterpret_cast<float *>(out + s * out_pitch + o)[pp] = sum;
+        }
+        // the next tile overwrites xw / red: everyone has read them (the reads above precede this barrier in program order of every wave)
+        __syncthreads();
     }
 }
 
@@ -332,11 +342,16 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
             const int W = (16 * nt - 1) * decimation + taps_length, steps = (15 * decimation + taps_length + 3) / 4;
             const size_t lds = sizeof(float) * (2 * (size_t)(W + 8) + 32 + 15 * (size_t)decimation + 4 * (size_t)steps + 4 + 1024);
             if (lds > 76 * 1024) continue;                           // two workgroups per CU
-            const dim3 grid(cdiv(n_out, 16 * nt), (unsigned)n_streams);
-#define FIR_MFMA(NTV) do { if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_fir_mfma<NTV>, lds); if (arc) return arc; }                       \
-            hipLaunchKernelGGL((k_fir_mfma<NTV>), grid, dim3(256), lds, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,     \
-                               decimation, taps, taps_length); } while (0)
-            if (nt == 8) FIR_MFMA(8); else if (nt == 4) FIR_MFMA(4); else if (nt == 2) FIR_MFMA(2); else FIR_MFMA(1);
+            const int n_tiles = cdiv(n_out, 16 * nt), ns = cdiv(W + 8, 256);
+            if (ns > 32) continue;                                   // register staging: at most 32 float2 per thread
+            int tpw = (int)(((long)n_tiles * n_streams + 4095) / 4096); if (tpw < 1) tpw = 1; if (tpw > 16) tpw = 16;      // ~4096 workgroups, each a run of consecutive tiles
+            const dim3 grid(cdiv(n_tiles, tpw), (unsigned)n_streams);
+#define FIR_MFMA(NTV, NSV) do { if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_fir_mfma<NTV, NSV>, lds); if (arc) return arc; }                 \
+            hipLaunchKernelGGL((k_fir_mfma<NTV, NSV>), grid, dim3(256), lds, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,   \
+                               decimation, taps, taps_length, tpw); } while (0)
+#define FIR_MFMA_NS(NTV) do { if (ns <= 8) FIR_MFMA(NTV, 8); else if (ns <= 16) FIR_MFMA(NTV, 16); else FIR_MFMA(NTV, 32); } while (0)
+            if (nt == 8) FIR_MFMA_NS(8); else if (nt == 4) FIR_MFMA_NS(4); else if (nt == 2) FIR_MFMA_NS(2); else FIR_MFMA_NS(1);
+#undef FIR_MFMA_NS
 #undef FIR_MFMA
             CSDR_LAUNCH_CHECK();
             return n_out;
