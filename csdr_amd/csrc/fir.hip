@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
     };
     fetch(tile0);
     for (int k = t; k < PAD + 4 * steps + 4; k += 256) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
-    const int wave = t >> 6, lane = t & 63, i = lane & 15, kk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;      // wave-uniform: the K loop below is a scalar loop
     const int s_lo = wave * steps / 4, s_hi = (wave + 1) * steps / 4;
     const int n = lane & 15, g = n >> 1, part = n & 1;
     const float *ap = hz + PAD + kk - D * i;                          // + 4 step
@@ -291,8 +291,15 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
         __syncthreads();
         if (tile + 1 < tile1) fetch(tile + 1);                        // in flight during the product
         f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int st = s_lo; st < s_hi; st++) {
+        int st = s_lo;
+        for (; st + 8 <= s_hi; st += 8) {                             // 16 LDS reads in flight, then 8 dependent MFMAs (one accumulator: 16x16x4 chains at 32-cycle issue)
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int a = b0 + 8 * (st + u); av[u] = ap[4 * (st + u)]; bv[u] = xw[a ^ ((a >> 5) & 30)]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], NT == 8 ? bv[u] : bv[u] * bm, acc, 0, 0, 0);
+        }
+        for (; st < s_hi; st++) {
             const int a = b0 + 8 * st;
             const float b = xw[a ^ ((a >> 5) & 30)];
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? b : b * bm, acc, 0, 0, 0);
