@@ -290,14 +290,17 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
         }
         __syncthreads();
         if (tile + 1 < tile1) fetch(tile + 1);                        // in flight during the product
-        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         int st = s_lo;
-        for (; st + 8 <= s_hi; st += 8) {                             // 16 LDS reads in flight, then 8 dependent MFMAs (one accumulator: 16x16x4 chains at 32-cycle issue)
-            float av[8], bv[8];
+        for (; st + 8 <= s_hi; st += 8) {                             // 16 LDS reads in flight, then 8 MFMAs on two alternating accumulators (a dependent
+            float av[8], bv[8];                                       // 16x16x4 chain issues every 40 cycles, independent ones every 32)
 #pragma unroll
             for (int u = 0; u < 8; u++) { const int a = b0 + 8 * (st + u); av[u] = ap[4 * (st + u)]; bv[u] = xw[a ^ ((a >> 5) & 30)]; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], NT == 8 ? bv[u] : bv[u] * bm, acc, 0, 0, 0);
+            for (int u = 0; u < 8; u += 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], NT == 8 ? bv[u] : bv[u] * bm, acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], NT == 8 ? bv[u + 1] : bv[u + 1] * bm, acc1, 0, 0, 0);
+            }
         }
         for (; st < s_hi; st++) {
             const int a = b0 + 8 * st;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], NT == 8 ? b : b * bm, acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r];
+        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r] + acc1[r];
         __syncthreads();
         {   // C layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (i)
             const int r = t >> 6, ln = t & 63;
