@@ -195,7 +195,7 @@ def main():
         if k_avg_ms > 0:
             tf = flops / (k_avg_ms * 1e-3) / 1e12
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(tf, 2), "peak": bc.FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / bc.FP32_PEAK_TFLOPS, 4),
-                               "traffic": None, "traffic_source": None, "algorithmic_flops_per_launch": flops, "kernel_avg_ms": round(k_avg_ms, 4),
+                               "traffic": None, "traffic_source": None, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": hbm_min, "kernel_avg_ms": round(k_avg_ms, 4),
                                "kernel_launches_timed": kl.value,
                                "hbm_bound_alternative": {"algorithmic_bytes_per_launch": hbm_min, "achieved_GBps": round(hbm_min / (k_avg_ms * 1e-3) / 1e9, 1),
                                                          "frac_of_8TBps": round(hbm_min / (k_avg_ms * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4),
