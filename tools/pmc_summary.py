@@ -15,7 +15,7 @@ for name, ctr in [("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")]:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(os.path.join(run, name, f))):
         if r["Counter_Name"] == ctr:
-            nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+            nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("csdr_amd::", "")
             nm = nm.split("(")[0].strip() if not nm.startswith("(") else nm
             agg[nm].append(float(r["Counter_Value"]))
     for k, v in agg.items():
