@@ -89,7 +89,7 @@ def main():
                "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[0]: fir_decimate_cc (decim=%d, %g HAMMING, %d taps) on synthetic complexf, batched" % (D, args.tbw, nt),
-                          "streams_per_gpu": S, "block_samples_per_stream": T, "stream_rate_sps": 2400000, "parallelism": "streams sharded, no data-path collective"},
+                          "streams_per_gpu": S, "block_samples_per_stream": T, "decimation": D, "taps": nt, "stream_rate_sps": 2400000, "parallelism": "streams sharded, no data-path collective"},
                "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(algo / (k_ms * 1e-3) / 1e9, 1), "peak": bc.HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(algo / (k_ms * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                             "algorithmic_bytes_per_launch": algo, "kernel_avg_ms": round(k_ms, 4), "kernel_launches_timed": args.steps},
