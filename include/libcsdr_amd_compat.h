@@ -9,6 +9,8 @@
  * the device batch API (include/csdr_amd.h) and copies the result back before returning, i.e. it appears
  * synchronous like the reference.  Per-call PCIe + launch latency makes this the compatibility path, not the
  * fast path; throughput work goes through the batch API / the csdr CLI shim.
+ * Threads: like the reference's functions these keep no hidden state and may be called from several host threads at once; the library keeps one
+ * device context (stream + staging) per calling thread, released when that thread exits.
  * There is NO CPU fallback: without a gfx950 device the first call prints the reason and aborts.
  */
 #ifndef LIBCSDR_AMD_COMPAT_H
