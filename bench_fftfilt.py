@@ -6,7 +6,12 @@ One step = one csdr_amd_fftfilt_process call: `--streams` independent complexf s
 samples, inputs resident in HBM, overlap carried inside the object.  Algorithmic bytes = 16 B per input sample (8 in + 8 out; taps_fft is
 cache resident).  The headline `value` is at `--taps` (default 1023); `sweep` holds the other tap counts.
 
-    python bench_fftfilt.py [--gpus N] [--steps K] [--warmup W] [--streams 64] [--blocks 16] [--taps 1023] [--no-sweep] [--verify]
+The interface keeps the reference's framing (blocks of 65537 - taps samples, state carried); behind it the library serves filters of <= 4096 taps with
+ONE pass over HBM (fftfilt_lds.hip: the same linear convolution by overlap-save with 4096 / 8192 / 16384-point transforms that fit a CU's LDS -- a 65536-point
+transform cannot, and needs three passes).  The line says which path ran (`config.method`, `roofline.kernel`); `full_size_transform` is the same step
+through the 65536-point three-pass path (`--method full` makes that one the headline).
+
+    python bench_fftfilt.py [--gpus N] [--steps K] [--warmup W] [--streams 64] [--blocks 16] [--taps 1023] [--method auto|full] [--no-sweep] [--verify]
 """
 import argparse
 import ctypes as C
@@ -31,6 +36,7 @@ def main():
     ap.add_argument("--streams", type=int, default=64)
     ap.add_argument("--blocks", type=int, default=16)
     ap.add_argument("--taps", type=int, default=1023)
+    ap.add_argument("--method", choices=["auto", "full"], default="auto")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true")
@@ -58,12 +64,17 @@ def main():
     pitch = nb * FFT
     torch.cuda.synchronize()
 
-    def run(ntaps, steps, warmup, verify=False):
+    def run(ntaps, steps, warmup, verify=False, method="auto"):
         taps = ctx.firdes_bandpass_c(ntaps, -0.1, 0.2)
+        if method == "full":
+            os.environ["CSDR_AMD_FFTFILT_LDS_OFF"] = "1"                # read by csdr_amd_fftfilt_create
         f = L.csdr_amd_fftfilt_create(ctx.h, FFT, taps.ctypes.data_as(C.c_void_p), ntaps, S, nb)
+        os.environ.pop("CSDR_AMD_FFTFILT_LDS_OFF", None)
         if not f:
             raise SystemExit("fftfilt_create: " + ctx.err())
         inp = L.csdr_amd_fftfilt_input_size(f)
+        kname = L.csdr_amd_fftfilt_kernel_name(f).decode() or "k_f64_cols_fwd + k_f64_rows + k_f64_cols_inv_oa (whole call; split in profiles/)"
+        window = L.csdr_amd_fftfilt_window(f)
 
         def step():
             rc = L.csdr_amd_fftfilt_process(f, x.data_ptr(), y.data_ptr(), nb, pitch, pitch)
@@ -101,18 +112,27 @@ def main():
                 worst = max(worst, vc.relrms(got[:want.size], want))
             ver = {"rows": rows, "blocks": nb, "max_rel_rms": worst, "tolerance": 1e-5, "ok": bool(worst < 1e-5)}
         L.csdr_amd_fftfilt_destroy(f)
-        return inp, wall, ev_ms, ver
+        return inp, wall, ev_ms, ver, kname, window
 
-    inp, wall, ev_ms, ver = run(args.taps, args.steps, args.warmup, args.verify)
+    inp, wall, ev_ms, ver, kname, window = run(args.taps, args.steps, args.warmup, args.verify, args.method)
     sweep = []
+    other = None
+    k4 = max(args.steps // 4, 5)
     if not args.no_sweep:
         for nt in SWEEP:
             if nt == args.taps:
                 continue
-            i2, w2, e2, _ = run(nt, max(args.steps // 4, 5), 2)
+            i2, w2, e2, _, kn2, win2 = run(nt, k4, 2, method=args.method)
             if rank == 0:
-                sweep.append({"taps": nt, "input_size": i2, "value": round(S * nb * i2 * max(args.steps // 4, 5) * world / w2 / 1e6, 1),
-                              "frac": round(16.0 * S * nb * i2 / (e2 / max(args.steps // 4, 5) * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4)})
+                sweep.append({"taps": nt, "input_size": i2, "window": win2 or FFT, "value": round(S * nb * i2 * k4 * world / w2 / 1e6, 1),
+                              "frac": round(16.0 * S * nb * i2 / (e2 / k4 * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4)})
+        if args.method == "auto" and window:
+            i2, w2, e2, v2, kn2, _ = run(args.taps, k4, 2, args.verify, "full")
+            if rank == 0:
+                other = {"kernel": kn2, "value": round(S * nb * i2 * k4 * world / w2 / 1e6, 1), "ms_per_step": round(w2 / k4 * 1e3, 4),
+                         "frac": round(16.0 * S * nb * i2 / (e2 / k4 * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4)}
+                if v2 is not None:
+                    other["verify"] = v2
     if rank == 0:
         samples = S * nb * inp * args.steps * world
         algo = 16.0 * S * nb * inp
@@ -121,13 +141,17 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[2]: bandpass_fir_fft_cc overlap-add, fft 65536, taps %d (firdes_bandpass_c -0.1 0.2 HAMMING)" % args.taps,
-                          "streams_per_gpu": S, "blocks_per_step": nb, "input_size": inp, "taps": args.taps, "parallelism": "streams sharded, no data-path collective"},
-               "roofline": {"bound": "hbm", "kernel": "k_f64_cols_fwd + k_f64_rows + k_f64_cols_inv_oa (whole call; split in profiles/)",
+                          "streams_per_gpu": S, "blocks_per_step": nb, "input_size": inp, "taps": args.taps,
+                          "method": ("one pass: overlap-save windows of %d points in LDS behind the 65536-point framing" % window) if window else "65536-point transform, three passes",
+                          "parallelism": "streams sharded, no data-path collective"},
+               "roofline": {"bound": "hbm", "kernel": kname,
                             "achieved": round(algo / (k_ms * 1e-3) / 1e9, 1), "peak": bc.HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(algo / (k_ms * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                             "algorithmic_bytes_per_launch": algo, "kernel_avg_ms": round(k_ms, 4), "kernel_launches_timed": args.steps},
                "sweep": sweep}
-        tr = bc.pmc_traffic("k_f64", {"streams_per_gpu": S, "blocks_per_step": nb, "taps": args.taps})
+        if other is not None:
+            res["full_size_transform"] = other
+        tr = bc.pmc_traffic("k_fftfilt_lds" if window else "k_f64", {"streams_per_gpu": S, "blocks_per_step": nb, "taps": args.taps})
         if tr:
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = tr
         if ver is not None:

@@ -128,6 +128,8 @@ def lib():
     L.csdr_amd_fftfilt_destroy.argtypes = [vp]
     L.csdr_amd_fftfilt_input_size.argtypes = [vp]
     L.csdr_amd_fftfilt_reset.argtypes = [vp]
+    L.csdr_amd_fftfilt_kernel_name.restype = C.c_char_p; L.csdr_amd_fftfilt_kernel_name.argtypes = [vp]
+    L.csdr_amd_fftfilt_window.argtypes = [vp]
     L.csdr_amd_fftfilt_process.argtypes = [vp, vp, vp, i, sz, sz]
     L.csdr_amd_fft_c2c.argtypes = [vp, vp, vp, i, i]
     L.csdr_amd_fastddc_init.argtypes = [vp, fl, i, fl]

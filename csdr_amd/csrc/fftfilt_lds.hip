@@ -1,0 +1,401 @@
+// fftfilt_lds.hip -- bandpass_fir_fft_cc (csdr.c:1810-1886 = apply_fir_fft_cc, libcsdr.c:814-849, per block) as ONE pass over HBM.
+//
+// What the reference computes per stream is the linear convolution of the input with the taps: every block of input_size = fft_size - taps + 1 samples is
+// zero padded, transformed, multiplied by the taps' spectrum, transformed back, and the last taps - 1 results are added onto the start of the next
+// block (overlap ADD).  The block size is bookkeeping: any partition of the stream yields the same samples up to float rounding.  A 65536-point transform
+// (BASELINE config 3) does not fit a CU (512 KiB), so fft64k.hip needs three passes over HBM (3 x 16 B per sample).  The taps, however, are short
+// (63 ... 4095): here the stream is cut into windows of N = 4096 / 8192 / 16384 samples that DO fit the 160 KiB of LDS, each window overlapping its
+// predecessor by taps - 1 samples (overlap SAVE: no dependency between windows, hence between workgroups), and one workgroup does
+//     load window -> N-point transform -> x taps spectrum (N-point, 1/N folded in) -> inverse transform -> store the N - (taps - 1) valid samples
+// with every intermediate in registers / LDS: 8 B read + 8 B written per sample, the algorithmic minimum.  The caller still sees the reference's framing
+// (n_blocks x input_size samples in, the same count out, state carried between calls): the state is the last taps - 1 INPUT samples per stream instead of the
+// reference's last taps - 1 partial OUTPUT sums -- the same information.
+//
+// Transform: in-place decimation-in-frequency stages (natural order in, digit-reversed out), the taps spectrum stored in that digit-reversed order, then the
+// mirrored decimation-in-time stages (digit-reversed in, natural out): no reordering pass.  N / 16 threads, 16 points each; first and last stage (radix 16,
+// stride N / 16) work on the registers the global loads / stores use; the last forward stage, the bin product and the first inverse stage share registers.
+// Plans: 4096 = 16.16.16, 8192 = 16.8.8.8, 16384 = 16.16.8.8.  Every stage function is __host__ __device__: tests/test_abi_cpu.py runs the very same index algebra
+// on the CPU (csdr_amd_debug_fftfilt_lds), thread by thread, phase by phase.
+#include "common.hpp"
+#include "fft_butterflies.hpp"
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+
+using namespace csdr_amd;
+
+#define FFL_HD __host__ __device__ __forceinline__
+
+namespace {
+
+template <int N> struct FflPlan;
+template <> struct FflPlan<4096>  { static constexpr int NS = 3, R1 = 16, R2 = 16, R3 = 16, R4 = 1, PADSH = 4; };
+template <> struct FflPlan<8192>  { static constexpr int NS = 4, R1 = 16, R2 = 8,  R3 = 8,  R4 = 8, PADSH = 3; };
+template <> struct FflPlan<16384> { static constexpr int NS = 4, R1 = 16, R2 = 16, R3 = 8,  R4 = 8, PADSH = 3; };
+
+template <int N> struct FflGeom {
+    using P = FflPlan<N>;
+    static constexpr int T = N / 16;                       // threads
+    static constexpr int TWN = N / 16;                     // sub-stage twiddle table: exp(-2 pi i e / TWN)
+    static constexpr int DATA = N + (N >> P::PADSH);       // padded points
+    static constexpr size_t LDS_BYTES = (size_t)(DATA + TWN) * sizeof(float2);
+};
+
+template <int PADSH> FFL_HD int ffl_pad(int p) { return p + (p >> PADSH); }
+FFL_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+
+template <int R, bool INV> struct FflDft;
+template <bool INV> struct FflDft<16, INV> { static FFL_HD void run(float2 (&a)[16]) { dft16<INV>(a); } };
+template <bool INV> struct FflDft<8, INV>  { static FFL_HD void run(float2 (&a)[8])  { dft8<INV>(a); } };
+
+// w^k, k = 0..15, by a multiplication tree of depth <= 4 (keeps the rounding of the high powers at a few ulp)
+FFL_HD void ffl_powers16(float2 w1, float2 (&w)[16])
+{
+    w[0] = make_float2(1.f, 0.f); w[1] = w1; w[2] = cmul(w1, w1); w[3] = cmul(w[2], w1); w[4] = cmul(w[2], w[2]);
+    w[5] = cmul(w[4], w1); w[6] = cmul(w[3], w[3]); w[7] = cmul(w[4], w[3]); w[8] = cmul(w[4], w[4]);
+    w[9] = cmul(w[8], w1); w[10] = cmul(w[5], w[5]); w[11] = cmul(w[8], w[3]); w[12] = cmul(w[6], w[6]);
+    w[13] = cmul(w[8], w[5]); w[14] = cmul(w[7], w[7]); w[15] = cmul(w[8], w[7]);
+}
+
+// ---- phase 1: v[j] = x[t + T j] -> radix 16 over j -> x W_N^(t k) -> lds[t + T k]
+template <int N>
+FFL_HD void ffl_first(float2 (&v)[16], float2 *lds, float2 w1, int t)
+{
+    using G = FflGeom<N>; constexpr int PS = G::P::PADSH;
+    dft16<false>(v);
+    float2 w[16]; ffl_powers16(w1, w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) lds[ffl_pad<PS>(t + G::T * k)] = k ? cmul(v[k], w[k]) : v[k];
+}
+
+// ---- last phase: lds[t + T k] x conj(W_N^(t k)) -> inverse radix 16 -> v[j] = y[t + T j]
+template <int N>
+FFL_HD void ffl_last(float2 (&v)[16], const float2 *lds, float2 w1, int t)
+{
+    using G = FflGeom<N>; constexpr int PS = G::P::PADSH;
+    float2 w[16]; ffl_powers16(cconj(w1), w);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const float2 a = lds[ffl_pad<PS>(t + G::T * k)]; v[k] = k ? cmul(a, w[k]) : a; }
+    dft16<true>(v);
+}
+
+// ---- a middle stage on sub-transforms of length L, radix R, in place.  Forward: butterfly then twiddle W_L^(o k); inverse: conj twiddle then butterfly.
+template <int N, int L, int R, bool INV>
+FFL_HD void ffl_mid(float2 *lds, const float2 *tws, int t)
+{
+    using G = FflGeom<N>; constexpr int PS = G::P::PADSH, U = 16 / R, S = L / R, TS = G::TWN / L;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int q = t + G::T * u, blk = q / S, o = q % S, base = blk * L + o;
+        float2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            a[j] = lds[ffl_pad<PS>(base + S * j)];
+            if (INV && j) a[j] = cmul(a[j], cconj(tws[TS * o * j]));
+        }
+        FflDft<R, INV>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; k++) lds[ffl_pad<PS>(base + S * k)] = (!INV && k) ? cmul(a[k], tws[TS * o * k]) : a[k];
+    }
+}
+
+// ---- centre: last forward stage (L = R, stride 1) from LDS, bin product with the taps spectrum (slot order: Hperm[slot * T + t]), first inverse stage back to LDS
+template <int N, int R>
+FFL_HD void ffl_centre(float2 *lds, const float2 *hperm, int t)
+{
+    using G = FflGeom<N>; constexpr int PS = G::P::PADSH, U = 16 / R;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int q = t + G::T * u, base = q * R;
+        float2 a[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) a[j] = lds[ffl_pad<PS>(base + j)];
+        FflDft<R, false>::run(a);
+#pragma unroll
+        for (int k = 0; k < R; k++) a[k] = cmul(a[k], hperm[(size_t)(u * R + k) * G::T + t]);      // libcsdr.c:826-830 (and 836-839: the 1/N is in the table)
+        FflDft<R, true>::run(a);
+#pragma unroll
+        for (int j = 0; j < R; j++) lds[ffl_pad<PS>(base + j)] = a[j];
+    }
+}
+
+// The phases between the first and the last one, in order; `sync` separates them (a barrier on the device, "all threads done" in the CPU harness).
+// PHASE counts from 0; returns false when there is no such phase.
+template <int N> struct FflMidPhases {
+    using P = FflPlan<N>;
+    static constexpr int COUNT = 2 * (P::NS - 2) + 1;
+    template <int PHASE> static FFL_HD void run(float2 *lds, const float2 *tws, const float2 *hperm, int t)
+    {
+        constexpr int L2 = N / P::R1, L3 = L2 / P::R2, L4 = L3 / P::R3;
+        if constexpr (P::NS == 3) {
+            if constexpr (PHASE == 0) ffl_mid<N, L2, P::R2, false>(lds, tws, t);
+            else if constexpr (PHASE == 1) ffl_centre<N, P::R3>(lds, hperm, t);
+            else ffl_mid<N, L2, P::R2, true>(lds, tws, t);
+        } else {
+            if constexpr (PHASE == 0) ffl_mid<N, L2, P::R2, false>(lds, tws, t);
+            else if constexpr (PHASE == 1) ffl_mid<N, L3, P::R3, false>(lds, tws, t);
+            else if constexpr (PHASE == 2) ffl_centre<N, P::R4>(lds, hperm, t);
+            else if constexpr (PHASE == 3) ffl_mid<N, L3, P::R3, true>(lds, tws, t);
+            else ffl_mid<N, L2, P::R2, true>(lds, tws, t);
+            (void)L4;
+        }
+    }
+};
+
+// frequency index held at in-place position p after the forward stages: p = k1 N/R1 + k2 N/(R1 R2) + ... holds X[k1 + R1 k2 + R1 R2 k3 + ...]
+template <int N> int ffl_freq_of_position(int p)
+{
+    using P = FflPlan<N>;
+    const int r[4] = {P::R1, P::R2, P::R3, P::R4};
+    int len = N, f = 0, mul = 1;
+    for (int s = 0; s < P::NS; s++) { len /= r[s]; const int k = p / len; p -= k * len; f += k * mul; mul *= r[s]; }
+    return f;
+}
+// slot (u, k) of thread t in the centre phase <-> position (t + T u) R + k
+template <int N> int ffl_slot_position(int slot, int t)
+{
+    using P = FflPlan<N>;
+    const int R = P::NS == 3 ? P::R3 : P::R4;
+    return (t + FflGeom<N>::T * (slot / R)) * R + slot % R;
+}
+
+// ------------------------------------------------------------------------------------------------ device kernel
+// grid (8 * ceil(n_chunks / 8), n_streams): workgroup ids are dealt round robin over the 8 XCDs, so id -> chunk (id % 8) * per_xcd + id / 8 keeps
+// neighbouring windows (which share taps - 1 samples) on one XCD's L2.
+template <int N>
+__global__ __launch_bounds__(N / 16) void k_fftfilt_lds(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, long m_new,
+                                                        int n_chunks, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ hperm,
+                                                        const float2 *__restrict__ g_tw1, const float2 *__restrict__ g_tws)
+{
+    using G = FflGeom<N>;
+    extern __shared__ float4 ffl_raw[];
+    float2 *lds = reinterpret_cast<float2 *>(ffl_raw), *tws = lds + G::DATA;
+    const int t = threadIdx.x;
+    const int per_xcd = (n_chunks + 7) >> 3;
+    const int c = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (c >= n_chunks) return;
+    const size_t s = blockIdx.y;
+    for (int i = t; i < G::TWN; i += G::T) tws[i] = g_tws[i];
+    const int V = N - k1p;
+    const long w0 = (long)c * V - k1p;                                   // window start, in samples of this call's input (negative: history)
+    const float2 *x = in + s * in_pitch, *h = hist + s * (size_t)k1p;
+    float2 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const long p = w0 + t + G::T * j;
+        v[j] = p < 0 ? h[k1p + p] : (p < m_new ? x[p] : make_float2(0.f, 0.f));
+    }
+    const float2 w1 = g_tw1[t];
+    ffl_first<N>(v, lds, w1, t);
+    __syncthreads();
+    FflMidPhases<N>::template run<0>(lds, tws, hperm, t); __syncthreads();
+    FflMidPhases<N>::template run<1>(lds, tws, hperm, t); __syncthreads();
+    FflMidPhases<N>::template run<2>(lds, tws, hperm, t); __syncthreads();
+    if constexpr (FflMidPhases<N>::COUNT == 5) {
+        FflMidPhases<N>::template run<3>(lds, tws, hperm, t); __syncthreads();
+        FflMidPhases<N>::template run<4>(lds, tws, hperm, t); __syncthreads();
+    }
+    ffl_last<N>(v, lds, w1, t);
+    float2 *y = out + s * out_pitch;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int n = t + G::T * j;
+        const long o = (long)c * V + n - k1p;
+        if (n >= k1p && o < m_new) y[o] = v[j];
+    }
+}
+
+// the last k1p input samples of (history ++ this call's input) become the next call's history
+__global__ __launch_bounds__(256) void k_fftfilt_hist(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist_old, float2 *__restrict__ hist_new,
+                                                      int k1p, long m_new)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= k1p) return;
+    const size_t s = blockIdx.y;
+    const long p = m_new - k1p + i;
+    hist_new[s * k1p + i] = p >= 0 ? in[s * in_pitch + p] : hist_old[s * k1p + (k1p + p)];
+}
+
+// double-precision transform of the zero-padded taps on the host (once per set_taps; csdr.c:1869-1871 does it in float with the FFT library)
+void host_dft_pow2(std::vector<double> &re, std::vector<double> &im)
+{
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t k = 0; k < len / 2; k++) {
+            const double ang = -2.0 * M_PI * (double)k / (double)len, wr = cos(ang), wi = sin(ang);
+            for (size_t i = k; i < n; i += len) {
+                const size_t j = i + len / 2;
+                const double xr = re[j] * wr - im[j] * wi, xi = re[j] * wi + im[j] * wr;
+                re[j] = re[i] - xr; im[j] = im[i] - xi; re[i] += xr; im[i] += xi;
+            }
+        }
+    }
+}
+
+template <int N>
+void ffl_host_tables(const cf32 *taps, int taps_len, std::vector<float2> &hperm, std::vector<float2> &tw1, std::vector<float2> &tws)
+{
+    using G = FflGeom<N>;
+    std::vector<double> re(N, 0.0), im(N, 0.0);
+    for (int k = 0; k < taps_len; k++) { re[k] = taps[k].i; im[k] = taps[k].q; }
+    host_dft_pow2(re, im);
+    hperm.resize(N);
+    for (int slot = 0; slot < 16; slot++)
+        for (int t = 0; t < G::T; t++) {
+            const int f = ffl_freq_of_position<N>(ffl_slot_position<N>(slot, t));
+            hperm[(size_t)slot * G::T + t] = make_float2((float)(re[f] / N), (float)(im[f] / N));
+        }
+    tw1.resize(G::T); tws.resize(G::TWN);
+    for (int t = 0; t < G::T; t++) { const double a = -2.0 * M_PI * t / N; tw1[t] = make_float2((float)cos(a), (float)sin(a)); }
+    for (int e = 0; e < G::TWN; e++) { const double a = -2.0 * M_PI * e / G::TWN; tws[e] = make_float2((float)cos(a), (float)sin(a)); }
+}
+
+// the kernel's algorithm on the CPU: same stage functions, one "thread" after the other, phases in order
+template <int N>
+void ffl_host_run(const cf32 *taps, int taps_len, const cf32 *x, long m_new, cf32 *y)
+{
+    using G = FflGeom<N>;
+    std::vector<float2> hperm, tw1, tws; ffl_host_tables<N>(taps, taps_len, hperm, tw1, tws);
+    const int k1p = (taps_len - 1 + 15) & ~15, V = N - k1p;
+    const long n_chunks = (m_new + V - 1) / V;
+    std::vector<float2> lds(G::DATA);
+    for (long c = 0; c < n_chunks; c++) {
+        const long w0 = c * V - k1p;
+        for (int t = 0; t < G::T; t++) {
+            float2 v[16];
+            for (int j = 0; j < 16; j++) { const long p = w0 + t + G::T * j; v[j] = (p < 0 || p >= m_new) ? make_float2(0.f, 0.f) : make_float2(x[p].i, x[p].q); }
+            ffl_first<N>(v, lds.data(), tw1[t], t);
+        }
+        for (int t = 0; t < G::T; t++) FflMidPhases<N>::template run<0>(lds.data(), tws.data(), hperm.data(), t);
+        for (int t = 0; t < G::T; t++) FflMidPhases<N>::template run<1>(lds.data(), tws.data(), hperm.data(), t);
+        for (int t = 0; t < G::T; t++) FflMidPhases<N>::template run<2>(lds.data(), tws.data(), hperm.data(), t);
+        if constexpr (FflMidPhases<N>::COUNT == 5) {
+            for (int t = 0; t < G::T; t++) FflMidPhases<N>::template run<3>(lds.data(), tws.data(), hperm.data(), t);
+            for (int t = 0; t < G::T; t++) FflMidPhases<N>::template run<4>(lds.data(), tws.data(), hperm.data(), t);
+        }
+        for (int t = 0; t < G::T; t++) {
+            float2 v[16];
+            ffl_last<N>(v, lds.data(), tw1[t], t);
+            for (int j = 0; j < 16; j++) {
+                const int n = t + G::T * j; const long o = c * V + n - k1p;
+                if (n >= k1p && o < m_new) y[o] = cf32{v[j].x, v[j].y};
+            }
+        }
+    }
+}
+
+} // namespace
+
+namespace csdr_amd {
+
+struct FftfiltLds {
+    int n, taps_len, k1p, n_streams;
+    float2 *d_hperm, *d_tw1, *d_tws, *d_hist[2]; int flip;
+};
+
+// window size for a filter of taps_len taps: the smallest plan that keeps >= 3/4 of every window as output; 0 = none fits (the caller keeps its other paths)
+int fftfilt_lds_pick(int taps_len)
+{
+    if (getenv("CSDR_AMD_FFTFILT_LDS_OFF")) return 0;
+    if (const char *e = getenv("CSDR_AMD_FFTFILT_LDS_N")) { const int n = atoi(e); if ((n == 4096 || n == 8192 || n == 16384) && taps_len - 1 + 15 < n / 2) return n; }
+    const int k1p = (taps_len - 1 + 15) & ~15;
+    for (int n : {4096, 8192, 16384}) if (4 * k1p <= n) return n;
+    return 0;
+}
+
+void fftfilt_lds_destroy(FftfiltLds *p)
+{
+    if (!p) return;
+    (void)hipFree(p->d_hperm); (void)hipFree(p->d_tw1); (void)hipFree(p->d_tws); (void)hipFree(p->d_hist[0]); (void)hipFree(p->d_hist[1]);
+    delete p;
+}
+
+int fftfilt_lds_set_taps(FftfiltLds *p, hipStream_t st, const cf32 *taps, int taps_len)
+{
+    std::vector<float2> hperm, tw1, tws;
+    if (p->n == 4096) ffl_host_tables<4096>(taps, taps_len, hperm, tw1, tws);
+    else if (p->n == 8192) ffl_host_tables<8192>(taps, taps_len, hperm, tw1, tws);
+    else ffl_host_tables<16384>(taps, taps_len, hperm, tw1, tws);
+    CSDR_HIP(hipStreamSynchronize(st));
+    CSDR_HIP(hipMemcpy(p->d_hperm, hperm.data(), sizeof(float2) * hperm.size(), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(p->d_tw1, tw1.data(), sizeof(float2) * tw1.size(), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(p->d_tws, tws.data(), sizeof(float2) * tws.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fftfilt_lds_reset(FftfiltLds *p, hipStream_t st)
+{
+    CSDR_HIP(hipMemsetAsync(p->d_hist[0], 0, sizeof(float2) * (size_t)p->n_streams * (p->k1p + 16), st));
+    CSDR_HIP(hipMemsetAsync(p->d_hist[1], 0, sizeof(float2) * (size_t)p->n_streams * (p->k1p + 16), st));
+    p->flip = 0;
+    return 0;
+}
+
+FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps_len, int n_streams)
+{
+    FftfiltLds *p = new FftfiltLds();
+    p->n = n; p->taps_len = taps_len; p->k1p = (taps_len - 1 + 15) & ~15; p->n_streams = n_streams; p->flip = 0;
+    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = nullptr;
+    hipError_t e = hipMalloc((void **)&p->d_hperm, sizeof(float2) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw1, sizeof(float2) * (n / 16));
+    if (e == hipSuccess) e = hipMalloc((void **)&p->d_tws, sizeof(float2) * (n / 16));
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&p->d_hist[i], sizeof(float2) * (size_t)n_streams * (p->k1p + 16));
+    if (e != hipSuccess) { fail(e, "hipMalloc(fftfilt_lds)", __FILE__, __LINE__); fftfilt_lds_destroy(p); return nullptr; }
+    if (fftfilt_lds_set_taps(p, st, taps, taps_len) || fftfilt_lds_reset(p, st)) { fftfilt_lds_destroy(p); return nullptr; }
+    return p;
+}
+
+const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
+int fftfilt_lds_window(const FftfiltLds *p) { return p->n; }
+
+template <int N>
+static int ffl_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
+{
+    using G = FflGeom<N>;
+    int rc = lds_attr_once((const void *)k_fftfilt_lds<N>, G::LDS_BYTES); if (rc) return rc;
+    const int V = N - p->k1p;
+    const int n_chunks = (int)((m_new + V - 1) / V);
+    hipLaunchKernelGGL(k_fftfilt_lds<N>, dim3(8 * ((n_chunks + 7) / 8), p->n_streams), dim3(G::T), G::LDS_BYTES, st, (const float2 *)in, in_pitch,
+                       (const float2 *)p->d_hist[p->flip], p->k1p, m_new, n_chunks, (float2 *)out, out_pitch, (const float2 *)p->d_hperm, (const float2 *)p->d_tw1,
+                       (const float2 *)p->d_tws);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+// m_new new samples per stream in, m_new filtered samples out
+int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
+{
+    if (m_new <= 0) return 0;
+    int rc;
+    if (p->n == 4096) rc = ffl_launch<4096>(p, st, in, in_pitch, m_new, out, out_pitch);
+    else if (p->n == 8192) rc = ffl_launch<8192>(p, st, in, in_pitch, m_new, out, out_pitch);
+    else rc = ffl_launch<16384>(p, st, in, in_pitch, m_new, out, out_pitch);
+    if (rc) return rc;
+    if (p->k1p > 0) {
+        hipLaunchKernelGGL(k_fftfilt_hist, dim3(cdiv(p->k1p, 256), p->n_streams), dim3(256), 0, st, (const float2 *)in, in_pitch, (const float2 *)p->d_hist[p->flip],
+                           p->d_hist[p->flip ^ 1], p->k1p, m_new);
+        CSDR_LAUNCH_CHECK();
+        p->flip ^= 1;
+    }
+    return 0;
+}
+
+} // namespace csdr_amd
+
+// Test hook (CPU, no device): the LDS kernel's algorithm -- same stage functions, same tables -- on m_new samples of one stream from the zero state.
+extern "C" int csdr_amd_debug_fftfilt_lds(int n, const float *taps_iq, int taps_len, const float *x_iq, long m_new, float *y_iq)
+{
+    const cf32 *taps = reinterpret_cast<const cf32 *>(taps_iq), *x = reinterpret_cast<const cf32 *>(x_iq); cf32 *y = reinterpret_cast<cf32 *>(y_iq);
+    if (taps_len < 1 || ((taps_len - 1 + 15) & ~15) >= n) return -3;
+    if (n == 4096) ffl_host_run<4096>(taps, taps_len, x, m_new, y);
+    else if (n == 8192) ffl_host_run<8192>(taps, taps_len, x, m_new, y);
+    else if (n == 16384) ffl_host_run<16384>(taps, taps_len, x, m_new, y);
+    else return -3;
+    return 0;
+}

@@ -308,16 +308,16 @@ int csdr_amd_scale_add(csdr_amd_ctx *c, csdr_complexf *io, size_t n, float scale
 } // extern "C"
 
 // ====================================================================================== overlap-add object
-struct csdr_amd_fftfilt {
-    csdr_amd_ctx *ctx;
-    int fft, taps_len, inp, ovl, n_streams, max_blocks;
-    cf32 *d_taps_fft, *d_pad, *d_td, *d_carry[2];
-    cf32 *d_taps_fft_t; float2 *d_tw;      // fft_size 65536: taps spectrum in [k1][k2] order and the twiddle tables of the three-pass transform (fft64k.hip)
-    int flip;
-    hipfftHandle plan_one, plan_batch; int plan_batch_n;
-};
-
 namespace csdr_amd {
+struct FftfiltLds;
+int fftfilt_lds_pick(int taps_len);
+FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps_len, int n_streams);
+void fftfilt_lds_destroy(FftfiltLds *p);
+int fftfilt_lds_set_taps(FftfiltLds *p, hipStream_t st, const cf32 *taps, int taps_len);
+int fftfilt_lds_reset(FftfiltLds *p, hipStream_t st);
+int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch);
+const char *fftfilt_lds_kernel_name(const FftfiltLds *p);
+int fftfilt_lds_window(const FftfiltLds *p);
 int fft64k_upload_tables(float2 *d_tw);
 int fft64k_transpose_taps(hipStream_t st, const cf32 *d_taps_fft, cf32 *d_taps_fft_t);
 int fft64k_filter(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int n_blocks, int n_streams, cf32 *d_work, const cf32 *d_taps_fft_t,
@@ -325,6 +325,17 @@ int fft64k_filter(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int 
 int fft64k_filter_oa(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int ovl, int n_blocks, int n_streams, cf32 *d_work, const cf32 *d_taps_fft_t,
                      const float2 *d_tw, cf32 *d_tails, const cf32 *d_carry_in, cf32 *d_carry_out, cf32 *out, size_t out_pitch);
 }
+
+struct csdr_amd_fftfilt {
+    csdr_amd_ctx *ctx;
+    int fft, taps_len, inp, ovl, n_streams, max_blocks;
+    cf32 *d_taps_fft, *d_pad, *d_td, *d_carry[2];
+    cf32 *d_taps_fft_t; float2 *d_tw;      // fft_size 65536: taps spectrum in [k1][k2] order and the twiddle tables of the three-pass transform (fft64k.hip)
+    int flip;
+    hipfftHandle plan_one, plan_batch; int plan_batch_n;
+    csdr_amd::FftfiltLds *lds;             // taps short enough for LDS-sized windows: the one-pass kernel of fftfilt_lds.hip (every other buffer stays unallocated)
+};
+
 
 static int fftfilt_make_batch_plan(csdr_amd_fftfilt *f, int batch)
 {
@@ -342,6 +353,7 @@ extern "C" {
 int csdr_amd_fftfilt_set_taps(csdr_amd_fftfilt *f, const csdr_complexf *host_taps, int taps_length)
 {   // csdr.c:1869-1871: zero padded taps -> forward FFT
     if (taps_length != f->taps_len) return fail_msg(-3, "fftfilt: taps_length changed (%d -> %d); create a new filter", f->taps_len, taps_length);
+    if (f->lds) return fftfilt_lds_set_taps(f->lds, f->ctx->stream, host_taps, taps_length);
     std::vector<cf32> pad((size_t)f->fft, cf32{0.f, 0.f});
     for (int k = 0; k < taps_length; k++) pad[k] = host_taps[k];
     CSDR_HIP(hipStreamSynchronize(f->ctx->stream));
@@ -358,6 +370,12 @@ csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const
     csdr_amd_fftfilt *f = new csdr_amd_fftfilt();
     f->ctx = ctx; f->fft = fft_size; f->taps_len = taps_length; f->inp = fft_size - taps_length + 1; f->ovl = taps_length - 1;
     f->n_streams = n_streams; f->max_blocks = max_blocks; f->flip = 0; f->plan_batch_n = 0;
+    f->lds = nullptr; f->d_taps_fft = f->d_pad = f->d_td = f->d_carry[0] = f->d_carry[1] = f->d_taps_fft_t = nullptr; f->d_tw = nullptr; f->plan_one = 0;
+    if (const int win = fftfilt_lds_pick(taps_length)) {
+        f->lds = fftfilt_lds_create(ctx->stream, win, host_taps, taps_length, n_streams);
+        if (!f->lds) { delete f; return nullptr; }
+        return f;
+    }
     const size_t tot = (size_t)n_streams * max_blocks * fft_size;
     hipError_t e = hipMalloc((void **)&f->d_taps_fft, sizeof(cf32) * fft_size);
     if (e == hipSuccess) e = hipMalloc((void **)&f->d_pad, sizeof(cf32) * tot);
@@ -381,6 +399,7 @@ void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f)
 {
     if (!f) return;
     (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->lds) { fftfilt_lds_destroy(f->lds); delete f; return; }
     hipfftDestroy(f->plan_one); if (f->plan_batch_n) hipfftDestroy(f->plan_batch);
     (void)hipFree(f->d_taps_fft); (void)hipFree(f->d_pad); (void)hipFree(f->d_td); (void)hipFree(f->d_carry[0]); (void)hipFree(f->d_carry[1]);
     (void)hipFree(f->d_taps_fft_t); (void)hipFree(f->d_tw);
@@ -388,9 +407,13 @@ void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f)
 }
 
 int csdr_amd_fftfilt_input_size(const csdr_amd_fftfilt *f) { return f->inp; }
+/* which path serves this filter: the one-pass kernel's name and its window size, or "" / 0 */
+const char *csdr_amd_fftfilt_kernel_name(const csdr_amd_fftfilt *f) { return f->lds ? fftfilt_lds_kernel_name(f->lds) : ""; }
+int csdr_amd_fftfilt_window(const csdr_amd_fftfilt *f) { return f->lds ? fftfilt_lds_window(f->lds) : 0; }
 
 int csdr_amd_fftfilt_reset(csdr_amd_fftfilt *f)
 {   // csdr.c:1862: the first block's overlap source is all zeros
+    if (f->lds) return fftfilt_lds_reset(f->lds, f->ctx->stream);
     CSDR_HIP(hipMemsetAsync(f->d_carry[0], 0, sizeof(cf32) * (size_t)f->n_streams * (f->ovl + 1), f->ctx->stream));
     CSDR_HIP(hipMemsetAsync(f->d_carry[1], 0, sizeof(cf32) * (size_t)f->n_streams * (f->ovl + 1), f->ctx->stream));
     f->flip = 0;
@@ -402,6 +425,7 @@ int csdr_amd_fftfilt_process(csdr_amd_fftfilt *f, const csdr_complexf *in, csdr_
     if (n_blocks <= 0) return 0;
     if (n_blocks > f->max_blocks) return fail_msg(-3, "fftfilt: %d blocks exceed max_blocks %d", n_blocks, f->max_blocks);
     hipStream_t st = f->ctx->stream;
+    if (f->lds) return fftfilt_lds_process(f->lds, st, in, in_pitch, (long)n_blocks * f->inp, out, out_pitch);
     const int batch = f->n_streams * n_blocks;
     int rc = 0;
     if (f->d_taps_fft_t && f->ovl <= f->inp) {

@@ -213,6 +213,10 @@ csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const
 void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f);
 int  csdr_amd_fftfilt_set_taps(csdr_amd_fftfilt *f, const csdr_complexf *host_taps, int taps_length);
 int  csdr_amd_fftfilt_input_size(const csdr_amd_fftfilt *f);
+/* Taps short enough for windows that fit a CU's LDS (<= 4096 taps) are served by ONE pass over HBM (fftfilt_lds.hip: overlap-save with 4096 / 8192 / 16384-point
+ * transforms in LDS; same samples out, same framing at this interface): its kernel name and window size, or "" / 0 when the full-size transform path runs. */
+const char *csdr_amd_fftfilt_kernel_name(const csdr_amd_fftfilt *f);
+int  csdr_amd_fftfilt_window(const csdr_amd_fftfilt *f);
 int  csdr_amd_fftfilt_reset(csdr_amd_fftfilt *f);
 int  csdr_amd_fftfilt_process(csdr_amd_fftfilt *f, const csdr_complexf *in, csdr_complexf *out,
                               int n_blocks, size_t in_pitch, size_t out_pitch);
@@ -378,6 +382,7 @@ int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const flo
 /* Test hook: the register-level 16-point butterfly of the three-pass 65536-point transform (fft64k.hip) on the CPU; 16 interleaved complex floats */
 void csdr_amd_debug_dft16(const float *in32, float *out32, int inverse);
 /* Test hook: the 8-point butterfly of the channelizer's 512-point inverse transforms (fastddc_mfma.hip) on the CPU; 8 interleaved complex floats */
+int  csdr_amd_debug_fftfilt_lds(int n, const float *taps_iq, int taps_len, const float *x_iq, long m_new, float *y_iq);   /* CPU run of the one-pass filter kernel's stages */
 void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse);
 /* Test hook: one tile (16 outputs from 256 limited samples) of the NFM chain's matrix-core de-emphasis FIR on the CPU: digit planes,
  * Toeplitz digit table and accumulator classes as k_nfm_deemph_mfma combines them. */

@@ -175,3 +175,23 @@ def test_nfm_deemph_digit_planes():
             want = np.array([np.dot(taps, x[i:i + taps.size].astype(np.float64)) for i in range(16)])
             assert np.abs(out - want).max() < 4e-7 * amp * np.abs(taps).sum(), (sr, np.abs(out - want).max())
     assert fn(12345, 1.0, x.ctypes.data, out.ctypes.data) == -1
+
+
+@pytest.mark.parametrize("n,ntaps,m", [(4096, 63, 9000), (4096, 1023, 7000), (8192, 1023, 20000), (8192, 2047, 13000), (16384, 4095, 30000), (4096, 1, 4097), (8192, 500, 100)])
+def test_fftfilt_lds_stages_on_cpu(n, ntaps, m):
+    """The one-pass FFT filter kernel (fftfilt_lds.hip) is built from __host__ __device__ stage functions: the CPU runs the same index algebra (in-place
+    decimation-in-frequency stages, taps spectrum in digit-reversed slot order, mirrored inverse stages, overlap-save windows) thread by thread and must
+    reproduce the linear convolution bandpass_fir_fft_cc computes (libcsdr.c:814-849)."""
+    import numpy as np
+    import csdr_amd
+    L = csdr_amd.lib()
+    f = L.csdr_amd_debug_fftfilt_lds
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p]; f.restype = C.c_int
+    rng = np.random.default_rng(n + ntaps)
+    h = ((rng.standard_normal(ntaps) + 1j * rng.standard_normal(ntaps)) / ntaps).astype(np.complex64)
+    x = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+    y = np.zeros(m, np.complex64)
+    assert f(n, h.ctypes.data, ntaps, x.ctypes.data, m, y.ctypes.data) == 0
+    want = np.convolve(x.astype(np.complex128), h.astype(np.complex128))[:m]
+    assert np.sqrt(np.mean(np.abs(y - want) ** 2) / np.mean(np.abs(want) ** 2)) < 2e-6
+    assert f(4096, h.ctypes.data, 5000, x.ctypes.data, m, y.ctypes.data) != 0        # taps that do not fit the window are refused

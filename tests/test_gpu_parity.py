@@ -237,6 +237,52 @@ def test_bandpass_fir_fft_c3_streams(gpu, port):
     assert relrms(a[1], port.bandpass_fir_fft_cc(x[1], taps, fft)) < TOL
 
 
+def test_bandpass_fir_fft_paths(gpu, port, monkeypatch):
+    """Which path serves which filter: <= 4096 taps the one-pass kernel (windows of 4096 / 8192 / 16384 points in LDS), longer filters and
+    CSDR_AMD_FFTFILT_LDS_OFF the full-size transform (three passes at 65536, hipFFT otherwise); all of them give the oracle's samples (libcsdr.c:814-849)."""
+    import ctypes as C
+    rng = np.random.default_rng(35)
+    L = gpu.L
+
+    def path_of(ntaps, fft):
+        taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
+        f = L.csdr_amd_fftfilt_create(gpu.h, fft, taps.ctypes.data_as(C.c_void_p), ntaps, 1, 1)
+        assert f
+        name, win = L.csdr_amd_fftfilt_kernel_name(f).decode(), L.csdr_amd_fftfilt_window(f)
+        L.csdr_amd_fftfilt_destroy(f)
+        return name, win
+    assert path_of(63, 65536) == ("k_fftfilt_lds<4096>", 4096) and path_of(1023, 65536)[1] == 4096
+    assert path_of(1025, 65536)[1] == 4096 and path_of(1041, 65536)[1] == 8192 and path_of(2047, 65536)[1] == 8192 and path_of(4095, 65536)[1] == 16384
+    assert path_of(8191, 65536) == ("", 0)
+    # a filter too long for LDS windows: the 65536-point path
+    fft, ntaps = 65536, 8191
+    x = crand(rng, (fft - ntaps + 1) * 2)
+    taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
+    assert relrms(gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=1), port.bandpass_fir_fft_cc(x, taps, fft)) < TOL
+    # the full-size paths on the filters the one-pass kernel normally takes
+    monkeypatch.setenv("CSDR_AMD_FFTFILT_LDS_OFF", "1")
+    assert path_of(1023, 65536) == ("", 0)
+    for ntaps, fft in [(1023, 65536), (255, 1024)]:
+        x = np.stack([crand(rng, (fft - ntaps + 1) * 3) for _ in range(2)])
+        taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
+        a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=2)
+        for s in range(2):
+            assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, fft)) < TOL
+
+
+def test_bandpass_one_pass_ragged(gpu, port):
+    """The one-pass kernel at every window size: streams x blocks that do not divide into windows, calls shorter than the filter's history, pitches larger
+    than the row; vs the oracle's block-by-block overlap-add."""
+    rng = np.random.default_rng(36)
+    for ntaps, fft, per in [(63, 256, 1), (1023, 2048, 3), (1500, 4096, None), (4095, 8192, 2), (3001, 65536, 1)]:
+        inp = fft - ntaps + 1
+        x = np.stack([crand(rng, inp * 5) for _ in range(5)])
+        taps = port.firdes_bandpass_c(ntaps, -0.2, 0.3)
+        a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=per)
+        for s in range(5):
+            assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, fft)) < TOL
+
+
 def test_bandpass_small_and_chained_overlap(gpu, port):
     rng = np.random.default_rng(5)
     for ntaps, fft in [(79, 256), (601, 1024)]:                        # second case: input_size (424) < overlap (600)
