@@ -17,12 +17,19 @@
 // Plans: 4096 = 16.16.16, 8192 = 16.8.8.8, 16384 = 16.16.8.8.  Every stage function is __host__ __device__: tests/test_abi_cpu.py runs the very same index algebra
 // on the CPU (csdr_amd_debug_fftfilt_lds), thread by thread, phase by phase.
 #include "common.hpp"
+// no bit-exact contract on this path (float FFT filtering, 1e-5 relative RMS): let the butterflies and twiddle products contract into FMAs
+#pragma clang fp contract(fast)
 #include "fft_butterflies.hpp"
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
 
 using namespace csdr_amd;
+
+typedef int ffl_i32x4 __attribute__((ext_vector_type(4)));
+typedef float ffl_f32x2 __attribute__((ext_vector_type(2)));
+__device__ ffl_f32x2 ffl_buf_load(ffl_i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ void ffl_buf_store(ffl_f32x2 v, ffl_i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 #define FFL_HD __host__ __device__ __forceinline__
 
@@ -160,48 +167,86 @@ template <int N> int ffl_slot_position(int slot, int t)
 }
 
 // ------------------------------------------------------------------------------------------------ device kernel
-// grid (8 * ceil(n_chunks / 8), n_streams): workgroup ids are dealt round robin over the 8 XCDs, so id -> chunk (id % 8) * per_xcd + id / 8 keeps
-// neighbouring windows (which share taps - 1 samples) on one XCD's L2.
+// Persistent workgroups (a few per CU) walk the windows of the call; the NEXT window's samples are fetched into registers while the current one is
+// transformed, so the HBM pipe never waits for the butterflies.  Window w = (stream, chunk); workgroup ids are dealt round robin over the 8 XCDs, so each
+// XCD gets a contiguous range of windows and the workgroups of one XCD take consecutive windows at the same time: the taps - 1 samples neighbouring
+// windows share are served by that XCD's L2.
+// Buffer loads / stores with the hardware range check do the edges: a window's samples in front of the call's input come from the history (a second
+// descriptor), samples behind its end read as zero, results outside [0, m_new) are dropped -- no divergent branch anywhere.  (The LLVM intrinsics are declared
+// directly, see fir.hip.)
 template <int N>
-__global__ __launch_bounds__(N / 16) void k_fftfilt_lds(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, long m_new,
-                                                        int n_chunks, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ hperm,
+__device__ __forceinline__ void ffl_load_window(float2 (&v)[16], const float2 *x, const float2 *h, int w0, int k1p, int m_new, int t)
+{
+    constexpr int T = FflGeom<N>::T;
+    const unsigned long long bx = (unsigned long long)x, bh = (unsigned long long)h;
+    const ffl_i32x4 rx = {(int)(unsigned)bx, (int)((bx >> 32) & 0xffffu), m_new * 8, 0x00020000};
+    const int v0 = (w0 + t) * 8;                                        // negative (history) -> out of range as unsigned -> 0
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const ffl_f32x2 r = ffl_buf_load(rx, v0 + T * 8 * j, 0, 0); v[j] = make_float2(r.x, r.y); }
+    if (w0 < 0) {                                                       // uniform: the stream's first window
+        const ffl_i32x4 rh = {(int)(unsigned)bh, (int)((bh >> 32) & 0xffffu), k1p * 8, 0x00020000};
+        const int vh = (k1p + w0 + t) * 8;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const ffl_f32x2 r = ffl_buf_load(rh, vh + T * 8 * j, 0, 0); v[j].x += r.x; v[j].y += r.y; }
+    }
+}
+
+template <int N, bool PF, int MINWG, bool HOIST>
+__global__ __launch_bounds__(N / 16, MINWG) void k_fftfilt_lds(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, int m_new,
+                                                        int n_chunks, int n_windows, float2 *__restrict__ out, size_t out_pitch, const float2 *hperm,
                                                         const float2 *__restrict__ g_tw1, const float2 *__restrict__ g_tws)
 {
     using G = FflGeom<N>;
     extern __shared__ float4 ffl_raw[];
     float2 *lds = reinterpret_cast<float2 *>(ffl_raw), *tws = lds + G::DATA;
     const int t = threadIdx.x;
-    const int per_xcd = (n_chunks + 7) >> 3;
-    const int c = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (c >= n_chunks) return;
-    const size_t s = blockIdx.y;
     for (int i = t; i < G::TWN; i += G::T) tws[i] = g_tws[i];
+    float2 w1 = g_tw1[t];
     const int V = N - k1p;
-    const long w0 = (long)c * V - k1p;                                   // window start, in samples of this call's input (negative: history)
-    const float2 *x = in + s * in_pitch, *h = hist + s * (size_t)k1p;
-    float2 v[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const long p = w0 + t + G::T * j;
-        v[j] = p < 0 ? h[k1p + p] : (p < m_new ? x[p] : make_float2(0.f, 0.f));
+    const int per_xcd = (n_windows + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;      // gridDim.x is a multiple of 8
+    const int w_end = min(n_windows, (xcd + 1) * per_xcd);
+    int w = xcd * per_xcd + (blockIdx.x >> 3);
+    if (w >= w_end) return;
+    float2 v[16], nx[16];
+    {
+        const int s = w / n_chunks, c = w - s * n_chunks;
+        ffl_load_window<N>(v, in + (size_t)s * in_pitch, hist + (size_t)s * k1p, c * V - k1p, k1p, m_new, t);
     }
-    const float2 w1 = g_tw1[t];
-    ffl_first<N>(v, lds, w1, t);
-    __syncthreads();
-    FflMidPhases<N>::template run<0>(lds, tws, hperm, t); __syncthreads();
-    FflMidPhases<N>::template run<1>(lds, tws, hperm, t); __syncthreads();
-    FflMidPhases<N>::template run<2>(lds, tws, hperm, t); __syncthreads();
-    if constexpr (FflMidPhases<N>::COUNT == 5) {
-        FflMidPhases<N>::template run<3>(lds, tws, hperm, t); __syncthreads();
-        FflMidPhases<N>::template run<4>(lds, tws, hperm, t); __syncthreads();
-    }
-    ffl_last<N>(v, lds, w1, t);
-    float2 *y = out + s * out_pitch;
+    for (; w < w_end; w += stride) {
+        const int s = w / n_chunks, c = w - s * n_chunks;
+        if (!HOIST) {                                                   // keep the loop-invariant twiddle powers and taps spectrum OUT of registers (residency over reuse)
+            asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+            asm volatile("" : "+s"(hperm));
+        }
+        ffl_first<N>(v, lds, w1, t);
+        const int wn = w + stride;
+        if (PF && wn < w_end) {                                         // uniform
+            const int sn = wn / n_chunks, cn = wn - sn * n_chunks;
+            ffl_load_window<N>(nx, in + (size_t)sn * in_pitch, hist + (size_t)sn * k1p, cn * V - k1p, k1p, m_new, t);
+        }
+        __syncthreads();
+        FflMidPhases<N>::template run<0>(lds, tws, hperm, t); __syncthreads();
+        FflMidPhases<N>::template run<1>(lds, tws, hperm, t); __syncthreads();
+        FflMidPhases<N>::template run<2>(lds, tws, hperm, t); __syncthreads();
+        if constexpr (FflMidPhases<N>::COUNT == 5) {
+            FflMidPhases<N>::template run<3>(lds, tws, hperm, t); __syncthreads();
+            FflMidPhases<N>::template run<4>(lds, tws, hperm, t); __syncthreads();
+        }
+        ffl_last<N>(v, lds, w1, t);
+        __syncthreads();                                                // the next window's first stage overwrites the exchange buffer
+        // results n = k1p .. N-1 of the window are outputs c V + (n - k1p): descriptor based at output c V, range = what is left of the call
+        const unsigned long long by = (unsigned long long)(out + (size_t)s * out_pitch + (size_t)c * V);
+        const ffl_i32x4 ry = {(int)(unsigned)by, (int)((by >> 32) & 0xffffu), (m_new - c * V) * 8, 0x00020000};
+        const int vy = (t - k1p) * 8;                                   // negative (the window's overlap part) -> dropped
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int n = t + G::T * j;
-        const long o = (long)c * V + n - k1p;
-        if (n >= k1p && o < m_new) y[o] = v[j];
+        for (int j = 0; j < 16; j++) { const ffl_f32x2 r = {v[j].x, v[j].y}; ffl_buf_store(r, ry, vy + G::T * 8 * j, 0, 0); }
+        if (PF) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = nx[j];
+        } else if (wn < w_end) {
+            const int sn = wn / n_chunks, cn = wn - sn * n_chunks;
+            ffl_load_window<N>(v, in + (size_t)sn * in_pitch, hist + (size_t)sn * k1p, cn * V - k1p, k1p, m_new, t);
+        }
     }
 }
 
@@ -354,16 +399,21 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
 const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
 int fftfilt_lds_window(const FftfiltLds *p) { return p->n; }
 
-template <int N>
+template <int N, bool PF, int MINWG, bool HOIST>
 static int ffl_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
 {
     using G = FflGeom<N>;
-    int rc = lds_attr_once((const void *)k_fftfilt_lds<N>, G::LDS_BYTES); if (rc) return rc;
+    int rc = lds_attr_once((const void *)k_fftfilt_lds<N, PF, MINWG, HOIST>, G::LDS_BYTES); if (rc) return rc;
     const int V = N - p->k1p;
     const int n_chunks = (int)((m_new + V - 1) / V);
-    hipLaunchKernelGGL(k_fftfilt_lds<N>, dim3(8 * ((n_chunks + 7) / 8), p->n_streams), dim3(G::T), G::LDS_BYTES, st, (const float2 *)in, in_pitch,
-                       (const float2 *)p->d_hist[p->flip], p->k1p, m_new, n_chunks, (float2 *)out, out_pitch, (const float2 *)p->d_hperm, (const float2 *)p->d_tw1,
-                       (const float2 *)p->d_tws);
+    const long n_windows = (long)n_chunks * p->n_streams;
+    if (n_windows > 0x7fffffffL || m_new > (1L << 27)) return fail_msg(-3, "fftfilt: call too large (2^27 samples per stream at most)");
+    long grid = (long)current_device_cu_count() * MINWG;
+    if (grid > n_windows) grid = n_windows;
+    grid = (grid + 7) & ~7L;
+    hipLaunchKernelGGL((k_fftfilt_lds<N, PF, MINWG, HOIST>), dim3((unsigned)grid), dim3(G::T), G::LDS_BYTES, st, (const float2 *)in, in_pitch,
+                       (const float2 *)p->d_hist[p->flip], p->k1p, (int)m_new, n_chunks, (int)n_windows, (float2 *)out, out_pitch, (const float2 *)p->d_hperm,
+                       (const float2 *)p->d_tw1, (const float2 *)p->d_tws);
     CSDR_LAUNCH_CHECK();
     return 0;
 }
@@ -373,9 +423,17 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
 {
     if (m_new <= 0) return 0;
     int rc;
-    if (p->n == 4096) rc = ffl_launch<4096>(p, st, in, in_pitch, m_new, out, out_pitch);
-    else if (p->n == 8192) rc = ffl_launch<8192>(p, st, in, in_pitch, m_new, out, out_pitch);
-    else rc = ffl_launch<16384>(p, st, in, in_pitch, m_new, out, out_pitch);
+    static const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;      // experiment switch: prefetch / residency variants
+    if (p->n == 4096) {
+        if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else if (mode == 2) rc = ffl_launch<4096, false, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else rc = ffl_launch<4096, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+    } else if (p->n == 8192) {
+        if (mode == 1) rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else if (mode == 3) rc = ffl_launch<8192, true, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+    } else rc = ffl_launch<16384, false, 1, false>(p, st, in, in_pitch, m_new, out, out_pitch);
     if (rc) return rc;
     if (p->k1p > 0) {
         hipLaunchKernelGGL(k_fftfilt_hist, dim3(cdiv(p->k1p, 256), p->n_streams), dim3(256), 0, st, (const float2 *)in, in_pitch, (const float2 *)p->d_hist[p->flip],
