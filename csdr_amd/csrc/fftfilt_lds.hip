@@ -408,7 +408,9 @@ static int ffl_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_p
     const int n_chunks = (int)((m_new + V - 1) / V);
     const long n_windows = (long)n_chunks * p->n_streams;
     if (n_windows > 0x7fffffffL || m_new > (1L << 27)) return fail_msg(-3, "fftfilt: call too large (2^27 samples per stream at most)");
-    long grid = (long)current_device_cu_count() * MINWG;
+    constexpr int wpe = N / 16 / 64 / 4;                               // waves per SIMD of one workgroup (MINWG counts waves per SIMD)
+    constexpr int by_regs = MINWG / wpe > 0 ? MINWG / wpe : 1, by_lds = (int)(160 * 1024 / G::LDS_BYTES);
+    long grid = (long)current_device_cu_count() * (by_regs < by_lds ? by_regs : by_lds);
     if (grid > n_windows) grid = n_windows;
     grid = (grid + 7) & ~7L;
     hipLaunchKernelGGL((k_fftfilt_lds<N, PF, MINWG, HOIST>), dim3((unsigned)grid), dim3(G::T), G::LDS_BYTES, st, (const float2 *)in, in_pitch,
@@ -423,16 +425,16 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
 {
     if (m_new <= 0) return 0;
     int rc;
-    static const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;      // experiment switch: prefetch / residency variants
+    // Measured on one box (profiles/r2_notes.md): 4096-point windows run best with four resident workgroups per CU and no register prefetch (0.318 ms per
+    // 64 x 16 blocks; three workgroups 0.346, prefetching variants 0.33-0.36); 8192-point windows with one 512-thread workgroup that prefetches the next window
+    // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
+    static const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
     if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else if (mode == 2) rc = ffl_launch<4096, false, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
         else rc = ffl_launch<4096, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
     } else if (p->n == 8192) {
-        if (mode == 1) rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else if (mode == 3) rc = ffl_launch<8192, true, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        if (mode == 2) rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
     } else rc = ffl_launch<16384, false, 1, false>(p, st, in, in_pitch, m_new, out, out_pitch);
     if (rc) return rc;
     if (p->k1p > 0) {
