@@ -183,7 +183,11 @@ __global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *
                 const int idx = threadIdx.x + 512 * k, row = idx / row4, col = idx - row * row4;
                 if (idx < rows * row4) nxt[row * P4 + col] = nx[k];
             }
-            __syncthreads();                                          // the other buffer is complete; nobody reads this one any more
+            // the other buffer is complete; nobody reads this one any more.  An LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for this
+            // residue's bin stores to land, which are meant to drain under the next residue's product
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             cur ^= 1;
         }
     }

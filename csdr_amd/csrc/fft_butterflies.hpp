@@ -5,7 +5,13 @@
 
 namespace {
 
-__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// (the transforms carry no bit-exact contract -- float FFT paths are gated at 1e-5 relative RMS -- so their products may contract into FMAs even though the
+// library is built -ffp-contract=off for the phase recurrences)
+__host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+#pragma clang fp contract(fast)
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
 __host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // multiplication by -j (forward) / +j (inverse)
