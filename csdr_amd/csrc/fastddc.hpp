@@ -36,5 +36,6 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
 int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts);
 int ddc_mfma_set_profiling(DdcMfma *m, int on);
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches);
+const char *ddc_mfma_kernel_name(const DdcMfma *m);       // the fold kernel the last collect() launched
 
 } // namespace csdr_amd

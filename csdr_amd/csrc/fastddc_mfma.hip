@@ -46,6 +46,7 @@ struct DdcMfma {
     cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
     int pending_blocks[2]; int fill, drain;                            // set being filled next / folded next
     bool inline_set[2], chains_on_side[2];
+    bool gemm_three = false;                                           // the fold kernel of the last collect(): k_ddc_gemm3 (three real products) or k_ddc_gemm
     hipStream_t side; hipEvent_t ev_ready[2], ev_free[2], ev_fork; bool free_recorded[2];
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void k_ddc_xt(const float2 *__restrict__ X, fl
         if (qp < pre && r < inv) Xt[((size_t)r * nbp + b) * pre + ((qp - pre / 2) & (pre - 1))] = tile[tx][ty + 8 * j];
     }
 }
+
 
 // ------------------------------------------------------------------ the fold as a matrix product
 // grid (residue slots, ceil(Cpad / 256) channel groups, ceil(n_blocks / (32 NBT)) block groups); 512 threads: wave w owns channels 32 w .. 32 w + 31 of
@@ -193,24 +195,143 @@ __global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *
     }
 }
 
+// ------------------------------------------------------------------ the fold with three real products per complex one (pre_decimation 128)
+// k_ddc_gemm3: the persistent fold above with two changes.
+//  (1) Gauss's three-multiplication form:  P1 = sum Hre Xre,  P2 = sum Him Xim,  P3 = sum (Hre + Him)(Xre + Xim);  C = (P1 - P2) + j (P3 - P1 - P2).
+//      Six matrix instructions per k-group and block tile instead of eight (the sums cost one VALU add each and replace the sign flips); three accumulator
+//      tiles instead of two.  The kernel is bound by the fp32 matrix pipe (SQ_VALU_MFMA_BUSY_CYCLES = 60 % of the kernel with the four-product form), so
+//      the product shrinks by a quarter.  Rounding: C_im carries the rounding of three sums of comparable size instead of one -- a few 1e-7, gate 1e-5.
+//  (2) The next residue's spectra go from HBM straight into the other LDS buffer (global_load_lds_dwordx4: a row = 128 complex = 1 KiB = one wave instruction),
+//      which frees the 32 staging registers the third accumulator tile needs.  Issued after the first k-groups so that the taps fetches in front of it are
+//      not queued behind it (vector memory returns in order); the barrier at the end of a residue waits for this wave's own pieces and sits BEFORE the bin
+//      stores, which therefore drain under the next residue's product together with its first taps fetches.
+template <int NBT>
+__global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
+                                                       const ChanGeom *__restrict__ geom, int inv, int Cpad, int n_channels, int nbp, int nbl, int n_blocks, float scale)
+{
+    extern __shared__ float4 xs_all[];                              // 2 x [32 NBT rows][65] float4
+    constexpr int PRE = 128, G = PRE / 4, P4 = PRE / 2 + 1, ROWS = 32 * NBT, BUF = ROWS * P4, RPW = ROWS / 8;      // rows per wave
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c_base = blockIdx.y * 256 + wave * 32, b_base = blockIdx.z * ROWS;
+    const int i = lane & 31, hi = lane >> 5;
+    const size_t gstride = (size_t)Cpad * 2;                          // float4 per k-group
+    const bool active = c_base < Cpad;
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)xs_all;
+    // rows wave * RPW .. + RPW - 1 of residue r into buffer `buf`: one 1-KiB piece per row (blocks past the end re-read the last one: their columns are never stored)
+    auto dma_rows = [&](int r, int buf) {
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const int row = wave * RPW + k, b = min(b_base + row, n_blocks - 1);
+            const float2 *src = Xt + (((size_t)(b / nbl) * inv + r) * nbl + (b % nbl)) * PRE + 2 * lane;        // 16 bytes per lane
+            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(lds_base + ((uint32_t)buf * BUF + (uint32_t)row * P4) * 16u));
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(la) : "memory");
+        }
+    };
+    // Barrier between residues.  Vector memory returns in order, so "this wave's pieces of the next buffer have landed" = "at most `newer` younger operations are
+    // still out" (newer = the taps fetches issued after the pieces that nothing has waited for yet; 0 = wait for everything).
+    auto pieces_landed_then_barrier = [&](bool all) {
+        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    int r = blockIdx.x;
+    if (r >= inv) return;
+    dma_rows(r, 0);
+    const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_base + i) * 2 + hi;
+    constexpr int AD = 8;                                               // taps fetches in flight per wave, in k-groups (4: the wave ran dry -- 4 groups of 12 matrix instructions are 1.3 us)
+    float4 a[AD];
+#pragma unroll
+    for (int d = 0; d < AD; d++) a[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < AD; d++) a[d] = ap[(size_t)d * gstride];
+    }
+    pieces_landed_then_barrier(true);
+    int cur = 0;
+    for (;;) {
+        const int rn = r + gridDim.x;
+        f32x16 acc[NBT][3];
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++)
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[bt][p][e] = 0.f;
+        const float4 *xrow = xs_all + cur * BUF + i * P4 + hi;
+#define DDC_STEP3(AV, GG)                                                                                                  \
+        {                                                                                                                  \
+            const float hs0 = (AV).x + (AV).y, hs1 = (AV).z + (AV).w;                                                      \
+            _Pragma("unroll") for (int bt = 0; bt < NBT; bt++) {                                                           \
+                const float4 xv = xrow[bt * 32 * P4 + 2 * (GG)];                                                           \
+                const float xs0 = xv.x + xv.y, xs1 = xv.z + xv.w;                                                          \
+                acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.x, acc[bt][0], 0, 0, 0);                      \
+                acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, xv.y, acc[bt][1], 0, 0, 0);                      \
+                acc[bt][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hs0, xs0, acc[bt][2], 0, 0, 0);                          \
+                acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.z, acc[bt][0], 0, 0, 0);                      \
+                acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, xv.w, acc[bt][1], 0, 0, 0);                      \
+                acc[bt][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hs1, xs1, acc[bt][2], 0, 0, 0);                          \
+            }                                                                                                              \
+        }
+        if (active) {
+            static_assert(G % AD == 0 && G >= 2 * AD && AD == 8, "k loop (the barrier's vmcnt(8) counts the AD fetches of the next residue)");
+#pragma unroll
+            for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = ap[(size_t)(AD + d) * gstride]; DDC_STEP3(av, d); }
+            if (rn < inv) dma_rows(rn, cur ^ 1);                      // behind the first 2 AD taps fetches
+            const float4 *apn = reinterpret_cast<const float4 *>(Ht) + ((size_t)min(rn, inv - 1) * G * Cpad + c_base + i) * 2 + hi;      // next residue's taps (the last residue re-reads its own)
+            for (int g = AD; g < G - AD; g += AD) {                    // straight-line body: the loads stay AD groups ahead of their use
+#pragma unroll
+                for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = ap[(size_t)(g + AD + d) * gstride]; DDC_STEP3(av, g + d); }
+            }
+#pragma unroll
+            for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = apn[(size_t)d * gstride]; DDC_STEP3(av, G - AD + d); }      // the last AD groups: the fetches run into the next residue
+            ap = apn;
+        } else if (rn < inv) dma_rows(rn, cur ^ 1);
+#undef DDC_STEP3
+        if (rn < inv) pieces_landed_then_barrier(!active);            // every wave is through with this buffer and has its pieces of the other one; the AD newest
+                                                                      // operations are the next residue's first taps fetches, which stay in flight across the bin stores
+        if (active) {
+            // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (c >= n_channels) continue;
+                int mm = (r - geom[c].offsetbin) % inv; if (mm < 0) mm += inv;
+                float2 *dst = Ct + ((size_t)mm * Cpad + c) * nbp + b_base + i;
+#pragma unroll
+                for (int bt = 0; bt < NBT; bt++)
+                    if (b_base + bt * 32 + i < n_blocks) {
+                        const float p1 = acc[bt][0][e], p2 = acc[bt][1][e], p3 = acc[bt][2][e];
+                        dst[bt * 32] = make_float2((p1 - p2) * scale, (p3 - p1 - p2) * scale);      // (streaming `nt` stores here and in the forward passes: the consumers got 3-5 us slower each)
+                    }
+            }
+        }
+        if (rn >= inv) break;
+        r = rn; cur ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------ the residual shift: data-independent bookkeeping
 // Both tables are BLOCK-MAJOR (index b * n_channels + c): a wave's lanes are consecutive channels, so every access below is coalesced (the general
 // path's [channel][block] arrays cost one scattered 4-byte store per lane and step: 20 us for 256 x 64 entries).
 // k_ddc_chain_t: per channel, the (decimation_remain, starting_phase, output offset) of every block of the call (libcsdr_gpl.c:153-158, float32 phase
 // bookkeeping exactly as decimating_shift_addition_cc returns it) and the samples produced.
-__global__ __launch_bounds__(64) void k_ddc_chain_t(DdcChanState *__restrict__ state, const ChanGeom *__restrict__ geom, int n_channels, int n_blocks,
-                                                    int post_in, int post_dec, int *__restrict__ blk_remain, float *__restrict__ blk_phase, int *__restrict__ blk_off,
-                                                    int *__restrict__ counts)
+struct DdcChainJob {                                                 // one call's data-independent bookkeeping (set k of the plan)
+    DdcChanState *state; const ChanGeom *geom; int n_channels, n_blocks, post_in, post_dec, kmax;
+    int *blk_remain; float *blk_phase; int *blk_off; int *counts; float2 *R;
+};
+__device__ __forceinline__ void ddc_chain_body(const DdcChainJob &j, int c)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= n_channels) return;
-    DdcChanState s = state[c];
-    const float r = geom[c].rate2;
+    if (c >= j.n_channels) return;
+    DdcChanState s = j.state[c];
+    const float r = j.geom[c].rate2;
+    const int post_in = j.post_in, post_dec = j.post_dec, n_channels = j.n_channels;
     const int sh = (post_dec & (post_dec - 1)) == 0 ? __ffs(post_dec) - 1 : -1;    // post_decimation is 2 for every power-of-two decimation: a shift, not a division
     int off = 0;
-    for (int b = 0; b < n_blocks; b++) {                              // 64 strictly sequential steps on 4 waves: every dependent instruction counts
+    for (int b = 0; b < j.n_blocks; b++) {                            // 64 strictly sequential steps: every dependent instruction counts
         const size_t id = (size_t)b * n_channels + c;
-        blk_remain[id] = s.remain; blk_phase[id] = s.phase; blk_off[id] = off;
+        j.blk_remain[id] = s.remain; j.blk_phase[id] = s.phase; j.blk_off[id] = off;
         int k = 0, pos = s.remain;
         if (pos < post_in) { k = (sh >= 0 ? (post_in - 1 - pos) >> sh : (post_in - 1 - pos) / post_dec) + 1; pos += k * post_dec; }
         s.remain = pos - post_in;
@@ -219,32 +340,32 @@ __global__ __launch_bounds__(64) void k_ddc_chain_t(DdcChanState *__restrict__ s
         while (p < -PI_F) p += 2 * PI_F;
         s.phase = p; off += k;
     }
-    state[c] = s; counts[c] = off;
+    j.state[c] = s; j.counts[c] = off;
 }
+__global__ __launch_bounds__(64) void k_ddc_chain_t(DdcChainJob j) { ddc_chain_body(j, blockIdx.x * 64 + threadIdx.x); }
 // k_ddc_rot: the phasor recurrence (c, s) <- (c cd - s sd, s cd + c sd) of every (block, channel) chain from (cos, sin)(its starting phase), replayed in
 // float32 like libcsdr_gpl.c:141-152; every ROT_CK-th state is kept (R[kc * n_chains + id]), the consumer replays the < ROT_CK steps in between itself.
 constexpr int ROT_CK = 16;
-__global__ __launch_bounds__(64) void k_ddc_rot(const ChanGeom *__restrict__ geom, const float *__restrict__ blk_phase, float2 *__restrict__ R,
-                                                int n_chains, int n_channels, int kmax)
+__device__ __forceinline__ void ddc_rot_body(const DdcChainJob &j, int id)
 {
-    const int id = blockIdx.x * 64 + threadIdx.x;
+    const int n_chains = j.n_channels * j.n_blocks;
     if (id >= n_chains) return;
-    const ChanGeom g = geom[id % n_channels];
-    const float cd = g.cosdelta, sd = g.sindelta, ph = blk_phase[id];
+    const ChanGeom g = j.geom[id % j.n_channels];
+    const float cd = g.cosdelta, sd = g.sindelta, ph = j.blk_phase[id];
     float co = (float)cos((double)ph), sn = (float)sin((double)ph);
-    for (int k0 = 0; k0 < kmax; k0 += ROT_CK) {
-        R[(size_t)(k0 / ROT_CK) * n_chains + id] = make_float2(co, sn);
+    for (int k0 = 0; k0 < j.kmax; k0 += ROT_CK) {
+        j.R[(size_t)(k0 / ROT_CK) * n_chains + id] = make_float2(co, sn);
 #pragma unroll
         for (int kk = 0; kk < ROT_CK; kk++) { const float c1 = co * cd - sn * sd, s1 = sn * cd + co * sd; co = c1; sn = s1; }
     }
 }
+__global__ __launch_bounds__(64) void k_ddc_rot(DdcChainJob j) { ddc_rot_body(j, blockIdx.x * 64 + threadIdx.x); }
 
 // ------------------------------------------------------------------ 512-point transforms in LDS: N = 512 = 8 x 8 x 8
 // n = 64 n1 + 8 n2 + n3, k = k1 + 8 k2 + 64 k3;  W^(nk) = W8^(n1 k1) W512^((8 n2 + n3) k1) W8^(n2 k2) W64^(n3 k2) W8^(n3 k3).
 // A workgroup of 256 threads holds 16 transforms (rows of I512_PITCH cells, one pad cell per 8: every stage's accesses are conflict free or 2-way).
 // Stage 1 works on values straight from global memory: thread (j = t & 15: transform, i = t >> 4) loads x_j[64 a + tp], a = 0..7, for its four
 // tp = i + 16 s, so the 16 lanes j of one load instruction read one 128-byte run; stages 2 and 3 are done by one wave per transform, in place.
-constexpr int I512_PITCH = 580;
 __device__ __forceinline__ int pad8(int idx) { return idx + (idx >> 3); }
 // row pitch for NT transforms per workgroup: the NT lanes of one global-load instruction (one per transform) then write NT rows: 580 (16 rows) and
 // 578 (8 rows) spread them over the banks (2-way at worst)
@@ -288,8 +409,12 @@ __device__ __forceinline__ void fft512_stages23(float2 *data, int t, const float
 // Xt[residue][block][q] (q = q' with the first fft_swap_sides folded in).  The natural-order spectrum never exists; no framing copy.
 template <int NT>
 __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ tail_out, float2 *__restrict__ Y,
-                                                    const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl, int n_blocks)
+                                                    const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl, int n_blocks, DdcChainJob cj)
 {
+    // rows blockIdx.y >= n_blocks are riders -- the call's data-independent chain tables (k_ddc_chain_t's work), done beside the transforms instead of in front
+    // of them (12 us of strictly sequential float bookkeeping on a handful of waves).  Measured: kernels of their own 0.175 ms per step, riders at the end of
+    // the grid 0.168, riders at the front (dispatched first, s_setprio 3) 0.172 -- beside a CU full of transform waves the chain runs 3 x slower than alone.
+    if ((int)blockIdx.y >= n_blocks) { ddc_chain_body(cj, (((int)blockIdx.y - n_blocks) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x); return; }
     extern __shared__ float4 lds_raw[];
     constexpr int PITCH = I512<NT>::pitch, NS = NT / 4, IW = 256 / NT;
     float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + NT * PITCH, *twb = tw + 512;
@@ -322,8 +447,10 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
 }
 
 // 128 = 16 (a) x 8 (c): n2 = 8 a + c, k2 = ka + 16 kc; W128^(n2 k2) = W16^(a ka) W128^(c ka) W8^(c kc).  8 lanes per transform, 32 transforms per workgroup.
-__global__ __launch_bounds__(256) void k_ddc_fwd128(const float2 *__restrict__ Y, float2 *__restrict__ Xt, const float2 *__restrict__ g_tw, int nbp, int n_blocks)
+__global__ __launch_bounds__(256) void k_ddc_fwd128(const float2 *__restrict__ Y, float2 *__restrict__ Xt, const float2 *__restrict__ g_tw, int nbp, int n_blocks, DdcChainJob cj)
 {
+    // the last row of workgroups (when the call carries riders): the phasor checkpoints of every (block, channel) chain (k_ddc_rot's work)
+    if (cj.R && blockIdx.y == gridDim.y - 1) { ddc_rot_body(cj, (int)blockIdx.x * 256 + (int)threadIdx.x); return; }
     __shared__ __attribute__((aligned(16))) float2 ex[32 * 144];       // [transform][c][18]: ka fastest, pitch 18
     const int t = threadIdx.x, tr = t >> 3, c = t & 7, r = blockIdx.x, b = blockIdx.y * 32 + tr;
     const bool ok = b < n_blocks;
@@ -588,36 +715,53 @@ int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, 
 bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->pre == 128 && !getenv("CSDR_AMD_DDC_FWD_OFF"); }
 
 // chain tables + phasor checkpoints of one call into set k (data independent)
+static DdcChainJob mfma_chain_job(DdcMfma *m, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
+{
+    DdcChainJob j;
+    j.state = d_state; j.geom = d_geom; j.n_channels = m->C; j.n_blocks = n_blocks; j.post_in = m->post_in; j.post_dec = m->post_dec; j.kmax = m->kmax;
+    j.blk_remain = m->d_blk_remain[k]; j.blk_phase = m->d_blk_phase[k]; j.blk_off = m->d_blk_off[k]; j.counts = m->d_counts[k]; j.R = m->d_R[k];
+    return j;
+}
 static int mfma_chains(DdcMfma *m, hipStream_t st, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
 {
-    hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, st, d_state, d_geom, m->C, n_blocks, m->post_in, m->post_dec,
-                       m->d_blk_remain[k], m->d_blk_phase[k], m->d_blk_off[k], m->d_counts[k]);
+    const DdcChainJob j = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
+    hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, st, j);
     CSDR_LAUNCH_CHECK();
-    const int n_chains = m->C * n_blocks;
-    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv(n_chains, 64)), dim3(64), 0, st, d_geom, m->d_blk_phase[k], m->d_R[k], n_chains, m->C, m->kmax);
+    hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv((size_t)m->C * n_blocks, 64)), dim3(64), 0, st, j);
     CSDR_LAUNCH_CHECK();
     return 0;
 }
 
-// forward transform of n_loc windows: window b starts at in[b inp - ovl] (positions < 0 come from `tail`); the result goes to Xt chunk `xt` with block pitch nbl
-static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt)
+// forward transform of n_loc windows: window b starts at in[b inp - ovl] (positions < 0 come from `tail`); the result goes to Xt chunk `xt` with block pitch nbl.
+// riders != nullptr: the call's chain tables and phasor checkpoints are computed by extra workgroups of the two passes (pass 1 carries the chains, pass 2 the
+// checkpoints, which need the chains' phases: stream order) instead of by kernels of their own.
+static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt, const DdcChainJob *riders)
 {
     if (n_loc <= 0) return 0;
+    DdcChainJob cj; memset(&cj, 0, sizeof cj);
+    if (riders) cj = *riders;
     const char *fv = getenv("CSDR_AMD_DDC_FWD");                      // pass 1: 16 columns n2 per workgroup (128-byte runs); "8": 64-byte runs, more workgroups per CU
 #define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
-                     reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc
+                     reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc, cj
     if (fv && atoi(fv) == 8) {
         const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
-        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc), dim3(256), lds, st, DDC_FWD_ARGS);
+        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc + (riders ? cdiv(cj.n_channels, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
     } else {
         const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
         { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_loc), dim3(256), lds, st, DDC_FWD_ARGS);
+        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_loc + (riders ? cdiv(cj.n_channels, 8 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
     }
 #undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_loc, 32)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(xt), m->d_tw, m->nbl, n_loc);
+    const bool rot_rides = riders && (size_t)cj.n_channels * cj.n_blocks <= 512u * 256u;
+    if (!rot_rides) cj.R = nullptr;
+    hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_loc, 32) + (rot_rides ? 1 : 0)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(xt),
+                       m->d_tw, m->nbl, n_loc, cj);
     CSDR_LAUNCH_CHECK();
+    if (riders && !rot_rides) {
+        hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv((size_t)m->C * cj.n_blocks, 64)), dim3(64), 0, st, *riders);
+        CSDR_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -638,7 +782,10 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     static const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
     hipStream_t st = inl ? mainst : m->side;
     int rc = 0;
-    if (inl && !chains_side) {
+    static const bool riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr;
+    const bool ride = inl && !chains_side && !spectra && !riders_off && ddc_mfma_can_forward(m);      // chain work done by extra workgroups of the forward passes
+    if (ride) {
+    } else if (inl && !chains_side) {
         rc = mfma_chains(m, mainst, k, n_blocks, d_state, d_geom); if (rc) return rc;
     } else {
         CSDR_HIP(hipEventRecord(m->ev_fork, mainst));                   // the producers of `in` queued so far; the readers of this set's tables (inline: same stream order)
@@ -665,7 +812,8 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
         }
         if (m->world == 1) {
-            rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k]); if (rc) return rc;
+            const DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
+            rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr); if (rc) return rc;
             m->flip ^= 1;
         } else {
             // rank g transforms blocks [g nbl, (g + 1) nbl): the root sends it the samples of its windows, stream[g nbl inp - ovl, min((g + 1) nbl, n) inp),
@@ -683,11 +831,11 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             rc = cm->group_end(cm); if (rc) return rc;
             cf32 *chunk = m->d_Xt[k] + (size_t)m->rank * m->inv * m->nbl * m->pre;
             if (m->rank == 0) {
-                rc = mfma_forward(m, st, in, m->d_tail[m->flip], nullptr, n_loc, chunk); if (rc) return rc;
+                rc = mfma_forward(m, st, in, m->d_tail[m->flip], nullptr, n_loc, chunk, nullptr); if (rc) return rc;
                 // the next call's overlap = the newest ovl samples of the stream (input_size >= overlap_length at this geometry)
                 CSDR_HIP(hipMemcpyAsync(m->d_tail[m->flip ^ 1], in + (size_t)n_blocks * inp - ovl, sizeof(cf32) * (size_t)ovl, hipMemcpyDeviceToDevice, st));
                 m->flip ^= 1;
-            } else { rc = mfma_forward(m, st, m->d_in_local + ovl, m->d_in_local, nullptr, n_loc, chunk); if (rc) return rc; }
+            } else { rc = mfma_forward(m, st, m->d_in_local + ovl, m->d_in_local, nullptr, n_loc, chunk, nullptr); if (rc) return rc; }
             rc = cm->all_gather(cm, m->d_Xt[k], 2 * (size_t)m->inv * m->nbl * m->pre, st); if (rc) return rc;      // in place: every rank's chunk sits at its offset
         }
     }
@@ -697,6 +845,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     return 0;
 }
 
+const char *ddc_mfma_kernel_name(const DdcMfma *m) { return m->gemm_three ? "k_ddc_gemm3" : "k_ddc_gemm"; }
 int ddc_mfma_set_profiling(DdcMfma *m, int on) { m->profiling = on != 0; m->ev_used = 0; m->prof_ms = 0; m->prof_launches = 0; return 0; }
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches)
 {
@@ -737,15 +886,27 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     const int per_res = (int)(grid.y * grid.z);
     int slots = n_cu / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
     bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
-    if (const char *e = getenv("CSDR_AMD_DDC_GEMM")) { if (!strcmp(e, "simple")) persist = false; else if (!strcmp(e, "persist") && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true; }
+    if (const char *e = getenv("CSDR_AMD_DDC_GEMM")) { if (!strcmp(e, "simple")) persist = false; else if (!strncmp(e, "persist", 7) && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true; }
     const size_t lds_use = persist ? 2 * lds : lds;
     const dim3 grid_use(persist ? (unsigned)slots : grid.x, grid.y, grid.z);
 #define DDC_GEMM_LAUNCH(NBTV, PV) do {                                                                                                               \
         if (lds_use > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<NBTV, PV>, lds_use); if (rc) return rc; }                    \
         hipLaunchKernelGGL((k_ddc_gemm<NBTV, PV>), grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]),           \
                            reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); } while (0)
-    if (nbt == 2) { if (persist) DDC_GEMM_LAUNCH(2, true); else DDC_GEMM_LAUNCH(2, false); }
-    else          { if (persist) DDC_GEMM_LAUNCH(1, true); else DDC_GEMM_LAUNCH(1, false); }
+    // three-product form with LDS-DMA staging: pre_decimation 128 (a spectra row = one 1-KiB piece), persistent shape; CSDR_AMD_DDC_GEMM=persist4 keeps the four-product kernel
+    const char *ge = getenv("CSDR_AMD_DDC_GEMM");
+    const bool three = persist && m->pre == 128 && !(ge && !strcmp(ge, "persist4"));
+    m->gemm_three = three;
+    if (three) {
+        if (nbt == 2) { const int rc = lds_attr_once((const void *)k_ddc_gemm3<2>, lds_use); if (rc) return rc;
+                        hipLaunchKernelGGL(k_ddc_gemm3<2>, grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]), reinterpret_cast<float2 *>(m->d_Ct),
+                                           d_geom, m->inv, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); }
+        else { const int rc = lds_attr_once((const void *)k_ddc_gemm3<1>, lds_use); if (rc) return rc;
+               hipLaunchKernelGGL(k_ddc_gemm3<1>, grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]), reinterpret_cast<float2 *>(m->d_Ct),
+                                  d_geom, m->inv, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); }
+    }
+    else if (nbt == 2) { if (persist) DDC_GEMM_LAUNCH(2, true); else DDC_GEMM_LAUNCH(2, false); }
+    else               { if (persist) DDC_GEMM_LAUNCH(1, true); else DDC_GEMM_LAUNCH(1, false); }
 #undef DDC_GEMM_LAUNCH
     CSDR_LAUNCH_CHECK();
     if (e1) CSDR_HIP(hipEventRecord(e1, st));

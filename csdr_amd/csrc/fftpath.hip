@@ -624,7 +624,7 @@ void csdr_amd_fastddc_inv_destroy(csdr_amd_fastddc_inv *f)
     delete f;
 }
 
-const char *csdr_amd_fastddc_inv_kernel_name(const csdr_amd_fastddc_inv *f) { return f->mf ? "k_ddc_gemm" : "k_ddc_fold_ct"; }
+const char *csdr_amd_fastddc_inv_kernel_name(const csdr_amd_fastddc_inv *f) { return f->mf ? ddc_mfma_kernel_name(f->mf) : "k_ddc_fold_ct"; }
 int csdr_amd_fastddc_inv_set_profiling(csdr_amd_fastddc_inv *f, int on) { return f->mf ? ddc_mfma_set_profiling(f->mf, on) : 0; }
 int csdr_amd_fastddc_inv_kernel_time(csdr_amd_fastddc_inv *f, double *total_ms, long *launches)
 {

@@ -86,7 +86,7 @@ def test_c4_bank_fused_forward(gpu, port):
     x = (rng.uniform(-1, 1, ddc.input_size * nb + 100) + 1j * rng.uniform(-1, 1, ddc.input_size * nb + 100)).astype(c64)
     rates = np.concatenate([vc.c4_rates(256)[3::8][:32], np.array([0.0, -0.2222, 0.3711, 0.125, 0.4999], f32)])
     outs = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=40, retune=(1, 35, 0.0517))
-    assert gpu.last_ddc_kernel == "k_ddc_gemm"
+    assert gpu.last_ddc_kernel in ("k_ddc_gemm", "k_ddc_gemm3")
     pspec, want = vc.fastddc_oracle_channels(x, tbw, D, rates, [c for c in range(nch) if c != 35])
     for c, w in want.items():
         assert outs[c].size == w.size, "channel %d" % c
