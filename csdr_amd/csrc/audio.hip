@@ -113,31 +113,28 @@ __global__ __launch_bounds__(256) void k_agc_peaks(const float *__restrict__ in,
     __syncthreads();
     if (threadIdx.x == 0) peaks[(size_t)blockIdx.y * (n_blocks + 2) + 2 + blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
 }
-__global__ void k_agc_gains(float *__restrict__ peaks, float *__restrict__ gains, const float *__restrict__ state, int block, int n_blocks, int n_streams, float reference)
-{   // one lane per stream: the short sequential chain of target gains (libcsdr.c:964-971)
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_streams) return;
-    const float *st = state + (size_t)s * (2 * block + 4) + 2 * block;
-    float *pk = peaks + (size_t)s * (n_blocks + 2);
-    float *g = gains + (size_t)s * (n_blocks + 1);
-    pk[0] = st[0]; pk[1] = st[1]; g[0] = st[2];
-    for (int j = 0; j < n_blocks; j++) {
-        float peak = pk[j + 2];
-        if (peak < pk[j + 1]) peak = pk[j + 1];
-        if (peak < pk[j]) peak = pk[j];
-        float target = reference / peak;
-        if (target > 50.f) target = 50.f;
-        g[j + 1] = target;
-    }
+// target gain of output block j (libcsdr.c:964-971): the peak of sequence blocks j, j+1, j+2 (the first two peaks of a call are the state's), capped at 50.
+// peaks: [n_streams][n_blocks + 2], entries 2.. = the new blocks' peaks (entries 0, 1 are not used: the state is read directly)
+__device__ __forceinline__ float agc_peak_at(const float *st_tail, const float *pk, int i) { return i < 2 ? st_tail[i] : pk[i]; }
+__device__ __forceinline__ float agc_gain_after(const float *st_tail, const float *pk, int j, float reference)
+{   // g[j + 1] of the reference's chain; g[0] = st_tail[2] (last_gain)
+    float peak = agc_peak_at(st_tail, pk, j + 2);
+    const float p1 = agc_peak_at(st_tail, pk, j + 1), p0 = agc_peak_at(st_tail, pk, j);
+    if (peak < p1) peak = p1;
+    if (peak < p0) peak = p0;
+    float target = reference / peak;
+    if (target > 50.f) target = 50.f;
+    return target;
 }
 __global__ __launch_bounds__(256) void k_agc_apply(const float *__restrict__ in, float *__restrict__ out, size_t in_pitch, size_t out_pitch,
-                                                   int block, int n_blocks, const float *__restrict__ state, const float *__restrict__ gains,
+                                                   int block, int n_blocks, const float *__restrict__ state, const float *__restrict__ peaks, float reference,
                                                    int16_t *__restrict__ out_s16, size_t s16_pitch)
 {   // grid (n_blocks, n_streams): output block j = sequence block j with the gain ramped from g[j] to g[j+1] (:973-978);
     // optionally convert_f_s16 (libcsdr.c:2397, x86 truncation semantics) of the result in the same pass (chains that end in `| convert_f_s16`)
     const int j = blockIdx.x; const size_t s = blockIdx.y;
     const float *x = agc_seq_block(state + s * (2 * block + 4), in + s * in_pitch, block, j);
-    const float g0 = gains[s * (n_blocks + 1) + j], g1 = gains[s * (n_blocks + 1) + j + 1];
+    const float *st_tail = state + s * (2 * block + 4) + 2 * block, *pk = peaks + s * (n_blocks + 2);
+    const float g0 = j ? agc_gain_after(st_tail, pk, j - 1, reference) : st_tail[2], g1 = agc_gain_after(st_tail, pk, j, reference);      // the short chain of target gains, evaluated where it is used
     float *y = out ? out + s * out_pitch + (size_t)j * block : nullptr;
     int16_t *z = out_s16 ? out_s16 + s * s16_pitch + (size_t)j * block : nullptr;
     for (int k = threadIdx.x; k < block; k += 256) {
@@ -152,7 +149,7 @@ __global__ __launch_bounds__(256) void k_agc_apply(const float *__restrict__ in,
     }
 }
 __global__ __launch_bounds__(256) void k_agc_update(const float *__restrict__ in, size_t in_pitch, int block, int n_blocks,
-                                                    float *__restrict__ state, const float *__restrict__ peaks, const float *__restrict__ gains)
+                                                    float *__restrict__ state, const float *__restrict__ peaks, float reference)
 {   // grid (1, n_streams): rotate the two look-ahead buffers (libcsdr.c:983-989)
     const size_t s = blockIdx.y;
     float *st = state + s * (2 * block + 4);
@@ -162,10 +159,12 @@ __global__ __launch_bounds__(256) void k_agc_update(const float *__restrict__ in
         const float nb2 = *(agc_seq_block(st, row, block, n_blocks + 1) + k);
         st[k] = nb1; st[block + k] = nb2;
     }
+    __syncthreads();                                                  // every thread has read the old look-ahead buffers
     if (threadIdx.x == 0) {
-        st[2 * block + 0] = peaks[s * (n_blocks + 2) + n_blocks];
-        st[2 * block + 1] = peaks[s * (n_blocks + 2) + n_blocks + 1];
-        st[2 * block + 2] = gains[s * (n_blocks + 1) + n_blocks];
+        const float *pk = peaks + s * (n_blocks + 2);
+        const float lg = agc_gain_after(st + 2 * block, pk, n_blocks - 1, reference);
+        const float p0 = agc_peak_at(st + 2 * block, pk, n_blocks), p1 = agc_peak_at(st + 2 * block, pk, n_blocks + 1);
+        st[2 * block + 0] = p0; st[2 * block + 1] = p1; st[2 * block + 2] = lg;
     }
 }
 
@@ -245,23 +244,26 @@ int csdr_amd_deemphasis_wfm_ff(csdr_amd_ctx *c, const float *in, float *out, int
 int csdr_amd_fastagc_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams, int n_blocks, int block,
                         size_t in_pitch, size_t out_pitch, float reference, float *state_io)
 {
-    return csdr_amd::fastagc_ff_s16(c, in, out, nullptr, n_streams, n_blocks, block, in_pitch, out_pitch, 0, reference, state_io);
+    return csdr_amd::fastagc_ff_s16(c, in, out, nullptr, n_streams, n_blocks, block, in_pitch, out_pitch, 0, reference, state_io, false);
 }
 
 } // extern "C"
 
 // fastagc_ff with an optional second output: the same samples through convert_f_s16 (used by the NFM chain object; out may be null)
+float *csdr_amd::fastagc_peaks_buffer(csdr_amd_ctx *c, int n_streams, int n_blocks)
+{
+    return (float *)c->get_scratch(3, sizeof(float) * (size_t)n_streams * (n_blocks + 2));
+}
+// have_peaks: the producer of `in` already wrote every new block's peak |x| to fastagc_peaks_buffer()[s * (n_blocks + 2) + 2 + j] (the NFM chain's de-emphasis kernel)
 int csdr_amd::fastagc_ff_s16(csdr_amd_ctx *c, const float *in, float *out, int16_t *out_s16, int n_streams, int n_blocks, int block,
-                             size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io)
+                             size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io, bool have_peaks)
 {
     if (n_blocks <= 0 || n_streams <= 0) return 0;
-    float *peaks = (float *)c->get_scratch(3, sizeof(float) * (size_t)n_streams * (2 * n_blocks + 3));
+    float *peaks = fastagc_peaks_buffer(c, n_streams, n_blocks);
     if (!peaks) return -2;
-    float *gains = peaks + (size_t)n_streams * (n_blocks + 2);
-    hipLaunchKernelGGL(k_agc_peaks, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, peaks); CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_agc_gains, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, peaks, gains, state_io, block, n_blocks, n_streams, reference); CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_agc_apply, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, out, in_pitch, out_pitch, block, n_blocks, state_io, gains, out_s16, s16_pitch); CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_agc_update, dim3(1, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, state_io, peaks, gains); CSDR_LAUNCH_CHECK();
+    if (!have_peaks) { hipLaunchKernelGGL(k_agc_peaks, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, peaks); CSDR_LAUNCH_CHECK(); }
+    hipLaunchKernelGGL(k_agc_apply, dim3(n_blocks, n_streams), dim3(256), 0, c->stream, in, out, in_pitch, out_pitch, block, n_blocks, state_io, peaks, reference, out_s16, s16_pitch); CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_agc_update, dim3(1, n_streams), dim3(256), 0, c->stream, in, in_pitch, block, n_blocks, state_io, peaks, reference); CSDR_LAUNCH_CHECK();
     return 0;
 }
 

@@ -33,7 +33,8 @@ void drop_fft_plans(hipStream_t st);      // fftpath.hip
 
 // fastagc_ff (audio.hip) with an optional convert_f_s16 output written in the same pass; `out` may be null
 int fastagc_ff_s16(struct ::csdr_amd_ctx *c, const float *in, float *out, int16_t *out_s16, int n_streams, int n_blocks, int block,
-                   size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io);
+                   size_t in_pitch, size_t out_pitch, size_t s16_pitch, float reference, float *state_io, bool have_peaks = false);
+float *fastagc_peaks_buffer(struct ::csdr_amd_ctx *c, int n_streams, int n_blocks);      // [n_streams][n_blocks + 2]; entries 2.. = peak |x| of the call's new blocks
 
 } // namespace csdr_amd
 

@@ -29,6 +29,7 @@
 //  * Outputs that need the previous block's tail (history) or do not fill a tile run on k_ddc_direct, a plain one-thread-per-
 //    output evaluation of the same model, which is also the fallback for shapes the matrix-core kernel does not cover.
 #include "common.hpp"
+#include "nfm_demod.hpp"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -160,14 +161,17 @@ __global__ __launch_bounds__(64) void k_ddc_corr(const float2 *__restrict__ ctab
     if (m >= n_rows) return;
     const float2 C = ctab[m];
     float c = C.x, s = C.y;
-    for (int k = 0; k < 1024; k++) {
-        if ((k & 31) == 16) {
-            const float2 ref = cmulf(C, dtab[k + 2048]);
+    // 1024 strictly sequential steps per lane: straight-line runs of 16 (the loop counter, the sample test and the branch were most of the 42 us this took)
+    for (int j = 0; j < 32; j++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const float c2 = c * cd - s * sd, s2 = s * cd + c * sd; c = c2; s = s2; }      // libcsdr_gpl.c:44-45
+        {
+            const float2 ref = cmulf(C, dtab[32 * j + 16 + 2048]);
             const float inv = 1.0f / (ref.x * ref.x + ref.y * ref.y);
-            corr[(size_t)m * 32 + (k >> 5)] = make_float2((c * ref.x + s * ref.y) * inv, (s * ref.x - c * ref.y) * inv);
+            corr[(size_t)m * 32 + j] = make_float2((c * ref.x + s * ref.y) * inv, (s * ref.x - c * ref.y) * inv);
         }
-        const float c2 = c * cd - s * sd, s2 = s * cd + c * sd;       // libcsdr_gpl.c:44-45
-        c = c2; s = s2;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const float c2 = c * cd - s * sd, s2 = s * cd + c * sd; c = c2; s = s2; }
     }
 }
 
@@ -245,10 +249,14 @@ struct DdcParams {
 // on every SIMD, so that one tile's LDS reads / epilogue overlap the other tile's matrix products (the per-tile chain is serial inside a wave).
 //   LDS: 16 ring buffers of RB bytes (pitch RB + 16: the 16 streams of a B-fragment read hit different banks) + reduction buffer + prefix table.
 //   DMA: a "row-step" fetches the next 1 KiB of all 16 streams (16 / (4 NT) instructions per wave).
-template <int RBL, int NT>
+// FUSE (the NFM chain, nfm.hip): the reducer does not store the decimated complex samples but demodulates them (fmdemod_quadri_cf | limit_ff) and stores the three
+// digit planes the de-emphasis FIR reads.  y[k - 1] of a tile's first output comes from the previous tile of the same workgroup (re-reduced from the other team's
+// partial sums, or handed over through `ylast` across groups); the FIRST output of a segment has its predecessor in another workgroup: it is left to
+// k_nfm_demod_boundary, for which the segment's first and last complex samples are still stored.
+template <int RBL, int NT, bool FUSE>
 __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
                                                        const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
-                                                       const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p)
+                                                       const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p, DdcFuse fz)
 {
     constexpr int RB = 1 << RBL, RP = RB + 16, SPW = 16 / (4 * NT);                   // SPW: streams fetched per wave in a row-step
     extern __shared__ float4 lds_raw[];
@@ -256,6 +264,7 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
     float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][4 waves][64 lanes]
     float *lcum = reinterpret_cast<float *>(red + 2 * NT * 256);                      // the prefix-sum table: a vector load from global memory inside the tile
                                                                                       // loop would need vmcnt(0), i.e. drain the whole DMA ring
+    float2 *ylast = reinterpret_cast<float2 *>(lcum + DDC_NGRAN * 16);                // FUSE: [2][16] last sample of the previous group's last tile
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     const int team = wv >> 2, w = wv & 3;
     for (int i = tid; i < DDC_NGRAN * 16; i += 256 * NT) lcum[i] = cum[i];            // (visible after the barrier that ends the prologue)
@@ -412,10 +421,38 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         if (active && w == (gi & 3)) {
             const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
             const int stream = sb * 16 + col;
-            if (stream < p.n_streams) {
-                float2 *dst = out + (size_t)stream * out_pitch + (8 * ti - p.k_out0) + 2 * q;
-                dst[0] = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
-                dst[1] = make_float2((a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+            const float2 y0 = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
+            const float2 y1 = make_float2((a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+            if (!FUSE) {
+                if (stream < p.n_streams) {
+                    float2 *dst = out + (size_t)stream * out_pitch + (8 * ti - p.k_out0) + 2 * q;
+                    dst[0] = y0; dst[1] = y1;
+                }
+            } else {
+                // predecessor of output 2q: lane (col, q - 1)'s second output; for q = 0 the previous tile's last output
+                float2 prev = make_float2(__shfl_up(y1.x, 16), __shfl_up(y1.y, 16));
+                if (q == 0 && it > 0) {
+                    if (team > 0) {                                                  // same group, previous team: its partial sums are complete (same barrier)
+                        const float4 *pb = red + ((gi & 1) * NT + team - 1) * 256 + 48 + col;
+                        const float4 pa = pb[0], pbv = pb[64], pc = pb[128], pd = pb[192];
+                        prev = make_float2((pa.z + pbv.z) + (pc.z + pd.z), (pa.w + pbv.w) + (pc.w + pd.w));
+                    } else prev = ylast[((gi - 1) & 1) * 16 + col];                  // previous group's last team: handed over (double buffered: the writer of this group is on its way)
+                }
+                if (team == NT - 1 && q == 3) ylast[(gi & 1) * 16 + col] = y1;
+                if (stream < p.n_streams) {
+                    const long kk = (long)(8 * ti - p.k_out0) + 2 * q;
+                    float2 *ydst = out + (size_t)stream * out_pitch + kk;
+                    if (it == 0 && q == 0) ydst[0] = y0;                             // the segment's first sample (k_nfm_demod_boundary demodulates it) ...
+                    if (it == n_it - 1 && q == 3) ydst[1] = y1;                      // ... and its last one (the next segment's / the trailing outputs' predecessor)
+                    int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
+                    int dg[3];
+                    if (!(it == 0 && q == 0)) {
+                        nfm_demod_digits(y0, prev, fz.max_amp, fz.q_per_amp, dg);
+                        pd0[0] = (int8_t)dg[0]; pd0[fz.plane_bytes] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes] = (int8_t)dg[2];
+                    }
+                    nfm_demod_digits(y1, y0, fz.max_amp, fz.q_per_amp, dg);
+                    pd0[1] = (int8_t)dg[0]; pd0[fz.plane_bytes + 1] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes + 1] = (int8_t)dg[2];
+                }
             }
         }
     }
@@ -469,6 +506,8 @@ __global__ __launch_bounds__(256) void k_ddc_save_hist(const uint8_t *__restrict
 }
 
 } // namespace
+
+namespace csdr_amd { long ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, size_t block_samples, csdr_complexf *out, size_t out_pitch, const DdcFuse *fuse, DdcFuseInfo *info); }
 
 struct csdr_amd_ddc {
     csdr_amd_ctx *ctx;
@@ -574,6 +613,16 @@ int csdr_amd_ddc_kernel_time(csdr_amd_ddc *d, double *total_ms, long *launches)
 
 long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, size_t block_samples, csdr_complexf *out, size_t out_pitch)
 {
+    return csdr_amd::ddc_process_fused(d, in, in_pitch, block_samples, out, out_pitch, nullptr, nullptr);
+}
+
+} // extern "C"
+
+// The front end's call; fuse != nullptr (the NFM chain): the matrix-core kernel writes the limited demodulator output as digit planes instead of y, *info says
+// which outputs are left for k_nfm_demod_boundary (their complex samples are in `out`).
+long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, size_t block_samples, csdr_complexf *out, size_t out_pitch, const DdcFuse *fuse, DdcFuseInfo *info)
+{
+    if (info) { memset(info, 0, sizeof *info); }
     csdr_amd_ctx *c = d->ctx; hipStream_t st = c->stream;
     if (d->ended) return fail_msg(-3, "ddc: stream already ended by a block that was not a multiple of 1024 samples; reset first");
     if (block_samples == 0) return 0;
@@ -647,16 +696,21 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
             if (n_seg < 1) n_seg = 1;
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
-            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float);
-            { const int arc = lds_attr_once(nt == 2 ? (const void *)k_ddc_mfma<rbl, 2> : (const void *)k_ddc_mfma<rbl, 1>, lds); if (arc) return arc; }
-            if (e0) CSDR_HIP(hipEventRecord(e0, st));
-            if (nt == 2)
-                hipLaunchKernelGGL((k_ddc_mfma<rbl, 2>), dim3(n_wsb, n_seg), dim3(512), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,
-                                   reinterpret_cast<float2 *>(out), out_pitch, p);
-            else
-                hipLaunchKernelGGL((k_ddc_mfma<rbl, 1>), dim3(n_wsb, n_seg), dim3(256), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, d->d_corr,
-                                   reinterpret_cast<float2 *>(out), out_pitch, p);
+            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2);
+            DdcFuse fz; memset(&fz, 0, sizeof fz); if (fuse) fz = *fuse;
+#define DDC_LAUNCH(NTV, FV, THREADS) do {                                                                                                                  \
+                const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV>, lds); if (arc) return arc;                                              \
+                if (e0) CSDR_HIP(hipEventRecord(e0, st));                                                                                                      \
+                hipLaunchKernelGGL((k_ddc_mfma<rbl, NTV, FV>), dim3(n_wsb, n_seg), dim3(THREADS), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, \
+                                   d->d_corr, reinterpret_cast<float2 *>(out), out_pitch, p, fz); } while (0)
+            if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, 512); else DDC_LAUNCH(1, true, 256); }
+            else      { if (nt == 2) DDC_LAUNCH(2, false, 512); else DDC_LAUNCH(1, false, 256); }
+#undef DDC_LAUNCH
             CSDR_LAUNCH_CHECK();
+            if (fuse && info) {
+                info->fused = true; info->n_lead = (long)(8 * ta - k_first); info->seg_outputs = 8L * p.tiles_per_seg; info->n_seg = n_seg;
+                info->trail_first = (long)(8 * (tb + 1) - k_first); info->n_trail = (long)(k_hi - 8 * (tb + 1) + 1);
+            }
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
             d->kernel_name = "k_ddc_mfma";
         } else d->kernel_name = "k_ddc_direct";
@@ -681,6 +735,8 @@ long csdr_amd_ddc_process(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, s
     d->B += T; d->next_k += n_out;
     return n_out;
 }
+
+extern "C" {
 
 // Test hook (tests/test_ddc_table_cpu.py): evaluates ONE tile on the CPU exactly the way k_ddc_mfma does -- same table, same lane/byte
 // layout, same K-range split over four waves, same snapshot / half-K-step handling of chunk boundaries, same post factors -- so the

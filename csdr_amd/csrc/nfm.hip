@@ -14,6 +14,7 @@
 //   outputs x 16 channels x 256 inputs per tile, band 93 % dense, one resident weight set): k_nfm_deemph_mfma.  Digit pairs of equal weight
 //   share an accumulator; only the (low x low) pair is dropped (2^-31 of full scale).
 #include "common.hpp"
+#include "nfm_demod.hpp"
 #include <math.h>
 #include <string.h>
 #include <string>
@@ -30,23 +31,33 @@ constexpr int NFM_FIR_NK = 4;              // 64-input K-steps per tile of 16 ou
 __global__ __launch_bounds__(256) void k_nfm_demod_limit(const cf32 *__restrict__ y, size_t y_pitch, int n, const cf32 *__restrict__ last,
                                                          int8_t *__restrict__ planes, size_t plane_bytes, size_t dl_pitch, int dl_fill, float max_amp, float q_per_amp)
 {
-    const float Kf = 0.340447550238101026565118445432744920253753662109375f;   // libcsdr.c:1021
     const int s = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const cf32 *src = y + (size_t)s * y_pitch;
     const cf32 x = src[k];
     const cf32 p = k ? src[k - 1] : last[s];
-    const float dq = x.q - p.q, di = x.i - p.i;
-    const float num = x.i * dq - x.q * di, den = x.i * x.i + x.q * x.q;
-    float rd = __builtin_amdgcn_rcpf(den);                                     // same evaluation as k_fmdemod (audio.hip)
-    rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
-    float v = (den != 0.f) ? (Kf * num) * rd : 0.f;
-    v = (max_amp < v) ? max_amp : v; v = (-max_amp > v) ? -max_amp : v;        // limit_ff libcsdr.c:1133-1136
-    int qv = __float2int_rn(v * q_per_amp);                                    // |qv| <= NFM_XQ
-    const int d2 = ((qv + 128) & 255) - 128; qv = (qv - d2) >> 8;
-    const int d1 = ((qv + 128) & 255) - 128; qv = (qv - d1) >> 8;
+    int d[3]; nfm_demod_digits(make_float2(x.i, x.q), make_float2(p.i, p.q), max_amp, q_per_amp, d);
     int8_t *dst = planes + (size_t)s * dl_pitch + dl_fill + k;
-    dst[0] = (int8_t)qv; dst[plane_bytes] = (int8_t)d1; dst[2 * plane_bytes] = (int8_t)d2;
+    dst[0] = (int8_t)d[0]; dst[plane_bytes] = (int8_t)d[1]; dst[2 * plane_bytes] = (int8_t)d[2];
+}
+
+// The same for the outputs the fused front end left over (DdcFuseInfo): the leading outputs [0, n_lead) (plain kernel), the first output of every segment of the
+// matrix-core kernel (its predecessor belongs to another workgroup) and the trailing outputs; y holds these samples and their predecessors.
+__global__ __launch_bounds__(64) void k_nfm_demod_boundary(const cf32 *__restrict__ y, size_t y_pitch, const cf32 *__restrict__ last, DdcFuseInfo info,
+                                                           DdcFuse f)
+{
+    const int s = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    long k;
+    if (j < info.n_lead) k = j;
+    else if (j < info.n_lead + info.n_seg) k = info.n_lead + (long)(j - info.n_lead) * info.seg_outputs;
+    else if (j < info.n_lead + info.n_seg + info.n_trail) k = info.trail_first + (j - info.n_lead - info.n_seg);
+    else return;
+    const cf32 *src = y + (size_t)s * y_pitch;
+    const cf32 x = src[k];
+    const cf32 p = k ? src[k - 1] : last[s];
+    int d[3]; nfm_demod_digits(make_float2(x.i, x.q), make_float2(p.i, p.q), f.max_amp, f.q_per_amp, d);
+    int8_t *dst = f.planes + (size_t)s * f.dl_pitch + f.dl_fill + k;
+    dst[0] = (int8_t)d[0]; dst[f.plane_bytes] = (int8_t)d[1]; dst[2 * f.plane_bytes] = (int8_t)d[2];
 }
 
 // out[s][i] = sum_t taps[t] x[s][i + t] for i < n_tiles * 16, x given as digit planes.  One workgroup = 16 channels x NFM_FIR_SPAN consecutive
@@ -58,10 +69,14 @@ constexpr int NFM_FIR_SPAN = 64;                                   // tiles per 
 constexpr int NFM_FIR_ROW = 16 * NFM_FIR_SPAN + 64 * NFM_FIR_NK;   // staged bytes per channel and plane (1280)
 constexpr int NFM_FIR_RP = NFM_FIR_ROW + 16;                       // LDS pitch: odd multiple of 16 bytes (the 16 channels of a B read hit different banks)
 
+// peaks != nullptr (fastagc block = the workgroup's span of 1024 outputs): the workgroup also leaves max |out| of its span per channel at
+// peaks[stream * peak_pitch + 2 + blockIdx.x] -- fastagc_ff's first pass (libcsdr.c:957-962) without reading the audio back.
 __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restrict__ planes, size_t plane_bytes, size_t dl_pitch, const v4i *__restrict__ frags,
-                                                         float scale, float *__restrict__ out, size_t out_pitch, int n_tiles, int n_streams)
+                                                         float scale, float *__restrict__ out, size_t out_pitch, int n_tiles, int n_streams,
+                                                         float *__restrict__ peaks, int peak_pitch)
 {
     __shared__ __attribute__((aligned(16))) int8_t lds[3 * 16 * NFM_FIR_RP];
+    __shared__ float wpeak[4][16];
     const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, q = lane >> 4, wv = tid >> 6;
     v4i A[NFM_FIR_NK * 3];
 #pragma unroll
@@ -79,6 +94,7 @@ __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restric
     __syncthreads();
     const int stream = (int)blockIdx.y * 16 + col;
     const int8_t *row = lds + col * NFM_FIR_RP + 16 * q;
+    float pmax = 0.f;
     for (int t = wv; t < nt; t += 4) {
         const int8_t *src = row + 16 * t;
         v4i acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -107,6 +123,14 @@ __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restric
         }
         if (stream < n_streams)
             *reinterpret_cast<float4 *>(out + (size_t)stream * out_pitch + 16 * (size_t)(tile0 + t) + 4 * q) = r;
+        pmax = fmaxf(fmaxf(pmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+    }
+    if (peaks) {                                                      // uniform
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 16)); pmax = fmaxf(pmax, __shfl_xor(pmax, 32));      // over q: the channel's outputs of this wave's tiles
+        if (q == 0) wpeak[wv][col] = pmax;
+        __syncthreads();
+        if (tid < 16 && (int)blockIdx.y * 16 + tid < n_streams)
+            peaks[(size_t)((int)blockIdx.y * 16 + tid) * peak_pitch + 2 + blockIdx.x] = fmaxf(fmaxf(wpeak[0][tid], wpeak[1][tid]), fmaxf(wpeak[2][tid], wpeak[3][tid]));
     }
 }
 
@@ -159,6 +183,8 @@ __global__ void k_nfm_store_last(const cf32 *__restrict__ y, size_t y_pitch, int
 }
 
 } // namespace
+
+namespace csdr_amd { long ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_pitch, size_t block_samples, csdr_complexf *out, size_t out_pitch, const DdcFuse *fuse, DdcFuseInfo *info); }
 
 struct csdr_amd_nfm {
     csdr_amd_ctx *ctx;
@@ -242,12 +268,22 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
 {
     csdr_amd_ctx *c = w->ctx; hipStream_t st = c->stream;
     const int S = w->n_streams;
-    const long n_y = csdr_amd_ddc_process(w->ddc, in, in_pitch, block_samples, w->d_y, w->y_pitch);
+    // front end; on its matrix-core path the reducer epilogue demodulates, limits and writes the digit planes itself (the decimated complex stream never goes
+    // to HBM: only the samples at workgroup / kernel boundaries do, for k_nfm_demod_boundary).  CSDR_AMD_NFM_FUSE=0: the separate pass over y.
+    static const bool fuse_off = getenv("CSDR_AMD_NFM_FUSE") && atoi(getenv("CSDR_AMD_NFM_FUSE")) == 0;
+    DdcFuse fz; fz.planes = w->d_planes; fz.plane_bytes = w->plane_bytes; fz.dl_pitch = w->dl_pitch; fz.dl_fill = w->dl_fill; fz.max_amp = w->limit; fz.q_per_amp = NFM_XQ / w->limit;
+    DdcFuseInfo fi; memset(&fi, 0, sizeof fi);
+    const long n_y = ddc_process_fused(w->ddc, in, in_pitch, block_samples, w->d_y, w->y_pitch, fuse_off ? nullptr : &fz, &fi);
     if (n_y < 0) return n_y;
     if (n_y == 0) return 0;
     if ((size_t)n_y > w->max_y) return fail_msg(-3, "nfm: front end produced more than the planned %zu samples", w->max_y);
-    // fmdemod_quadri_cf | limit_ff, appended behind the filter's unconsumed input
-    hipLaunchKernelGGL(k_nfm_demod_limit, dim3(cdiv(n_y, 256), S), dim3(256), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, w->d_planes, w->plane_bytes, w->dl_pitch, w->dl_fill, w->limit, NFM_XQ / w->limit);
+    if (fi.fused) {
+        const long nb_out = fi.n_lead + fi.n_seg + fi.n_trail;
+        hipLaunchKernelGGL(k_nfm_demod_boundary, dim3(cdiv(nb_out, 64), S), dim3(64), 0, st, w->d_y, w->y_pitch, w->d_last, fi, fz);
+    } else {
+        // fmdemod_quadri_cf | limit_ff, appended behind the filter's unconsumed input
+        hipLaunchKernelGGL(k_nfm_demod_limit, dim3(cdiv(n_y, 256), S), dim3(256), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, w->d_planes, w->plane_bytes, w->dl_pitch, w->dl_fill, w->limit, NFM_XQ / w->limit);
+    }
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_nfm_store_last, dim3(cdiv(S, 64)), dim3(64), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, S);
     CSDR_LAUNCH_CHECK();
@@ -261,13 +297,17 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
         {
             const int n_tiles = ne / 16, n_sb = (S + 15) / 16;
             const int gx = (n_tiles + NFM_FIR_SPAN - 1) / NFM_FIR_SPAN;
+            // fastagc's peak pass rides in the de-emphasis kernel when an AGC block is exactly a workgroup's span
+            const bool fuse_peaks = w->agc_block == 16 * NFM_FIR_SPAN && !(getenv("CSDR_AMD_NFM_FUSE") && atoi(getenv("CSDR_AMD_NFM_FUSE")) == 0);
+            float *peaks = fuse_peaks ? fastagc_peaks_buffer(c, S, nb) : nullptr;
+            if (fuse_peaks && !peaks) return -2;
             hipLaunchKernelGGL(k_nfm_deemph_mfma, dim3(gx, n_sb), dim3(256), 0, st, w->d_planes, w->plane_bytes, w->dl_pitch, (const v4i *)w->d_fir_frags, w->fir_scale,
-                               w->d_de, w->a_pitch, n_tiles, S);
+                               w->d_de, w->a_pitch, n_tiles, S, peaks, nb + 2);
             CSDR_LAUNCH_CHECK();
+            // fastagc_ff | convert_f_s16 in one pass (the float audio is written only when the caller wants the parity tap)
+            int rc = fastagc_ff_s16(c, w->d_de, audio_f, audio_s16, S, nb, w->agc_block, w->a_pitch, out_pitch, out_pitch, w->agc_ref, w->d_agc_state, fuse_peaks);
+            if (rc) return rc;
         }
-        // fastagc_ff | convert_f_s16 in one pass (the float audio is written only when the caller wants the parity tap)
-        int rc = fastagc_ff_s16(c, w->d_de, audio_f, audio_s16, S, nb, w->agc_block, w->a_pitch, out_pitch, out_pitch, w->agc_ref, w->d_agc_state);
-        if (rc) return rc;
     }
     // keep the unconsumed filter input in front
     const int rem = n_in - ne;
