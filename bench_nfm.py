@@ -103,11 +103,18 @@ def main():
     L.csdr_amd_ddc_kernel_time(fe, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_ddc_kernel_name(fe).decode()
     if rank == 0:
-        tr = bc.pmc_traffic(kname, {"channels_per_gpu": S, "block_samples_per_channel": T})
-        traffic, traffic_src = tr if tr else (None, None)
         samples = S * T * args.steps * world
         k_avg_ms = kms.value / max(kl.value, 1)
-        algo = (2.0 + 8.0 / D) * S * T                      # front-end kernel: 2 B of u8 IQ in + one complexf per D samples out
+        # front-end kernel: 2 B of u8 IQ in per sample; out per D samples: one complexf (the stand-alone front end), or -- inside the chain object, whose reducer
+        # epilogue demodulates and limits -- the three digit bytes the de-emphasis FIR reads (CSDR_AMD_NFM_FUSE=0 restores the complexf store)
+        fused = (not args.front_end_only) and os.environ.get("CSDR_AMD_NFM_FUSE", "1") != "0" and kname.startswith("k_ddc_mfma")
+        algo = (2.0 + (3.0 if fused else 8.0) / D) * S * T
+        if fused:
+            kname += " (fused fmdemod_quadri_cf | limit_ff epilogue)"
+        tr = bc.pmc_traffic("k_ddc_mfma", {"channels_per_gpu": S, "block_samples_per_channel": T})
+        traffic, traffic_src = tr if tr else (None, None)
+        if traffic and not (0.8 < traffic / algo < 1.25):
+            traffic, traffic_src = None, None                 # a summary of the other (fused / unfused) variant
         res = {"metric": "complex MS/s in->out, NFM chain @2.4 MS/s x N channels", "value": round(samples / wall / 1e6, 1), "unit": "complex MS/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
