@@ -203,6 +203,11 @@ def main():
             tr = bc.pmc_traffic(kname, {"channels": args.channels, "blocks_per_step": nb})
             if tr:
                 res["roofline"]["traffic"], res["roofline"]["traffic_source"] = tr
+            if kname.startswith("k_ddc_gemm3"):
+                # ALGORITHMIC flops (4 real multiply-adds per complex one, fastddc.c:126-141) over the kernel's time; the kernel itself issues 3 (Gauss), i.e. the
+                # matrix pipe is busy for 3/4 of this fraction
+                res["roofline"]["executed_flops_per_launch"] = 0.75 * flops
+                res["roofline"]["matrix_pipe_frac"] = round(0.75 * tf / bc.FP32_PEAK_TFLOPS, 4)
         else:
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": None, "peak": bc.FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                                "note": "general kernels (geometry outside the matrix-core path): no per-kernel timing"}
