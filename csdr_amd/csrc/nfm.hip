@@ -270,7 +270,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
     const int S = w->n_streams;
     // front end; on its matrix-core path the reducer epilogue demodulates, limits and writes the digit planes itself (the decimated complex stream never goes
     // to HBM: only the samples at workgroup / kernel boundaries do, for k_nfm_demod_boundary).  CSDR_AMD_NFM_FUSE=0: the separate pass over y.
-    static const bool fuse_off = getenv("CSDR_AMD_NFM_FUSE") && atoi(getenv("CSDR_AMD_NFM_FUSE")) == 0;
+    const char *fe = getenv("CSDR_AMD_NFM_FUSE"); const bool fuse_off = fe && atoi(fe) == 0;      // read per call: the tests switch it inside one process
     DdcFuse fz; fz.planes = w->d_planes; fz.plane_bytes = w->plane_bytes; fz.dl_pitch = w->dl_pitch; fz.dl_fill = w->dl_fill; fz.max_amp = w->limit; fz.q_per_amp = NFM_XQ / w->limit;
     DdcFuseInfo fi; memset(&fi, 0, sizeof fi);
     const long n_y = ddc_process_fused(w->ddc, in, in_pitch, block_samples, w->d_y, w->y_pitch, fuse_off ? nullptr : &fz, &fi);
@@ -298,7 +298,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
             const int n_tiles = ne / 16, n_sb = (S + 15) / 16;
             const int gx = (n_tiles + NFM_FIR_SPAN - 1) / NFM_FIR_SPAN;
             // fastagc's peak pass rides in the de-emphasis kernel when an AGC block is exactly a workgroup's span
-            const bool fuse_peaks = w->agc_block == 16 * NFM_FIR_SPAN && !(getenv("CSDR_AMD_NFM_FUSE") && atoi(getenv("CSDR_AMD_NFM_FUSE")) == 0);
+            const bool fuse_peaks = w->agc_block == 16 * NFM_FIR_SPAN && !fuse_off;
             float *peaks = fuse_peaks ? fastagc_peaks_buffer(c, S, nb) : nullptr;
             if (fuse_peaks && !peaks) return -2;
             hipLaunchKernelGGL(k_nfm_deemph_mfma, dim3(gx, n_sb), dim3(256), 0, st, w->d_planes, w->plane_bytes, w->dl_pitch, (const v4i *)w->d_fir_frags, w->fir_scale,

@@ -12,7 +12,7 @@ struct DdcFuse { int8_t *planes; size_t plane_bytes, dl_pitch; int dl_fill; floa
 // which outputs of a call the fused kernel could NOT demodulate itself (their predecessor was computed by another workgroup or kernel); y holds them
 struct DdcFuseInfo { bool fused; long n_lead, seg_outputs, n_seg, trail_first, n_trail; };
 
-// x = y[k], p = y[k - 1] (libcsdr.c:1040-1071, :1130-1137); digit j of round(v / max_amp * NFM_XQ) = d[0] * 65536 + d[1] * 256 + d[2]
+// x = y[k], p = y[k - 1] (libcsdr.c:1040-1071, :1130-1137); round(v / max_amp * NFM_XQ) = D0 * 65536 + D1 * 256 + D2 with Dj = (int8_t)d[j]
 __device__ __forceinline__ void nfm_demod_digits(float2 x, float2 p, float max_amp, float q_per_amp, int (&d)[3])
 {
     const float Kf = 0.340447550238101026565118445432744920253753662109375f;   // libcsdr.c:1021
@@ -22,10 +22,10 @@ __device__ __forceinline__ void nfm_demod_digits(float2 x, float2 p, float max_a
     rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
     float v = (den != 0.f) ? (Kf * num) * rd : 0.f;
     v = (max_amp < v) ? max_amp : v; v = (-max_amp > v) ? -max_amp : v;        // limit_ff libcsdr.c:1133-1136
-    int qv = __float2int_rn(v * q_per_amp);                                    // |qv| <= NFM_XQ
-    d[2] = ((qv + 128) & 255) - 128; qv = (qv - d[2]) >> 8;
-    d[1] = ((qv + 128) & 255) - 128; qv = (qv - d[1]) >> 8;
-    d[0] = qv;
+    const int qv = __float2int_rn(v * q_per_amp);                              // |qv| <= NFM_XQ
+    // balanced base-256 digits: d2 = sext8(qv), then (qv - d2) >> 8 = (qv + 128) >> 8, and so on.  The callers store the LOW BYTE of each entry, so the
+    // sign extensions are never computed: two add / shift pairs instead of ten integer operations per sample
+    d[2] = qv; d[1] = (qv + 128) >> 8; d[0] = (d[1] + 128) >> 8;
 }
 
 } // namespace csdr_amd

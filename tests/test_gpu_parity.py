@@ -421,6 +421,30 @@ def test_nfm_chain_device_resident(gpu, port, mode):
         assert d.max() <= 1 and (d > 0).mean() < 0.05
 
 
+def test_nfm_fused_epilogue_is_bit_identical(gpu, monkeypatch):
+    """The chain object's front end demodulates / limits in its reducer epilogue and leaves the samples at workgroup and kernel boundaries to
+    k_nfm_demod_boundary; fastagc's peaks come from the de-emphasis kernel.  With CSDR_AMD_NFM_FUSE=0 the same object runs the separate passes over the
+    decimated stream: both must give the SAME bits -- 19 channels (a partly filled 16-stream row), ragged block sizes (leading / trailing edge outputs of every
+    length, blocks below the matrix-core kernel's minimum), an AGC block that is NOT the de-emphasis kernel's span."""
+    n = 1024 * 700
+    u8 = np.stack([to_u8(fm_signal(np.random.default_rng(6000 + s), n, dev=4e3 / 2.4e6, offset=0.03)) for s in range(19)])
+    for agc_block, blocks in [(1024, [1024 * 300, 1024 * 150 + 512 * 2, 1024 * 249]), (512, [1024 * 120] * 5 + [1024 * 100])]:
+        outs = []
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("CSDR_AMD_NFM_FUSE", fuse)
+            res = []
+            for blk in (None, blocks):
+                if blk is None:
+                    res.append(gpu.nfm_chain(u8, 0.07, agc_block=agc_block))
+                else:
+                    res.append(gpu.nfm_chain(u8, 0.07, agc_block=agc_block, block=blk[1]))      # calls of blk[1] samples + a shorter last one
+            outs.append(res)
+        for a, b in zip(outs[0], outs[1]):
+            assert a[0].shape == b[0].shape and np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        d = np.abs(outs[0][0][0][:, :outs[0][1][0].shape[1]].astype(np.int32) - outs[0][1][0][:, :outs[0][0][0].shape[1]].astype(np.int32))
+        assert d.max() <= 1 and (d > 0).mean() < 0.05                    # one call vs blocks: other tile boundaries, other summation order
+
+
 # ---------------------------------------------------------------- f2 blocks
 def test_f2_elementwise(gpu, port):
     rng = np.random.default_rng(41)
