@@ -105,4 +105,17 @@ xi = xf[:2 * S4 * nb * inp]; yo = yf[:2 * S4 * nb * inp]
 ms = timeit(lambda: L.csdr_amd_fftfilt_process(f, xi.data_ptr(), yo.data_ptr(), nb, nb * inp, nb * inp))
 report("bandpass_fir_fft_cc fft=65536 taps=1023 (64 streams x 16 blocks)", ms, 16 * S4 * nb * inp, S4 * nb * inp)
 L.csdr_amd_fftfilt_destroy(f)
+
+# ---- IMA ADPCM codec (f3): a serial state machine per stream (one lane per stream).  The call's time is the per-stream chain (~55 dependent instructions per sample at
+# one wave instruction per ~5 cycles = ~190 ns per sample) whatever the stream count, up to 2 x 1024 x 64 = 131072 streams; staging the rows through LDS for coalesced
+# accesses, the step table in LDS and spreading the streams over more waves were all measured and changed nothing (profiles/r2_notes.md)
+for S5, n5 in ((4096, 48000), (65536, 12000)):
+    x16 = torch.randint(-20000, 20000, (S5 * n5,), dtype=torch.int16, device="cuda")
+    enc = torch.empty(S5 * n5 // 2, dtype=torch.uint8, device="cuda"); dec = torch.empty(S5 * n5, dtype=torch.int16, device="cuda")
+    stt = torch.zeros(2 * S5, dtype=torch.int32, device="cuda")
+    report("encode_ima_adpcm_i16_u8 (%d streams x %d)" % (S5, n5),
+           timeit(lambda: L.csdr_amd_encode_ima_adpcm_i16_u8(ctx.h, x16.data_ptr(), enc.data_ptr(), S5, n5, n5, n5 // 2, stt.data_ptr()), reps=3, warm=1), 2.5 * S5 * n5, S5 * n5)
+    report("decode_ima_adpcm_u8_i16 (%d streams x %d)" % (S5, n5),
+           timeit(lambda: L.csdr_amd_decode_ima_adpcm_u8_i16(ctx.h, enc.data_ptr(), dec.data_ptr(), S5, n5 // 2, n5 // 2, n5, stt.data_ptr()), reps=3, warm=1), 2.5 * S5 * n5, S5 * n5)
+    del x16, enc, dec
 ctx.close()
