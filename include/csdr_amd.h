@@ -315,7 +315,13 @@ int  csdr_amd_fastddc_inv_block(csdr_amd_ctx *ctx, const csdr_complexf *d_spectr
  * fmdemod_quadri_cf | fractional_decimator_ff R | deemphasis_wfm_ff fs tau | convert_f_s16
  * for n_streams independent u8 IQ streams in one pass: each input byte is read from HBM once, each
  * audio sample written once.  Streaming: call repeatedly with consecutive blocks; all cross-block state
- * (shift phase, FIR/demod history, de-emphasis state, decimator position) lives in the object. */
+ * (shift phase, FIR/demod history, de-emphasis state, decimator position) lives in the object.
+ * Scope: an FM AUDIO chain.  Its matrix-core front end models the reference's float rotator as C_m D^k per 1024-sample chunk; for rates at which
+ * the reference's recurrence (libcsdr_gpl.c:44-45) drifts from that model (1e-5 .. 4e-5 per chunk at e.g. 0.05, 0.25) the deviation is a slowly
+ * varying complex factor common to y[k] and y[k-1], which fmdemod_quadri_cf cancels: the audio is within the stated tolerance at every rate
+ * (tests/test_edges_gpu.py::test_wfm_other_shift_rates), but the object's INTERNAL complex samples are not a substitute for
+ * `convert_u8_f | shift_addition_cc | fir_decimate_cc` at such rates.  The complex front end for that is csdr_amd_ddc_* below, which replays the
+ * drift per chunk (k_ddc_corr) and is held to 1e-5 on the complex samples themselves. */
 typedef struct csdr_amd_wfm csdr_amd_wfm;
 csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation,
                                   const float *host_taps, int taps_length, int frac_rate,
