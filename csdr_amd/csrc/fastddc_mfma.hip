@@ -46,7 +46,10 @@ struct DdcMfma {
     cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
     int pending_blocks[2]; int fill, drain;                            // set being filled next / folded next
     bool inline_set[2], chains_on_side[2];
-    bool gemm_three = false;                                           // the fold kernel of the last collect(): k_ddc_gemm3 (three real products) or k_ddc_gemm
+    bool gemm_three = false;
+    // the NEXT call's chain tables, computed one call ahead by riders of the inverse-transform kernel (data independent; valid for process() calls of equal size
+    // with no retune in between).  On the side stream beside the fold they cost more than they hid: 0.182 vs 0.167 ms per step.
+    DdcChanState *d_state_spec = nullptr, *last_state = nullptr; bool spec_valid = false, ahead_ok = false; int spec_set = 0, spec_blocks = 0;                                           // the fold kernel of the last collect(): k_ddc_gemm3 (three real products) or k_ddc_gemm
     hipStream_t side; hipEvent_t ev_ready[2], ev_free[2], ev_fork; bool free_recorded[2];
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
 // k_ddc_chain_t: per channel, the (decimation_remain, starting_phase, output offset) of every block of the call (libcsdr_gpl.c:153-158, float32 phase
 // bookkeeping exactly as decimating_shift_addition_cc returns it) and the samples produced.
 struct DdcChainJob {                                                 // one call's data-independent bookkeeping (set k of the plan)
-    DdcChanState *state; const ChanGeom *geom; int n_channels, n_blocks, post_in, post_dec, kmax;
+    DdcChanState *state, *state_out; const ChanGeom *geom; int n_channels, n_blocks, post_in, post_dec, kmax;      // state_out: where the advanced state goes (= state, or the shadow of tables computed ahead)
+    int mode;                                                       // riders of forward pass 1: 1 = the chain tables; 2 = the tables exist already (computed one call ahead): commit their state, phasor checkpoints
     int *blk_remain; float *blk_phase; int *blk_off; int *counts; float2 *R;
 };
 __device__ __forceinline__ void ddc_chain_body(const DdcChainJob &j, int c)
@@ -340,7 +344,7 @@ __device__ __forceinline__ void ddc_chain_body(const DdcChainJob &j, int c)
         while (p < -PI_F) p += 2 * PI_F;
         s.phase = p; off += k;
     }
-    j.state[c] = s; j.counts[c] = off;
+    j.state_out[c] = s; j.counts[c] = off;
 }
 __global__ __launch_bounds__(64) void k_ddc_chain_t(DdcChainJob j) { ddc_chain_body(j, blockIdx.x * 64 + threadIdx.x); }
 // k_ddc_rot: the phasor recurrence (c, s) <- (c cd - s sd, s cd + c sd) of every (block, channel) chain from (cos, sin)(its starting phase), replayed in
@@ -414,7 +418,14 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
     // rows blockIdx.y >= n_blocks are riders -- the call's data-independent chain tables (k_ddc_chain_t's work), done beside the transforms instead of in front
     // of them (12 us of strictly sequential float bookkeeping on a handful of waves).  Measured: kernels of their own 0.175 ms per step, riders at the end of
     // the grid 0.168, riders at the front (dispatched first, s_setprio 3) 0.172 -- beside a CU full of transform waves the chain runs 3 x slower than alone.
-    if ((int)blockIdx.y >= n_blocks) { ddc_chain_body(cj, (((int)blockIdx.y - n_blocks) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x); return; }
+    if ((int)blockIdx.y >= n_blocks) {
+        const int id = (((int)blockIdx.y - n_blocks) * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+        if (cj.mode == 2) {                                             // tables computed one call ahead: make their end state the current one, then the checkpoints
+            if (id < cj.n_channels) cj.state[id] = cj.state_out[id];
+            ddc_rot_body(cj, id);
+        } else ddc_chain_body(cj, id);
+        return;
+    }
     extern __shared__ float4 lds_raw[];
     constexpr int PITCH = I512<NT>::pitch, NS = NT / 4, IW = 256 / NT;
     float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + NT * PITCH, *twb = tw + 512;
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
 __global__ __launch_bounds__(256) void k_ddc_fwd128(const float2 *__restrict__ Y, float2 *__restrict__ Xt, const float2 *__restrict__ g_tw, int nbp, int n_blocks, DdcChainJob cj)
 {
     // the last row of workgroups (when the call carries riders): the phasor checkpoints of every (block, channel) chain (k_ddc_rot's work)
-    if (cj.R && blockIdx.y == gridDim.y - 1) { ddc_rot_body(cj, (int)blockIdx.x * 256 + (int)threadIdx.x); return; }
+    if (cj.R && blockIdx.y == gridDim.y - 1) { ddc_rot_body(cj, (int)blockIdx.x * 256 + (int)threadIdx.x); return; }      // (host: only behind a mode-1 pass 1)
     __shared__ __attribute__((aligned(16))) float2 ex[32 * 144];       // [transform][c][18]: ka fastest, pitch 18
     const int t = threadIdx.x, tr = t >> 3, c = t & 7, r = blockIdx.x, b = blockIdx.y * 32 + tr;
     const bool ok = b < n_blocks;
@@ -555,8 +566,13 @@ template <int NT> struct I256 { static constexpr int pitch = NT == 16 ? 292 : 29
 template <int NT>
 __global__ __launch_bounds__(256) void k_ddc_ifft256d_post(const float2 *__restrict__ Ct, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ R,
                                                            const float2 *__restrict__ g_tw, const int *__restrict__ blk_remain, const int *__restrict__ blk_off,
-                                                           const ChanGeom *__restrict__ geom, int Cpad, int nbp, int n_blocks, int n_channels, int scrap, int post_in)
+                                                           const ChanGeom *__restrict__ geom, int Cpad, int nbp, int n_blocks, int n_channels, int scrap, int post_in,
+                                                           DdcChainJob ahead, int n_riders)
 {
+    // riders (NT = 8 launch only; a multiple of 16 workgroups so that the main ones keep their XCD pairing): the NEXT call's chain tables, data independent, from the
+    // state this call's chain ended with (into the other table set and a shadow state: the next call commits them if it has the size assumed and nothing retuned)
+    if ((int)blockIdx.x < n_riders) { ddc_chain_body(ahead, (int)blockIdx.x * 256 + (int)threadIdx.x); return; }
+    const int bx = (int)blockIdx.x - n_riders;
     extern __shared__ float4 lds_raw[];
     constexpr int PITCH = I256<NT>::pitch, NS = NT / 4, IW = 256 / NT;
     float2 *data = reinterpret_cast<float2 *>(lds_raw), *tw = data + NT * PITCH;
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(256) void k_ddc_ifft256d_post(const float2 *__restr
     int c, b0;
     if (NT == 16) { c = blockIdx.y; b0 = blockIdx.x * 16; }
     else {   // linear id L = 16 g + 8 h + u: (channel, line) pair P = 8 g + u, half h: the two halves of a 128-byte bin line share an XCD
-        const int L = blockIdx.x, h = (L >> 3) & 1, P = (L >> 4) * 8 + (L & 7), nl = (n_blocks + 15) / 16;
+        const int L = bx, h = (L >> 3) & 1, P = (L >> 4) * 8 + (L & 7), nl = (n_blocks + 15) / 16;
         c = P / nl; b0 = (P - c * nl) * 16 + 8 * h;
         if (c >= n_channels) return;
     }
@@ -674,6 +690,7 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
         if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_free[k], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_state_spec, sizeof(DdcChanState) * (size_t)n_channels);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(m->d_Ht, 0, sizeof(float) * 2 * (size_t)m->Cpad * fft, ctx->stream);      // padded channel rows stay zero
     if (e != hipSuccess) { fail(e, "hipMalloc(fastddc matrix-core path)", __FILE__, __LINE__); ddc_mfma_destroy(m); return nullptr; }
@@ -697,12 +714,18 @@ void ddc_mfma_destroy(DdcMfma *m)
         if (m->ev_free[k]) (void)hipEventDestroy(m->ev_free[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    (void)hipFree(m->d_state_spec);
     for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete m;
 }
 
 // everything queued by submit / collect has finished (retunes and destruction)
-int ddc_mfma_quiesce(DdcMfma *m) { CSDR_HIP(hipStreamSynchronize(m->side)); CSDR_HIP(hipStreamSynchronize(m->ctx->stream)); return 0; }
+int ddc_mfma_quiesce(DdcMfma *m)
+{   // (before a retune: the tables computed ahead belong to the old rate / state)
+    CSDR_HIP(hipStreamSynchronize(m->side)); CSDR_HIP(hipStreamSynchronize(m->ctx->stream));
+    m->spec_valid = false;
+    return 0;
+}
 
 int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, int c_count)
 {
@@ -718,7 +741,7 @@ bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->
 static DdcChainJob mfma_chain_job(DdcMfma *m, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
 {
     DdcChainJob j;
-    j.state = d_state; j.geom = d_geom; j.n_channels = m->C; j.n_blocks = n_blocks; j.post_in = m->post_in; j.post_dec = m->post_dec; j.kmax = m->kmax;
+    j.state = d_state; j.state_out = d_state; j.mode = 1; j.geom = d_geom; j.n_channels = m->C; j.n_blocks = n_blocks; j.post_in = m->post_in; j.post_dec = m->post_dec; j.kmax = m->kmax;
     j.blk_remain = m->d_blk_remain[k]; j.blk_phase = m->d_blk_phase[k]; j.blk_off = m->d_blk_off[k]; j.counts = m->d_counts[k]; j.R = m->d_R[k];
     return j;
 }
@@ -740,25 +763,26 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *
     if (n_loc <= 0) return 0;
     DdcChainJob cj; memset(&cj, 0, sizeof cj);
     if (riders) cj = *riders;
+    const size_t rider_lanes = riders ? (cj.mode == 2 ? (size_t)cj.n_channels * cj.n_blocks : (size_t)cj.n_channels) : 0;      // mode 2: one lane per (block, channel) chain
     const char *fv = getenv("CSDR_AMD_DDC_FWD");                      // pass 1: 16 columns n2 per workgroup (128-byte runs); "8": 64-byte runs, more workgroups per CU
 #define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
                      reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc, cj
     if (fv && atoi(fv) == 8) {
         const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
-        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc + (riders ? cdiv(cj.n_channels, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
+        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc + (riders ? cdiv(rider_lanes, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
     } else {
         const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
         { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_loc + (riders ? cdiv(cj.n_channels, 8 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
+        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_loc + (riders ? cdiv(rider_lanes, 8 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
     }
 #undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
-    const bool rot_rides = riders && (size_t)cj.n_channels * cj.n_blocks <= 512u * 256u;
+    const bool rot_rides = riders && cj.mode == 1 && (size_t)cj.n_channels * cj.n_blocks <= 512u * 256u;      // mode 2: pass 1 did the checkpoints
     if (!rot_rides) cj.R = nullptr;
     hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_loc, 32) + (rot_rides ? 1 : 0)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(xt),
                        m->d_tw, m->nbl, n_loc, cj);
     CSDR_LAUNCH_CHECK();
-    if (riders && !rot_rides) {
+    if (riders && cj.mode == 1 && !rot_rides) {
         hipLaunchKernelGGL(k_ddc_rot, dim3(cdiv((size_t)m->C * cj.n_blocks, 64)), dim3(64), 0, st, *riders);
         CSDR_LAUNCH_CHECK();
     }
@@ -783,7 +807,14 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     hipStream_t st = inl ? mainst : m->side;
     int rc = 0;
     static const bool riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr;
-    const bool ride = inl && !chains_side && !spectra && !riders_off && ddc_mfma_can_forward(m);      // chain work done by extra workgroups of the forward passes
+    static const bool spec_off = getenv("CSDR_AMD_DDC_SPEC_OFF") != nullptr;
+    const bool fused_fwd = inl && !chains_side && !spectra && ddc_mfma_can_forward(m);
+    // Chain tables one call ahead: the previous process() call's inverse-transform kernel carried riders that computed the tables of THIS call (set k) from the
+    // state it ended with -- valid when this call has the size that was assumed and nothing retuned in between (ddc_mfma_quiesce).
+    const bool spec_hit = fused_fwd && m->spec_valid && m->spec_set == k && m->spec_blocks == n_blocks;
+    m->spec_valid = false;
+    const bool ride = fused_fwd && !riders_off;                        // chain work done by extra workgroups of the forward passes (hit: only the commit + the checkpoints)
+    m->last_state = d_state; m->ahead_ok = fused_fwd && !spec_off && !riders_off;
     if (ride) {
     } else if (inl && !chains_side) {
         rc = mfma_chains(m, mainst, k, n_blocks, d_state, d_geom); if (rc) return rc;
@@ -812,7 +843,8 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
         }
         if (m->world == 1) {
-            const DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
+            DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
+            if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }
             rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr); if (rc) return rc;
             m->flip ^= 1;
         } else {
@@ -918,6 +950,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     const int pairs = m->C * cdiv(n_blocks, 16);
     const dim3 g16(cdiv(n_blocks, 16), m->C), g8(cdiv(pairs, 8) * 16);
 #define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R[k], m->d_tw, m->d_blk_remain[k], m->d_blk_off[k], d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in
+    DdcChainJob ahead; memset(&ahead, 0, sizeof ahead);
     if (full && nt16) {
         const size_t lds2 = (size_t)(16 * I512<16>::pitch + I512<16>::tw_n) * sizeof(float2);
         { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post<16>, lds2); if (rc) return rc; }
@@ -925,9 +958,16 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     } else if (full) {
         hipLaunchKernelGGL(k_ddc_ifft512_post<8>, g8, dim3(256), (size_t)(8 * I512<8>::pitch + I512<8>::tw_n) * sizeof(float2), st, DDC_IFFT_ARGS, m->post_dec);
     } else if (nt16) {
-        hipLaunchKernelGGL(k_ddc_ifft256d_post<16>, g16, dim3(256), (size_t)(16 * I256<16>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS);
+        hipLaunchKernelGGL(k_ddc_ifft256d_post<16>, g16, dim3(256), (size_t)(16 * I256<16>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS, ahead, 0);
     } else {
-        hipLaunchKernelGGL(k_ddc_ifft256d_post<8>, g8, dim3(256), (size_t)(8 * I256<8>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS);
+        int n_riders = 0;
+        if (m->ahead_ok && m->inline_set[k] && m->last_state && m->C <= 16 * 256) {      // the next call's chain tables into the other set, state into the shadow
+            ahead = mfma_chain_job(m, k ^ 1, n_blocks, m->last_state, d_geom);
+            ahead.state_out = m->d_state_spec;
+            n_riders = 16;
+            m->spec_valid = true; m->spec_set = k ^ 1; m->spec_blocks = n_blocks;
+        }
+        hipLaunchKernelGGL(k_ddc_ifft256d_post<8>, dim3(g8.x + n_riders), dim3(256), (size_t)(8 * I256<8>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS, ahead, n_riders);
     }
 #undef DDC_IFFT_ARGS
     CSDR_LAUNCH_CHECK();
