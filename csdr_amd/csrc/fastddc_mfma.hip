@@ -47,6 +47,7 @@ struct DdcMfma {
     int pending_blocks[2]; int fill, drain;                            // set being filled next / folded next
     bool inline_set[2], chains_on_side[2];
     bool gemm_three = false;
+    bool y_holds[2] = {false, false};                                  // set k's spectra are still pass-1 output in d_Y (the fold runs pass 2 itself)
     // the NEXT call's chain tables, computed one call ahead by riders of the inverse-transform kernel (data independent; valid for process() calls of equal size
     // with no retune in between).  On the side stream beside the fold they cost more than they hid: 0.182 vs 0.167 ms per step.
     DdcChanState *d_state_spec = nullptr, *last_state = nullptr; bool spec_valid = false, ahead_ok = false; int spec_set = 0, spec_blocks = 0;                                           // the fold kernel of the last collect(): k_ddc_gemm3 (three real products) or k_ddc_gemm
@@ -208,12 +209,17 @@ __global__ __launch_bounds__(512, PERSIST ? 2 : 4) void k_ddc_gemm(const float *
 //      which frees the 32 staging registers the third accumulator tile needs.  Issued after the first k-groups so that the taps fetches in front of it are
 //      not queued behind it (vector memory returns in order); the barrier at the end of a residue waits for this wave's own pieces and sits BEFORE the bin
 //      stores, which therefore drain under the next residue's product together with its first taps fetches.
-template <int NBT>
+//  FWD (one GPU, process()): the second pass of the forward transform happens HERE -- the workgroup reads the residue's 64 rows of pass-1 output Y[block][r][0..127]
+//      (1 KiB each), runs the 128-point transforms (16 x 8, eight lanes per row, exchange inside the row's own LDS space) and leaves the result where the staging
+//      would have put it: k_ddc_fwd128, its 34 MB round trip and one kernel boundary are gone; the butterflies run on the vector ALUs beside the matrix pipe.
+template <int NBT, bool FWD>
 __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
-                                                       const ChanGeom *__restrict__ geom, int inv, int Cpad, int n_channels, int nbp, int nbl, int n_blocks, float scale)
+                                                       const ChanGeom *__restrict__ geom, int inv, int Cpad, int n_channels, int nbp, int nbl, int n_blocks, float scale,
+                                                       const float2 *__restrict__ g_tw)
 {
     extern __shared__ float4 xs_all[];                              // 2 x [32 NBT rows][65] float4
     constexpr int PRE = 128, G = PRE / 4, P4 = PRE / 2 + 1, ROWS = 32 * NBT, BUF = ROWS * P4, RPW = ROWS / 8;      // rows per wave
+    constexpr int AD = FWD ? 4 : 8;                                     // taps fetches in flight per wave, in k-groups (4 and 8 measured equal; FWD needs the registers)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c_base = blockIdx.y * 256 + wave * 32, b_base = blockIdx.z * ROWS;
     const int i = lane & 31, hi = lane >> 5;
@@ -233,17 +239,47 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
     };
     // Barrier between residues.  Vector memory returns in order, so "this wave's pieces of the next buffer have landed" = "at most `newer` younger operations are
     // still out" (newer = the taps fetches issued after the pieces that nothing has waited for yet; 0 = wait for everything).
+    // FWD: thread (tr, c) = lane c of the 128-point transform of row tr (rows past the tile's NBT * 32: idle)
+    const int tr = threadIdx.x >> 3, fc = threadIdx.x & 7;
+    const bool frow = tr < ROWS;
+    auto y_load = [&](int r, float2 (&v)[16]) {                       // Xt plays Y here: [block][512][128]
+        const int b = min(b_base + tr, n_blocks - 1);
+        const float2 *src = Xt + ((size_t)b * 512 + r) * 128 + fc;
+#pragma unroll
+        for (int a16 = 0; a16 < 16; a16++) v[a16] = frow ? src[8 * a16] : make_float2(0.f, 0.f);
+    };
+    auto fft_rows = [&](float2 (&v)[16], int buf) {                   // 128 = 16 (a) x 8 (c): as k_ddc_fwd128, the exchange in the row's own 1040 bytes
+        if (!frow) return;
+        float2 *rowp = reinterpret_cast<float2 *>(xs_all + (size_t)buf * BUF + (size_t)tr * P4);
+        dft16<false>(v);
+#pragma unroll
+        for (int ka = 0; ka < 16; ka++) rowp[fc * 16 + ka] = cmul(v[ka], g_tw[(4 * fc * ka) & 511]);
+        __builtin_amdgcn_wave_barrier();                              // the eight lanes of a row sit in one wave: LDS operations of a wave complete in order
+        float2 e[8], o[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) {
+            const float4 two = *reinterpret_cast<const float4 *>(&rowp[cc * 16 + 2 * fc]);
+            e[cc] = make_float2(two.x, two.y); o[cc] = make_float2(two.z, two.w);
+        }
+        dft8<false>(e); dft8<false>(o);
+        __builtin_amdgcn_wave_barrier();                              // every lane of the row has read before anyone overwrites
+#pragma unroll
+        for (int kc = 0; kc < 8; kc++) {
+            const int q = (2 * fc + 16 * kc + 64) & 127;               // q' = ka + 16 kc with ka = 2 c (and 2 c + 1); q = (q' - pre/2) mod pre
+            *reinterpret_cast<float4 *>(&rowp[q]) = make_float4(e[kc].x, e[kc].y, o[kc].x, o[kc].y);
+        }
+    };
     auto pieces_landed_then_barrier = [&](bool all) {
-        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AD) : "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     };
     int r = blockIdx.x;
     if (r >= inv) return;
-    dma_rows(r, 0);
+    float2 yv[16];
+    if (FWD) { y_load(r, yv); fft_rows(yv, 0); } else dma_rows(r, 0);
     const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_base + i) * 2 + hi;
-    constexpr int AD = 8;                                               // taps fetches in flight per wave, in k-groups (4: the wave ran dry -- 4 groups of 12 matrix instructions are 1.3 us)
     float4 a[AD];
 #pragma unroll
     for (int d = 0; d < AD; d++) a[d] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -278,19 +314,20 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
             }                                                                                                              \
         }
         if (active) {
-            static_assert(G % AD == 0 && G >= 2 * AD && AD == 8, "k loop (the barrier's vmcnt(8) counts the AD fetches of the next residue)");
+            static_assert(G % AD == 0 && G >= 2 * AD, "k loop (the barrier's vmcnt(AD) counts the AD fetches of the next residue)");
 #pragma unroll
             for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = ap[(size_t)(AD + d) * gstride]; DDC_STEP3(av, d); }
-            if (rn < inv) dma_rows(rn, cur ^ 1);                      // behind the first 2 AD taps fetches
+            if (rn < inv) { if (FWD) y_load(rn, yv); else dma_rows(rn, cur ^ 1); }      // behind the first 2 AD taps fetches
             const float4 *apn = reinterpret_cast<const float4 *>(Ht) + ((size_t)min(rn, inv - 1) * G * Cpad + c_base + i) * 2 + hi;      // next residue's taps (the last residue re-reads its own)
             for (int g = AD; g < G - AD; g += AD) {                    // straight-line body: the loads stay AD groups ahead of their use
 #pragma unroll
                 for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = ap[(size_t)(g + AD + d) * gstride]; DDC_STEP3(av, g + d); }
             }
+            if (FWD && rn < inv) fft_rows(yv, cur ^ 1);                // vector-ALU work between the matrix instructions of the other wave on this SIMD
 #pragma unroll
             for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = apn[(size_t)d * gstride]; DDC_STEP3(av, G - AD + d); }      // the last AD groups: the fetches run into the next residue
             ap = apn;
-        } else if (rn < inv) dma_rows(rn, cur ^ 1);
+        } else if (rn < inv) { if (FWD) { y_load(rn, yv); fft_rows(yv, cur ^ 1); } else dma_rows(rn, cur ^ 1); }
 #undef DDC_STEP3
         if (rn < inv) pieces_landed_then_barrier(!active);            // every wave is through with this buffer and has its pieces of the other one; the AD newest
                                                                       // operations are the next residue's first taps fetches, which stay in flight across the bin stores
@@ -758,7 +795,7 @@ static int mfma_chains(DdcMfma *m, hipStream_t st, int k, int n_blocks, DdcChanS
 // forward transform of n_loc windows: window b starts at in[b inp - ovl] (positions < 0 come from `tail`); the result goes to Xt chunk `xt` with block pitch nbl.
 // riders != nullptr: the call's chain tables and phasor checkpoints are computed by extra workgroups of the two passes (pass 1 carries the chains, pass 2 the
 // checkpoints, which need the chains' phases: stream order) instead of by kernels of their own.
-static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt, const DdcChainJob *riders)
+static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt, const DdcChainJob *riders, bool skip_pass2 = false)
 {
     if (n_loc <= 0) return 0;
     DdcChainJob cj; memset(&cj, 0, sizeof cj);
@@ -777,8 +814,9 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *
     }
 #undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
-    const bool rot_rides = riders && cj.mode == 1 && (size_t)cj.n_channels * cj.n_blocks <= 512u * 256u;      // mode 2: pass 1 did the checkpoints
+    const bool rot_rides = !skip_pass2 && riders && cj.mode == 1 && (size_t)cj.n_channels * cj.n_blocks <= 512u * 256u;      // mode 2: pass 1 did the checkpoints
     if (!rot_rides) cj.R = nullptr;
+    if (!skip_pass2)
     hipLaunchKernelGGL(k_ddc_fwd128, dim3(512, cdiv(n_loc, 32) + (rot_rides ? 1 : 0)), dim3(256), 0, st, reinterpret_cast<const float2 *>(m->d_Y), reinterpret_cast<float2 *>(xt),
                        m->d_tw, m->nbl, n_loc, cj);
     CSDR_LAUNCH_CHECK();
@@ -787,6 +825,19 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *
         CSDR_LAUNCH_CHECK();
     }
     return 0;
+}
+
+// will collect() fold n_blocks blocks with k_ddc_gemm3 (persistent shape, pre_decimation 128)?  submit() needs to know: only that kernel can run pass 2 itself
+static bool ddc_folds_with_gemm3(const DdcMfma *m, int n_blocks)
+{
+    const int nbt = n_blocks > 32 ? 2 : 1;
+    const size_t lds = (size_t)32 * nbt * (m->pre / 2 + 1) * sizeof(float4);
+    const int per_res = (int)(cdiv(m->Cpad, 256) * cdiv(n_blocks, 32 * nbt));
+    int slots = current_device_cu_count() / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
+    bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
+    const char *e = getenv("CSDR_AMD_DDC_GEMM");
+    if (e) { if (!strcmp(e, "simple")) persist = false; else if (!strncmp(e, "persist", 7) && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true; }
+    return persist && m->pre == 128 && !(e && !strcmp(e, "persist4"));
 }
 
 // Stage one call: `in` = n_blocks x input_size NEW wideband samples (on rank 0 of a sharded bank; ignored elsewhere), or `spectra` = the natural
@@ -815,6 +866,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     m->spec_valid = false;
     const bool ride = fused_fwd && !riders_off;                        // chain work done by extra workgroups of the forward passes (hit: only the commit + the checkpoints)
     m->last_state = d_state; m->ahead_ok = fused_fwd && !spec_off && !riders_off;
+    m->y_holds[k] = false;
     if (ride) {
     } else if (inl && !chains_side) {
         rc = mfma_chains(m, mainst, k, n_blocks, d_state, d_geom); if (rc) return rc;
@@ -845,7 +897,10 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
         if (m->world == 1) {
             DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
             if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }
-            rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr); if (rc) return rc;
+            static const bool fuse2_off = getenv("CSDR_AMD_DDC_PASS2") != nullptr;       // set: k_ddc_fwd128 stays a kernel of its own
+            const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
+            rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2); if (rc) return rc;
+            m->y_holds[k] = skip2;
             m->flip ^= 1;
         } else {
             // rank g transforms blocks [g nbl, (g + 1) nbl): the root sends it the samples of its windows, stream[g nbl inp - ovl, min((g + 1) nbl, n) inp),
@@ -927,15 +982,18 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
                            reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); } while (0)
     // three-product form with LDS-DMA staging: pre_decimation 128 (a spectra row = one 1-KiB piece), persistent shape; CSDR_AMD_DDC_GEMM=persist4 keeps the four-product kernel
     const char *ge = getenv("CSDR_AMD_DDC_GEMM");
-    const bool three = persist && m->pre == 128 && !(ge && !strcmp(ge, "persist4"));
-    m->gemm_three = three;
+    const bool three = ddc_folds_with_gemm3(m, n_blocks);
+    (void)ge; m->gemm_three = three;
     if (three) {
-        if (nbt == 2) { const int rc = lds_attr_once((const void *)k_ddc_gemm3<2>, lds_use); if (rc) return rc;
-                        hipLaunchKernelGGL(k_ddc_gemm3<2>, grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]), reinterpret_cast<float2 *>(m->d_Ct),
-                                           d_geom, m->inv, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); }
-        else { const int rc = lds_attr_once((const void *)k_ddc_gemm3<1>, lds_use); if (rc) return rc;
-               hipLaunchKernelGGL(k_ddc_gemm3<1>, grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]), reinterpret_cast<float2 *>(m->d_Ct),
-                                  d_geom, m->inv, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); }
+        // the second pass of the forward transform inside the fold: one GPU, process() (pass 1's output Y belongs to this call), submit() skipped k_ddc_fwd128
+        const bool fwd = m->y_holds[k];
+        const float2 *src = fwd ? reinterpret_cast<const float2 *>(m->d_Y) : reinterpret_cast<const float2 *>(m->d_Xt[k]);
+#define DDC_GEMM3_LAUNCH(NBTV, FV) do { const int rc = lds_attr_once((const void *)k_ddc_gemm3<NBTV, FV>, lds_use); if (rc) return rc;                     \
+        hipLaunchKernelGGL((k_ddc_gemm3<NBTV, FV>), grid_use, dim3(512), lds_use, st, m->d_Ht, src, reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->Cpad, m->C,  \
+                           m->nbp, m->nbl, n_blocks, scale, m->d_tw); } while (0)
+        if (nbt == 2) { if (fwd) DDC_GEMM3_LAUNCH(2, true); else DDC_GEMM3_LAUNCH(2, false); }
+        else          { if (fwd) DDC_GEMM3_LAUNCH(1, true); else DDC_GEMM3_LAUNCH(1, false); }
+#undef DDC_GEMM3_LAUNCH
     }
     else if (nbt == 2) { if (persist) DDC_GEMM_LAUNCH(2, true); else DDC_GEMM_LAUNCH(2, false); }
     else               { if (persist) DDC_GEMM_LAUNCH(1, true); else DDC_GEMM_LAUNCH(1, false); }

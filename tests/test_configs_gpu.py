@@ -138,7 +138,9 @@ def test_bank_pipelined_single_rank_communicator(gpu):
     L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm)
     for c in range(nch):
         got = np.concatenate(outs[c])
-        assert got.size == want[c].size and np.array_equal(got, want[c]), "channel %d" % c
+        # (process() runs the second forward pass inside the fold, the staged form as a kernel of its own: the same butterflies, but the compiler contracts
+        # the twiddle products differently in the two contexts -- equal to rounding, not to the bit)
+        assert got.size == want[c].size and vc.relrms(got, want[c]) < 2e-6, "channel %d" % c
 
 
 def test_bank_general_geometry(gpu, port):
