@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
 {
     extern __shared__ float4 xs_all[];                              // 2 x [32 NBT rows][65] float4
     constexpr int PRE = 128, G = PRE / 4, P4 = PRE / 2 + 1, ROWS = 32 * NBT, BUF = ROWS * P4, RPW = ROWS / 8;      // rows per wave
-    constexpr int AD = FWD ? 4 : 8;                                     // taps fetches in flight per wave, in k-groups (4 and 8 measured equal; FWD needs the registers)
+    constexpr int AD = FWD ? 4 : 8;                                     // taps fetches in flight per wave, in k-groups (FWD: 8 spills)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c_base = blockIdx.y * 256 + wave * 32, b_base = blockIdx.z * ROWS;
     const int i = lane & 31, hi = lane >> 5;
@@ -231,30 +231,36 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
 #pragma unroll
         for (int k = 0; k < RPW; k++) {
             const int row = wave * RPW + k, b = min(b_base + row, n_blocks - 1);
-            const float2 *src = Xt + (((size_t)(b / nbl) * inv + r) * nbl + (b % nbl)) * PRE + 2 * lane;        // 16 bytes per lane
+            const float2 *src = (FWD ? Xt + ((size_t)b * 512 + r) * PRE                                            // pass-1 output Y[block][r][0..127]
+                                     : Xt + (((size_t)(b / nbl) * inv + r) * nbl + (b % nbl)) * PRE) + 2 * lane;      // 16 bytes per lane
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(lds_base + ((uint32_t)buf * BUF + (uint32_t)row * P4) * 16u));
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(la) : "memory");
         }
     };
-    // Barrier between residues.  Vector memory returns in order, so "this wave's pieces of the next buffer have landed" = "at most `newer` younger operations are
-    // still out" (newer = the taps fetches issued after the pieces that nothing has waited for yet; 0 = wait for everything).
+    // Taps fetches by hand: as plain loads the compiler sinks each one to just in front of its use (to shorten live ranges) and waits vmcnt(0) right behind it --
+    // the prefetch distance is gone and every k-group pays a memory round trip.  taps_fetch issues, taps_ready waits until at most AD - 1 younger operations are out
+    // (the fetches of the following groups, issued in order; anything else that is younger only makes the wait conservative) and ties the value to the wait.
+    typedef float g3_v4f __attribute__((ext_vector_type(4)));
+    auto taps_fetch = [&](g3_v4f &dst, const float4 *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); };
+#define G3_TAPS_READY(V, K) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(V) : "n"(K))
+    // A value in flight must never meet a merge of definitions (a branch around a fetch, the residue loop's back edge): the compiler, which takes the asm's output for
+    // ready, may copy the register there.  Hence: every wave fetches (inactive ones from a clamped channel base), and a residue's fetches start at the top of its
+    // own iteration -- their latency is covered by the PREVIOUS residue's bin stores, which are issued right behind them.
     // FWD: thread (tr, c) = lane c of the 128-point transform of row tr (rows past the tile's NBT * 32: idle)
-    const int tr = threadIdx.x >> 3, fc = threadIdx.x & 7;
-    const bool frow = tr < ROWS;
-    auto y_load = [&](int r, float2 (&v)[16]) {                       // Xt plays Y here: [block][512][128]
-        const int b = min(b_base + tr, n_blocks - 1);
-        const float2 *src = Xt + ((size_t)b * 512 + r) * 128 + fc;
-#pragma unroll
-        for (int a16 = 0; a16 < 16; a16++) v[a16] = frow ? src[8 * a16] : make_float2(0.f, 0.f);
-    };
-    auto fft_rows = [&](float2 (&v)[16], int buf) {                   // 128 = 16 (a) x 8 (c): as k_ddc_fwd128, the exchange in the row's own 1040 bytes
-        if (!frow) return;
+    const int tr = wave * RPW + (lane >> 3), fc = lane & 7;           // a wave transforms exactly the rows it staged (RPW = 8: all lanes; 4: the lower half)
+    const bool frow = (lane >> 3) < RPW;
+    auto fft_rows = [&](int buf) {                                    // 128 = 16 (a) x 8 (c), as k_ddc_fwd128, IN PLACE in the row's 1040 bytes of LDS.  Row tr was staged by
+        if (!frow) return;                                            // this very wave (rows 8 w .. 8 w + 7), so no workgroup barrier is needed in front -- only its own pieces
         float2 *rowp = reinterpret_cast<float2 *>(xs_all + (size_t)buf * BUF + (size_t)tr * P4);
+        float2 v[16];
+#pragma unroll
+        for (int a16 = 0; a16 < 16; a16++) v[a16] = rowp[8 * a16 + fc];
         dft16<false>(v);
+        __builtin_amdgcn_wave_barrier();                              // (the eight lanes of a row sit in one wave: every lane has read before anyone writes; LDS operations of a wave complete in order)
 #pragma unroll
         for (int ka = 0; ka < 16; ka++) rowp[fc * 16 + ka] = cmul(v[ka], g_tw[(4 * fc * ka) & 511]);
-        __builtin_amdgcn_wave_barrier();                              // the eight lanes of a row sit in one wave: LDS operations of a wave complete in order
+        __builtin_amdgcn_wave_barrier();
         float2 e[8], o[8];
 #pragma unroll
         for (int cc = 0; cc < 8; cc++) {
@@ -262,36 +268,56 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
             e[cc] = make_float2(two.x, two.y); o[cc] = make_float2(two.z, two.w);
         }
         dft8<false>(e); dft8<false>(o);
-        __builtin_amdgcn_wave_barrier();                              // every lane of the row has read before anyone overwrites
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int kc = 0; kc < 8; kc++) {
             const int q = (2 * fc + 16 * kc + 64) & 127;               // q' = ka + 16 kc with ka = 2 c (and 2 c + 1); q = (q' - pre/2) mod pre
             *reinterpret_cast<float4 *>(&rowp[q]) = make_float4(e[kc].x, e[kc].y, o[kc].x, o[kc].y);
         }
     };
-    auto pieces_landed_then_barrier = [&](bool all) {
-        if (all) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(AD) : "memory");
+    int r = blockIdx.x;
+    if (r >= inv) return;
+    dma_rows(r, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's pieces of the first buffer
+    const int c_eff = min(c_base, Cpad - 32);                         // channel base the taps are fetched from (waves past the last channel tile compute a copy nobody stores)
+    f32x16 acc[NBT][3];
+    // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+    auto store_bins = [&](int rr) {
+        if (!active) return;
+        int mm[16];                                                   // all sixteen offsetbin fetches in flight at once (inside the store loop each one was waited for on its own)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int c = min(c_base + (e & 3) + 8 * (e >> 2) + 4 * hi, n_channels - 1);
+            mm[e] = (rr - geom[c].offsetbin) & (inv - 1);             // inv is 512 here (a power of two): no division on the store path
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (c >= n_channels) continue;
+            float2 *dst = Ct + ((size_t)mm[e] * Cpad + c) * nbp + b_base + i;
+#pragma unroll
+            for (int bt = 0; bt < NBT; bt++)
+                if (b_base + bt * 32 + i < n_blocks) {
+                    const float p1 = acc[bt][0][e], p2 = acc[bt][1][e], p3 = acc[bt][2][e];
+                    dst[bt * 32] = make_float2((p1 - p2) * scale, (p3 - p1 - p2) * scale);      // (streaming `nt` stores here and in the forward passes: the consumers got 3-5 us slower each)
+                }
+        }
+    };
+    int cur = 0, r_prev = -1;
+    for (;;) {
+        const int rn = r + gridDim.x;
+        const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_eff + i) * 2 + hi;
+        g3_v4f a[AD];
+#pragma unroll
+        for (int d = 0; d < AD; d++) taps_fetch(a[d], ap + (size_t)d * gstride);
+        if (r_prev >= 0) store_bins(r_prev);                          // the previous residue's bins: their stores cover the first fetches' latency and drain under this product
+        // FWD: each wave transforms the rows it staged (landed: they are older than the previous product's last taps fetches, all consumed), with the accumulators
+        // dead -- inside the product the transform's registers pushed the kernel into spills.  ONE barrier per residue: every wave has left the previous product
+        // (the other buffer may be overwritten) and this buffer is complete.
+        if (FWD) fft_rows(cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    };
-    int r = blockIdx.x;
-    if (r >= inv) return;
-    float2 yv[16];
-    if (FWD) { y_load(r, yv); fft_rows(yv, 0); } else dma_rows(r, 0);
-    const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_base + i) * 2 + hi;
-    float4 a[AD];
-#pragma unroll
-    for (int d = 0; d < AD; d++) a[d] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (active) {
-#pragma unroll
-        for (int d = 0; d < AD; d++) a[d] = ap[(size_t)d * gstride];
-    }
-    pieces_landed_then_barrier(true);
-    int cur = 0;
-    for (;;) {
-        const int rn = r + gridDim.x;
-        f32x16 acc[NBT][3];
 #pragma unroll
         for (int bt = 0; bt < NBT; bt++)
 #pragma unroll
@@ -299,11 +325,17 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[bt][p][e] = 0.f;
         const float4 *xrow = xs_all + cur * BUF + i * P4 + hi;
+        // the spectra operand of k-group GG + 1 is read from LDS while group GG multiplies
+        float4 xn[NBT];
+#pragma unroll
+        for (int bt = 0; bt < NBT; bt++) xn[bt] = xrow[bt * 32 * P4];
 #define DDC_STEP3(AV, GG)                                                                                                  \
         {                                                                                                                  \
             const float hs0 = (AV).x + (AV).y, hs1 = (AV).z + (AV).w;                                                      \
+            float4 xc[NBT];                                                                                                \
+            _Pragma("unroll") for (int bt = 0; bt < NBT; bt++) { xc[bt] = xn[bt]; xn[bt] = xrow[bt * 32 * P4 + 2 * min((GG) + 1, G - 1)]; }  \
             _Pragma("unroll") for (int bt = 0; bt < NBT; bt++) {                                                           \
-                const float4 xv = xrow[bt * 32 * P4 + 2 * (GG)];                                                           \
+                const float4 xv = xc[bt];                                                                                  \
                 const float xs0 = xv.x + xv.y, xs1 = xv.z + xv.w;                                                          \
                 acc[bt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.x, acc[bt][0], 0, 0, 0);                      \
                 acc[bt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, xv.y, acc[bt][1], 0, 0, 0);                      \
@@ -313,44 +345,29 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
                 acc[bt][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hs1, xs1, acc[bt][2], 0, 0, 0);                          \
             }                                                                                                              \
         }
-        if (active) {
-            static_assert(G % AD == 0 && G >= 2 * AD, "k loop (the barrier's vmcnt(AD) counts the AD fetches of the next residue)");
+        static_assert(G % AD == 0 && G >= 2 * AD, "k loop");
+        // straight-line (fully unrolled): across a loop back edge the compiler's wait-count bookkeeping gives up.  A fetch is ready when at most AD - 1 younger
+        // operations are out (the fetches of the following groups, issued in order; anything else that is younger only makes the wait conservative)
 #pragma unroll
-            for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = ap[(size_t)(AD + d) * gstride]; DDC_STEP3(av, d); }
-            if (rn < inv) { if (FWD) y_load(rn, yv); else dma_rows(rn, cur ^ 1); }      // behind the first 2 AD taps fetches
-            const float4 *apn = reinterpret_cast<const float4 *>(Ht) + ((size_t)min(rn, inv - 1) * G * Cpad + c_base + i) * 2 + hi;      // next residue's taps (the last residue re-reads its own)
-            for (int g = AD; g < G - AD; g += AD) {                    // straight-line body: the loads stay AD groups ahead of their use
+        for (int d = 0; d < AD; d++) { G3_TAPS_READY(a[d], AD - 1); const g3_v4f av = a[d]; taps_fetch(a[d], ap + (size_t)(AD + d) * gstride); DDC_STEP3(av, d); }
+        if (rn < inv) dma_rows(rn, cur ^ 1);                          // behind the first 2 AD taps fetches
 #pragma unroll
-                for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = ap[(size_t)(g + AD + d) * gstride]; DDC_STEP3(av, g + d); }
-            }
-            if (FWD && rn < inv) fft_rows(yv, cur ^ 1);                // vector-ALU work between the matrix instructions of the other wave on this SIMD
+        for (int g = AD; g < G - AD; g += AD) {
 #pragma unroll
-            for (int d = 0; d < AD; d++) { const float4 av = a[d]; a[d] = apn[(size_t)d * gstride]; DDC_STEP3(av, G - AD + d); }      // the last AD groups: the fetches run into the next residue
-            ap = apn;
-        } else if (rn < inv) { if (FWD) { y_load(rn, yv); fft_rows(yv, cur ^ 1); } else dma_rows(rn, cur ^ 1); }
-#undef DDC_STEP3
-        if (rn < inv) pieces_landed_then_barrier(!active);            // every wave is through with this buffer and has its pieces of the other one; the AD newest
-                                                                      // operations are the next residue's first taps fetches, which stay in flight across the bin stores
-        if (active) {
-            // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (c >= n_channels) continue;
-                int mm = (r - geom[c].offsetbin) % inv; if (mm < 0) mm += inv;
-                float2 *dst = Ct + ((size_t)mm * Cpad + c) * nbp + b_base + i;
-#pragma unroll
-                for (int bt = 0; bt < NBT; bt++)
-                    if (b_base + bt * 32 + i < n_blocks) {
-                        const float p1 = acc[bt][0][e], p2 = acc[bt][1][e], p3 = acc[bt][2][e];
-                        dst[bt * 32] = make_float2((p1 - p2) * scale, (p3 - p1 - p2) * scale);      // (streaming `nt` stores here and in the forward passes: the consumers got 3-5 us slower each)
-                    }
-            }
+            for (int d = 0; d < AD; d++) { G3_TAPS_READY(a[d], AD - 1); const g3_v4f av = a[d]; taps_fetch(a[d], ap + (size_t)(g + AD + d) * gstride); DDC_STEP3(av, g + d); }
         }
+#define G3_LAST(D) { G3_TAPS_READY(a[D], AD - 1 - (D)); const g3_v4f av = a[D]; DDC_STEP3(av, G - AD + (D)); }      /* the last AD groups: nothing new is fetched */
+        G3_LAST(0) G3_LAST(1) G3_LAST(2) G3_LAST(3)
+        if constexpr (AD == 8) { G3_LAST(4) G3_LAST(5) G3_LAST(6) G3_LAST(7) }
+#undef G3_LAST
+#undef DDC_STEP3
+        r_prev = r;
         if (rn >= inv) break;
         r = rn; cur ^= 1;
     }
+    store_bins(r_prev);
 }
+#undef G3_TAPS_READY
 
 // ------------------------------------------------------------------ the residual shift: data-independent bookkeeping
 // Both tables are BLOCK-MAJOR (index b * n_channels + c): a wave's lanes are consecutive channels, so every access below is coalesced (the general

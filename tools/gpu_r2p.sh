@@ -1,8 +1,7 @@
 #!/bin/bash
-# fastddc: pass 2 of the forward transform inside the fold (A/B with CSDR_AMD_DDC_PASS2=1 on one box) + the channelizer's parity tests
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_gpu_parity.py tests/test_cli_gpu.py -q -x -k "c4 or bank or fastddc" 2>&1 | grep -E "passed|failed|Error|error" | tail -5
+timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_gpu_parity.py tests/test_cli_gpu.py -q -k "c4 or bank or fastddc" 2>&1 | grep -E "passed|failed|Error|error" | tail -3
 for rep in 1 2; do
+  timeout 200 python bench_fastddc.py --steps 300 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['verify']['ok'], d['verify']['max_rel_rms'])"
   CSDR_AMD_DDC_PASS2=1 timeout 200 python bench_fastddc.py --steps 300 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('separate pass 2', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['verify']['ok'], d['verify']['max_rel_rms'])"
-  timeout 200 python bench_fastddc.py --steps 300 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pass 2 in fold  ', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['verify']['ok'], d['verify']['max_rel_rms'])"
 done
