@@ -191,6 +191,25 @@ __device__ __forceinline__ void ffl_load_window(float2 (&v)[16], const float2 *x
     }
 }
 
+// Prefetch of the NEXT window into registers, issued by hand: written as plain loads the compiler sinks them to their use at the top of the next iteration (and the
+// prefetching variants measured no better than the plain ones).  The values are made "real" for the compiler at the END of the iteration (ffl_prefetch_ready:
+// by then they have landed; vmcnt(16) lets this window's 16 output stores stay in flight), so nothing in flight crosses the loop's back edge.
+template <int N>
+__device__ __forceinline__ void ffl_prefetch_issue(ffl_f32x2 (&nx)[16], const float2 *x, int w0, int m_new, int t)
+{
+    constexpr int T = FflGeom<N>::T;
+    const unsigned long long bx = (unsigned long long)x;
+    const ffl_i32x4 rx = {(int)(unsigned)bx, (int)((bx >> 32) & 0xffffu), m_new * 8, 0x00020000};
+    const int v0 = (w0 + t) * 8;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const int vo = v0 + T * 8 * j; asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(nx[j]) : "v"(vo), "s"(rx) : "memory"); }
+}
+__device__ __forceinline__ void ffl_prefetch_ready(ffl_f32x2 (&nx)[16])
+{
+    asm volatile("s_waitcnt vmcnt(16)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(nx[4]), "+v"(nx[5]), "+v"(nx[6]), "+v"(nx[7]),
+                                         "+v"(nx[8]), "+v"(nx[9]), "+v"(nx[10]), "+v"(nx[11]), "+v"(nx[12]), "+v"(nx[13]), "+v"(nx[14]), "+v"(nx[15]));
+}
+
 template <int N, bool PF, int MINWG, bool HOIST>
 __global__ __launch_bounds__(N / 16, MINWG) void k_fftfilt_lds(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, int m_new,
                                                         int n_chunks, int n_windows, float2 *__restrict__ out, size_t out_pitch, const float2 *hperm,
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(N / 16, MINWG) void k_fftfilt_lds(const float2 *__r
     const int w_end = min(n_windows, (xcd + 1) * per_xcd);
     int w = xcd * per_xcd + (blockIdx.x >> 3);
     if (w >= w_end) return;
-    float2 v[16], nx[16];
+    float2 v[16]; ffl_f32x2 nx[16];
     {
         const int s = w / n_chunks, c = w - s * n_chunks;
         ffl_load_window<N>(v, in + (size_t)s * in_pitch, hist + (size_t)s * k1p, c * V - k1p, k1p, m_new, t);
@@ -220,10 +239,12 @@ __global__ __launch_bounds__(N / 16, MINWG) void k_fftfilt_lds(const float2 *__r
         }
         ffl_first<N>(v, lds, w1, t);
         const int wn = w + stride;
-        if (PF && wn < w_end) {                                         // uniform
-            const int sn = wn / n_chunks, cn = wn - sn * n_chunks;
-            ffl_load_window<N>(nx, in + (size_t)sn * in_pitch, hist + (size_t)sn * k1p, cn * V - k1p, k1p, m_new, t);
-        }
+        // the window prefetched: the next one if there is one and it lies inside the call's input (a stream's first window, which starts in the history, is loaded the
+        // ordinary way below); otherwise this one again, ignored -- the fetches are unconditional so that no branch surrounds a value in flight
+        int sn = wn / n_chunks, cn = wn - sn * n_chunks;
+        const bool pre = PF && wn < w_end && cn > 0;
+        if (!pre) { sn = s; cn = c; }
+        if (PF) ffl_prefetch_issue<N>(nx, in + (size_t)sn * in_pitch, cn * V - k1p, m_new, t);
         __syncthreads();
         FflMidPhases<N>::template run<0>(lds, tws, hperm, t); __syncthreads();
         FflMidPhases<N>::template run<1>(lds, tws, hperm, t); __syncthreads();
@@ -240,12 +261,13 @@ __global__ __launch_bounds__(N / 16, MINWG) void k_fftfilt_lds(const float2 *__r
         const int vy = (t - k1p) * 8;                                   // negative (the window's overlap part) -> dropped
 #pragma unroll
         for (int j = 0; j < 16; j++) { const ffl_f32x2 r = {v[j].x, v[j].y}; ffl_buf_store(r, ry, vy + G::T * 8 * j, 0, 0); }
-        if (PF) {
+        if (PF) ffl_prefetch_ready(nx);
+        if (pre) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = nx[j];
+            for (int j = 0; j < 16; j++) v[j] = make_float2(nx[j].x, nx[j].y);
         } else if (wn < w_end) {
-            const int sn = wn / n_chunks, cn = wn - sn * n_chunks;
-            ffl_load_window<N>(v, in + (size_t)sn * in_pitch, hist + (size_t)sn * k1p, cn * V - k1p, k1p, m_new, t);
+            const int s2 = wn / n_chunks, c2 = wn - s2 * n_chunks;
+            ffl_load_window<N>(v, in + (size_t)s2 * in_pitch, hist + (size_t)s2 * k1p, c2 * V - k1p, k1p, m_new, t);
         }
     }
 }
@@ -431,6 +453,8 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     static const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
     if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else if (mode == 4) rc = ffl_launch<4096, true, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
         else rc = ffl_launch<4096, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
     } else if (p->n == 8192) {
         if (mode == 2) rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);

@@ -1,7 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_configs_gpu.py tests/test_gpu_parity.py tests/test_cli_gpu.py -q -k "c4 or bank or fastddc" 2>&1 | grep -E "passed|failed|Error|error" | tail -3
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -k "bandpass" 2>&1 | grep -E "passed|failed|Error|error" | tail -3
 for rep in 1 2; do
-  timeout 200 python bench_fastddc.py --steps 300 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['verify']['ok'], d['verify']['max_rel_rms'])"
-  CSDR_AMD_DDC_PASS2=1 timeout 200 python bench_fastddc.py --steps 300 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('separate pass 2', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['verify']['ok'], d['verify']['max_rel_rms'])"
+for mode in 0 1 3; do
+  CSDR_AMD_FFTFILT_LDS_MODE=$mode timeout 200 python bench_fftfilt.py --steps 100 --no-sweep --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('mode $mode', d['value'], d['ms_per_step'], d['roofline']['frac'], d['verify']['ok'], d['verify']['max_rel_rms'])"
+done
+done
+for mode in 0 2; do
+  CSDR_AMD_FFTFILT_LDS_MODE=$mode timeout 200 python bench_fftfilt.py --steps 100 --no-sweep --no-cpu-baseline --taps 2047 --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('taps 2047 mode $mode', d['value'], d['ms_per_step'], d['roofline']['frac'], d['verify']['ok'])"
 done
