@@ -871,11 +871,11 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     if (m->pending_blocks[k]) return fail_msg(-3, "fastddc: two calls are already staged; collect one first");
     hipStream_t mainst = m->ctx->stream;
     const bool inl = inline_call && m->world == 1 && !m->pending_blocks[k ^ 1];
-    static const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
+    const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
     hipStream_t st = inl ? mainst : m->side;
     int rc = 0;
-    static const bool riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr;
-    static const bool spec_off = getenv("CSDR_AMD_DDC_SPEC_OFF") != nullptr;
+    const bool riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr;
+    const bool spec_off = getenv("CSDR_AMD_DDC_SPEC_OFF") != nullptr;
     const bool fused_fwd = inl && !chains_side && !spectra && ddc_mfma_can_forward(m);
     // Chain tables one call ahead: the previous process() call's inverse-transform kernel carried riders that computed the tables of THIS call (set k) from the
     // state it ended with -- valid when this call has the size that was assumed and nothing retuned in between (ddc_mfma_quiesce).
@@ -914,7 +914,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
         if (m->world == 1) {
             DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
             if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }
-            static const bool fuse2_off = getenv("CSDR_AMD_DDC_PASS2") != nullptr;       // set: k_ddc_fwd128 stays a kernel of its own
+            const bool fuse2_off = getenv("CSDR_AMD_DDC_PASS2") != nullptr;       // set: k_ddc_fwd128 stays a kernel of its own
             const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
             rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2); if (rc) return rc;
             m->y_holds[k] = skip2;

@@ -450,7 +450,7 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     // Measured on one box (profiles/r2_notes.md): 4096-point windows run best with four resident workgroups per CU and no register prefetch (0.318 ms per
     // 64 x 16 blocks; three workgroups 0.346, prefetching variants 0.33-0.36); 8192-point windows with one 512-thread workgroup that prefetches the next window
     // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
-    static const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
+    const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
     if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
         else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);

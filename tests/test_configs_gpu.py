@@ -98,6 +98,24 @@ def test_c4_bank_fused_forward(gpu, port):
     assert outs[35].size == w35.size and vc.relrms(outs[35], w35) < TOL
 
 
+@pytest.mark.parametrize("switch", ["CSDR_AMD_DDC_SPEC_OFF=1", "CSDR_AMD_DDC_RIDERS_OFF=1", "CSDR_AMD_DDC_PASS2=1", "CSDR_AMD_DDC_GEMM=persist4", "CSDR_AMD_DDC_GEMM=simple",
+                                    "CSDR_AMD_DDC_FWD=8", "CSDR_AMD_DDC_IFFT=512", "CSDR_AMD_DDC_IFFT=16"])
+def test_c4_bank_alternative_paths(gpu, monkeypatch, switch):
+    """The bank's alternative kernels / schedules stay correct: each switch turns one of the default choices off (chain tables one call ahead, riders, pass 2 inside the
+    fold, the three-product fold, the persistent fold, 16-column forward pass, half-size inverse transforms); same stream as the default within rounding."""
+    tbw, D, nch, nb = 0.001, 256, 37, 11
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(48)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = np.ascontiguousarray(vc.c4_rates(256)[2::7][:nch])
+    want = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=4, retune=(2, 5, 0.0321))
+    k, v = switch.split("=")
+    monkeypatch.setenv(k, v)
+    got = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=4, retune=(2, 5, 0.0321))
+    for c in range(nch):
+        assert got[c].size == want[c].size and vc.relrms(got[c], want[c]) < 2e-6, "channel %d" % c
+
+
 def test_bank_pipelined_single_rank_communicator(gpu):
     """submit(N + 1) before collect(N) (two batches staged: the second one's chains and forward transform run on the side stream under the first one's
     fold) gives the stream process() gives; the bank is created through the sharded entry point on a ONE-rank RCCL communicator of the library's own
