@@ -232,6 +232,9 @@ __device__ __forceinline__ void ddc_chain(const v4i (&A)[DDC_NKW * 3], const v4i
     }
 }
 
+#ifndef DDC_RING_PAD
+#define DDC_RING_PAD 32       // bytes between the streams' rings beyond the ring itself (see k_ddc_mfma)
+#endif
 #ifndef DDC_DIAG
 #define DDC_DIAG 0          // experiments: 1 = DMA ring + barriers only (no LDS reads / math), 2 = math only (ring filled once)
 #endif
@@ -247,7 +250,9 @@ struct DdcParams {
 // One workgroup = 16 streams x the tiles [t0, t1) of its segment, walked in time order, NT tiles at a time: the workgroup has NT teams of
 // 4 waves; team j computes tile NT*g + j of group g (wave w of a team: K-range w), all teams read the same input ring.  NT = 2 puts two waves
 // on every SIMD, so that one tile's LDS reads / epilogue overlap the other tile's matrix products (the per-tile chain is serial inside a wave).
-//   LDS: 16 ring buffers of RB bytes (pitch RB + 16: the 16 streams of a B-fragment read hit different banks) + reduction buffer + prefix table.
+//   LDS: 16 ring buffers of RB bytes (pitch RB + 32: a ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, ... -- and with the 16-byte slot of
+//   lane (stream, q) = (2 stream + q) mod 16 every group touches 16 different slots; pitch RB + 16 left 4 two-way conflicts per read: 40 % of the kernel's LDS cycles
+//   were conflict cycles, SQ_LDS_BANK_CONFLICT) + reduction buffer + prefix table.
 //   DMA: a "row-step" fetches the next 1 KiB of all 16 streams (16 / (4 NT) instructions per wave).
 // FUSE (the NFM chain, nfm.hip): the reducer does not store the decimated complex samples but demodulates them (fmdemod_quadri_cf | limit_ff) and stores the three
 // digit planes the de-emphasis FIR reads.  y[k - 1] of a tile's first output comes from the previous tile of the same workgroup (re-reduced from the other team's
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                                                        const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
                                                        const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p, DdcFuse fz)
 {
-    constexpr int RB = 1 << RBL, RP = RB + 16, SPW = 16 / (4 * NT);                   // SPW: streams fetched per wave in a row-step
+    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, SPW = 16 / (4 * NT);                   // SPW: streams fetched per wave in a row-step
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
     float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][4 waves][64 lanes]
@@ -696,7 +701,7 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
             if (n_seg < 1) n_seg = 1;
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
-            const size_t lds = (size_t)16 * ((1u << rbl) + 16) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2);
+            const size_t lds = (size_t)16 * ((1u << rbl) + DDC_RING_PAD) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2);
             DdcFuse fz; memset(&fz, 0, sizeof fz); if (fuse) fz = *fuse;
 #define DDC_LAUNCH(NTV, FV, THREADS) do {                                                                                                                  \
                 const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV>, lds); if (arc) return arc;                                              \

@@ -740,7 +740,11 @@ __device__ __forceinline__ void wfm_chain(const v4i (&A)[WFM_NK * 3], const v4i 
 }
 
 constexpr int SEQ_RB = 9216;               // ring bytes per stream: 9 x 1 KiB (the 8-tile step's window 3312 B + the next step's 3200 B + fetch granularity)
-constexpr int SEQ_RP = SEQ_RB + 16;        // LDS pitch: odd multiple of 16 bytes
+#ifndef SEQ_RING_PAD
+#define SEQ_RING_PAD 32
+#endif
+constexpr int SEQ_RP = SEQ_RB + SEQ_RING_PAD;   // LDS pitch.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...): with the 16-byte slot of lane
+                                           // (stream, q) = (2 stream + q) mod 16 every group touches 16 different slots; + 16 (slot = stream + q) left 4 two-way conflicts per read
 constexpr int SEQ_NGR = 4 * WFM_NK;        // 16-byte granules per window
 
 // FUSE: the back end of the chain inside this kernel.  The workgroup produces its streams' audio in time order, so the one-pole de-emphasis
