@@ -479,6 +479,9 @@ __global__ __launch_bounds__(256) void k_ddc_direct(const uint8_t *__restrict__ 
     const uint8_t *hrow = hist + (size_t)s * (2 * DDC_HIST);
     const long long c0 = p.B >> 10;
     float ai = 0.f, aq = 0.f;
+    // (four taps per lane and round: the loop is a chain of dependent gathers -- sample bytes, chunk phasor, model phasor, correction -- and one round trip per
+    // tap made this edge kernel 32 us of the NFM step)
+#pragma unroll 4
     for (int t = lane; t < p.L; t += 64) {
         const long long n = (long long)p.D * k + t, rel = n - p.B;
         uint32_t vi, vq;

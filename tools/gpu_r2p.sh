@@ -1,9 +1,7 @@
 #!/bin/bash
-# A/B on one box: ring pitch + 16 (libcsdr_amd_A.so) vs + 32 in the WFM and NFM front ends
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-for lib in libcsdr_amd_A.so libcsdr_amd.so; do
-  CSDR_AMD_LIB=$PWD/csdr_amd/$lib timeout 200 python bench.py --steps 300 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('wfm $lib', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_avg_ms'], d['verify']['ok'])"
-  CSDR_AMD_LIB=$PWD/csdr_amd/$lib timeout 200 python bench_nfm.py --steps 200 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('nfm $lib', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel_avg_ms'], d['verify']['ok'])"
-done
-done
+timeout 900 python -m pytest tests -q -m gpu -k "nfm or ddc" 2>&1 | grep -E "passed|failed|Error|error" | tail -3
+timeout 200 python bench_nfm.py --steps 200 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('nfm', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['verify']['ok'])"
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2p_nfm -- python bench_nfm.py --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+f=$(find gpurun_out/r2p_nfm -name "*kernel_stats.csv" | sort | tail -1); grep "k_" $f | cut -d, -f1-4 | cut -c1-110 | head -14
