@@ -175,6 +175,62 @@ def test_bank_general_geometry(gpu, port):
         assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < TOL
 
 
+def test_c1_fir_decimate_at_256_streams(gpu, port):
+    """bench_fir.py's timed configuration (BASELINE configs[0] batched): 256 streams x 2 400 256 complexf samples, decimation 10, 79 taps; rows spread over the
+    batch against the oracle's fir_decimate_cc (libcsdr.c:528-549), and the long-filter shape (50 / 801 taps, the matrix-core kernel) on 64 streams."""
+    import torch
+    L = gpu.L
+    for S, D, tbw, kern in ((256, 10, 0.05, "poly"), (64, 50, 0.005, "mfma")):
+        T = 2344 * 1024
+        nt = gpu.firdes_filter_len(tbw)
+        taps_h = gpu.firdes_lowpass_f(nt, 0.5 / D, "HAMMING")
+        taps = gpu.upload(taps_h)
+        g = torch.Generator(device="cuda"); g.manual_seed(77 + D)
+        x = (torch.rand((S, T, 2), device="cuda", generator=g) * 2 - 1).contiguous()
+        opitch = T // D + 8
+        y = torch.empty((S, opitch, 2), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        n = L.csdr_amd_fir_decimate_cc(gpu.h, x.data_ptr(), y.data_ptr(), S, T, T, opitch, D, taps.ptr, nt)
+        assert n == (T - nt) // D + 1, gpu.err()
+        gpu.sync()
+        for r in vc.pick_rows(S, want=5):
+            want = port.fir_decimate_cc(x[r].cpu().numpy().view(np.complex64).ravel(), D, taps_h)
+            got = y[r, :n].cpu().numpy().view(np.complex64).ravel()
+            assert want.size == got.size and vc.relrms(got, want) < TOL, (kern, r)
+        taps.free(); del x, y
+
+
+def test_c3_fft_filter_at_64_streams(gpu, port):
+    """bench_fftfilt.py's timed configuration (BASELINE configs[2]): 64 streams x 16 blocks at the 65536-point framing, 1023 taps -- the one-pass kernel and, with
+    CSDR_AMD_FFTFILT_LDS_OFF, the three-pass 65536-point transform -- and the sweep's longest filter (4095 taps: 16384-point windows), rows against the oracle's
+    block-by-block overlap-add (libcsdr.c:814-849)."""
+    import torch
+    L = gpu.L
+    S, nb, FFT = 64, 16, 65536
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = (torch.rand((S, nb * FFT, 2), device="cuda", generator=g) * 2 - 1).contiguous()
+    y = torch.empty((S, nb * FFT, 2), dtype=torch.float32, device="cuda")
+    pitch = nb * FFT
+    for ntaps, full in ((1023, False), (1023, True), (4095, False)):
+        taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
+        if full:
+            os.environ["CSDR_AMD_FFTFILT_LDS_OFF"] = "1"
+        try:
+            f = L.csdr_amd_fftfilt_create(gpu.h, FFT, taps.ctypes.data_as(C.c_void_p), ntaps, S, nb)
+        finally:
+            os.environ.pop("CSDR_AMD_FFTFILT_LDS_OFF", None)
+        assert f, gpu.err()
+        assert (L.csdr_amd_fftfilt_window(f) == 0) == full
+        inp = L.csdr_amd_fftfilt_input_size(f)
+        assert L.csdr_amd_fftfilt_process(f, x.data_ptr(), y.data_ptr(), nb, pitch, pitch) >= 0, gpu.err()
+        gpu.sync()
+        for r in vc.pick_rows(S, want=3):
+            want = port.bandpass_fir_fft_cc(x[r, :nb * inp].cpu().numpy().view(np.complex64).ravel(), taps, FFT)
+            got = y[r, :nb * inp].cpu().numpy().view(np.complex64).ravel()
+            assert vc.relrms(got[:want.size], want) < TOL, (ntaps, full, r)
+        L.csdr_amd_fftfilt_destroy(f)
+
+
 def test_c2_wfm_at_1024_streams(gpu):
     """bench.py's timed configuration: 1024 streams x 2 400 256 samples (4.9 GB of u8 IQ), 16 full audio rows of the bench's noise input vs
     the oracle (statistical gate, see verify_configs.verify_wfm) and 6 rows carrying a real FM signal, spread over other stream blocks,
