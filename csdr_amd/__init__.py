@@ -601,14 +601,17 @@ class Context:
         self.L.csdr_amd_fastddc_inv_destroy(f)
         return [np.concatenate(o) for o in outs]
 
-    def fastddc_bank(self, x, tbw, decimation, shift_rates, window="HAMMING", blocks_per_call=None, retune=None):
+    def fastddc_bank(self, x, tbw, decimation, shift_rates, window="HAMMING", blocks_per_call=None, retune=None, schedule=None, retunes=None):
         """forward + inverse in one object (csdr_amd_fastddc_bank_*): x = wideband samples -> list of per-channel outputs.
-        retune = (call_index, channel, rate): applied before that call."""
+        retune = (call_index, channel, rate): applied before that call.  schedule = explicit list of blocks per call (instead of blocks_per_call);
+        retunes = {call_index: [(channel, rate), ...]}."""
         x = np.ascontiguousarray(x, c64)
         rates = np.ascontiguousarray(shift_rates, f32); nc = rates.size
         ddc, _ = self.fastddc_init(tbw, decimation, 0.0)
         nb = x.size // ddc.input_size
         per = nb if not blocks_per_call else blocks_per_call
+        if schedule:
+            per = max(schedule)
         bk = self.L.csdr_amd_fastddc_bank_create(self.h, tbw, decimation, _hp(rates), nc, WINDOWS[window], max(per, 1))
         if not bk:
             raise CsdrAmdError(self.err())
@@ -616,9 +619,11 @@ class Context:
         outs = [[] for _ in range(nc)]
         b = 0; call = 0
         while b < nb:
-            k = min(per, nb - b)
+            k = min(per, nb - b) if not schedule else min(schedule[call % len(schedule)], nb - b)
             if retune and retune[0] == call:
                 self.check(self.L.csdr_amd_fastddc_bank_set_rate(bk, retune[1], retune[2]), "bank_set_rate")
+            for ch, rt in (retunes or {}).get(call, []):
+                self.check(self.L.csdr_amd_fastddc_bank_set_rate(bk, ch, rt), "bank_set_rate")
             pitch = self.L.csdr_amd_fastddc_bank_max_output(bk, k) + 8
             do = self.alloc(8 * nc * pitch)
             counts = np.zeros(nc, np.int32)

@@ -116,6 +116,28 @@ def test_c4_bank_alternative_paths(gpu, monkeypatch, switch):
         assert got[c].size == want[c].size and vc.relrms(got[c], want[c]) < 2e-6, "channel %d" % c
 
 
+def test_c4_bank_random_schedule(gpu, monkeypatch):
+    """Chain tables computed one call ahead (riders of the previous call's inverse transforms, committed when the size matches and nothing retuned) against the same
+    bank with that machinery off, on a random schedule: 26 calls of 1 .. 7 blocks with runs of equal sizes (hits) and changes (misses), retunes of random channels
+    before a third of the calls -- every channel's stream equal to rounding, equal sample counts."""
+    tbw, D, nch = 0.001, 256, 23
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(49)
+    sizes = []
+    while len(sizes) < 26:
+        sizes += [int(rng.integers(1, 8))] * int(rng.integers(1, 5))
+    sizes = sizes[:26]
+    nb = sum(sizes)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = np.ascontiguousarray(vc.c4_rates(256)[1::11][:nch])
+    retunes = {int(c): [(int(rng.integers(0, nch)), float(rng.uniform(-0.45, 0.45)))] for c in rng.choice(np.arange(1, 26), 8, replace=False)}
+    got = gpu.fastddc_bank(x, tbw, D, rates, schedule=sizes, retunes=retunes)
+    monkeypatch.setenv("CSDR_AMD_DDC_SPEC_OFF", "1"); monkeypatch.setenv("CSDR_AMD_DDC_RIDERS_OFF", "1")
+    want = gpu.fastddc_bank(x, tbw, D, rates, schedule=sizes, retunes=retunes)
+    for c in range(nch):
+        assert got[c].size == want[c].size and vc.relrms(got[c], want[c]) < 2e-6, "channel %d" % c
+
+
 def test_bank_pipelined_single_rank_communicator(gpu):
     """submit(N + 1) before collect(N) (two batches staged: the second one's chains and forward transform run on the side stream under the first one's
     fold) gives the stream process() gives; the bank is created through the sharded entry point on a ONE-rank RCCL communicator of the library's own
