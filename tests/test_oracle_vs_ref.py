@@ -85,6 +85,18 @@ def test_shift_addition_stream(port, ref, rate):
     assert abs(pa - pb) < 1e-5
 
 
+@pytest.mark.parametrize("chunk", [1000, 777, 4096 + 3, 1])
+def test_shift_addition_odd_chunks(port, ref, chunk):
+    """The phase advance `starting_phase += d.rate*PI*input_size` (libcsdr_gpl.c:48) for chunk lengths that are not 1024 (the association of that
+    product): oracle and compiled reference walk the same stream in `chunk`-sample calls (a ragged last call included) and must agree on samples and on the phase."""
+    rng = np.random.default_rng(14)
+    x = crand(rng, (chunk * 37 + 5) if chunk > 1 else 3000)
+    for rate in (-0.085, 0.3141, 0.03125, 0.4999):
+        (a, pa), (b, pb) = port.shift_addition_cc(x, rate, chunk=chunk), ref.shift_addition_cc(x, rate, chunk=chunk)
+        assert relrms(a, b) < 2e-6
+        assert abs(pa - pb) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["shift_math_cc", "shift_table_cc", "shift_unroll_cc", "shift_addfast_cc"])
 @pytest.mark.parametrize("rate", [-0.085, 0.3141, 4e-4])
 def test_shift_variants(port, ref, name, rate):
