@@ -746,67 +746,118 @@ int passthrough(bool read_preamble, int send_size)
 // N processes re-reading the same spectrum.  Here: one forward transform per block and ONE multi-channel inverse call for all clients;
 //   csdr fastddc_bank_cc <decimation> <transition_bw> <window> <ctl | -> <out_0> <shift_rate_0> [<out_1> <shift_rate_1> ...]
 // out_k: a path (file or fifo) or fd:<n>;  ctl: a fifo path / fd:<n> carrying lines "<channel> <shift_rate>\n" (newest line per poll), or "-".
+// Several GPUs (ddcd_old.cpp:238-252): start the SAME command line once per GPU with CSDR_AMD_RANK / CSDR_AMD_WORLD (and CSDR_AMD_DEVICE) set and
+// CSDR_AMD_COMM_FILE naming a path all ranks can reach: rank 0 creates the library's RCCL communicator id there, reads the wideband stream from stdin and the control
+// channel; every rank owns a block of the channels (csdr_amd_fastddc_bank_create_sharded) and writes only those outputs.  Per batch rank 0 broadcasts a small header
+// (blocks, end of stream, retunes) so that all ranks make the same calls.
 int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
 {
     if (argc < 8 || (argc - 6) % 2) return badsyntax("usage: fastddc_bank_cc <decimation> <transition_bw> <window> <ctl|-> <out_0> <rate_0> [<out_k> <rate_k> ...]");
     int D = 0; float tbw = 0.05f; sscanf(argv[2], "%d", &D); sscanf(argv[3], "%g", &tbw);
     const int window = window_from(argv[4]);
     const int n_ch = (argc - 6) / 2;
+    int rank = 0, world = 1;
+    if (const char *e = getenv("CSDR_AMD_WORLD")) world = atoi(e);
+    if (const char *e = getenv("CSDR_AMD_RANK")) rank = atoi(e);
+    const bool multi = getenv("CSDR_AMD_WORLD") != nullptr;            // (a world of 1 still goes through the communicator: the single-GPU test of this path)
+    if (world < 1 || rank < 0 || rank >= world) return badsyntax("CSDR_AMD_RANK / CSDR_AMD_WORLD out of range");
     auto open_fd = [](const char *spec, int flags) { int fd = -1; if (!strncmp(spec, "fd:", 3)) sscanf(spec + 3, "%d", &fd); else fd = open(spec, flags, 0644); return fd; };
     Control ctl;
-    if (strcmp(argv[5], "-")) { ctl.fd = open_fd(argv[5], O_RDONLY | O_NONBLOCK); if (ctl.fd <= 0) return badsyntax("cannot open the control channel"); fcntl(ctl.fd, F_SETFL, fcntl(ctl.fd, F_GETFL, 0) | O_NONBLOCK); }
-    std::vector<int> out_fd(n_ch); std::vector<float> rates(n_ch);
-    for (int k = 0; k < n_ch; k++) {
-        sscanf(argv[7 + 2 * k], "%g", &rates[k]);
-        out_fd[k] = open_fd(argv[6 + 2 * k], O_WRONLY | O_CREAT | O_TRUNC);
-        if (out_fd[k] < 0) { fprintf(stderr, "csdr fastddc_bank_cc: cannot open output %s\n", argv[6 + 2 * k]); return -1; }
-    }
+    if (rank == 0 && strcmp(argv[5], "-")) { ctl.fd = open_fd(argv[5], O_RDONLY | O_NONBLOCK); if (ctl.fd <= 0) return badsyntax("cannot open the control channel"); fcntl(ctl.fd, F_SETFL, fcntl(ctl.fd, F_GETFL, 0) | O_NONBLOCK); }
+    std::vector<float> rates(n_ch);
+    for (int k = 0; k < n_ch; k++) sscanf(argv[7 + 2 * k], "%g", &rates[k]);
     csdr_fastddc_t ddc;
     if (csdr_amd_fastddc_init(&ddc, tbw, D, 0)) return badsyntax("error in fastddc_init()");
     int nb_max = (int)(block / ddc.input_size); if (nb_max < 1) nb_max = 1;
-    csdr_amd_fastddc_bank *bank = csdr_amd_fastddc_bank_create(c, tbw, D, rates.data(), n_ch, window, nb_max);
+    csdr_amd_comm *comm = nullptr; csdr_amd_fastddc_bank *bank = nullptr;
+    int first = 0, count = n_ch;
+    if (multi) {
+        const char *cf = getenv("CSDR_AMD_COMM_FILE");
+        if (!cf && world > 1) return badsyntax("CSDR_AMD_COMM_FILE must name a file every rank can reach");
+        char id[128];
+        if (rank == 0) {
+            if (csdr_amd_comm_unique_id(id)) die("communicator id");
+            if (cf) { std::string tmp = std::string(cf) + ".tmp"; FILE *f = fopen(tmp.c_str(), "wb"); if (!f || fwrite(id, 1, 128, f) != 128) die("cannot write CSDR_AMD_COMM_FILE"); fclose(f); if (rename(tmp.c_str(), cf)) die("rename CSDR_AMD_COMM_FILE"); }
+        } else {
+            bool ok = false;
+            for (int tries = 0; tries < 6000 && !ok; tries++) { FILE *f = fopen(cf, "rb"); if (f) { ok = fread(id, 1, 128, f) == 128; fclose(f); } if (!ok) usleep(10000); }
+            if (!ok) die("timed out waiting for CSDR_AMD_COMM_FILE");
+        }
+        comm = csdr_amd_comm_create(c, id, rank, world);
+        if (!comm) die("communicator");
+        bank = csdr_amd_fastddc_bank_create_sharded(c, tbw, D, rates.data(), n_ch, window, nb_max, comm);
+        if (bank) csdr_amd_fastddc_bank_channel_slice(bank, &first, &count);
+    } else bank = csdr_amd_fastddc_bank_create(c, tbw, D, rates.data(), n_ch, window, nb_max);
     if (!bank) die("fastddc_bank create");
+    std::vector<int> out_fd(n_ch, -1);
+    for (int k = first; k < first + count; k++) {                       // this rank's clients only
+        out_fd[k] = open_fd(argv[6 + 2 * k], O_WRONLY | O_CREAT | O_TRUNC);
+        if (out_fd[k] < 0) { fprintf(stderr, "csdr fastddc_bank_cc: cannot open output %s\n", argv[6 + 2 * k]); return -1; }
+    }
     const size_t pitch = (size_t)csdr_amd_fastddc_bank_max_output(bank, nb_max) + 8;
     const size_t in_elems = (size_t)nb_max * ddc.input_size;
     csdr_complexf *h_in = nullptr, *h_out = nullptr;
-    if (hipHostMalloc((void **)&h_in, in_elems * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&h_out, (size_t)n_ch * pitch * 8, hipHostMallocDefault) != hipSuccess) die("pinned buffers");
+    if (hipHostMalloc((void **)&h_in, in_elems * 8, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&h_out, (size_t)count * pitch * 8, hipHostMallocDefault) != hipSuccess) die("pinned buffers");
     csdr_complexf *d_in = (csdr_complexf *)csdr_amd_malloc(c, in_elems * 8 + 64);
-    csdr_complexf *d_out = (csdr_complexf *)csdr_amd_malloc(c, (size_t)n_ch * pitch * 8 + 64);
-    if (!d_in || !d_out) die("device buffers");
-    std::vector<int> counts(n_ch);
-    fprintf(stderr, "csdr fastddc_bank_cc: %d channels, fft_size = %d, input_size = %d, %d blocks per call\n", n_ch, ddc.fft_size, ddc.input_size, nb_max);
+    csdr_complexf *d_out = (csdr_complexf *)csdr_amd_malloc(c, (size_t)count * pitch * 8 + 64);
+    // batch header, rank 0 -> all: {blocks, end of stream, retunes, (channel, rate bits) x up to 16}
+    enum { HDR_INTS = 3 + 2 * 16 };
+    int *h_hdr = nullptr; if (hipHostMalloc((void **)&h_hdr, HDR_INTS * sizeof(int), hipHostMallocDefault) != hipSuccess) die("pinned header");
+    int *d_hdr = (int *)csdr_amd_malloc(c, HDR_INTS * sizeof(int) + 64);
+    if (!d_in || !d_out || !d_hdr) die("device buffers");
+    std::vector<int> counts(count);
+    fprintf(stderr, "csdr fastddc_bank_cc: %d channels%s, fft_size = %d, input_size = %d, %d blocks per call\n", n_ch, multi ? " (sharded)" : "", ddc.fft_size, ddc.input_size, nb_max);
+    if (multi) fprintf(stderr, "csdr fastddc_bank_cc: rank %d of %d serves channels %d .. %d\n", rank, world, first, first + count - 1);
     size_t have = 0;
     for (bool eof = false; !eof;) {
-        size_t got = 0;
-        if (!read_full((char *)h_in + have * 8, (in_elems - have) * 8, &got)) eof = true;
-        have += got / 8;
-        if (ctl.fd) {
-            // every complete line since the last poll is applied (several clients may retune between two blocks)
-            const ssize_t r = read(ctl.fd, ctl.buf + ctl.fill, sizeof(ctl.buf) - 1 - ctl.fill);
-            if (r > 0) {
-                int end = ctl.fill + (int)r, start = 0;
-                for (int i = 0; i < end; i++) if (ctl.buf[i] == '\n') {
-                    ctl.buf[i] = 0; int ch = -1; float rate = 0;
-                    if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch) { MUST(csdr_amd_fastddc_bank_set_rate(bank, ch, rate)); fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ch, rate); }
-                    start = i + 1;
+        int nb = 0, n_ret = 0; int ret_ch[16]; float ret_rate[16];
+        if (rank == 0) {
+            size_t got = 0;
+            if (!read_full((char *)h_in + have * 8, (in_elems - have) * 8, &got)) eof = true;
+            have += got / 8;
+            if (ctl.fd) {
+                // every complete line since the last poll is applied (several clients may retune between two blocks)
+                const ssize_t r = read(ctl.fd, ctl.buf + ctl.fill, sizeof(ctl.buf) - 1 - ctl.fill);
+                if (r > 0) {
+                    int end = ctl.fill + (int)r, start = 0;
+                    for (int i = 0; i < end; i++) if (ctl.buf[i] == '\n') {
+                        ctl.buf[i] = 0; int ch = -1; float rate = 0;
+                        if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch && n_ret < 16) { ret_ch[n_ret] = ch; ret_rate[n_ret] = rate; n_ret++; }
+                        start = i + 1;
+                    }
+                    memmove(ctl.buf, ctl.buf + start, end - start); ctl.fill = end - start;
                 }
-                memmove(ctl.buf, ctl.buf + start, end - start); ctl.fill = end - start;
             }
+            nb = (int)(have / ddc.input_size);
         }
-        const int nb = (int)(have / ddc.input_size);
+        if (multi) {
+            if (rank == 0) {
+                h_hdr[0] = nb; h_hdr[1] = eof ? 1 : 0; h_hdr[2] = n_ret;
+                for (int i = 0; i < n_ret; i++) { h_hdr[3 + 2 * i] = ret_ch[i]; memcpy(&h_hdr[4 + 2 * i], &ret_rate[i], 4); }
+                MUST(csdr_amd_h2d(c, d_hdr, h_hdr, HDR_INTS * sizeof(int)));
+            }
+            MUST(csdr_amd_comm_broadcast(comm, d_hdr, HDR_INTS * sizeof(int), 0));
+            MUST(csdr_amd_d2h(c, h_hdr, d_hdr, HDR_INTS * sizeof(int)));
+            nb = h_hdr[0]; eof = h_hdr[1] != 0; n_ret = h_hdr[2];
+            for (int i = 0; i < n_ret; i++) { ret_ch[i] = h_hdr[3 + 2 * i]; memcpy(&ret_rate[i], &h_hdr[4 + 2 * i], 4); }
+        }
+        for (int i = 0; i < n_ret; i++) {
+            if (ret_ch[i] >= first && ret_ch[i] < first + count) { MUST(csdr_amd_fastddc_bank_set_rate(bank, ret_ch[i] - first, ret_rate[i])); fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ret_ch[i], ret_rate[i]); }
+        }
         if (nb == 0) continue;
         const size_t used = (size_t)nb * ddc.input_size;
-        MUST(csdr_amd_h2d(c, d_in, h_in, used * 8));
+        if (rank == 0) MUST(csdr_amd_h2d(c, d_in, h_in, used * 8));
         MUST(csdr_amd_fastddc_bank_process(bank, d_in, nb, d_out, pitch, counts.data()));
-        MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)n_ch * pitch * 8));
-        for (int k = 0; k < n_ch; k++) {
+        MUST(csdr_amd_d2h(c, h_out, d_out, (size_t)count * pitch * 8));
+        for (int k = 0; k < count; k++) {
             size_t done = 0; const size_t bytes = (size_t)counts[k] * 8; const char *src = (const char *)(h_out + (size_t)k * pitch);
-            while (done < bytes) { ssize_t r = write(out_fd[k], src + done, bytes - done); if (r < 0) { if (errno == EINTR) continue; break; } done += (size_t)r; }
+            while (done < bytes) { ssize_t r = write(out_fd[first + k], src + done, bytes - done); if (r < 0) { if (errno == EINTR) continue; break; } done += (size_t)r; }
         }
-        memmove(h_in, h_in + used, (have - used) * 8);
-        have -= used;
+        if (rank == 0) { memmove(h_in, h_in + used, (have - used) * 8); have -= used; }
     }
-    for (int k = 0; k < n_ch; k++) close(out_fd[k]);
+    for (int k = first; k < first + count; k++) close(out_fd[k]);
+    csdr_amd_fastddc_bank_destroy(bank);
+    if (comm) csdr_amd_comm_destroy(comm);
     return 0;
 }
 

@@ -494,6 +494,37 @@ def test_cli_f3_adpcm(port):
 
 
 # ---------------------------------------------------------------- f4: the ddcd topology (one forward transform, N channels, per-channel retune)
+def test_cli_fastddc_bank_multi_rank_mode(tmp_path):
+    """`csdr fastddc_bank_cc` started the way one rank of a multi-GPU bank is (CSDR_AMD_RANK / CSDR_AMD_WORLD / CSDR_AMD_COMM_FILE: the library's own RCCL communicator,
+    the sharded bank entry point, the per-batch header broadcast, only this rank's outputs opened) with a world of ONE -- all a single-GPU box can run -- must write
+    what the plain command writes, retune included (config 4's geometry: the sharded bank needs the matrix-core path)."""
+    rng = np.random.default_rng(18)
+    D, tbw, nch, nblk = 256, 0.001, 5, 5
+    inp = 57344
+    x = crand(rng, nblk * inp + 11)
+    rates = [0.11, -0.2, 0.3, 0.0, -0.4321]
+    res = {}
+    for tag, extra in (("plain", {}), ("rank", {"CSDR_AMD_RANK": "0", "CSDR_AMD_WORLD": "1", "CSDR_AMD_COMM_FILE": str(tmp_path / "comm.id")})):
+        outs = [str(tmp_path / ("%s_ch%d.bin" % (tag, k))) for k in range(nch)]
+        fifo = str(tmp_path / ("ctl_" + tag)); os.mkfifo(fifo)
+        args = ["fastddc_bank_cc", D, tbw, "HAMMING", fifo]
+        for o, r in zip(outs, rates):
+            args += [o, r]
+        env = dict(os.environ, CSDR_AMD_BLOCK=str(2 * inp), **extra)
+        p = subprocess.Popen([CLI] + [str(a) for a in args], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        ctl = open(fifo, "w")
+        ctl.write("3 0.25\n"); ctl.flush()                            # applied before the first batch
+        p.stdin.write(x.tobytes()); p.stdin.close()
+        assert p.wait(timeout=120) == 0, p.stderr.read().decode()
+        err = p.stderr.read().decode()
+        ctl.close()
+        if extra:
+            assert "rank 0 of 1 serves channels 0 .. 4" in err and os.path.getsize(extra["CSDR_AMD_COMM_FILE"]) == 128
+        res[tag] = [np.fromfile(o, c64) for o in outs]
+    for a, b in zip(res["plain"], res["rank"]):
+        assert a.size == b.size and a.size > 0 and relrms(b, a) <= 2e-6
+
+
 def test_cli_fastddc_bank(port, tmp_path):
     import time
     rng = np.random.default_rng(17)
