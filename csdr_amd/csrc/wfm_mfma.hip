@@ -233,18 +233,29 @@ __device__ __forceinline__ void load_B(v4i (&Bf)[WFM_NK], const uint8_t *__restr
         for (int ks = 0; ks < WFM_NK; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(src + 64 * ks);
     } else {
         const uint8_t *hrow = hist + (size_t)stream * (2 * WFM_HIST);
-#pragma unroll 1
+        // All fetches of the window in flight at once, from an always-valid address chosen per lane (history / block / a dummy), then a select: with one
+        // conditional fetch per K-step in a rolled loop the edge launch was 32 serial memory round trips per wave (22 us for a handful of tiles).
+        bool ragged = false;
+#pragma unroll
         for (int ks = 0; ks < WFM_NK; ks++) {
             const long long off = wbr + 64 * ks + 16 * q;
-            v4i v = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-            if (off < 0) { if (off >= -2 * WFM_HIST) v = *reinterpret_cast<const v4i *>(hrow + off + 2 * WFM_HIST); }
-            else if (off + 16 <= two_T) v = *reinterpret_cast<const v4i *>(row + off);
-            else { // ragged end of the last block: byte-wise
-                uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
-                for (int k = 0; k < 16; k++) if (off + k < two_T) { const uint32_t by = row[off + k]; w[k / 4] = (w[k / 4] & ~(0xffu << (8 * (k & 3)))) | (by << (8 * (k & 3))); }
-                v = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+            const bool in_hist = off < 0 && off >= -2 * WFM_HIST, in_blk = off >= 0 && off + 16 <= two_T;
+            const uint8_t *src = in_hist ? hrow + (off + 2 * WFM_HIST) : row + (in_blk ? off : 0);
+            const v4i v = *reinterpret_cast<const v4i *>(src);
+            const v4i z = {(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+            Bf[ks] = (in_hist || in_blk) ? v : z;
+            ragged = ragged || (off >= 0 && off < two_T && off + 16 > two_T);
+        }
+        if (ragged) {                                                   // ragged end of the last block: byte-wise (a block that is not a multiple of 1024 samples ends the stream)
+#pragma unroll
+            for (int ks = 0; ks < WFM_NK; ks++) {
+                const long long off = wbr + 64 * ks + 16 * q;
+                if (off >= 0 && off < two_T && off + 16 > two_T) {
+                    uint32_t w[4] = {0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u};
+                    for (int k = 0; k < 16; k++) if (off + k < two_T) { const uint32_t by = row[off + k]; w[k / 4] = (w[k / 4] & ~(0xffu << (8 * (k & 3)))) | (by << (8 * (k & 3))); }
+                    Bf[ks] = v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+                }
             }
-            Bf[ks] = v;
         }
     }
 }
