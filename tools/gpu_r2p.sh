@@ -1,3 +1,8 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2t
-timeout 800 python tools/bench_ops.py 2>/dev/null > gpurun_out/r2t/r2t_ops.jsonl; wc -l gpurun_out/r2t/r2t_ops.jsonl; cut -c1-150 gpurun_out/r2t/r2t_ops.jsonl | tail -14
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests -q -m gpu -k "fir" 2>&1 | grep -E "passed|failed|Error|error" | tail -3
+for rep in 1 2; do
+for lib in libcsdr_amd_A.so libcsdr_amd.so; do
+  CSDR_AMD_LIB=$PWD/csdr_amd/$lib timeout 200 python bench_fir.py --decimation 50 --tbw 0.005 --streams 64 --no-cpu-baseline --verify 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', d['value'], d['ms_per_step'], d['roofline']['frac'], d['verify']['ok'], d['verify']['max_rel_rms'])"
+done
+done
