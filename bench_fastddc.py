@@ -55,8 +55,110 @@ def verify(ctx, L, ddc, args, x, rates, first, count, nb):
     return {"channels": chans, "blocks": nb, "max_rel_rms": worst, "tolerance": 1e-5, "kernel": kname, "ok": bool(ok and worst < 1e-5)}
 
 
+# xGMI on MI355X: 7 links per GPU, 153.6 GB/s per link counting BOTH directions (1075 GB/s aggregate in AMD's figures) = 76.8 GB/s per link and direction.
+# The exchange model below prices every transfer at that per-direction rate (and shows the optimistic "153.6 per direction" reading beside it).
+XGMI_LINK_GBS = 76.8
+
+
+def emulate(args):
+    """--emulate-world W: ONE rank's real per-batch work of a W-rank bank, timed alone on this box's GPU (csdr_amd_comm_create_null: the exchange calls
+    return at once and move nothing, every kernel of the rank's schedule runs), for every rank in turn, beside the single-GPU bank on the same number of
+    blocks and a bytes-per-link model of the exchange.  An EMULATION: it measures compute per rank, it does not measure a multi-GPU run."""
+    import numpy as np
+    import torch
+    import csdr_amd
+    W = args.emulate_world
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream()
+    ctx = csdr_amd.Context(0, hip_stream=stream.cuda_stream)
+    L = ctx.L
+    ddc, err = ctx.fastddc_init(args.tbw, args.decimation, 0.0)
+    assert err == 0
+    nb = args.blocks                                                       # blocks per GLOBAL batch
+    rates = (-0.5 + (np.arange(args.channels) + 0.5) / args.channels).astype(np.float32)
+    g = torch.Generator(device=dev); g.manual_seed(4)
+    x = (torch.rand((nb * ddc.input_size + ddc.overlap_length, 2), device=dev, generator=g) * 2 - 1).contiguous()
+    mode = csdr_amd.SHARD[args.shard]
+
+    def time_steps(step, n):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    # single GPU, same blocks: calls of at most 64 blocks (the fold kernel's tile), i.e. what bench_fastddc.py times, repeated
+    per1 = min(nb, 64)
+    bank1 = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, rates.ctypes.data_as(C.c_void_p), args.channels, 2, per1)
+    pitch1 = L.csdr_amd_fastddc_bank_max_output(bank1, per1) + 8
+    out1 = torch.empty((args.channels, pitch1, 2), dtype=torch.float32, device=dev)
+
+    def step1():
+        for b in range(0, nb, per1):
+            if L.csdr_amd_fastddc_bank_process(bank1, x.data_ptr() + 8 * b * ddc.input_size, min(per1, nb - b), out1.data_ptr(), pitch1, None) < 0:
+                raise SystemExit(ctx.err())
+    t1 = time_steps(step1, args.steps)
+    L.csdr_amd_fastddc_bank_destroy(bank1); del out1
+
+    ranks = range(W) if args.rank < 0 else [args.rank]
+    t_rank = {}
+    for r in ranks:
+        comm = L.csdr_amd_comm_create_null(ctx.h, r, W)
+        bank = L.csdr_amd_fastddc_bank_create_sharded_by(ctx.h, args.tbw, args.decimation, rates.ctypes.data_as(C.c_void_p), args.channels, 2, nb, comm, mode)
+        if not bank:
+            raise SystemExit("bank_create_sharded_by: " + ctx.err())
+        f0 = C.c_int(); c0 = C.c_int(); L.csdr_amd_fastddc_bank_channel_slice(bank, C.byref(f0), C.byref(c0))
+        pitch = L.csdr_amd_fastddc_bank_max_output(bank, nb) + 8
+        out = torch.empty((c0.value, pitch, 2), dtype=torch.float32, device=dev)
+        submit = L.csdr_amd_fastddc_bank_submit_local if (args.local_input and mode == 1) else L.csdr_amd_fastddc_bank_submit
+
+        def step():
+            if submit(bank, x.data_ptr(), nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
+                raise SystemExit(ctx.err())
+        if submit(bank, x.data_ptr(), nb) < 0:                            # one batch always staged, like the pipelined multi-GPU loop
+            raise SystemExit(ctx.err())
+        t_rank[r] = time_steps(step, args.steps)
+        L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)
+        L.csdr_amd_fastddc_bank_finish(bank, None)
+        ctx.sync(); torch.cuda.synchronize()
+        L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm); del out
+    worst = max(t_rank.values())
+    # ---- exchange model: bytes each GPU pushes through ONE of its links per batch (every peer sits behind its own link: full mesh)
+    in_b = 8.0 * nb * ddc.input_size; spec_b = 8.0 * nb * ddc.fft_size; out_b = 8.0 * nb * (ddc.post_input_size // ddc.post_decimation) * args.channels
+    per_link = {
+        "input_scatter_root": in_b / W,                                    # the root sends every peer its 1/W of the stream (only when the stream lives on one GPU)
+        "output_all_to_all": out_b / W / W if mode == 1 else 0.0,          # every rank sends each peer 1/W of its 1/W of the outputs
+        "spectra_all_gather": spec_b / W if mode == 0 else 0.0,            # every rank sends each peer its 1/W of the spectra
+    }
+    model = {}
+    for name, gbs in (("at_76p8_GBps_per_direction", XGMI_LINK_GBS), ("at_153p6_GBps_per_direction_optimistic", 2 * XGMI_LINK_GBS)):
+        t_root = (per_link["input_scatter_root"] + per_link["output_all_to_all"] + per_link["spectra_all_gather"]) / (gbs * 1e9)
+        t_dist = (per_link["output_all_to_all"] + per_link["spectra_all_gather"]) / (gbs * 1e9)
+        model[name] = {"t_exchange_ms_input_on_rank0": round(t_root * 1e3, 4), "t_exchange_ms_input_distributed_at_ingest": round(t_dist * 1e3, 4),
+                       "predicted_scaling_input_on_rank0": round(t1 / max(worst, t_root), 2),
+                       "predicted_scaling_input_distributed_at_ingest": round(t1 / max(worst, t_dist), 2)}
+    res = {"metric": "fastddc 256-channel channelizer: ONE rank's per-batch work of a world-%d bank, emulated on one GPU" % W, "emulation": True,
+           "note": "compute per rank measured alone on one MI355X with a null transport; the exchange is a bytes-per-link model, NOT a measurement; "
+                   "exchange and compute overlap by construction (own streams, batch N+1's input / batch N's output under batch N's / N+1's kernels)",
+           "world": W, "shard": args.shard, "blocks_per_global_batch": nb, "channels": args.channels, "steps": args.steps,
+           "t1_ms_single_gpu_same_blocks": round(t1 * 1e3, 4), "t_rank_ms": {str(r): round(v * 1e3, 4) for r, v in t_rank.items()},
+           "t_rank_ms_worst": round(worst * 1e3, 4), "t_rank_us_per_64_blocks": round(worst * 1e6 * 64 / nb, 2),
+           "compute_only_scaling": round(t1 / worst, 2), "bytes_per_link_per_batch": {k: int(v) for k, v in per_link.items()}, "exchange_model": model,
+           "input_GSps_single_gpu": round(nb * ddc.input_size / t1 / 1e9, 2), "input_GSps_world_compute_only": round(nb * ddc.input_size / worst / 1e9, 2)}
+    print(json.dumps(res))
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--emulate-world", type=int, default=0, help="time ONE rank's work of a world-N bank on this GPU (null transport) instead of running the bench")
+    ap.add_argument("--rank", type=int, default=-1, help="with --emulate-world: the rank to time (default: every rank in turn)")
+    ap.add_argument("--shard", choices=["blocks", "channels"], default="blocks")
+    ap.add_argument("--local-input", action="store_true", help="with --emulate-world --shard blocks: every rank is handed its own run (no input exchange)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=3)
@@ -67,6 +169,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true")
     args = ap.parse_args()
+    if args.emulate_world:
+        return emulate(args)
 
     import numpy as np
     import torch

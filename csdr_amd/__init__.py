@@ -157,6 +157,18 @@ def lib():
     L.csdr_amd_comm_broadcast.argtypes = [vp, vp, sz, i]
     L.csdr_amd_fastddc_bank_create_sharded.restype = vp; L.csdr_amd_fastddc_bank_create_sharded.argtypes = [vp, fl, i, vp, i, i, i, vp]
     L.csdr_amd_fastddc_bank_channel_slice.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.csdr_amd_fastddc_bank_create_sharded_by.restype = vp; L.csdr_amd_fastddc_bank_create_sharded_by.argtypes = [vp, fl, i, vp, i, i, i, vp, i]
+    L.csdr_amd_fastddc_bank_shard_mode.argtypes = [vp]
+    L.csdr_amd_fastddc_bank_local_blocks.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
+    L.csdr_amd_fastddc_bank_overlap.argtypes = [vp]
+    L.csdr_amd_fastddc_bank_submit_local.argtypes = [vp, vp, i]
+    L.csdr_amd_fastddc_bank_finish.argtypes = [vp, vp]
+    L.csdr_amd_fastddc_bank_set_rate_global.argtypes = [vp, i, fl]
+    L.csdr_amd_loopback_create.restype = vp; L.csdr_amd_loopback_create.argtypes = [i]
+    L.csdr_amd_loopback_destroy.argtypes = [vp]; L.csdr_amd_loopback_destroy.restype = None
+    L.csdr_amd_loopback_abort.argtypes = [vp]; L.csdr_amd_loopback_abort.restype = None
+    L.csdr_amd_comm_create_loopback.restype = vp; L.csdr_amd_comm_create_loopback.argtypes = [vp, vp, i]
+    L.csdr_amd_comm_create_null.restype = vp; L.csdr_amd_comm_create_null.argtypes = [vp, i, i]
     L.csdr_amd_fastddc_inv_kernel_name.restype = C.c_char_p; L.csdr_amd_fastddc_inv_kernel_name.argtypes = [vp]
     L.csdr_amd_fastddc_inv_set_profiling.argtypes = [vp, i]
     L.csdr_amd_fastddc_inv_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
@@ -636,6 +648,8 @@ class Context:
         self.L.csdr_amd_fastddc_bank_destroy(bk)
         return [np.concatenate(o) for o in outs]
 
+    # (the multi-rank form of the bank on ONE GPU: sharded_bank_loopback below, module level -- one Context per rank thread)
+
     def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0):
         """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call;
         `pitch_pad` = extra bytes of row pitch (multiple of 16; a pitch that is not a multiple of 128 selects the quad kernel).
@@ -757,3 +771,96 @@ class Context:
         af = self.download(d_agc, f32, S * pd2).reshape(S, pd2)[:, :na]
         pcm = self.download(d_pcm, np.int16, S * pd2).reshape(S, pd2)[:, :na]
         return (pcm[0].copy(), af[0].copy()) if squeeze else (pcm.copy(), af.copy())
+
+
+SHARD = {"channels": 0, "blocks": 1}
+
+
+def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode="blocks", window="HAMMING", retunes=None, pipelined=True,
+                          local_input=False, device=0):
+    """The multi-rank fastddc bank (csdr_amd_fastddc_bank_create_sharded_by) run for real on ONE GPU: `world` rank threads, one Context each, joined by the
+    library's loopback communicator (every exchange = stream-ordered device copies).  x = the wideband stream (on rank 0; local_input: every rank is handed
+    its own run of each batch instead), schedule = blocks per batch, retunes = {batch index: [(global channel, rate), ...]} applied before that batch.
+    pipelined: submit(k + 1) is queued before collect(k) wherever no retune sits in between.  Returns the per-channel outputs (all channels, gathered from the
+    ranks' slices)."""
+    import threading
+    L = lib()
+    x = np.ascontiguousarray(x, c64)
+    rates = np.ascontiguousarray(shift_rates, f32); nc = rates.size
+    retunes = retunes or {}
+    grp = L.csdr_amd_loopback_create(world)
+    if not grp:
+        raise CsdrAmdError(L.csdr_amd_last_error().decode())
+    outs = [None] * nc
+    errors = []
+
+    def rank_main(rank):
+        ctx = None
+        try:
+            ctx = Context(device)
+            comm = L.csdr_amd_comm_create_loopback(ctx.h, grp, rank)
+            if not comm:
+                raise CsdrAmdError(ctx.err())
+            per = max(schedule)
+            bank = L.csdr_amd_fastddc_bank_create_sharded_by(ctx.h, tbw, decimation, _hp(rates), nc, WINDOWS[window], per, comm, SHARD[mode])
+            if not bank:
+                raise CsdrAmdError(ctx.err())
+            first = C.c_int(); count = C.c_int()
+            L.csdr_amd_fastddc_bank_channel_slice(bank, C.byref(first), C.byref(count))
+            first, count = first.value, count.value
+            inp = L.csdr_amd_fastddc_bank_input_size(bank); ovl = L.csdr_amd_fastddc_bank_overlap(bank)
+            starts = np.concatenate([[0], np.cumsum(schedule)])
+            di = ctx.upload(x) if (rank == 0 and not local_input) else None
+            mine = [[] for _ in range(count)]
+            held = {}
+
+            def submit(k):
+                nb = schedule[k]
+                if local_input:
+                    f0 = C.c_int(); n0 = C.c_int()
+                    L.csdr_amd_fastddc_bank_local_blocks(bank, nb, C.byref(f0), C.byref(n0))
+                    a = (starts[k] + f0.value) * inp
+                    run = np.zeros(ovl + n0.value * inp, c64)
+                    lo = max(0, a - ovl)
+                    run[ovl - (a - lo):] = x[lo:a + n0.value * inp]
+                    held[k] = ctx.upload(run)
+                    ctx.check(L.csdr_amd_fastddc_bank_submit_local(bank, held[k].ptr, nb), "bank_submit_local")
+                else:
+                    ctx.check(L.csdr_amd_fastddc_bank_submit(bank, di.at(8 * starts[k] * inp) if di is not None else None, nb), "bank_submit")
+
+            submitted = -1
+            for k in range(len(schedule)):
+                for ch, rt in retunes.get(k, []):
+                    ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt), "bank_set_rate_global")
+                if submitted < k:
+                    submit(k); submitted = k
+                if pipelined and k + 1 < len(schedule) and (k + 1) not in retunes:
+                    submit(k + 1); submitted = k + 1
+                pitch = L.csdr_amd_fastddc_bank_max_output(bank, schedule[k]) + 8
+                do = ctx.alloc(8 * count * pitch)
+                ctx.check(L.csdr_amd_fastddc_bank_collect(bank, do.ptr, pitch, None), "bank_collect")
+                counts = np.zeros(count, np.int32)
+                ctx.check(L.csdr_amd_fastddc_bank_finish(bank, _hp(counts)), "bank_finish")
+                y = ctx.download(do, c64, count * pitch).reshape(count, pitch)
+                for c in range(count):
+                    mine[c].append(y[c, :counts[c]].copy())
+                held.pop(k, None)
+            for c in range(count):
+                outs[first + c] = np.concatenate(mine[c])
+            L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm)
+        except BaseException as e:      # a dead rank must not leave the others waiting at a rendezvous
+            errors.append((rank, e))
+            L.csdr_amd_loopback_abort(grp)
+        finally:
+            if ctx is not None:
+                ctx.close()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    L.csdr_amd_loopback_destroy(grp)
+    if errors:
+        raise CsdrAmdError("rank %d: %r" % errors[0])
+    return outs

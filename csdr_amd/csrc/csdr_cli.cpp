@@ -818,15 +818,16 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
             if (ctl.fd) {
                 // every complete line since the last poll is applied (several clients may retune between two blocks)
                 const ssize_t r = read(ctl.fd, ctl.buf + ctl.fill, sizeof(ctl.buf) - 1 - ctl.fill);
-                if (r > 0) {
-                    int end = ctl.fill + (int)r, start = 0;
-                    for (int i = 0; i < end; i++) if (ctl.buf[i] == '\n') {
-                        ctl.buf[i] = 0; int ch = -1; float rate = 0;
-                        if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch && n_ret < 16) { ret_ch[n_ret] = ch; ret_rate[n_ret] = rate; n_ret++; }
-                        start = i + 1;
-                    }
-                    memmove(ctl.buf, ctl.buf + start, end - start); ctl.fill = end - start;
+                if (r > 0) ctl.fill += (int)r;
+                // at most 16 retunes travel in one batch header: further complete lines stay in the buffer for the next batch (none is dropped)
+                int start = 0;
+                for (int i = 0; i < ctl.fill && n_ret < 16; i++) if (ctl.buf[i] == '\n') {
+                    ctl.buf[i] = 0; int ch = -1; float rate = 0;
+                    if (sscanf(ctl.buf + start, "%d %g", &ch, &rate) == 2 && ch >= 0 && ch < n_ch) { ret_ch[n_ret] = ch; ret_rate[n_ret] = rate; n_ret++; }
+                    start = i + 1;
                 }
+                if (start) { memmove(ctl.buf, ctl.buf + start, ctl.fill - start); ctl.fill -= start; }
+                else if (ctl.fill >= (int)sizeof(ctl.buf) - 1) ctl.fill = 0;      // an over-long line without a newline: discard it
             }
             nb = (int)(have / ddc.input_size);
         }
@@ -842,7 +843,8 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
             for (int i = 0; i < n_ret; i++) { ret_ch[i] = h_hdr[3 + 2 * i]; memcpy(&ret_rate[i], &h_hdr[4 + 2 * i], 4); }
         }
         for (int i = 0; i < n_ret; i++) {
-            if (ret_ch[i] >= first && ret_ch[i] < first + count) { MUST(csdr_amd_fastddc_bank_set_rate(bank, ret_ch[i] - first, ret_rate[i])); fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ret_ch[i], ret_rate[i]); }
+            MUST(csdr_amd_fastddc_bank_set_rate_global(bank, ret_ch[i], ret_rate[i]));      // every rank makes the call; a rank applies it to what it computes
+            if (ret_ch[i] >= first && ret_ch[i] < first + count) fprintf(stderr, "csdr fastddc_bank_cc: channel %d retuned to %g\n", ret_ch[i], ret_rate[i]);
         }
         if (nb == 0) continue;
         const size_t used = (size_t)nb * ddc.input_size;

@@ -41,6 +41,10 @@ struct DdcMfma {
     float *d_Ht; cf32 *d_Ct; float2 *d_tw;
     // sharding (a bank over several GPUs): this rank's channels [C] of all, the forward transform split by blocks (nbl per rank), Xt = one chunk per rank
     int rank, world, nbl; const DdcComm *comm; cf32 *d_in_local;
+    // time-sliced bank (fftpath.hip: the bank deals the BLOCKS of a batch to the ranks, every rank runs this object unsharded on its run): where the next call's
+    // blocks sit in the batch (ddc_mfma_set_segment), and per set the samples every rank's run produces [seg_world][C]
+    int seg_nbl = 0, seg_first = 0, seg_total = 0, seg_world = 0, spec_seg_first = 0, spec_seg_total = 0; int *d_seg_counts[2] = {nullptr, nullptr}; int seg_counts_world = 0;
+    const int *last_seg_counts = nullptr;
     // Two sets of everything a call produces before the fold (transposed spectra, chain tables, phasor checkpoints): submit() fills one set on the side
     // stream -- exchange + forward transform + chains -- while collect() folds the other on the context's stream.
     cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
@@ -378,25 +382,101 @@ struct DdcChainJob {                                                 // one call
     DdcChanState *state, *state_out; const ChanGeom *geom; int n_channels, n_blocks, post_in, post_dec, kmax;      // state_out: where the advanced state goes (= state, or the shadow of tables computed ahead)
     int mode;                                                       // riders of forward pass 1: 1 = the chain tables; 2 = the tables exist already (computed one call ahead): commit their state, phasor checkpoints
     int *blk_remain; float *blk_phase; int *blk_off; int *counts; float2 *R;
+    // time-sliced bank (the blocks of a batch dealt to the ranks in runs of seg_nbl): this rank's n_blocks blocks are global blocks [seg_first, seg_first + n_blocks) of
+    // seg_total; `state` is the state at global block 0, state_out the one behind block seg_total - 1; seg_counts[rank][channel] = samples every rank's run produces
+    int seg_nbl, seg_first, seg_total, seg_world; int *seg_counts;
 };
-__device__ __forceinline__ void ddc_chain_body(const DdcChainJob &j, int c)
+// one block of decimating_shift_addition_cc's bookkeeping (libcsdr_gpl.c:153-158): samples produced, state advanced
+__device__ __forceinline__ int ddc_chain_step(DdcChanState &s, float r, int post_in, int post_dec, int sh)
+{
+    int k = 0, pos = s.remain;
+    if (pos < post_in) { k = (sh >= 0 ? (post_in - 1 - pos) >> sh : (post_in - 1 - pos) / post_dec) + 1; pos += k * post_dec; }
+    s.remain = pos - post_in;
+    float p = s.phase + r * PI_F * (float)k;                           // libcsdr_gpl.c:155
+    while (p > PI_F) p -= 2 * PI_F;
+    while (p < -PI_F) p += 2 * PI_F;
+    s.phase = p;
+    return k;
+}
+// When post_input_size is a multiple of post_decimation (every power-of-two decimation: 448 / 2) and 0 <= remain < post_decimation, a block neither changes
+// `remain` nor the sample count k = post_in / post_dec, and the phase advances by the same float d = r PI k every block; for |d| < 6 the reference's two
+// while loops (libcsdr_gpl.c:156-157) run at most once, so a step is five dependent float operations -- the same values, bit for bit, as ddc_chain_step.
+struct DdcChainFast { bool ok; int k; float d; };
+__device__ __forceinline__ DdcChainFast ddc_chain_fast(const DdcChanState &s, float r, int post_in, int post_dec)
+{
+    DdcChainFast f;
+    f.k = post_in / post_dec; f.d = r * PI_F * (float)f.k;
+    f.ok = post_in % post_dec == 0 && s.remain >= 0 && s.remain < post_dec && fabsf(f.d) < 6.0f;
+    return f;
+}
+__device__ __forceinline__ float ddc_phase_step(float p, float d)
+{
+    p = p + d;
+    const float lo = p - 2 * PI_F; p = p > PI_F ? lo : p;
+    const float hi = p + 2 * PI_F; p = p < -PI_F ? hi : p;
+    return p;
+}
+// The chain of a time-sliced bank: every rank walks ALL blocks of the batch (the state is a strictly sequential float recurrence, but data independent, so
+// nothing has to be exchanged), keeps the tables of its own run only -- offsets local to the run -- and notes how many samples every run produces (what the
+// output exchange needs to stitch a channel's stream together).
+__device__ __forceinline__ void ddc_chain_body_seg(const DdcChainJob &j, int c)
 {
     if (c >= j.n_channels) return;
     DdcChanState s = j.state[c];
     const float r = j.geom[c].rate2;
     const int post_in = j.post_in, post_dec = j.post_dec, n_channels = j.n_channels;
+    const int sh = (post_dec & (post_dec - 1)) == 0 ? __ffs(post_dec) - 1 : -1;
+    const DdcChainFast f = ddc_chain_fast(s, r, post_in, post_dec);
+    for (int g = 0; g < j.seg_world; g++) {
+        const int b0 = min(g * j.seg_nbl, j.seg_total), b1 = min(b0 + j.seg_nbl, j.seg_total);
+        const bool mine = b0 == j.seg_first && j.n_blocks > 0;
+        int cnt = 0;
+        if (f.ok) {
+            float p = s.phase;
+            if (mine) for (int b = b0; b < b1; b++) {
+                const size_t id = (size_t)(b - b0) * n_channels + c;
+                j.blk_remain[id] = s.remain; j.blk_phase[id] = p; j.blk_off[id] = (b - b0) * f.k;
+                p = ddc_phase_step(p, f.d);
+            } else for (int b = b0; b < b1; b++) p = ddc_phase_step(p, f.d);
+            s.phase = p; cnt = (b1 - b0) * f.k;
+        } else if (mine) {
+            for (int b = b0; b < b1; b++) {
+                const size_t id = (size_t)(b - b0) * n_channels + c;
+                j.blk_remain[id] = s.remain; j.blk_phase[id] = s.phase; j.blk_off[id] = cnt;
+                cnt += ddc_chain_step(s, r, post_in, post_dec, sh);
+            }
+        } else for (int b = b0; b < b1; b++) cnt += ddc_chain_step(s, r, post_in, post_dec, sh);
+        if (mine) j.counts[c] = cnt;
+        j.seg_counts[(size_t)g * n_channels + c] = cnt;
+    }
+    if (j.n_blocks <= 0) j.counts[c] = 0;
+    j.state_out[c] = s;
+}
+__device__ __forceinline__ void ddc_chain_body(const DdcChainJob &j, int c)
+{
+    if (j.seg_nbl) { ddc_chain_body_seg(j, c); return; }
+    if (c >= j.n_channels) return;
+    DdcChanState s = j.state[c];
+    const float r = j.geom[c].rate2;
+    const int post_in = j.post_in, post_dec = j.post_dec, n_channels = j.n_channels;
     const int sh = (post_dec & (post_dec - 1)) == 0 ? __ffs(post_dec) - 1 : -1;    // post_decimation is 2 for every power-of-two decimation: a shift, not a division
+    const DdcChainFast f = ddc_chain_fast(s, r, post_in, post_dec);
+    if (f.ok) {                                                       // (lanes of a wave may differ: both forms give the same values)
+        float p = s.phase;
+        for (int b = 0; b < j.n_blocks; b++) {
+            const size_t id = (size_t)b * n_channels + c;
+            j.blk_remain[id] = s.remain; j.blk_phase[id] = p; j.blk_off[id] = b * f.k;
+            p = ddc_phase_step(p, f.d);
+        }
+        s.phase = p;
+        j.state_out[c] = s; j.counts[c] = j.n_blocks * f.k;
+        return;
+    }
     int off = 0;
-    for (int b = 0; b < j.n_blocks; b++) {                            // 64 strictly sequential steps: every dependent instruction counts
+    for (int b = 0; b < j.n_blocks; b++) {                            // strictly sequential steps: every dependent instruction counts
         const size_t id = (size_t)b * n_channels + c;
         j.blk_remain[id] = s.remain; j.blk_phase[id] = s.phase; j.blk_off[id] = off;
-        int k = 0, pos = s.remain;
-        if (pos < post_in) { k = (sh >= 0 ? (post_in - 1 - pos) >> sh : (post_in - 1 - pos) / post_dec) + 1; pos += k * post_dec; }
-        s.remain = pos - post_in;
-        float p = s.phase + r * PI_F * (float)k;                       // libcsdr_gpl.c:155
-        while (p > PI_F) p -= 2 * PI_F;
-        while (p < -PI_F) p += 2 * PI_F;
-        s.phase = p; off += k;
+        off += ddc_chain_step(s, r, post_in, post_dec, sh);
     }
     j.state_out[c] = s; j.counts[c] = off;
 }
@@ -768,7 +848,7 @@ void ddc_mfma_destroy(DdcMfma *m)
         if (m->ev_free[k]) (void)hipEventDestroy(m->ev_free[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    (void)hipFree(m->d_state_spec);
+    (void)hipFree(m->d_state_spec); (void)hipFree(m->d_seg_counts[0]); (void)hipFree(m->d_seg_counts[1]);
     for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete m;
 }
@@ -797,7 +877,34 @@ static DdcChainJob mfma_chain_job(DdcMfma *m, int k, int n_blocks, DdcChanState 
     DdcChainJob j;
     j.state = d_state; j.state_out = d_state; j.mode = 1; j.geom = d_geom; j.n_channels = m->C; j.n_blocks = n_blocks; j.post_in = m->post_in; j.post_dec = m->post_dec; j.kmax = m->kmax;
     j.blk_remain = m->d_blk_remain[k]; j.blk_phase = m->d_blk_phase[k]; j.blk_off = m->d_blk_off[k]; j.counts = m->d_counts[k]; j.R = m->d_R[k];
+    j.seg_nbl = m->seg_nbl; j.seg_first = m->seg_first; j.seg_total = m->seg_total; j.seg_world = m->seg_world; j.seg_counts = m->d_seg_counts[k];
     return j;
+}
+
+// Time-sliced bank: the next submit()'s n_blocks blocks are global blocks [first, first + n_blocks) of a batch of `total`, dealt to `world` ranks in runs of nbl.
+// The state handed to submit() is the one at the batch's block 0; the call leaves it behind the batch's last block.  nbl = 0: back to a plain call.
+int ddc_mfma_set_segment(DdcMfma *m, int nbl, int first, int total, int world)
+{
+    if (nbl && m->seg_counts_world < world) {
+        CSDR_HIP(hipStreamSynchronize(m->side)); CSDR_HIP(hipStreamSynchronize(m->ctx->stream));
+        for (int k = 0; k < 2; k++) { (void)hipFree(m->d_seg_counts[k]); m->d_seg_counts[k] = nullptr; CSDR_HIP(hipMalloc((void **)&m->d_seg_counts[k], sizeof(int) * (size_t)world * m->C)); }
+        m->seg_counts_world = world; m->spec_valid = false;
+    }
+    m->seg_nbl = nbl; m->seg_first = first; m->seg_total = total; m->seg_world = world;
+    return 0;
+}
+const int *ddc_mfma_seg_counts(const DdcMfma *m) { return m->last_seg_counts; }
+int ddc_mfma_pending_blocks(const DdcMfma *m) { return m->pending_blocks[m->drain]; }
+// a rank whose run of the batch is empty still has to carry its channels' states over the batch (and to know every run's sample counts)
+int ddc_mfma_skip_batch(DdcMfma *m, DdcChanState *d_state, const ChanGeom *d_geom)
+{
+    if (!m->seg_nbl) return fail_msg(-3, "fastddc: skip_batch outside a time-sliced bank");
+    const int k = m->fill;
+    DdcChainJob j = mfma_chain_job(m, k, 0, d_state, d_geom);
+    hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, m->ctx->stream, j);
+    CSDR_LAUNCH_CHECK();
+    m->spec_valid = false; m->last_seg_counts = m->d_seg_counts[k];
+    return 0;
 }
 static int mfma_chains(DdcMfma *m, hipStream_t st, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
 {
@@ -863,7 +970,7 @@ static bool ddc_folds_with_gemm3(const DdcMfma *m, int n_blocks)
 // inline = true (process(): submit immediately followed by collect, nothing else staged): the transforms go on the context's stream itself and only the
 // chains use the side stream, beside them -- on one GPU the forward transforms cannot overlap the previous batch's fold anyway (the fold's workgroups
 // hold the whole LDS of every CU), and a stream hand-off per kernel group costs more than it hides.
-int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call)
+int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call, const cf32 *ext_tail)
 {
     if (n_blocks <= 0) return fail_msg(-3, "fastddc: nothing to submit");
     if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
@@ -879,7 +986,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     const bool fused_fwd = inl && !chains_side && !spectra && ddc_mfma_can_forward(m);
     // Chain tables one call ahead: the previous process() call's inverse-transform kernel carried riders that computed the tables of THIS call (set k) from the
     // state it ended with -- valid when this call has the size that was assumed and nothing retuned in between (ddc_mfma_quiesce).
-    const bool spec_hit = fused_fwd && m->spec_valid && m->spec_set == k && m->spec_blocks == n_blocks;
+    const bool spec_hit = fused_fwd && m->spec_valid && m->spec_set == k && m->spec_blocks == n_blocks && m->spec_seg_first == m->seg_first && m->spec_seg_total == m->seg_total;
     m->spec_valid = false;
     const bool ride = fused_fwd && !riders_off;                        // chain work done by extra workgroups of the forward passes (hit: only the commit + the checkpoints)
     m->last_state = d_state; m->ahead_ok = fused_fwd && !spec_off && !riders_off;
@@ -916,9 +1023,11 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }
             const bool fuse2_off = getenv("CSDR_AMD_DDC_PASS2") != nullptr;       // set: k_ddc_fwd128 stays a kernel of its own
             const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
-            rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2); if (rc) return rc;
+            // ext_tail: the overlap in front of the first window comes from the caller (a time-sliced bank: the stream before this rank's run is another rank's)
+            if (ext_tail) rc = mfma_forward(m, st, in, ext_tail, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
+            else { rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2); m->flip ^= 1; }
+            if (rc) return rc;
             m->y_holds[k] = skip2;
-            m->flip ^= 1;
         } else {
             // rank g transforms blocks [g nbl, (g + 1) nbl): the root sends it the samples of its windows, stream[g nbl inp - ovl, min((g + 1) nbl, n) inp),
             // over its own link (seven transfers in flight from the root), then the chunks are all-gathered over the full mesh
@@ -1040,7 +1149,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
             ahead = mfma_chain_job(m, k ^ 1, n_blocks, m->last_state, d_geom);
             ahead.state_out = m->d_state_spec;
             n_riders = 16;
-            m->spec_valid = true; m->spec_set = k ^ 1; m->spec_blocks = n_blocks;
+            m->spec_valid = true; m->spec_set = k ^ 1; m->spec_blocks = n_blocks; m->spec_seg_first = m->seg_first; m->spec_seg_total = m->seg_total;
         }
         hipLaunchKernelGGL(k_ddc_ifft256d_post<8>, dim3(g8.x + n_riders), dim3(256), (size_t)(8 * I256<8>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS, ahead, n_riders);
     }
@@ -1048,6 +1157,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     CSDR_LAUNCH_CHECK();
     CSDR_HIP(hipEventRecord(m->ev_free[k], st)); m->free_recorded[k] = true;
     if (d_counts) *d_counts = m->d_counts[k];
+    m->last_seg_counts = m->d_seg_counts[k];
     m->pending_blocks[k] = 0; m->drain ^= 1;
     return n_blocks;
 }

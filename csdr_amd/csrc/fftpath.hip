@@ -701,67 +701,247 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
 // The ddcd topology (ddcd_old.cpp:238-252, 474-492: one `csdr fastddc_fwd_cc` feeding N `csdr fastddc_inv_cc --fd` clients) as ONE call per block
 // batch: new wideband samples in, every channel's decimated samples out.  At config 4's geometry the forward transform writes the fold's own
 // layout directly (fastddc_mfma.hip: no natural-order spectrum, no framing copy); other geometries chain the two halves through a spectrum buffer.
-// Sharded over several GPUs (csdr_amd_fastddc_bank_create_sharded): every rank owns a slice of the channels; the wideband input lives on rank 0, the
-// forward transform is split by blocks over the ranks and the transposed spectra are all-gathered (fastddc_mfma.hip: ddc_mfma_submit).
+//
+// Over several GPUs (csdr_amd_fastddc_bank_create_sharded / _sharded_by) the OUTPUT is always channel-sharded -- rank r delivers a block-distributed slice
+// of the channels, the place a client of that channel connects to -- and there are two ways to get there:
+//   CSDR_AMD_SHARD_CHANNELS  the compute is channel-sharded too: the forward transform is split by blocks, the transposed spectra are all-gathered
+//                            (9.1 B per input sample on every rank's links), every rank folds its channels (fastddc_mfma.hip: ddc_mfma_submit);
+//   CSDR_AMD_SHARD_BLOCKS    (default) the compute is TIME-sliced: rank r runs the whole single-GPU pipeline -- all channels -- on its run of the batch's
+//                            blocks, and only the decimated outputs are exchanged (all-to-all: every rank sends each peer that peer's channels of its run,
+//                            1/world of 8 B per input sample per link).  What makes it possible is that the one piece of state that crosses block boundaries,
+//                            decimating_shift_addition_cc's (remain, phase) per channel (fastddc.c:152-164), is data independent: every rank walks the chain
+//                            over the whole batch itself (ddc_chain_body_seg).  The spectrum never leaves the GPU that computed it.
 struct csdr_amd_fastddc_bank {
     csdr_amd_ctx *ctx; csdr_amd_fastddc_inv *inv; csdr_amd_fastddc_fwd *fwd; cf32 *d_spec; int max_blocks; bool fused;
     csdr_amd_comm *comm; int first_channel, n_channels_total; int staged[2], n_staged;      // general path: block counts of the staged calls
+    const int *last_counts = nullptr; int last_count_n = 0;            // device counts of the batch collected last (csdr_amd_fastddc_bank_finish)
+    // ---- time-sliced mode
+    int shard_mode = CSDR_AMD_SHARD_CHANNELS; const DdcComm *dc = nullptr; int world = 1, rank = 0, nbl = 0, out_count = 0;
+    size_t pitch_loc = 0;
+    cf32 *d_in_loc[2] = {nullptr, nullptr}, *d_out_loc[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr}, *d_tail_root[2] = {nullptr, nullptr};
+    int *d_pref[2] = {nullptr, nullptr}; int tail_flip = 0;
+    hipStream_t xin = nullptr, xout = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_in_ready[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    bool in_free_rec[2] = {false, false}, done_rec[2] = {false, false};
+    struct Batch { int n_glob; const cf32 *in; bool local; } batch[2]; int fill = 0, drain = 0, n_batches = 0, last_slot = -1;
 };
 
+static void shard_slice(int n, int world, int rank, int *first, int *count)      // block distribution, counts differ by at most one (csdr_amd/dist.py: shard)
+{
+    const int base = n / world, extra = n % world;
+    *count = base + (rank < extra ? 1 : 0); *first = rank * base + (rank < extra ? rank : extra);
+}
+
+// per output channel of this rank: where every rank's run starts in the channel's stream of the batch (pref[g][cc]), and the total (pref[world][cc])
+__global__ __launch_bounds__(64) void k_bank_prefix(const int *__restrict__ seg_counts, int *__restrict__ pref, int n_channels_total, int first, int count, int world)
+{
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc >= count) return;
+    int acc = 0;
+    for (int g = 0; g < world; g++) { pref[g * count + cc] = acc; acc += seg_counts[(size_t)g * n_channels_total + first + cc]; }
+    pref[world * count + cc] = acc;
+}
+// out[cc][pref[g][cc] + t] = the run of rank g, t < its count: from the received piece (g != me) or this rank's own rows
+__global__ __launch_bounds__(256) void k_bank_stitch(const float2 *__restrict__ own, const float2 *__restrict__ recv, const int *__restrict__ pref, float2 *__restrict__ out,
+                                                     size_t pitch_loc, size_t out_pitch, int first, int count, int me)
+{
+    const int cc = blockIdx.x, g = blockIdx.y;
+    const int at = pref[g * count + cc], cnt = pref[(g + 1) * count + cc] - at;
+    const float2 *src = g == me ? own + (size_t)(first + cc) * pitch_loc : recv + ((size_t)g * count + cc) * pitch_loc;
+    float2 *dst = out + (size_t)cc * out_pitch + at;
+    for (int t = threadIdx.x; t < cnt; t += 256) dst[t] = src[t];
+}
+
 static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
-                                          int window, int max_blocks, csdr_amd_comm *comm)
+                                          int window, int max_blocks, csdr_amd_comm *comm, int shard_mode)
 {
     csdr_amd_fastddc_bank *b = new csdr_amd_fastddc_bank();
     b->ctx = ctx; b->max_blocks = max_blocks; b->fwd = nullptr; b->d_spec = nullptr; b->comm = comm; b->n_staged = 0;
     b->first_channel = 0; b->n_channels_total = n_channels;
     int count = n_channels;
     const DdcComm *dc = comm ? csdr_amd_comm_ddc(comm) : nullptr;
-    if (dc && dc->world > 1) {   // block distribution of the channels, counts differ by at most one (csdr_amd/dist.py: shard)
-        const int base = n_channels / dc->world, extra = n_channels % dc->world;
-        count = base + (dc->rank < extra ? 1 : 0); b->first_channel = dc->rank * base + (dc->rank < extra ? dc->rank : extra);
+    const bool multi = dc && dc->world > 1;
+    if (multi) {
+        shard_slice(n_channels, dc->world, dc->rank, &b->first_channel, &count);
         if (count < 1) { fail_msg(-3, "fastddc_bank: fewer channels than ranks"); delete b; return nullptr; }
+        b->dc = dc; b->world = dc->world; b->rank = dc->rank; b->out_count = count;
     }
-    b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates + b->first_channel, count, window, max_blocks, dc && dc->world > 1 ? dc : nullptr);
+    b->shard_mode = multi ? shard_mode : CSDR_AMD_SHARD_CHANNELS;
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {                     // every rank: all channels, its run of the blocks
+        b->nbl = (max_blocks + b->world - 1) / b->world;
+        b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, b->nbl, nullptr);
+    } else
+        b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates + b->first_channel, count, window, max_blocks, multi ? dc : nullptr);
     if (!b->inv) { delete b; return nullptr; }
     b->fused = ddc_mfma_can_forward(b->inv->mf);
-    if (dc && dc->world > 1 && !b->fused) { fail_msg(-3, "fastddc_bank: sharding needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512)"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
+    if (multi && !b->fused) { fail_msg(-3, "fastddc_bank: sharding needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512)"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
+    const csdr_fastddc_t g = b->inv->geom[0];
+    if (multi && g.input_size < g.overlap_length) { fail_msg(-3, "fastddc_bank: sharding needs input_size >= overlap_length"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
     if (!b->fused) {
-        csdr_fastddc_t g = b->inv->geom[0];
         b->fwd = csdr_amd_fastddc_fwd_create(ctx, &g, max_blocks);
         if (!b->fwd || hipMalloc((void **)&b->d_spec, sizeof(cf32) * (size_t)max_blocks * g.fft_size) != hipSuccess) {
             fail_msg(-2, "fastddc_bank: cannot allocate the spectrum buffer"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
     }
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {
+        b->pitch_loc = ((size_t)csdr_amd_fastddc_inv_max_output(b->inv, b->nbl) + 8 + 1) / 2 * 2;
+        const size_t in_elems = (size_t)b->nbl * g.input_size + g.overlap_length;
+        hipError_t e = hipStreamCreateWithFlags(&b->xin, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&b->xout, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipMalloc((void **)&b->d_out_loc[k], sizeof(cf32) * (size_t)n_channels * b->pitch_loc);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->d_recv[k], sizeof(cf32) * (size_t)b->world * count * b->pitch_loc);
+            if (e == hipSuccess) e = hipMalloc((void **)&b->d_pref[k], sizeof(int) * (size_t)(b->world + 1) * count);
+            if (e == hipSuccess && b->rank != 0) e = hipMalloc((void **)&b->d_in_loc[k], sizeof(cf32) * in_elems);
+            if (e == hipSuccess && b->rank == 0) { e = hipMalloc((void **)&b->d_tail_root[k], sizeof(cf32) * (size_t)(g.overlap_length + 1));
+                if (e == hipSuccess) e = hipMemsetAsync(b->d_tail_root[k], 0, sizeof(cf32) * (size_t)(g.overlap_length + 1), ctx->stream); }      // csdr.c:2279: the stream starts behind zeros
+            for (hipEvent_t *ev : {&b->ev_in_ready[k], &b->ev_in_free[k], &b->ev_out_ready[k], &b->ev_done[k]}) if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        }
+        if (e != hipSuccess) { fail(e, "fastddc_bank (time-sliced buffers)", __FILE__, __LINE__); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
+    }
     return b;
+}
+
+// ---- time-sliced mode: submit = the input exchange of a batch (or nothing, when every rank is handed its own run), collect = this rank's pipeline + output exchange
+static inline int blk_first_of(const csdr_amd_fastddc_bank *b, int g, int n_glob) { const long long f = (long long)g * b->nbl; return f < n_glob ? (int)f : n_glob; }
+
+static int bank_submit_blocks(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_glob, bool local)
+{
+    if (b->n_batches == 2) return fail_msg(-3, "fastddc_bank: two batches are already staged; collect one first");
+    const csdr_fastddc_t &g = b->inv->geom[0];
+    const int inp = g.input_size, ovl = g.overlap_length, slot = b->fill;
+    const int b0 = blk_first_of(b, b->rank, n_glob), b1 = blk_first_of(b, b->rank + 1, n_glob), n_loc = b1 - b0;
+    if (!local) {     // the wideband stream lives on rank 0 (ddcd's single fastddc_fwd_cc): every rank is sent the samples of its run, with the overlap in front, over its own link
+        const DdcComm *cm = b->dc;
+        if (b->rank == 0) { CSDR_HIP(hipEventRecord(b->ev_fork, b->ctx->stream)); CSDR_HIP(hipStreamWaitEvent(b->xin, b->ev_fork, 0)); }      // the producers of `in`
+        else if (b->in_free_rec[slot]) CSDR_HIP(hipStreamWaitEvent(b->xin, b->ev_in_free[slot], 0));                                     // the transforms that read this slot two batches ago
+        int rc = cm->group_start(cm); if (rc) return rc;
+        if (b->rank == 0) {
+            for (int p = 1; p < b->world; p++) {
+                const int p0 = blk_first_of(b, p, n_glob), p1 = blk_first_of(b, p + 1, n_glob);
+                if (p1 > p0) { rc = cm->send(cm, in + (size_t)p0 * inp - ovl, 2 * ((size_t)(p1 - p0) * inp + ovl), p, b->xin); if (rc) return rc; }
+            }
+        } else if (n_loc > 0) { rc = cm->recv(cm, b->d_in_loc[slot], 2 * ((size_t)n_loc * inp + ovl), 0, b->xin); if (rc) return rc; }
+        rc = cm->group_end(cm); if (rc) return rc;
+        CSDR_HIP(hipEventRecord(b->ev_in_ready[slot], b->xin));
+    }
+    b->batch[slot] = {n_glob, in, local};
+    b->fill ^= 1; b->n_batches++;
+    return 0;
+}
+
+static int bank_collect_blocks(csdr_amd_fastddc_bank *b, csdr_complexf *out, size_t out_pitch)
+{
+    if (!b->n_batches) return fail_msg(-3, "fastddc_bank: nothing staged to collect");
+    csdr_amd_fastddc_inv *f = b->inv;
+    const csdr_fastddc_t &g = f->geom[0];
+    const int inp = g.input_size, ovl = g.overlap_length, slot = b->drain, W = b->world, me = b->rank;
+    const csdr_amd_fastddc_bank::Batch bt = b->batch[slot];
+    if ((size_t)csdr_amd_fastddc_inv_max_output(f, bt.n_glob) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
+    hipStream_t st = b->ctx->stream;
+    const int b0 = blk_first_of(b, me, bt.n_glob), b1 = blk_first_of(b, me + 1, bt.n_glob), n_loc = b1 - b0;
+    if (!bt.local && me != 0) CSDR_HIP(hipStreamWaitEvent(st, b->ev_in_ready[slot], 0));
+    if (b->done_rec[slot]) CSDR_HIP(hipStreamWaitEvent(st, b->ev_done[slot], 0));      // the output exchange two batches ago read d_out_loc / d_pref of this slot
+    int rc = ddc_mfma_set_segment(f->mf, b->nbl, b0, bt.n_glob, W); if (rc) return rc;
+    if (n_loc > 0) {
+        const cf32 *src, *tail;
+        if (bt.local) { tail = bt.in; src = bt.in + ovl; }
+        else if (me == 0) { tail = b->d_tail_root[b->tail_flip]; src = bt.in; }
+        else { tail = b->d_in_loc[slot]; src = b->d_in_loc[slot] + ovl; }
+        rc = ddc_mfma_submit(f->mf, src, nullptr, n_loc, f->d_state, f->d_geom, true, tail); if (rc) return rc;
+        rc = ddc_mfma_collect(f->mf, f->d_geom, b->d_out_loc[slot], b->pitch_loc, nullptr); if (rc < 0) return rc;
+    } else { rc = ddc_mfma_skip_batch(f->mf, f->d_state, f->d_geom); if (rc) return rc; }
+    if (!bt.local && me == 0) {      // the next batch's overlap = the newest ovl samples of the stream (input_size >= overlap_length: checked at create)
+        CSDR_HIP(hipMemcpyAsync(b->d_tail_root[b->tail_flip ^ 1], bt.in + (size_t)bt.n_glob * inp - ovl, sizeof(cf32) * (size_t)ovl, hipMemcpyDeviceToDevice, st));
+        b->tail_flip ^= 1;
+    }
+    hipLaunchKernelGGL(k_bank_prefix, dim3(cdiv(b->out_count, 64)), dim3(64), 0, st, ddc_mfma_seg_counts(f->mf), b->d_pref[slot], b->n_channels_total, b->first_channel, b->out_count, W);
+    CSDR_LAUNCH_CHECK();
+    CSDR_HIP(hipEventRecord(b->ev_in_free[slot], st)); b->in_free_rec[slot] = true;
+    CSDR_HIP(hipEventRecord(b->ev_out_ready[slot], st));
+    // output exchange on its own stream (under the next batch's transforms): every rank sends each peer that peer's channels of its run
+    const DdcComm *cm = b->dc;
+    CSDR_HIP(hipStreamWaitEvent(b->xout, b->ev_out_ready[slot], 0));
+    rc = cm->group_start(cm); if (rc) return rc;
+    for (int p = 0; p < W; p++) {
+        if (p == me) continue;
+        int pf, pc; shard_slice(b->n_channels_total, W, p, &pf, &pc);
+        const int p_loc = blk_first_of(b, p + 1, bt.n_glob) - blk_first_of(b, p, bt.n_glob);
+        if (n_loc > 0) { rc = cm->send(cm, b->d_out_loc[slot] + (size_t)pf * b->pitch_loc, 2 * (size_t)pc * b->pitch_loc, p, b->xout); if (rc) return rc; }
+        if (p_loc > 0) { rc = cm->recv(cm, b->d_recv[slot] + (size_t)p * b->out_count * b->pitch_loc, 2 * (size_t)b->out_count * b->pitch_loc, p, b->xout); if (rc) return rc; }
+    }
+    rc = cm->group_end(cm); if (rc) return rc;
+    hipLaunchKernelGGL(k_bank_stitch, dim3(b->out_count, W), dim3(256), 0, b->xout, reinterpret_cast<const float2 *>(b->d_out_loc[slot]), reinterpret_cast<const float2 *>(b->d_recv[slot]),
+                       b->d_pref[slot], reinterpret_cast<float2 *>(out), b->pitch_loc, out_pitch, b->first_channel, b->out_count, me);
+    CSDR_LAUNCH_CHECK();
+    CSDR_HIP(hipEventRecord(b->ev_done[slot], b->xout)); b->done_rec[slot] = true;
+    b->last_counts = b->d_pref[slot] + (size_t)W * b->out_count; b->last_count_n = b->out_count; b->last_slot = slot;
+    b->drain ^= 1; b->n_batches--;
+    return 0;
 }
 
 extern "C" {
 
 csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
                                                     int window, int max_blocks)
-{ return bank_create(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, max_blocks, nullptr); }
+{ return bank_create(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, max_blocks, nullptr, CSDR_AMD_SHARD_CHANNELS); }
 
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded_by(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
+                                                               int window, int max_blocks, csdr_amd_comm *comm, int shard_mode)
+{
+    if (shard_mode != CSDR_AMD_SHARD_CHANNELS && shard_mode != CSDR_AMD_SHARD_BLOCKS) { fail_msg(-3, "fastddc_bank: unknown shard mode %d", shard_mode); return nullptr; }
+    return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, shard_mode);
+}
 csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
                                                             int window, int max_blocks, csdr_amd_comm *comm)
-{ return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm); }
+{ return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, CSDR_AMD_SHARD_BLOCKS); }
 
 void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
 {
     if (!b) return;
+    if (b->xin) { (void)hipStreamSynchronize(b->xin); (void)hipStreamDestroy(b->xin); }
+    if (b->xout) { (void)hipStreamSynchronize(b->xout); (void)hipStreamDestroy(b->xout); }
     if (b->fwd) csdr_amd_fastddc_fwd_destroy(b->fwd);
     if (b->inv) csdr_amd_fastddc_inv_destroy(b->inv);
     (void)hipFree(b->d_spec);
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(b->d_in_loc[k]); (void)hipFree(b->d_out_loc[k]); (void)hipFree(b->d_recv[k]); (void)hipFree(b->d_tail_root[k]); (void)hipFree(b->d_pref[k]);
+        for (hipEvent_t ev : {b->ev_in_ready[k], b->ev_in_free[k], b->ev_out_ready[k], b->ev_done[k]}) if (ev) (void)hipEventDestroy(ev);
+    }
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     delete b;
 }
 
-int csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count) { *first = b->first_channel; *count = b->inv->n_channels; return 0; }
-int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate) { return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate); }
+int csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count)
+{ *first = b->first_channel; *count = b->shard_mode == CSDR_AMD_SHARD_BLOCKS ? b->out_count : b->inv->n_channels; return 0; }
+int csdr_amd_fastddc_bank_shard_mode(const csdr_amd_fastddc_bank *b) { return b->world > 1 ? b->shard_mode : -1; }
+int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate)
+{   // channel = index into this rank's output slice (an unsharded bank: the channel)
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return fail_msg(-3, "fastddc_bank: a time-sliced bank retunes through csdr_amd_fastddc_bank_set_rate_global (every rank holds every channel)");
+    return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
+}
+int csdr_amd_fastddc_bank_set_rate_global(csdr_amd_fastddc_bank *b, int channel, float shift_rate)
+{   // every rank makes the same call; a rank applies it to what it computes
+    if (channel < 0 || channel >= b->n_channels_total) return fail_msg(-3, "fastddc_bank: channel %d out of range", channel);
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
+    if (channel < b->first_channel || channel >= b->first_channel + b->inv->n_channels) return 0;
+    return csdr_amd_fastddc_inv_set_rate(b->inv, channel - b->first_channel, shift_rate);
+}
 int csdr_amd_fastddc_bank_input_size(const csdr_amd_fastddc_bank *b) { return b->inv->geom[0].input_size; }
+int csdr_amd_fastddc_bank_overlap(const csdr_amd_fastddc_bank *b) { return b->inv->geom[0].overlap_length; }
 int csdr_amd_fastddc_bank_max_output(const csdr_amd_fastddc_bank *b, int n_blocks) { return csdr_amd_fastddc_inv_max_output(b->inv, n_blocks); }
 csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b) { return b->inv; }
+int csdr_amd_fastddc_bank_local_blocks(const csdr_amd_fastddc_bank *b, int n_blocks, int *first, int *count)
+{
+    if (b->shard_mode != CSDR_AMD_SHARD_BLOCKS) { *first = 0; *count = n_blocks; return 0; }
+    *first = blk_first_of(b, b->rank, n_blocks); *count = blk_first_of(b, b->rank + 1, n_blocks) - *first;
+    return 0;
+}
 
 static int bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, bool inline_call)
 {
     if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return bank_submit_blocks(b, in, n_blocks, false);
     if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom, inline_call);
     if (b->n_staged) return fail_msg(-3, "fastddc_bank: this geometry stages one call at a time");
     int rc = csdr_amd_fastddc_fwd_process(b->fwd, in, b->d_spec, n_blocks); if (rc) return rc;
@@ -769,32 +949,53 @@ static int bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_
     return 0;
 }
 int csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks) { return bank_submit(b, in, n_blocks, false); }
+int csdr_amd_fastddc_bank_submit_local(csdr_amd_fastddc_bank *b, const csdr_complexf *in_run, int n_blocks)
+{
+    if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
+    if (b->shard_mode != CSDR_AMD_SHARD_BLOCKS) return fail_msg(-3, "fastddc_bank: submit_local needs a time-sliced bank");
+    return bank_submit_blocks(b, in_run, n_blocks, true);
+}
+
+// the context's stream (and, with out_counts, the host) behind everything the batch collected last still has in flight on the exchange stream
+int csdr_amd_fastddc_bank_finish(csdr_amd_fastddc_bank *b, int *out_counts)
+{
+    hipStream_t st = b->ctx->stream;
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS && b->last_slot >= 0) CSDR_HIP(hipStreamWaitEvent(st, b->ev_done[b->last_slot], 0));
+    if (out_counts) {
+        if (!b->last_counts) return fail_msg(-3, "fastddc_bank: nothing collected yet");
+        CSDR_HIP(hipMemcpyAsync(out_counts, b->last_counts, sizeof(int) * (size_t)b->last_count_n, hipMemcpyDeviceToHost, st));
+        CSDR_HIP(hipStreamSynchronize(st));
+    }
+    return 0;
+}
 
 int csdr_amd_fastddc_bank_collect(csdr_amd_fastddc_bank *b, csdr_complexf *out, size_t out_pitch, int *out_counts)
 {
     csdr_amd_fastddc_inv *f = b->inv;
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {
+        const int rc = bank_collect_blocks(b, out, out_pitch); if (rc) return rc;
+        return out_counts ? csdr_amd_fastddc_bank_finish(b, out_counts) : 0;
+    }
     if (!b->fused) {
         if (!b->n_staged) return fail_msg(-3, "fastddc_bank: nothing staged to collect");
         b->n_staged = 0;
         return csdr_amd_fastddc_inv_process(f, b->d_spec, b->staged[0], out, out_pitch, out_counts);
     }
-    hipStream_t st = f->ctx->stream;
+    const int pending = ddc_mfma_pending_blocks(f->mf);                   // validated BEFORE anything is queued that writes `out` with this pitch
+    if (pending > 0 && (size_t)csdr_amd_fastddc_inv_max_output(f, pending) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
     const int *d_cnt = nullptr;
     const int rc = ddc_mfma_collect(f->mf, f->d_geom, out, out_pitch, &d_cnt); if (rc < 0) return rc;
-    if ((size_t)csdr_amd_fastddc_inv_max_output(f, rc) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
-    if (out_counts) {
-        CSDR_HIP(hipMemcpyAsync(out_counts, d_cnt, sizeof(int) * f->n_channels, hipMemcpyDeviceToHost, st));
-        CSDR_HIP(hipStreamSynchronize(st));
-    }
-    return 0;
+    b->last_counts = d_cnt; b->last_count_n = f->n_channels;
+    return out_counts ? csdr_amd_fastddc_bank_finish(b, out_counts) : 0;
 }
 
 int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
 {
     if (n_blocks <= 0) return 0;
     if ((size_t)csdr_amd_fastddc_inv_max_output(b->inv, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
-    const int rc = bank_submit(b, in, n_blocks, true); if (rc) return rc;
-    return csdr_amd_fastddc_bank_collect(b, out, out_pitch, out_counts);
+    int rc = bank_submit(b, in, n_blocks, true); if (rc) return rc;
+    rc = csdr_amd_fastddc_bank_collect(b, out, out_pitch, out_counts); if (rc) return rc;
+    return out_counts ? 0 : csdr_amd_fastddc_bank_finish(b, nullptr);
 }
 
 } // extern "C"

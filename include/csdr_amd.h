@@ -292,14 +292,51 @@ void csdr_amd_comm_destroy(csdr_amd_comm *c);
 int  csdr_amd_comm_rank(const csdr_amd_comm *c);
 int  csdr_amd_comm_world(const csdr_amd_comm *c);
 int  csdr_amd_comm_broadcast(csdr_amd_comm *c, void *dev_buf, size_t bytes, int root);        /* on the context's stream (test / bench plumbing) */
-/* fastddc bank sharded over the communicator (BASELINE config 4 at 2 / 4 / 8 GPUs): host_shift_rates_all = ALL channels on every rank; rank r keeps the
- * block-distributed slice csdr_amd_fastddc_bank_channel_slice reports (out rows = that slice).  `in` of submit / process is read on rank 0 only (the
- * wideband input lives there, like ddcd's single fastddc_fwd_cc: ddcd_old.cpp:238-252): per batch the root sends every rank the samples of ITS blocks'
- * windows (point to point, one link each), every rank transforms its blocks, the transposed spectra are all-gathered over the full mesh, every rank
- * folds its channels.  Needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512).  All ranks make the same calls in the same order. */
+/* Two more transports behind the same communicator type, for boxes with ONE GPU:
+ * loopback -- the `world` ranks live in one process, one host thread + one context each (all on one device, or on several); every exchange is a
+ *   stream-ordered device copy.  The multi-rank code of the channelizer runs unchanged (tests at world 2 / 4 / 8 on one MI355X).  Every rank thread
+ *   must make the same exchange calls in the same order; a rank that never arrives fails the others after 60 s instead of hanging them.
+ * null -- rank `rank` of a `world`-rank schedule with NO peers: every exchange call returns at once and moves nothing.  For timing one rank's own
+ *   work of a world-N schedule on one GPU (bench_fastddc.py --emulate-world); the outputs are meaningless. */
+typedef struct csdr_amd_loopback csdr_amd_loopback;
+csdr_amd_loopback *csdr_amd_loopback_create(int world);
+void csdr_amd_loopback_destroy(csdr_amd_loopback *g);
+void csdr_amd_loopback_abort(csdr_amd_loopback *g);                 /* a rank thread gave up: fail the others' rendezvous at once */
+csdr_amd_comm *csdr_amd_comm_create_loopback(csdr_amd_ctx *ctx, csdr_amd_loopback *g, int rank);
+csdr_amd_comm *csdr_amd_comm_create_null(csdr_amd_ctx *ctx, int rank, int world);
+/* fastddc bank over the communicator (BASELINE config 4 at 2 / 4 / 8 GPUs): host_shift_rates_all = ALL channels on every rank; rank r DELIVERS the
+ * block-distributed slice of the channels csdr_amd_fastddc_bank_channel_slice reports (out rows = that slice; a channel's client connects to that GPU).
+ * Two ways of dividing the work (shard_mode):
+ *   CSDR_AMD_SHARD_BLOCKS (what csdr_amd_fastddc_bank_create_sharded picks): time slices.  The blocks of a batch are dealt to the ranks in runs of
+ *     ceil(max_blocks / world); every rank runs the whole single-GPU pipeline -- forward transform, fold of ALL channels, inverse transforms -- on its run and
+ *     only the decimated outputs cross the links (all-to-all: each rank sends every peer that peer's channels of its run; 8 B per input sample in total, 1/world
+ *     of it per link).  Possible because the only state that crosses block boundaries, decimating_shift_addition_cc's (remain, phase) per channel
+ *     (fastddc.c:152-164), is data independent: every rank walks it over the whole batch itself.  The spectra never leave the GPU that computed them.
+ *   CSDR_AMD_SHARD_CHANNELS: the compute is channel-sharded as well: forward transform split by blocks, transposed spectra all-gathered over the full mesh
+ *     (9.1 B per input sample arrive at EVERY rank), every rank folds its own channels.  Link bound beyond two GPUs; kept as the
+ *     measured alternative.
+ * Input: submit / process read `in` on rank 0 only (the wideband stream lives there, like ddcd's single fastddc_fwd_cc, ddcd_old.cpp:238-252) and send every
+ * rank the samples of its blocks point to point; csdr_amd_fastddc_bank_submit_local (time slices only) takes each rank's OWN run instead -- overlap_length
+ * samples of the stream in front of the run's first block (zeros at the start of the stream), then its blocks -- when the ingest already distributes the
+ * stream (csdr_amd_fastddc_bank_local_blocks tells a rank which blocks of an n-block batch are its run).
+ * Needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512).  All ranks make the same calls in the same order.
+ * A time-sliced bank finishes a batch on its exchange stream: `out` is complete once csdr_amd_fastddc_bank_finish has been called (it orders the
+ * context's stream behind the exchange; with out_counts it also waits and returns the sample counts).  collect() with out_counts != NULL and process()
+ * call it themselves. */
+enum { CSDR_AMD_SHARD_CHANNELS = 0, CSDR_AMD_SHARD_BLOCKS = 1 };
 csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
                                                             int window, int max_blocks, csdr_amd_comm *comm);
+csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded_by(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
+                                                               int window, int max_blocks, csdr_amd_comm *comm, int shard_mode);
 int  csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count);
+int  csdr_amd_fastddc_bank_shard_mode(const csdr_amd_fastddc_bank *b);                          /* -1: one GPU */
+int  csdr_amd_fastddc_bank_local_blocks(const csdr_amd_fastddc_bank *b, int n_blocks, int *first, int *count);
+int  csdr_amd_fastddc_bank_overlap(const csdr_amd_fastddc_bank *b);
+int  csdr_amd_fastddc_bank_submit_local(csdr_amd_fastddc_bank *b, const csdr_complexf *in_run, int n_blocks);
+int  csdr_amd_fastddc_bank_finish(csdr_amd_fastddc_bank *b, int *out_counts);
+/* retune by GLOBAL channel number; every rank makes the same call (csdr_amd_fastddc_bank_set_rate takes an index into the rank's own slice and is refused
+ * by a time-sliced bank, where every rank holds every channel) */
+int  csdr_amd_fastddc_bank_set_rate_global(csdr_amd_fastddc_bank *b, int channel, float shift_rate);
 /* the bank's inverse half (kernel name / profiling: csdr_amd_fastddc_inv_kernel_name, _set_profiling, _kernel_time) */
 csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b);
 

@@ -1,0 +1,139 @@
+"""The multi-rank fastddc bank (ddcd_old.cpp:238-252, 474-492: one forward transform feeding many inverse halves) RUN at world 2 / 4 / 8
+on the one GPU a box has: `world` rank threads joined by the library's loopback communicator (comm.cpp: every exchange a stream-ordered device copy), each
+driving csdr_amd_fastddc_bank_create_sharded_by + submit / collect / finish exactly as one process per GPU would over RCCL.  Both ways of dividing the work
+are covered: time slices (the default: blocks dealt to the ranks, outputs exchanged all-to-all) and channel slices (spectra all-gathered).  BASELINE config
+4's geometry, all 256 channels; batches of 64, 5, 1 and 64 blocks (runs of ceil(64 / world) blocks: with 5 and 1 most ranks have nothing to transform and
+must still carry their channels' states and take part in the exchange), a retune between batches.  Every channel against the single-GPU bank (2e-6: the
+same kernels, another summation context for the second forward pass), a spread of channels against the CPU oracle (1e-5)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import verify_configs as vc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+c64 = np.complex64
+f32 = np.float32
+TBW, D, NCH = 0.001, 256, 256
+SCHEDULE = [64, 5, 1, 64]
+RETUNES = {2: [(37, 0.123), (200, -0.3711)]}           # before the third batch
+ORACLE_CHANNELS = [0, 31, 32, 100, 127, 128, 223, 224, 255]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch  # noqa: F401
+    import csdr_amd
+    ctx = csdr_amd.Context(0)
+    assert ctx.arch().startswith("gfx950")
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def case(gpu, port):
+    """input, the single-GPU bank's outputs and the oracle's (computed once for all worlds / modes)"""
+    ddc, err = gpu.fastddc_init(TBW, D, 0.0)
+    assert err == 0 and ddc.fft_size == 65536 and ddc.input_size >= ddc.overlap_length
+    nb = sum(SCHEDULE)
+    rng = np.random.default_rng(83)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = vc.c4_rates(NCH)
+    single = gpu.fastddc_bank(x, TBW, D, rates, schedule=SCHEDULE, retunes=RETUNES)
+    _, want = vc.fastddc_oracle_channels(x, TBW, D, rates, ORACLE_CHANNELS)
+    for c in ORACLE_CHANNELS:                             # the reference point itself is oracle-clean
+        assert single[c].size == want[c].size and vc.relrms(single[c], want[c]) < 1e-5
+    return x, rates, single, want
+
+
+def _check(outs, single, want):
+    assert len(outs) == NCH and all(o is not None for o in outs)
+    worst = 0.0
+    for c in range(NCH):
+        assert outs[c].size == single[c].size, "channel %d: %d samples, single GPU %d" % (c, outs[c].size, single[c].size)
+        worst = max(worst, vc.relrms(outs[c], single[c]))
+    assert worst < 2e-6, "worst channel vs the single-GPU bank: %g" % worst
+    for c in ORACLE_CHANNELS:
+        assert vc.relrms(outs[c], want[c]) < 1e-5, "channel %d vs oracle" % c
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("mode", ["blocks", "channels"])
+def test_sharded_bank_loopback(gpu, case, mode, world):
+    import csdr_amd
+    x, rates, single, want = case
+    outs = csdr_amd.sharded_bank_loopback(world, x, TBW, D, rates, SCHEDULE, mode=mode, retunes=RETUNES, pipelined=True)
+    _check(outs, single, want)
+
+
+def test_sharded_bank_loopback_unpipelined_and_odd_world(gpu, case):
+    """three ranks (256 channels do not divide: slices of 86 / 85 / 85; runs of 22 blocks), every batch submitted and collected in turn"""
+    import csdr_amd
+    x, rates, single, want = case
+    for mode in ("blocks", "channels"):
+        outs = csdr_amd.sharded_bank_loopback(3, x, TBW, D, rates, SCHEDULE, mode=mode, retunes=RETUNES, pipelined=False)
+        _check(outs, single, want)
+
+
+def test_time_sliced_bank_local_ingest(gpu, case):
+    """csdr_amd_fastddc_bank_submit_local: every rank is handed its own run of each batch (overlap in front) -- no input exchange at all"""
+    import csdr_amd
+    x, rates, single, want = case
+    outs = csdr_amd.sharded_bank_loopback(4, x, TBW, D, rates, SCHEDULE, mode="blocks", retunes=RETUNES, pipelined=True, local_input=True)
+    _check(outs, single, want)
+
+
+def test_loopback_broadcast_and_failure(gpu):
+    """the transport itself: a broadcast over four rank threads; a rank that never arrives fails the others instead of hanging them"""
+    import threading
+    import csdr_amd
+    L = gpu.L
+    W = 4
+    grp = L.csdr_amd_loopback_create(W)
+    assert grp
+    got = [None] * W
+
+    def rank_main(r):
+        ctx = csdr_amd.Context(0)
+        comm = L.csdr_amd_comm_create_loopback(ctx.h, grp, r)
+        buf = ctx.upload(np.full(1024, 7 if r == 2 else r, np.int32))
+        rc = L.csdr_amd_comm_broadcast(comm, buf.ptr, 4096, 2)
+        got[r] = (rc, ctx.download(buf, np.int32, 1024))
+        L.csdr_amd_comm_destroy(comm); ctx.close()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    for r in range(W):
+        assert got[r][0] == 0 and (got[r][1] == 7).all()
+    L.csdr_amd_loopback_abort(grp)                        # from now on every rendezvous fails at once
+    ctx = csdr_amd.Context(0)
+    comm = L.csdr_amd_comm_create_loopback(ctx.h, grp, 0)
+    buf = ctx.alloc(4096)
+    assert L.csdr_amd_comm_broadcast(comm, buf.ptr, 4096, 0) < 0 and "did not arrive" in ctx.err()
+    L.csdr_amd_comm_destroy(comm); ctx.close()
+    L.csdr_amd_loopback_destroy(grp)
+
+
+def test_null_transport_times_one_rank(gpu):
+    """csdr_amd_comm_create_null: rank 3 of 8 with no peers -- the calls of a world-8 schedule go through (what bench_fastddc.py --emulate-world times)"""
+    L = gpu.L
+    ddc, _ = gpu.fastddc_init(TBW, D, 0.0)
+    rates = vc.c4_rates(NCH)
+    for mode in (0, 1):
+        comm = L.csdr_amd_comm_create_null(gpu.h, 3, 8)
+        assert comm and (L.csdr_amd_comm_rank(comm), L.csdr_amd_comm_world(comm)) == (3, 8)
+        bank = L.csdr_amd_fastddc_bank_create_sharded_by(gpu.h, TBW, D, rates.ctypes.data_as(C.c_void_p), NCH, 2, 64, comm, mode)
+        assert bank, gpu.err()
+        f0 = C.c_int(); c0 = C.c_int(); L.csdr_amd_fastddc_bank_channel_slice(bank, C.byref(f0), C.byref(c0))
+        assert (f0.value, c0.value) == (96, 32) and L.csdr_amd_fastddc_bank_shard_mode(bank) == mode
+        di = gpu.alloc(8 * 64 * ddc.input_size)
+        pitch = L.csdr_amd_fastddc_bank_max_output(bank, 64) + 8
+        do = gpu.alloc(8 * 32 * pitch)
+        for _ in range(3):
+            assert L.csdr_amd_fastddc_bank_process(bank, di.ptr, 64, do.ptr, pitch, None) == 0, gpu.err()
+        gpu.sync()
+        L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm)
