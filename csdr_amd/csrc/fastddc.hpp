@@ -34,12 +34,11 @@ int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, 
 bool ddc_mfma_can_forward(const DdcMfma *m);
 int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call, const cf32 *ext_tail = nullptr);
 // time-sliced bank (fftpath.hip): position of the next call's blocks inside a batch dealt to `world` ranks in runs of nbl blocks; the per-rank sample counts
-// [world][n_channels] (device) of the call collected last / skipped last; a batch in which this rank has no blocks
-int ddc_mfma_set_segment(DdcMfma *m, int nbl, int first, int total, int world);
-const int *ddc_mfma_seg_counts(const DdcMfma *m);
+// offsets [world + 1][n_channels] (device, written into the caller's buffers); a batch in which this rank has no blocks
+int ddc_mfma_set_segment(DdcMfma *m, int nbl, int first, int total, int world, int *pref_cur, int *pref_next);
 int ddc_mfma_pending_blocks(const DdcMfma *m);      // block count of the call collect() would fold next (0: nothing staged)
 int ddc_mfma_skip_batch(DdcMfma *m, DdcChanState *d_state, const ChanGeom *d_geom);
-int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts);
+int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts, hipEvent_t after_inverse = nullptr);      // after_inverse: recorded when the call's last kernel completes
 int ddc_mfma_set_profiling(DdcMfma *m, int on);
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches);
 const char *ddc_mfma_kernel_name(const DdcMfma *m);       // the fold kernel the last collect() launched

@@ -24,6 +24,7 @@
 // decimating_shift_addition_cc with the reference's float32 phasor recurrence REPLAYED (k_ddc_rot: one lane per (channel, block) chain, data
 // independent) -- the folded bins are read once, the output written once; no hipFFT plan, no [channel][block][inv] round trips.
 #include "fastddc.hpp"
+#include <hip/hip_ext.h>
 #include "fft_butterflies.hpp"
 #include <math.h>
 #include <stddef.h>
@@ -43,8 +44,7 @@ struct DdcMfma {
     int rank, world, nbl; const DdcComm *comm; cf32 *d_in_local;
     // time-sliced bank (fftpath.hip: the bank deals the BLOCKS of a batch to the ranks, every rank runs this object unsharded on its run): where the next call's
     // blocks sit in the batch (ddc_mfma_set_segment), and per set the samples every rank's run produces [seg_world][C]
-    int seg_nbl = 0, seg_first = 0, seg_total = 0, seg_world = 0, spec_seg_first = 0, spec_seg_total = 0; int *d_seg_counts[2] = {nullptr, nullptr}; int seg_counts_world = 0;
-    const int *last_seg_counts = nullptr;
+    int seg_nbl = 0, seg_first = 0, seg_total = 0, seg_world = 0, spec_seg_first = 0, spec_seg_total = 0; int *seg_cur = nullptr, *seg_next = nullptr;
     // Two sets of everything a call produces before the fold (transposed spectra, chain tables, phasor checkpoints): submit() fills one set on the side
     // stream -- exchange + forward transform + chains -- while collect() folds the other on the context's stream.
     cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
@@ -384,7 +384,7 @@ struct DdcChainJob {                                                 // one call
     int *blk_remain; float *blk_phase; int *blk_off; int *counts; float2 *R;
     // time-sliced bank (the blocks of a batch dealt to the ranks in runs of seg_nbl): this rank's n_blocks blocks are global blocks [seg_first, seg_first + n_blocks) of
     // seg_total; `state` is the state at global block 0, state_out the one behind block seg_total - 1; seg_counts[rank][channel] = samples every rank's run produces
-    int seg_nbl, seg_first, seg_total, seg_world; int *seg_counts;
+    int seg_nbl, seg_first, seg_total, seg_world; int *seg_pref;      // seg_pref[g][channel] = samples of the runs of ranks < g; row seg_world = the batch's total
 };
 // one block of decimating_shift_addition_cc's bookkeeping (libcsdr_gpl.c:153-158): samples produced, state advanced
 __device__ __forceinline__ int ddc_chain_step(DdcChanState &s, float r, int post_in, int post_dec, int sh)
@@ -427,6 +427,7 @@ __device__ __forceinline__ void ddc_chain_body_seg(const DdcChainJob &j, int c)
     const int post_in = j.post_in, post_dec = j.post_dec, n_channels = j.n_channels;
     const int sh = (post_dec & (post_dec - 1)) == 0 ? __ffs(post_dec) - 1 : -1;
     const DdcChainFast f = ddc_chain_fast(s, r, post_in, post_dec);
+    int total = 0;
     for (int g = 0; g < j.seg_world; g++) {
         const int b0 = min(g * j.seg_nbl, j.seg_total), b1 = min(b0 + j.seg_nbl, j.seg_total);
         const bool mine = b0 == j.seg_first && j.n_blocks > 0;
@@ -447,8 +448,9 @@ __device__ __forceinline__ void ddc_chain_body_seg(const DdcChainJob &j, int c)
             }
         } else for (int b = b0; b < b1; b++) cnt += ddc_chain_step(s, r, post_in, post_dec, sh);
         if (mine) j.counts[c] = cnt;
-        j.seg_counts[(size_t)g * n_channels + c] = cnt;
+        j.seg_pref[(size_t)g * n_channels + c] = total; total += cnt;
     }
+    j.seg_pref[(size_t)j.seg_world * n_channels + c] = total;
     if (j.n_blocks <= 0) j.counts[c] = 0;
     j.state_out[c] = s;
 }
@@ -848,7 +850,7 @@ void ddc_mfma_destroy(DdcMfma *m)
         if (m->ev_free[k]) (void)hipEventDestroy(m->ev_free[k]);
     }
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    (void)hipFree(m->d_state_spec); (void)hipFree(m->d_seg_counts[0]); (void)hipFree(m->d_seg_counts[1]);
+    (void)hipFree(m->d_state_spec);
     for (auto &pr : m->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete m;
 }
@@ -877,33 +879,28 @@ static DdcChainJob mfma_chain_job(DdcMfma *m, int k, int n_blocks, DdcChanState 
     DdcChainJob j;
     j.state = d_state; j.state_out = d_state; j.mode = 1; j.geom = d_geom; j.n_channels = m->C; j.n_blocks = n_blocks; j.post_in = m->post_in; j.post_dec = m->post_dec; j.kmax = m->kmax;
     j.blk_remain = m->d_blk_remain[k]; j.blk_phase = m->d_blk_phase[k]; j.blk_off = m->d_blk_off[k]; j.counts = m->d_counts[k]; j.R = m->d_R[k];
-    j.seg_nbl = m->seg_nbl; j.seg_first = m->seg_first; j.seg_total = m->seg_total; j.seg_world = m->seg_world; j.seg_counts = m->d_seg_counts[k];
+    j.seg_nbl = m->seg_nbl; j.seg_first = m->seg_first; j.seg_total = m->seg_total; j.seg_world = m->seg_world; j.seg_pref = m->seg_cur;
     return j;
 }
 
 // Time-sliced bank: the next submit()'s n_blocks blocks are global blocks [first, first + n_blocks) of a batch of `total`, dealt to `world` ranks in runs of nbl.
-// The state handed to submit() is the one at the batch's block 0; the call leaves it behind the batch's last block.  nbl = 0: back to a plain call.
-int ddc_mfma_set_segment(DdcMfma *m, int nbl, int first, int total, int world)
+// The state handed to submit() is the one at the batch's block 0; the call leaves it behind the batch's last block.  pref_cur receives this call's run
+// offsets ([world + 1][n_channels] ints, device), pref_next those of the NEXT call when its chain is computed one call ahead (the caller alternates two
+// buffers: this call's pref_next is the next call's pref_cur).  nbl = 0: back to a plain call.
+int ddc_mfma_set_segment(DdcMfma *m, int nbl, int first, int total, int world, int *pref_cur, int *pref_next)
 {
-    if (nbl && m->seg_counts_world < world) {
-        CSDR_HIP(hipStreamSynchronize(m->side)); CSDR_HIP(hipStreamSynchronize(m->ctx->stream));
-        for (int k = 0; k < 2; k++) { (void)hipFree(m->d_seg_counts[k]); m->d_seg_counts[k] = nullptr; CSDR_HIP(hipMalloc((void **)&m->d_seg_counts[k], sizeof(int) * (size_t)world * m->C)); }
-        m->seg_counts_world = world; m->spec_valid = false;
-    }
-    m->seg_nbl = nbl; m->seg_first = first; m->seg_total = total; m->seg_world = world;
+    m->seg_nbl = nbl; m->seg_first = first; m->seg_total = total; m->seg_world = world; m->seg_cur = pref_cur; m->seg_next = pref_next;
     return 0;
 }
-const int *ddc_mfma_seg_counts(const DdcMfma *m) { return m->last_seg_counts; }
 int ddc_mfma_pending_blocks(const DdcMfma *m) { return m->pending_blocks[m->drain]; }
 // a rank whose run of the batch is empty still has to carry its channels' states over the batch (and to know every run's sample counts)
 int ddc_mfma_skip_batch(DdcMfma *m, DdcChanState *d_state, const ChanGeom *d_geom)
 {
     if (!m->seg_nbl) return fail_msg(-3, "fastddc: skip_batch outside a time-sliced bank");
-    const int k = m->fill;
-    DdcChainJob j = mfma_chain_job(m, k, 0, d_state, d_geom);
+    DdcChainJob j = mfma_chain_job(m, m->fill, 0, d_state, d_geom);
     hipLaunchKernelGGL(k_ddc_chain_t, dim3(cdiv(m->C, 64)), dim3(64), 0, m->ctx->stream, j);
     CSDR_LAUNCH_CHECK();
-    m->spec_valid = false; m->last_seg_counts = m->d_seg_counts[k];
+    m->spec_valid = false;
     return 0;
 }
 static int mfma_chains(DdcMfma *m, hipStream_t st, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
@@ -997,7 +994,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     } else {
         CSDR_HIP(hipEventRecord(m->ev_fork, mainst));                   // the producers of `in` queued so far; the readers of this set's tables (inline: same stream order)
         CSDR_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0));
-        if (!inl && m->free_recorded[k]) CSDR_HIP(hipStreamWaitEvent(m->side, m->ev_free[k], 0));      // the fold that read this set two calls ago
+        // (the fold that read this set two calls ago was queued on the context's stream before this call: ev_fork orders the side stream behind it)
         rc = mfma_chains(m, m->side, k, n_blocks, d_state, d_geom); if (rc) return rc;
     }
     if (spectra) {
@@ -1074,7 +1071,7 @@ int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches)
 
 // Fold + inverse transforms + scrap + residual shift of the oldest staged call, on the context's stream.  Returns its block count (or < 0);
 // *d_counts receives the device array of samples written per channel.
-int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts)
+int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts, hipEvent_t after_inverse)
 {
     const int k = m->drain, n_blocks = m->pending_blocks[k];
     if (!n_blocks) return fail_msg(-3, "fastddc: nothing staged to collect");
@@ -1147,17 +1144,21 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
         int n_riders = 0;
         if (m->ahead_ok && m->inline_set[k] && m->last_state && m->C <= 16 * 256) {      // the next call's chain tables into the other set, state into the shadow
             ahead = mfma_chain_job(m, k ^ 1, n_blocks, m->last_state, d_geom);
-            ahead.state_out = m->d_state_spec;
+            ahead.state_out = m->d_state_spec; ahead.seg_pref = m->seg_next;
             n_riders = 16;
             m->spec_valid = true; m->spec_set = k ^ 1; m->spec_blocks = n_blocks; m->spec_seg_first = m->seg_first; m->spec_seg_total = m->seg_total;
         }
+        // after_inverse: an event that completes with THIS kernel (its own completion signal: a hipEventRecord behind it would put a marker packet between this
+        // call's last kernel and the next call's first one)
+        if (after_inverse) hipExtLaunchKernelGGL(k_ddc_ifft256d_post<8>, dim3(g8.x + n_riders), dim3(256), (size_t)(8 * I256<8>::pitch + 512) * sizeof(float2), st, nullptr, after_inverse, 0, DDC_IFFT_ARGS, ahead, n_riders);
+        else
         hipLaunchKernelGGL(k_ddc_ifft256d_post<8>, dim3(g8.x + n_riders), dim3(256), (size_t)(8 * I256<8>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS, ahead, n_riders);
+        after_inverse = nullptr;
     }
 #undef DDC_IFFT_ARGS
     CSDR_LAUNCH_CHECK();
-    CSDR_HIP(hipEventRecord(m->ev_free[k], st)); m->free_recorded[k] = true;
+    if (after_inverse) CSDR_HIP(hipEventRecord(after_inverse, st));     // (the other inverse-transform variants)
     if (d_counts) *d_counts = m->d_counts[k];
-    m->last_seg_counts = m->d_seg_counts[k];
     m->pending_blocks[k] = 0; m->drain ^= 1;
     return n_blocks;
 }

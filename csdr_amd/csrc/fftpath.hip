@@ -719,7 +719,7 @@ struct csdr_amd_fastddc_bank {
     int shard_mode = CSDR_AMD_SHARD_CHANNELS; const DdcComm *dc = nullptr; int world = 1, rank = 0, nbl = 0, out_count = 0;
     size_t pitch_loc = 0;
     cf32 *d_in_loc[2] = {nullptr, nullptr}, *d_out_loc[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr}, *d_tail_root[2] = {nullptr, nullptr};
-    int *d_pref[2] = {nullptr, nullptr}; int tail_flip = 0;
+    int *d_pref[3] = {nullptr, nullptr, nullptr}; int tail_flip = 0, pref_at = 0;      // run-offset tables: this batch's, the next one's (computed one call ahead), and the one the previous batch's stitch may still read
     hipStream_t xin = nullptr, xout = nullptr;
     hipEvent_t ev_fork = nullptr, ev_in_ready[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool in_free_rec[2] = {false, false}, done_rec[2] = {false, false};
@@ -732,24 +732,23 @@ static void shard_slice(int n, int world, int rank, int *first, int *count)     
     *count = base + (rank < extra ? 1 : 0); *first = rank * base + (rank < extra ? rank : extra);
 }
 
-// per output channel of this rank: where every rank's run starts in the channel's stream of the batch (pref[g][cc]), and the total (pref[world][cc])
-__global__ __launch_bounds__(64) void k_bank_prefix(const int *__restrict__ seg_counts, int *__restrict__ pref, int n_channels_total, int first, int count, int world)
-{
-    const int cc = blockIdx.x * 64 + threadIdx.x;
-    if (cc >= count) return;
-    int acc = 0;
-    for (int g = 0; g < world; g++) { pref[g * count + cc] = acc; acc += seg_counts[(size_t)g * n_channels_total + first + cc]; }
-    pref[world * count + cc] = acc;
-}
-// out[cc][pref[g][cc] + t] = the run of rank g, t < its count: from the received piece (g != me) or this rank's own rows
+// out[cc][pref[g][first + cc] + t] = the run of rank g, t < its count: from the received piece (g != me) or this rank's own rows.  pref = the chain's table
+// [world + 1][n_channels_total] (fastddc_mfma.hip: ddc_chain_body_seg).  grid (channels of the slice, world, pieces of a run)
 __global__ __launch_bounds__(256) void k_bank_stitch(const float2 *__restrict__ own, const float2 *__restrict__ recv, const int *__restrict__ pref, float2 *__restrict__ out,
-                                                     size_t pitch_loc, size_t out_pitch, int first, int count, int me)
+                                                     size_t pitch_loc, size_t out_pitch, int n_total, int first, int count, int me)
 {
     const int cc = blockIdx.x, g = blockIdx.y;
-    const int at = pref[g * count + cc], cnt = pref[(g + 1) * count + cc] - at;
+    const int at = pref[(size_t)g * n_total + first + cc], cnt = pref[(size_t)(g + 1) * n_total + first + cc] - at;
     const float2 *src = g == me ? own + (size_t)(first + cc) * pitch_loc : recv + ((size_t)g * count + cc) * pitch_loc;
     float2 *dst = out + (size_t)cc * out_pitch + at;
-    for (int t = threadIdx.x; t < cnt; t += 256) dst[t] = src[t];
+    const int per = (cnt + (int)gridDim.z - 1) / (int)gridDim.z, t0 = (int)blockIdx.z * per, t1 = min(t0 + per, cnt);
+    for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) dst[t] = src[t];
+}
+// the batch's samples per channel of the slice (the last row of the table)
+__global__ __launch_bounds__(64) void k_bank_counts(const int *__restrict__ pref, int *__restrict__ counts, int n_total, int first, int count, int world)
+{
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    if (cc < count) counts[cc] = pref[(size_t)world * n_total + first + cc];
 }
 
 static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates, int n_channels,
@@ -791,7 +790,7 @@ static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw
         for (int k = 0; k < 2 && e == hipSuccess; k++) {
             e = hipMalloc((void **)&b->d_out_loc[k], sizeof(cf32) * (size_t)n_channels * b->pitch_loc);
             if (e == hipSuccess) e = hipMalloc((void **)&b->d_recv[k], sizeof(cf32) * (size_t)b->world * count * b->pitch_loc);
-            if (e == hipSuccess) e = hipMalloc((void **)&b->d_pref[k], sizeof(int) * (size_t)(b->world + 1) * count);
+            for (int t = k; t < 3 && e == hipSuccess; t += 2) e = hipMalloc((void **)&b->d_pref[t], sizeof(int) * ((size_t)(b->world + 1) * n_channels + count));      // the chain's table + this slice's counts
             if (e == hipSuccess && b->rank != 0) e = hipMalloc((void **)&b->d_in_loc[k], sizeof(cf32) * in_elems);
             if (e == hipSuccess && b->rank == 0) { e = hipMalloc((void **)&b->d_tail_root[k], sizeof(cf32) * (size_t)(g.overlap_length + 1));
                 if (e == hipSuccess) e = hipMemsetAsync(b->d_tail_root[k], 0, sizeof(cf32) * (size_t)(g.overlap_length + 1), ctx->stream); }      // csdr.c:2279: the stream starts behind zeros
@@ -814,7 +813,7 @@ static int bank_submit_blocks(csdr_amd_fastddc_bank *b, const csdr_complexf *in,
     if (!local) {     // the wideband stream lives on rank 0 (ddcd's single fastddc_fwd_cc): every rank is sent the samples of its run, with the overlap in front, over its own link
         const DdcComm *cm = b->dc;
         if (b->rank == 0) { CSDR_HIP(hipEventRecord(b->ev_fork, b->ctx->stream)); CSDR_HIP(hipStreamWaitEvent(b->xin, b->ev_fork, 0)); }      // the producers of `in`
-        else if (b->in_free_rec[slot]) CSDR_HIP(hipStreamWaitEvent(b->xin, b->ev_in_free[slot], 0));                                     // the transforms that read this slot two batches ago
+        else if (b->in_free_rec[slot]) CSDR_HIP(hipStreamWaitEvent(b->xin, b->ev_out_ready[slot], 0));                                   // the transforms that read this slot two batches ago
         int rc = cm->group_start(cm); if (rc) return rc;
         if (b->rank == 0) {
             for (int p = 1; p < b->world; p++) {
@@ -841,24 +840,29 @@ static int bank_collect_blocks(csdr_amd_fastddc_bank *b, csdr_complexf *out, siz
     hipStream_t st = b->ctx->stream;
     const int b0 = blk_first_of(b, me, bt.n_glob), b1 = blk_first_of(b, me + 1, bt.n_glob), n_loc = b1 - b0;
     if (!bt.local && me != 0) CSDR_HIP(hipStreamWaitEvent(st, b->ev_in_ready[slot], 0));
-    if (b->done_rec[slot]) CSDR_HIP(hipStreamWaitEvent(st, b->ev_done[slot], 0));      // the output exchange two batches ago read d_out_loc / d_pref of this slot
-    int rc = ddc_mfma_set_segment(f->mf, b->nbl, b0, bt.n_glob, W); if (rc) return rc;
+    // the output exchange two batches ago read d_out_loc / the offsets table of this slot: normally long finished -- then no wait packet goes into the stream
+    // (a cross-stream wait costs ~10 us of bubble in front of the next kernel even when the event has fired)
+    if (b->done_rec[slot] && hipEventQuery(b->ev_done[slot]) != hipSuccess) CSDR_HIP(hipStreamWaitEvent(st, b->ev_done[slot], 0));
+    // three tables in rotation: the riders of this batch's inverse-transform kernel write the NEXT batch's offsets while the previous batch's stitch may still
+    // read its own table; the one written now was last read by the stitch two batches ago (waited for above)
+    int *pref = b->d_pref[b->pref_at], *pref_next = b->d_pref[(b->pref_at + 1) % 3];
+    b->pref_at = (b->pref_at + 1) % 3;
+    int rc = ddc_mfma_set_segment(f->mf, b->nbl, b0, bt.n_glob, W, pref, pref_next); if (rc) return rc;
     if (n_loc > 0) {
         const cf32 *src, *tail;
         if (bt.local) { tail = bt.in; src = bt.in + ovl; }
         else if (me == 0) { tail = b->d_tail_root[b->tail_flip]; src = bt.in; }
         else { tail = b->d_in_loc[slot]; src = b->d_in_loc[slot] + ovl; }
         rc = ddc_mfma_submit(f->mf, src, nullptr, n_loc, f->d_state, f->d_geom, true, tail); if (rc) return rc;
-        rc = ddc_mfma_collect(f->mf, f->d_geom, b->d_out_loc[slot], b->pitch_loc, nullptr); if (rc < 0) return rc;
+        rc = ddc_mfma_collect(f->mf, f->d_geom, b->d_out_loc[slot], b->pitch_loc, nullptr, b->ev_out_ready[slot]); if (rc < 0) return rc;
     } else { rc = ddc_mfma_skip_batch(f->mf, f->d_state, f->d_geom); if (rc) return rc; }
+    const bool out_ready_recorded = n_loc > 0;                           // (by the call's last kernel itself)
     if (!bt.local && me == 0) {      // the next batch's overlap = the newest ovl samples of the stream (input_size >= overlap_length: checked at create)
         CSDR_HIP(hipMemcpyAsync(b->d_tail_root[b->tail_flip ^ 1], bt.in + (size_t)bt.n_glob * inp - ovl, sizeof(cf32) * (size_t)ovl, hipMemcpyDeviceToDevice, st));
         b->tail_flip ^= 1;
     }
-    hipLaunchKernelGGL(k_bank_prefix, dim3(cdiv(b->out_count, 64)), dim3(64), 0, st, ddc_mfma_seg_counts(f->mf), b->d_pref[slot], b->n_channels_total, b->first_channel, b->out_count, W);
-    CSDR_LAUNCH_CHECK();
-    CSDR_HIP(hipEventRecord(b->ev_in_free[slot], st)); b->in_free_rec[slot] = true;
-    CSDR_HIP(hipEventRecord(b->ev_out_ready[slot], st));
+    b->in_free_rec[slot] = true;
+    if (!out_ready_recorded) CSDR_HIP(hipEventRecord(b->ev_out_ready[slot], st));
     // output exchange on its own stream (under the next batch's transforms): every rank sends each peer that peer's channels of its run
     const DdcComm *cm = b->dc;
     CSDR_HIP(hipStreamWaitEvent(b->xout, b->ev_out_ready[slot], 0));
@@ -871,11 +875,14 @@ static int bank_collect_blocks(csdr_amd_fastddc_bank *b, csdr_complexf *out, siz
         if (p_loc > 0) { rc = cm->recv(cm, b->d_recv[slot] + (size_t)p * b->out_count * b->pitch_loc, 2 * (size_t)b->out_count * b->pitch_loc, p, b->xout); if (rc) return rc; }
     }
     rc = cm->group_end(cm); if (rc) return rc;
-    hipLaunchKernelGGL(k_bank_stitch, dim3(b->out_count, W), dim3(256), 0, b->xout, reinterpret_cast<const float2 *>(b->d_out_loc[slot]), reinterpret_cast<const float2 *>(b->d_recv[slot]),
-                       b->d_pref[slot], reinterpret_cast<float2 *>(out), b->pitch_loc, out_pitch, b->first_channel, b->out_count, me);
+    int *d_cnt = pref + (size_t)(W + 1) * b->n_channels_total;
+    hipLaunchKernelGGL(k_bank_stitch, dim3(b->out_count, W, 8), dim3(256), 0, b->xout, reinterpret_cast<const float2 *>(b->d_out_loc[slot]), reinterpret_cast<const float2 *>(b->d_recv[slot]),
+                       pref, reinterpret_cast<float2 *>(out), b->pitch_loc, out_pitch, b->n_channels_total, b->first_channel, b->out_count, me);
+    CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bank_counts, dim3(cdiv(b->out_count, 64)), dim3(64), 0, b->xout, pref, d_cnt, b->n_channels_total, b->first_channel, b->out_count, W);
     CSDR_LAUNCH_CHECK();
     CSDR_HIP(hipEventRecord(b->ev_done[slot], b->xout)); b->done_rec[slot] = true;
-    b->last_counts = b->d_pref[slot] + (size_t)W * b->out_count; b->last_count_n = b->out_count; b->last_slot = slot;
+    b->last_counts = d_cnt; b->last_count_n = b->out_count; b->last_slot = slot;
     b->drain ^= 1; b->n_batches--;
     return 0;
 }
@@ -905,7 +912,7 @@ void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
     if (b->inv) csdr_amd_fastddc_inv_destroy(b->inv);
     (void)hipFree(b->d_spec);
     for (int k = 0; k < 2; k++) {
-        (void)hipFree(b->d_in_loc[k]); (void)hipFree(b->d_out_loc[k]); (void)hipFree(b->d_recv[k]); (void)hipFree(b->d_tail_root[k]); (void)hipFree(b->d_pref[k]);
+        (void)hipFree(b->d_in_loc[k]); (void)hipFree(b->d_out_loc[k]); (void)hipFree(b->d_recv[k]); (void)hipFree(b->d_tail_root[k]); (void)hipFree(b->d_pref[k]); if (k == 0) (void)hipFree(b->d_pref[2]);
         for (hipEvent_t ev : {b->ev_in_ready[k], b->ev_in_free[k], b->ev_out_ready[k], b->ev_done[k]}) if (ev) (void)hipEventDestroy(ev);
     }
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
