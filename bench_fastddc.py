@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench_fastddc.py -- BASELINE.json configs[3]: fastddc_fwd_cc + fastddc_inv_cc, 256 output channels from one 61.44 MS/s
-complexf input, channels sharded across N GPUs with an RCCL broadcast of the forward spectrum.
+complexf input, the channels' outputs sharded across N GPUs.
 
-One step = `--blocks` consecutive overlap-save blocks (input_size = 57344 samples each at D=256, tbw=0.001: fft 65536,
-taps 8193, fft_inv 512): rank 0 frames + FFTs the new input once, the [blocks, 65536] spectrum is broadcast over xGMI,
-every rank folds/IFFTs/post-shifts its slice of the channels.  Reports wideband INPUT MS/s (whole job) and aggregate output MS/s.
+One step = one batch of consecutive overlap-save blocks (input_size = 57344 samples each at D=256, tbw=0.001: fft 65536,
+taps 8193, fft_inv 512) through the bank object: `--blocks` blocks on one GPU, `--blocks` x N over N GPUs -- the bank is time-sliced
+(csdr_amd_fastddc_bank_create_sharded: every rank runs the whole pipeline on its run of `--blocks` blocks, the decimated outputs are
+exchanged all-to-all so that rank r ends up with its slice of the channels; --shard channels selects the channel-sharded compute with
+the all-gathered spectra instead).  Reports wideband INPUT MS/s (whole job) and aggregate output MS/s.
+--emulate-world W times ONE rank's work of a W-rank bank on one GPU (no transport) beside a bytes-per-link model of the exchange.
 
     python bench_fastddc.py [--gpus N] [--steps K] [--warmup W] [--channels 256] [--blocks 64] [--no-cpu-baseline] [--verify]
 N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench_fastddc.py --gpus N ...
@@ -191,7 +194,7 @@ def main():
     L = ctx.L
     ddc, err = ctx.fastddc_init(args.tbw, args.decimation, 0.0)
     assert err == 0
-    nb = args.blocks
+    nb = args.blocks * (world if (world > 1 and not shared and args.shard == "blocks") else 1)      # time slices: every rank gets a run of --blocks blocks per batch
     # channel c sits at shift_rate = -0.5 + (c + 0.5)/C  
     rates = (-0.5 + (np.arange(args.channels) + 0.5) / args.channels).astype(np.float32)
     first, count = cd.shard(args.channels, rank, world)
@@ -212,7 +215,7 @@ def main():
             comm = L.csdr_amd_comm_create(ctx.h, idb, rank, world)
             if not comm:
                 raise SystemExit("comm_create: " + ctx.err())
-            bank = L.csdr_amd_fastddc_bank_create_sharded(ctx.h, args.tbw, args.decimation, rates.ctypes.data_as(C.c_void_p), args.channels, 2, nb, comm)
+            bank = L.csdr_amd_fastddc_bank_create_sharded_by(ctx.h, args.tbw, args.decimation, rates.ctypes.data_as(C.c_void_p), args.channels, 2, nb, comm, csdr_amd.SHARD[args.shard])
         else:
             bank = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
         if not bank:
@@ -273,6 +276,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if bank:
+        L.csdr_amd_fastddc_bank_finish(bank, None)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kms = C.c_double(0); kl = C.c_long(0)
@@ -288,8 +293,10 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[3]: fastddc_fwd_cc + fastddc_inv_cc", "channels": args.channels, "decimation": args.decimation,
                           "transition_bw": args.tbw, "fft_size": ddc.fft_size, "fft_inv_size": ddc.fft_inv_size, "blocks_per_step": nb,
-                          "parallelism": "channels sharded over ranks; forward transform split by blocks, input scattered point-to-point, transposed spectra all-gathered (RCCL, from libcsdr_amd.so)",
-                          "pipelining": "batch N+1 staged (exchange + forward transform, side stream) under the fold of batch N" if world > 1 else "none (one process() per step)"},
+                          "parallelism": ("time slices: every rank runs the whole pipeline on its run of the batch's blocks (input sent point to point from rank 0), decimated outputs exchanged "
+                                          "all-to-all so that rank r delivers its slice of the channels (RCCL, from libcsdr_amd.so)") if args.shard == "blocks" else
+                                         "channels sharded over ranks; forward transform split by blocks, input scattered point-to-point, transposed spectra all-gathered (RCCL, from libcsdr_amd.so)",
+                          "pipelining": "batch N+1's input exchange and batch N's output exchange on their own streams beside the kernels" if world > 1 else "none (one process() per step)"},
                "aggregate_output_msps": round(in_samples / args.decimation * args.channels / wall / 1e6, 2),
                "realtime_factor_at_61p44_msps": round(in_samples / wall / 61.44e6, 3),
                "taps_fft_bytes_per_step": h_bytes}
@@ -327,6 +334,7 @@ def main():
     if bank:
         if pipelined:
             L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)   # drain the staged batch
+        L.csdr_amd_fastddc_bank_finish(bank, None)
         ctx.sync(); torch.cuda.synchronize()
         L.csdr_amd_fastddc_bank_destroy(bank)
         if comm:

@@ -4,8 +4,9 @@ on ROCm) on the GPU box, gloo in the CPU tests.
 Where the hot path shards:
   * WFM / NFM chains, converters, FIRs: streams are independent -> block-distribute streams over ranks, NO data-path
     collective (replicas).  Only the barrier and the max-over-ranks of the timing use the communicator.
-  * fastddc: ONE exchange step -- the forward overlap-save FFT is computed once (rank 0) and the fft_size spectrum
-    block is broadcast; rank r then runs its slice of the channels (own taps_fft slab), outputs stay per rank.
+  * fastddc: the one path with an exchange.  The C library (csdr_amd/csrc/comm.cpp, fftpath.hip) offers two schedules: time slices (default: every rank
+    runs the whole pipeline on its run of a batch's blocks, the decimated outputs are exchanged all-to-all; bank_time_sliced below is its CPU model) and
+    channel slices (forward transform split by blocks, spectra all-gathered: bank_exchange below).  fastddc_sharded is the round-1 root broadcast.
 """
 import os
 import torch
@@ -125,3 +126,48 @@ def bank_exchange(x_or_none, n_blocks, max_blocks, input_size, overlap, fft_size
     else:
         gathered[0] = torch.from_numpy(chunk.view(np.float32).reshape(-1).copy())
     return nbl, np.stack([t.numpy().view(np.complex64).reshape(nbl, fft_size) for t in gathered])
+
+
+def bank_time_sliced(x_or_none, n_blocks, max_blocks, input_size, overlap, n_channels, run_fn, rank, world):
+    """The time-sliced bank's batch (csdr_amd/csrc/fftpath.hip: bank_submit_blocks / bank_collect_blocks) on torch.distributed -- the CPU model used by
+    tests/test_dist_cpu.py: rank 0 sends every rank the samples of its run of blocks (overlap in front, point to point); every rank runs the whole
+    channelizer on its run for ALL channels, starting each channel's shift state where the blocks in front of the run leave it (data independent: walked
+    locally); the per-channel outputs are exchanged all-to-all so that rank r ends up with its block-distributed slice of the channels, runs in rank order.
+    run_fn(samples [overlap + n_loc * input_size] complex64, first_block, n_blocks) -> list of n_channels complex64 arrays (this run's output per channel).
+    Returns (first_channel, [stitched output per channel of this rank's slice])."""
+    import numpy as np
+    nbl, ranges = bank_block_ranges(n_blocks, max_blocks, world, input_size, overlap)
+    b0, b1, s0, s1 = ranges[rank]
+    if rank == 0:
+        xin = np.concatenate([np.zeros(overlap, np.complex64), np.asarray(x_or_none, np.complex64)])
+        reqs = []
+        for g in range(1, world):
+            g0, g1, t0, t1 = ranges[g]
+            if g1 > g0:
+                reqs.append(dist.isend(torch.from_numpy(xin[overlap + t0:overlap + t1].view(np.float32).copy()), g))
+        mine = xin[overlap + s0:overlap + s1]
+        for r in reqs:
+            r.wait()
+    elif b1 > b0:
+        buf = torch.empty(2 * (s1 - s0), dtype=torch.float32)
+        dist.recv(buf, 0)
+        mine = buf.numpy().view(np.complex64)
+    else:
+        mine = np.zeros(overlap, np.complex64)
+    outs = run_fn(mine, b0, n_blocks)                                 # every channel, this run
+    # all-to-all of the outputs: lengths first (the C library knows them from the chain; the model just sends them), then the samples
+    first, count = shard(n_channels, rank, world)
+    pieces = {rank: [outs[first + c] for c in range(count)]}
+    for shift in range(1, world):
+        to = (rank + shift) % world; frm = (rank - shift) % world
+        tf, tc = shard(n_channels, to, world)
+        payload = np.concatenate([np.asarray(outs[tf + c], np.complex64) for c in range(tc)]) if tc else np.zeros(0, np.complex64)
+        lens = torch.tensor([len(outs[tf + c]) for c in range(tc)], dtype=torch.int64)
+        req1 = dist.isend(lens, to); got_lens = torch.empty(count, dtype=torch.int64); dist.recv(got_lens, frm); req1.wait()
+        req2 = dist.isend(torch.from_numpy(payload.view(np.float32).copy()), to)
+        got = torch.empty(2 * int(got_lens.sum()), dtype=torch.float32); dist.recv(got, frm); req2.wait()
+        g = got.numpy().view(np.complex64); at = 0; lst = []
+        for c in range(count):
+            lst.append(g[at:at + int(got_lens[c])].copy()); at += int(got_lens[c])
+        pieces[frm] = lst
+    return first, [np.concatenate([pieces[g][c] for g in range(world)]) for c in range(count)]

@@ -411,15 +411,17 @@ class Port:
         self.L.orc_fft_swap_sides(_p(tf), ddc.fft_size)
         return tf
 
-    def fastddc_inv_cc(self, spectra, ddc, taps_fft):
+    def fastddc_inv_cc(self, spectra, ddc, taps_fft, status=None):
+        """status = (decimation_remain, starting_phase) to continue a stream; with a status the call returns (samples, status after the last block)."""
         spectra = np.ascontiguousarray(spectra, c64); taps_fft = _cf(taps_fft)
-        st = _DsaStatus(0, 0.0, 0)
+        st = _DsaStatus(0, 0.0, 0) if status is None else _DsaStatus(int(status[0]), float(status[1]), 0)
         outs = []
         ob = np.zeros(ddc.post_input_size + 2, c64)
         for b in range(spectra.shape[0]):
             st = self.L.orc_fastddc_inv_cc(_p(spectra[b]), _p(ob), C.byref(ddc), _p(taps_fft), st)
             outs.append(ob[:st.output_size].copy())
-        return np.concatenate(outs) if outs else np.zeros(0, c64)
+        y = np.concatenate(outs) if outs else np.zeros(0, c64)
+        return y if status is None else (y, (st.decimation_remain, st.starting_phase))
 
     # ---- chains
     def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000):

@@ -149,3 +149,70 @@ def test_gloo_world3_bank_schedule():
     for c, rate in enumerate(rates):
         d, _ = po.fastddc_init(tbw, D, rate)
         assert np.array_equal(got[c], po.fastddc_inv_cc(spec, d, po.fastddc_taps_fft(d, rate, D)))
+
+
+def _sliced_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from csdr_amd import dist as cd
+    import oracle
+    cd.init("gloo")
+    po = oracle.port()
+    D, tbw = 16, 0.05
+    rates = [-0.1, 0.2, 0.33, -0.4, 0.05]
+    ddc, _ = po.fastddc_init(tbw, D, 0.0)
+    n_blocks, max_blocks = 7, 8                                     # runs of 4 blocks: [0, 4) and [4, 7)
+    rng = np.random.default_rng(15)
+    x = (rng.uniform(-1, 1, ddc.input_size * n_blocks) + 1j * rng.uniform(-1, 1, ddc.input_size * n_blocks)).astype(np.complex64)
+    zero = np.zeros((1, ddc.fft_size), np.complex64)
+
+    def run(samples, first_block, n_glob):
+        n_loc = (samples.size - ddc.overlap_length) // ddc.input_size
+        spec = np.stack([po.fft_c2c(samples[b * ddc.input_size:b * ddc.input_size + ddc.fft_size], True) for b in range(n_loc)]) if n_loc else np.zeros((0, ddc.fft_size), np.complex64)
+        outs = []
+        for rate in rates:
+            d, _ = po.fastddc_init(tbw, D, rate)
+            tf = po.fastddc_taps_fft(d, rate, D)
+            st = (0, 0.0)
+            for _ in range(first_block):                             # the shift state in front of the run: data independent, so walked on zeros
+                _, st = po.fastddc_inv_cc(zero, d, tf, status=st)
+            y, _ = po.fastddc_inv_cc(spec, d, tf, status=st)
+            outs.append(y)
+        return outs
+
+    first, outs = cd.bank_time_sliced(x if rank == 0 else None, n_blocks, max_blocks, ddc.input_size, ddc.overlap_length, len(rates), run, rank, world)
+    cd.barrier()
+    q.put((rank, first, [o.tolist() for o in outs]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_time_sliced_bank_schedule(world):
+    """The time-sliced bank (fftpath.hip: bank_submit_blocks / bank_collect_blocks; the default of csdr_amd_fastddc_bank_create_sharded) as a gloo model: runs of
+    blocks per rank, every rank all channels with the shift state walked locally over the blocks in front of its run, outputs exchanged all-to-all and
+    stitched in rank order -- bit-identical to the unsharded oracle."""
+    import oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_sliced_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    po = oracle.port()
+    D, tbw = 16, 0.05
+    rates = [-0.1, 0.2, 0.33, -0.4, 0.05]
+    ddc, _ = po.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(15)
+    x = (rng.uniform(-1, 1, ddc.input_size * 7) + 1j * rng.uniform(-1, 1, ddc.input_size * 7)).astype(np.complex64)
+    spec = po.fastddc_fwd_cc(x, ddc)
+    got = {}
+    for rank, first, outs in res:
+        for k, o in enumerate(outs):
+            got[first + k] = np.array(o, dtype=np.complex64)
+    assert sorted(got) == list(range(len(rates)))
+    for c, rate in enumerate(rates):
+        d, _ = po.fastddc_init(tbw, D, rate)
+        assert np.array_equal(got[c], po.fastddc_inv_cc(spec, d, po.fastddc_taps_fft(d, rate, D)))
