@@ -178,7 +178,6 @@ def lib():
     L.csdr_amd_wfm_process.restype = C.c_long; L.csdr_amd_wfm_process.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.csdr_amd_wfm_kernel_name.restype = C.c_char_p; L.csdr_amd_wfm_kernel_name.argtypes = [vp]
     L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
-    L.csdr_amd_debug_wfm_select.restype = None; L.csdr_amd_debug_wfm_select.argtypes = [i]
     L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.csdr_amd_ddc_create.restype = vp; L.csdr_amd_ddc_create.argtypes = [vp, i, fl, i, vp, i, sz]
     L.csdr_amd_ddc_destroy.argtypes = [vp]
@@ -652,7 +651,7 @@ class Context:
 
     def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0):
         """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call;
-        `pitch_pad` = extra bytes of row pitch (multiple of 16; a pitch that is not a multiple of 128 selects the quad kernel).
+        `pitch_pad` = extra bytes of row pitch (multiple of 16).
         The front-end kernel of the last call is left in `self.last_wfm_kernel`."""
         x2, squeeze = self._2d(iq_u8, np.uint8)
         s, nbytes = x2.shape; n = nbytes // 2

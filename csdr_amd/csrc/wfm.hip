@@ -198,10 +198,11 @@ struct csdr_amd_wfm {
     int n_streams, D, L, F, audio_rate;
     float shift_rate, tau, alpha;
     size_t max_block;
-    float *d_taps, *d_demod, *d_last[2], *d_seg_state;
+    float *d_taps, *d_demod, *d_last[2];
     float phase;                     // shift_addition_cc starting_phase (host float, like the reference's by-value state)
     cf32 *d_rot;
-    uint8_t *d_hist;
+    uint8_t *d_hist;                 // VALU front end: 2 * HIST bytes per stream
+    uint8_t *d_head[2]; int hflip;   // matrix-core chain kernel: 1 KiB per stream, second half = the previous block's newest 512 bytes (two buffers: wfm_mfma.hip)
     size_t demod_pitch;
     long long B, next_j;
     int last_T, flip;
@@ -217,9 +218,7 @@ struct csdr_amd_wfm {
     WfmMfmaDevice mfma;
     float2 *d_ctab; size_t ctab_cap;
     float2 c_prev;                   // phasor seed of the previous block's last chunk (history windows)
-    // side stream: the bounds-checked edge tiles and the history copy run beside the dominant kernel (which leaves the CUs' wave slots
-    // mostly free: 4 waves per CU), joined before the back end
-    hipStream_t side; hipEvent_t ev_fork, ev_join;
+    long long tab_first; bool tab_valid;      // the device table of seeds covers chunks [tab_first, tab_first + ctab_cap)
 };
 
 extern "C" {
@@ -238,55 +237,43 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     w->demod_pitch = (max_audio + 40 + 63) & ~(size_t)63;          // + the octet-aligned start (up to 31 samples) and tile padding
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    w->d_demod = nullptr; w->d_rot = nullptr; w->d_hist = nullptr; w->d_head[0] = w->d_head[1] = nullptr; w->hflip = 0;
+    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_seq_frags = nullptr; w->mfma.d_seq_cum = nullptr; w->mfma.d_dtab = nullptr;
+    {
+        const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons); read once, here
+        w->use_mfma = !(force && !strcmp(force, "valu")) && wfm_mfma_supported(decimation, taps_length, frac_rate);
+    }
     alloc((void **)&w->d_taps, sizeof(float) * taps_length);
-    alloc((void **)&w->d_demod, sizeof(float) * w->demod_pitch * n_streams);
     alloc((void **)&w->d_last[0], sizeof(float) * n_streams);
     alloc((void **)&w->d_last[1], sizeof(float) * n_streams);
-    alloc((void **)&w->d_seg_state, sizeof(float) * n_streams);
-    alloc((void **)&w->d_rot, sizeof(cf32) * (HIST + max_block_samples + 64));
-    alloc((void **)&w->d_hist, (size_t)2 * HIST * n_streams);
-    if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); delete w; return nullptr; }
+    if (w->use_mfma) {
+        alloc((void **)&w->d_head[0], wfm_mfma_head_bytes(n_streams));
+        alloc((void **)&w->d_head[1], wfm_mfma_head_bytes(n_streams));
+    } else {                                                       // the VALU front end's intermediates: demodulated floats, rotator table, history
+        alloc((void **)&w->d_demod, sizeof(float) * w->demod_pitch * n_streams);
+        alloc((void **)&w->d_rot, sizeof(cf32) * (HIST + max_block_samples + 64));
+        alloc((void **)&w->d_hist, (size_t)2 * HIST * n_streams);
+    }
+    if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); csdr_amd_wfm_destroy(w); return nullptr; }
     (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     w->kernel_name = "k_wfm_front";
-    w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_frags = nullptr; w->mfma.d_consts = nullptr; w->mfma.d_kb_of = nullptr; w->mfma.d_seq_frags = nullptr; w->mfma.d_seq_cum = nullptr; w->mfma.d_dtab = nullptr;
-    {
-        const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons)
-        const bool want_mfma = !(force && !strcmp(force, "valu"));
-        if (want_mfma && wfm_mfma_supported(decimation, taps_length, frac_rate)) {
-            WfmMfmaTable t;
-            wfm_mfma_build_table(decimation, taps_length, frac_rate, shift_rate, host_taps, t);
-            w->mfma.tile_stride_bytes = t.tile_stride_bytes; w->mfma.win_off_bytes = t.win_off_bytes; w->mfma.n_phases = t.n_phases; w->mfma.scale = t.scale;
-            w->ctab_cap = max_block_samples / 1024 + 8;
-            hipError_t e2 = hipMalloc(&w->mfma.d_frags, t.frags.size());
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_consts, t.consts.size() * sizeof(float));
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_kb_of, t.kb_of.size() * sizeof(int));
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->d_ctab, w->ctab_cap * sizeof(float2));
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_frags, t.frags.data(), t.frags.size(), hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_consts, t.consts.data(), t.consts.size() * sizeof(float), hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_kb_of, t.kb_of.data(), t.kb_of.size() * sizeof(int), hipMemcpyHostToDevice);
-            w->mfma.seq_scale = t.seq_scale;
-            if (e2 == hipSuccess) e2 = hipMalloc(&w->mfma.d_seq_frags, t.seq_frags.size());
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_seq_cum, t.seq_cum.size() * sizeof(float));
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_dtab, t.dtab.size() * sizeof(float2));
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_seq_frags, t.seq_frags.data(), t.seq_frags.size(), hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_seq_cum, t.seq_cum.data(), t.seq_cum.size() * sizeof(float), hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_dtab, t.dtab.data(), t.dtab.size() * sizeof(float2), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) { fail(e2, "hipMalloc/hipMemcpy(wfm mfma table)", __FILE__, __LINE__); delete w; return nullptr; }
-            w->use_mfma = true; w->kernel_name = "k_wfm_mfma";
-        }
+    if (w->use_mfma) {
+        WfmMfmaTable t;
+        wfm_mfma_build_table(decimation, taps_length, frac_rate, shift_rate, host_taps, t);
+        w->mfma.tile_stride_bytes = t.tile_stride_bytes; w->mfma.win_off_bytes = t.win_off_bytes; w->mfma.seq_scale = t.seq_scale;
+        w->ctab_cap = 16 * (max_block_samples / 1024 + 8);                 // 16 calls of the largest block ahead (2.4 M-sample blocks: 300 KB)
+        hipError_t e2 = hipMalloc((void **)&w->d_ctab, w->ctab_cap * sizeof(float2));
+        if (e2 == hipSuccess) e2 = hipMalloc(&w->mfma.d_seq_frags, t.seq_frags.size());
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_seq_cum, t.seq_cum.size() * sizeof(float));
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_dtab, t.dtab.size() * sizeof(float2));
+        if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_seq_frags, t.seq_frags.data(), t.seq_frags.size(), hipMemcpyHostToDevice);
+        if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_seq_cum, t.seq_cum.data(), t.seq_cum.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e2 == hipSuccess) e2 = hipMemcpy(w->mfma.d_dtab, t.dtab.data(), t.dtab.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e2 != hipSuccess) { fail(e2, "hipMalloc/hipMemcpy(wfm mfma table)", __FILE__, __LINE__); csdr_amd_wfm_destroy(w); return nullptr; }
+        w->kernel_name = "k_wfm_mfma_seq";
     }
     w->profiling = false; w->ev_used = 0; w->prof_ms = 0; w->prof_launches = 0;
-    w->side = nullptr; w->ev_fork = nullptr; w->ev_join = nullptr;
-    {
-        const char *e = getenv("CSDR_AMD_WFM_SIDE");
-        if (w->use_mfma && e && atoi(e) == 1) {      // opt-in: measured 1.324 vs 1.301 ms per step WITH the fork/join (cross-stream events cost more than the 2 x 22 us they hide)
-            if (hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking) != hipSuccess) w->side = nullptr;
-            if (w->side && (hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) != hipSuccess)) {
-                (void)hipStreamDestroy(w->side); w->side = nullptr;
-            }
-        }
-    }
-    if (csdr_amd_wfm_reset(w)) { delete w; return nullptr; }
+    if (csdr_amd_wfm_reset(w)) { csdr_amd_wfm_destroy(w); return nullptr; }
     return w;
 }
 
@@ -294,19 +281,10 @@ void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
 {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
-    (void)hipFree(w->d_taps); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]); (void)hipFree(w->d_seg_state);
-    (void)hipFree(w->d_rot); (void)hipFree(w->d_hist);
+    (void)hipFree(w->d_taps); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]);
+    (void)hipFree(w->d_rot); (void)hipFree(w->d_hist); (void)hipFree(w->d_head[0]); (void)hipFree(w->d_head[1]);
     for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-    if (w->mfma.d_frags) (void)hipFree(w->mfma.d_frags);
-    if (w->mfma.d_consts) (void)hipFree(w->mfma.d_consts);
-    if (w->mfma.d_kb_of) (void)hipFree(w->mfma.d_kb_of);
-    if (w->mfma.d_seq_frags) (void)hipFree(w->mfma.d_seq_frags);
-    if (w->mfma.d_seq_cum) (void)hipFree(w->mfma.d_seq_cum);
-    if (w->mfma.d_dtab) (void)hipFree(w->mfma.d_dtab);
-    if (w->d_ctab) (void)hipFree(w->d_ctab);
-    if (w->side) { (void)hipStreamSynchronize(w->side); (void)hipStreamDestroy(w->side); }
-    if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
-    if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+    (void)hipFree(w->mfma.d_seq_frags); (void)hipFree(w->mfma.d_seq_cum); (void)hipFree(w->mfma.d_dtab); (void)hipFree(w->d_ctab);
     delete w;
 }
 
@@ -316,10 +294,12 @@ int csdr_amd_wfm_reset(csdr_amd_wfm *w)
     w->phase = 0.f;
     CSDR_HIP(hipMemsetAsync(w->d_last[0], 0, sizeof(float) * w->n_streams, st));
     CSDR_HIP(hipMemsetAsync(w->d_last[1], 0, sizeof(float) * w->n_streams, st));
-    CSDR_HIP(hipMemsetAsync(w->d_rot, 0, sizeof(cf32) * (HIST + w->max_block + 64), st));
-    CSDR_HIP(hipMemsetAsync(w->d_hist, 0x80, (size_t)2 * HIST * w->n_streams, st));
+    if (w->d_rot) CSDR_HIP(hipMemsetAsync(w->d_rot, 0, sizeof(cf32) * (HIST + w->max_block + 64), st));
+    if (w->d_hist) CSDR_HIP(hipMemsetAsync(w->d_hist, 0x80, (size_t)2 * HIST * w->n_streams, st));
+    for (int k = 0; k < 2; k++) if (w->d_head[k]) CSDR_HIP(hipMemsetAsync(w->d_head[k], 0x80, wfm_mfma_head_bytes(w->n_streams), st));      // 0x80 = zero samples in front of the stream
+    w->hflip = 0;
     w->B = 0; w->next_j = 0; w->last_T = 0; w->flip = 0; w->ended = false;
-    w->c_prev = make_float2(1.f, 0.f);
+    w->c_prev = make_float2(1.f, 0.f); w->tab_valid = false; w->tab_first = 0;
     return 0;
 }
 
@@ -354,28 +334,44 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     if (((uintptr_t)in & 15) || (in_pitch & 15)) return fail_msg(-3, "wfm: input pointer and pitch must be 16-byte aligned");
     const int T = (int)block_samples;
     int rc = 0;
-    bool hist_saved = false;
+    const float2 *ctab_call = nullptr;
     if (w->use_mfma) {
-        // 1a. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping
-        //     (libcsdr_gpl.c:33-34, 48-51; chunks of 1024 per csdr.c:911-918).  ctab[0] belongs to the previous block's last chunk.
+        // 1a. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping (libcsdr_gpl.c:33-34, 48-51; chunks
+        //     of 1024 per csdr.c:911-918).  The sequence depends on nothing but the shift rate, so the device holds a TABLE of it that runs far ahead of the
+        //     stream (16 calls' worth) and a call only passes an offset: no upload sits between two calls' kernels (round 2 uploaded every call's seeds in
+        //     front of its kernel: a copy-engine hand-off of ~10 us per step).  Entry k of the table = chunk tab_first + k; a call needs the chunk in front
+        //     of its block (history windows) up to two behind it.
         const size_t nch = ((size_t)T + 1023) / 1024;
-        if (nch + 3 > w->ctab_cap) return fail_msg(-3, "wfm: chunk table too small");
-        float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * (nch + 3));
-        if (!hc) return -2;
+        const long long first = w->B / 1024 - 1;                              // (blocks are multiples of 1024 except a stream's last one)
         const float inc = (w->shift_rate * 2) * PI_F;
+        if (nch + 3 > w->ctab_cap) return fail_msg(-3, "wfm: chunk table too small");
+        if (!w->tab_valid || first < w->tab_first || first + (long long)nch + 3 > w->tab_first + (long long)w->ctab_cap) {
+            float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * w->ctab_cap);
+            if (!hc) return -2;
+            float ph = w->phase;
+            hc[0] = w->c_prev;
+            for (size_t k = 1; k < w->ctab_cap; k++) {
+                hc[k] = make_float2((float)cos((double)ph), (float)sin((double)ph));
+                float nx = ph + inc * (float)1024;
+                while (nx > PI_F) nx -= 2 * PI_F;
+                while (nx < -PI_F) nx += 2 * PI_F;
+                ph = nx;
+            }
+            rc = c->pinned_upload(w->d_ctab, sizeof(float2) * w->ctab_cap); if (rc) return rc;
+            w->tab_first = first; w->tab_valid = true;
+        }
+        ctab_call = w->d_ctab + (first - w->tab_first);
+        // the stream's phase behind this block (and the seed of its last chunk, for a table rebuilt at the next call)
         float ph = w->phase;
-        hc[0] = w->c_prev;
-        for (size_t m = 0; m <= nch + 1; m++) {
-            hc[1 + m] = make_float2((float)cos((double)ph), (float)sin((double)ph));
-            if (m + 1 == nch) w->c_prev = hc[1 + m];
-            const int len = (m < nch && (size_t)T - m * 1024 < 1024) ? (int)((size_t)T - m * 1024) : 1024;
+        for (size_t m = 0; m < nch; m++) {
+            if (m + 1 == nch) w->c_prev = make_float2((float)cos((double)ph), (float)sin((double)ph));
+            const int len = ((size_t)T - m * 1024 < 1024) ? (int)((size_t)T - m * 1024) : 1024;
             float nx = ph + inc * (float)len;
             while (nx > PI_F) nx -= 2 * PI_F;
             while (nx < -PI_F) nx += 2 * PI_F;
-            if (m + 1 == nch) w->phase = nx;
             ph = nx;
         }
-        rc = c->pinned_upload(w->d_ctab, sizeof(float2) * (nch + 3)); if (rc) return rc;
+        w->phase = ph;
     } else {
         // 1b. rotator table for this block behind the previous block's tail (history positions keep their own phasors)
         if (w->last_T) CSDR_HIP(hipMemcpyAsync(w->d_rot, w->d_rot + w->last_T, sizeof(cf32) * HIST, hipMemcpyDeviceToDevice, st));
@@ -391,59 +387,46 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     }
     const long long n_audio_ll = j_hi - w->next_j + 1;
     const int n_audio = n_audio_ll > 0 ? (int)n_audio_ll : 0;
-    if ((size_t)n_audio + 40 > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
-    if (n_audio > 0) {
-        if ((size_t)n_audio > out_pitch) return fail_msg(-3, "wfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, n_audio);
-        WfmParams p; p.D = w->D; p.L = w->L; p.F = w->F; p.T = T; p.B = w->B; p.j_first = w->next_j; p.n_audio = n_audio;
-        const int span = w->D * (w->F * (TILE_A - 1) + 1) + w->L + 16;          // samples per tile window (+alignment slack)
-        const size_t lds = (size_t)((span + 7) / 8 * 8 + 2 * TILE_A) * sizeof(float2) + 64;
-        if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_wfm_front, lds); if (arc) return arc; }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (w->profiling) {
-            if (w->ev_used == w->ev_pool.size()) {
-                hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b));
-                w->ev_pool.emplace_back(a, b);
-            }
-            e0 = w->ev_pool[w->ev_used].first; e1 = w->ev_pool[w->ev_used].second; w->ev_used++;
+    if (n_audio > 0 && (size_t)n_audio > out_pitch) return fail_msg(-3, "wfm: out_pitch %zu smaller than the %d audio samples of this block", out_pitch, n_audio);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (w->profiling && n_audio > 0) {
+        if (w->ev_used == w->ev_pool.size()) {
+            hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b));
+            w->ev_pool.emplace_back(a, b);
         }
-        bool forked = false, back_done = false;
-        if (w->use_mfma) {
-            hipStream_t se = st;
-            if (w->side) {                                                     // fork: edge tiles + history copy beside the dominant kernel
-                CSDR_HIP(hipEventRecord(w->ev_fork, st));
-                CSDR_HIP(hipStreamWaitEvent(w->side, w->ev_fork, 0));
-                se = w->side; forked = true;
-            }
-            WfmBackArgs back;
-            back.alpha = w->alpha; back.last_in = w->d_last[w->flip]; back.last_out = w->d_last[w->flip ^ 1]; back.seg_state = w->d_seg_state;
-            back.s16 = audio_s16; back.af = audio_f; back.out_pitch = out_pitch; back.skip = (int)(w->next_j % 32); back.done = false;
-            rc = wfm_mfma_launch(st, se, e0, e1, in, in_pitch, w->d_hist, w->mfma, w->d_ctab, w->d_demod, w->demod_pitch, w->n_streams, T, w->B, w->next_j, n_audio, &back);
-            if (rc) return rc;
-            back_done = back.done;
-            w->kernel_name = wfm_mfma_last_kernel();
-            if (forked) {
-                if (T >= HIST) { hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, se, in, in_pitch, T, w->d_hist); CSDR_LAUNCH_CHECK(); hist_saved = true; }
-                CSDR_HIP(hipEventRecord(w->ev_join, se));
-                CSDR_HIP(hipStreamWaitEvent(st, w->ev_join, 0));
-            }
-        } else {
+        e0 = w->ev_pool[w->ev_used].first; e1 = w->ev_pool[w->ev_used].second; w->ev_used++;
+    }
+    if (w->use_mfma) {
+        // the whole chain, the carried de-emphasis state and the next call's history in ONE launch (wfm_mfma.hip)
+        WfmBackArgs back;
+        back.alpha = w->alpha; back.last_in = w->d_last[w->flip]; back.last_out = w->d_last[w->flip ^ 1];
+        back.s16 = audio_s16; back.af = audio_f; back.out_pitch = out_pitch; back.head_in = w->d_head[w->hflip]; back.head_out = w->d_head[w->hflip ^ 1];
+        rc = wfm_mfma_launch(st, e0, e1, in, in_pitch, w->mfma, ctab_call, w->n_streams, T, w->B, w->next_j, n_audio, back);
+        if (rc) return rc;
+        w->hflip ^= 1;
+        if (n_audio > 0) w->flip ^= 1;
+    } else {
+        if ((size_t)n_audio + 40 > w->demod_pitch) return fail_msg(-3, "wfm: internal audio buffer too small");
+        if (n_audio > 0) {
+            WfmParams p; p.D = w->D; p.L = w->L; p.F = w->F; p.T = T; p.B = w->B; p.j_first = w->next_j; p.n_audio = n_audio;
+            const int span = w->D * (w->F * (TILE_A - 1) + 1) + w->L + 16;          // samples per tile window (+alignment slack)
+            const size_t lds = (size_t)((span + 7) / 8 * 8 + 2 * TILE_A) * sizeof(float2) + 64;
+            if (lds > 64 * 1024) { const int arc = lds_attr_once((const void *)k_wfm_front, lds); if (arc) return arc; }
             if (e0) CSDR_HIP(hipEventRecord(e0, st));
             hipLaunchKernelGGL(k_wfm_front, dim3(w->n_streams, cdiv(n_audio, TILE_A)), dim3(256), lds, st,
                                in, in_pitch, w->d_hist, w->d_rot, w->d_taps, w->d_demod, w->demod_pitch, p);
             CSDR_LAUNCH_CHECK();
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
-        }
-        if (!back_done) {                                                  // (the sequential front end does the back end itself)
             hipLaunchKernelGGL(k_wfm_back, dim3(cdiv(n_audio, BK_CHUNK), w->n_streams), dim3(256), 0, st,
-                               w->d_demod, w->demod_pitch, w->use_mfma ? (int)(w->next_j % 32) : 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
+                               w->d_demod, w->demod_pitch, 0, n_audio, w->alpha, w->d_last[w->flip], w->d_last[w->flip ^ 1], audio_s16, audio_f, out_pitch);
+            CSDR_LAUNCH_CHECK();
+            w->flip ^= 1;
+        }
+        // 3. history for the next block
+        if (T >= HIST) {
+            hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, st, in, in_pitch, T, w->d_hist);
             CSDR_LAUNCH_CHECK();
         }
-        w->flip ^= 1;
-    }
-    // 3. history for the next block (already done on the side stream when that path ran)
-    if (T >= HIST && !hist_saved) {
-        hipLaunchKernelGGL(k_wfm_save_hist, dim3(w->n_streams), dim3(256), 0, st, in, in_pitch, T, w->d_hist);
-        CSDR_LAUNCH_CHECK();
     }
     if (T % 1024) w->ended = true;
     w->B += T; w->next_j += n_audio; w->last_T = T;

@@ -418,7 +418,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
 /* the chain's front end object (kernel name / profiling: csdr_amd_ddc_kernel_name, csdr_amd_ddc_set_profiling, csdr_amd_ddc_kernel_time) */
 csdr_amd_ddc *csdr_amd_nfm_front_end(csdr_amd_nfm *w);
 
-/* Test hook: one tile of the SEQUENTIAL WFM kernel (phase-independent weight set, post factors, chunk-boundary handling) on the CPU.
+/* Test hook: one tile of the WFM chain kernel (k_wfm_mfma_seq: phase-independent weight set, post factors, chunk-boundary handling) on the CPU.
  * n0: window base sample (multiple of 8); window: 512 raw bytes; ctab2: (cos, sin) of chunks n0>>10, +1; out16: 16 rows. */
 int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const float *taps, long long n0, const uint8_t *window,
                                 const float *ctab2, float *out16);
@@ -430,15 +430,6 @@ void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse);
 /* Test hook: one tile (16 outputs from 256 limited samples) of the NFM chain's matrix-core de-emphasis FIR on the CPU: digit planes,
  * Toeplitz digit table and accumulator classes as k_nfm_deemph_mfma combines them. */
 int csdr_amd_debug_nfm_deemph_tile(int audio_rate, float max_amp, const float *x, float *out16);
-/* Test hook: front-end kernel of the following csdr_amd_wfm_process calls: -1 = default (the first whose preconditions hold of:) 0 = sequential
- * (k_wfm_mfma_seq), 1 = octet (k_wfm_mfma_oct), 2 = quad (k_wfm_mfma_wg), 3 = per-wave (k_wfm_mfma). */
-void csdr_amd_debug_wfm_select(int kernel);
-/* Test hook: CPU evaluation of one matrix-core tile with the kernel's own weight table and layout (no GPU needed);
- * out16 must hold 32 floats (16 results + scratch).  See csdr_amd/csrc/wfm_mfma.hip. */
-int csdr_amd_debug_wfm_mfma_tile(int D, int L, int F, float shift_rate, const float *taps, int phase, const uint8_t *window,
-                                 const float *C0, const float *C1, float *out16, int *n_phases, int *straddle,
-                                 int *tile_stride_bytes, int *win_off_bytes);
-
 #ifdef __cplusplus
 }
 #endif

@@ -106,30 +106,53 @@ def test_wfm_stream_counts(gpu, port, n_streams):
         assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
 
 
-@pytest.mark.parametrize("pitch_pad,block,select,kernel", [
-    (0, None, -1, "k_wfm_mfma_seq"), (0, 16384 * 5, -1, "k_wfm_mfma_seq"), (0, None, 1, "k_wfm_mfma_oct"), (0, 16384 * 5, 1, "k_wfm_mfma_oct"),
-    (16, None, -1, "k_wfm_mfma_wg"), (16, 16384 * 5, -1, "k_wfm_mfma_wg"), (0, None, 2, "k_wfm_mfma_wg"), (0, 16384 * 5, 3, "k_wfm_mfma")])
-def test_wfm_workgroup_kernels(gpu, port, pitch_pad, block, select, kernel):
-    """All front-end kernels on the same input: the sequential kernel (one weight set, time-contiguous walk; needs base and pitch to be
-    multiples of 128 bytes), the octet kernel (same precondition), the quad kernel (any 16-byte-aligned pitch) and the per-wave kernel, in one
-    call and in blocks whose audio start is not octet aligned; 19 streams = one full and one ragged 16-stream block."""
+@pytest.mark.parametrize("pitch_pad,block", [(0, None), (0, 16384 * 5), (16, None), (16, 16384 * 5), (48, 1024 * 7), (112, 1024 * 33), (0, 1024 * 3)])
+def test_wfm_chain_kernel_pitches_and_blocks(gpu, port, pitch_pad, block):
+    """The ONE chain kernel (k_wfm_mfma_seq) on the same input with row pitches that are / are not multiples of 128 bytes (any 16-byte-aligned pitch is
+    taken: round 2 needed the quad kernel for those), in one call and in blocks whose audio start is not a multiple of 4 (partial tiles at both ends of
+    every call, windows that start in the previous block's history, calls shorter than one segment); 19 streams = one full and one ragged 16-stream block."""
     from tests_helpers import wfm_signal_u8
     taps = port.firdes_lowpass_f(79, 0.05)
-    n = 16384 * 15                                  # three blocks of 16384*5, each long enough for the workgroup kernels
+    n = 16384 * 15
     base = [wfm_signal_u8(300 + s, n) for s in range(3)]
     u8 = np.stack([base[s % 3] for s in range(19)])
-    gpu.L.csdr_amd_debug_wfm_select(select)
-    try:
-        s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=block, pitch_pad=pitch_pad)
-    finally:
-        gpu.L.csdr_amd_debug_wfm_select(-1)
-    assert gpu.last_wfm_kernel == kernel
+    s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=block, pitch_pad=pitch_pad)
+    assert gpu.last_wfm_kernel == "k_wfm_mfma_seq"
     want = [port.wfm_chain(b, -0.085, 10, taps) for b in base]
     for s in (0, 1, 2, 15, 16, 18):
         ps, pf = want[s % 3]
         m = min(pf.size, af.shape[1])
         assert m >= n // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL
         assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
+def test_wfm_ragged_last_block(gpu, port):
+    """a stream whose last block is not a multiple of 1024 samples (it ends the stream): the fetch is masked at the row's last 16-byte piece"""
+    from tests_helpers import wfm_signal_u8
+    taps = port.firdes_lowpass_f(79, 0.05)
+    for n in (16384 * 4 + 1000, 16384 * 4 + 8, 16384 * 2 + 777):
+        u8 = np.stack([wfm_signal_u8(40 + s, n) for s in range(3)])
+        s16, af = gpu.wfm_chain(u8, -0.085, 10, taps, block=16384)
+        for s in range(3):
+            ps, pf = port.wfm_chain(u8[s], -0.085, 10, taps)
+            m = min(pf.size, af.shape[1])
+            assert m >= n // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL
+            assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
+@pytest.mark.parametrize("D,F,L", [(8, 6, 63), (10, 4, 79), (12, 5, 47), (6, 8, 95)])
+def test_wfm_other_decimations(gpu, port, D, F, L):
+    """tile strides other than the benchmark's 400 bytes (8 D F): the ring and the weight set are built for any supported (D, F, taps)"""
+    from tests_helpers import wfm_signal_u8
+    taps = port.firdes_lowpass_f(L, 0.5 / D)
+    n = 16384 * 6
+    u8 = np.stack([wfm_signal_u8(60 + s, n) for s in range(2)])
+    s16, af = gpu.wfm_chain(u8, -0.085, D, taps, frac_rate=F, block=16384 * 2)
+    assert gpu.last_wfm_kernel == "k_wfm_mfma_seq"
+    for s in range(2):
+        ps, pf = port.wfm_chain(u8[s], -0.085, D, taps, frac_rate=F)
+        m = min(pf.size, af.shape[1])
+        assert m >= n // (D * F) - 8 and relrms(af[s, :m], pf[:m]) <= TOL
 
 
 @pytest.mark.parametrize("rate", [0.25, 0.05, -0.3141])
