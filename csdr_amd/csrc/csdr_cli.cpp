@@ -659,8 +659,11 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
     // After EOF the pass is repeated (a few times at most) while some stage still consumes input: an operator that works through its input in
     // windows (fractional_decimator_ff) leaves a tail shorter than its window, which only the next call takes as the end of the stream.
     int extra_passes = 0, rc = 0;
-    for (bool eof = false, again = true; again;) {
-        if (!eof) {
+    bool failed = false;
+    for (bool eof = false, again = true; again && !failed;) {
+        // a new input buffer only when the first operator cannot take a whole block from what it already holds: an operator that leaves a tail per pass
+        // (fir_decimate_cc, fractional_decimator_ff, deemphasis_nfm_ff) otherwise let the carry grow by that tail every pass while full blocks kept arriving
+        if (!eof && L[0].have_b < block * first->in_elem) {
             HostBuf *b = io.full_in.pop();
             eof = b->eof;
             Link &l0 = L[0];
@@ -690,7 +693,7 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
                 // producer writes to an aligned staging buffer and the result is appended behind the carry by a device copy
                 dst = (nx.have_b % 16 == 0) ? nx.d_in[nx.cur] + nx.have_b : nx.d_stage;
                 dst_cap = (nx.cap_b - nx.have_b) / s->out_elem;
-                if (nx.have_b % s->out_elem) { fprintf(stderr, "csdr chain: element sizes of \"%s\" and its consumer do not line up\n", g_cmd); return 1; }
+                if (nx.have_b % s->out_elem) { fprintf(stderr, "csdr chain: element sizes of \"%s\" and its consumer do not line up\n", g_cmd); failed = true; break; }
             }
             size_t consumed = 0;
             n_out = n_in ? s->process(c, d_src, n_in, dst, dst_cap, &consumed) : 0;
@@ -699,7 +702,7 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
                 Link &lk = L[k];
                 if (consumed * s->in_elem > lk.have_b) consumed = lk.have_b / s->in_elem;
                 if (k == 0 && consumed == 0 && lk.have_b >= block * s->in_elem && !eof) {
-                    fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); return 1; }
+                    fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); failed = true; break; }
                 const size_t rest_b = lk.have_b - consumed * s->in_elem;
                 if (consumed) {
                     if (rest_b) MUST(csdr_amd_d2d(c, lk.d_in[lk.cur ^ 1], lk.d_in[lk.cur] + consumed * s->in_elem, rest_b));
@@ -714,10 +717,11 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             if (!(eof && stages[k + 1]->flush_partial)) n_in -= n_in % stages[k + 1]->granule;
             d_src = nx.d_in[nx.cur];
         }
+        if (failed) break;
         if (n_out > 0) {
             HostBuf *ob = io.free_out.pop();
             ob->bytes = (size_t)n_out * last->out_elem;
-            if (ob->bytes > ob->cap) { fprintf(stderr, "csdr %s: output block larger than its staging buffer\n", g_cmd); return 1; }
+            if (ob->bytes > ob->cap) { fprintf(stderr, "csdr %s: output block larger than its staging buffer\n", g_cmd); io.free_out.push(ob); failed = true; break; }
             if (hipMemcpyAsync(ob->p, d_out, ob->bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(ob->ev, st) != hipSuccess) die("download");
             ob->pending = true;
             // d_out is reused by the next pass: the download is ordered before the next kernels on the same stream
@@ -727,8 +731,11 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
         for (size_t k = 0; k < n_st; k++) if (L[k].have_b) leftover = true;
         again = !eof || (progressed && leftover && extra_passes++ < 4);
     }
+    // every exit goes through here: what was queued for the writer is written before the process ends
+    if (failed) rc = 1;
     hout[NBUF].eof = true; io.full_out.push(&hout[NBUF]);
     pthread_join(th_w, nullptr);
+    (void)hipStreamSynchronize(st);
     return rc;
 }
 

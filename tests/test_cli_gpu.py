@@ -80,6 +80,28 @@ def test_cli_fir_decimate_refeed(port):
         assert relrms(got, want) <= TOL
 
 
+def test_cli_long_streams_small_blocks(port):
+    """Millions of samples through operators that leave an unconsumed tail every pass (csdr.c:1114-1177, 1511-1524), input arriving in full blocks: the
+    carry in front of the first operator must stay bounded (round 2 took a new buffer every pass and died with 'block too small' after ~225 k samples at
+    block 4096 / 81 taps, ~5 M samples at block 65536 / 801 taps)."""
+    rng = np.random.default_rng(44)
+    x = crand(rng, 2_500_000)
+    taps = port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.5 / 10)
+    got = np.frombuffer(run(["fir_decimate_cc", 10, 0.05, "HAMMING"], x, 4096), c64)
+    want = port.fir_decimate_cc(x, 10, taps)
+    assert got.size == want.size and relrms(got, want) <= TOL
+    x2 = crand(rng, 6_000_000)
+    taps50 = port.firdes_lowpass_f(port.firdes_filter_len(0.005), 0.5 / 50)
+    got = np.frombuffer(run(["fir_decimate_cc", 50, 0.005, "HAMMING"], x2, 65536), c64)
+    want = port.fir_decimate_cc(x2, 50, taps50)
+    assert got.size == want.size and relrms(got, want) <= TOL
+    a = rng.uniform(-1, 1, 2_200_000).astype(f32)
+    got = np.frombuffer(run(["fractional_decimator_ff", 5], a, 4096), f32)
+    want = port.fractional_decimator_ff(a, 5.0)
+    m = min(got.size, want.size)
+    assert abs(got.size - want.size) <= 1 and relrms(got[:m], want[:m]) <= TOL
+
+
 def test_cli_fm_audio_stages(port):
     rng = np.random.default_rng(5)
     x = crand(rng, 40000)
