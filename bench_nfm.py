@@ -60,6 +60,14 @@ def main():
     pitch = 2 * T
     g = torch.Generator(device="cuda"); g.manual_seed(5000 + rank)
     x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda", generator=g)
+    strict_rows = []
+    if args.verify and rank == 0 and not args.front_end_only:
+        # rows held to +-1 LSB on every sample: a real narrow-band FM signal in a few rows spread over the batch, put there BEFORE the timed loop
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from tests_helpers import nfm_signal_u8
+        strict_rows = sorted({r for r in (5, S // 3 + 1, (2 * S) // 3 + 2, S - 2) if 0 <= r < S})
+        for k, r in enumerate(strict_rows):
+            x[r, :2 * T] = torch.from_numpy(nfm_signal_u8(7100 + k, T, offset=0.05)).cuda()
     n_out_max = (T // D + 2048 + 63) // 64 * 64
     out_s16 = torch.empty((S, n_out_max), dtype=torch.int16, device="cuda")
     out_y = torch.empty((S, n_out_max, 2), dtype=torch.float32, device="cuda") if args.front_end_only else None
@@ -134,7 +142,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import verify_configs as vc
             L.csdr_amd_ddc_set_profiling(fe, 0)
-            res["verify"] = vc.verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max)
+            res["verify"] = vc.verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, rows=[r for r in vc.pick_rows(S) if r not in strict_rows], strict_rows=strict_rows)
         if world == 1 and not args.no_cpu_baseline and not args.front_end_only:
             res["cpu_baseline"] = bc.cpu_baseline("nfm", unit="complex MS/s", single_amount=100.0, probe_amount=4.0, target_wall_s=8.0,
                                                   describe="config 5 NFM chain (README.md:87), one 2.4 MS/s u8 IQ channel per thread, in process with the CLI's block framing")

@@ -250,13 +250,17 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
         const bool head = F < 0;                                                     // wave uniform: the run [-1024, 0)
         const uint8_t *sbase = head ? hblock : sblock + F;
         const uint32_t ldst = lds_in_addr + (SPW * wv) * SEQ_RP + (uint32_t)fslot;
-        const bool live = head || !ragged || F + 16 * lane < p.two_T;                // ragged end: the row's last 16-byte piece is the last one fetched
+        const bool mask = ragged && !head;                                           // wave uniform; ragged end: the row's last 16-byte piece is the last one fetched
+        const bool live = !mask || F + 16 * lane < p.two_T;
 #pragma unroll
         for (int r = 0; r < SPW; r++) {
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * SEQ_RP));
             const uint32_t vo = head ? voff_h[r] : voff[r];
             uint32_t keep;
-            if (live)
+            if (!mask)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(la) : "memory");
+            else if (live)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(la) : "memory");
         }
@@ -302,14 +306,17 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
     if (iir_wave && blockIdx.y == 0) {                                               // first segment: the exact carried state (NaN reset as libcsdr.c:1092)
         yst = p.last_in[min(s0 + col, last_stream)]; if (yst != yst) yst = 0.f;
     }
+    // the segment's audio samples, counted from its first tile's first sample (ints: this bookkeeping runs every step, on wave 0 between two barriers)
     const long long j_end = p.j_first + p.n_audio;
+    const int seg_lo = (int)max(0LL, p.j_first - 4 * t0);                           // > 0 only in the call's first segment, when j_first is not a multiple of 4
+    const int seg_hi = (int)min(4LL * n_it, j_end - 4 * t0);                        // samples of the segment that exist in this call
+    const long long idx0 = 4 * t0 - p.j_first;                                      // output index of the segment's sample 0
     auto emit = [&](int g) {                                                         // convert_f_s16 + store of step g's 16 x 32 samples, one per thread
         if (g < 0) return;
-        const int srow = tid / SPS, k = tid % SPS;
-        const long long j = 4 * (t0 + (long long)g * TPG) + k;
-        if (tid < 16 * SPS && j >= p.j_first && j < j_end && (k >> 2) < n_it - g * TPG && s0 + srow < p.n_streams) {
+        const int srow = tid / SPS, k = tid % SPS, kr = g * SPS + k;
+        if (tid < 16 * SPS && kr >= seg_lo && kr < seg_hi && s0 + srow < p.n_streams) {
             const float e = lds_out[(g % 3) * (16 * SEQ_OUTP) + srow * SEQ_OUTP + k];
-            const long long idx = j - p.j_first;
+            const long long idx = idx0 + kr;
             const float scaled = e * 32767.0f;                                       // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
             const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
             p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)iv;
@@ -378,9 +385,8 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
         if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
         emit(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
         if (iir_wave) {                                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
-            const long long jg = 4 * (t0 + (long long)gi * TPG);                     // the step's first audio index
-            const int lo = (int)max(0LL, min((long long)SPS, p.j_first - jg));       // samples [lo, hi) of the step exist in this call (warm-up steps: all)
-            const int hi = (int)max(0LL, min((long long)min(SPS, 4 * (n_it - gi * TPG)), j_end - jg));
+            const int lo = gi == 0 ? seg_lo : 0;                                     // samples [lo, hi) of the step exist in this call (warm-up steps: all)
+            const int hi = gi < 0 ? SPS : min(SPS, seg_hi - gi * SPS);
             if (lo == 0 && (hi & 3) == 0) {
                 float *row = lout + col * SEQ_OUTP + QL * q;                         // this lane's quarter: samples QL q .. QL q + QL - 1
                 const int nv = hi;                                                   // valid samples of the step (a multiple of 4 here; all except in a segment's last step)

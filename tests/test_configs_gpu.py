@@ -303,6 +303,90 @@ def test_c5_nfm_at_512_channels(gpu):
     assert res["ok"], res
 
 
+def _replicated(signals, S, T):
+    """x[s] = signals[(s + s // 16) % 16]: every stream of the batch carries one of 16 signals, and every signal visits every column of a 16-stream group"""
+    import torch
+    base = torch.from_numpy(np.stack(signals)).cuda()
+    idx = (torch.arange(S, device="cuda") + torch.arange(S, device="cuda") // 16) % 16
+    return base[idx].contiguous(), idx.cpu().numpy()
+
+
+def test_c2_wfm_every_stream_block_and_segment(gpu, port):
+    """bench.py's timed shape, 100 % of it: all 1024 streams x 2 400 256 samples carry one of 16 FM signals.  Every replica of a signal must be BIT-identical
+    (the 64 stream blocks x 4 time segments of the launch, every column of the matrix product), and the 16 distinct rows are held to +-1 LSB against the
+    oracle on every one of their 48 001 samples -- together: every sample of every stream, at the cost of 16 oracle rows."""
+    import torch
+    S, T = 1024, 2344 * 1024
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.05), 0.5 / 10, "HAMMING")
+    sigs = [wfm_signal_u8(2100 + k, T) for k in range(16)]
+    x, idx = _replicated(sigs, S, T)
+    n_audio_max = (T // 50 + 64 + 63) // 64 * 64
+    out = torch.zeros((S, n_audio_max), dtype=torch.int16, device="cuda")
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+    assert w, gpu.err()
+    try:
+        n = L.csdr_amd_wfm_process(w, x.data_ptr(), 2 * T, T, out.data_ptr(), None, n_audio_max)
+        assert n >= 48000, gpu.err()
+        gpu.sync()
+        assert L.csdr_amd_wfm_kernel_name(w).decode() == "k_wfm_mfma_seq"
+    finally:
+        L.csdr_amd_wfm_destroy(w)
+    first = {int(k): int(np.nonzero(idx == k)[0][0]) for k in range(16)}
+    ref_rows = out[torch.tensor([first[int(k)] for k in idx], device="cuda")]
+    assert torch.equal(out[:, :n], ref_rows[:, :n]), "replicas of one signal differ between stream blocks / columns"
+    for k in range(16):
+        ps, _ = port.wfm_chain(sigs[k], -0.085, 10, taps)
+        got = out[first[k], :n].cpu().numpy()
+        m = min(ps.size, got.size)
+        assert 0 <= n - ps.size <= 2 and vc.s16_diff(got[:m], ps[:m]).max() <= 1, "signal %d" % k
+
+
+def test_c5_nfm_every_channel(gpu, port):
+    """bench_nfm.py's timed shape, all of it: 512 channels x 2 400 256 samples carry one of 16 narrow-band FM signals; replicas bit-identical, the 16
+    distinct rows +-1 LSB against the oracle's stage-by-stage chain on every sample."""
+    import torch
+    S, T, D = 512, 2344 * 1024, 50
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.005), 0.5 / D, "HAMMING")
+    sigs = [nfm_signal_u8(3100 + k, T, offset=0.05) for k in range(16)]
+    x, idx = _replicated(sigs, S, T)
+    n_out_max = (T // D + 2048 + 63) // 64 * 64
+    out = torch.zeros((S, n_out_max), dtype=torch.int16, device="cuda")
+    obj = L.csdr_amd_nfm_create(gpu.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
+    assert obj, gpu.err()
+    try:
+        n = L.csdr_amd_nfm_process(obj, x.data_ptr(), 2 * T, T, out.data_ptr(), None, n_out_max)
+        assert n > 0, gpu.err()
+        gpu.sync()
+    finally:
+        L.csdr_amd_nfm_destroy(obj)
+    first = {int(k): int(np.nonzero(idx == k)[0][0]) for k in range(16)}
+    ref_rows = out[torch.tensor([first[int(k)] for k in idx], device="cuda")]
+    assert torch.equal(out[:, :n], ref_rows[:, :n]), "replicas of one signal differ between channel blocks / columns"
+    nfm_taps = gpu.nfm_taps(48000)
+    for k in range(16):
+        ps, _ = port.nfm_chain(sigs[k], -0.05, nfm_taps, D, 0.005, 1024)
+        got = out[first[k], :n].cpu().numpy()
+        assert n == ps.size and vc.s16_diff(got, ps).max() <= 1, "signal %d" % k
+
+
+def test_c4_bank_at_the_timed_size(gpu, port):
+    """bench_fastddc.py's timed call: the bank object, 256 channels x 64 blocks in ONE process() (the fold kernel with the second forward pass inside, two
+    32-block accumulator tiles, chain riders) -- 40 channels spread over every 32-channel wave tile against the oracle"""
+    tbw, D, nch, nb = 0.001, 256, 256, 64
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(64)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = vc.c4_rates(nch)
+    check = sorted(set(list(range(0, 256, 8)) + [1, 31, 33, 127, 128, 129, 254, 255]))
+    _, want = vc.fastddc_oracle_channels(x, tbw, D, rates, check)
+    outs = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=nb)
+    assert gpu.last_ddc_kernel == "k_ddc_gemm3" and len(check) >= 36
+    for c in check:
+        assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < TOL, "channel %d" % c
+
+
 class _Plan(C.Structure):        # fft_fftw.h:14-20
     _fields_ = [("size", C.c_int), ("input", C.c_void_p), ("output", C.c_void_p), ("plan", C.c_void_p)]
 

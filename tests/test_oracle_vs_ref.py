@@ -253,11 +253,13 @@ def test_fastddc_geometry(port, ref):
             d.pre_decimation, d.post_decimation) == (65536, 8193, 57344, 512, 64, 448, 128, 2)
 
 
-@pytest.mark.parametrize("D,tbw,shift", [(16, 0.05, -0.1), (256, 0.005, 0.3 + 0.5 / 256), (6, 0.05, 0.2)])
+@pytest.mark.parametrize("D,tbw,shift", [(16, 0.05, -0.1), (256, 0.005, 0.3 + 0.5 / 256), (6, 0.05, 0.2),
+                                         # BASELINE config 4's exact geometry (fft 65536 / inverse 512), channels 0, 127, 255 of -0.5 + (c + 0.5) / 256
+                                         (256, 0.001, -0.5 + 0.5 / 256), (256, 0.001, -0.5 + 127.5 / 256), (256, 0.001, -0.5 + 255.5 / 256)])
 def test_fastddc_stream(port, ref, D, tbw, shift):
     rng = np.random.default_rng(4)
     da, _ = port.fastddc_init(tbw, D, shift); db, _ = ref.fastddc_init(tbw, D, shift)
-    x = crand(rng, da.input_size * 12)
+    x = crand(rng, da.input_size * (12 if da.fft_size < 65536 else 5))
     sa = port.fastddc_fwd_cc(x, da); sb = ref.fastddc_fwd_cc(x, db)
     assert relrms(sa, sb) < 1e-6
     ta = port.fastddc_taps_fft(da, shift, D); tb = ref.fastddc_taps_fft(db, shift, D)
