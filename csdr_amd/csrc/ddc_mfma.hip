@@ -245,6 +245,9 @@ struct DdcParams {
     long long k_out0;                 // output index stored at out[stream][0]
     int D, nk_used;                   // decimation; K-steps of the window that hold weights at all
     float scale;
+    int n_out;                        // outputs of this call: only k_out0 <= 8 tile + o < k_out0 + n_out are stored (the first / last tile of a call may be partial)
+    const uint8_t *hist_in;           // != nullptr: the tiles start in the previous blocks' tail (2 KiB per stream in front of the block: ring positions < 0)
+    long long two_T; uint8_t *hist_out;   // hist_out != nullptr: the last segment's workgroups keep the block's newest DDC_HIST samples for the next call (k_ddc_save_hist's work)
 };
 
 // One workgroup = 16 streams x the tiles [t0, t1) of its segment, walked in time order, NT tiles at a time: the workgroup has NT teams of
@@ -300,28 +303,44 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
     // ---- DMA state
     const int tstride = 16 * p.D;                                                    // bytes of input per tile
     long long wg = t0 * tstride - 2 * p.B;                                           // window start of the current GROUP's first tile, bytes from the block start
-    const long long F0 = wg & ~1023LL;
-    const long long F_end = ((t1 - 1) * tstride - 2 * p.B + DDC_WIN + 1023) & ~1023LL;
+    const long long F0 = wg & ~1023LL;                                               // (floor: a call's first tiles start in the history, at negative positions)
+    long long F_end = ((t1 - 1) * tstride - 2 * p.B + DDC_WIN + 1023) & ~1023LL;
+    if (p.hist_in && F_end > p.two_T) F_end = p.two_T;                               // a partial last tile's window reaches beyond the block: those bytes feed no stored output
     long long F = F0;                                                                // next row-step
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
-    uint32_t voff[SPW];
+    uint32_t voff[SPW], voff_h[SPW];
 #pragma unroll
     for (int r = 0; r < SPW; r++) {
-        const int srow = min(sb * 16 + SPW * wv + r, last_stream) - sb * 16;         // rows past the last stream re-read it (results discarded)
-        voff[r] = (uint32_t)max(srow, 0) * (uint32_t)in_pitch + 16u * lane;
+        const int srow = max(min(sb * 16 + SPW * wv + r, last_stream) - sb * 16, 0); // rows past the last stream re-read it (results discarded)
+        voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
+        voff_h[r] = (uint32_t)srow * (uint32_t)(2 * DDC_HIST) + 16u * lane;
     }
     const uint8_t *sblock = in + (long long)sb * 16 * (long long)in_pitch;
     auto row_step = [&]() {
-        const uint8_t *sbase = sblock + F;
+        // F < 0: a run of the history (2 KiB per stream = positions [-2048, 0); a window may start up to 7 D samples in front of that: those bytes feed only
+        // outputs the previous call has already delivered -- any readable address will do)
+        const bool head = F < 0;                                                     // wave uniform; two straight-line copies (a select between the two offset arrays sent them to scratch)
         const uint32_t ldst = lds_in_addr + (SPW * wv) * RP + (uint32_t)(F & (RB - 1));
+        // nt: the input is read exactly once.  Inline asm with hand-counted vmcnt (see wfm_mfma.hip: the builtin form makes the
+        // compiler serialise the DMA with the LDS reads of the other ring positions).
+        if (head) {
+            const uint8_t *sbase = p.hist_in + (size_t)sb * 16 * (2 * DDC_HIST) + (F < -2 * DDC_HIST ? 0 : F + 2 * DDC_HIST);
 #pragma unroll
-        for (int r = 0; r < SPW; r++) {
-            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
-            uint32_t keep;
-            // nt: the input is read exactly once.  Inline asm with hand-counted vmcnt (see wfm_mfma.hip: the builtin form makes the
-            // compiler serialise the DMA with the LDS reads of the other ring positions).
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff[r]), "s"(sbase), "s"(la) : "memory");
+            for (int r = 0; r < SPW; r++) {
+                const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff_h[r]), "s"(sbase), "s"(la) : "memory");
+            }
+        } else {
+            const uint8_t *sbase = sblock + F;
+#pragma unroll
+            for (int r = 0; r < SPW; r++) {
+                const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff[r]), "s"(sbase), "s"(la) : "memory");
+            }
         }
         F += 1024;
     };
@@ -349,10 +368,10 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
     wait_for(wg + (long long)(NT - 1) * tstride);
     __syncthreads();
     const uint8_t *lrow = lds_in + col * RP;
+    const int kk_seg = (int)(8 * t0 - p.k_out0);                                     // output index of the segment's first tile's first output (< 0: a partial first tile)
     for (int gi = 0; gi < n_grp; gi++, wg += (long long)NT * tstride) {
         const int it = gi * NT + team;                                               // this team's tile of the group
         const bool active = it < n_it;
-        const long long ti = t0 + it;
         const long long ws = wg + (long long)team * tstride;                         // window start of this team's tile
 #if DDC_DIAG == 1
         float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
@@ -362,7 +381,8 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
             const long long n0 = p.B + (ws >> 1);                                    // global index of the tile's first sample
             const WaveGeom g = ddc_wave_geom(n0, w);
             const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
-            const long long chunk_rel = g.chunk - (p.B >> 10);
+            const int chunk_rel = (int)(g.chunk - (p.B >> 10));                      // -1: the previous block's last chunk (history); -2: in front of it (feeds only outputs that are not stored)
+            const int ci0 = max(chunk_rel + 1, 0);                                   // table row of side 0
             // ---- B fragments of this wave's K-range from the ring
             const int base = (int)(ws & (RB - 1)) + 64 * DDC_NKW * w + 16 * q;
             v4i Bf[DDC_NKW];
@@ -384,11 +404,11 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                 default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
             }
             // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
-            float2 P0 = cmulf(ctab[chunk_rel + 1], dtab[g.e0 + 2048]);
+            float2 P0 = cmulf(ctab[ci0], dtab[g.e0 + 2048]);
             // optional per-chunk correction (rates for which the reference's float recurrence drifts away from C_m D^k): sampled at the
             // centre of the K-range's part in each chunk
             const int off = (int)((n0 + 32LL * DDC_NKW * w) & 1023);
-            if (corr) P0 = cmulf(P0, corr[(chunk_rel + 1) * 32 + ((off + (g.two ? (1024 - off) / 2 : 16 * DDC_NKW)) >> 5)]);
+            if (corr) P0 = cmulf(P0, corr[ci0 * 32 + ((off + (g.two ? (1024 - off) / 2 : 16 * DDC_NKW)) >> 5)]);
             float u[4];
             if (g.two) {
                 const float4 cb = *reinterpret_cast<const float4 *>(lcum + g.gb * 16 + 4 * q);
@@ -428,10 +448,13 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
             const int stream = sb * 16 + col;
             const float2 y0 = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
             const float2 y1 = make_float2((a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+            const int kk = kk_seg + 8 * it + 2 * q;                                  // index of y0 in the call's outputs; the first / last tile of a call may be partial
+            const bool ok0 = (unsigned)kk < (unsigned)p.n_out, ok1 = (unsigned)(kk + 1) < (unsigned)p.n_out;
             if (!FUSE) {
                 if (stream < p.n_streams) {
-                    float2 *dst = out + (size_t)stream * out_pitch + (8 * ti - p.k_out0) + 2 * q;
-                    dst[0] = y0; dst[1] = y1;
+                    float2 *dst = out + (size_t)stream * out_pitch + kk;
+                    if (ok0) dst[0] = y0;
+                    if (ok1) dst[1] = y1;
                 }
             } else {
                 // predecessor of output 2q: lane (col, q - 1)'s second output; for q = 0 the previous tile's last output
@@ -445,20 +468,32 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                 }
                 if (team == NT - 1 && q == 3) ylast[(gi & 1) * 16 + col] = y1;
                 if (stream < p.n_streams) {
-                    const long kk = (long)(8 * ti - p.k_out0) + 2 * q;
                     float2 *ydst = out + (size_t)stream * out_pitch + kk;
-                    if (it == 0 && q == 0) ydst[0] = y0;                             // the segment's first sample (k_nfm_demod_boundary demodulates it) ...
-                    if (it == n_it - 1 && q == 3) ydst[1] = y1;                      // ... and its last one (the next segment's / the trailing outputs' predecessor)
+                    // complex samples k_nfm_demod_boundary needs: the call's first output and every segment's first one (their predecessors live elsewhere), the segments'
+                    // last ones (the next segment's predecessor) and the call's last one (the next call's)
+                    const bool seg_first = it == 0 && q == 0, seg_last = it == n_it - 1 && q == 3;
+                    if (ok0 && (seg_first || kk == 0 || kk == p.n_out - 1)) ydst[0] = y0;
+                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == p.n_out - 1)) ydst[1] = y1;
                     int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
                     int dg[3];
-                    if (!(it == 0 && q == 0)) {
+                    if (ok0 && !seg_first && kk != 0) {
                         nfm_demod_digits(y0, prev, fz.max_amp, fz.q_per_amp, dg);
                         pd0[0] = (int8_t)dg[0]; pd0[fz.plane_bytes] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes] = (int8_t)dg[2];
                     }
-                    nfm_demod_digits(y1, y0, fz.max_amp, fz.q_per_amp, dg);
-                    pd0[1] = (int8_t)dg[0]; pd0[fz.plane_bytes + 1] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes + 1] = (int8_t)dg[2];
+                    if (ok1 && kk + 1 != 0) {
+                        nfm_demod_digits(y1, y0, fz.max_amp, fz.q_per_amp, dg);
+                        pd0[1] = (int8_t)dg[0]; pd0[fz.plane_bytes + 1] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes + 1] = (int8_t)dg[2];
+                    }
                 }
             }
+        }
+    }
+    if (p.hist_out && blockIdx.y + 1 == gridDim.y) {                                 // 16 streams x 2 KiB: the next call's history
+        for (int i = tid; i < 16 * (2 * DDC_HIST / 16); i += 256 * NT) {
+            const int srow = i / (2 * DDC_HIST / 16), piece = i % (2 * DDC_HIST / 16);
+            if (sb * 16 + srow < p.n_streams)
+                *reinterpret_cast<uint4 *>(p.hist_out + (size_t)(sb * 16 + srow) * (2 * DDC_HIST) + 16 * piece) =
+                    *reinterpret_cast<const uint4 *>(sblock + (size_t)srow * in_pitch + (p.two_T - 2 * DDC_HIST) + 16 * piece);
         }
     }
 }
@@ -525,8 +560,9 @@ struct csdr_amd_ddc {
     float *d_taps; uint8_t *d_hist[2]; int hflip;
     void *d_frags; float *d_cum; float2 *d_dtab, *d_ctab, *d_corr; size_t ctab_cap; bool need_corr;
     float scale; int nk_used;
-    bool use_mfma, ended;
+    bool use_mfma, ended, whole_off;
     float phase; float2 c_prev;
+    long long tab_first; bool tab_valid;      // the device tables of chunk seeds (and drift corrections) cover chunks [tab_first, tab_first + ctab_cap)
     long long B, next_k;
     std::string kernel_name;
     bool profiling; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used; double prof_ms; long prof_launches;
@@ -544,7 +580,7 @@ csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     d->ctx = ctx; d->n_streams = n_streams; d->D = decimation; d->L = taps_length; d->shift_rate = shift_rate; d->max_block = max_block_samples;
     d->d_taps = nullptr; d->d_hist[0] = d->d_hist[1] = nullptr; d->d_frags = nullptr; d->d_cum = nullptr; d->d_dtab = nullptr; d->d_ctab = nullptr; d->d_corr = nullptr;
     d->profiling = false; d->ev_used = 0; d->prof_ms = 0; d->prof_launches = 0;
-    d->ctab_cap = max_block_samples / 1024 + 8;
+    d->ctab_cap = 16 * (max_block_samples / 1024 + 8);                 // seeds for 16 calls of the largest block ahead (see ddc_process_fused)
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&d->d_taps, sizeof(float) * taps_length);
@@ -560,6 +596,7 @@ csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (e == hipSuccess) e = hipMemcpy(d->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     const char *force = getenv("CSDR_AMD_DDC_PATH");                  // "direct" forces the plain kernel (A/B comparisons)
     d->use_mfma = ddc_mfma_supported(decimation, taps_length) && !(force && !strcmp(force, "direct"));
+    d->whole_off = getenv("CSDR_AMD_DDC_WHOLE") && atoi(getenv("CSDR_AMD_DDC_WHOLE")) == 0;      // A/B: interior tiles only, the edges on k_ddc_direct (round 2's split)
     d->scale = 0; d->nk_used = 0;
     if (d->use_mfma) {
         DdcTable t;
@@ -592,7 +629,7 @@ void csdr_amd_ddc_destroy(csdr_amd_ddc *d)
 
 int csdr_amd_ddc_reset(csdr_amd_ddc *d)
 {
-    d->phase = 0.f; d->c_prev = make_float2(1.f, 0.f); d->B = 0; d->next_k = 0; d->ended = false; d->hflip = 0;
+    d->phase = 0.f; d->c_prev = make_float2(1.f, 0.f); d->B = 0; d->next_k = 0; d->ended = false; d->hflip = 0; d->tab_valid = false; d->tab_first = 0;
     CSDR_HIP(hipMemsetAsync(d->d_hist[0], 0x80, (size_t)2 * DDC_HIST * d->n_streams, d->ctx->stream));
     CSDR_HIP(hipMemsetAsync(d->d_hist[1], 0x80, (size_t)2 * DDC_HIST * d->n_streams, d->ctx->stream));
     return 0;
@@ -639,31 +676,46 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
     if (in_pitch < 2 * block_samples && d->n_streams > 1) return fail_msg(-3, "ddc: in_pitch smaller than the block");
     const int T = (int)block_samples;
     // 1. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping (libcsdr_gpl.c:33-34, 48-51;
-    //    chunks of 1024 per csdr.c:911-918).  ctab[0] belongs to the previous block's last chunk.
+    //    chunks of 1024 per csdr.c:911-918), and -- for rates whose recurrence drifts -- the per-chunk corrections.  Both depend on nothing but the shift
+    //    rate: the device holds TABLES that run 16 calls ahead of the stream, a call passes an offset (round 2: an upload and a 21-us k_ddc_corr in front of
+    //    every call's kernel).  Entry k = chunk tab_first + k; a call needs the chunk in front of its block (history) up to two behind it.
     const size_t nch = ((size_t)T + 1023) / 1024;
     if (nch + 3 > d->ctab_cap) return fail_msg(-3, "ddc: chunk table too small");
-    float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * (nch + 3));
-    if (!hc) return -2;
-    {
-        const float inc = (d->shift_rate * 2) * PI_F;
+    const long long first = d->B / 1024 - 1;
+    const float inc = (d->shift_rate * 2) * PI_F;
+    int rc = 0;
+    if (!d->tab_valid || first < d->tab_first || first + (long long)nch + 3 > d->tab_first + (long long)d->ctab_cap) {
+        float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * d->ctab_cap);
+        if (!hc) return -2;
         float ph = d->phase;
         hc[0] = d->c_prev;
-        for (size_t m = 0; m <= nch + 1; m++) {
-            hc[1 + m] = make_float2((float)cos((double)ph), (float)sin((double)ph));
-            if (m + 1 == nch) d->c_prev = hc[1 + m];
-            const int len = (m < nch && (size_t)T - m * 1024 < 1024) ? (int)((size_t)T - m * 1024) : 1024;
+        for (size_t k = 1; k < d->ctab_cap; k++) {
+            hc[k] = make_float2((float)cos((double)ph), (float)sin((double)ph));
+            float nx = ph + inc * (float)1024;
+            while (nx > PI_F) nx -= 2 * PI_F;
+            while (nx < -PI_F) nx += 2 * PI_F;
+            ph = nx;
+        }
+        rc = c->pinned_upload(d->d_ctab, sizeof(float2) * d->ctab_cap); if (rc) return rc;
+        if (d->need_corr) {
+            hipLaunchKernelGGL(k_ddc_corr, dim3(cdiv(d->ctab_cap, 64)), dim3(64), 0, st, d->d_ctab, d->d_dtab, d->d_corr, (int)d->ctab_cap, (float)cos((double)inc), (float)sin((double)inc));
+            CSDR_LAUNCH_CHECK();
+        }
+        d->tab_first = first; d->tab_valid = true;
+    }
+    const float2 *ctab = d->d_ctab + (first - d->tab_first);
+    const float2 *corr = d->need_corr ? d->d_corr + (first - d->tab_first) * 32 : nullptr;
+    {   // the stream's phase behind this block (and the seed of its last chunk, for a table rebuilt at the next call)
+        float ph = d->phase;
+        for (size_t m = 0; m < nch; m++) {
+            if (m + 1 == nch) d->c_prev = make_float2((float)cos((double)ph), (float)sin((double)ph));
+            const int len = ((size_t)T - m * 1024 < 1024) ? (int)((size_t)T - m * 1024) : 1024;
             float nx = ph + inc * (float)len;
             while (nx > PI_F) nx -= 2 * PI_F;
             while (nx < -PI_F) nx += 2 * PI_F;
-            if (m + 1 == nch) d->phase = nx;
             ph = nx;
         }
-    }
-    int rc = c->pinned_upload(d->d_ctab, sizeof(float2) * (nch + 3)); if (rc) return rc;
-    if (d->need_corr) {
-        const float inc = (d->shift_rate * 2) * PI_F;
-        hipLaunchKernelGGL(k_ddc_corr, dim3(cdiv(nch + 2, 64)), dim3(64), 0, st, d->d_ctab, d->d_dtab, d->d_corr, (int)(nch + 2), (float)cos((double)inc), (float)sin((double)inc));
-        CSDR_LAUNCH_CHECK();
+        d->phase = ph;
     }
     // 2. outputs that become computable with this block: y[k] needs input up to D k + L - 1
     const long long avail_last = d->B + T - 1;
@@ -671,6 +723,7 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
     if (avail_last - (d->L - 1) >= 0) k_hi = (avail_last - (d->L - 1)) / d->D;
     const long long n_out_ll = k_hi - d->next_k + 1;
     const long n_out = n_out_ll > 0 ? (long)n_out_ll : 0;
+    bool hist_saved = false;
     if (n_out > 0) {
         if ((size_t)n_out > out_pitch && d->n_streams > 1) return fail_msg(-3, "ddc: out_pitch %zu smaller than the %ld outputs of this block", out_pitch, n_out);
         const long long k_first = d->next_k;
@@ -682,16 +735,25 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
         // whole tiles (8 outputs) whose window lies inside this block, fetched as 1-KiB runs of whole lines
         long long ta = 0, tb = -1;
         const long long tstride = 16LL * d->D;
+        bool whole = false;                                           // the matrix-core kernel takes the whole call (history head, partial tiles): no k_ddc_direct
         if (d->use_mfma && (((uintptr_t)in | in_pitch) & 127) == 0 && in_pitch * 16 + 4096 < ((size_t)1 << 32)) {
-            ta = (k_first + 7) / 8; tb = (k_hi + 1) / 8 - 1;
-            while (ta <= tb && ta * tstride - 2 * d->B < 0) ta++;
-            while (tb >= ta && ((tb * tstride - 2 * d->B + DDC_WIN + 1023) & ~1023LL) > 2LL * T) tb--;
-            if (tb - ta + 1 < 4) { ta = 0; tb = -1; }
+            if ((T & 511) == 0 && T >= 2 * DDC_HIST && !d->whole_off) {
+                ta = k_first / 8; tb = k_hi / 8; whole = true;           // (a window starts at most 7 D + L - 1 samples in front of the block: inside the 3 head runs)
+                if (tb - ta + 1 < 4 || ta * tstride - 2 * d->B < -3072) { ta = 0; tb = -1; whole = false; }
+            } else {
+                // a ragged / very short block (it ends the stream): whole tiles whose window lies inside this block, fetched as 1-KiB runs of whole lines; the rest below
+                ta = (k_first + 7) / 8; tb = (k_hi + 1) / 8 - 1;
+                while (ta <= tb && ta * tstride - 2 * d->B < 0) ta++;
+                while (tb >= ta && ((tb * tstride - 2 * d->B + DDC_WIN + 1023) & ~1023LL) > 2LL * T) tb--;
+                if (tb - ta + 1 < 4) { ta = 0; tb = -1; }
+            }
         }
         const int n_cu = current_device_cu_count();
         if (tb >= ta) {
             DdcParams p;
             p.n_streams = d->n_streams; p.B = d->B; p.tile_first = ta; p.n_tiles = (int)(tb - ta + 1); p.k_out0 = k_first; p.D = d->D; p.nk_used = d->nk_used; p.scale = d->scale;
+            p.two_T = 2LL * T; p.hist_out = (T >= DDC_HIST && (T & 7) == 0) ? d->d_hist[d->hflip ^ 1] : nullptr; hist_saved = p.hist_out != nullptr;
+            p.n_out = (int)n_out; p.hist_in = whole ? d->d_hist[d->hflip] : nullptr;
             const int n_wsb = (d->n_streams + 15) / 16;
             // 8 KiB ring per stream (window 2304 B + the next group's bytes + 1-KiB fetch granularity on both sides need > 4 KiB), one workgroup per CU.
             // Two teams (512 threads, two waves per SIMD) when the ring also holds a second tile per group: 3 * 16 D <= 3842.
@@ -709,15 +771,16 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
 #define DDC_LAUNCH(NTV, FV, THREADS) do {                                                                                                                  \
                 const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV>, lds); if (arc) return arc;                                              \
                 if (e0) CSDR_HIP(hipEventRecord(e0, st));                                                                                                      \
-                hipLaunchKernelGGL((k_ddc_mfma<rbl, NTV, FV>), dim3(n_wsb, n_seg), dim3(THREADS), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, d->d_ctab, \
-                                   d->d_corr, reinterpret_cast<float2 *>(out), out_pitch, p, fz); } while (0)
+                hipLaunchKernelGGL((k_ddc_mfma<rbl, NTV, FV>), dim3(n_wsb, n_seg), dim3(THREADS), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, ctab, \
+                                   corr, reinterpret_cast<float2 *>(out), out_pitch, p, fz); } while (0)
             if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, 512); else DDC_LAUNCH(1, true, 256); }
             else      { if (nt == 2) DDC_LAUNCH(2, false, 512); else DDC_LAUNCH(1, false, 256); }
 #undef DDC_LAUNCH
             CSDR_LAUNCH_CHECK();
             if (fuse && info) {
-                info->fused = true; info->n_lead = (long)(8 * ta - k_first); info->seg_outputs = 8L * p.tiles_per_seg; info->n_seg = n_seg;
-                info->trail_first = (long)(8 * (tb + 1) - k_first); info->n_trail = (long)(k_hi - 8 * (tb + 1) + 1);
+                info->fused = true; info->seg_outputs = 8L * p.tiles_per_seg; info->n_seg = n_seg; info->seg_first = (long)(8 * ta - k_first);
+                if (whole) { info->n_lead = 8 * ta < k_first ? 1 : 0; info->trail_first = n_out; info->n_trail = 0; }      // lead = the call's first output when its tile is partial
+                else { info->n_lead = (long)(8 * ta - k_first); info->trail_first = (long)(8 * (tb + 1) - k_first); info->n_trail = (long)(k_hi - 8 * (tb + 1) + 1); }
             }
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
             d->kernel_name = "k_ddc_mfma";
@@ -725,18 +788,19 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
         // everything else: leading outputs (history), trailing outputs of the last partial tile, or the whole block
         DirectParams q;
         q.n_streams = d->n_streams; q.B = d->B; q.T = T; q.D = d->D; q.L = d->L; q.k_out0 = k_first;
-        if (tb >= ta) { q.ka0 = k_first; q.na = (int)(8 * ta - k_first); q.kb0 = 8 * (tb + 1); q.nb = (int)(k_hi - q.kb0 + 1); }
+        if (whole) { q.ka0 = k_first; q.na = 0; q.kb0 = 0; q.nb = 0; }
+        else if (tb >= ta) { q.ka0 = k_first; q.na = (int)(8 * ta - k_first); q.kb0 = 8 * (tb + 1); q.nb = (int)(k_hi - q.kb0 + 1); }
         else { q.ka0 = k_first; q.na = (int)n_out; q.kb0 = 0; q.nb = 0; }
         if (q.na + q.nb > 0) {
             if (tb < ta && e0) CSDR_HIP(hipEventRecord(e0, st));
-            hipLaunchKernelGGL(k_ddc_direct, dim3(cdiv(q.na + q.nb, 4), d->n_streams), dim3(256), 0, st, in, in_pitch, d->d_hist[d->hflip], d->d_taps, d->d_dtab, d->d_ctab, d->d_corr,
+            hipLaunchKernelGGL(k_ddc_direct, dim3(cdiv(q.na + q.nb, 4), d->n_streams), dim3(256), 0, st, in, in_pitch, d->d_hist[d->hflip], d->d_taps, d->d_dtab, ctab, corr,
                                reinterpret_cast<float2 *>(out), out_pitch, q);
             CSDR_LAUNCH_CHECK();
             if (tb < ta && e1) CSDR_HIP(hipEventRecord(e1, st));
         }
     }
-    // 3. history for the next block
-    hipLaunchKernelGGL(k_ddc_save_hist, dim3(d->n_streams), dim3(256), 0, st, in, in_pitch, T, d->d_hist[d->hflip], d->d_hist[d->hflip ^ 1]);
+    // 3. history for the next block (the matrix-core kernel's last segment has done it when it ran on a whole block)
+    if (!hist_saved) hipLaunchKernelGGL(k_ddc_save_hist, dim3(d->n_streams), dim3(256), 0, st, in, in_pitch, T, d->d_hist[d->hflip], d->d_hist[d->hflip ^ 1]);
     CSDR_LAUNCH_CHECK();
     d->hflip ^= 1;
     if (T % 1024) d->ended = true;

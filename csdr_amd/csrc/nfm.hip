@@ -43,13 +43,15 @@ __global__ __launch_bounds__(256) void k_nfm_demod_limit(const cf32 *__restrict_
 
 // The same for the outputs the fused front end left over (DdcFuseInfo): the leading outputs [0, n_lead) (plain kernel), the first output of every segment of the
 // matrix-core kernel (its predecessor belongs to another workgroup) and the trailing outputs; y holds these samples and their predecessors.
-__global__ __launch_bounds__(64) void k_nfm_demod_boundary(const cf32 *__restrict__ y, size_t y_pitch, const cf32 *__restrict__ last, DdcFuseInfo info,
-                                                           DdcFuse f)
+// Thread 0 of a stream also keeps the call's last sample as the next call's predecessor (two `last` buffers: k_nfm_store_last's work).
+__global__ __launch_bounds__(64) void k_nfm_demod_boundary(const cf32 *__restrict__ y, size_t y_pitch, const cf32 *__restrict__ last, cf32 *__restrict__ last_out, int n_y,
+                                                           DdcFuseInfo info, DdcFuse f)
 {
     const int s = blockIdx.y, j = blockIdx.x * 64 + threadIdx.x;
+    if (j == 0) last_out[s] = y[(size_t)s * y_pitch + n_y - 1];
     long k;
     if (j < info.n_lead) k = j;
-    else if (j < info.n_lead + info.n_seg) k = info.n_lead + (long)(j - info.n_lead) * info.seg_outputs;
+    else if (j < info.n_lead + info.n_seg) { k = info.seg_first + (long)(j - info.n_lead) * info.seg_outputs; if (k < info.n_lead) return; }      // (a partial first tile: the lead covers output 0)
     else if (j < info.n_lead + info.n_seg + info.n_trail) k = info.trail_first + (j - info.n_lead - info.n_seg);
     else return;
     const cf32 *src = y + (size_t)s * y_pitch;
@@ -191,7 +193,7 @@ struct csdr_amd_nfm {
     int n_streams, D, Ld, agc_block, cli_prefix;
     float limit, agc_ref;
     csdr_amd_ddc *ddc;
-    cf32 *d_y; size_t y_pitch; cf32 *d_last;
+    cf32 *d_y; size_t y_pitch; cf32 *d_last, *d_last2; int lflip;
     int8_t *d_planes; size_t plane_bytes; size_t dl_pitch; int dl_fill;   // limited demodulator output (three digit planes) waiting for the de-emphasis filter
     void *d_fir_frags; float fir_scale;             // de-emphasis taps as int8 digit fragments; scale of the recombined product
     float *d_de; size_t a_pitch;                    // de-emphasised blocks
@@ -227,6 +229,7 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&w->d_y, sizeof(cf32) * w->y_pitch * n_streams);
     alloc((void **)&w->d_last, sizeof(cf32) * n_streams);
+    alloc((void **)&w->d_last2, sizeof(cf32) * n_streams);
     w->plane_bytes = w->dl_pitch * n_streams;
     alloc((void **)&w->d_planes, 3 * w->plane_bytes);
     alloc(&w->d_fir_frags, (size_t)NFM_FIR_NK * 3 * 64 * 16);
@@ -247,7 +250,7 @@ void csdr_amd_nfm_destroy(csdr_amd_nfm *w)
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
     if (w->ddc) csdr_amd_ddc_destroy(w->ddc);
-    (void)hipFree(w->d_y); (void)hipFree(w->d_last); (void)hipFree(w->d_planes); (void)hipFree(w->d_fir_frags); (void)hipFree(w->d_de);
+    (void)hipFree(w->d_y); (void)hipFree(w->d_last); (void)hipFree(w->d_last2); (void)hipFree(w->d_planes); (void)hipFree(w->d_fir_frags); (void)hipFree(w->d_de);
     (void)hipFree(w->d_agc_state);
     delete w;
 }
@@ -258,6 +261,7 @@ int csdr_amd_nfm_reset(csdr_amd_nfm *w)
     w->dl_fill = w->cli_prefix;                                                                                // zeros (the planes are cleared below): see csdr_amd_nfm_create
     CSDR_HIP(hipMemsetAsync(w->d_planes, 0, 3 * w->plane_bytes, st));                                          // bytes behind the valid samples meet zero weights, but must be initialised
     CSDR_HIP(hipMemsetAsync(w->d_last, 0, sizeof(cf32) * w->n_streams, st));                                   // the CLI starts fmdemod from (0, 0) (csdr.c:1044)
+    CSDR_HIP(hipMemsetAsync(w->d_last2, 0, sizeof(cf32) * w->n_streams, st)); w->lflip = 0;
     CSDR_HIP(hipMemsetAsync(w->d_agc_state, 0, sizeof(float) * (size_t)w->n_streams * (2 * w->agc_block + 4), st));   // calloc'ed fastagc state (csdr.c:1393-1394)
     return csdr_amd_ddc_reset(w->ddc);
 }
@@ -277,16 +281,19 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
     if (n_y < 0) return n_y;
     if (n_y == 0) return 0;
     if ((size_t)n_y > w->max_y) return fail_msg(-3, "nfm: front end produced more than the planned %zu samples", w->max_y);
+    cf32 *last_in = w->lflip ? w->d_last2 : w->d_last, *last_out = w->lflip ? w->d_last : w->d_last2;
     if (fi.fused) {
         const long nb_out = fi.n_lead + fi.n_seg + fi.n_trail;
-        hipLaunchKernelGGL(k_nfm_demod_boundary, dim3(cdiv(nb_out, 64), S), dim3(64), 0, st, w->d_y, w->y_pitch, w->d_last, fi, fz);
+        hipLaunchKernelGGL(k_nfm_demod_boundary, dim3(cdiv(nb_out > 0 ? nb_out : 1, 64), S), dim3(64), 0, st, w->d_y, w->y_pitch, last_in, last_out, (int)n_y, fi, fz);
+        CSDR_LAUNCH_CHECK();
     } else {
         // fmdemod_quadri_cf | limit_ff, appended behind the filter's unconsumed input
-        hipLaunchKernelGGL(k_nfm_demod_limit, dim3(cdiv(n_y, 256), S), dim3(256), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, w->d_planes, w->plane_bytes, w->dl_pitch, w->dl_fill, w->limit, NFM_XQ / w->limit);
+        hipLaunchKernelGGL(k_nfm_demod_limit, dim3(cdiv(n_y, 256), S), dim3(256), 0, st, w->d_y, w->y_pitch, (int)n_y, last_in, w->d_planes, w->plane_bytes, w->dl_pitch, w->dl_fill, w->limit, NFM_XQ / w->limit);
+        CSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_nfm_store_last, dim3(cdiv(S, 64)), dim3(64), 0, st, w->d_y, w->y_pitch, (int)n_y, last_out, S);
+        CSDR_LAUNCH_CHECK();
     }
-    CSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_nfm_store_last, dim3(cdiv(S, 64)), dim3(64), 0, st, w->d_y, w->y_pitch, (int)n_y, w->d_last, S);
-    CSDR_LAUNCH_CHECK();
+    w->lflip ^= 1;
     const int n_in = w->dl_fill + (int)n_y;
     // deemphasis_nfm_ff produces input - taps outputs (libcsdr.c:1121); run it for whole AGC blocks only
     const int ne_all = n_in - w->Ld;

@@ -10,7 +10,7 @@ namespace csdr_amd {
 // where the fused front end puts the limited demodulator output: planes [3][n_streams][dl_pitch] int8, sample k of the call at offset dl_fill + k
 struct DdcFuse { int8_t *planes; size_t plane_bytes, dl_pitch; int dl_fill; float max_amp, q_per_amp; };
 // which outputs of a call the fused kernel could NOT demodulate itself (their predecessor was computed by another workgroup or kernel); y holds them
-struct DdcFuseInfo { bool fused; long n_lead, seg_outputs, n_seg, trail_first, n_trail; };
+struct DdcFuseInfo { bool fused; long n_lead, seg_first, seg_outputs, n_seg, trail_first, n_trail; };      // seg_first: output index of segment 0's first sample (may be < 0: a partial first tile)
 
 // x = y[k], p = y[k - 1] (libcsdr.c:1040-1071, :1130-1137); round(v / max_amp * NFM_XQ) = D0 * 65536 + D1 * 256 + D2 with Dj = (int8_t)d[j]
 __device__ __forceinline__ void nfm_demod_digits(float2 x, float2 p, float max_amp, float q_per_amp, int (&d)[3])
