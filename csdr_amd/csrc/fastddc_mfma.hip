@@ -58,6 +58,8 @@ struct DdcMfma {
     hipStream_t side; hipEvent_t ev_ready[2], ev_free[2], ev_fork; bool free_recorded[2];
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
+    // A/B switches, read ONCE when the object is created: a call never looks at the environment
+    struct Opt { bool fwd_off, riders_off, spec_off, pass2_own, ifft_full, ifft16; int chains_side, fwd_cols, gemm; } opt;      // gemm: 0 default, 1 simple, 2 persist, 3 persist4
     // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
     bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -808,6 +810,16 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
     m->kmax = (post_in - 1) / post_dec + 1; m->rpitch = (m->kmax + ROT_CK - 1) / ROT_CK;      // checkpoints per chain
     m->input_size = input_size; m->overlap = overlap;
     m->comm = comm; m->rank = comm ? comm->rank : 0; m->world = comm ? comm->world : 1;
+    {
+        DdcMfma::Opt &o = m->opt;
+        o.fwd_off = getenv("CSDR_AMD_DDC_FWD_OFF") != nullptr;
+        o.riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr; o.spec_off = getenv("CSDR_AMD_DDC_SPEC_OFF") != nullptr;
+        o.pass2_own = getenv("CSDR_AMD_DDC_PASS2") != nullptr;
+        o.chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;
+        const char *fv = getenv("CSDR_AMD_DDC_FWD"); o.fwd_cols = (fv && atoi(fv) == 8) ? 8 : 16;
+        const char *iv = getenv("CSDR_AMD_DDC_IFFT"); o.ifft_full = iv && strstr(iv, "512"); o.ifft16 = iv && strstr(iv, "16");
+        const char *ge = getenv("CSDR_AMD_DDC_GEMM"); o.gemm = !ge ? 0 : !strcmp(ge, "simple") ? 1 : !strcmp(ge, "persist4") ? 3 : !strncmp(ge, "persist", 7) ? 2 : 0;
+    }
     m->nbl = m->world > 1 ? (max_blocks + m->world - 1) / m->world : m->nbp;
     const size_t xt_elems = (size_t)m->world * inv * m->nbl * pre;
     hipError_t e = hipMalloc((void **)&m->d_Ht, sizeof(float) * 2 * (size_t)m->Cpad * fft);
@@ -871,7 +883,7 @@ int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, 
     return 0;
 }
 
-bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->pre == 128 && !getenv("CSDR_AMD_DDC_FWD_OFF"); }
+bool ddc_mfma_can_forward(const DdcMfma *m) { return m && m->fft == 65536 && m->pre == 128 && !m->opt.fwd_off; }
 
 // chain tables + phasor checkpoints of one call into set k (data independent)
 static DdcChainJob mfma_chain_job(DdcMfma *m, int k, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom)
@@ -922,10 +934,10 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *
     DdcChainJob cj; memset(&cj, 0, sizeof cj);
     if (riders) cj = *riders;
     const size_t rider_lanes = riders ? (cj.mode == 2 ? (size_t)cj.n_channels * cj.n_blocks : (size_t)cj.n_channels) : 0;      // mode 2: one lane per (block, channel) chain
-    const char *fv = getenv("CSDR_AMD_DDC_FWD");                      // pass 1: 16 columns n2 per workgroup (128-byte runs); "8": 64-byte runs, more workgroups per CU
+    // pass 1: 16 columns n2 per workgroup (128-byte runs); CSDR_AMD_DDC_FWD=8: 64-byte runs, more workgroups per CU
 #define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
                      reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc, cj
-    if (fv && atoi(fv) == 8) {
+    if (m->opt.fwd_cols == 8) {
         const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
         hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc + (riders ? cdiv(rider_lanes, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
     } else {
@@ -956,9 +968,8 @@ static bool ddc_folds_with_gemm3(const DdcMfma *m, int n_blocks)
     const int per_res = (int)(cdiv(m->Cpad, 256) * cdiv(n_blocks, 32 * nbt));
     int slots = current_device_cu_count() / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
     bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
-    const char *e = getenv("CSDR_AMD_DDC_GEMM");
-    if (e) { if (!strcmp(e, "simple")) persist = false; else if (!strncmp(e, "persist", 7) && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true; }
-    return persist && m->pre == 128 && !(e && !strcmp(e, "persist4"));
+    if (m->opt.gemm == 1) persist = false; else if (m->opt.gemm >= 2 && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true;
+    return persist && m->pre == 128 && m->opt.gemm != 3;
 }
 
 // Stage one call: `in` = n_blocks x input_size NEW wideband samples (on rank 0 of a sharded bank; ignored elsewhere), or `spectra` = the natural
@@ -975,11 +986,10 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
     if (m->pending_blocks[k]) return fail_msg(-3, "fastddc: two calls are already staged; collect one first");
     hipStream_t mainst = m->ctx->stream;
     const bool inl = inline_call && m->world == 1 && !m->pending_blocks[k ^ 1];
-    const int chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
+    const int chains_side = m->opt.chains_side;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
     hipStream_t st = inl ? mainst : m->side;
     int rc = 0;
-    const bool riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr;
-    const bool spec_off = getenv("CSDR_AMD_DDC_SPEC_OFF") != nullptr;
+    const bool riders_off = m->opt.riders_off, spec_off = m->opt.spec_off;
     const bool fused_fwd = inl && !chains_side && !spectra && ddc_mfma_can_forward(m);
     // Chain tables one call ahead: the previous process() call's inverse-transform kernel carried riders that computed the tables of THIS call (set k) from the
     // state it ended with -- valid when this call has the size that was assumed and nothing retuned in between (ddc_mfma_quiesce).
@@ -1018,7 +1028,7 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
         if (m->world == 1) {
             DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
             if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }
-            const bool fuse2_off = getenv("CSDR_AMD_DDC_PASS2") != nullptr;       // set: k_ddc_fwd128 stays a kernel of its own
+            const bool fuse2_off = m->opt.pass2_own;                              // CSDR_AMD_DDC_PASS2: k_ddc_fwd128 stays a kernel of its own
             const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
             // ext_tail: the overlap in front of the first window comes from the caller (a time-sliced bank: the stream before this rank's run is another rank's)
             if (ext_tail) rc = mfma_forward(m, st, in, ext_tail, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
@@ -1096,7 +1106,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     const int per_res = (int)(grid.y * grid.z);
     int slots = n_cu / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
     bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
-    if (const char *e = getenv("CSDR_AMD_DDC_GEMM")) { if (!strcmp(e, "simple")) persist = false; else if (!strncmp(e, "persist", 7) && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true; }
+    if (m->opt.gemm == 1) persist = false; else if (m->opt.gemm >= 2 && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true;
     const size_t lds_use = persist ? 2 * lds : lds;
     const dim3 grid_use(persist ? (unsigned)slots : grid.x, grid.y, grid.z);
 #define DDC_GEMM_LAUNCH(NBTV, PV) do {                                                                                                               \
@@ -1104,9 +1114,8 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
         hipLaunchKernelGGL((k_ddc_gemm<NBTV, PV>), grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]),           \
                            reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); } while (0)
     // three-product form with LDS-DMA staging: pre_decimation 128 (a spectra row = one 1-KiB piece), persistent shape; CSDR_AMD_DDC_GEMM=persist4 keeps the four-product kernel
-    const char *ge = getenv("CSDR_AMD_DDC_GEMM");
     const bool three = ddc_folds_with_gemm3(m, n_blocks);
-    (void)ge; m->gemm_three = three;
+    m->gemm_three = three;
     if (three) {
         // the second pass of the forward transform inside the fold: one GPU, process() (pass 1's output Y belongs to this call), submit() skipped k_ddc_fwd128
         const bool fwd = m->y_holds[k];
@@ -1125,9 +1134,8 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     if (e1) CSDR_HIP(hipEventRecord(e1, st));
     // inverse transforms.  post_decimation 2 (every power-of-two decimation): half-size transforms of the aliased bins; CSDR_AMD_DDC_IFFT = 512 keeps
     // the full-size form, "16" whole 128-byte bin lines per workgroup (16 blocks) instead of half lines (8 blocks, more workgroups per CU)
-    const char *iv = getenv("CSDR_AMD_DDC_IFFT");
-    const bool full = m->post_dec != 2 || (iv && strstr(iv, "512"));
-    const bool nt16 = iv && strstr(iv, "16");
+    const bool full = m->post_dec != 2 || m->opt.ifft_full;
+    const bool nt16 = m->opt.ifft16;
     const int pairs = m->C * cdiv(n_blocks, 16);
     const dim3 g16(cdiv(n_blocks, 16), m->C), g8(cdiv(pairs, 8) * 16);
 #define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R[k], m->d_tw, m->d_blk_remain[k], m->d_blk_off[k], d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in

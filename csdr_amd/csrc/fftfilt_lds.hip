@@ -364,6 +364,7 @@ namespace csdr_amd {
 struct FftfiltLds {
     int n, taps_len, k1p, n_streams;
     float2 *d_hperm, *d_tw1, *d_tws, *d_hist[2]; int flip;
+    int mode;                                       // CSDR_AMD_FFTFILT_LDS_MODE (A/B: prefetch / residency variant of the 4096-point kernel), read at create
 };
 
 // window size for a filter of taps_len taps: the smallest plan that keeps >= 3/4 of every window as output; 0 = none fits (the caller keeps its other paths)
@@ -408,6 +409,7 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
 {
     FftfiltLds *p = new FftfiltLds();
     p->n = n; p->taps_len = taps_len; p->k1p = (taps_len - 1 + 15) & ~15; p->n_streams = n_streams; p->flip = 0;
+    p->mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
     p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = nullptr;
     hipError_t e = hipMalloc((void **)&p->d_hperm, sizeof(float2) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw1, sizeof(float2) * (n / 16));
@@ -450,7 +452,7 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     // Measured on one box (profiles/r2_notes.md): 4096-point windows run best with four resident workgroups per CU and no register prefetch (0.318 ms per
     // 64 x 16 blocks; three workgroups 0.346, prefetching variants 0.33-0.36); 8192-point windows with one 512-thread workgroup that prefetches the next window
     // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
-    const int mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
+    const int mode = p->mode;
     if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
         else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);

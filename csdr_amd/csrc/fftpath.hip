@@ -520,6 +520,7 @@ struct csdr_amd_fastddc_inv {
     ChanGeom *d_geom; DdcChanState *d_state;
     int *d_blk_remain, *d_blk_off, *d_counts; float *d_blk_phase;
     std::map<int, hipfftHandle> plans;
+    bool fold_old;                                                  // CSDR_AMD_DDC_FOLD_OLD (A/B: the untiled fold of the general path), read at create
 };
 
 extern "C" {
@@ -536,7 +537,7 @@ static csdr_amd_fastddc_inv *fastddc_inv_create_comm(csdr_amd_ctx *ctx, float tr
 {
     if (n_channels < 1 || max_blocks < 1) { fail_msg(-3, "fastddc_inv: bad sizes"); return nullptr; }
     csdr_amd_fastddc_inv *f = new csdr_amd_fastddc_inv();
-    f->ctx = ctx; f->n_channels = n_channels; f->max_blocks = max_blocks;
+    f->ctx = ctx; f->n_channels = n_channels; f->max_blocks = max_blocks; f->fold_old = getenv("CSDR_AMD_DDC_FOLD_OLD") != nullptr;
     f->tbw = transition_bw; f->decimation = decimation; f->window = window;
     f->geom.resize(n_channels);
     std::vector<ChanGeom> cg(n_channels);
@@ -669,7 +670,7 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
         CSDR_FFT(hipfftSetStream(h, st));
         f->plans[batch] = h;
     }
-    const bool ct_ok = f->n_channels >= 4 && pre >= 2 && (pre & (pre - 1)) == 0 && !getenv("CSDR_AMD_DDC_FOLD_OLD");
+    const bool ct_ok = f->n_channels >= 4 && pre >= 2 && (pre & (pre - 1)) == 0 && !f->fold_old;
     // tile choice measured on config 4 (256 channels, 64 blocks per call), GS/s of wideband input: <8,4> 8.6, <8,8> 7.1-7.2, <4,16> 5.0, <6,12> 3.5,
     // <16,4> 3.0, <2,16> 3.0, <16,8> 2.6, <16,2> 1.9, <32,2> 1.0 -- 8 channels share every spectrum value; the 64 accumulators of <8,4> leave room for
     // 4-5 waves per SIMD, which hides the load latency that <8,8> (2 waves per SIMD) exposes

@@ -342,12 +342,14 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     if (input_size < taps_length || n_streams <= 0) return 0;
     const int n_out = (input_size - taps_length) / decimation + 1;     // libcsdr.c:536-538 loop bound
     PolyCfg g;
-    if (!getenv("CSDR_AMD_FIR_GENERIC") && poly_cfg(decimation, taps_length, 8, g)) {
+    // (the FIR entry points are plain functions: their A/B switches are read once per process)
+    static const bool force_generic = getenv("CSDR_AMD_FIR_GENERIC") != nullptr, mfma_off = getenv("CSDR_AMD_FIR_MFMA_OFF") != nullptr;
+    if (!force_generic && poly_cfg(decimation, taps_length, 8, g)) {
         launch_poly<float2>(c, g, (const float2 *)in, (float2 *)out, n_out, n_streams, in_pitch, out_pitch, decimation, taps, taps_length);
         CSDR_LAUNCH_CHECK();
         return n_out;
     }
-    if (!getenv("CSDR_AMD_FIR_MFMA_OFF")) {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
+    if (!mfma_off) {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
         for (int nt = 8; nt >= 1; nt >>= 1) {
             const int W = (16 * nt - 1) * decimation + taps_length, steps = (15 * decimation + taps_length + 3) / 4;
             const size_t lds = sizeof(float) * (2 * (size_t)(W + 8) + 32 + 15 * (size_t)decimation + 4 * (size_t)steps + 4 + 1024);
@@ -385,7 +387,8 @@ int csdr_amd_fir_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams,
     const int n_out = input_size - taps_length;                         // libcsdr.c:1121: i < input_size - taps_length
     if (n_out <= 0 || n_streams <= 0) return 0;
     PolyCfg g;
-    if (!getenv("CSDR_AMD_FIR_GENERIC") && poly_cfg(1, taps_length, 4, g)) {
+    static const bool force_generic = getenv("CSDR_AMD_FIR_GENERIC") != nullptr;
+    if (!force_generic && poly_cfg(1, taps_length, 4, g)) {
         launch_poly<float>(c, g, in, out, n_out, n_streams, in_pitch, out_pitch, 1, taps, taps_length);
         CSDR_LAUNCH_CHECK();
         return n_out;

@@ -199,6 +199,7 @@ struct csdr_amd_nfm {
     float *d_de; size_t a_pitch;                    // de-emphasised blocks
     float *d_agc_state;
     size_t max_y;
+    bool fuse_off;                                  // CSDR_AMD_NFM_FUSE=0 (A/B: separate demodulator / AGC-peak passes), read when the object is created
 };
 
 extern "C" {
@@ -217,6 +218,7 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     w->ctx = ctx; w->n_streams = n_streams; w->D = decimation; w->Ld = Ld; w->agc_block = agc_block; w->limit = limit_max; w->agc_ref = agc_reference;
     w->ddc = csdr_amd_ddc_create(ctx, n_streams, shift_rate, decimation, host_taps, taps_length, max_block_samples);
     if (!w->ddc) { delete w; return nullptr; }
+    { const char *fe = getenv("CSDR_AMD_NFM_FUSE"); w->fuse_off = fe && atoi(fe) == 0; }
     w->max_y = max_block_samples / decimation + 2;
     w->y_pitch = (w->max_y + 15) & ~(size_t)15;
     // The reference's `csdr deemphasis_nfm_ff` runs its FIR over its freshly allocated buffer before it reads anything (csdr.c:1076-1081: `processed`
@@ -274,7 +276,7 @@ long csdr_amd_nfm_process(csdr_amd_nfm *w, const uint8_t *in, size_t in_pitch, s
     const int S = w->n_streams;
     // front end; on its matrix-core path the reducer epilogue demodulates, limits and writes the digit planes itself (the decimated complex stream never goes
     // to HBM: only the samples at workgroup / kernel boundaries do, for k_nfm_demod_boundary).  CSDR_AMD_NFM_FUSE=0: the separate pass over y.
-    const char *fe = getenv("CSDR_AMD_NFM_FUSE"); const bool fuse_off = fe && atoi(fe) == 0;      // read per call: the tests switch it inside one process
+    const bool fuse_off = w->fuse_off;
     DdcFuse fz; fz.planes = w->d_planes; fz.plane_bytes = w->plane_bytes; fz.dl_pitch = w->dl_pitch; fz.dl_fill = w->dl_fill; fz.max_amp = w->limit; fz.q_per_amp = NFM_XQ / w->limit;
     DdcFuseInfo fi; memset(&fi, 0, sizeof fi);
     const long n_y = ddc_process_fused(w->ddc, in, in_pitch, block_samples, w->d_y, w->y_pitch, fuse_off ? nullptr : &fz, &fi);
