@@ -460,6 +460,7 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
         else rc = ffl_launch<4096, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
     } else if (p->n == 8192) {
         if (mode == 2) rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+        else if (mode == 4) rc = ffl_launch<8192, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);      // (the second __launch_bounds__ argument is waves per SIMD: 4 = 128 registers = TWO workgroups per CU)
         else rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
     } else rc = ffl_launch<16384, false, 1, false>(p, st, in, in_pitch, m_new, out, out_pitch);
     if (rc) return rc;
