@@ -1,8 +1,12 @@
 // adpcm.hip -- IMA ADPCM codec: encode_ima_adpcm_i16_u8 / decode_ima_adpcm_u8_i16 (ima_adpcm.c:110-174) and the
 // waterfall compressor `csdr compress_fft_adpcm_f_u8` (csdr.c:1745-1768).  Integer, bit exact.
-// The codec is a strictly serial state machine (predictor + step index) per stream, so the parallel axis is the STREAM for the two codec calls
-// (one lane per stream) and the BLOCK for the waterfall compressor, whose encoder restarts from the zero state for every FFT row (one lane per row).
+// ENCODING is a strictly serial state machine (the code of a sample depends on the predictor the previous codes left): the parallel axis is the STREAM
+// (one lane per stream), and the BLOCK for the waterfall compressor, whose encoder restarts from the zero state for every FFT row (one lane per row).
+// DECODING is not serial: the step index is a chain of clamped adds of table values of the nibbles, the predictor a chain of clamped adds of
+// diff(step[index], nibble) (ima_adpcm.c:109-131).  Maps x -> clamp(x + a, lo, hi) compose into maps of the same form (exactly, in integers), so both chains
+// are parallel scans over time: k_adpcm_decode_scan, one workgroup per stream walking chunks of 8192 samples, 32 samples per lane.
 #include "common.hpp"
+#include <stdlib.h>
 using namespace csdr_amd;
 
 namespace {
@@ -60,6 +64,120 @@ __global__ void k_adpcm_decode(const uint8_t *__restrict__ in, int16_t *__restri
     for (size_t k = 0; k < n; k++) { const unsigned b = x[k]; y[2 * k] = (int16_t)dec_one(b & 0xf, st); y[2 * k + 1] = (int16_t)dec_one((b >> 4) & 0xf, st); }
     state_io[2 * s] = st.index; state_io[2 * s + 1] = st.prev;
 }
+// ---- decode as two scans.  A clamped add f(x) = min(max(x + a, lo), hi); (f2 o f1)(x) = clamp(x + a1 + a2, clamp(lo1 + a2, lo2, hi2), clamp(hi1 + a2, lo2, hi2)).
+struct CMap { int a, lo, hi; };
+__device__ __forceinline__ int cclamp(int x, int lo, int hi) { return min(max(x, lo), hi); }
+__device__ __forceinline__ CMap cmap_then(const CMap &f1, const CMap &f2) { return CMap{f1.a + f2.a, cclamp(f1.lo + f2.a, f2.lo, f2.hi), cclamp(f1.hi + f2.a, f2.lo, f2.hi)}; }
+__device__ __forceinline__ int cmap_apply(const CMap &f, int x) { return cclamp(x + f.a, f.lo, f.hi); }
+constexpr int CM_INF = 1 << 29;
+__device__ __forceinline__ CMap cmap_id() { return CMap{0, -CM_INF, CM_INF}; }
+__device__ __forceinline__ CMap cmap_shfl_up(const CMap &f, int d) { return CMap{__shfl_up(f.a, d, 64), __shfl_up(f.lo, d, 64), __shfl_up(f.hi, d, 64)}; }
+// exclusive prefix of the lanes' maps over the 256 threads of a workgroup (time order = thread order), and the workgroup's total
+__device__ __forceinline__ void cmap_scan256(CMap mine, CMap *wave_tot /* LDS [4] */, int tid, CMap &excl, CMap &total)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    CMap inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const CMap up = cmap_shfl_up(inc, d); if (lane >= d) inc = cmap_then(up, inc); }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    CMap before = cmap_id(); total = cmap_id();
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const CMap t = wave_tot[w]; if (w < wv) before = cmap_then(before, t); total = cmap_then(total, t); }
+    CMap ex = cmap_shfl_up(inc, 1); if (lane == 0) ex = cmap_id();
+    excl = cmap_then(before, ex);
+    __syncthreads();                                                // wave_tot is reused by the next scan
+}
+
+constexpr int DEC_S = 32;                                           // samples (16 input bytes, 64 output bytes) per lane and chunk
+__global__ __launch_bounds__(256) void k_adpcm_decode_scan(const uint8_t *__restrict__ in, int16_t *__restrict__ out, size_t n, size_t in_pitch, size_t out_pitch, int *__restrict__ state_io)
+{
+    // two look-up tables in LDS (divergent indices: not the scalar constant cache):
+    //   l_dn[index][code] = (signed difference << 8) | next index   -- one read per sample gives both (|difference| < 2^17)
+    //   l_pair[byte]      = the index map of the byte's TWO nibbles (low first), packed (a + 2) | lo << 8 | hi << 16: scan 1 composes per byte, not per sample
+    __shared__ int l_dn[89 * 16];
+    __shared__ int l_pair[256];
+    __shared__ CMap wave_tot[4];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < 89 * 16; k += 256) {
+        const int idx = k >> 4, step = c_step[idx], code = k & 15;
+        int d = step >> 3;
+        if (code & 1) d += step >> 2;
+        if (code & 2) d += step >> 1;
+        if (code & 4) d += step;
+        if (code & 8) d = -d;
+        const int nx = cclamp(idx + ((code & 4) ? 2 * (code & 3) + 2 : -1), 0, 88);
+        l_dn[k] = d * 256 + nx;
+    }
+    {
+        const int c0 = tid & 15, c1 = tid >> 4;
+        const CMap m = cmap_then(CMap{(c0 & 4) ? 2 * (c0 & 3) + 2 : -1, 0, 88}, CMap{(c1 & 4) ? 2 * (c1 & 3) + 2 : -1, 0, 88});
+        l_pair[tid] = (m.a + 2) | (m.lo << 8) | (m.hi << 16);
+    }
+    const uint8_t *x = in + (size_t)s * in_pitch; int16_t *y = out + (size_t)s * out_pitch;
+    int index0 = state_io[2 * s], prev0 = state_io[2 * s + 1];       // state at the chunk's first sample (same value in every thread)
+    const bool in_al = (((uintptr_t)x) & 7) == 0, out_al = (((uintptr_t)y) & 15) == 0;
+    __syncthreads();
+    for (size_t c0 = 0; c0 < n; c0 += 256 * (DEC_S / 2)) {          // c0: first input byte of the chunk
+        const size_t b0 = c0 + (size_t)tid * (DEC_S / 2);           // this lane's first byte
+        const int nb = b0 >= n ? 0 : (int)min((size_t)(DEC_S / 2), n - b0);      // valid bytes of this lane (0 .. 8)
+        unsigned long long bits[DEC_S / 16];
+#pragma unroll
+        for (int k = 0; k < DEC_S / 16; k++) bits[k] = 0;
+        if (nb == DEC_S / 2 && in_al) {
+#pragma unroll
+            for (int k = 0; k < DEC_S / 16; k++) bits[k] = reinterpret_cast<const unsigned long long *>(x + b0)[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < DEC_S / 2; k++) if (k < nb) bits[k / 8] |= (unsigned long long)x[b0 + k] << (8 * (k % 8));
+        }
+        const int ns = 2 * nb;                                       // valid samples: nibble j of `bits` = sample j (low nibble first, ima_adpcm.c:171-172)
+        // ---- scan 1: the step index.  index += {-1,-1,-1,-1,2,4,6,8}[code & 7], clamped to [0, 88]
+        CMap mi = cmap_id();
+#pragma unroll
+        for (int k = 0; k < DEC_S / 2; k++) {
+            const int e = l_pair[(unsigned)(bits[k / 8] >> (8 * (k % 8))) & 0xff];
+            if (k < nb) mi = cmap_then(mi, CMap{(e & 0xff) - 2, (e >> 8) & 0xff, e >> 16});
+        }
+        CMap ex, tot;
+        cmap_scan256(mi, wave_tot, tid, ex, tot);
+        int idx = cmap_apply(ex, index0);
+        index0 = cmap_apply(tot, index0);
+        // ---- the differences (they need the index in front of every sample), and scan 2: the predictor, clamped to int16
+        int diff[DEC_S];
+        CMap mp = cmap_id();
+#pragma unroll
+        for (int j = 0; j < DEC_S; j++) {
+            const unsigned code = (unsigned)(bits[j / 16] >> (4 * (j % 16))) & 0xf;
+            const int e = l_dn[idx * 16 + (int)code];
+            const int d = e >> 8;
+            diff[j] = d;
+            if (j < ns) { mp = cmap_then(mp, CMap{d, -32768, 32767}); idx = e & 0xff; }
+        }
+        cmap_scan256(mp, wave_tot, tid, ex, tot);
+        int pv = cmap_apply(ex, prev0);
+        prev0 = cmap_apply(tot, prev0);
+        // ---- outputs
+        int16_t o[DEC_S];
+#pragma unroll
+        for (int j = 0; j < DEC_S; j++) { pv = cclamp(pv + diff[j], -32768, 32767); o[j] = (int16_t)pv; }
+        int16_t *dst = y + 2 * b0;
+        if (ns == DEC_S && out_al) {
+#pragma unroll
+            for (int k = 0; k < DEC_S / 8; k++) {
+                uint4 v;
+                v.x = (uint16_t)o[8 * k] | ((unsigned)(uint16_t)o[8 * k + 1] << 16); v.y = (uint16_t)o[8 * k + 2] | ((unsigned)(uint16_t)o[8 * k + 3] << 16);
+                v.z = (uint16_t)o[8 * k + 4] | ((unsigned)(uint16_t)o[8 * k + 5] << 16); v.w = (uint16_t)o[8 * k + 6] | ((unsigned)(uint16_t)o[8 * k + 7] << 16);
+                reinterpret_cast<uint4 *>(dst)[k] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DEC_S; j++) if (j < ns) dst[j] = o[j];
+        }
+    }
+    if (tid == 0) { state_io[2 * s] = index0; state_io[2 * s + 1] = prev0; }
+}
+
 __device__ __forceinline__ int db_to_short(float v)
 {   // temp = input*100 stored to a short (csdr.c:1763): float product, truncation towards zero (x86 cvttss2si: 0x80000000 when out of range), low 16 bits
     const float p = v * 100;
@@ -92,7 +210,10 @@ int csdr_amd_encode_ima_adpcm_i16_u8(csdr_amd_ctx *c, const int16_t *in, uint8_t
 int csdr_amd_decode_ima_adpcm_u8_i16(csdr_amd_ctx *c, const uint8_t *in, int16_t *out, int n_streams, size_t n, size_t in_pitch, size_t out_pitch, int *state_io)
 {
     if (!n || n_streams <= 0) return 0;
-    hipLaunchKernelGGL(k_adpcm_decode, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, n, in_pitch, out_pitch, state_io);
+    // two parallel scans per stream (one workgroup per stream); CSDR_AMD_ADPCM_SERIAL (A/B, read once per process): one lane per stream
+    static const bool serial = getenv("CSDR_AMD_ADPCM_SERIAL") != nullptr;
+    if (serial) hipLaunchKernelGGL(k_adpcm_decode, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, n, in_pitch, out_pitch, state_io);
+    else hipLaunchKernelGGL(k_adpcm_decode_scan, dim3(n_streams), dim3(256), 0, c->stream, in, out, n, in_pitch, out_pitch, state_io);
     CSDR_LAUNCH_CHECK();
     return 0;
 }

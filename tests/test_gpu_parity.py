@@ -538,3 +538,34 @@ def test_f3_adpcm(gpu, port):
     fftrows = (rng.uniform(-120, 10, 37 * 2048) + 20 * np.sin(np.arange(37 * 2048) * 0.05)).astype(f32)
     fftrows[5] = 400.0; fftrows[6] = -400.0; fftrows[7] = 3e7
     assert np.array_equal(gpu.compress_fft_adpcm_f_u8(fftrows, 2048), port.compress_fft_adpcm_f_u8(fftrows, 2048))
+
+
+def test_adpcm_decode_scans_bit_exact(gpu, port):
+    """decode_ima_adpcm_u8_i16 as two parallel scans of clamped-add maps (adpcm.hip: k_adpcm_decode_scan) against the serial definition (ima_adpcm.c:109-131,
+    165-174), bit for bit: EVERY start index 0..88 with predictors at both rails and in between (one stream each), random codes and runs that pin the index /
+    the predictor at their clamps, lengths around the 4096-byte chunk and the 16-byte lane, several calls with the state carried, an unaligned row pitch."""
+    rng = np.random.default_rng(89)
+    starts = [(i, p) for i in range(89) for p in (-32768, -1234, 0, 32767)]
+    S = len(starts)
+    for n in (1, 7, 8, 9, 15, 16, 17, 4095, 4096, 4097, 9000, 3 * 4096 + 13):
+        x = rng.integers(0, 256, (S, n), dtype=np.uint8)
+        x[::3, : n // 2] = 0x77                                     # +7, +7, ...: index and predictor run into their upper clamps
+        x[1::3, : n // 3] = 0xff                                    # -7, -7, ...: the lower rail
+        st = np.array(starts, np.int32)
+        got, gs = gpu.decode_ima_adpcm_u8_i16(x, st, calls=1 if n < 100 else 3)
+        for s in range(0, S, 7):
+            want, ws = port.decode_ima_adpcm_u8_i16(x[s], tuple(int(v) for v in starts[s]))
+            assert np.array_equal(got[s], want), (n, s)
+            assert [int(v) for v in gs[s]] == [int(v) for v in ws], (n, s)
+    # an odd pitch (rows not 8-byte aligned): the byte-wise load path
+    L = gpu.L
+    n, S2 = 4099, 5
+    x = rng.integers(0, 256, (S2, n), dtype=np.uint8)
+    pitch_in, pitch_out = n + 3, 2 * n + 1
+    xi = np.zeros((S2, pitch_in), np.uint8); xi[:, :n] = x
+    di = gpu.upload(xi); do = gpu.alloc(2 * S2 * pitch_out + 64); ds = gpu.upload(np.zeros(2 * S2, np.int32))
+    import ctypes as C
+    gpu.check(L.csdr_amd_decode_ima_adpcm_u8_i16(gpu.h, di.ptr, do.ptr, S2, n, pitch_in, pitch_out, ds.ptr), "decode")
+    y = gpu.download(do, np.int16, S2 * pitch_out).reshape(S2, pitch_out)[:, :2 * n]
+    for s in range(S2):
+        assert np.array_equal(y[s], port.decode_ima_adpcm_u8_i16(x[s])[0])
