@@ -389,7 +389,7 @@ struct DdcChainJob {                                                 // one call
     int seg_nbl, seg_first, seg_total, seg_world; int *seg_pref;      // seg_pref[g][channel] = samples of the runs of ranks < g; row seg_world = the batch's total
 };
 // one block of decimating_shift_addition_cc's bookkeeping (libcsdr_gpl.c:153-158): samples produced, state advanced
-__device__ __forceinline__ int ddc_chain_step(DdcChanState &s, float r, int post_in, int post_dec, int sh)
+__host__ __device__ __forceinline__ int ddc_chain_step(DdcChanState &s, float r, int post_in, int post_dec, int sh)
 {
     int k = 0, pos = s.remain;
     if (pos < post_in) { k = (sh >= 0 ? (post_in - 1 - pos) >> sh : (post_in - 1 - pos) / post_dec) + 1; pos += k * post_dec; }
@@ -401,19 +401,22 @@ __device__ __forceinline__ int ddc_chain_step(DdcChanState &s, float r, int post
     return k;
 }
 // When post_input_size is a multiple of post_decimation (every power-of-two decimation: 448 / 2) and 0 <= remain < post_decimation, a block neither changes
-// `remain` nor the sample count k = post_in / post_dec, and the phase advances by the same float d = r PI k every block; for |d| < 6 the reference's two
-// while loops (libcsdr_gpl.c:156-157) run at most once, so a step is five dependent float operations -- the same values, bit for bit, as ddc_chain_step.
-struct DdcChainFast { bool ok; int k; float d; };
-__device__ __forceinline__ DdcChainFast ddc_chain_fast(const DdcChanState &s, float r, int post_in, int post_dec)
+// `remain` nor the sample count k = post_in / post_dec, and the phase advances by the same float d = r PI k every block; for |d| < 6 (channels near the bin
+// grid: config 4's have d = 0) the reference's two while loops (libcsdr_gpl.c:156-157) run at most once, so a step is five dependent float operations --
+// the same values, bit for bit, as ddc_chain_step (larger |d|: the loops themselves).
+struct DdcChainFast { bool ok, big; int k; float d; };
+__host__ __device__ __forceinline__ DdcChainFast ddc_chain_fast(const DdcChanState &s, float r, int post_in, int post_dec)
 {
     DdcChainFast f;
     f.k = post_in / post_dec; f.d = r * PI_F * (float)f.k;
-    f.ok = post_in % post_dec == 0 && s.remain >= 0 && s.remain < post_dec && fabsf(f.d) < 6.0f;
+    f.ok = post_in % post_dec == 0 && s.remain >= 0 && s.remain < post_dec;
+    f.big = !(fabsf(f.d) < 6.0f);                                    // a residual shift of a turn or more per block: the wraps may run more than once
     return f;
 }
-__device__ __forceinline__ float ddc_phase_step(float p, float d)
+__host__ __device__ __forceinline__ float ddc_phase_step(float p, float d, bool big = false)
 {
     p = p + d;
+    if (big) { while (p > PI_F) p -= 2 * PI_F; while (p < -PI_F) p += 2 * PI_F; return p; }
     const float lo = p - 2 * PI_F; p = p > PI_F ? lo : p;
     const float hi = p + 2 * PI_F; p = p < -PI_F ? hi : p;
     return p;
@@ -439,8 +442,8 @@ __device__ __forceinline__ void ddc_chain_body_seg(const DdcChainJob &j, int c)
             if (mine) for (int b = b0; b < b1; b++) {
                 const size_t id = (size_t)(b - b0) * n_channels + c;
                 j.blk_remain[id] = s.remain; j.blk_phase[id] = p; j.blk_off[id] = (b - b0) * f.k;
-                p = ddc_phase_step(p, f.d);
-            } else for (int b = b0; b < b1; b++) p = ddc_phase_step(p, f.d);
+                p = ddc_phase_step(p, f.d, f.big);
+            } else for (int b = b0; b < b1; b++) p = ddc_phase_step(p, f.d, f.big);
             s.phase = p; cnt = (b1 - b0) * f.k;
         } else if (mine) {
             for (int b = b0; b < b1; b++) {
@@ -470,7 +473,7 @@ __device__ __forceinline__ void ddc_chain_body(const DdcChainJob &j, int c)
         for (int b = 0; b < j.n_blocks; b++) {
             const size_t id = (size_t)b * n_channels + c;
             j.blk_remain[id] = s.remain; j.blk_phase[id] = p; j.blk_off[id] = b * f.k;
-            p = ddc_phase_step(p, f.d);
+            p = ddc_phase_step(p, f.d, f.big);
         }
         s.phase = p;
         j.state_out[c] = s; j.counts[c] = j.n_blocks * f.k;
@@ -1172,6 +1175,28 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
 }
 
 } // namespace csdr_amd
+
+// Test hook (tests/test_abi_cpu.py): the residual-shift bookkeeping of `n_blocks` consecutive blocks of one channel on the CPU, through the GENERAL step (mode 0: the
+// reference's arithmetic, libcsdr_gpl.c:153-158) or the FAST path the kernels take when a block changes neither `remain` nor the sample count (mode 1; returns -1 when its
+// precondition does not hold): phases_out[b] = the phase in front of block b, *remain_io / *phase_io = the state in front of block 0, behind the last block on return.
+extern "C" int csdr_amd_debug_ddc_chain(int mode, float rate2, int post_in, int post_dec, int n_blocks, int *remain_io, float *phase_io, float *phases_out, int *count_out)
+{
+    using namespace csdr_amd;
+    DdcChanState s{*remain_io, *phase_io};
+    const int sh = (post_dec & (post_dec - 1)) == 0 ? __builtin_ctz(post_dec) : -1;
+    int total = 0;
+    if (mode == 1) {
+        const DdcChainFast f = ddc_chain_fast(s, rate2, post_in, post_dec);
+        if (!f.ok) return -1;
+        float p = s.phase;
+        for (int b = 0; b < n_blocks; b++) { phases_out[b] = p; p = ddc_phase_step(p, f.d, f.big); total += f.k; }
+        s.phase = p;
+    } else {
+        for (int b = 0; b < n_blocks; b++) { phases_out[b] = s.phase; total += ddc_chain_step(s, rate2, post_in, post_dec, sh); }
+    }
+    *remain_io = s.remain; *phase_io = s.phase; *count_out = total;
+    return 0;
+}
 
 // Test hook: the 8-point butterfly of the 512-point transform on the CPU; 8 interleaved complex floats
 extern "C" void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse)

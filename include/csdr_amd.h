@@ -427,6 +427,9 @@ void csdr_amd_debug_dft16(const float *in32, float *out32, int inverse);
 /* Test hook: the 8-point butterfly of the channelizer's 512-point inverse transforms (fastddc_mfma.hip) on the CPU; 8 interleaved complex floats */
 int  csdr_amd_debug_fftfilt_lds(int n, const float *taps_iq, int taps_len, const float *x_iq, long m_new, float *y_iq);   /* CPU run of the one-pass filter kernel's stages */
 void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse);
+/* Test hook: the channelizer's residual-shift bookkeeping (decimating_shift_addition_cc's (remain, phase) per block, libcsdr_gpl.c:153-158) over n_blocks blocks on the
+ * CPU; mode 0 = the general step, mode 1 = the constant-step fast path of the kernels (-1 when it does not apply).  phases_out[b] = phase in front of block b. */
+int  csdr_amd_debug_ddc_chain(int mode, float rate2, int post_in, int post_dec, int n_blocks, int *remain_io, float *phase_io, float *phases_out, int *count_out);
 /* Test hook: one tile (16 outputs from 256 limited samples) of the NFM chain's matrix-core de-emphasis FIR on the CPU: digit planes,
  * Toeplitz digit table and accumulator classes as k_nfm_deemph_mfma combines them. */
 int csdr_amd_debug_nfm_deemph_tile(int audio_rate, float max_amp, const float *x, float *out16);

@@ -195,3 +195,40 @@ def test_fftfilt_lds_stages_on_cpu(n, ntaps, m):
     want = np.convolve(x.astype(np.complex128), h.astype(np.complex128))[:m]
     assert np.sqrt(np.mean(np.abs(y - want) ** 2) / np.mean(np.abs(want) ** 2)) < 2e-6
     assert f(4096, h.ctypes.data, 5000, x.ctypes.data, m, y.ctypes.data) != 0        # taps that do not fit the window are refused
+
+
+def test_ddc_chain_fast_path_is_bit_identical(libpath, port):
+    import numpy as np
+    """The channelizer's shift state per block (fastddc.c:152-164 -> decimating_shift_addition_cc, libcsdr_gpl.c:131-160) is walked by every rank of a time-sliced bank over
+    the WHOLE batch: the kernels take a five-operation fast path when a block changes neither `remain` nor the sample count.  Both forms against the oracle's
+    decimating_shift_addition_cc on zero input (the state is data independent), 3000 blocks, every channel rate of config 4 plus awkward ones: same phases, bit for bit."""
+    L = C.CDLL(libpath)
+    fn = L.csdr_amd_debug_ddc_chain
+    fn.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_void_p, C.POINTER(C.c_int)]
+    d0, _ = port.fastddc_init(0.001, 256, 0.0)
+    post_in, post_dec, nb = d0.post_input_size, d0.post_decimation, 3000
+    assert (post_in, post_dec) == (448, 2)
+    rates = [-0.5 + (c + 0.5) / 256 for c in range(0, 256, 17)] + [0.0, 0.123, -0.3711, 0.25, -0.4999, 0.49999]
+    zeros = np.zeros(post_in, np.complex64)
+    for rate in rates:
+        d, _ = port.fastddc_init(0.001, 256, float(rate))
+        rate2 = float(d.dsadata.rate)                                # the channel's decimating_shift_addition rate (fastddc.c:60-66)
+        got = []
+        for mode in (0, 1):
+            rem = C.c_int(0); ph = C.c_float(0.0); cnt = C.c_int(0)
+            phases = np.zeros(nb, np.float32)
+            rc = fn(mode, rate2, post_in, post_dec, nb, C.byref(rem), C.byref(ph), phases.ctypes.data, C.byref(cnt))
+            assert rc == 0, (rate, mode)
+            got.append((phases, rem.value, np.float32(ph.value), cnt.value))
+        assert np.array_equal(got[0][0].view(np.uint32), got[1][0].view(np.uint32)) and got[0][1:] == got[1][1:], rate
+        # the oracle: decimating_shift_addition_cc block by block (libcsdr_gpl.c:131-160), state carried
+        st = (0, 0.0, 0); total = 0
+        for b in range(400):
+            assert np.float32(st[1]).view(np.uint32) == got[0][0][b].view(np.uint32), (rate, b)
+            _, st = port.decimating_shift_addition_cc(zeros, float(d.post_shift), post_dec, st)
+            total += st[2]
+        assert total == 400 * (post_in // post_dec)
+    # a geometry where the fast path must refuse (post_in not a multiple of post_dec): the general step still runs
+    rem = C.c_int(0); ph = C.c_float(0.0); cnt = C.c_int(0); phases = np.zeros(10, np.float32)
+    assert fn(1, 0.01, 449, 2, 10, C.byref(rem), C.byref(ph), phases.ctypes.data, C.byref(cnt)) == -1
+    assert fn(0, 0.01, 449, 2, 10, C.byref(rem), C.byref(ph), phases.ctypes.data, C.byref(cnt)) == 0 and cnt.value in (2245, 2246)
