@@ -190,7 +190,10 @@ struct SeqParams {
     const uint8_t *head_in; uint8_t *head_out;
 };
 
-constexpr int SEQ_RB = 9216;               // ring bytes per stream: 9 x 1 KiB (the 8-tile step's window 7 x stride + 512 B + the next step's + fetch granularity)
+#ifndef SEQ_RB_KIB
+#define SEQ_RB_KIB 9
+#endif
+constexpr int SEQ_RB = 1024 * SEQ_RB_KIB;  // ring bytes per stream: 9 x 1 KiB (the 8-tile step's window 7 x stride + 512 B + the next step's + fetch granularity)
 #ifndef SEQ_RING_PAD
 #define SEQ_RING_PAD 32
 #endif
