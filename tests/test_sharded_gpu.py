@@ -137,3 +137,26 @@ def test_null_transport_times_one_rank(gpu):
             assert L.csdr_amd_fastddc_bank_process(bank, di.ptr, 64, do.ptr, pitch, None) == 0, gpu.err()
         gpu.sync()
         L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm)
+
+
+def test_time_sliced_bank_at_the_emulated_size(gpu, port):
+    """bench_fastddc.py --emulate-world 8's configuration run for real: 8 rank threads, batches of 512 blocks (64 per rank: every rank's pipeline at the shape the
+    single-GPU bench times, the chain walked over 448 foreign blocks, the 3.7-MB-per-peer output exchange), two batches so that state and overlap cross a batch
+    boundary.  All 256 channels against the single-GPU bank fed the same stream in calls of 64 blocks, five against the oracle."""
+    import csdr_amd
+    ddc, _ = gpu.fastddc_init(TBW, D, 0.0)
+    nb = 1024
+    rng = np.random.default_rng(512)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = vc.c4_rates(NCH)
+    outs = csdr_amd.sharded_bank_loopback(8, x, TBW, D, rates, [512, 512], mode="blocks", pipelined=True)
+    single = gpu.fastddc_bank(x, TBW, D, rates, blocks_per_call=64)
+    worst = 0.0
+    for c in range(NCH):
+        assert outs[c].size == single[c].size, "channel %d" % c
+        worst = max(worst, vc.relrms(outs[c], single[c]))
+    assert worst < 2e-6, worst
+    check = [0, 77, 128, 200, 255]
+    _, want = vc.fastddc_oracle_channels(x, TBW, D, rates, check)
+    for c in check:
+        assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < 1e-5, "channel %d vs oracle" % c
