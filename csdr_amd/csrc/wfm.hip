@@ -16,7 +16,8 @@
 // Only y[Fj+9] and y[Fj+10] feed the audio, so 2 of every F FIR outputs are computed (exact, 2.5x fewer MACs
 // at F = 5).  HBM traffic: 2 B in per complex sample + 2/(D F) B out: every input byte is read once.
 //
-// Round-1 structure (two launches per block):
+// This file: the chain OBJECT (state, bookkeeping, csdr_amd_wfm_*) and the VALU fallback.  The default path is ONE kernel per call, k_wfm_mfma_seq (wfm_mfma.hip:
+// the whole chain on the matrix cores); the two kernels below serve shapes it does not cover (D F odd, long filters) and CSDR_AMD_WFM_PATH=valu:
 //   k_wfm_front : (stream, tile of A audio samples) per workgroup.  u8 window -> float -> rotate -> LDS;
 //                 FIR pairs from LDS (two lanes per output, 40 taps each); quadrature demod; writes the
 //                 pre-de-emphasis audio float (4 B per D*F input samples) to a scratch row.
@@ -234,7 +235,7 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     w->shift_rate = shift_rate; w->tau = tau; w->max_block = max_block_samples;
     const float dt = (float)(1.0 / audio_rate); w->alpha = dt / (tau + dt);          // libcsdr.c:1090-1091
     const size_t max_audio = max_block_samples / ((size_t)decimation * frac_rate) + 8;
-    w->demod_pitch = (max_audio + 40 + 63) & ~(size_t)63;          // + the octet-aligned start (up to 31 samples) and tile padding
+    w->demod_pitch = (max_audio + 40 + 63) & ~(size_t)63;          // (VALU path's scratch rows; tile padding)
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     w->d_demod = nullptr; w->d_rot = nullptr; w->d_hist = nullptr; w->d_head[0] = w->d_head[1] = nullptr; w->hflip = 0;
