@@ -155,6 +155,45 @@ def test_wfm_other_decimations(gpu, port, D, F, L):
         assert m >= n // (D * F) - 8 and relrms(af[s, :m], pf[:m]) <= TOL
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_wfm_random_block_schedules(gpu, port, seed):
+    """csdr_amd_wfm_process over RANDOM call sizes (multiples of 1024 between 1 and 90 chunks, a ragged last call), stream counts and row pitches: every call's
+    first / last tile is partial somewhere, windows start in the history, the seed table is rebuilt on the way; the concatenated audio equals the oracle's stream."""
+    import ctypes as C
+    from tests_helpers import wfm_signal_u8
+    rng = np.random.default_rng(seed)
+    L = gpu.L
+    S = int(rng.integers(1, 40))
+    sizes = [1024 * int(rng.integers(1, 91)) for _ in range(int(rng.integers(3, 9)))] + [int(rng.integers(1, 1024)) * 2]
+    n = sum(sizes)
+    pad = 16 * int(rng.integers(0, 9))
+    taps = port.firdes_lowpass_f(79, 0.05)
+    base = [wfm_signal_u8(900 + seed * 10 + k, n) for k in range(min(S, 3))]
+    pitch = (2 * n + 15) // 16 * 16 + pad
+    xx = np.zeros((S, pitch), np.uint8)
+    for s in range(S):
+        xx[s, :2 * n] = base[s % len(base)]
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, max(sizes))
+    assert w, gpu.err()
+    di = gpu.upload(xx)
+    apitch = n // 50 + 64
+    ds = gpu.alloc(2 * S * apitch); df = gpu.alloc(4 * S * apitch)
+    pos = na = 0
+    for k in sizes:
+        got = L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na), apitch)
+        assert got >= 0, gpu.err()
+        pos += k; na += got
+    s16 = gpu.download(ds, np.int16, S * apitch).reshape(S, apitch)[:, :na]
+    af = gpu.download(df, f32, S * apitch).reshape(S, apitch)[:, :na]
+    L.csdr_amd_wfm_destroy(w)
+    want = [port.wfm_chain(b, -0.085, 10, taps) for b in base]
+    for s in sorted({0, S // 2, S - 1}):
+        ps, pf = want[s % len(base)]
+        m = min(pf.size, na)
+        assert m >= n // 50 - 8 and relrms(af[s, :m], pf[:m]) <= TOL, (seed, s, sizes)
+        assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
 @pytest.mark.parametrize("rate", [0.25, 0.05, -0.3141])
 def test_wfm_other_shift_rates(gpu, port, rate):
     """Shift rates other than the benchmark's, including 0.25 and 0.05 for which the reference's float phasor recurrence drifts by up to
