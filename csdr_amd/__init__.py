@@ -685,16 +685,17 @@ class Context:
         pitch = (nbytes + 127) // 128 * 128 + pitch_pad
         xx = np.full((s, pitch), 0x80, np.uint8); xx[:, :nbytes] = x2
         taps = np.ascontiguousarray(taps, f32)
-        block = n if block is None else block
+        sched = list(block) if isinstance(block, (list, tuple)) else None          # `block` may be a list of call sizes (the rest of the stream follows in one call)
+        block = n if block is None else (max(sched) if sched else block)
         d = self.L.csdr_amd_ddc_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, max(block, 1024))
         if not d:
             raise CsdrAmdError(self.err())
         di = self.upload(xx)
         opitch = n // decimation + 64
         do = self.alloc(8 * s * opitch)
-        pos = 0; no = 0; self.ddc_kernels = set()
+        pos = 0; no = 0; self.ddc_kernels = set(); call = 0
         while pos < n:
-            k = min(block, n - pos)
+            k = min(sched[call] if (sched and call < len(sched)) else block, n - pos); call += 1
             got = self.check(self.L.csdr_amd_ddc_process(d, di.at(2 * pos), pitch, k, do.at(8 * no), opitch), "ddc_process")
             self.ddc_kernels.add(self.L.csdr_amd_ddc_kernel_name(d).decode())
             pos += k; no += got
@@ -712,16 +713,17 @@ class Context:
         xx = np.full((S, pitch), 0x80, np.uint8); xx[:, :nbytes] = x2
         nt = self.firdes_filter_len(tbw)
         taps = np.ascontiguousarray(self.firdes_lowpass_f(nt, 0.5 / decimation), f32)
-        block = n if block is None else block
+        sched = list(block) if isinstance(block, (list, tuple)) else None
+        block = n if block is None else (max(sched) if sched else block)
         w = self.L.csdr_amd_nfm_create(self.h, S, shift_rate, decimation, _hp(taps), taps.size, audio_rate, agc_block, 1.0, 1.0, max(block, 1024))
         if not w:
             raise CsdrAmdError(self.err())
         di = self.upload(xx)
         apitch = n // decimation + 1024 + 64
         ds = self.alloc(2 * S * apitch); df = self.alloc(4 * S * apitch)
-        pos = 0; na = 0
+        pos = 0; na = 0; call = 0
         while pos < n:
-            k = min(block, n - pos)
+            k = min(sched[call] if (sched and call < len(sched)) else block, n - pos); call += 1
             got = self.check(self.L.csdr_amd_nfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na), apitch), "nfm_process")
             pos += k; na += got
         pcm = self.download(ds, np.int16, S * apitch).reshape(S, apitch)[:, :na]

@@ -88,3 +88,27 @@ def test_ddc_matches_unfused_device_ops(gpu, port):
     ref = gpu.fir_decimate_cc(sh, D, taps)
     m = min(ref.size, y.shape[1])
     assert m >= (n - L) // D and relrms(y[0, :m], ref[:m]) <= TOL
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_ddc_and_nfm_random_call_sizes(gpu, port, seed):
+    """The receiver front end and the NFM chain over RANDOM call sizes (multiples of 1024 samples, the stream's tail in a last ragged call): the matrix-core kernel
+    takes whole calls -- first / last tile partial, windows starting in the history buffer, seed tables rebuilt on the way -- and only the ragged last call goes to the
+    plain kernel; the complex stream against the oracle's three stages (1e-5), the chain's audio against the single-call run of the same object (bit identical)."""
+    rng = np.random.default_rng(seed)
+    D, L, rate = 50, 801, [0.11, -0.2718, 0.05][seed % 3]
+    sizes = [1024 * int(rng.integers(2, 70)) for _ in range(int(rng.integers(3, 8)))]
+    n = sum(sizes) + 1024 * 3 + int(rng.integers(1, 512)) * 2
+    S = int(rng.integers(1, 34))
+    taps = port.firdes_lowpass_f(L, 0.5 / D)
+    base = [nfm_signal_u8(700 + 10 * seed + k, n, offset=-rate) for k in range(min(S, 2))]
+    u8 = np.stack([base[s % len(base)] for s in range(S)])
+    y = gpu.ddc_u8(u8, rate, D, taps, block=sizes + [1024 * 3])
+    assert "k_ddc_mfma" in gpu.ddc_kernels
+    want = [oracle_front(port, b, rate, D, taps) for b in base]
+    check(y, want, sorted({0, S // 2, S - 1}), len(base))
+    if seed == 21:
+        pcm1, af1 = gpu.nfm_chain(u8[:5], -rate)
+        pcm2, af2 = gpu.nfm_chain(u8[:5], -rate, block=sizes + [1024 * 3])
+        m = min(pcm1.shape[1], pcm2.shape[1])
+        assert m >= pcm1.shape[1] - 2048 and np.array_equal(pcm1[:, :m], pcm2[:, :m])
