@@ -442,8 +442,12 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
 #if DDC_DIAG != 2
         if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + RB) row_step(); }
 #endif
-        // ---- reduction of the four K-range shares and store: the waves of a team take turns
-        if (active && w == (gi & 3)) {
+        // ---- reduction of the four K-range shares and store: the waves of a team take turns.  FUSE: TWO waves of the team share the epilogue -- role A (wave gi mod 4)
+        // demodulates the tile's even outputs (it needs the predecessor logic), role B (wave gi + 2 mod 4) the odd ones: the reducer is on every group's critical path (the
+        // other waves wait for it at the next barrier), and fmdemod_quadri_cf | limit_ff + the digit split is two thirds of its work.  Both sum the same partials in the
+        // same order: the values are those of the one-wave epilogue, bit for bit.
+        const bool role_a = w == (gi & 3), role_b = FUSE && w == ((gi + 2) & 3);
+        if (active && (role_a || role_b)) {
             const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
             const int stream = sb * 16 + col;
             const float2 y0 = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                     if (ok0) dst[0] = y0;
                     if (ok1) dst[1] = y1;
                 }
-            } else {
+            } else if (role_a) {
                 // predecessor of output 2q: lane (col, q - 1)'s second output; for q = 0 the previous tile's last output
                 float2 prev = make_float2(__shfl_up(y1.x, 16), __shfl_up(y1.y, 16));
                 if (q == 0 && it > 0) {
@@ -468,19 +472,26 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                 }
                 if (team == NT - 1 && q == 3) ylast[(gi & 1) * 16 + col] = y1;
                 if (stream < p.n_streams) {
-                    float2 *ydst = out + (size_t)stream * out_pitch + kk;
                     // complex samples k_nfm_demod_boundary needs: the call's first output and every segment's first one (their predecessors live elsewhere), the segments'
                     // last ones (the next segment's predecessor) and the call's last one (the next call's)
-                    const bool seg_first = it == 0 && q == 0, seg_last = it == n_it - 1 && q == 3;
+                    float2 *ydst = out + (size_t)stream * out_pitch + kk;
+                    const bool seg_first = it == 0 && q == 0;
                     if (ok0 && (seg_first || kk == 0 || kk == p.n_out - 1)) ydst[0] = y0;
-                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == p.n_out - 1)) ydst[1] = y1;
-                    int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
-                    int dg[3];
                     if (ok0 && !seg_first && kk != 0) {
+                        int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
+                        int dg[3];
                         nfm_demod_digits(y0, prev, fz.max_amp, fz.q_per_amp, dg);
                         pd0[0] = (int8_t)dg[0]; pd0[fz.plane_bytes] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes] = (int8_t)dg[2];
                     }
+                }
+            } else {                                                                 // role B: the odd outputs (their predecessor is this lane's own even one)
+                if (stream < p.n_streams) {
+                    float2 *ydst = out + (size_t)stream * out_pitch + kk;
+                    const bool seg_last = it == n_it - 1 && q == 3;
+                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == p.n_out - 1)) ydst[1] = y1;
                     if (ok1 && kk + 1 != 0) {
+                        int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
+                        int dg[3];
                         nfm_demod_digits(y1, y0, fz.max_amp, fz.q_per_amp, dg);
                         pd0[1] = (int8_t)dg[0]; pd0[fz.plane_bytes + 1] = (int8_t)dg[1]; pd0[2 * fz.plane_bytes + 1] = (int8_t)dg[2];
                     }
