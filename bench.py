@@ -14,6 +14,11 @@ samples (1.0001 s of signal) of every stream through the whole chain (state carr
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are independent, so ranks share nothing on
 the data path (replicas of the per-GPU workload, "scaling": "weak"); barrier + max-over-ranks timing over RCCL.
 Prints ONE JSON line on rank 0.
+
+Before the W warm-up steps the bench runs untimed steps for --spinup-ms (default 60 ms, reported as "spinup_steps_before_warmup"): after idle the GPU
+takes about 25 launches to reach its running clocks (the chain kernel's first launches measure 990-1175 us, then settle at ~905: profiles/r3_notes.md),
+and the metric is a stream's steady-state rate.  The K timed steps are untouched: every one runs the whole chain on the whole batch.  --spinup-ms 0
+gives the cold number (about 3 % lower at --steps 20 --warmup 5).
 """
 import argparse
 import ctypes as C
@@ -49,6 +54,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)        # ~0.5 s of timed work at ~1 ms per step
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spinup-ms", type=float, default=60.0,
+                    help="untimed steps for about this long BEFORE the W warm-up steps: after idle the GPU needs ~25 launches (25 ms) to ramp its clocks -- the first "
+                         "launches of the chain kernel run up to 25 %% slower (profiles/r3_notes.md) -- and the metric is a stream's steady-state rate; 0 = off")
     ap.add_argument("--streams", type=int, default=1024)
     ap.add_argument("--block", type=int, default=2344 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -112,6 +120,7 @@ def main():
             raise SystemExit("wfm_process: " + ctx.err())
         return n
 
+    spin_steps = bc.spinup(step, ctx.sync, args.spinup_ms)
     for _ in range(args.warmup):
         step()
     ctx.sync(); torch.cuda.synchronize()
@@ -143,7 +152,7 @@ def main():
         achieved_gbs = ALGO_BYTES_PER_SAMPLE * samples_per_step_gpu / (k_avg_ms * 1e-3) / 1e9
         res = {
             "metric": "complex MS/s in->out, WFM demod chain @2.4 MS/s x N streams",
-            "value": round(msps, 1), "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(msps, 1), "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_before_warmup": spin_steps,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: full WFM pipe u8 IQ -> s16 audio (convert_u8_f|shift_addition_cc -0.085|fir_decimate_cc 10 0.05 HAMMING|"

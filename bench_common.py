@@ -102,3 +102,23 @@ def pmc_traffic(kernel_name, match):
         if d.get("kernel", "").startswith(kernel_name) and all(w.get(k) == v for k, v in match.items()):
             best = (d["traffic_bytes_per_launch"], "profiles/" + os.path.basename(f) + " (rocprofv3 PMC passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)")
     return best
+
+
+def spinup(step, sync, ms, chunk=8, cap=2048):
+    """Untimed steps for about `ms` milliseconds before a bench's warm-up: an idle GPU takes ~25 ms of back-to-back launches to reach its running clocks
+    (profiles/r3_notes.md: the first launches of a 0.9-ms kernel measure up to 25 % slow), and every metric here is a stream's steady-state rate.
+    Returns the number of steps run (reported in the JSON line as "spinup_steps_before_warmup")."""
+    import time
+    n = 0
+    if ms <= 0:
+        return 0
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms and n < cap:
+        for _ in range(chunk):
+            step()
+        n += chunk
+        sync()
+    return n
+
+
+SPINUP_HELP = ("untimed steps for about this many ms BEFORE the W warm-up steps (GPU clock ramp after idle, see bench_common.spinup); 0 = off")

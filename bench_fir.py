@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spinup-ms", type=float, default=60.0, help=bc.SPINUP_HELP)
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--block", type=int, default=2344 * 1024)
     ap.add_argument("--decimation", type=int, default=10)
@@ -65,6 +66,7 @@ def main():
             raise SystemExit("fir_decimate_cc: " + ctx.err())
         return n
 
+    spin_steps = bc.spinup(step, ctx.sync, args.spinup_ms)
     for _ in range(args.warmup):
         step()
     ctx.sync(); torch.cuda.synchronize()
@@ -86,7 +88,7 @@ def main():
         k_ms = ev_ms / args.steps                                             # one kernel per step: the HIP-event time per step IS the kernel's
         kname = "k_fir_poly" if nt <= 128 else ("k_fir_generic" if os.environ.get("CSDR_AMD_FIR_MFMA_OFF") else "k_fir_mfma")
         res = {"metric": "complex MS/s in, fir_decimate_cc %d %g HAMMING @2.4 MS/s x N streams" % (D, args.tbw), "value": round(samples / wall / 1e6, 1),
-               "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
+               "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_before_warmup": spin_steps, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[0]: fir_decimate_cc (decim=%d, %g HAMMING, %d taps) on synthetic complexf, batched" % (D, args.tbw, nt),
                           "streams_per_gpu": S, "block_samples_per_stream": T, "decimation": D, "taps": nt, "stream_rate_sps": 2400000, "parallelism": "streams sharded, no data-path collective"},

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)        # ~0.3 s of timed work
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spinup-ms", type=float, default=60.0, help=bc.SPINUP_HELP)
     ap.add_argument("--streams", type=int, default=512)
     ap.add_argument("--block", type=int, default=2344 * 1024)
     ap.add_argument("--front-end-only", action="store_true", help="time csdr_amd_ddc_process alone (convert | shift | fir_decimate)")
@@ -90,6 +91,7 @@ def main():
             raise SystemExit("process: " + ctx.err())
         return n
 
+    spin_steps = bc.spinup(step, ctx.sync, args.spinup_ms)
     for _ in range(args.warmup):
         step()
     ctx.sync(); torch.cuda.synchronize()
@@ -124,7 +126,7 @@ def main():
         if traffic and not (0.8 < traffic / algo < 1.25):
             traffic, traffic_src = None, None                 # a summary of the other (fused / unfused) variant
         res = {"metric": "complex MS/s in->out, NFM chain @2.4 MS/s x N channels", "value": round(samples / wall / 1e6, 1), "unit": "complex MS/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_before_warmup": spin_steps, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[4]: NFM chain u8 IQ -> s16 audio (convert_u8_f|shift_addition_cc -0.05|fir_decimate_cc 50 0.005 HAMMING|fmdemod_quadri_cf|"
                                       "limit_ff|deemphasis_nfm_ff 48000|fastagc_ff|convert_f_s16)" + (" -- FRONT END ONLY (first three stages)" if args.front_end_only else ""),
