@@ -136,6 +136,24 @@ __device__ __forceinline__ void tile_rows(const v4i (&acc)[3], const v4i (&snap)
     }
 }
 
+// One row-step of a fetching wave in one piece of code: R rows, 1 KiB each, LDS destinations RP bytes apart (M0 saved once, stepped by s_add_u32), no branch between the pieces.
+template <int R, int RP>
+__device__ __forceinline__ void dma_rows(const uint32_t (&vo)[R], const uint8_t *sbase, uint32_t la0)
+{
+    uint32_t keep;
+    static_assert(R == 2 || R == 8, "rows per fetching wave");
+#define DMA_NEXT(k) "s_add_u32 m0, m0, %[rp]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #k "], %[sb] nt\n\t"
+    if constexpr (R == 2)
+        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t" DMA_NEXT(1) "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
+    else
+        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t"
+                     DMA_NEXT(1) DMA_NEXT(2) DMA_NEXT(3) DMA_NEXT(4) DMA_NEXT(5) DMA_NEXT(6) DMA_NEXT(7) "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4]), [v5] "v"(vo[5]), [v6] "v"(vo[6]), [v7] "v"(vo[7]),
+                       [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
+#undef DMA_NEXT
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int KB>
@@ -161,16 +179,22 @@ __device__ __forceinline__ void wfm_chain(const v4i (&A)[WFM_NK * 3], const v4i 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The sequential kernel.  One 24-fragment weight set, no wave tied to a tile phase: a workgroup owns 16 streams x a contiguous run of
-// tiles (a "segment"), its 8 waves take 8 consecutive tiles per step, and the input slides through a per-stream LDS ring filled by LDS-DMA in
-// whole 1-KiB runs -- every input byte is fetched exactly once, in long sequential runs per stream (PMC: 1.005 x the algorithmic bytes).
-// A chunk boundary inside the 256-sample window is 16-byte granular (window bases are multiples of 8 samples): the boundary K-step is
-// multiplied twice with complementary lane groups of the B operand zeroed, the accumulator chain is snapshotted in between; each boundary
-// position is its own straight-line code variant (wfm_chain<KB>).
+// tiles (a "segment"), its SEQ_TPG = 6 compute waves take 6 consecutive tiles per step, and the input slides through a per-stream LDS ring
+// filled by LDS-DMA in whole 1-KiB runs -- every input byte is fetched exactly once, in long sequential runs per stream (PMC: 1.005 x the
+// algorithmic bytes).  A chunk boundary inside the 256-sample window is 16-byte granular (window bases are multiples of 8 samples): the
+// boundary K-step is multiplied twice with complementary lane groups of the B operand zeroed, the accumulator chain is snapshotted in
+// between; each boundary position is its own straight-line code variant (wfm_chain<KB>).
+//
+// Who fetches (round 3, profiles/r3_notes.md): SEQ_NLD = 2 LOADER waves, 8 streams each.  The CU accepts 64 LDS-DMA pieces in flight; beyond
+// that an issuing wave stalls for as long as the memory takes (160-330 cycles per piece at the kernel's rate).  While the eight waves of the
+// earlier layout each fetched two streams, every wave sat in that stall for a quarter to a third of each step (per-wave cycle counts,
+// -DWFM_PROF: tools/diag_wfm.py) and did its tile afterwards.  Now the stall belongs to two waves that do nothing else, a row-step is one
+// straight piece of code (M0 saved once, stepped by s_add: dma_rows), and the six compute waves run tile -> barrier -> tile.
 //
 // The back end of the chain runs inside: the workgroup produces its streams' audio in time order, so the one-pole de-emphasis
-// (libcsdr.c:1081-1097) is a state carried in wave 0 from step to step, and convert_f_s16 + the stores are done by all threads one step
-// later (one sample per thread, three staging buffers so that nobody waits): the demodulated audio never goes to HBM as floats.  A segment
-// that starts in the middle of a call demodulates two steps (64 audio samples) ahead of its range from zero state without storing them --
+// (libcsdr.c:1081-1097) is a state carried in wave 0 from step to step (wave 0 takes no part in the stores), and convert_f_s16 + the stores
+// follow one step later out of a ring of SEQ_OUTS steps' samples per stream: the demodulated audio never goes to HBM as floats.  A segment
+// that starts in the middle of a call demodulates two steps (48 audio samples) ahead of its range from zero state without storing them --
 // the filter forgets as 0.706^k --; the first segment starts from the exact state the previous call left, the last one leaves its own.
 //
 // A call's edges, all inside this launch:
@@ -193,26 +217,54 @@ struct SeqParams {
 #ifndef SEQ_RB_KIB
 #define SEQ_RB_KIB 9
 #endif
-constexpr int SEQ_RB = 1024 * SEQ_RB_KIB;  // ring bytes per stream: 9 x 1 KiB (the 8-tile step's window 7 x stride + 512 B + the next step's + fetch granularity)
+constexpr int SEQ_RB = 1024 * SEQ_RB_KIB;  // ring bytes per stream: 9 x 1 KiB (a step's window (SEQ_TPG - 1) x stride + 512 B, the next step's, what is in flight beyond, fetch granularity)
 #ifndef SEQ_RING_PAD
 #define SEQ_RING_PAD 32
 #endif
 constexpr int SEQ_RP = SEQ_RB + SEQ_RING_PAD;   // LDS pitch.  A ds_read_b128 is served in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...): with the 16-byte slot of lane
                                            // (stream, q) = (2 stream + q) mod 16 every group touches 16 different slots; + 16 (slot = stream + q) left 4 two-way conflicts per read
 constexpr int SEQ_NGR = 4 * WFM_NK;        // 16-byte granules per window
-constexpr int SEQ_OUTP = 36;               // floats per stream row of the output staging (32 + pad, 16-byte multiple)
-constexpr int SEQ_TPG = 8;                 // tiles per step = waves per workgroup
+#ifndef SEQ_TPG_N
+#define SEQ_TPG_N 6
+#endif
+#ifndef SEQ_NLD_N
+#define SEQ_NLD_N 2
+#endif
+constexpr int SEQ_TPG = SEQ_TPG_N;         // tiles per step = compute waves per workgroup
+constexpr int SEQ_NLD = SEQ_NLD_N;         // loader waves: they issue the LDS-DMA (a wave stalls 200-300 cycles per 1-KiB piece while the CU's address path is busy) and
+                                           // run the de-emphasis, so that the compute waves never wait at an issue; 0 = the compute waves fetch for themselves
+constexpr int SEQ_NW = SEQ_TPG + SEQ_NLD;  // waves per workgroup
+constexpr int SEQ_NLW = SEQ_NLD ? SEQ_NLD : SEQ_TPG;   // waves that fetch
+constexpr int SEQ_LINE = 64;               // audio samples stored at a time per stream: one 128-byte line of the s16 output row
+constexpr int SEQ_OUTS = (SEQ_LINE - 1 + 3 * 4 * SEQ_TPG + 4 * SEQ_TPG - 1) / (4 * SEQ_TPG);   // audio staging: a ring of this many steps' samples per stream (a step = 4 SEQ_TPG
+constexpr int SEQ_OUTR = SEQ_OUTS * 4 * SEQ_TPG;   // samples): written by the tile waves, filtered in place by the de-emphasis one step later, stored one step after that in whole
+constexpr int SEQ_OUTP = SEQ_OUTR + 4;     // lines, which may reach SEQ_LINE - 1 samples back; row pitch in floats
+static_assert(16 % SEQ_NLW == 0 && (16 / SEQ_NLW) * 7 <= 63 && SEQ_TPG % 2 == 0, "rows per fetching wave (vmcnt counts to 63); the de-emphasis scan works on pairs");
 constexpr int SEQ_HEAD = 1024;             // bytes of the per-stream head (one fetch run)
 
-__global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags, const float *__restrict__ cum,
+#ifndef WFM_DIAG
+#define WFM_DIAG 0      // diagnostic builds (tools/diag_wfm.py): 1 = no ring reads (B operand from registers), 2 = ring reads but no matrix products, 3 = compute waves idle,
+#endif                  // 4 = 3 + no audio stores, 5 = 4 + no de-emphasis, 6 = 3 with non-temporal audio stores, 7 = 3 with the audio stores to one line per stream
+#ifdef WFM_PROF
+// diagnostic build (tools/diag_wfm.sh): shader-clock cycles per wave summed over the launch: [wave][compute, wait vmcnt, barrier, DMA issue, emit, de-emphasis, steps]
+__device__ unsigned long long g_wfm_prof[SEQ_NW][8];
+#define PROF_T(k) { const long long t_now = __builtin_readcyclecounter(); prof[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define PROF_T(k)
+#endif
+
+__global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags, const float *__restrict__ cum,
                                                                const float2 *__restrict__ dtab, const float2 *__restrict__ ctab, SeqParams p)
 {
-    constexpr int TPG = SEQ_TPG, SPW = 16 / TPG, NTHR = 64 * TPG;                    // tiles per step; streams fetched per wave in a row-step
+    constexpr int TPG = SEQ_TPG, SPW = 16 / SEQ_NLW, NTHR = 64 * SEQ_NW;              // tiles per step; streams fetched per fetching wave in a row-step
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
-    float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 3 x 16 x SEQ_OUTP floats
-    float *lcum = lds_out + 3 * 16 * SEQ_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
+    float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 16 x SEQ_OUTP floats
+    float *lcum = lds_out + 16 * SEQ_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
+    const bool computes = wv < TPG;                                                  // wave uniform roles
+    const bool fetches = SEQ_NLD ? wv >= TPG : true;
+    const int fw = SEQ_NLD ? wv - TPG : wv;                                          // index among the fetching waves
     for (int i = tid; i < (SEQ_NGR + 1) * 16; i += NTHR) lcum[i] = cum[i];
     const int sb = blockIdx.x;
     const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
@@ -224,6 +276,7 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
     v4i A[WFM_NK * 3];
 #pragma unroll
     for (int s = 0; s < WFM_NK * 3; s++) A[s] = frags[s * 64 + lane];
+
     float c_lo[4], c_hi[4];                                                          // prefix values at the window's ends, rows 4q .. 4q+3
     {
         const float4 a = *reinterpret_cast<const float4 *>(cum + 4 * q), b = *reinterpret_cast<const float4 *>(cum + (size_t)SEQ_NGR * 16 + 4 * q);
@@ -242,7 +295,7 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
     uint32_t voff[SPW], voff_h[SPW];
 #pragma unroll
     for (int r = 0; r < SPW; r++) {
-        const int srow = max(min(sb * 16 + SPW * wv + r, last_stream) - sb * 16, 0);
+        const int srow = max(min(sb * 16 + SPW * fw + r, last_stream) - sb * 16, 0);
         voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
         voff_h[r] = (uint32_t)srow * (uint32_t)SEQ_HEAD + 16u * lane;
     }
@@ -252,9 +305,11 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
     auto row_step = [&]() {
         const bool head = F < 0;                                                     // wave uniform: the run [-1024, 0)
         const uint8_t *sbase = head ? hblock : sblock + F;
-        const uint32_t ldst = lds_in_addr + (SPW * wv) * SEQ_RP + (uint32_t)fslot;
+        const uint32_t ldst = lds_in_addr + (SPW * fw) * SEQ_RP + (uint32_t)fslot;
         const bool mask = ragged && !head;                                           // wave uniform; ragged end: the row's last 16-byte piece is the last one fetched
         const bool live = !mask || F + 16 * lane < p.two_T;
+        if (!head && !ragged) dma_rows<SPW, SEQ_RP>(voff, sbase, __builtin_amdgcn_readfirstlane((int)ldst));      // the common case
+        else
 #pragma unroll
         for (int r = 0; r < SPW; r++) {
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * SEQ_RP));
@@ -288,8 +343,10 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
         if (newer > 7) newer = 7;
         wait_newer(newer);
     };
-    while (F < F_end && F + 1024 <= wg + SEQ_RB) row_step();
-    wait_for(wg + (long long)(TPG - 1) * tstride);
+    if (fetches) {
+        while (F < F_end && F + 1024 <= wg + SEQ_RB) row_step();
+        wait_for(wg + (long long)(TPG - 1) * tstride);
+    }
     __syncthreads();
     const uint8_t *lrow = lds_in + col * SEQ_RP;
     const int s0 = sb * 16;
@@ -314,22 +371,68 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
     const int seg_lo = (int)max(0LL, p.j_first - 4 * t0);                           // > 0 only in the call's first segment, when j_first is not a multiple of 4
     const int seg_hi = (int)min(4LL * n_it, j_end - 4 * t0);                        // samples of the segment that exist in this call
     const long long idx0 = 4 * t0 - p.j_first;                                      // output index of the segment's sample 0
-    auto emit = [&](int g) {                                                         // convert_f_s16 + store of step g's 16 x 32 samples, one per thread
+    // convert_f_s16 + store of step g's 16 x SPS samples.  With loader waves, wave 0 (which runs the de-emphasis) is left out: the other compute waves share the samples
+    constexpr int EMIT_T0 = SEQ_NLD ? 64 : 0, EMIT_N = SEQ_NLD ? 64 * (TPG - 1) : NTHR;
+    // Stores.  Usual case (16-byte aligned rows): whole 128-byte LINES of the s16 output rows, 64 samples, 8 lanes x 16 bytes each -- lines of the OUTPUT row, whatever
+    // the call's first sample is: after step g the line whose last sample lies in step g is complete (the same step for all 16 streams: 16 lines = 2 waves' worth of
+    // lanes, in 3 of 8 steps); it may start up to 63 samples back, hence the ring of SEQ_OUTS steps.  Why lines: 48 bytes per stream and step (what a step produces)
+    // reach the memory as partial writes -- 2 % of the bytes cost the LDS-DMA stream 19 % of its rate (0.88 against 0.72 ms per call with idle compute waves; with the
+    // same store instructions aimed at one resident line per stream: 0.72: profiles/r3_notes.md).
+    const bool emit_vec = ((((size_t)p.s16 | (size_t)p.af) & 15) == 0) && (p.out_pitch & 7) == 0;
+    const int emit_a = (int)((SEQ_LINE - (idx0 & (SEQ_LINE - 1))) & (SEQ_LINE - 1));  // segment samples n = emit_a (mod 64) start a line
+    auto s16_of = [](float e) { const float scaled = e * 32767.0f; return (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000; };
+    auto emit = [&](int g) {                                                         // g = n_grp: the segment's last, incomplete line
         if (g < 0) return;
-        const int srow = tid / SPS, k = tid % SPS, kr = g * SPS + k;
-        if (tid < 16 * SPS && kr >= seg_lo && kr < seg_hi && s0 + srow < p.n_streams) {
-            const float e = lds_out[(g % 3) * (16 * SEQ_OUTP) + srow * SEQ_OUTP + k];
+        if (emit_vec) {
+            const int ei = tid - 64;                                                 // waves 1 and 2 (wave 0 runs the de-emphasis)
+            if (ei < 0 || ei >= 16 * (SEQ_LINE / 8)) return;
+            // lines k = 0, 1, ...: samples [emit_a + 64 (k - 1), emit_a + 64 k); complete once sample emit_a + 64 k - 1 exists (floor divisions: arithmetic shifts)
+            const int k_before = (g * SPS - emit_a) >> 6, k_now = g < n_grp ? ((g + 1) * SPS - emit_a) >> 6 : k_before + 1;
+            if (k_now <= k_before) return;                                           // (at most one line per step: SPS < 64)
+            static_assert(4 * SEQ_TPG < SEQ_LINE && SEQ_LINE == 64, "one line per step at most");
+            const int srow = ei / (SEQ_LINE / 8);
+            const int n0 = emit_a + SEQ_LINE * (k_now - 1) + 8 * (ei % (SEQ_LINE / 8));   // this lane's 8 samples
+            if (s0 + srow >= p.n_streams || n0 + 8 <= seg_lo || n0 >= seg_hi) return;
+            const float *src = lds_out + srow * SEQ_OUTP;
+            float e[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) e[i] = src[(n0 + i + SEQ_OUTR) % SEQ_OUTR];  // (n0 >= -64)
+            const size_t o = (size_t)(s0 + srow) * p.out_pitch + (size_t)(idx0 + n0);
+            if (n0 >= seg_lo && n0 + 8 <= seg_hi) {
+                int v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = s16_of(e[i]);                     // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
+                uint4 w;
+                w.x = (unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16); w.y = (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16);
+                w.z = (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16); w.w = (unsigned)(v[6] & 0xffff) | ((unsigned)v[7] << 16);
+                *reinterpret_cast<uint4 *>(p.s16 + o) = w;
+                if (p.af) { *reinterpret_cast<float4 *>(p.af + o) = make_float4(e[0], e[1], e[2], e[3]); *reinterpret_cast<float4 *>(p.af + o + 4) = make_float4(e[4], e[5], e[6], e[7]); }
+            } else {                                                                 // cut by the call's first / last sample or by the segment's ends
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (n0 + i >= seg_lo && n0 + i < seg_hi) { p.s16[o + i] = (int16_t)s16_of(e[i]); if (p.af) p.af[o + i] = e[i]; }
+            }
+            return;
+        }
+        if (tid < EMIT_T0 || g >= n_grp) return;
+#pragma unroll
+        for (int e0 = 0; e0 < 16 * SPS; e0 += EMIT_N) {
+            const int ei = e0 + tid - EMIT_T0;
+            const int srow = ei / SPS, k = ei % SPS, kr = g * SPS + k;
+            if (ei >= 16 * SPS || kr < seg_lo || kr >= seg_hi || s0 + srow >= p.n_streams) continue;
+            const float e = lds_out[srow * SEQ_OUTP + (g % SEQ_OUTS) * SPS + k];
             const long long idx = idx0 + kr;
-            const float scaled = e * 32767.0f;                                       // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
-            const int iv = (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000;
-            p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)iv;
+            p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)s16_of(e);      // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
             if (p.af) p.af[(size_t)(s0 + srow) * p.out_pitch + idx] = e;
         }
     };
+#ifdef WFM_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
     for (int gi = -n_warm; gi < n_grp; gi++) {
         const int it = gi * TPG + wv;
-        float *lout = lds_out + ((gi + 3) % 3) * (16 * SEQ_OUTP);
-        if (it < n_it) {
+        float *lout = lds_out + ((gi + SEQ_OUTS) % SEQ_OUTS) * SPS;                   // this step's samples in every stream's ring
+        if (computes && it < n_it && (WFM_DIAG < 3)) {
             const long long ws = wg + (long long)wv * tstride;
             const long long n0 = (ws + p.B2) >> 1;                                   // global index of the window's first sample
             const int off = (int)(n0 & 1023);
@@ -344,10 +447,15 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
 #pragma unroll
             for (int ks = 0; ks < WFM_NK; ks++) {
                 unsigned a = a0 + 64u * ks; a = min(a, a - (unsigned)SEQ_RB);
-                Bf[ks] = *reinterpret_cast<const v4i *>(lrow + a) ^ (int)0x80808080;
+                if (WFM_DIAG == 1) Bf[ks] = v4i{(int)a, lane, ks, gi};
+                else Bf[ks] = *reinterpret_cast<const v4i *>(lrow + a) ^ (int)0x80808080;
             }
             v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
             const bool lo_lane = q < hq;
+            if (WFM_DIAG == 2) {
+#pragma unroll
+                for (int ks = 0; ks < WFM_NK; ks++) { acc[ks % 3] += Bf[ks]; snap[ks % 3] ^= Bf[ks]; }
+            } else
             switch (kb) {
                 case 0: wfm_chain<0>(A, Bf, lo_lane, acc, snap); break;
                 case 1: wfm_chain<1>(A, Bf, lo_lane, acc, snap); break;
@@ -382,12 +490,17 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
             rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
             lout[col * SEQ_OUTP + 4 * wv + q] = (den != 0.f) ? (K * num) * rd : 0.f;   // audio 4 * tile + q of stream col
         }
+        PROF_T(0)
         const long long wg_n = wg + (long long)TPG * tstride;
-        if (gi + 1 < n_grp) wait_for(wg_n + (long long)(TPG - 1) * tstride);
+        if (fetches && gi + 1 < n_grp) wait_for(wg_n + (long long)(TPG - 1) * tstride);
+        PROF_T(1)
         __syncthreads();
-        if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
-        emit(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
-        if (iir_wave) {                                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
+        PROF_T(2)
+        if (fetches && gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
+        PROF_T(3)
+        if (computes && WFM_DIAG != 4 && WFM_DIAG != 5) emit(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
+        PROF_T(4)
+        if (iir_wave && WFM_DIAG != 5) {                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
             const int lo = gi == 0 ? seg_lo : 0;                                     // samples [lo, hi) of the step exist in this call (warm-up steps: all)
             const int hi = gi < 0 ? SPS : min(SPS, seg_hi - gi * SPS);
             if (lo == 0 && (hi & 3) == 0) {
@@ -395,10 +508,10 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
                 const int nv = hi;                                                   // valid samples of the step (a multiple of 4 here; all except in a segment's last step)
                 float x[QL], z[QL], y[QL];
 #pragma unroll
-                for (int j = 0; j < QL; j += 4) {
-                    const float4 v = *reinterpret_cast<const float4 *>(row + j);
+                for (int j = 0; j < QL; j += 2) {                                   // (pairs: QL q + j is even and nv a multiple of 4, a pair is valid or not as a whole)
+                    const float2 v = *reinterpret_cast<const float2 *>(row + j);
                     const bool ok = QL * q + j < nv;                                 // samples behind the valid ones do not exist: feed zeros (their outputs are not stored)
-                    x[j] = ok ? v.x : 0.f; x[j + 1] = ok ? v.y : 0.f; x[j + 2] = ok ? v.z : 0.f; x[j + 3] = ok ? v.w : 0.f;
+                    x[j] = ok ? v.x : 0.f; x[j + 1] = ok ? v.y : 0.f;
                 }
                 z[0] = p.alpha * x[0];
 #pragma unroll
@@ -412,11 +525,13 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
 #pragma unroll
                 for (int j = 0; j < QL; j++) y[j] = z[j] + bp[j + 1] * S;
 #pragma unroll
-                for (int j = 0; j < QL; j += 4) *reinterpret_cast<float4 *>(row + j) = make_float4(y[j], y[j + 1], y[j + 2], y[j + 3]);
-                // new carried state = the value after the last VALID sample (nv - 1): it lives in quarter (nv - 1) / QL at position (nv - 1) % QL (3 or 7)
+                for (int j = 0; j < QL; j += 2) *reinterpret_cast<float2 *>(row + j) = make_float2(y[j], y[j + 1]);
+                // new carried state = the value after the last VALID sample (nv - 1): it lives in quarter (nv - 1) / QL at position (nv - 1) % QL (odd)
                 if (nv > 0) {
                     const int lq = (nv - 1) / QL, lj = (nv - 1) % QL;
-                    const float ylast = lj == 3 ? y[3] : y[QL - 1];
+                    float ylast = y[QL - 1];
+#pragma unroll
+                    for (int j = 1; j < QL - 1; j += 2) if (lj == j) ylast = y[j];
                     yst = __shfl(ylast, col + 16 * lq, 64);
                 }
             } else {                                                                 // a call's first / last step with a partial tile: sample by sample over the valid range
@@ -428,10 +543,17 @@ __global__ __launch_bounds__(64 * SEQ_TPG) void k_wfm_mfma_seq(const uint8_t *__
                 yst = __shfl(yv, col, 64);
             }
         }
+        PROF_T(5)
+#ifdef WFM_PROF
+        prof[6] += 1;
+#endif
         wg = wg_n; wslot += TPG * tstride; if (wslot >= SEQ_RB) wslot -= SEQ_RB;
     }
+#ifdef WFM_PROF
+    if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
+#endif
     __syncthreads();
-    emit(n_grp - 1);
+    if (computes) { emit(n_grp - 1); emit(n_grp); }
     if (blockIdx.y + 1 == gridDim.y) {                                               // the call's last segment: what the next call starts from
         if (iir_lane && s0 + lane < p.n_streams) p.last_out[s0 + lane] = yst;
         // the block's newest 512 bytes -> bytes 512.. of the other head buffer (16 streams x 32 pieces of 16 bytes)
@@ -479,18 +601,18 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
     int n_seg = (n_cu + n_wsb - 1) / n_wsb; if (n_seg < 1) n_seg = 1;
     if (n_seg > sp.n_tiles / 64) n_seg = sp.n_tiles / 64;
     if (n_seg < 1) n_seg = 1;
-    sp.tiles_per_seg = ((sp.n_tiles + n_seg - 1) / n_seg + 7) / 8 * 8;
+    sp.tiles_per_seg = ((sp.n_tiles + n_seg - 1) / n_seg + SEQ_TPG - 1) / SEQ_TPG * SEQ_TPG;
     n_seg = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
     sp.alpha = back.alpha; sp.last_in = back.last_in; sp.last_out = back.last_out; sp.s16 = back.s16; sp.af = back.af; sp.out_pitch = back.out_pitch;
     sp.j_first = j_first; sp.n_audio = n_audio; sp.head_in = back.head_in; sp.head_out = back.head_out;
-    const size_t lds = (size_t)16 * SEQ_RP + 3 * 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
+    const size_t lds = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
     { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq, lds); if (arc) return arc; }
     // timing events ride on the kernel's own dispatch (start / completion signal of its packet): hipEventRecord in front of and behind it would put two
     // marker packets into the stream, ~10 us of bubbles that the un-profiled path does not have
     if (ev_begin && ev_end)
-        hipExtLaunchKernelGGL(k_wfm_mfma_seq, dim3(n_wsb, n_seg), dim3(64 * SEQ_TPG), lds, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        hipExtLaunchKernelGGL(k_wfm_mfma_seq, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
     else
-        hipLaunchKernelGGL(k_wfm_mfma_seq, dim3(n_wsb, n_seg), dim3(64 * SEQ_TPG), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        hipLaunchKernelGGL(k_wfm_mfma_seq, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
     CSDR_LAUNCH_CHECK();
     if (T < 256 || (T & 7)) {      // a block shorter than the history, or a ragged last block: the kernel's epilogue skipped the copy
         hipLaunchKernelGGL(k_wfm_roll_head, dim3(n_streams), dim3(256), 0, st, in, in_pitch, 2LL * T, back.head_in, back.head_out);
@@ -500,6 +622,15 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
 }
 
 } // namespace csdr_amd
+
+#ifdef WFM_PROF
+extern "C" int csdr_amd_debug_wfm_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wfm_prof), sizeof(unsigned long long) * SEQ_NW * 8) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[SEQ_NW * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wfm_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 // Test hook (tests/test_mfma_table_cpu.py): ONE tile of the sequential kernel on the CPU -- the phase-independent weight set, the
 // snapshot / lane-group masking at a chunk boundary, the post factors C_m D^e and the prefix-sum offset constants, exactly as
