@@ -54,3 +54,32 @@ struct csdr_amd_ctx {
     void *pinned_acquire(size_t bytes);
     int pinned_upload(void *dst_dev, size_t bytes);
 };
+
+// ---- LDS-DMA row-step shared by the ring kernels (wfm_mfma.hip, ddc_mfma.hip).  Device code only.
+#ifdef __HIPCC__
+namespace csdr_amd {
+// One row-step of a fetching wave as one piece of code: R rows, 1 KiB each (lane l: bytes 16 l .. 16 l + 15 of the run at sbase + vo[r]), LDS destinations RP bytes
+// apart from la0 on.  M0 (the LDS destination) is saved once and stepped by s_add_u32, no branch between the pieces, `nt`: every byte is read once.  (Hand-written:
+// the builtin form makes the compiler serialise the DMA with the LDS reads of other ring positions; vmcnt is counted by the callers.)
+template <int R, int RP>
+__device__ __forceinline__ void dma_rows(const uint32_t (&vo)[R], const uint8_t *sbase, uint32_t la0)
+{
+    uint32_t keep;
+    static_assert(R == 2 || R == 4 || R == 8, "rows per fetching wave");
+#define DMA_NEXT(k) "s_add_u32 m0, m0, %[rp]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #k "], %[sb] nt\n\t"
+    if constexpr (R == 2)
+        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t" DMA_NEXT(1) "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
+    else if constexpr (R == 4)
+        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t" DMA_NEXT(1) DMA_NEXT(2) DMA_NEXT(3) "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
+    else
+        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t"
+                     DMA_NEXT(1) DMA_NEXT(2) DMA_NEXT(3) DMA_NEXT(4) DMA_NEXT(5) DMA_NEXT(6) DMA_NEXT(7) "s_mov_b32 m0, %[keep]"
+                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4]), [v5] "v"(vo[5]), [v6] "v"(vo[6]), [v7] "v"(vo[7]),
+                       [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
+#undef DMA_NEXT
+}
+
+} // namespace csdr_amd
+#endif

@@ -261,12 +261,23 @@ struct DdcParams {
 // digit planes the de-emphasis FIR reads.  y[k - 1] of a tile's first output comes from the previous tile of the same workgroup (re-reduced from the other team's
 // partial sums, or handed over through `ylast` across groups); the FIRST output of a segment has its predecessor in another workgroup: it is left to
 // k_nfm_demod_boundary, for which the segment's first and last complex samples are still stored.
+#ifdef DDC_PROF
+// diagnostic build (tools/diag_nfm.py): shader-clock cycles per wave summed over the launch: [wave][compute, wait vmcnt, barrier, DMA issue, reduce / demodulate / store, groups]
+__device__ unsigned long long g_ddc_prof[8][8];
+#define DPROF_T(k) { const long long t_now = __builtin_readcyclecounter(); prof[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define DPROF_T(k)
+#endif
+
 template <int RBL, int NT, bool FUSE>
 __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
                                                        const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
                                                        const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p, DdcFuse fz)
 {
-    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, SPW = 16 / (4 * NT);                   // SPW: streams fetched per wave in a row-step
+    // FUSE: two waves of every team own the epilogue (roles A and B below) and the other two fetch: an LDS-DMA issue stalls its wave for as long as the memory
+    // takes once the CU's 64 pieces are in flight (profiles/r3_notes.md), the epilogue is ~1200 cycles on the group's critical path -- a wave with both was the
+    // last at every barrier.  Team 0: roles on K-ranges 0 / 2, team 1: on 1 / 3, so every SIMD hosts one of each kind.
+    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, NFW = FUSE ? 2 * NT : 4 * NT, SPW = 16 / NFW;   // fetching waves; streams fetched per fetching wave in a row-step
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
     float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][4 waves][64 lanes]
@@ -275,6 +286,9 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
     float2 *ylast = reinterpret_cast<float2 *>(lcum + DDC_NGRAN * 16);                // FUSE: [2][16] last sample of the previous group's last tile
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     const int team = wv >> 2, w = wv & 3;
+    const bool has_role = FUSE && ((w & 1) == (team & 1));                             // wave uniform
+    const bool fetches = !has_role;
+    const int fw = FUSE ? 2 * team + (w >> 1) : wv;                                    // index among the fetching waves
     for (int i = tid; i < DDC_NGRAN * 16; i += 256 * NT) lcum[i] = cum[i];            // (visible after the barrier that ends the prologue)
     const int sb = blockIdx.x;
     const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
@@ -311,7 +325,7 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
     uint32_t voff[SPW], voff_h[SPW];
 #pragma unroll
     for (int r = 0; r < SPW; r++) {
-        const int srow = max(min(sb * 16 + SPW * wv + r, last_stream) - sb * 16, 0); // rows past the last stream re-read it (results discarded)
+        const int srow = max(min(sb * 16 + SPW * fw + r, last_stream) - sb * 16, 0); // rows past the last stream re-read it (results discarded)
         voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
         voff_h[r] = (uint32_t)srow * (uint32_t)(2 * DDC_HIST) + 16u * lane;
     }
@@ -320,31 +334,14 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         // F < 0: a run of the history (2 KiB per stream = positions [-2048, 0); a window may start up to 7 D samples in front of that: those bytes feed only
         // outputs the previous call has already delivered -- any readable address will do)
         const bool head = F < 0;                                                     // wave uniform; two straight-line copies (a select between the two offset arrays sent them to scratch)
-        const uint32_t ldst = lds_in_addr + (SPW * wv) * RP + (uint32_t)(F & (RB - 1));
-        // nt: the input is read exactly once.  Inline asm with hand-counted vmcnt (see wfm_mfma.hip: the builtin form makes the
-        // compiler serialise the DMA with the LDS reads of the other ring positions).
+        const uint32_t ldst = lds_in_addr + (SPW * fw) * RP + (uint32_t)(F & (RB - 1));
         if (head) {
             const uint8_t *sbase = p.hist_in + (size_t)sb * 16 * (2 * DDC_HIST) + (F < -2 * DDC_HIST ? 0 : F + 2 * DDC_HIST);
-#pragma unroll
-            for (int r = 0; r < SPW; r++) {
-                const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
-                uint32_t keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(voff_h[r]), "s"(sbase), "s"(la) : "memory");
-            }
-        } else {
-            const uint8_t *sbase = sblock + F;
-#pragma unroll
-            for (int r = 0; r < SPW; r++) {
-                const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
-                uint32_t keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(voff[r]), "s"(sbase), "s"(la) : "memory");
-            }
-        }
+            dma_rows<SPW, RP>(voff_h, sbase, __builtin_amdgcn_readfirstlane((int)ldst));
+        } else dma_rows<SPW, RP>(voff, sblock + F, __builtin_amdgcn_readfirstlane((int)ldst));
         F += 1024;
     };
-    // every wave issues exactly SPW VMEM loads per row-step and they return in order: vmcnt(SPW n) leaves at most the n newest row-steps in flight
+    // every fetching wave issues exactly SPW VMEM loads per row-step and they return in order: vmcnt(SPW n) leaves at most the n newest row-steps in flight
     auto wait_newer = [&](long long newer) {
         switch ((int)newer) {
             case 0: wait_vmcnt<0>(); break;
@@ -364,11 +361,16 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         if (newer > 7) newer = 7;
         wait_newer(newer);
     };
-    while (F < F_end && F + 1024 <= wg + RB) row_step();
-    wait_for(wg + (long long)(NT - 1) * tstride);
+    if (fetches) {
+        while (F < F_end && F + 1024 <= wg + RB) row_step();
+        wait_for(wg + (long long)(NT - 1) * tstride);
+    }
     __syncthreads();
     const uint8_t *lrow = lds_in + col * RP;
     const int kk_seg = (int)(8 * t0 - p.k_out0);                                     // output index of the segment's first tile's first output (< 0: a partial first tile)
+#ifdef DDC_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#endif
     for (int gi = 0; gi < n_grp; gi++, wg += (long long)NT * tstride) {
         const int it = gi * NT + team;                                               // this team's tile of the group
         const bool active = it < n_it;
@@ -435,19 +437,25 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         rbuf[w * 64 + lane] = part;
         // ---- the next group's windows must have landed before anyone passes the barrier; the ring space behind them is refilled right after
         const long long wg_n = wg + (long long)NT * tstride;
+        DPROF_T(0)
 #if DDC_DIAG != 2
-        if (gi + 1 < n_grp) wait_for(wg_n + (long long)(NT - 1) * tstride);
+        if (fetches && gi + 1 < n_grp) wait_for(wg_n + (long long)(NT - 1) * tstride);
 #endif
+        DPROF_T(1)
         __syncthreads();
+        DPROF_T(2)
 #if DDC_DIAG != 2
-        if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + RB) row_step(); }
+        if (fetches && gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + RB) row_step(); }
 #endif
-        // ---- reduction of the four K-range shares and store: the waves of a team take turns.  FUSE: TWO waves of the team share the epilogue -- role A (wave gi mod 4)
-        // demodulates the tile's even outputs (it needs the predecessor logic), role B (wave gi + 2 mod 4) the odd ones: the reducer is on every group's critical path (the
-        // other waves wait for it at the next barrier), and fmdemod_quadri_cf | limit_ff + the digit split is two thirds of its work.  Both sum the same partials in the
-        // same order: the values are those of the one-wave epilogue, bit for bit.
-        const bool role_a = w == (gi & 3), role_b = FUSE && w == ((gi + 2) & 3);
-        if (active && (role_a || role_b)) {
+        DPROF_T(3)
+        // ---- reduction of the four K-range shares and store.  Plain front end: the waves of a team take turns.  FUSE: TWO fixed waves of the team share the epilogue
+        // -- role A demodulates the tile's even outputs (it needs the predecessor logic), role B the odd ones; fmdemod_quadri_cf | limit_ff + the digit split is two
+        // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
+        const bool role_a = FUSE ? w == (team & 1) : w == (gi & 3), role_b = FUSE && w == (team & 1) + 2;
+#ifndef DDC_NOSTORE
+#define DDC_NOSTORE 0       // experiment: 1 = the epilogue computes but stores nothing (what the stores cost the input stream)
+#endif
+        if (active && (role_a || role_b) && !(DDC_NOSTORE && kk_seg != -12345)) {
             const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
             const int stream = sb * 16 + col;
             const float2 y0 = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
@@ -498,7 +506,11 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                 }
             }
         }
+        DPROF_T(4)
     }
+#ifdef DDC_PROF
+    if (lane == 0 && wv < 8) { for (int k = 0; k < 5; k++) atomicAdd(&g_ddc_prof[wv][k], (unsigned long long)prof[k]); atomicAdd(&g_ddc_prof[wv][5], (unsigned long long)n_grp); }
+#endif
     if (p.hist_out && blockIdx.y + 1 == gridDim.y) {                                 // 16 streams x 2 KiB: the next call's history
         for (int i = tid; i < 16 * (2 * DDC_HIST / 16); i += 256 * NT) {
             const int srow = i / (2 * DDC_HIST / 16), piece = i % (2 * DDC_HIST / 16);
@@ -508,6 +520,15 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         }
     }
 }
+
+#ifdef DDC_PROF
+extern "C" int csdr_amd_debug_ddc_prof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[64]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ddc_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 // Plain evaluation of the same model, one WAVE per output (lanes split the taps): outputs [ka0, ka0 + na) and [kb0, kb0 + nb) of every stream.
 // Samples before the block come from the history buffer (the previous blocks' last DDC_HIST samples).

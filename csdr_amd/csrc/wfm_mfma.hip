@@ -136,24 +136,6 @@ __device__ __forceinline__ void tile_rows(const v4i (&acc)[3], const v4i (&snap)
     }
 }
 
-// One row-step of a fetching wave in one piece of code: R rows, 1 KiB each, LDS destinations RP bytes apart (M0 saved once, stepped by s_add_u32), no branch between the pieces.
-template <int R, int RP>
-__device__ __forceinline__ void dma_rows(const uint32_t (&vo)[R], const uint8_t *sbase, uint32_t la0)
-{
-    uint32_t keep;
-    static_assert(R == 2 || R == 8, "rows per fetching wave");
-#define DMA_NEXT(k) "s_add_u32 m0, m0, %[rp]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #k "], %[sb] nt\n\t"
-    if constexpr (R == 2)
-        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t" DMA_NEXT(1) "s_mov_b32 m0, %[keep]"
-                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
-    else
-        asm volatile("s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[la]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[sb] nt\n\t"
-                     DMA_NEXT(1) DMA_NEXT(2) DMA_NEXT(3) DMA_NEXT(4) DMA_NEXT(5) DMA_NEXT(6) DMA_NEXT(7) "s_mov_b32 m0, %[keep]"
-                     : [keep] "=&s"(keep) : [v0] "v"(vo[0]), [v1] "v"(vo[1]), [v2] "v"(vo[2]), [v3] "v"(vo[3]), [v4] "v"(vo[4]), [v5] "v"(vo[5]), [v6] "v"(vo[6]), [v7] "v"(vo[7]),
-                       [sb] "s"(sbase), [la] "s"(la0), [rp] "n"(RP) : "memory", "scc");
-#undef DMA_NEXT
-}
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int KB>
