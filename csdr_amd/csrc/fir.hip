@@ -184,7 +184,10 @@ __global__ __launch_bounds__(64) void k_fir_poly(const T *__restrict__ in, T *__
             }
         }
         const int outs = min(TO, n_out - t * TO);
-        T *dst = out_s + (size_t)t * TO + R * lane;
+#ifndef FIR_DIAG
+#define FIR_DIAG 0      // experiments: 1 = every tile's results go to the stream's first tile (stores that never leave L2): what the output stream costs the input stream
+#endif
+        T *dst = out_s + (size_t)(FIR_DIAG == 1 ? 0 : t) * TO + R * lane;
         if (R * lane + R <= outs && sizeof(T) * R >= 16 && (((uintptr_t)dst) & 15) == 0) {          // whole lane: 16-byte stores
             float4 *d4 = reinterpret_cast<float4 *>(dst);
             const float *af = reinterpret_cast<const float *>(acc);
