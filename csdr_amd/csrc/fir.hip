@@ -77,6 +77,9 @@ template <> __device__ __forceinline__ float2 zero_of<float2>() { return make_fl
 __device__ __forceinline__ void mac(float &acc, float v, float h) { acc = fmaf(v, h, acc); }
 __device__ __forceinline__ void mac(float2 &acc, float2 v, float h) { acc.x = fmaf(v.x, h, acc.x); acc.y = fmaf(v.y, h, acc.y); }
 
+#ifndef FIR_STORE_TILES
+#define FIR_STORE_TILES 8
+#endif
 template <typename T, int R, int U>
 __global__ __launch_bounds__(64) void k_fir_poly(const T *__restrict__ in, T *__restrict__ out, int n_out, size_t in_pitch, size_t out_pitch,
                                                  int D, const float *__restrict__ taps, int ntaps, int NA, int Q, int n_tiles, int tiles_per_wg)
@@ -164,8 +167,7 @@ __global__ __launch_bounds__(64) void k_fir_poly(const T *__restrict__ in, T *__
 #pragma unroll
             for (int r = 0; r < R; r++) mac(acc[r], (r + j < R) ? w0[r + j] : w1[r + j - R], h[j]);
     };
-    auto compute = [&](int t) {
-        T acc[R];
+    auto compute = [&](int t, T (&acc)[R]) {
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = zero_of<T>();
         const char *rowb = reinterpret_cast<const char *>(x);
@@ -183,10 +185,12 @@ __global__ __launch_bounds__(64) void k_fir_poly(const T *__restrict__ in, T *__
                 block(acc, wb, wa, h + R);
             }
         }
-        const int outs = min(TO, n_out - t * TO);
+    };
 #ifndef FIR_DIAG
 #define FIR_DIAG 0      // experiments: 1 = every tile's results go to the stream's first tile (stores that never leave L2): what the output stream costs the input stream
 #endif
+    auto store = [&](int t, const T (&acc)[R]) {
+        const int outs = min(TO, n_out - t * TO);
         T *dst = out_s + (size_t)(FIR_DIAG == 1 ? 0 : t) * TO + R * lane;
         if (R * lane + R <= outs && sizeof(T) * R >= 16 && (((uintptr_t)dst) & 15) == 0) {          // whole lane: 16-byte stores
             float4 *d4 = reinterpret_cast<float4 *>(dst);
@@ -198,14 +202,25 @@ __global__ __launch_bounds__(64) void k_fir_poly(const T *__restrict__ in, T *__
             for (int r = 0; r < R; r++) if (R * lane + r < outs) dst[r] = acc[r];
         }
     };
+    // The results of KD consecutive tiles are stored together (KD x 64 R outputs, contiguous): beside a saturated read stream the memory charges a store event of 2 KiB
+    // almost what it charges one of 128 bytes per byte, one of 4 - 8 KiB half of that (tools/microbench/dma_write_mix.hip, profiles/r3_notes.md).
+    constexpr int KD = FIR_STORE_TILES;
     __syncthreads();
     fetch(va, tile);
-    for (; tile < tile_end; tile++) {
-        stage(va);
-        __syncthreads();
-        if (tile + 1 < tile_end) fetch(va, tile + 1);
-        compute(tile);
-        __syncthreads();                                           // everyone is done reading x[][] before the next tile overwrites it
+    for (; tile < tile_end; tile += KD) {
+        T hold[KD][R];
+#pragma unroll
+        for (int j = 0; j < KD; j++) {
+            if (tile + j < tile_end) {                             // (wave uniform)
+                stage(va);
+                __syncthreads();
+                if (tile + j + 1 < tile_end) fetch(va, tile + j + 1);
+                compute(tile + j, hold[j]);
+                __syncthreads();                                   // everyone is done reading x[][] before the next tile overwrites it
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KD; j++) if (tile + j < tile_end) store(tile + j, hold[j]);
     }
 }
 
