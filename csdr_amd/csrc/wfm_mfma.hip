@@ -174,8 +174,9 @@ __device__ __forceinline__ void wfm_chain(const v4i (&A)[WFM_NK * 3], const v4i 
 // straight piece of code (M0 saved once, stepped by s_add: dma_rows), and the six compute waves run tile -> barrier -> tile.
 //
 // The back end of the chain runs inside: the workgroup produces its streams' audio in time order, so the one-pole de-emphasis
-// (libcsdr.c:1081-1097) is a state carried in wave 0 from step to step (wave 0 takes no part in the stores), and convert_f_s16 + the stores
-// follow one step later out of a ring of SEQ_OUTS steps' samples per stream: the demodulated audio never goes to HBM as floats.  A segment
+// (libcsdr.c:1081-1097) is a state carried in wave 0 from step to step, and convert_f_s16 follows one step later out of a ring of SEQ_OUTS
+// steps' samples per stream, done by the loader waves, which hold the s16 lines in registers until 4 KiB per stream go out together (see "Stores"
+// in the kernel): the demodulated audio never goes to HBM as floats.  A segment
 // that starts in the middle of a call demodulates two steps (48 audio samples) ahead of its range from zero state without storing them --
 // the filter forgets as 0.706^k --; the first segment starts from the exact state the previous call left, the last one leaves its own.
 //
@@ -213,10 +214,10 @@ constexpr int SEQ_NGR = 4 * WFM_NK;        // 16-byte granules per window
 #define SEQ_NLD_N 2
 #endif
 constexpr int SEQ_TPG = SEQ_TPG_N;         // tiles per step = compute waves per workgroup
-constexpr int SEQ_NLD = SEQ_NLD_N;         // loader waves: they issue the LDS-DMA (a wave stalls 200-300 cycles per 1-KiB piece while the CU's address path is busy) and
-                                           // run the de-emphasis, so that the compute waves never wait at an issue; 0 = the compute waves fetch for themselves
+constexpr int SEQ_NLD = SEQ_NLD_N;         // loader waves: they issue the LDS-DMA (a wave stalls 160-330 cycles per 1-KiB piece once the CU's 64 pieces are in flight), so that
+                                           // the compute waves never wait at an issue, and they collect the finished audio in their otherwise empty registers
 constexpr int SEQ_NW = SEQ_TPG + SEQ_NLD;  // waves per workgroup
-constexpr int SEQ_NLW = SEQ_NLD ? SEQ_NLD : SEQ_TPG;   // waves that fetch
+constexpr int SEQ_NLW = SEQ_NLD;           // waves that fetch
 constexpr int SEQ_LINE = 64;               // audio samples stored at a time per stream: one 128-byte line of the s16 output row
 constexpr int SEQ_OUTS = (SEQ_LINE - 1 + 3 * 4 * SEQ_TPG + 4 * SEQ_TPG - 1) / (4 * SEQ_TPG);   // audio staging: a ring of this many steps' samples per stream (a step = 4 SEQ_TPG
 constexpr int SEQ_OUTR = SEQ_OUTS * 4 * SEQ_TPG;   // samples): written by the tile waves, filtered in place by the de-emphasis one step later, stored one step after that in whole
@@ -244,9 +245,8 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 16 x SEQ_OUTP floats
     float *lcum = lds_out + 16 * SEQ_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
-    const bool computes = wv < TPG;                                                  // wave uniform roles
-    const bool fetches = SEQ_NLD ? wv >= TPG : true;
-    const int fw = SEQ_NLD ? wv - TPG : wv;                                          // index among the fetching waves
+    const bool fetches = wv >= TPG;
+    const int fw = wv - TPG;                                                         // index among the fetching waves
     for (int i = tid; i < (SEQ_NGR + 1) * 16; i += NTHR) lcum[i] = cum[i];
     const int sb = blockIdx.x;
     const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
@@ -353,50 +353,20 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     const int seg_lo = (int)max(0LL, p.j_first - 4 * t0);                           // > 0 only in the call's first segment, when j_first is not a multiple of 4
     const int seg_hi = (int)min(4LL * n_it, j_end - 4 * t0);                        // samples of the segment that exist in this call
     const long long idx0 = 4 * t0 - p.j_first;                                      // output index of the segment's sample 0
-    // convert_f_s16 + store of step g's 16 x SPS samples.  With loader waves, wave 0 (which runs the de-emphasis) is left out: the other compute waves share the samples
-    constexpr int EMIT_T0 = SEQ_NLD ? 64 : 0, EMIT_N = SEQ_NLD ? 64 * (TPG - 1) : NTHR;
-    // Stores.  Usual case (16-byte aligned rows): whole 128-byte LINES of the s16 output rows, 64 samples, 8 lanes x 16 bytes each -- lines of the OUTPUT row, whatever
-    // the call's first sample is: after step g the line whose last sample lies in step g is complete (the same step for all 16 streams: 16 lines = 2 waves' worth of
-    // lanes, in 3 of 8 steps); it may start up to 63 samples back, hence the ring of SEQ_OUTS steps.  Why lines: 48 bytes per stream and step (what a step produces)
-    // reach the memory as partial writes -- 2 % of the bytes cost the LDS-DMA stream 19 % of its rate (0.88 against 0.72 ms per call with idle compute waves; with the
-    // same store instructions aimed at one resident line per stream: 0.72: profiles/r3_notes.md).
+    // ---- Stores (convert_f_s16, libcsdr.c:2397, x86 truncation semantics).  Usual case (16-byte aligned rows; emit_vec): the LOADER waves take the audio out of the
+    // staging ring, one step after the de-emphasis, in whole 128-byte LINES of the s16 output row (64 samples, 8 lanes x 16 bytes; lines of the OUTPUT row, whatever the
+    // call's first sample is: after step g the line whose last sample lies in step g is complete -- the same step for all 16 streams; it may start up to 63 samples
+    // back, hence the ring of SEQ_OUTS steps) and keep them in registers -- a loader uses none otherwise -- until 32 lines = 4 KiB per stream are together.  Why: beside a
+    // saturated read stream the memory charges 2 % of the bytes written as stores with 17-20 % of the read rate, whatever the cache policy or the instruction count,
+    // nothing if the lines stay in L2, half of it for 4 KiB per row at a time, a quarter for 8 KiB (tools/microbench/dma_write_mix.hip, profiles/r3_notes.md).
+    // Lines cut by the call's first / last sample or the segment's ends, and every line when the float audio is wanted too, are stored at once.
     const bool emit_vec = ((((size_t)p.s16 | (size_t)p.af) & 15) == 0) && (p.out_pitch & 7) == 0;
     const int emit_a = (int)((SEQ_LINE - (idx0 & (SEQ_LINE - 1))) & (SEQ_LINE - 1));  // segment samples n = emit_a (mod 64) start a line
     auto s16_of = [](float e) { const float scaled = e * 32767.0f; return (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000; };
-    auto emit = [&](int g) {                                                         // g = n_grp: the segment's last, incomplete line
-        if (g < 0) return;
-        if (emit_vec) {
-            const int ei = tid - 64;                                                 // waves 1 and 2 (wave 0 runs the de-emphasis)
-            if (ei < 0 || ei >= 16 * (SEQ_LINE / 8)) return;
-            // lines k = 0, 1, ...: samples [emit_a + 64 (k - 1), emit_a + 64 k); complete once sample emit_a + 64 k - 1 exists (floor divisions: arithmetic shifts)
-            const int k_before = (g * SPS - emit_a) >> 6, k_now = g < n_grp ? ((g + 1) * SPS - emit_a) >> 6 : k_before + 1;
-            if (k_now <= k_before) return;                                           // (at most one line per step: SPS < 64)
-            static_assert(4 * SEQ_TPG < SEQ_LINE && SEQ_LINE == 64, "one line per step at most");
-            const int srow = ei / (SEQ_LINE / 8);
-            const int n0 = emit_a + SEQ_LINE * (k_now - 1) + 8 * (ei % (SEQ_LINE / 8));   // this lane's 8 samples
-            if (s0 + srow >= p.n_streams || n0 + 8 <= seg_lo || n0 >= seg_hi) return;
-            const float *src = lds_out + srow * SEQ_OUTP;
-            float e[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) e[i] = src[(n0 + i + SEQ_OUTR) % SEQ_OUTR];  // (n0 >= -64)
-            const size_t o = (size_t)(s0 + srow) * p.out_pitch + (size_t)(idx0 + n0);
-            if (n0 >= seg_lo && n0 + 8 <= seg_hi) {
-                int v[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) v[i] = s16_of(e[i]);                     // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
-                uint4 w;
-                w.x = (unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16); w.y = (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16);
-                w.z = (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16); w.w = (unsigned)(v[6] & 0xffff) | ((unsigned)v[7] << 16);
-                *reinterpret_cast<uint4 *>(p.s16 + o) = w;
-                if (p.af) { *reinterpret_cast<float4 *>(p.af + o) = make_float4(e[0], e[1], e[2], e[3]); *reinterpret_cast<float4 *>(p.af + o + 4) = make_float4(e[4], e[5], e[6], e[7]); }
-            } else {                                                                 // cut by the call's first / last sample or by the segment's ends
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (n0 + i >= seg_lo && n0 + i < seg_hi) { p.s16[o + i] = (int16_t)s16_of(e[i]); if (p.af) p.af[o + i] = e[i]; }
-            }
-            return;
-        }
-        if (tid < EMIT_T0 || g >= n_grp) return;
+    // rows or pitches that are not 16-byte aligned: sample by sample, by the compute waves except wave 0 (which runs the de-emphasis)
+    constexpr int EMIT_T0 = 64, EMIT_N = 64 * (TPG - 1);
+    auto emit_scalar = [&](int g) {
+        if (g < 0 || g >= n_grp || tid < EMIT_T0) return;
 #pragma unroll
         for (int e0 = 0; e0 < 16 * SPS; e0 += EMIT_N) {
             const int ei = e0 + tid - EMIT_T0;
@@ -404,17 +374,97 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             if (ei >= 16 * SPS || kr < seg_lo || kr >= seg_hi || s0 + srow >= p.n_streams) continue;
             const float e = lds_out[srow * SEQ_OUTP + (g % SEQ_OUTS) * SPS + k];
             const long long idx = idx0 + kr;
-            p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)s16_of(e);      // convert_f_s16 libcsdr.c:2397 (x86 truncation semantics)
+            p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)s16_of(e);
             if (p.af) p.af[(size_t)(s0 + srow) * p.out_pitch + idx] = e;
         }
     };
 #ifdef WFM_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
 #endif
+    if (fetches) {
+        // ======================================================================== the loader waves: fetch, and take the finished audio out
+        typedef unsigned wfm_u4 __attribute__((ext_vector_type(4)));
+        constexpr int NST = 32;                                                      // lines held per stream: 4 KiB (48 lines = 6 KiB: 256 registers and spills, slower)
+        // (32 named registers, written through selects: any array or switch form went to scratch memory)
+#define WFM_ST_ALL(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
+                      X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+#define X(k) wfm_u4 st##k = {0u, 0u, 0u, 0u};
+        WFM_ST_ALL(X)
+#undef X
+        int n_st = 0, st_n0 = 0;                                                     // lines held, first sample of the first one (wave uniform)
+        const int srow = 8 * fw + (lane >> 3), pc = lane & 7;                        // this lane: stream row of the workgroup, 16-byte piece of a line
+        const bool row_ok = s0 + srow < p.n_streams;
+        int16_t *const orow = p.s16 + (size_t)(s0 + srow) * p.out_pitch;
+        auto flush = [&]() __attribute__((always_inline)) {
+#define X(j) if (j < n_st && row_ok) *reinterpret_cast<uint4 *>(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);
+            WFM_ST_ALL(X)
+#undef X
+            n_st = 0;
+        };
+        auto take_line = [&](int g) __attribute__((always_inline)) {                                              // g = n_grp: the segment's last, incomplete line
+            if (g < 0 || !emit_vec) return;
+            // lines k = 0, 1, ...: samples [emit_a + 64 (k - 1), emit_a + 64 k); complete once sample emit_a + 64 k - 1 exists (floor divisions: arithmetic shifts)
+            const int k_before = (g * SPS - emit_a) >> 6, k_now = g < n_grp ? ((g + 1) * SPS - emit_a) >> 6 : k_before + 1;
+            if (k_now <= k_before) return;                                           // (at most one line per step: SPS < 64)
+            static_assert(4 * SEQ_TPG < SEQ_LINE && SEQ_LINE == 64 && SEQ_NLD == 2, "one line per step at most; 8 streams x 8 pieces per loader");
+            const int nl = emit_a + SEQ_LINE * (k_now - 1), n0 = nl + 8 * pc;        // the line's first sample, this lane's
+            if (nl + SEQ_LINE <= seg_lo || nl >= seg_hi) return;
+            const float *src = lds_out + srow * SEQ_OUTP;
+            float e[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) e[i] = src[(n0 + i + SEQ_OUTR) % SEQ_OUTR];  // (n0 >= -64)
+            int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = s16_of(e[i]);
+            const wfm_u4 w = {(unsigned)(v[0] & 0xffff) | ((unsigned)v[1] << 16), (unsigned)(v[2] & 0xffff) | ((unsigned)v[3] << 16),
+                              (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16), (unsigned)(v[6] & 0xffff) | ((unsigned)v[7] << 16)};
+            if (nl >= seg_lo && nl + SEQ_LINE <= seg_hi && !p.af) {                  // a whole line (wave uniform): held
+                if (n_st == 0) st_n0 = nl;
+#define X(k) st##k = n_st == k ? w : st##k;           // (selects: a switch became a store through a pointer and sent the registers to scratch memory)
+                WFM_ST_ALL(X)
+#undef X
+                if (++n_st == NST) flush();
+            } else if (row_ok) {
+                const size_t o = (size_t)(idx0 + n0);                                // (may wrap below zero in front of a cut line's first valid sample: never dereferenced there)
+                float *const arow = p.af ? p.af + (size_t)(s0 + srow) * p.out_pitch : nullptr;
+                if (n0 >= seg_lo && n0 + 8 <= seg_hi) {
+                    *reinterpret_cast<uint4 *>(orow + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    if (arow) { *reinterpret_cast<float4 *>(arow + o) = make_float4(e[0], e[1], e[2], e[3]); *reinterpret_cast<float4 *>(arow + o + 4) = make_float4(e[4], e[5], e[6], e[7]); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (n0 + i >= seg_lo && n0 + i < seg_hi) { orow[o + i] = (int16_t)v[i]; if (arow) arow[o + i] = e[i]; }
+                }
+            }
+        };
+        for (int gi = -n_warm; gi < n_grp; gi++) {
+            PROF_T(0)
+            const long long wg_n = wg + (long long)TPG * tstride;
+            if (gi + 1 < n_grp) wait_for(wg_n + (long long)(TPG - 1) * tstride);
+            PROF_T(1)
+            __syncthreads();
+            PROF_T(2)
+            if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
+            PROF_T(3)
+            if (WFM_DIAG != 4) take_line(gi - 1);                                    // the previous step's audio: filtered by wave 0 before it came to this barrier
+            PROF_T(4)
+#ifdef WFM_PROF
+            prof[6] += 1;
+#endif
+            wg = wg_n;
+        }
+#ifdef WFM_PROF
+        if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
+#endif
+        __syncthreads();
+        if (WFM_DIAG != 4) { take_line(n_grp - 1); take_line(n_grp); flush(); }
+#undef WFM_ST_ALL
+    } else {
+    // ============================================================================ the compute waves
     for (int gi = -n_warm; gi < n_grp; gi++) {
         const int it = gi * TPG + wv;
         float *lout = lds_out + ((gi + SEQ_OUTS) % SEQ_OUTS) * SPS;                   // this step's samples in every stream's ring
-        if (computes && it < n_it && (WFM_DIAG < 3)) {
+        if (it < n_it && (WFM_DIAG < 3)) {
             const long long ws = wg + (long long)wv * tstride;
             const long long n0 = (ws + p.B2) >> 1;                                   // global index of the window's first sample
             const int off = (int)(n0 & 1023);
@@ -474,13 +524,9 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         }
         PROF_T(0)
         const long long wg_n = wg + (long long)TPG * tstride;
-        if (fetches && gi + 1 < n_grp) wait_for(wg_n + (long long)(TPG - 1) * tstride);
-        PROF_T(1)
         __syncthreads();
         PROF_T(2)
-        if (fetches && gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
-        PROF_T(3)
-        if (computes && WFM_DIAG != 4 && WFM_DIAG != 5) emit(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
+        if (!emit_vec) emit_scalar(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
         PROF_T(4)
         if (iir_wave && WFM_DIAG != 5) {                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
             const int lo = gi == 0 ? seg_lo : 0;                                     // samples [lo, hi) of the step exist in this call (warm-up steps: all)
@@ -535,7 +581,8 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
 #endif
     __syncthreads();
-    if (computes) { emit(n_grp - 1); emit(n_grp); }
+    if (!emit_vec) emit_scalar(n_grp - 1);
+    }
     if (blockIdx.y + 1 == gridDim.y) {                                               // the call's last segment: what the next call starts from
         if (iir_lane && s0 + lane < p.n_streams) p.last_out[s0 + lane] = yst;
         // the block's newest 512 bytes -> bytes 512.. of the other head buffer (16 streams x 32 pieces of 16 bytes)

@@ -70,6 +70,16 @@ __global__ __launch_bounds__(128) void k(const uint8_t *in, unsigned pitch, int 
                     pos += SCR; fill = 0;
                 }
             }
+        } else if (same_line == -1) {
+            // line major: one store instruction = one 128-byte line of 8 rows (lane = 8 row + piece), the LINES lines of an event back to back
+            for (int ev = 1; ev * per4 / 4 <= rounds; ev++) {
+                const int target = ev * per4 / 4;
+                while (*flag < target) __builtin_amdgcn_s_sleep(8);
+                for (int l = 0; l < LINES; l++)
+                    for (int half = 0; half < 2; half++)
+                        *reinterpret_cast<uint4 *>(ob + (size_t)(8 * half + (lane >> 3)) * out_pitch + pos + (size_t)l * 128 + (lane & 7) * 16) = v;
+                pos += LINES * 128;
+            }
         } else
         for (int ev = 1; ev * per4 / 4 <= rounds; ev++) {
             const int target = ev * per4 / 4;
@@ -93,7 +103,7 @@ template <int LINES, int RP = 0> void run(const uint8_t *d, unsigned pitch, uint
     for (int i = 0; i < 10; i++) hipLaunchKernelGGL((k<LINES, RP>), dim3(64, 4), dim3(128), lds, 0, d, pitch, rounds, out, out_pitch, same_line);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-    printf("reads policy %d, stores: %2d line(s) = %4d bytes per row and event%s: %.3f ms per pass over the 4.92 GB (%.2f TB/s of reads) [%d]\n", RP, LINES, LINES * 128, same_line == 1 ? " (always the same lines: never leave L2)" : same_line ? " staged in a scratch, flushed in pieces of" : "",
+    printf("reads policy %d, stores: %2d line(s) = %4d bytes per row and event%s: %.3f ms per pass over the 4.92 GB (%.2f TB/s of reads) [%d]\n", RP, LINES, LINES * 128, same_line == 1 ? " (always the same lines: never leave L2)" : same_line == -1 ? " (line major: each instruction one line of 8 rows)" : same_line ? " staged in a scratch, flushed in pieces of" : "",
            ms, 1024.0 * rounds * 4 * 1024 / (ms * 1e-3) / 1e12, same_line);
 }
 int main()
@@ -106,7 +116,7 @@ int main()
         run<0>(d, pitch, o, out_pitch, 0);
         run<1>(d, pitch, o, out_pitch, 0); run<1>(d, pitch, o, out_pitch, 1);
         run<8>(d, pitch, o, out_pitch, 0); run<32>(d, pitch, o, out_pitch, 0); run<128>(d, pitch, o, out_pitch, 0);
-        run<1>(d, pitch, o, out_pitch, 1024); run<1>(d, pitch, o, out_pitch, 4096); run<1>(d, pitch, o, out_pitch, 8192); run<1>(d, pitch, o, out_pitch, 16384);
+        run<8>(d, pitch, o, out_pitch, -1); run<32>(d, pitch, o, out_pitch, -1); run<64>(d, pitch, o, out_pitch, -1); run<128>(d, pitch, o, out_pitch, -1);
         run<0, 1>(d, pitch, o, out_pitch, 0); run<1, 1>(d, pitch, o, out_pitch, 0);
 
     }
