@@ -342,6 +342,45 @@ def test_c2_wfm_every_stream_block_and_segment(gpu, port):
         assert 0 <= n - ps.size <= 2 and vc.s16_diff(got[:m], ps[:m]).max() <= 1, "signal %d" % k
 
 
+def test_c2_wfm_every_stream_in_three_calls(gpu, port):
+    """The timed shape as a STREAM: the same 1024 x 2 400 256 batch handed over in three calls of unequal size (1139 + 600 + 605 chunks), s16 only, every call into
+    its own aligned rows -- what bench.py's timed loop does from its second step on: the later calls start in the history, their first audio sample falls anywhere in a
+    128-byte line of the output row, and every one of the 4 long time segments of a launch fills and flushes the loader waves' line registers several times.  Replicas
+    bit-identical; the 16 distinct rows +-1 LSB against the oracle's stream on every sample."""
+    import torch
+    S, T = 1024, 2344 * 1024
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.05), 0.5 / 10, "HAMMING")
+    sigs = [wfm_signal_u8(2100 + k, T) for k in range(16)]
+    x, idx = _replicated(sigs, S, T)
+    calls = [1139 * 1024, 600 * 1024, 605 * 1024]
+    n_audio_max = (max(calls) // 50 + 64 + 63) // 64 * 64
+    out = torch.zeros((S, n_audio_max), dtype=torch.int16, device="cuda")
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, max(calls))
+    assert w, gpu.err()
+    parts, pos = [], 0
+    try:
+        for k in calls:
+            n = L.csdr_amd_wfm_process(w, x.data_ptr() + 2 * pos, 2 * T, k, out.data_ptr(), None, n_audio_max)
+            assert n > 0, gpu.err()
+            gpu.sync()
+            parts.append(out[:, :n].clone())
+            pos += k
+        assert L.csdr_amd_wfm_kernel_name(w).decode() == "k_wfm_mfma_seq"
+    finally:
+        L.csdr_amd_wfm_destroy(w)
+    got_all = torch.cat(parts, dim=1)
+    n = got_all.shape[1]
+    first = {int(k): int(np.nonzero(idx == k)[0][0]) for k in range(16)}
+    ref_rows = got_all[torch.tensor([first[int(k)] for k in idx], device="cuda")]
+    assert torch.equal(got_all, ref_rows), "replicas of one signal differ between stream blocks / columns"
+    for k in range(16):
+        ps, _ = port.wfm_chain(sigs[k], -0.085, 10, taps)
+        got = got_all[first[k]].cpu().numpy()
+        m = min(ps.size, got.size)
+        assert 0 <= n - ps.size <= 2 and vc.s16_diff(got[:m], ps[:m]).max() <= 1, "signal %d" % k
+
+
 def test_c5_nfm_every_channel(gpu, port):
     """bench_nfm.py's timed shape, all of it: 512 channels x 2 400 256 samples carry one of 16 narrow-band FM signals; replicas bit-identical, the 16
     distinct rows +-1 LSB against the oracle's stage-by-stage chain on every sample."""

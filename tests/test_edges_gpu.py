@@ -194,6 +194,49 @@ def test_wfm_random_block_schedules(gpu, port, seed):
         assert np.abs(s16[s, :m].astype(np.int32) - ps[:m]).max() <= 1
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_wfm_random_block_schedules_s16_only(gpu, port, seed):
+    """The same walk over random call sizes the way a streaming caller runs it -- s16 only (no float audio), every call into a 16-byte-aligned row buffer of its
+    own: the path on which the loader waves collect the finished lines in registers and store 4 KiB per stream at once (k_wfm_mfma_seq, "Stores").  Call sizes make
+    every call's first audio sample fall anywhere in a 128-byte line of its output row; long calls fill and flush the registers several times per segment, short
+    ones never fill them; stream counts that are not multiples of 16 leave rows of the last workgroup without an owner.  +-1 LSB against the oracle's stream."""
+    import ctypes as C
+    from tests_helpers import wfm_signal_u8
+    rng = np.random.default_rng(seed)
+    L = gpu.L
+    S = int(rng.integers(1, 40))
+    head = [1024 * int(rng.integers(1, 91)) for _ in range(int(rng.integers(3, 7)))] + [1024 * int(rng.integers(300, 420))]
+    rng.shuffle(head)
+    sizes = head + [int(rng.integers(1, 1024)) * 2]
+    n = sum(sizes)
+    taps = port.firdes_lowpass_f(79, 0.05)
+    base = [wfm_signal_u8(1900 + seed * 10 + k, n) for k in range(min(S, 3))]
+    pitch = (2 * n + 15) // 16 * 16
+    xx = np.zeros((S, pitch), np.uint8)
+    for s in range(S):
+        xx[s, :2 * n] = base[s % len(base)]
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, max(sizes))
+    assert w, gpu.err()
+    di = gpu.upload(xx)
+    apitch = (max(sizes) // 50 + 64 + 7) // 8 * 8
+    ds = gpu.alloc(2 * S * apitch)
+    out = np.zeros((S, n // 50 + 64), np.int16)
+    pos = na = 0
+    for k in sizes:
+        got = L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.ptr, None, apitch)
+        assert got >= 0, gpu.err()
+        if got:
+            out[:, na:na + got] = gpu.download(ds, np.int16, S * apitch).reshape(S, apitch)[:, :got]
+        pos += k; na += got
+    L.csdr_amd_wfm_destroy(w)
+    want = [port.wfm_chain(b, -0.085, 10, taps) for b in base]
+    for s in sorted({0, S // 2, S - 1}):
+        ps, _ = want[s % len(base)]
+        m = min(ps.size, na)
+        assert m >= n // 50 - 8, (seed, s, sizes)
+        assert np.abs(out[s, :m].astype(np.int32) - ps[:m]).max() <= 1, (seed, s, sizes)
+
+
 @pytest.mark.parametrize("rate", [0.25, 0.05, -0.3141])
 def test_wfm_other_shift_rates(gpu, port, rate):
     """Shift rates other than the benchmark's, including 0.25 and 0.05 for which the reference's float phasor recurrence drifts by up to
