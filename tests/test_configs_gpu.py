@@ -119,7 +119,7 @@ def test_c4_bank_alternative_paths(gpu, monkeypatch, switch):
 def test_c4_bank_random_schedule(gpu, monkeypatch):
     """Chain tables computed one call ahead (riders of the previous call's inverse transforms, committed when the size matches and nothing retuned) against the same
     bank with that machinery off, on a random schedule: 26 calls of 1 .. 7 blocks with runs of equal sizes (hits) and changes (misses), retunes of random channels
-    before a third of the calls -- every channel's stream equal to rounding, equal sample counts."""
+    before a third of the calls -- every channel's stream equal to rounding, equal sample counts; three channels that are never retuned also against the oracle."""
     tbw, D, nch = 0.001, 256, 23
     ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
     rng = np.random.default_rng(49)
@@ -136,6 +136,12 @@ def test_c4_bank_random_schedule(gpu, monkeypatch):
     want = gpu.fastddc_bank(x, tbw, D, rates, schedule=sizes, retunes=retunes)
     for c in range(nch):
         assert got[c].size == want[c].size and vc.relrms(got[c], want[c]) < 2e-6, "channel %d" % c
+    # ... and the oracle on three channels that are never retuned (the whole random schedule, 1e-5)
+    touched = {ch for lst in retunes.values() for ch, _ in lst}
+    check = [c for c in range(nch) if c not in touched][:3]
+    _, ref = vc.fastddc_oracle_channels(x, tbw, D, rates, check)
+    for c in check:
+        assert got[c].size == ref[c].size and vc.relrms(got[c], ref[c]) < 1e-5, "channel %d vs oracle" % c
 
 
 def test_bank_pipelined_single_rank_communicator(gpu):
