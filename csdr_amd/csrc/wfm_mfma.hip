@@ -226,8 +226,8 @@ static_assert(16 % SEQ_NLW == 0 && (16 / SEQ_NLW) * 7 <= 63 && SEQ_TPG % 2 == 0,
 constexpr int SEQ_HEAD = 1024;             // bytes of the per-stream head (one fetch run)
 
 #ifndef WFM_DIAG
-#define WFM_DIAG 0      // diagnostic builds (tools/diag_wfm.py): 1 = no ring reads (B operand from registers), 2 = ring reads but no matrix products, 3 = compute waves idle,
-#endif                  // 4 = 3 + no audio stores, 5 = 4 + no de-emphasis, 6 = 3 with non-temporal audio stores, 7 = 3 with the audio stores to one line per stream
+#define WFM_DIAG 0      // diagnostic builds (tools/diag_wfm.py; the compute waves still take part in every barrier): 1 = no ring reads (B operand from registers),
+#endif                  // 2 = ring reads but no matrix products, 3 = compute waves idle, 4 = 3 + no audio stores, 5 = 4 + no de-emphasis
 #ifdef WFM_PROF
 // diagnostic build (tools/diag_wfm.sh): shader-clock cycles per wave summed over the launch: [wave][compute, wait vmcnt, barrier, DMA issue, emit, de-emphasis, steps]
 __device__ unsigned long long g_wfm_prof[SEQ_NW][8];
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             PROF_T(2)
             if (gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + SEQ_RB) row_step(); }
             PROF_T(3)
-            if (WFM_DIAG != 4) take_line(gi - 1);                                    // the previous step's audio: filtered by wave 0 before it came to this barrier
+            if (WFM_DIAG < 4) take_line(gi - 1);                                    // the previous step's audio: filtered by wave 0 before it came to this barrier
             PROF_T(4)
 #ifdef WFM_PROF
             prof[6] += 1;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
 #endif
         __syncthreads();
-        if (WFM_DIAG != 4) { take_line(n_grp - 1); take_line(n_grp); flush(); }
+        if (WFM_DIAG < 4) { take_line(n_grp - 1); take_line(n_grp); flush(); }
 #undef WFM_ST_ALL
     } else {
     // ============================================================================ the compute waves
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         PROF_T(2)
         if (!emit_vec) emit_scalar(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
         PROF_T(4)
-        if (iir_wave && WFM_DIAG != 5) {                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
+        if (iir_wave && WFM_DIAG < 5) {                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
             const int lo = gi == 0 ? seg_lo : 0;                                     // samples [lo, hi) of the step exist in this call (warm-up steps: all)
             const int hi = gi < 0 ? SPS : min(SPS, seg_hi - gi * SPS);
             if (lo == 0 && (hi & 3) == 0) {
