@@ -530,6 +530,25 @@ def test_f3_adpcm(gpu, port):
             assert np.array_equal(y[s], w) and tuple(st[s]) == ws
             w, ws = port.decode_ima_adpcm_u8_i16(y[s], tuple(stn[s]))
             assert np.array_equal(z[s], w) and tuple(zt[s]) == ws
+    # the encoder that stages through LDS (rows on 16-byte boundaries): lengths of every residue of its 128-sample chunks and 8-sample pieces (odd: the last sample
+    # is dropped, ima_adpcm.c:154-163), two calls with the state carried between them, 130 streams, padded pitches
+    L = gpu.L
+    for n in (2, 6, 14, 128, 130, 254, 1000 + 2, 3 * 128 + 77):
+        S = 130
+        xs = rng.integers(-25000, 25000, (S, n)).astype(np.int16)
+        stn = np.stack([rng.integers(0, 89, S), rng.integers(-32768, 32768, S)], axis=1).astype(np.int32)
+        ip = (n + 8 + 7) // 8 * 8; op = (n // 2 + 16 + 15) // 16 * 16
+        xp = np.zeros((S, ip), np.int16); xp[:, :n] = xs
+        di = gpu.upload(xp); do = gpu.alloc(S * op); ds = gpu.upload(stn.reshape(-1))
+        first = (n // 2) & ~31 if n >= 128 else n                # a second call starts on a 16-byte boundary of both rows
+        gpu.check(L.csdr_amd_encode_ima_adpcm_i16_u8(gpu.h, di.ptr, do.ptr, S, first, ip, op, ds.ptr), "adpcm encode")
+        if first < n:
+            gpu.check(L.csdr_amd_encode_ima_adpcm_i16_u8(gpu.h, di.at(2 * first), do.at(first // 2), S, n - first, ip, op, ds.ptr), "adpcm encode")
+        y = gpu.download(do, np.uint8, S * op).reshape(S, op)[:, :n // 2]
+        so = gpu.download(ds, np.int32, 2 * S).reshape(S, 2)
+        for s_ in (0, 1, 63, 64, 129):
+            w, ws = port.encode_ima_adpcm_i16_u8(xs[s_], tuple(stn[s_]))
+            assert np.array_equal(y[s_], w) and tuple(so[s_]) == ws, (n, s_)
     # encode -> decode round trip tracks the input (size-independent property at a larger size)
     big = (12000 * np.sin(np.arange(1 << 20) * 0.002)).astype(np.int16)
     enc, _ = gpu.encode_ima_adpcm_i16_u8(big)
