@@ -41,7 +41,17 @@ using namespace csdr_amd;
 namespace {
 
 constexpr int DDC_NKT = 36;                 // 64-byte K-steps per tile window (8 outputs): 2*(7 D + L) <= 2304 bytes
-constexpr int DDC_NKW = 9;                  // K-steps per wave
+#ifndef DDC_WPT_N
+#define DDC_WPT_N 4
+#endif
+constexpr int DDC_WPT = DDC_WPT_N;          // waves per team = K-ranges per tile.  -DDDC_WPT_N=6: 18 instead of 27 register-resident weight fragments per wave, 155 registers,
+                                            // THREE waves per SIMD (two teams of six): measured 0.784 against 0.792 ms per NFM step with two fetchers per team, 0.797 with
+                                            // four -- every K-range pays its own post-processing, the kernel is bound by instruction issue, not by latency (profiles/r3_notes.md)
+constexpr int DDC_NKW = DDC_NKT / DDC_WPT;  // K-steps per wave
+static_assert(DDC_NKT % DDC_WPT == 0 && (DDC_WPT == 4 || DDC_WPT == 6), "K-range split");
+#ifndef DDC_FETCHERS
+#define DDC_FETCHERS 2                      // fused epilogue: waves per team that fetch (of the DDC_WPT - 2 without an epilogue role)
+#endif
 constexpr int DDC_WIN = 64 * DDC_NKT;       // 2304 bytes
 constexpr int DDC_HIST = 1024;              // complex samples of input history kept per stream between blocks (>= L - 1; one chunk, so that history has ONE phasor seed)
 constexpr int DDC_DTAB = 3072;              // D^k for k in [-2048, 1024)
@@ -232,11 +242,25 @@ __device__ __forceinline__ void ddc_chain(const v4i (&A)[DDC_NKW * 3], const v4i
     }
 }
 
+// the K-ranges' shares of a lane's two outputs, always summed in this order (the fused epilogue's roles and its predecessor logic must agree bit for bit)
+template <int WPT>
+__device__ __forceinline__ float4 ddc_reduce(const float4 *b)
+{
+    const float4 p0 = b[0], p1 = b[64], p2 = b[128], p3 = b[192];
+    float4 r = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+    if constexpr (WPT == 6) {
+        const float4 p4 = b[256], p5 = b[320];
+        r.x += p4.x + p5.x; r.y += p4.y + p5.y; r.z += p4.z + p5.z; r.w += p4.w + p5.w;
+    }
+    return r;
+}
+
 #ifndef DDC_RING_PAD
 #define DDC_RING_PAD 32       // bytes between the streams' rings beyond the ring itself (see k_ddc_mfma)
 #endif
 #ifndef DDC_DIAG
-#define DDC_DIAG 0          // experiments: 1 = DMA ring + barriers only (no LDS reads / math), 2 = math only (ring filled once)
+#define DDC_DIAG 0          // experiments (timing only): 1 = DMA ring + barriers only (no LDS reads / math), 2 = math only (ring filled once), 3 = the epilogue waves skip their
+                            // K-range, 4 = the fetching waves skip theirs
 #endif
 struct DdcParams {
     int n_streams;
@@ -263,33 +287,38 @@ struct DdcParams {
 // k_nfm_demod_boundary, for which the segment's first and last complex samples are still stored.
 #ifdef DDC_PROF
 // diagnostic build (tools/diag_nfm.py): shader-clock cycles per wave summed over the launch: [wave][compute, wait vmcnt, barrier, DMA issue, reduce / demodulate / store, groups]
-__device__ unsigned long long g_ddc_prof[8][8];
+__device__ unsigned long long g_ddc_prof[16][8];
 #define DPROF_T(k) { const long long t_now = __builtin_readcyclecounter(); prof[k] += t_now - t_prev; t_prev = t_now; }
 #else
 #define DPROF_T(k)
 #endif
 
 template <int RBL, int NT, bool FUSE>
-__global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
+__global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
                                                        const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
                                                        const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p, DdcFuse fz)
 {
-    // FUSE: two waves of every team own the epilogue (roles A and B below) and the other two fetch: an LDS-DMA issue stalls its wave for as long as the memory
+    // FUSE: two waves of every team own the epilogue (roles A and B below) and the others fetch: an LDS-DMA issue stalls its wave for as long as the memory
     // takes once the CU's 64 pieces are in flight (profiles/r3_notes.md), the epilogue is ~1200 cycles on the group's critical path -- a wave with both was the
-    // last at every barrier.  Team 0: roles on K-ranges 0 / 2, team 1: on 1 / 3, so every SIMD hosts one of each kind.
-    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, NFW = FUSE ? 2 * NT : 4 * NT, SPW = 16 / NFW;   // fetching waves; streams fetched per fetching wave in a row-step
+    // last at every barrier.  Team 0: roles on K-ranges 0 / 2, team 1: on 1 / 3, so every SIMD hosts one role wave (wave id mod 4 = 0, 2 / 3, 1 with six waves per team).
+    // Plain front end: the role rotates, the first four waves of a team fetch.
+    constexpr int WPT = DDC_WPT, NTHR = 64 * WPT * NT;
+    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, NFW = (FUSE ? DDC_FETCHERS : 4) * NT, SPW = 16 / NFW;   // fetching waves; streams fetched per fetching wave in a row-step
+    static_assert(16 % NFW == 0, "rows per fetching wave");
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
-    float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][4 waves][64 lanes]
-    float *lcum = reinterpret_cast<float *>(red + 2 * NT * 256);                      // the prefix-sum table: a vector load from global memory inside the tile
+    float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][WPT waves][64 lanes]
+    float *lcum = reinterpret_cast<float *>(red + 2 * NT * WPT * 64);                      // the prefix-sum table: a vector load from global memory inside the tile
                                                                                       // loop would need vmcnt(0), i.e. drain the whole DMA ring
     float2 *ylast = reinterpret_cast<float2 *>(lcum + DDC_NGRAN * 16);                // FUSE: [2][16] last sample of the previous group's last tile
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
-    const int team = wv >> 2, w = wv & 3;
-    const bool has_role = FUSE && ((w & 1) == (team & 1));                             // wave uniform
-    const bool fetches = !has_role;
-    const int fw = FUSE ? 2 * team + (w >> 1) : wv;                                    // index among the fetching waves
-    for (int i = tid; i < DDC_NGRAN * 16; i += 256 * NT) lcum[i] = cum[i];            // (visible after the barrier that ends the prologue)
+    const int team = wv / WPT, w = wv % WPT;
+    const int ra = team & 1, rb = ra + 2;                                              // FUSE: the K-ranges whose waves own the epilogue
+    const bool has_role = FUSE && (w == ra || w == rb);                                // wave uniform
+    const int rank = w - (w > ra) - (w > rb);                                          // FUSE: index among the team's waves without a role
+    const bool fetches = FUSE ? (!has_role && rank < DDC_FETCHERS) : w < 4;
+    const int fw = FUSE ? DDC_FETCHERS * team + rank : 4 * team + w;                   // index among the fetching waves
+    for (int i = tid; i < DDC_NGRAN * 16; i += NTHR) lcum[i] = cum[i];            // (visible after the barrier that ends the prologue)
     const int sb = blockIdx.x;
     const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
@@ -379,7 +408,7 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
 #else
         float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active && nact > 0) {                                                    // (nact is loop invariant: waves beyond a short window have nothing to add)
+        if (active && nact > 0 && !(DDC_DIAG == 3 && has_role) && !(DDC_DIAG == 4 && fetches)) {   // (nact is loop invariant: waves beyond a short window have nothing to add)
             const long long n0 = p.B + (ws >> 1);                                    // global index of the tile's first sample
             const WaveGeom g = ddc_wave_geom(n0, w);
             const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
@@ -393,16 +422,16 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
             // ---- one accumulator chain per digit; snapshot at the chunk boundary
             v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
             const bool lo_lane = half && q < 2;
-            switch (kb) {
+            switch (kb) {                                                            // (cases beyond DDC_NKW are never taken)
                 case 0: ddc_chain<0>(A, Bf, lo_lane, acc, snap); break;
                 case 1: ddc_chain<1>(A, Bf, lo_lane, acc, snap); break;
                 case 2: ddc_chain<2>(A, Bf, lo_lane, acc, snap); break;
                 case 3: ddc_chain<3>(A, Bf, lo_lane, acc, snap); break;
-                case 4: ddc_chain<4>(A, Bf, lo_lane, acc, snap); break;
-                case 5: ddc_chain<5>(A, Bf, lo_lane, acc, snap); break;
-                case 6: ddc_chain<6>(A, Bf, lo_lane, acc, snap); break;
-                case 7: ddc_chain<7>(A, Bf, lo_lane, acc, snap); break;
-                case 8: ddc_chain<8>(A, Bf, lo_lane, acc, snap); break;
+                case 4: ddc_chain<(4 < DDC_NKW ? 4 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                case 5: ddc_chain<(5 < DDC_NKW ? 5 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                case 6: ddc_chain<(6 < DDC_NKW ? 6 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                case 7: ddc_chain<(7 < DDC_NKW ? 7 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                case 8: ddc_chain<(8 < DDC_NKW ? 8 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
                 default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
             }
             // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
@@ -433,7 +462,7 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
             }
         }
 #endif
-        float4 *rbuf = red + ((gi & 1) * NT + team) * 256;
+        float4 *rbuf = red + ((gi & 1) * NT + team) * (WPT * 64);
         rbuf[w * 64 + lane] = part;
         // ---- the next group's windows must have landed before anyone passes the barrier; the ring space behind them is refilled right after
         const long long wg_n = wg + (long long)NT * tstride;
@@ -451,15 +480,14 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         // ---- reduction of the four K-range shares and store.  Plain front end: the waves of a team take turns.  FUSE: TWO fixed waves of the team share the epilogue
         // -- role A demodulates the tile's even outputs (it needs the predecessor logic), role B the odd ones; fmdemod_quadri_cf | limit_ff + the digit split is two
         // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
-        const bool role_a = FUSE ? w == (team & 1) : w == (gi & 3), role_b = FUSE && w == (team & 1) + 2;
+        const bool role_a = FUSE ? w == ra : w == gi % WPT, role_b = FUSE && w == rb;
 #ifndef DDC_NOSTORE
 #define DDC_NOSTORE 0       // experiment: 1 = the epilogue computes but stores nothing (what the stores cost the input stream)
 #endif
         if (active && (role_a || role_b) && !(DDC_NOSTORE && kk_seg != -12345)) {
-            const float4 a = rbuf[lane], b = rbuf[64 + lane], c = rbuf[128 + lane], d = rbuf[192 + lane];
+            const float4 yy = ddc_reduce<WPT>(rbuf + lane);                           // (y0.re, y0.im, y1.re, y1.im): outputs 2q, 2q + 1 of stream col
             const int stream = sb * 16 + col;
-            const float2 y0 = make_float2((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y));
-            const float2 y1 = make_float2((a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+            const float2 y0 = make_float2(yy.x, yy.y), y1 = make_float2(yy.z, yy.w);
             const int kk = kk_seg + 8 * it + 2 * q;                                  // index of y0 in the call's outputs; the first / last tile of a call may be partial
             const bool ok0 = (unsigned)kk < (unsigned)p.n_out, ok1 = (unsigned)(kk + 1) < (unsigned)p.n_out;
             if (!FUSE) {
@@ -473,9 +501,8 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
                 float2 prev = make_float2(__shfl_up(y1.x, 16), __shfl_up(y1.y, 16));
                 if (q == 0 && it > 0) {
                     if (team > 0) {                                                  // same group, previous team: its partial sums are complete (same barrier)
-                        const float4 *pb = red + ((gi & 1) * NT + team - 1) * 256 + 48 + col;
-                        const float4 pa = pb[0], pbv = pb[64], pc = pb[128], pd = pb[192];
-                        prev = make_float2((pa.z + pbv.z) + (pc.z + pd.z), (pa.w + pbv.w) + (pc.w + pd.w));
+                        const float4 pv = ddc_reduce<WPT>(red + ((gi & 1) * NT + team - 1) * (WPT * 64) + 48 + col);
+                        prev = make_float2(pv.z, pv.w);
                     } else prev = ylast[((gi - 1) & 1) * 16 + col];                  // previous group's last team: handed over (double buffered: the writer of this group is on its way)
                 }
                 if (team == NT - 1 && q == 3) ylast[(gi & 1) * 16 + col] = y1;
@@ -509,10 +536,10 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
         DPROF_T(4)
     }
 #ifdef DDC_PROF
-    if (lane == 0 && wv < 8) { for (int k = 0; k < 5; k++) atomicAdd(&g_ddc_prof[wv][k], (unsigned long long)prof[k]); atomicAdd(&g_ddc_prof[wv][5], (unsigned long long)n_grp); }
+    if (lane == 0 && wv < 16) { for (int k = 0; k < 5; k++) atomicAdd(&g_ddc_prof[wv][k], (unsigned long long)prof[k]); atomicAdd(&g_ddc_prof[wv][5], (unsigned long long)n_grp); }
 #endif
     if (p.hist_out && blockIdx.y + 1 == gridDim.y) {                                 // 16 streams x 2 KiB: the next call's history
-        for (int i = tid; i < 16 * (2 * DDC_HIST / 16); i += 256 * NT) {
+        for (int i = tid; i < 16 * (2 * DDC_HIST / 16); i += NTHR) {
             const int srow = i / (2 * DDC_HIST / 16), piece = i % (2 * DDC_HIST / 16);
             if (sb * 16 + srow < p.n_streams)
                 *reinterpret_cast<uint4 *>(p.hist_out + (size_t)(sb * 16 + srow) * (2 * DDC_HIST) + 16 * piece) =
@@ -524,8 +551,8 @@ __global__ __launch_bounds__(256 * NT) void k_ddc_mfma(const uint8_t *__restrict
 #ifdef DDC_PROF
 extern "C" int csdr_amd_debug_ddc_prof(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_prof), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
-    if (reset) { static unsigned long long z[64]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ddc_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ddc_prof), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[128]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ddc_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
@@ -798,15 +825,15 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
             if (n_seg < 1) n_seg = 1;
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
-            const size_t lds = (size_t)16 * ((1u << rbl) + DDC_RING_PAD) + (size_t)2 * nt * 4 * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2);
+            const size_t lds = (size_t)16 * ((1u << rbl) + DDC_RING_PAD) + (size_t)2 * nt * DDC_WPT * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2);
             DdcFuse fz; memset(&fz, 0, sizeof fz); if (fuse) fz = *fuse;
 #define DDC_LAUNCH(NTV, FV, THREADS) do {                                                                                                                  \
                 const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV>, lds); if (arc) return arc;                                              \
                 if (e0) CSDR_HIP(hipEventRecord(e0, st));                                                                                                      \
                 hipLaunchKernelGGL((k_ddc_mfma<rbl, NTV, FV>), dim3(n_wsb, n_seg), dim3(THREADS), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, ctab, \
                                    corr, reinterpret_cast<float2 *>(out), out_pitch, p, fz); } while (0)
-            if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, 512); else DDC_LAUNCH(1, true, 256); }
-            else      { if (nt == 2) DDC_LAUNCH(2, false, 512); else DDC_LAUNCH(1, false, 256); }
+            if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, 128 * DDC_WPT); else DDC_LAUNCH(1, true, 64 * DDC_WPT); }
+            else      { if (nt == 2) DDC_LAUNCH(2, false, 128 * DDC_WPT); else DDC_LAUNCH(1, false, 64 * DDC_WPT); }
 #undef DDC_LAUNCH
             CSDR_LAUNCH_CHECK();
             if (fuse && info) {
@@ -856,7 +883,7 @@ int csdr_amd_debug_ddc_mfma_tile(int D, int L, float shift_rate, const float *ta
     }
     const int nk_used = (2 * (7 * D + L) + 63) / 64;
     for (int r = 0; r < 16; r++) out16[r] = 0.f;
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < DDC_WPT; w++) {
         const WaveGeom g = ddc_wave_geom(n0, w);
         int nact = nk_used - DDC_NKW * w; if (nact > DDC_NKW) nact = DDC_NKW; if (nact < 0) nact = 0;
         const long long chunk_rel = g.chunk - (n0 >> 10);
