@@ -246,7 +246,7 @@ static void launch_poly(csdr_amd_ctx *c, const PolyCfg &g, const T *in, T *out, 
 {
     // few, fat workgroups: ~16 resident-wave generations per CU at most; each walks a contiguous range of tiles with the next tile's loads in flight
     const int n_tiles = cdiv(n_out, 64 * g.R);
-    static const long want = getenv("CSDR_AMD_FIR_WGS") ? atol(getenv("CSDR_AMD_FIR_WGS")) : 256L * 7 * 4;
+    static const long want = getenv("CSDR_AMD_FIR_WGS") ? atol(getenv("CSDR_AMD_FIR_WGS")) : 256L * 7 * 8;
     const int per = (int)(((long)n_tiles * n_streams + want - 1) / want);
     const int tiles_per_wg = per < 1 ? 1 : per;
     dim3 grid(cdiv(n_tiles, tiles_per_wg), (unsigned)n_streams);
