@@ -482,9 +482,9 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
         const bool role_a = FUSE ? w == ra : w == gi % WPT, role_b = FUSE && w == rb;
 #ifndef DDC_NOSTORE
-#define DDC_NOSTORE 0       // experiment: 1 = the epilogue computes but stores nothing (what the stores cost the input stream)
+#define DDC_NOSTORE 0       // experiment (timing only): 1 = no epilogue, nothing stored (what the stores cost the input stream)
 #endif
-        if (active && (role_a || role_b) && !(DDC_NOSTORE && kk_seg != -12345)) {
+        if (active && (role_a || role_b) && !DDC_NOSTORE) {
             const float4 yy = ddc_reduce<WPT>(rbuf + lane);                           // (y0.re, y0.im, y1.re, y1.im): outputs 2q, 2q + 1 of stream col
             const int stream = sb * 16 + col;
             const float2 y0 = make_float2(yy.x, yy.y), y1 = make_float2(yy.z, yy.w);
