@@ -38,7 +38,7 @@ namespace {
 template <int N> struct FflPlan;
 template <> struct FflPlan<4096>  { static constexpr int NS = 3, R1 = 16, R2 = 16, R3 = 16, R4 = 1, PADSH = 4; };
 template <> struct FflPlan<8192>  { static constexpr int NS = 4, R1 = 16, R2 = 8,  R3 = 8,  R4 = 8, PADSH = 3; };
-template <> struct FflPlan<16384> { static constexpr int NS = 4, R1 = 16, R2 = 16, R3 = 8,  R4 = 8, PADSH = 3; };
+template <> struct FflPlan<16384> { static constexpr int NS = 4, R1 = 16, R2 = 8,  R3 = 8,  R4 = 16, PADSH = 3; };
 
 template <int N> struct FflGeom {
     using P = FflPlan<N>;
