@@ -237,6 +237,43 @@ def test_wfm_random_block_schedules_s16_only(gpu, port, seed):
         assert np.abs(out[s, :m].astype(np.int32) - ps[:m]).max() <= 1, (seed, s, sizes)
 
 
+def test_wfm_float_audio_into_aligned_rows(gpu, port):
+    """s16 AND float audio into 16-byte-aligned rows (pitch a multiple of 8 samples), three calls: the loader waves store every finished line at once (16-byte s16
+    pieces + two float4 per lane) instead of holding it -- the third way the audio can leave k_wfm_mfma_seq besides the register-held lines (s16 only) and the
+    sample-by-sample path (unaligned rows)."""
+    import ctypes as C
+    from tests_helpers import wfm_signal_u8
+    L = gpu.L
+    S, sizes = 19, [1024 * 37, 1024 * 64, 1024 * 11 + 640]
+    n = sum(sizes)
+    taps = port.firdes_lowpass_f(79, 0.05)
+    base = [wfm_signal_u8(2900 + k, n) for k in range(3)]
+    pitch = (2 * n + 15) // 16 * 16
+    xx = np.zeros((S, pitch), np.uint8)
+    for s_ in range(S):
+        xx[s_, :2 * n] = base[s_ % 3]
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, max(sizes))
+    assert w, gpu.err()
+    di = gpu.upload(xx)
+    apitch = (max(sizes) // 50 + 64 + 7) // 8 * 8
+    ds = gpu.alloc(2 * S * apitch); df = gpu.alloc(4 * S * apitch)
+    o16 = np.zeros((S, n // 50 + 64), np.int16); of = np.zeros((S, n // 50 + 64), f32)
+    pos = na = 0
+    for k in sizes:
+        got = L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.ptr, df.ptr, apitch)
+        assert got >= 0, gpu.err()
+        if got:
+            o16[:, na:na + got] = gpu.download(ds, np.int16, S * apitch).reshape(S, apitch)[:, :got]
+            of[:, na:na + got] = gpu.download(df, f32, S * apitch).reshape(S, apitch)[:, :got]
+        pos += k; na += got
+    L.csdr_amd_wfm_destroy(w)
+    for s_ in (0, 7, 18):
+        ps, pf = port.wfm_chain(base[s_ % 3], -0.085, 10, taps)
+        m = min(pf.size, na)
+        assert m >= n // 50 - 8 and relrms(of[s_, :m], pf[:m]) <= TOL
+        assert np.abs(o16[s_, :m].astype(np.int32) - ps[:m]).max() <= 1
+
+
 @pytest.mark.parametrize("rate", [0.25, 0.05, -0.3141])
 def test_wfm_other_shift_rates(gpu, port, rate):
     """Shift rates other than the benchmark's, including 0.25 and 0.05 for which the reference's float phasor recurrence drifts by up to
