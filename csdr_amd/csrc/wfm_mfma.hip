@@ -175,7 +175,7 @@ __device__ __forceinline__ void wfm_chain(const v4i (&A)[WFM_NK * 3], const v4i 
 //
 // The back end of the chain runs inside: the workgroup produces its streams' audio in time order, so the one-pole de-emphasis
 // (libcsdr.c:1081-1097) is a state carried in wave 0 from step to step, and convert_f_s16 follows one step later out of a ring of SEQ_OUTS
-// steps' samples per stream, done by the loader waves, which hold the s16 lines in registers until 4 KiB per stream go out together (see "Stores"
+// steps' samples per stream, done by the loader waves, which hold the s16 lines in registers until 5.5 KiB per stream go out together (see "Stores"
 // in the kernel): the demodulated audio never goes to HBM as floats.  A segment
 // that starts in the middle of a call demodulates two steps (48 audio samples) ahead of its range from zero state without storing them --
 // the filter forgets as 0.706^k --; the first segment starts from the exact state the previous call left, the last one leaves its own.
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     // ---- Stores (convert_f_s16, libcsdr.c:2397, x86 truncation semantics).  Usual case (16-byte aligned rows; emit_vec): the LOADER waves take the audio out of the
     // staging ring, one step after the de-emphasis, in whole 128-byte LINES of the s16 output row (64 samples, 8 lanes x 16 bytes; lines of the OUTPUT row, whatever the
     // call's first sample is: after step g the line whose last sample lies in step g is complete -- the same step for all 16 streams; it may start up to 63 samples
-    // back, hence the ring of SEQ_OUTS steps) and keep them in registers -- a loader uses none otherwise -- until 32 lines = 4 KiB per stream are together.  Why: beside a
+    // back, hence the ring of SEQ_OUTS steps) and keep them in registers -- a loader uses none otherwise -- until 44 lines = 5.5 KiB per stream are together.  Why: beside a
     // saturated read stream the memory charges 2 % of the bytes written as stores with 17-20 % of the read rate, whatever the cache policy or the instruction count,
     // nothing if the lines stay in L2, half of it for 4 KiB per row at a time, a quarter for 8 KiB (tools/microbench/dma_write_mix.hip, profiles/r3_notes.md).
     // Lines cut by the call's first / last sample or the segment's ends, and every line when the float audio is wanted too, are stored at once.
@@ -384,10 +384,10 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     if (fetches) {
         // ======================================================================== the loader waves: fetch, and take the finished audio out
         typedef unsigned wfm_u4 __attribute__((ext_vector_type(4)));
-        constexpr int NST = 32;                                                      // lines held per stream: 4 KiB (48 lines = 6 KiB: 256 registers and spills, slower)
-        // (32 named registers, written through selects: any array or switch form went to scratch memory)
+        constexpr int NST = 44;                                                      // lines held per stream: 5.5 KiB, 176 registers (32 / 40 / 44 lines: 0.859 / 0.848 / 0.849 ms; 48: 256 registers and spills)
+        // (named registers, written through selects: any array or switch form went to scratch memory)
 #define WFM_ST_ALL(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
-                      X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31)
+                      X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43)
 #define X(k) wfm_u4 st##k = {0u, 0u, 0u, 0u};
         WFM_ST_ALL(X)
 #undef X

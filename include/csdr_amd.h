@@ -369,7 +369,7 @@ int  csdr_amd_wfm_reset(csdr_amd_wfm *w);
  * for the last block of a stream).  audio_s16: [n_streams][out_pitch]; audio_f (optional, may be NULL)
  * receives the float audio before convert_f_s16 (parity tap).  Returns audio samples written per stream.
  * Any in_pitch that is a multiple of 16 bytes and any audio pointers / out_pitch are accepted; the streaming rate the benchmarks quote needs audio_f == NULL,
- * audio_s16 on a 16-byte boundary and out_pitch a multiple of 8 samples (the kernel then keeps the finished s16 lines in registers and stores 4 KiB per stream at
+ * audio_s16 on a 16-byte boundary and out_pitch a multiple of 8 samples (the kernel then keeps the finished s16 lines in registers and stores 5.5 KiB per stream at
  * a time; other layouts are stored line by line or sample by sample: same values, 5-10 % slower). */
 long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, size_t block_samples,
                           int16_t *audio_s16, float *audio_f, size_t out_pitch);
