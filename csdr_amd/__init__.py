@@ -180,6 +180,14 @@ def lib():
     L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
     L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.csdr_amd_ddc_create.restype = vp; L.csdr_amd_ddc_create.argtypes = [vp, i, fl, i, vp, i, sz]
+    if hasattr(L, "csdr_amd_ddc_create_rates"):          # (absent from older builds selected with CSDR_AMD_LIB for A/B runs)
+        L.csdr_amd_ddc_create_rates.restype = vp; L.csdr_amd_ddc_create_rates.argtypes = [vp, i, vp, i, vp, i, sz]
+        L.csdr_amd_ddc_set_rate.argtypes = [vp, i, fl]
+        L.csdr_amd_ddc_get_rate.restype = fl; L.csdr_amd_ddc_get_rate.argtypes = [vp, i]
+        L.csdr_amd_ddc_fallback.argtypes = [vp]
+        L.csdr_amd_debug_wrap_phase.restype = fl; L.csdr_amd_debug_wrap_phase.argtypes = [fl]
+        L.csdr_amd_nfm_create_rates.restype = vp; L.csdr_amd_nfm_create_rates.argtypes = [vp, i, vp, i, vp, i, i, i, fl, fl, sz]
+        L.csdr_amd_nfm_set_rate.argtypes = [vp, i, fl]
     L.csdr_amd_ddc_destroy.argtypes = [vp]
     L.csdr_amd_ddc_reset.argtypes = [vp]
     L.csdr_amd_ddc_process.restype = C.c_long; L.csdr_amd_ddc_process.argtypes = [vp, vp, sz, sz, vp, sz]
@@ -676,10 +684,11 @@ class Context:
         self.L.csdr_amd_wfm_destroy(w)
         return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())
 
-    def ddc_u8(self, iq_u8, shift_rate, decimation, taps, block=None, pitch_pad=0):
+    def ddc_u8(self, iq_u8, shift_rate, decimation, taps, block=None, pitch_pad=0, retunes=None):
         """Fused front end convert_u8_f | shift_addition_cc | fir_decimate_cc (csdr_amd_ddc_*): iq_u8 [2n] or [streams, 2n] uint8 ->
         complex64 [streams, n_out].  `block` = samples per call; `pitch_pad` = extra bytes of row pitch (a pitch that is not a multiple of
-        128 selects the plain kernel).  The kernel of the last call is left in `self.last_ddc_kernel`, all kernels used in `self.ddc_kernels`."""
+        128 selects the plain kernel).  The kernel of the last call is left in `self.last_ddc_kernel`, all kernels used in `self.ddc_kernels`.
+        shift_rate: one float, or one per stream (csdr_amd_ddc_create_rates); retunes: {call index: [(stream, rate), ...]} applied in front of that call."""
         x2, squeeze = self._2d(iq_u8, np.uint8)
         s, nbytes = x2.shape; n = nbytes // 2
         pitch = (nbytes + 127) // 128 * 128 + pitch_pad
@@ -687,7 +696,11 @@ class Context:
         taps = np.ascontiguousarray(taps, f32)
         sched = list(block) if isinstance(block, (list, tuple)) else None          # `block` may be a list of call sizes (the rest of the stream follows in one call)
         block = n if block is None else (max(sched) if sched else block)
-        d = self.L.csdr_amd_ddc_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, max(block, 1024))
+        if np.ndim(shift_rate) == 0:
+            d = self.L.csdr_amd_ddc_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, max(block, 1024))
+        else:
+            rates = np.ascontiguousarray(shift_rate, f32); assert rates.size == s
+            d = self.L.csdr_amd_ddc_create_rates(self.h, s, _hp(rates), decimation, _hp(taps), taps.size, max(block, 1024))
         if not d:
             raise CsdrAmdError(self.err())
         di = self.upload(xx)
@@ -695,6 +708,8 @@ class Context:
         do = self.alloc(8 * s * opitch)
         pos = 0; no = 0; self.ddc_kernels = set(); call = 0
         while pos < n:
+            for st, r in (retunes or {}).get(call, []):
+                self.check(self.L.csdr_amd_ddc_set_rate(d, st, r), "ddc_set_rate")
             k = min(sched[call] if (sched and call < len(sched)) else block, n - pos); call += 1
             got = self.check(self.L.csdr_amd_ddc_process(d, di.at(2 * pos), pitch, k, do.at(8 * no), opitch), "ddc_process")
             self.ddc_kernels.add(self.L.csdr_amd_ddc_kernel_name(d).decode())
@@ -704,9 +719,10 @@ class Context:
         self.L.csdr_amd_ddc_destroy(d)
         return y[0].copy() if squeeze else y.copy()
 
-    def nfm_chain(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024, block=None):
+    def nfm_chain(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024, block=None, retunes=None):
         """BASELINE config 5 / README.md:87 through the chain object csdr_amd_nfm_* (matrix-core front end + audio-rate back end):
-        iq_u8 [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call."""
+        iq_u8 [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call.
+        shift_rate: one float, or one per stream (csdr_amd_nfm_create_rates); retunes: {call index: [(stream, rate), ...]}."""
         x2, squeeze = self._2d(iq_u8, np.uint8)
         S, nbytes = x2.shape; n = nbytes // 2
         pitch = (nbytes + 127) // 128 * 128
@@ -715,7 +731,11 @@ class Context:
         taps = np.ascontiguousarray(self.firdes_lowpass_f(nt, 0.5 / decimation), f32)
         sched = list(block) if isinstance(block, (list, tuple)) else None
         block = n if block is None else (max(sched) if sched else block)
-        w = self.L.csdr_amd_nfm_create(self.h, S, shift_rate, decimation, _hp(taps), taps.size, audio_rate, agc_block, 1.0, 1.0, max(block, 1024))
+        if np.ndim(shift_rate) == 0:
+            w = self.L.csdr_amd_nfm_create(self.h, S, shift_rate, decimation, _hp(taps), taps.size, audio_rate, agc_block, 1.0, 1.0, max(block, 1024))
+        else:
+            rates = np.ascontiguousarray(shift_rate, f32); assert rates.size == S
+            w = self.L.csdr_amd_nfm_create_rates(self.h, S, _hp(rates), decimation, _hp(taps), taps.size, audio_rate, agc_block, 1.0, 1.0, max(block, 1024))
         if not w:
             raise CsdrAmdError(self.err())
         di = self.upload(xx)
@@ -723,6 +743,8 @@ class Context:
         ds = self.alloc(2 * S * apitch); df = self.alloc(4 * S * apitch)
         pos = 0; na = 0; call = 0
         while pos < n:
+            for st, r in (retunes or {}).get(call, []):
+                self.check(self.L.csdr_amd_nfm_set_rate(w, st, r), "nfm_set_rate")
             k = min(sched[call] if (sched and call < len(sched)) else block, n - pos); call += 1
             got = self.check(self.L.csdr_amd_nfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na), apitch), "nfm_process")
             pos += k; na += got

@@ -30,6 +30,7 @@
 //    output evaluation of the same model, which is also the fallback for shapes the matrix-core kernel does not cover.
 #include "common.hpp"
 #include "nfm_demod.hpp"
+#include "seeds.hpp"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -107,11 +108,13 @@ void ddc_build_table(int D, int L, float shift_rate, const float *taps, DdcTable
     t.scale = (float)(gmax / 4194304.0);
     t.frags.assign((size_t)DDC_NKT * 3 * 64 * 16, 0);
     std::vector<double> gsum((size_t)(DDC_NGRAN - 1) * 16, 0.0);
+    std::vector<std::complex<double>> dpow((size_t)span);             // D^ts, once per sample of the window (a per-stream object builds one table per stream)
+    for (int ts = 0; ts < span; ts++) dpow[ts] = std::polar(pow(mag, ts), ang * ts);
     for (int r = 0; r < 16; r++) {
         const int o = r / 2, comp = r % 2;                            // row = (output o of the tile, Re / Im)
         for (int tp = 0; tp < L; tp++) {
             const int ts = D * o + tp;                                // sample relative to the tile's first sample
-            const std::complex<double> G = a * (double)taps[tp] * std::polar(pow(mag, ts), ang * ts);
+            const std::complex<double> G = a * (double)taps[tp] * dpow[ts];
             for (int c = 0; c < 2; c++) {
                 // real form of (Gr + j Gi)(I + j Q): Re row takes (Gr, -Gi) on (I, Q); Im row takes (Gi, Gr)
                 const double val = comp == 0 ? (c == 0 ? G.real() : -G.imag()) : (c == 0 ? G.imag() : G.real());
@@ -272,6 +275,12 @@ struct DdcParams {
     int n_out;                        // outputs of this call: only k_out0 <= 8 tile + o < k_out0 + n_out are stored (the first / last tile of a call may be partial)
     const uint8_t *hist_in;           // != nullptr: the tiles start in the previous blocks' tail (2 KiB per stream in front of the block: ring positions < 0)
     long long two_T; uint8_t *hist_out;   // hist_out != nullptr: the last segment's workgroups keep the block's newest DDC_HIST samples for the next call (k_ddc_save_hist's work)
+    int n_lead_store;                 // FUSE: the complex samples of outputs < n_lead_store are stored as well (k_nfm_demod_boundary redoes them after a retune's lead fix-up)
+    // PS (a shift rate per stream: one workgroup = ONE stream x 16 time segments, see k_ddc_mfma)
+    long long col_bytes; int col_chunks;      // input bytes / 1024-chunks between the starts of consecutive columns (tiles_per_seg tiles; a multiple of a whole chunk)
+    size_t frag_stride, tab_pitch;            // v4i per stream in `frags`; streams per chunk row of the seed table
+    int tab_len;                              // seed table rows from the call's first chunk on
+    const float *scales; const int *corr_row; size_t corr_chunks;
 };
 
 // One workgroup = 16 streams x the tiles [t0, t1) of its segment, walked in time order, NT tiles at a time: the workgroup has NT teams of
@@ -293,7 +302,7 @@ __device__ unsigned long long g_ddc_prof[16][8];
 #define DPROF_T(k)
 #endif
 
-template <int RBL, int NT, bool FUSE>
+template <int RBL, int NT, bool FUSE, bool PS>
 __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags,
                                                        const float *__restrict__ cum, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
                                                        const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DdcParams p, DdcFuse fz)
@@ -302,9 +311,20 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
     // takes once the CU's 64 pieces are in flight (profiles/r3_notes.md), the epilogue is ~1200 cycles on the group's critical path -- a wave with both was the
     // last at every barrier.  Team 0: roles on K-ranges 0 / 2, team 1: on 1 / 3, so every SIMD hosts one role wave (wave id mod 4 = 0, 2 / 3, 1 with six waves per team).
     // Plain front end: the role rotates, the first four waves of a team fetch.
+    // PS (csdr_amd_ddc_create_rates: a shift rate per stream): the weights a h D^t belong to ONE stream, so the 16 columns of the B operand are 16 TIME SEGMENTS
+    // ("columns") of that stream instead of 16 streams.  Column starts are a whole number of tiles AND of 1024-chunks apart (lcm(8 D, 1024) samples = 64 tiles at D = 50),
+    // so a tile's window sits at the same offset inside a chunk in every column: the chunk-boundary variant, the masks and D^e are the workgroup's, as before; only
+    // the chunk SEEDS differ per column.  The post factors of the next group (seed x D^e x drift correction per (team, K-range, side, column)) are put together by
+    // the role waves -- which never issue LDS-DMA, so their global loads do not drain a ring -- into an LDS table; every wave picks its two entries up per tile
+    // (fewer vector instructions per K-range than the scalar loads and complex products of the shared-rate kernel).  Roles as in the fused kernel, also when the
+    // complex samples are stored (!FUSE).  The first column of a call starts in the history buffer, every other one in the block itself; columns behind the block's
+    // end re-read column 0 (their outputs are not stored).
+    constexpr bool ROLES = FUSE || PS;
     constexpr int WPT = DDC_WPT, NTHR = 64 * WPT * NT;
-    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, NFW = (FUSE ? DDC_FETCHERS : 4) * NT, SPW = 16 / NFW;   // fetching waves; streams fetched per fetching wave in a row-step
+    constexpr int RB = 1 << RBL, RP = RB + DDC_RING_PAD, NFW = (ROLES ? DDC_FETCHERS : 4) * NT, SPW = 16 / NFW;   // fetching waves; streams fetched per fetching wave in a row-step
+    constexpr int PTN = NT * WPT * 2 * 16;                                             // PS: post factors per group
     static_assert(16 % NFW == 0, "rows per fetching wave");
+    static_assert(!PS || (WPT == 4 && DDC_FETCHERS == 2), "the per-stream kernel's role waves fill 64 table entries each");
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
     float4 *red = reinterpret_cast<float4 *>(lds_in + 16 * RP);                       // [2][NT teams][WPT waves][64 lanes]
@@ -314,13 +334,22 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     const int team = wv / WPT, w = wv % WPT;
     const int ra = team & 1, rb = ra + 2;                                              // FUSE: the K-ranges whose waves own the epilogue
-    const bool has_role = FUSE && (w == ra || w == rb);                                // wave uniform
+    const bool has_role = ROLES && (w == ra || w == rb);                               // wave uniform
     const int rank = w - (w > ra) - (w > rb);                                          // FUSE: index among the team's waves without a role
-    const bool fetches = FUSE ? (!has_role && rank < DDC_FETCHERS) : w < 4;
-    const int fw = FUSE ? DDC_FETCHERS * team + rank : 4 * team + w;                   // index among the fetching waves
+    const bool fetches = ROLES ? (!has_role && rank < DDC_FETCHERS) : w < 4;
+    const int fw = ROLES ? DDC_FETCHERS * team + rank : 4 * team + w;                  // index among the fetching waves
+    const int sb = blockIdx.x;                                                         // block of 16 streams; PS: the stream
+    float2 *ptab = ylast + 2 * 16;                                                     // PS: [2][PTN]
+    const int col0 = PS ? 16 * (int)blockIdx.y : 0;                                    // PS: absolute index of the workgroup's first column
+    float scale = p.scale;
+    if constexpr (PS) {
+        frags += (size_t)sb * p.frag_stride; cum += (size_t)sb * (DDC_NGRAN * 16); dtab += (size_t)sb * DDC_DTAB; ctab += sb;
+        scale = p.scales[sb];
+        const int crow = p.corr_row ? p.corr_row[sb] : -1;
+        corr = (corr && crow >= 0) ? corr + (size_t)crow * p.corr_chunks * 32 : nullptr;
+    }
     for (int i = tid; i < DDC_NGRAN * 16; i += NTHR) lcum[i] = cum[i];            // (visible after the barrier that ends the prologue)
-    const int sb = blockIdx.x;
-    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
+    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg * (PS ? 16 : 1);      // PS: column 0's first tile
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
     if (t0 >= t1) return;
     const int n_it = (int)(t1 - t0), n_grp = (n_it + NT - 1) / NT;
@@ -345,21 +374,55 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
     }
     // ---- DMA state
     const int tstride = 16 * p.D;                                                    // bytes of input per tile
-    long long wg = t0 * tstride - 2 * p.B;                                           // window start of the current GROUP's first tile, bytes from the block start
+    const long long org = PS ? (long long)col0 * p.col_bytes : 0LL;                  // PS: positions are counted from the start of the workgroup's column 0
+    long long wg = t0 * tstride - 2 * p.B - org;                                     // window start of the current GROUP's first tile, bytes from the block start
     const long long F0 = wg & ~1023LL;                                               // (floor: a call's first tiles start in the history, at negative positions)
-    long long F_end = ((t1 - 1) * tstride - 2 * p.B + DDC_WIN + 1023) & ~1023LL;
-    if (p.hist_in && F_end > p.two_T) F_end = p.two_T;                               // a partial last tile's window reaches beyond the block: those bytes feed no stored output
+    long long F_end = ((t1 - 1) * tstride - 2 * p.B - org + DDC_WIN + 1023) & ~1023LL;
+    if (p.hist_in && F_end > p.two_T - org) F_end = p.two_T - org;                   // a partial last tile's window reaches beyond the block: those bytes feed no stored output
     long long F = F0;                                                                // next row-step
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
     uint32_t voff[SPW], voff_h[SPW];
+    long long row_lim[SPW];                                                          // PS: bytes of the block from the row's column start on (wave uniform)
 #pragma unroll
     for (int r = 0; r < SPW; r++) {
-        const int srow = max(min(sb * 16 + SPW * fw + r, last_stream) - sb * 16, 0); // rows past the last stream re-read it (results discarded)
-        voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
-        voff_h[r] = (uint32_t)srow * (uint32_t)(2 * DDC_HIST) + 16u * lane;
+        if constexpr (PS) {
+            voff[r] = (uint32_t)((long long)(SPW * fw + r) * p.col_bytes) + 16u * lane;      // relative to column 0 of the workgroup
+            voff_h[r] = 16u * lane;
+            row_lim[r] = p.two_T - (long long)(col0 + SPW * fw + r) * p.col_bytes;
+        } else {
+            const int srow = max(min(sb * 16 + SPW * fw + r, last_stream) - sb * 16, 0); // rows past the last stream re-read it (results discarded)
+            voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
+            voff_h[r] = (uint32_t)srow * (uint32_t)(2 * DDC_HIST) + 16u * lane;
+            row_lim[r] = 0;
+        }
     }
-    const uint8_t *sblock = in + (long long)sb * 16 * (long long)in_pitch;
+    const uint8_t *sblock = PS ? in + (long long)sb * (long long)in_pitch + (long long)col0 * p.col_bytes : in + (long long)sb * 16 * (long long)in_pitch;
+    const uint32_t voff_c0 = 16u * lane;
     auto row_step = [&]() {
+        if constexpr (PS) {
+            // positions F are column 0's, counted from ITS start (for the call's very first column that is the block start: F < 0 = the history buffer);
+            // the other rows read the same position of their own column, which lies inside the block also for F < 0
+            const uint32_t ldst = lds_in_addr + (SPW * fw) * RP + (uint32_t)(F & (RB - 1));
+            if (F < 0 && col0 == 0) {                                                // (wave uniform; at most three row-steps of the call's first workgroups)
+#pragma unroll
+                for (int r = 0; r < SPW; r++) {
+                    const bool hrow = SPW * fw + r == 0 || F + 1024 > row_lim[r];      // the call's first column; columns behind the block's end (any readable bytes)
+                    const uint8_t *sbase = hrow ? p.hist_in + (size_t)sb * (2 * DDC_HIST) + (F < -2 * DDC_HIST ? 0 : F + 2 * DDC_HIST) : sblock + F;
+                    const uint32_t vo = hrow ? voff_h[r] : voff[r];
+                    const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * RP));
+                    uint32_t keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(la) : "memory");
+                }
+            } else {
+                uint32_t vo[SPW];
+#pragma unroll
+                for (int r = 0; r < SPW; r++) vo[r] = F + 1024 <= row_lim[r] ? voff[r] : voff_c0;      // behind the block's end: column 0's bytes again
+                dma_rows<SPW, RP>(vo, sblock + F, __builtin_amdgcn_readfirstlane((int)ldst));
+            }
+            F += 1024;
+            return;
+        }
         // F < 0: a run of the history (2 KiB per stream = positions [-2048, 0); a window may start up to 7 D samples in front of that: those bytes feed only
         // outputs the previous call has already delivered -- any readable address will do)
         const bool head = F < 0;                                                     // wave uniform; two straight-line copies (a select between the two offset arrays sent them to scratch)
@@ -390,6 +453,29 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         if (newer > 7) newer = 7;
         wait_newer(newer);
     };
+    // PS: the post factors of group `gnext` (window start of its first tile: wgn): this role wave's 64 of the PTN entries -- (K-range 2 role + lane / 32, side, column)
+    // of its own team; the loads are issued by ps_load, the products written by ps_store just in front of the barrier that ends the previous group
+    float2 psC = make_float2(1.f, 0.f), psD = psC, psK = psC;
+    const int ps_e = (2 * team + (w == rb ? 1 : 0)) * 64 + lane;
+    auto ps_load = [&](long long wgn) {
+        const int tcol = ps_e & 15, side = (ps_e >> 4) & 1, w2 = (ps_e >> 5) & 3;
+        const long long n02 = p.B + ((wgn + (long long)team * tstride) >> 1);
+        const WaveGeom g2 = ddc_wave_geom(n02, w2);
+        const int chunk_rel2 = (int)(g2.chunk - (p.B >> 10)) + (col0 + tcol) * p.col_chunks;
+        const int off2 = (int)((n02 + 32LL * DDC_NKW * w2) & 1023);
+        int ci = side ? chunk_rel2 + 2 : max(chunk_rel2 + 1, 0);
+        ci = min(ci, p.tab_len - 1);                                                 // (columns behind the block's end)
+        const int ex = side ? g2.e0 - 1024 : g2.e0;
+        const int cj = side ? max(off2 + 32 * DDC_NKW - 1024, 0) / 2 : off2 + (g2.two ? (1024 - off2) / 2 : 16 * DDC_NKW);
+        psC = ctab[(size_t)ci * p.tab_pitch]; psD = dtab[ex + 2048];
+        if (corr) psK = corr[(size_t)ci * 32 + (cj >> 5)];
+    };
+    auto ps_store = [&](int gnext) {
+        float2 P = cmulf(psC, psD);
+        if (corr) P = cmulf(P, psK);
+        ptab[(gnext & 1) * PTN + ps_e] = P;
+    };
+    if (PS && has_role) { ps_load(wg); ps_store(0); }
     if (fetches) {
         while (F < F_end && F + 1024 <= wg + RB) row_step();
         wait_for(wg + (long long)(NT - 1) * tstride);
@@ -404,6 +490,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         const int it = gi * NT + team;                                               // this team's tile of the group
         const bool active = it < n_it;
         const long long ws = wg + (long long)team * tstride;                         // window start of this team's tile
+        if (PS && has_role && gi + 1 < n_grp) ps_load(wg + (long long)NT * tstride);
 #if DDC_DIAG == 1
         float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
 #else
@@ -435,28 +522,37 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
                 default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
             }
             // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
-            float2 P0 = cmulf(ctab[ci0], dtab[g.e0 + 2048]);
-            // optional per-chunk correction (rates for which the reference's float recurrence drifts away from C_m D^k): sampled at the
-            // centre of the K-range's part in each chunk
+            const float2 *pt = ptab + (gi & 1) * PTN + ((team * WPT + w) * 2) * 16 + col;      // PS: prepared by the role waves one group ahead
+            float2 P0;
             const int off = (int)((n0 + 32LL * DDC_NKW * w) & 1023);
-            if (corr) P0 = cmulf(P0, corr[ci0 * 32 + ((off + (g.two ? (1024 - off) / 2 : 16 * DDC_NKW)) >> 5)]);
+            if constexpr (PS) P0 = pt[0];
+            else {
+                P0 = cmulf(ctab[ci0], dtab[g.e0 + 2048]);
+                // optional per-chunk correction (rates for which the reference's float recurrence drifts away from C_m D^k): sampled at the
+                // centre of the K-range's part in each chunk
+                if (corr) P0 = cmulf(P0, corr[ci0 * 32 + ((off + (g.two ? (1024 - off) / 2 : 16 * DDC_NKW)) >> 5)]);
+            }
             float u[4];
             if (g.two) {
                 const float4 cb = *reinterpret_cast<const float4 *>(lcum + g.gb * 16 + 4 * q);
                 const float cbv[4] = {cb.x, cb.y, cb.z, cb.w};
-                float2 P1 = cmulf(ctab[chunk_rel + 2], dtab[g.e0 - 1024 + 2048]);
-                if (corr) P1 = cmulf(P1, corr[(chunk_rel + 2) * 32 + (((off + 32 * DDC_NKW - 1024) / 2) >> 5)]);
+                float2 P1;
+                if constexpr (PS) P1 = pt[16];
+                else {
+                    P1 = cmulf(ctab[chunk_rel + 2], dtab[g.e0 - 1024 + 2048]);
+                    if (corr) P1 = cmulf(P1, corr[(chunk_rel + 2) * 32 + (((off + 32 * DDC_NKW - 1024) / 2) >> 5)]);
+                }
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    u[r] = fmaf(combine_digits(snap[0][r], snap[1][r], snap[2][r]), p.scale, cbv[r] - cg0[r]);
-                    v[r] = fmaf(combine_digits(acc[0][r] - snap[0][r], acc[1][r] - snap[1][r], acc[2][r] - snap[2][r]), p.scale, cg1[r] - cbv[r]);
+                    u[r] = fmaf(combine_digits(snap[0][r], snap[1][r], snap[2][r]), scale, cbv[r] - cg0[r]);
+                    v[r] = fmaf(combine_digits(acc[0][r] - snap[0][r], acc[1][r] - snap[1][r], acc[2][r] - snap[2][r]), scale, cg1[r] - cbv[r]);
                 }
                 part.x = P0.x * u[0] - P0.y * u[1] + (P1.x * v[0] - P1.y * v[1]); part.y = P0.x * u[1] + P0.y * u[0] + (P1.x * v[1] + P1.y * v[0]);
                 part.z = P0.x * u[2] - P0.y * u[3] + (P1.x * v[2] - P1.y * v[3]); part.w = P0.x * u[3] + P0.y * u[2] + (P1.x * v[3] + P1.y * v[2]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; r++) u[r] = fmaf(combine_digits(acc[0][r], acc[1][r], acc[2][r]), p.scale, cfull[r]);
+                for (int r = 0; r < 4; r++) u[r] = fmaf(combine_digits(acc[0][r], acc[1][r], acc[2][r]), scale, cfull[r]);
                 part.x = P0.x * u[0] - P0.y * u[1]; part.y = P0.x * u[1] + P0.y * u[0];
                 part.z = P0.x * u[2] - P0.y * u[3]; part.w = P0.x * u[3] + P0.y * u[2];
             }
@@ -464,6 +560,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
 #endif
         float4 *rbuf = red + ((gi & 1) * NT + team) * (WPT * 64);
         rbuf[w * 64 + lane] = part;
+        if (PS && has_role && gi + 1 < n_grp) ps_store(gi + 1);
         // ---- the next group's windows must have landed before anyone passes the barrier; the ring space behind them is refilled right after
         const long long wg_n = wg + (long long)NT * tstride;
         DPROF_T(0)
@@ -480,21 +577,21 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         // ---- reduction of the four K-range shares and store.  Plain front end: the waves of a team take turns.  FUSE: TWO fixed waves of the team share the epilogue
         // -- role A demodulates the tile's even outputs (it needs the predecessor logic), role B the odd ones; fmdemod_quadri_cf | limit_ff + the digit split is two
         // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
-        const bool role_a = FUSE ? w == ra : w == gi % WPT, role_b = FUSE && w == rb;
+        const bool role_a = ROLES ? w == ra : w == gi % WPT, role_b = ROLES && w == rb;
 #ifndef DDC_NOSTORE
 #define DDC_NOSTORE 0       // experiment (timing only): 1 = no epilogue, nothing stored (what the stores cost the input stream)
 #endif
         if (active && (role_a || role_b) && !DDC_NOSTORE) {
             const float4 yy = ddc_reduce<WPT>(rbuf + lane);                           // (y0.re, y0.im, y1.re, y1.im): outputs 2q, 2q + 1 of stream col
-            const int stream = sb * 16 + col;
+            const int stream = PS ? sb : sb * 16 + col;
             const float2 y0 = make_float2(yy.x, yy.y), y1 = make_float2(yy.z, yy.w);
-            const int kk = kk_seg + 8 * it + 2 * q;                                  // index of y0 in the call's outputs; the first / last tile of a call may be partial
+            const int kk = kk_seg + 8 * it + 2 * q + (PS ? col * 8 * p.tiles_per_seg : 0);  // index of y0 in the call's outputs; the first / last tile of a call may be partial
             const bool ok0 = (unsigned)kk < (unsigned)p.n_out, ok1 = (unsigned)(kk + 1) < (unsigned)p.n_out;
             if (!FUSE) {
                 if (stream < p.n_streams) {
                     float2 *dst = out + (size_t)stream * out_pitch + kk;
-                    if (ok0) dst[0] = y0;
-                    if (ok1) dst[1] = y1;
+                    if (ok0 && (!PS || role_a)) dst[0] = y0;                         // (PS: the two role waves share the stores)
+                    if (ok1 && (!PS || role_b)) dst[1] = y1;
                 }
             } else if (role_a) {
                 // predecessor of output 2q: lane (col, q - 1)'s second output; for q = 0 the previous tile's last output
@@ -511,7 +608,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
                     // last ones (the next segment's predecessor) and the call's last one (the next call's)
                     float2 *ydst = out + (size_t)stream * out_pitch + kk;
                     const bool seg_first = it == 0 && q == 0;
-                    if (ok0 && (seg_first || kk == 0 || kk == p.n_out - 1)) ydst[0] = y0;
+                    if (ok0 && (seg_first || kk == 0 || kk == p.n_out - 1 || kk < p.n_lead_store)) ydst[0] = y0;
                     if (ok0 && !seg_first && kk != 0) {
                         int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
                         int dg[3];
@@ -523,7 +620,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
                 if (stream < p.n_streams) {
                     float2 *ydst = out + (size_t)stream * out_pitch + kk;
                     const bool seg_last = it == n_it - 1 && q == 3;
-                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == p.n_out - 1)) ydst[1] = y1;
+                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == p.n_out - 1 || kk + 1 < p.n_lead_store)) ydst[1] = y1;
                     if (ok1 && kk + 1 != 0) {
                         int8_t *pd0 = fz.planes + (size_t)stream * fz.dl_pitch + fz.dl_fill + kk;
                         int dg[3];
@@ -538,6 +635,11 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
 #ifdef DDC_PROF
     if (lane == 0 && wv < 16) { for (int k = 0; k < 5; k++) atomicAdd(&g_ddc_prof[wv][k], (unsigned long long)prof[k]); atomicAdd(&g_ddc_prof[wv][5], (unsigned long long)n_grp); }
 #endif
+    if (PS && p.hist_out && blockIdx.y + 1 == gridDim.y) {                           // this stream's 2 KiB: the next call's history
+        const uint8_t *srow = in + (size_t)sb * in_pitch;
+        for (int i = tid; i < 2 * DDC_HIST / 16; i += NTHR)
+            *reinterpret_cast<uint4 *>(p.hist_out + (size_t)sb * (2 * DDC_HIST) + 16 * i) = *reinterpret_cast<const uint4 *>(srow + (p.two_T - 2 * DDC_HIST) + 16 * i);
+    } else
     if (p.hist_out && blockIdx.y + 1 == gridDim.y) {                                 // 16 streams x 2 KiB: the next call's history
         for (int i = tid; i < 16 * (2 * DDC_HIST / 16); i += NTHR) {
             const int srow = i / (2 * DDC_HIST / 16), piece = i % (2 * DDC_HIST / 16);
@@ -559,19 +661,34 @@ extern "C" int csdr_amd_debug_ddc_prof(unsigned long long *out, int reset)
 
 // Plain evaluation of the same model, one WAVE per output (lanes split the taps): outputs [ka0, ka0 + na) and [kb0, kb0 + nb) of every stream.
 // Samples before the block come from the history buffer (the previous blocks' last DDC_HIST samples).
-struct DirectParams { int n_streams; long long B; int T, D, L; long long k_out0, ka0, kb0; int na, nb; };
+struct DirectParams {
+    int n_streams; long long B; int T, D, L; long long k_out0, ka0, kb0; int na, nb;
+    // a shift rate per stream (0 / nullptr otherwise): seed of chunk row c of stream s at ctab[c * tab_pitch + s], D^k table of stream s at dtab + s * dtab_stride
+    size_t tab_pitch, dtab_stride; const int *corr_row; size_t corr_chunks;
+    const int *list;                  // != nullptr: blockIdx.y indexes this list of streams (the lead outputs of retuned streams)
+    const float2 *dtab_old;           // != nullptr: samples in front of the block were rotated at the rate of [stream]'s table here (a retune at the block boundary)
+    const float2 *corr_old;           // with dtab_old: [stream][32] drift corrections of that rate for the chunk in front of the block ((1, 0) where it had none)
+};
 
 __global__ __launch_bounds__(256) void k_ddc_direct(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ hist,
                                                     const float *__restrict__ taps, const float2 *__restrict__ dtab, const float2 *__restrict__ ctab,
                                                     const float2 *__restrict__ corr, float2 *__restrict__ out, size_t out_pitch, DirectParams p)
 {
-    const int s = blockIdx.y, lane = threadIdx.x & 63;
+    const int s = p.list ? p.list[blockIdx.y] : blockIdx.y, lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= p.na + p.nb) return;
     const long long k = idx < p.na ? p.ka0 + idx : p.kb0 + (idx - p.na);
     const uint8_t *row = in + (size_t)s * in_pitch;
     const uint8_t *hrow = hist + (size_t)s * (2 * DDC_HIST);
     const long long c0 = p.B >> 10;
+    const size_t cp = p.tab_pitch ? p.tab_pitch : 1;
+    const float2 *dtab_o = dtab;
+    if (p.tab_pitch) {
+        ctab += s; dtab += (size_t)s * p.dtab_stride;
+        const int crow = p.corr_row ? p.corr_row[s] : -1;
+        corr = (corr && crow >= 0) ? corr + (size_t)crow * p.corr_chunks * 32 : nullptr;
+        dtab_o = p.dtab_old ? p.dtab_old + (size_t)s * p.dtab_stride : dtab;
+    }
     float ai = 0.f, aq = 0.f;
     // (four taps per lane and round: the loop is a chain of dependent gathers -- sample bytes, chunk phasor, model phasor, correction -- and one round trip per
     // tap made this edge kernel 32 us of the NFM step)
@@ -581,8 +698,9 @@ __global__ __launch_bounds__(256) void k_ddc_direct(const uint8_t *__restrict__ 
         uint32_t vi, vq;
         if (rel < 0) { vi = hrow[2 * (rel + DDC_HIST)]; vq = hrow[2 * (rel + DDC_HIST) + 1]; }
         else { vi = row[2 * rel]; vq = row[2 * rel + 1]; }
-        float2 R = cmulf(ctab[(n >> 10) - c0 + 1], dtab[(int)(n & 1023) + 2048]);
-        if (corr) R = cmulf(R, corr[((n >> 10) - c0 + 1) * 32 + ((int)(n & 1023) >> 5)]);
+        float2 R = cmulf(ctab[((n >> 10) - c0 + 1) * cp], (rel < 0 ? dtab_o : dtab)[(int)(n & 1023) + 2048]);
+        if (rel < 0 && p.dtab_old) R = cmulf(R, p.corr_old[(size_t)s * 32 + ((int)(n & 1023) >> 5)]);
+        else if (corr) R = cmulf(R, corr[((n >> 10) - c0 + 1) * 32 + ((int)(n & 1023) >> 5)]);
         const float xi = u8_to_f(vi), xq = u8_to_f(vq);
         const float h = taps[t];
         ai = fmaf(h, xi * R.x - xq * R.y, ai);
@@ -625,31 +743,57 @@ struct csdr_amd_ddc {
     long long B, next_k;
     std::string kernel_name;
     bool profiling; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used; double prof_ms; long prof_launches;
+    // a shift rate per stream (csdr_amd_ddc_create_rates)
+    bool ps; std::vector<float> rates, h_taps; csdr_amd::SeedTables *seeds; float *d_scales;
+    float2 *d_dtab_old, *d_corr_old; int *d_list; std::vector<int> retuned;      // streams retuned since the last call: their first outputs straddle two rates (lead fix-up)
+    int fallback;                                                     // 1: the last call ran outside the matrix-core kernel (csdr_amd_ddc_fallback)
 };
+
+// tables of ONE stream of a per-stream object: weights, prefix sums, scale, D^k
+static int ddc_upload_stream_tables(csdr_amd_ddc *d, int s, float rate)
+{
+    if (d->use_mfma) {
+        DdcTable t;
+        ddc_build_table(d->D, d->L, rate, d->h_taps.data(), t);
+        CSDR_HIP(hipMemcpy((uint8_t *)d->d_frags + (size_t)s * t.frags.size(), t.frags.data(), t.frags.size(), hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(d->d_cum + (size_t)s * t.cum.size(), t.cum.data(), t.cum.size() * sizeof(float), hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(d->d_dtab + (size_t)s * DDC_DTAB, t.dtab.data(), sizeof(float2) * DDC_DTAB, hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(d->d_scales + s, &t.scale, sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float2> dt; ddc_build_dtab(rate, dt);
+        CSDR_HIP(hipMemcpy(d->d_dtab + (size_t)s * DDC_DTAB, dt.data(), sizeof(float2) * DDC_DTAB, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
 
 extern "C" {
 
-csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
-                                  size_t max_block_samples)
+static csdr_amd_ddc *ddc_create_impl(csdr_amd_ctx *ctx, int n_streams, const float *rates, bool ps, int decimation, const float *host_taps, int taps_length,
+                                     size_t max_block_samples)
 {
-    if (!ctx || n_streams < 1 || decimation < 1 || taps_length < 1 || !host_taps) { fail_msg(-3, "ddc_create: bad arguments"); return nullptr; }
+    if (!ctx || n_streams < 1 || decimation < 1 || taps_length < 1 || !host_taps || !rates) { fail_msg(-3, "ddc_create: bad arguments"); return nullptr; }
     if (taps_length - 1 > DDC_HIST) { fail_msg(-3, "ddc_create: %d taps exceed the %d-sample history", taps_length, DDC_HIST + 1); return nullptr; }
     if (max_block_samples < 1024) max_block_samples = 1024;
+    const float shift_rate = rates[0];
     csdr_amd_ddc *d = new csdr_amd_ddc();
     d->ctx = ctx; d->n_streams = n_streams; d->D = decimation; d->L = taps_length; d->shift_rate = shift_rate; d->max_block = max_block_samples;
     d->d_taps = nullptr; d->d_hist[0] = d->d_hist[1] = nullptr; d->d_frags = nullptr; d->d_cum = nullptr; d->d_dtab = nullptr; d->d_ctab = nullptr; d->d_corr = nullptr;
     d->profiling = false; d->ev_used = 0; d->prof_ms = 0; d->prof_launches = 0;
+    d->ps = ps; d->seeds = nullptr; d->d_scales = nullptr; d->d_dtab_old = nullptr; d->d_corr_old = nullptr; d->d_list = nullptr; d->fallback = 0;
     d->ctab_cap = 16 * (max_block_samples / 1024 + 8);                 // seeds for 16 calls of the largest block ahead (see ddc_process_fused)
     hipError_t e = hipSuccess;
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    const size_t nt = ps ? (size_t)n_streams : 1;                      // table sets
     alloc((void **)&d->d_taps, sizeof(float) * taps_length);
     alloc((void **)&d->d_hist[0], (size_t)2 * DDC_HIST * n_streams);
     alloc((void **)&d->d_hist[1], (size_t)2 * DDC_HIST * n_streams);
-    alloc((void **)&d->d_dtab, sizeof(float2) * DDC_DTAB);
-    alloc((void **)&d->d_ctab, sizeof(float2) * d->ctab_cap);
-    {   // CSDR_AMD_DDC_CORR: 0 = never, 1 = always, default = only for rates whose float recurrence drifts (model deviation > 2e-6 RMS)
-        const char *ce = getenv("CSDR_AMD_DDC_CORR");
-        d->need_corr = ce ? atoi(ce) != 0 : ddc_rotator_model_rms(shift_rate) > 2e-6;
+    alloc((void **)&d->d_dtab, sizeof(float2) * DDC_DTAB * nt);
+    if (!ps) alloc((void **)&d->d_ctab, sizeof(float2) * d->ctab_cap);
+    const char *ce = getenv("CSDR_AMD_DDC_CORR");                     // 0 = never, 1 = always, default = only for rates whose float recurrence drifts (model deviation > 2e-6 RMS)
+    auto drifts = [&](float r) { return ce ? atoi(ce) != 0 : ddc_rotator_model_rms(r) > 2e-6; };
+    d->need_corr = false;
+    if (!ps) {
+        d->need_corr = drifts(shift_rate);
         if (d->need_corr) alloc((void **)&d->d_corr, sizeof(float2) * d->ctab_cap * 32);
     }
     if (e == hipSuccess) e = hipMemcpy(d->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
@@ -657,7 +801,26 @@ csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     d->use_mfma = ddc_mfma_supported(decimation, taps_length) && !(force && !strcmp(force, "direct"));
     d->whole_off = getenv("CSDR_AMD_DDC_WHOLE") && atoi(getenv("CSDR_AMD_DDC_WHOLE")) == 0;      // A/B: interior tiles only, the edges on k_ddc_direct (round 2's split)
     d->scale = 0; d->nk_used = 0;
-    if (d->use_mfma) {
+    if (ps) {
+        d->rates.assign(rates, rates + n_streams); d->h_taps.assign(host_taps, host_taps + taps_length);
+        alloc((void **)&d->d_scales, sizeof(float) * n_streams);
+        if (d->use_mfma) {
+            d->nk_used = (2 * (7 * decimation + taps_length) + 63) / 64;
+            alloc(&d->d_frags, (size_t)DDC_NKT * 3 * 64 * 16 * nt);
+            alloc((void **)&d->d_cum, (size_t)DDC_NGRAN * 16 * sizeof(float) * nt);
+        }
+        for (int s = 0; s < n_streams && e == hipSuccess; s++) {
+            const int rc = ddc_upload_stream_tables(d, s, rates[s]);
+            if (rc) { csdr_amd_ddc_destroy(d); return nullptr; }
+        }
+        if (e == hipSuccess) {
+            d->seeds = seeds_create(ctx, n_streams, rates, d->d_dtab, DDC_DTAB, max_block_samples);
+            if (!d->seeds) { csdr_amd_ddc_destroy(d); return nullptr; }
+            std::vector<char> dr(n_streams);
+            for (int s = 0; s < n_streams; s++) dr[s] = drifts(rates[s]) ? 1 : 0;
+            if (seeds_set_drift(d->seeds, dr)) { csdr_amd_ddc_destroy(d); return nullptr; }
+        }
+    } else if (d->use_mfma) {
         DdcTable t;
         ddc_build_table(decimation, taps_length, shift_rate, host_taps, t);
         d->scale = t.scale; d->nk_used = (2 * (7 * decimation + taps_length) + 63) / 64;
@@ -676,12 +839,63 @@ csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     return d;
 }
 
+csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
+                                  size_t max_block_samples)
+{
+    return ddc_create_impl(ctx, n_streams, &shift_rate, false, decimation, host_taps, taps_length, max_block_samples);
+}
+
+csdr_amd_ddc *csdr_amd_ddc_create_rates(csdr_amd_ctx *ctx, int n_streams, const float *shift_rates, int decimation, const float *host_taps, int taps_length,
+                                        size_t max_block_samples)
+{
+    return ddc_create_impl(ctx, n_streams, shift_rates, true, decimation, host_taps, taps_length, max_block_samples);
+}
+
+// Retune of one stream: effective from the next call's first sample (a chunk boundary), the phase carries over -- `csdr shift_addition_cc --fifo` (csdr.c:881-923:
+// a new rate is picked up between two reads, starting_phase survives).  The first outputs of the next call still reach into samples rotated at the old rate:
+// they are recomputed by the plain kernel with both tables (ddc_process_fused).
+int csdr_amd_ddc_set_rate(csdr_amd_ddc *d, int stream, float shift_rate)
+{
+    if (!d->ps) return fail_msg(-3, "ddc_set_rate: the object shares one rate (create it with csdr_amd_ddc_create_rates)");
+    if (stream < 0 || stream >= d->n_streams) return fail_msg(-3, "ddc_set_rate: stream %d out of range", stream);
+    if (d->rates[stream] == shift_rate) return 0;
+    CSDR_HIP(hipStreamSynchronize(d->ctx->stream));                   // calls in flight read this stream's tables
+    if (!d->d_dtab_old) CSDR_HIP(hipMalloc((void **)&d->d_dtab_old, sizeof(float2) * DDC_DTAB * (size_t)d->n_streams));
+    if (!d->d_corr_old) CSDR_HIP(hipMalloc((void **)&d->d_corr_old, sizeof(float2) * 32 * (size_t)d->n_streams));
+    bool listed = false;
+    for (int v : d->retuned) listed |= v == stream;
+    if (!listed) {                                                    // (two retunes between calls: the history was rotated at the first old rate)
+        CSDR_HIP(hipMemcpy(d->d_dtab_old + (size_t)stream * DDC_DTAB, d->d_dtab + (size_t)stream * DDC_DTAB, sizeof(float2) * DDC_DTAB, hipMemcpyDeviceToDevice));
+        // ... and the old rate's drift corrections for the chunk in front of the next block
+        const float2 *co = seeds_corr_entry(d->seeds, stream, d->B / 1024 - 1);
+        if (co) CSDR_HIP(hipMemcpy(d->d_corr_old + (size_t)stream * 32, co, sizeof(float2) * 32, hipMemcpyDeviceToDevice));
+        else {
+            float2 one[32]; for (int i = 0; i < 32; i++) one[i] = make_float2(1.f, 0.f);
+            CSDR_HIP(hipMemcpy(d->d_corr_old + (size_t)stream * 32, one, sizeof one, hipMemcpyHostToDevice));
+        }
+        d->retuned.push_back(stream);
+    }
+    const int rc = ddc_upload_stream_tables(d, stream, shift_rate); if (rc) return rc;
+    d->rates[stream] = shift_rate;
+    const char *ce = getenv("CSDR_AMD_DDC_CORR");
+    return seeds_set_rate(d->seeds, stream, shift_rate, ce ? atoi(ce) != 0 : ddc_rotator_model_rms(shift_rate) > 2e-6);
+}
+
+float csdr_amd_ddc_get_rate(const csdr_amd_ddc *d, int stream)
+{
+    if (d->ps) return (stream >= 0 && stream < d->n_streams) ? d->rates[stream] : 0.f;
+    return d->shift_rate;
+}
+
+int csdr_amd_ddc_fallback(const csdr_amd_ddc *d) { return d->fallback; }
+
 void csdr_amd_ddc_destroy(csdr_amd_ddc *d)
 {
     if (!d) return;
     (void)hipStreamSynchronize(d->ctx->stream);
+    if (d->seeds) seeds_destroy(d->seeds);
     (void)hipFree(d->d_taps); (void)hipFree(d->d_hist[0]); (void)hipFree(d->d_hist[1]); (void)hipFree(d->d_frags); (void)hipFree(d->d_cum);
-    (void)hipFree(d->d_dtab); (void)hipFree(d->d_ctab); (void)hipFree(d->d_corr);
+    (void)hipFree(d->d_dtab); (void)hipFree(d->d_ctab); (void)hipFree(d->d_corr); (void)hipFree(d->d_scales); (void)hipFree(d->d_dtab_old); (void)hipFree(d->d_corr_old); (void)hipFree(d->d_list);
     for (auto &pr : d->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     delete d;
 }
@@ -689,6 +903,8 @@ void csdr_amd_ddc_destroy(csdr_amd_ddc *d)
 int csdr_amd_ddc_reset(csdr_amd_ddc *d)
 {
     d->phase = 0.f; d->c_prev = make_float2(1.f, 0.f); d->B = 0; d->next_k = 0; d->ended = false; d->hflip = 0; d->tab_valid = false; d->tab_first = 0;
+    d->retuned.clear();
+    if (d->seeds) { const int rc = seeds_reset(d->seeds); if (rc) return rc; }
     CSDR_HIP(hipMemsetAsync(d->d_hist[0], 0x80, (size_t)2 * DDC_HIST * d->n_streams, d->ctx->stream));
     CSDR_HIP(hipMemsetAsync(d->d_hist[1], 0x80, (size_t)2 * DDC_HIST * d->n_streams, d->ctx->stream));
     return 0;
@@ -743,6 +959,11 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
     const long long first = d->B / 1024 - 1;
     const float inc = (d->shift_rate * 2) * PI_F;
     int rc = 0;
+    SeedView sv; memset(&sv, 0, sizeof sv);
+    if (d->ps) {
+        // a rate per stream: the same bookkeeping, one lane per stream on a side stream, a few calls ahead (seeds.hip)
+        rc = seeds_acquire(d->seeds, first, nch + 3, (T % 1024) ? 0 : nch, &sv); if (rc) return rc;
+    } else
     if (!d->tab_valid || first < d->tab_first || first + (long long)nch + 3 > d->tab_first + (long long)d->ctab_cap) {
         float2 *hc = (float2 *)c->pinned_acquire(sizeof(float2) * d->ctab_cap);
         if (!hc) return -2;
@@ -762,9 +983,9 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
         }
         d->tab_first = first; d->tab_valid = true;
     }
-    const float2 *ctab = d->d_ctab + (first - d->tab_first);
-    const float2 *corr = d->need_corr ? d->d_corr + (first - d->tab_first) * 32 : nullptr;
-    {   // the stream's phase behind this block (and the seed of its last chunk, for a table rebuilt at the next call)
+    const float2 *ctab = d->ps ? sv.ctab : d->d_ctab + (first - d->tab_first);
+    const float2 *corr = d->ps ? sv.corr : d->need_corr ? d->d_corr + (first - d->tab_first) * 32 : nullptr;
+    if (!d->ps) {   // the stream's phase behind this block (and the seed of its last chunk, for a table rebuilt at the next call)
         float ph = d->phase;
         for (size_t m = 0; m < nch; m++) {
             if (m + 1 == nch) d->c_prev = make_float2((float)cos((double)ph), (float)sin((double)ph));
@@ -808,8 +1029,13 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
             }
         }
         const int n_cu = current_device_cu_count();
+        if (d->ps && !whole) { ta = 0; tb = -1; }                     // a rate per stream: the matrix-core kernel takes whole calls only, everything else is k_ddc_direct's
+        // retuned streams: their outputs with D k < B reach into samples that were rotated at the old rate
+        long n_fix = 0;
+        if (d->ps && !d->retuned.empty()) { n_fix = (long)((d->B + d->D - 1) / d->D - k_first); if (n_fix < 0) n_fix = 0; if (n_fix > n_out) n_fix = n_out; }
         if (tb >= ta) {
             DdcParams p;
+            memset(&p, 0, sizeof p);
             p.n_streams = d->n_streams; p.B = d->B; p.tile_first = ta; p.n_tiles = (int)(tb - ta + 1); p.k_out0 = k_first; p.D = d->D; p.nk_used = d->nk_used; p.scale = d->scale;
             p.two_T = 2LL * T; p.hist_out = (T >= DDC_HIST && (T & 7) == 0) ? d->d_hist[d->hflip ^ 1] : nullptr; hist_saved = p.hist_out != nullptr;
             p.n_out = (int)n_out; p.hist_in = whole ? d->d_hist[d->hflip] : nullptr;
@@ -825,28 +1051,53 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
             if (n_seg < 1) n_seg = 1;
             p.tiles_per_seg = (p.n_tiles + n_seg - 1) / n_seg;
             n_seg = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
-            const size_t lds = (size_t)16 * ((1u << rbl) + DDC_RING_PAD) + (size_t)2 * nt * DDC_WPT * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2);
+            int n_cols = 0, gx = n_wsb, gy = n_seg;
+            if (d->ps) {
+                // columns: a whole number of periods lcm(8 D, 1024) samples each, 16 per workgroup; about two workgroups per CU at most
+                long long per = 8LL * d->D; { long long a = per, b = 1024; while (b) { const long long t = a % b; a = b; b = t; } per = per / a * 1024; }
+                const int tpp = (int)(per / (8 * d->D));               // tiles per period
+                const int n_per = (p.n_tiles + tpp - 1) / tpp;
+                int n_ss = (2 * n_cu + d->n_streams - 1) / d->n_streams; if (n_ss < 1) n_ss = 1;
+                int np = (n_per + 16 * n_ss - 1) / (16 * n_ss); if (np < 1) np = 1;
+                p.tiles_per_seg = np * tpp;
+                n_cols = (p.n_tiles + p.tiles_per_seg - 1) / p.tiles_per_seg;
+                gx = d->n_streams; gy = (n_cols + 15) / 16;
+                p.col_bytes = (long long)p.tiles_per_seg * tstride; p.col_chunks = (int)(p.col_bytes / 2048);
+                p.frag_stride = (size_t)DDC_NKT * 3 * 64; p.tab_pitch = sv.pitch; p.tab_len = sv.n_entries;
+                p.scales = d->d_scales; p.corr_row = sv.corr_row; p.corr_chunks = sv.corr_chunks;
+            }
+            p.n_lead_store = (fuse && n_fix > 0) ? (int)n_fix + 1 : 0;
+            const size_t lds = (size_t)16 * ((1u << rbl) + DDC_RING_PAD) + (size_t)2 * nt * DDC_WPT * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2)
+                               + (d->ps ? (size_t)2 * nt * DDC_WPT * 2 * 16 * sizeof(float2) : 0);
             DdcFuse fz; memset(&fz, 0, sizeof fz); if (fuse) fz = *fuse;
-#define DDC_LAUNCH(NTV, FV, THREADS) do {                                                                                                                  \
-                const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV>, lds); if (arc) return arc;                                              \
+#define DDC_LAUNCH(NTV, FV, PSV, THREADS) do {                                                                                                             \
+                const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV, PSV>, lds); if (arc) return arc;                                         \
                 if (e0) CSDR_HIP(hipEventRecord(e0, st));                                                                                                      \
-                hipLaunchKernelGGL((k_ddc_mfma<rbl, NTV, FV>), dim3(n_wsb, n_seg), dim3(THREADS), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, ctab, \
+                hipLaunchKernelGGL((k_ddc_mfma<rbl, NTV, FV, PSV>), dim3(gx, gy), dim3(THREADS), lds, st, in, in_pitch, (const v4i *)d->d_frags, d->d_cum, d->d_dtab, ctab, \
                                    corr, reinterpret_cast<float2 *>(out), out_pitch, p, fz); } while (0)
-            if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, 128 * DDC_WPT); else DDC_LAUNCH(1, true, 64 * DDC_WPT); }
-            else      { if (nt == 2) DDC_LAUNCH(2, false, 128 * DDC_WPT); else DDC_LAUNCH(1, false, 64 * DDC_WPT); }
+            if (d->ps) {
+                if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, true, 128 * DDC_WPT); else DDC_LAUNCH(1, true, true, 64 * DDC_WPT); }
+                else      { if (nt == 2) DDC_LAUNCH(2, false, true, 128 * DDC_WPT); else DDC_LAUNCH(1, false, true, 64 * DDC_WPT); }
+            } else {
+                if (fuse) { if (nt == 2) DDC_LAUNCH(2, true, false, 128 * DDC_WPT); else DDC_LAUNCH(1, true, false, 64 * DDC_WPT); }
+                else      { if (nt == 2) DDC_LAUNCH(2, false, false, 128 * DDC_WPT); else DDC_LAUNCH(1, false, false, 64 * DDC_WPT); }
+            }
 #undef DDC_LAUNCH
             CSDR_LAUNCH_CHECK();
             if (fuse && info) {
-                info->fused = true; info->seg_outputs = 8L * p.tiles_per_seg; info->n_seg = n_seg; info->seg_first = (long)(8 * ta - k_first);
+                info->fused = true; info->seg_outputs = 8L * p.tiles_per_seg; info->n_seg = d->ps ? n_cols : n_seg; info->seg_first = (long)(8 * ta - k_first);
                 if (whole) { info->n_lead = 8 * ta < k_first ? 1 : 0; info->trail_first = n_out; info->n_trail = 0; }      // lead = the call's first output when its tile is partial
                 else { info->n_lead = (long)(8 * ta - k_first); info->trail_first = (long)(8 * (tb + 1) - k_first); info->n_trail = (long)(k_hi - 8 * (tb + 1) + 1); }
+                if (info->n_lead < p.n_lead_store) info->n_lead = p.n_lead_store;                                            // (retuned streams: the plain kernel below rewrites their first samples)
             }
             if (e1) CSDR_HIP(hipEventRecord(e1, st));
             d->kernel_name = "k_ddc_mfma";
         } else d->kernel_name = "k_ddc_direct";
         // everything else: leading outputs (history), trailing outputs of the last partial tile, or the whole block
         DirectParams q;
+        memset(&q, 0, sizeof q);
         q.n_streams = d->n_streams; q.B = d->B; q.T = T; q.D = d->D; q.L = d->L; q.k_out0 = k_first;
+        if (d->ps) { q.tab_pitch = sv.pitch; q.dtab_stride = DDC_DTAB; q.corr_row = sv.corr_row; q.corr_chunks = sv.corr_chunks; }
         if (whole) { q.ka0 = k_first; q.na = 0; q.kb0 = 0; q.nb = 0; }
         else if (tb >= ta) { q.ka0 = k_first; q.na = (int)(8 * ta - k_first); q.kb0 = 8 * (tb + 1); q.nb = (int)(k_hi - q.kb0 + 1); }
         else { q.ka0 = k_first; q.na = (int)n_out; q.kb0 = 0; q.nb = 0; }
@@ -857,7 +1108,22 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
             CSDR_LAUNCH_CHECK();
             if (tb < ta && e1) CSDR_HIP(hipEventRecord(e1, st));
         }
+        d->fallback = tb >= ta ? 0 : 1;
+        if (n_fix > 0) {
+            // the first outputs of the streams retuned since the last call, with the old rate's table for the samples in front of the block
+            const int nr = (int)d->retuned.size();
+            if (!d->d_list) CSDR_HIP(hipMalloc((void **)&d->d_list, sizeof(int) * d->n_streams));
+            int *hl = (int *)c->pinned_acquire(sizeof(int) * nr); if (!hl) return -2;
+            memcpy(hl, d->retuned.data(), sizeof(int) * nr);
+            rc = c->pinned_upload(d->d_list, sizeof(int) * nr); if (rc) return rc;
+            DirectParams f = q;
+            f.ka0 = k_first; f.na = (int)n_fix; f.kb0 = 0; f.nb = 0; f.list = d->d_list; f.dtab_old = d->d_dtab_old; f.corr_old = d->d_corr_old;
+            hipLaunchKernelGGL(k_ddc_direct, dim3(cdiv(f.na, 4), nr), dim3(256), 0, st, in, in_pitch, d->d_hist[d->hflip], d->d_taps, d->d_dtab, ctab, corr,
+                               reinterpret_cast<float2 *>(out), out_pitch, f);
+            CSDR_LAUNCH_CHECK();
+        }
     }
+    if (n_out > 0) d->retuned.clear();
     // 3. history for the next block (the matrix-core kernel's last segment has done it when it ran on a whole block)
     if (!hist_saved) hipLaunchKernelGGL(k_ddc_save_hist, dim3(d->n_streams), dim3(256), 0, st, in, in_pitch, T, d->d_hist[d->hflip], d->d_hist[d->hflip ^ 1]);
     CSDR_LAUNCH_CHECK();

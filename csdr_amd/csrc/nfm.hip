@@ -204,8 +204,8 @@ struct csdr_amd_nfm {
 
 extern "C" {
 
-csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
-                                  int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples)
+static csdr_amd_nfm *nfm_create_impl(csdr_amd_ctx *ctx, int n_streams, const float *rates, bool per_stream, int decimation, const float *host_taps, int taps_length,
+                                     int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples)
 {
     if (!ctx || n_streams < 1 || agc_block < 1 || agc_block > 2048 - 512 || (agc_block % 16) || !(limit_max > 0)) { fail_msg(-3, "nfm_create: bad arguments (agc_block: multiple of 16 up to 1536; limit > 0)"); return nullptr; }
     const float *dt = nullptr;
@@ -216,7 +216,8 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     csdr_amd_nfm *w = new csdr_amd_nfm();
     memset(w, 0, sizeof(*w));
     w->ctx = ctx; w->n_streams = n_streams; w->D = decimation; w->Ld = Ld; w->agc_block = agc_block; w->limit = limit_max; w->agc_ref = agc_reference;
-    w->ddc = csdr_amd_ddc_create(ctx, n_streams, shift_rate, decimation, host_taps, taps_length, max_block_samples);
+    w->ddc = per_stream ? csdr_amd_ddc_create_rates(ctx, n_streams, rates, decimation, host_taps, taps_length, max_block_samples)
+                        : csdr_amd_ddc_create(ctx, n_streams, rates[0], decimation, host_taps, taps_length, max_block_samples);
     if (!w->ddc) { delete w; return nullptr; }
     { const char *fe = getenv("CSDR_AMD_NFM_FUSE"); w->fuse_off = fe && atoi(fe) == 0; }
     w->max_y = max_block_samples / decimation + 2;
@@ -246,6 +247,21 @@ csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (csdr_amd_nfm_reset(w)) { csdr_amd_nfm_destroy(w); return nullptr; }
     return w;
 }
+
+csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
+                                  int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples)
+{
+    return nfm_create_impl(ctx, n_streams, &shift_rate, false, decimation, host_taps, taps_length, audio_rate, agc_block, agc_reference, limit_max, max_block_samples);
+}
+
+csdr_amd_nfm *csdr_amd_nfm_create_rates(csdr_amd_ctx *ctx, int n_streams, const float *shift_rates, int decimation, const float *host_taps, int taps_length,
+                                        int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples)
+{
+    if (!shift_rates) { fail_msg(-3, "nfm_create_rates: no rates"); return nullptr; }
+    return nfm_create_impl(ctx, n_streams, shift_rates, true, decimation, host_taps, taps_length, audio_rate, agc_block, agc_reference, limit_max, max_block_samples);
+}
+
+int csdr_amd_nfm_set_rate(csdr_amd_nfm *w, int stream, float shift_rate) { return csdr_amd_ddc_set_rate(w->ddc, stream, shift_rate); }
 
 void csdr_amd_nfm_destroy(csdr_amd_nfm *w)
 {

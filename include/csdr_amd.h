@@ -388,6 +388,19 @@ int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches);
 typedef struct csdr_amd_ddc csdr_amd_ddc;
 csdr_amd_ddc *csdr_amd_ddc_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation,
                                   const float *host_taps, int taps_length, size_t max_block_samples);
+/* The same with a shift rate PER STREAM -- the reference's unit of work is one (stream, shift_rate) pair: `csdr shift_addition_cc --fifo` retunes a running stream
+ * (csdr.c:881-923), ddcd starts one `csdr shift_unroll_cc --fd N | csdr fir_decimate_cc D bw` per client (ddcd_old.h:51-61).  shift_rates: n_streams floats.
+ * The matrix-core kernel then gives a workgroup ONE stream and puts 16 time segments of it into the 16 columns of the product (the weights are the stream's own);
+ * full rate needs blocks of >= 16 x lcm(8 D, 1024) samples per stream and call (409 600 at D = 50), shorter blocks fill fewer columns.
+ * csdr_amd_ddc_set_rate: effective from the next call's first sample, the float phase carries over exactly as the reference's starting_phase does; the outputs of
+ * that call whose window still reaches into samples rotated at the old rate are evaluated with both rates.  Returns 0 or a negative error. */
+csdr_amd_ddc *csdr_amd_ddc_create_rates(csdr_amd_ctx *ctx, int n_streams, const float *shift_rates, int decimation,
+                                        const float *host_taps, int taps_length, size_t max_block_samples);
+int   csdr_amd_ddc_set_rate(csdr_amd_ddc *d, int stream, float shift_rate);
+float csdr_amd_ddc_get_rate(const csdr_amd_ddc *d, int stream);
+/* 1 when the last process() call ran outside the matrix-core kernel (k_ddc_direct: odd decimation, windows beyond 2304 bytes, input pitch not a multiple of 128 bytes,
+ * ragged or very short blocks): same results, a fraction of the rate */
+int   csdr_amd_ddc_fallback(const csdr_amd_ddc *d);
 void csdr_amd_ddc_destroy(csdr_amd_ddc *d);
 int  csdr_amd_ddc_reset(csdr_amd_ddc *d);
 /* in: u8 IQ, [n_streams][in_pitch bytes], block_samples complex samples per stream (multiple of 1024 except for the last block of a
@@ -412,6 +425,10 @@ int csdr_amd_debug_ddc_mfma_tile(int D, int L, float shift_rate, const float *ta
 typedef struct csdr_amd_nfm csdr_amd_nfm;
 csdr_amd_nfm *csdr_amd_nfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length,
                                   int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples);
+/* a shift rate per channel, and its retune (csdr_amd_ddc_create_rates / csdr_amd_ddc_set_rate on the chain's front end) */
+csdr_amd_nfm *csdr_amd_nfm_create_rates(csdr_amd_ctx *ctx, int n_streams, const float *shift_rates, int decimation, const float *host_taps, int taps_length,
+                                        int audio_rate, int agc_block, float agc_reference, float limit_max, size_t max_block_samples);
+int  csdr_amd_nfm_set_rate(csdr_amd_nfm *w, int stream, float shift_rate);
 void csdr_amd_nfm_destroy(csdr_amd_nfm *w);
 int  csdr_amd_nfm_reset(csdr_amd_nfm *w);
 /* in: u8 IQ as for csdr_amd_ddc_process.  audio_s16: [n_streams][out_pitch]; audio_f (optional, may be NULL): the float audio before
