@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--spinup-ms", type=float, default=60.0, help=bc.SPINUP_HELP)
     ap.add_argument("--streams", type=int, default=512)
     ap.add_argument("--block", type=int, default=2344 * 1024)
+    ap.add_argument("--uniform-rate", action="store_true", help="ONE shift rate (-0.05) for all channels: the shared-weights kernel of rounds 1-3 (csdr_amd_nfm_create); default: "
+                    "a rate per channel (csdr_amd_nfm_create_rates), config 5 as SURVEY.md section 8d defines it")
     ap.add_argument("--front-end-only", action="store_true", help="time csdr_amd_ddc_process alone (convert | shift | fir_decimate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
@@ -59,25 +61,29 @@ def main():
     assert T % 1024 == 0
     taps = ctx.firdes_lowpass_f(ctx.firdes_filter_len(0.005), 0.5 / D, "HAMMING")      # csdr.c:1144-1158: 801 taps
     pitch = 2 * T
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import verify_configs as vc
+    rates = np.full(S, -0.05, np.float32) if args.uniform_rate else vc.c5_rates(S)
     g = torch.Generator(device="cuda"); g.manual_seed(5000 + rank)
     x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda", generator=g)
     strict_rows = []
     if args.verify and rank == 0 and not args.front_end_only:
         # rows held to +-1 LSB on every sample: a real narrow-band FM signal in a few rows spread over the batch, put there BEFORE the timed loop
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         from tests_helpers import nfm_signal_u8
-        strict_rows = sorted({r for r in (5, S // 3 + 1, (2 * S) // 3 + 2, S - 2) if 0 <= r < S})
+        strict_rows = sorted({r for r in (5, S // 3 + 1, (2 * S) // 3 + 2, S - 2) if 0 <= r < S})      # (with a rate per channel: the four drifting rates)
         for k, r in enumerate(strict_rows):
-            x[r, :2 * T] = torch.from_numpy(nfm_signal_u8(7100 + k, T, offset=0.05)).cuda()
+            x[r, :2 * T] = torch.from_numpy(nfm_signal_u8(7100 + k, T, offset=-float(rates[r]))).cuda()
     n_out_max = (T // D + 2048 + 63) // 64 * 64
     out_s16 = torch.empty((S, n_out_max), dtype=torch.int16, device="cuda")
     out_y = torch.empty((S, n_out_max, 2), dtype=torch.float32, device="cuda") if args.front_end_only else None
     torch.cuda.synchronize()
+    tp, rp = taps.ctypes.data_as(C.c_void_p), rates.ctypes.data_as(C.c_void_p)
     if args.front_end_only:
-        obj = L.csdr_amd_ddc_create(ctx.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, T)
+        obj = L.csdr_amd_ddc_create(ctx.h, S, -0.05, D, tp, taps.size, T) if args.uniform_rate else L.csdr_amd_ddc_create_rates(ctx.h, S, rp, D, tp, taps.size, T)
         fe = obj
     else:
-        obj = L.csdr_amd_nfm_create(ctx.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
+        obj = (L.csdr_amd_nfm_create(ctx.h, S, -0.05, D, tp, taps.size, 48000, 1024, 1.0, 1.0, T) if args.uniform_rate else
+               L.csdr_amd_nfm_create_rates(ctx.h, S, rp, D, tp, taps.size, 48000, 1024, 1.0, 1.0, T))
         fe = L.csdr_amd_nfm_front_end(obj) if obj else None
     if not obj:
         raise SystemExit("create: " + ctx.err())
@@ -128,9 +134,10 @@ def main():
         res = {"metric": "complex MS/s in->out, NFM chain @2.4 MS/s x N channels", "value": round(samples / wall / 1e6, 1), "unit": "complex MS/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_before_warmup": spin_steps, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[4]: NFM chain u8 IQ -> s16 audio (convert_u8_f|shift_addition_cc -0.05|fir_decimate_cc 50 0.005 HAMMING|fmdemod_quadri_cf|"
+               "config": {"workload": "configs[4]: NFM chain u8 IQ -> s16 audio (convert_u8_f|shift_addition_cc " + ("-0.05 for all channels" if args.uniform_rate else "<a rate per channel: %d distinct, -0.4999 .. 0.4999>" % len(set(rates.tolist()))) + "|fir_decimate_cc 50 0.005 HAMMING|fmdemod_quadri_cf|"
                                       "limit_ff|deemphasis_nfm_ff 48000|fastagc_ff|convert_f_s16)" + (" -- FRONT END ONLY (first three stages)" if args.front_end_only else ""),
-                          "channels_per_gpu": S, "block_samples_per_channel": T, "channel_rate_sps": 2400000,
+                          "channels_per_gpu": S, "block_samples_per_channel": T, "channel_rate_sps": 2400000, "shift_rates": "uniform" if args.uniform_rate else "per channel",
+                          "fallback": bool(L.csdr_amd_ddc_fallback(fe)),
                           "realtime_channels_equivalent": round(samples / wall / 2.4e6, 1), "parallelism": "channels sharded, no data-path collective"},
                "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(algo / (k_avg_ms * 1e-3) / 1e9, 1) if k_avg_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(algo / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_avg_ms else None, "traffic": traffic, "traffic_source": traffic_src,
@@ -141,10 +148,8 @@ def main():
                                             "frac": round((2.0 + 2.0 / D) * S * T / (ev_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
                "outputs_per_step_per_channel": produced // max(args.steps, 1)}
         if args.verify and not args.front_end_only:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import verify_configs as vc
             L.csdr_amd_ddc_set_profiling(fe, 0)
-            res["verify"] = vc.verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, rows=[r for r in vc.pick_rows(S) if r not in strict_rows], strict_rows=strict_rows)
+            res["verify"] = vc.verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, shift_rate=rates, rows=[r for r in vc.pick_rows(S) if r not in strict_rows], strict_rows=strict_rows)
         if world == 1 and not args.no_cpu_baseline and not args.front_end_only:
             res["cpu_baseline"] = bc.cpu_baseline("nfm", unit="complex MS/s", single_amount=100.0, probe_amount=4.0, target_wall_s=8.0,
                                                   describe="config 5 NFM chain (README.md:87), one 2.4 MS/s u8 IQ channel per thread, in process with the CLI's block framing")

@@ -314,10 +314,11 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
     // PS (csdr_amd_ddc_create_rates: a shift rate per stream): the weights a h D^t belong to ONE stream, so the 16 columns of the B operand are 16 TIME SEGMENTS
     // ("columns") of that stream instead of 16 streams.  Column starts are a whole number of tiles AND of 1024-chunks apart (lcm(8 D, 1024) samples = 64 tiles at D = 50),
     // so a tile's window sits at the same offset inside a chunk in every column: the chunk-boundary variant, the masks and D^e are the workgroup's, as before; only
-    // the chunk SEEDS differ per column.  The post factors of the next group (seed x D^e x drift correction per (team, K-range, side, column)) are put together by
-    // the role waves -- which never issue LDS-DMA, so their global loads do not drain a ring -- into an LDS table; every wave picks its two entries up per tile
-    // (fewer vector instructions per K-range than the scalar loads and complex products of the shared-rate kernel).  Roles as in the fused kernel, also when the
-    // complex samples are stored (!FUSE).  The first column of a call starts in the history buffer, every other one in the block itself; columns behind the block's
+    // the chunk SEEDS differ per column (and, for a stream whose rate drifts, the corrections).  The post factors of a group (seed x D^e x drift correction per
+    // (team, K-range, side, column)) are put together by the role waves -- which never issue LDS-DMA, so their global loads do not disturb a ring -- into an LDS
+    // table; every K-range wave picks its two entries up per tile (fewer vector instructions per K-range than the scalar loads and complex products of the
+    // shared-rate kernel: the role waves are this kernel's critical path, the others wait for them).  Roles as in the fused kernel, also when the complex samples
+    // are stored (!FUSE).  The first column of a call starts in the history buffer, every other one in the block itself; columns behind the block's
     // end re-read column 0 (their outputs are not stored).
     constexpr bool ROLES = FUSE || PS;
     constexpr int WPT = DDC_WPT, NTHR = 64 * WPT * NT;
@@ -453,29 +454,48 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         if (newer > 7) newer = 7;
         wait_newer(newer);
     };
-    // PS: the post factors of group `gnext` (window start of its first tile: wgn): this role wave's 64 of the PTN entries -- (K-range 2 role + lane / 32, side, column)
-    // of its own team; the loads are issued by ps_load, the products written by ps_store just in front of the barrier that ends the previous group
-    float2 psC = make_float2(1.f, 0.f), psD = psC, psK = psC;
+    // PS: the post factors of a group (window start of its first tile: wgn): this role wave's 64 of the PTN entries -- (K-range 2 role + lane / 32, side, column) of its
+    // own team.  A vector load of this kernel queues behind the CU's LDS-DMA pieces: ~3000 cycles (per-wave cycle profile, -DDDC_PROF: issued at the top of a group
+    // and used at its end the wait cost the role waves ~900 cycles on their way to the barrier).  So the three table loads of group g + 3 are issued right behind
+    // barrier g and stay in flight for a whole group; behind barrier g + 1 they are multiplied (ps_mul -> psP) and the registers reloaded; psP is written in front of
+    // barrier g + 2.  The loads are inline asm with the wait counted by hand: written as plain loads the compiler copied the destination registers at the first merge
+    // of control flow -- a wait for the full latency right behind the issue (the same finding as in fastddc_mfma.hip's fold).  A role wave's only other vector memory
+    // operations are its epilogue's stores, a group old at the wait.  (Measured alternatives, profiles/r4_notes.md: the seeds alone through an LDS table and the
+    // products in the K-range waves -- slower, the role waves' wait is what counts; two register sets two groups ahead -- the wait then needs the number of stores
+    // the epilogue in between has issued.)
+    typedef float ps_v2f __attribute__((ext_vector_type(2)));
+    ps_v2f psC = {1.f, 0.f}, psD = {1.f, 0.f}, psK = {1.f, 0.f};
+    float2 psP = make_float2(1.f, 0.f);
     const int ps_e = (2 * team + (w == rb ? 1 : 0)) * 64 + lane;
     auto ps_load = [&](long long wgn) {
         const int tcol = ps_e & 15, side = (ps_e >> 4) & 1, w2 = (ps_e >> 5) & 3;
-        const long long n02 = p.B + ((wgn + (long long)team * tstride) >> 1);
-        const WaveGeom g2 = ddc_wave_geom(n02, w2);
-        const int chunk_rel2 = (int)(g2.chunk - (p.B >> 10)) + (col0 + tcol) * p.col_chunks;
-        const int off2 = (int)((n02 + 32LL * DDC_NKW * w2) & 1023);
+        const long long n02 = p.B + ((wgn + (long long)team * tstride) >> 1);       // (wave uniform; ddc_wave_geom in 32-bit lane arithmetic)
+        const int o0 = (int)(n02 & 1023), chunk0 = (int)((n02 >> 10) - (p.B >> 10));
+        const int so = o0 + 32 * DDC_NKW * w2, off2 = so & 1023;
+        const int chunk_rel2 = chunk0 + (so >> 10) + (col0 + tcol) * p.col_chunks;
+        const bool two2 = off2 + 32 * DDC_NKW > 1024;
+        const int e02 = off2 - 32 * DDC_NKW * w2;
         int ci = side ? chunk_rel2 + 2 : max(chunk_rel2 + 1, 0);
-        ci = min(ci, p.tab_len - 1);                                                 // (columns behind the block's end)
-        const int ex = side ? g2.e0 - 1024 : g2.e0;
-        const int cj = side ? max(off2 + 32 * DDC_NKW - 1024, 0) / 2 : off2 + (g2.two ? (1024 - off2) / 2 : 16 * DDC_NKW);
-        psC = ctab[(size_t)ci * p.tab_pitch]; psD = dtab[ex + 2048];
-        if (corr) psK = corr[(size_t)ci * 32 + (cj >> 5)];
+        ci = min(ci, p.tab_len - 1);                                                 // (columns behind the block's end; groups behind the segment's last)
+        const int ex = side ? e02 - 1024 : e02;
+        const int cj = side ? max(off2 + 32 * DDC_NKW - 1024, 0) / 2 : off2 + (two2 ? (1024 - off2) / 2 : 16 * DDC_NKW);
+        const float2 *pc = ctab + (size_t)ci * p.tab_pitch, *pd = dtab + (ex + 2048);
+        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(psC) : "v"(pc) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(psD) : "v"(pd) : "memory");
+        if (corr) { const float2 *pk = corr + ((size_t)ci * 32 + (cj >> 5)); asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(psK) : "v"(pk) : "memory"); }
     };
-    auto ps_store = [&](int gnext) {
-        float2 P = cmulf(psC, psD);
-        if (corr) P = cmulf(P, psK);
-        ptab[(gnext & 1) * PTN + ps_e] = P;
+    auto ps_mul = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(psC), "+v"(psD), "+v"(psK) :: "memory");
+        float2 P = cmulf(make_float2(psC.x, psC.y), make_float2(psD.x, psD.y));
+        if (corr) P = cmulf(P, make_float2(psK.x, psK.y));
+        psP = P;
     };
-    if (PS && has_role) { ps_load(wg); ps_store(0); }
+    auto ps_store = [&](int g) { ptab[(g & 1) * PTN + ps_e] = psP; };
+    if (PS && has_role) {
+        ps_load(wg); ps_mul(); ps_store(0);
+        ps_load(wg + (long long)NT * tstride); ps_mul();                             // psP = group 1
+        ps_load(wg + 2LL * NT * tstride);                                            // in flight: group 2
+    }
     if (fetches) {
         while (F < F_end && F + 1024 <= wg + RB) row_step();
         wait_for(wg + (long long)(NT - 1) * tstride);
@@ -490,7 +510,6 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         const int it = gi * NT + team;                                               // this team's tile of the group
         const bool active = it < n_it;
         const long long ws = wg + (long long)team * tstride;                         // window start of this team's tile
-        if (PS && has_role && gi + 1 < n_grp) ps_load(wg + (long long)NT * tstride);
 #if DDC_DIAG == 1
         float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
 #else
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
                 default: ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap); break;
             }
             // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
-            const float2 *pt = ptab + (gi & 1) * PTN + ((team * WPT + w) * 2) * 16 + col;      // PS: prepared by the role waves one group ahead
+            const float2 *pt = ptab + (gi & 1) * PTN + ((team * WPT + w) * 2) * 16 + col;      // PS: prepared by the role waves
             float2 P0;
             const int off = (int)((n0 + 32LL * DDC_NKW * w) & 1023);
             if constexpr (PS) P0 = pt[0];
@@ -578,6 +597,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
         // -- role A demodulates the tile's even outputs (it needs the predecessor logic), role B the odd ones; fmdemod_quadri_cf | limit_ff + the digit split is two
         // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
         const bool role_a = ROLES ? w == ra : w == gi % WPT, role_b = ROLES && w == rb;
+        if (PS && has_role) { ps_mul(); ps_load(wg + 3LL * NT * tstride); }          // psP = group gi + 2; in flight: group gi + 3
 #ifndef DDC_NOSTORE
 #define DDC_NOSTORE 0       // experiment (timing only): 1 = no epilogue, nothing stored (what the stores cost the input stream)
 #endif
@@ -1068,7 +1088,7 @@ long csdr_amd::ddc_process_fused(csdr_amd_ddc *d, const uint8_t *in, size_t in_p
             }
             p.n_lead_store = (fuse && n_fix > 0) ? (int)n_fix + 1 : 0;
             const size_t lds = (size_t)16 * ((1u << rbl) + DDC_RING_PAD) + (size_t)2 * nt * DDC_WPT * 64 * sizeof(float4) + DDC_NGRAN * 16 * sizeof(float) + 2 * 16 * sizeof(float2)
-                               + (d->ps ? (size_t)2 * nt * DDC_WPT * 2 * 16 * sizeof(float2) : 0);
+                               + (d->ps ? (size_t)2 * nt * DDC_WPT * 2 * 16 * sizeof(float2) : 0);      // the per-stream kernel's post factors
             DdcFuse fz; memset(&fz, 0, sizeof fz); if (fuse) fz = *fuse;
 #define DDC_LAUNCH(NTV, FV, PSV, THREADS) do {                                                                                                             \
                 const int arc = lds_attr_once((const void *)k_ddc_mfma<rbl, NTV, FV, PSV>, lds); if (arc) return arc;                                         \

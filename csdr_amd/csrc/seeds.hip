@@ -27,9 +27,11 @@ __global__ __launch_bounds__(64) void k_seed_phases(const float *__restrict__ ra
     float p0 = 0.f, p1 = 0.f;
     if (old_ph) { p0 = old_ph[(size_t)idx * pitch + s]; p1 = old_ph[(size_t)(idx + 1) * pitch + s]; }
     ph[s] = p0; ph[pitch + s] = p1;
+    WrapPlan w; wrap_plan_init(w, step);
+    __builtin_amdgcn_s_setprio(3);                                    // eight waves beside the data kernels' thousands: a chain of dependent operations, let it issue
     float p = p1;
     for (int k = 2; k < cap; k++) {
-        p = wrap_phase_exact(p + step);                               // libcsdr_gpl.c:48-51, exactly (seeds.hpp)
+        p = wrap_plan_apply(w, p + step);                             // libcsdr_gpl.c:48-51, exactly (seeds.hpp)
         ph[(size_t)k * pitch + s] = p;
     }
 }
@@ -292,4 +294,11 @@ int seeds_acquire(SeedTables *t, long long first, size_t n, size_t n_next_hint, 
 
 } // namespace csdr_amd
 
-extern "C" float csdr_amd_debug_wrap_phase(float x) { return csdr_amd::wrap_phase_exact(x); }
+// Test hook: n chunk advances of the phase bookkeeping at `rate` from phase ph0 through the kernels' plan (host build); out[k] = phase after k + 1 chunks
+extern "C" void csdr_amd_debug_phase_chain(float rate, float ph0, int n, float *out)
+{
+    const float inc = (rate * 2) * csdr_amd::PI_F, step = inc * (float)1024;
+    csdr_amd::WrapPlan w; csdr_amd::wrap_plan_init(w, step);
+    float p = ph0;
+    for (int k = 0; k < n; k++) { p = csdr_amd::wrap_plan_apply(w, p + step); out[k] = p; }
+}

@@ -11,41 +11,65 @@
 
 namespace csdr_amd {
 
-// ---- the wrap loop without its iterations.  x: any float with |x| < 4096.  Returns exactly what
-//          while (x > PI_F) x -= 2 * PI_F;   while (x < -PI_F) x += 2 * PI_F;
-// leaves in float arithmetic.  Why this is not a plain fmod: every subtraction rounds to the grid of its RESULT's binade.  c = 2*PI_F = 0xC90FDB * 2^-21; for a result
-// in [2^e, 2^(e+1)), e >= 4, the grid is 2^(e-23) >= 4 * 2^-21 and c is never half-way between two grid points (0xC90FDB mod 2^k != 2^(k-1) for k = 2 .. 10), while the
-// minuend is on the grid already: the step subtracts the CONSTANT c_e = c rounded to that grid, exactly.  So all steps whose result stays in one binade collapse into
-// one exact fused multiply-add; the step that leaves a binade, and everything below 16 (where the grid reaches c's own and ties occur), are plain float subtractions.
-// A rate of 0.4 needs 410 iterations per chunk in the loop, this takes ~100 dependent operations for any rate (tests/test_abi_cpu.py checks it against the loop).
-__host__ __device__ inline float wrap_phase_exact(float x)
+// ---- the phase advance of one chunk without the wrap loop's iterations:   ph' = wrap(fl(ph + step)),   wrap(x):  while (x > PI_F) x -= 2 PI_F;  while (x < -PI_F) x += 2 PI_F;
+// every subtraction rounded to float (libcsdr_gpl.c:48-51).  A rate of 0.4 means 410 iterations per chunk, and the chunks of a stream are a strictly sequential chain:
+// what counts is the number of DEPENDENT operations per chunk.
+//   * Why not fmod: each subtraction rounds on the grid of its RESULT's binade.  c = 2 PI_F = 0xC90FDB * 2^-21; for a result in [2^e, 2^(e+1)), e >= 4, the grid is
+//     2^(e-23) >= 4 * 2^-21, c is never half-way between two grid points (0xC90FDB mod 2^k != 2^(k-1), k = 2 .. 10) and the minuend is on the grid already: the step
+//     subtracts the CONSTANT c_e = c rounded to that grid, exactly.  Binades 9-11 share one c_e, 6-7 another: five groups (lo = 512, 256, 64, 32, 16).
+//   * Steps stay inside a group while a - c_e >= lo (c_e > c) or > lo (c_e < c: the exact difference then lies below lo and rounds on the finer grid); their number
+//     for a value a is floor((a - lo') / c_e) with lo' = lo or lo + grid.
+//   * The values that ENTER a group span less than c + a rounding slack: from above they come out of [lo_above - c, lo_above), directly they are |ph + step| with
+//     |ph| <= PI.  So the step count takes one of three consecutive values, told apart by two comparisons against thresholds that depend on nothing but the
+//     stream's step (only its topmost group differs from the universal constants): a group costs two compares, two selects, two exact additions, the exact bulk
+//     subtraction, the one rounded subtraction that leaves the group, and a select -- eight dependent operations instead of a loop.  Below 16 (ties occur there): at most three plain steps.
+// tests/test_abi_cpu.py runs the host build of this against the loop.
+struct WrapPlan {
+    float t1[5], t2[5], k0[5];
+};
+
+__host__ __device__ inline void wrap_plan_init(WrapPlan &w, float step)
+{
+    const double PI = (double)(float)3.14159265358979323846, C = 2 * PI;
+    const double lo[5] = {512, 256, 64, 32, 16};
+    const double ce[5] = {0x1.922p+2, 0x1.921f8p+2, 0x1.921fcp+2, 0x1.921fbp+2, 0x1.921fb8p+2};      // c on the grids 2^-14 (binades 9-11), 2^-15, 2^-17 (6-7), 2^-18, 2^-19
+    const double grid[5] = {0x1p-14, 0x1p-15, 0x1p-17, 0x1p-18, 0x1p-19};
+    const double top = fabs((double)step) + PI + 0x1p-9;               // no |ph + step| exceeds this (the addition's rounding included)
+#pragma unroll                                                        // (constant indices: the plan has to live in registers -- as a scratch array every group paid a memory round trip)
+    for (int i = 0; i < 5; i++) {
+        const double lop = ce[i] < C ? lo[i] + grid[i] : lo[i];       // steps stay in the group while the result is >= lop
+        double hi = i ? lo[i - 1] : top; if (top < hi) hi = top;       // no value that enters the group reaches hi ...
+        double amin = hi - C - 0x1p-8; if (amin < lo[i]) amin = lo[i]; // ... and none lies below amin
+        double n0 = floor((amin - lop) / ce[i]); if (n0 < 0) n0 = 0;
+        while (lop + (n0 + 1) * ce[i] <= amin) n0 += 1;
+        while (n0 > 0 && lop + n0 * ce[i] > amin) n0 -= 1;
+        w.t1[i] = (float)(lop + (n0 + 1) * ce[i]); w.t2[i] = (float)(lop + (n0 + 2) * ce[i]);      // exact: multiples of the grid below 2^(e+1)
+        w.k0[i] = (float)(n0 * ce[i]);
+        if (hi <= lo[i]) { w.t1[i] = w.t2[i] = 8192.f; w.k0[i] = 0.f; }                             // never entered
+    }
+}
+
+// x = fl(ph + step) of the stream the plan was made for (|ph| <= PI)
+__host__ __device__ inline float wrap_plan_apply(const WrapPlan &w, float x)
 {
     const float PI = (float)3.14159265358979323846, C2 = 2 * PI;
     float a = fabsf(x);
-    if (!(a > PI)) return x;
-    // c rounded to the grids of binades 11 .. 4 (2^-12 .. 2^-19) and the reciprocals used for the step counts
-#define CSDR_WRAP_STAGE(E, CE)                                                                                       \
-    {                                                                                                                \
-        const float lo = (float)(1u << E), ce = CE;                                                                  \
-        if (a >= lo) {                                                                                               \
-            const float n = floorf((a - lo) * (1.0f / CE));           /* steps that stay in the binade (off by one at most) */ \
-            float a1 = fmaf(-n, ce, a);                               /* exact: a multiple of the binade's grid, below 2^(E+1) */ \
-            if (a1 < lo) a1 += ce;                                                                                   \
-            if (a1 < a && ((a1 + ce) - C2) < lo) a1 += ce;            /* the last step counted left the binade: c_e != c */ \
-            else if ((a1 - C2) >= lo) a1 -= ce;                       /* one more stays */                           \
-            a = a1 - C2;                                              /* the step that leaves the binade: plain float subtraction */ \
-        }                                                                                                            \
+    // (sums, not selects between table entries: the compiler turns a select of two array elements into a load through a selected ADDRESS, and the plan into scratch
+    // memory -- one memory round trip per group)
+#define CSDR_WRAP_GROUP(I, LO, CE)                                                                                    \
+    {                                                                                                                 \
+        const float k = (w.k0[I] + (a >= w.t1[I] ? CE : 0.f)) + (a >= w.t2[I] ? CE : 0.f);   /* exact: (n0 + 0..2) c_e */ \
+        const float r = (a - k) - C2;                                 /* exact bulk, then the (rounded) step that leaves the group */ \
+        a = a >= LO ? r : a;                                                                                          \
     }
-    CSDR_WRAP_STAGE(11, 0x1.922p+2f)             // c on the 2^-12 grid
-    CSDR_WRAP_STAGE(10, 0x1.922p+2f)             // 2^-13
-    CSDR_WRAP_STAGE(9, 0x1.922p+2f)              // 2^-14
-    CSDR_WRAP_STAGE(8, 0x1.921f8p+2f)            // 2^-15
-    CSDR_WRAP_STAGE(7, 0x1.921fcp+2f)            // 2^-16
-    CSDR_WRAP_STAGE(6, 0x1.921fcp+2f)            // 2^-17
-    CSDR_WRAP_STAGE(5, 0x1.921fbp+2f)            // 2^-18
-    CSDR_WRAP_STAGE(4, 0x1.921fb8p+2f)           // 2^-19
-#undef CSDR_WRAP_STAGE
-    while (a > PI) a -= C2;                                           // from below 16: at most three more
+    CSDR_WRAP_GROUP(0, 512.f, 0x1.922p+2f)
+    CSDR_WRAP_GROUP(1, 256.f, 0x1.921f8p+2f)
+    CSDR_WRAP_GROUP(2, 64.f, 0x1.921fcp+2f)
+    CSDR_WRAP_GROUP(3, 32.f, 0x1.921fbp+2f)
+    CSDR_WRAP_GROUP(4, 16.f, 0x1.921fb8p+2f)
+#undef CSDR_WRAP_GROUP
+#pragma unroll
+    for (int i = 0; i < 3; i++) a = a > PI ? a - C2 : a;              // from below 16
     return x < 0 ? 0.0f - a : a;                                      // (-c + c is +0 in the loop as well)
 }
 

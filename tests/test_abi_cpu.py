@@ -234,13 +234,14 @@ def test_ddc_chain_fast_path_is_bit_identical(libpath, port):
     assert fn(0, 0.01, 449, 2, 10, C.byref(rem), C.byref(ph), phases.ctypes.data, C.byref(cnt)) == 0 and cnt.value in (2245, 2246)
 
 
-def test_wrap_phase_exact_is_the_reference_loop(libpath, port):
-    """seeds.hpp: the phase wrap of `csdr shift_addition_cc` (libcsdr_gpl.c:48-51: while (ph > PI) ph -= 2 PI; while (ph < -PI) ph += 2 PI, every step rounded to
-    float) without its iterations -- the per-stream chain objects replay it for every 1024-chunk of every stream.  The host build of the same inline function
-    against the loop in numpy float32: chains of phase advances at awkward rates (the values the kernels actually see) and values around every binade edge."""
+def test_phase_chain_plan_is_the_reference_loop(libpath, port):
+    """seeds.hpp: the phase bookkeeping of `csdr shift_addition_cc` (libcsdr_gpl.c:48-51: ph += rate*PI*1024; while (ph > PI) ph -= 2 PI; while (ph < -PI) ph += 2 PI,
+    every step rounded to float) without the loops' iterations -- the per-stream chain objects replay it for every 1024-chunk of every stream, one lane per stream.
+    The host build of the kernels' plan (csdr_amd_debug_phase_chain) against the loop in numpy float32: chains of 400 chunks at rates across the band (each starts
+    from a different phase), incl. the largest ones (410 wraps per chunk) and rates whose steps sit next to a binade edge."""
     import numpy as np
-    fn = C.CDLL(libpath).csdr_amd_debug_wrap_phase
-    fn.restype = C.c_float; fn.argtypes = [C.c_float]
+    fn = C.CDLL(libpath).csdr_amd_debug_phase_chain
+    fn.restype = None; fn.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p]
     pi = np.float32(3.14159265358979323846); two_pi = np.float32(2) * pi
 
     def loop(x):
@@ -249,16 +250,16 @@ def test_wrap_phase_exact_is_the_reference_loop(libpath, port):
         while x < -pi: x = np.float32(x + two_pi)
         return x
 
-    vals = []
-    for rate in (0.4999, -0.4321, 0.25, -0.05, 0.085, 0.3333, -0.11, 0.0123, 0.5):
-        step = np.float32(np.float32(np.float32(rate) * np.float32(2)) * pi) * np.float32(1024)
-        ph = np.float32(0)
-        for _ in range(300):
-            nx = np.float32(ph + step); vals.append(nx); ph = loop(nx)
-            assert np.float32(fn(nx)).view(np.uint32) == ph.view(np.uint32), (rate, float(nx))
     rng = np.random.default_rng(7)
-    edge = [np.float32(2.0 ** e) + np.float32(k) * np.float32(6.2831855) + np.float32(d) for e in range(2, 12) for k in range(0, 3) for d in (-1e-3, 0.0, 1e-3, 0.3)]
-    rnd = (rng.uniform(-3300, 3300, 4000)).astype(np.float32)
-    for x in list(edge) + list(rnd) + [np.float32(-6.2831855), np.float32(6.2831855), pi, -pi, np.float32(0)]:
-        for v in (x, -x):
-            assert np.float32(fn(v)).view(np.uint32) == loop(v).view(np.uint32), float(v)
+    edge = [e / (2 * np.pi * 1024) * s for e in (16, 32, 64, 256, 512, 1024, 2048) for s in (0.999, 1.0, 1.001, -1.0)]
+    rates = [0.4999, -0.4321, 0.25, -0.05, 0.085, 0.3333, -0.11, 0.0123, 0.5, 0.0, -0.5, 1e-4] + edge + list(rng.uniform(-0.5, 0.5, 40))
+    n = 400
+    out = np.zeros(n, np.float32)
+    for i, rate in enumerate(rates):
+        rate = np.float32(rate)
+        ph = np.float32(rng.uniform(-3.14, 3.14)) if i % 2 else np.float32(0)
+        fn(rate, ph, n, out.ctypes.data)
+        step = np.float32(np.float32(rate * np.float32(2)) * pi) * np.float32(1024)
+        for k in range(n):
+            ph = loop(np.float32(ph + step))
+            assert out[k].view(np.uint32) == ph.view(np.uint32), (float(rate), k)

@@ -388,8 +388,56 @@ def test_c2_wfm_every_stream_in_three_calls(gpu, port):
 
 
 def test_c5_nfm_every_channel(gpu, port):
-    """bench_nfm.py's timed shape, all of it: 512 channels x 2 400 256 samples carry one of 16 narrow-band FM signals; replicas bit-identical, the 16
-    distinct rows +-1 LSB against the oracle's stage-by-stage chain on every sample."""
+    """bench_nfm.py's timed shape, all of it, as SURVEY.md section 8d defines config 5: 512 (stream, shift_rate) PAIRS x 2 400 256 samples -- every channel its own
+    rate (verify_configs.c5_rates: 512 distinct values incl. the drifting 0.05 / 0.25 / -0.05 / -0.25, 0 and +-0.4999), every channel its own narrow-band FM signal
+    at -rate.  32 channels spread over the batch (the special rates among them) +-1 LSB on every sample against the oracle's stage-by-stage chain; every channel
+    must have produced the same count and a live signal (RMS within 3 dB of the checked ones: a channel demodulated at a wrong rate is noise at full scale)."""
+    import torch
+    S, T, D = 512, 2344 * 1024, 50
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.005), 0.5 / D, "HAMMING")
+    rates = vc.c5_rates(S)
+    assert len(set(rates.tolist())) == S
+    # one modulating signal per channel would cost 512 x 2.4 M numpy samples: 16 base signals at offset 0, moved to -rate of the channel by a phase ramp before quantising
+    base = [tests_helpers_nfm_baseband(3100 + k, T) for k in range(16)]
+    n_out_max = (T // D + 2048 + 63) // 64 * 64
+    x = torch.empty((S, 2 * T), dtype=torch.uint8, device="cuda")
+    tt = torch.arange(T, device="cuda", dtype=torch.float64)
+    for c in range(S):
+        sig = torch.from_numpy(base[c % 16]).cuda() * torch.exp(2j * np.pi * (-float(rates[c])) * tt)
+        iq = torch.view_as_real(sig).reshape(-1).to(torch.float32)
+        x[c] = torch.clamp(torch.round(127.5 * (iq + 1)), 0, 255).to(torch.uint8)
+    out = torch.zeros((S, n_out_max), dtype=torch.int16, device="cuda")
+    obj = L.csdr_amd_nfm_create_rates(gpu.h, S, rates.ctypes.data_as(C.c_void_p), D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
+    assert obj, gpu.err()
+    try:
+        n = L.csdr_amd_nfm_process(obj, x.data_ptr(), 2 * T, T, out.data_ptr(), None, n_out_max)
+        assert n > 0, gpu.err()
+        gpu.sync()
+        assert L.csdr_amd_ddc_kernel_name(L.csdr_amd_nfm_front_end(obj)) == b"k_ddc_mfma" and L.csdr_amd_ddc_fallback(L.csdr_amd_nfm_front_end(obj)) == 0
+    finally:
+        L.csdr_amd_nfm_destroy(obj)
+    nfm_taps = gpu.nfm_taps(48000)
+    check = sorted(set(vc.pick_rows(S, want=25)) | {5, S // 3 + 1, (2 * S) // 3 + 2, S - 2, 7, 1, S - 5})
+    for c in check:
+        ps, _ = port.nfm_chain(x[c].cpu().numpy(), float(rates[c]), nfm_taps, D, 0.005, 1024)
+        got = out[c, :n].cpu().numpy()
+        assert n == ps.size and vc.s16_diff(got, ps).max() <= 1, "channel %d rate %g: %d" % (c, rates[c], vc.s16_diff(got, ps).max())
+    rms = out[:, 4096:n].to(torch.float32).pow(2).mean(dim=1).sqrt().cpu().numpy()
+    ref = np.median(rms[check])
+    assert (rms > ref / 1.41).all() and (rms < ref * 1.41).all(), (int(rms.argmin()), float(rms.min()), int(rms.argmax()), float(rms.max()), float(ref))
+
+
+def tests_helpers_nfm_baseband(seed, n, deviation=5e3 / 2.4e6):
+    """complex128 narrow-band FM signal at offset 0 (tests_helpers.nfm_signal_u8 before the frequency offset and the quantiser)"""
+    rng = np.random.default_rng(seed)
+    msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * np.arange(n)) + 0.3 * np.convolve(rng.uniform(-1, 1, n + 199), np.ones(200) / 200, "valid")
+    return 0.7 * np.exp(2j * np.pi * np.cumsum(deviation * msg)) + 0.01 * (rng.normal(size=n) + 1j * rng.normal(size=n))
+
+
+def test_c5_nfm_every_channel_uniform_rate(gpu, port):
+    """The same shape with ONE rate for all channels (the shared-weights kernel, csdr_amd_nfm_create): 512 channels carry one of 16 narrow-band FM signals; replicas
+    bit-identical, the 16 distinct rows +-1 LSB against the oracle's stage-by-stage chain on every sample."""
     import torch
     S, T, D = 512, 2344 * 1024, 50
     L = gpu.L

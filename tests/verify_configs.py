@@ -94,7 +94,7 @@ def verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, shift_rate=-0.05, d
     diffs = []; n_ref = -1; strict_max = 0
     for r in list(rows) + list(strict_rows):
         u8 = x[r, :2 * T].cpu().numpy()
-        ps, _ = port.nfm_chain(u8, shift_rate, nfm_taps, decimation, tbw, agc_block)
+        ps, _ = port.nfm_chain(u8, float(shift_rate[r]) if np.ndim(shift_rate) else shift_rate, nfm_taps, decimation, tbw, agc_block)   # (a rate per channel: an array)
         n_ref = ps.size
         got = out_s16[r, :n].cpu().numpy()
         m = min(ps.size, got.size)
@@ -109,6 +109,18 @@ def verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, shift_rate=-0.05, d
     res["gate"] = "frac_nonzero < 0.05, frac_over_1_lsb < 0.005 (noise input), strict rows max <= 1 LSB, got_len == expected_len"
     res["ok"] = bool(n == n_ref and n > 0 and res["frac_over_1_lsb"] < 5e-3 and res["frac_nonzero"] < 0.05 and strict_max <= 1)
     return res
+
+
+def c5_rates(n_channels=512):
+    """Config 5 as SURVEY.md section 8d states it: one (stream, shift_rate) pair per channel.  Rates spread over -0.45 .. 0.45 (none equal), with the awkward ones a
+    receiver bank meets put at fixed channels: 0.05 / 0.25 / -0.05 / -0.25 (the reference's float phasor recurrence drifts systematically there, ddc_mfma.hip), 0 (no
+    shift) and the largest rates (410 phase wraps per chunk)."""
+    r = (-0.45 + 0.9 * (np.arange(n_channels) + 0.5) / n_channels).astype(f32)
+    special = {5: 0.05, n_channels // 3 + 1: 0.25, (2 * n_channels) // 3 + 2: -0.05, n_channels - 2: -0.25, 7: 0.0, 1: 0.4999, n_channels - 5: -0.4999}
+    for k, v in special.items():
+        if 0 <= k < n_channels:
+            r[k] = v
+    return r
 
 
 def c4_rates(n_channels=256):

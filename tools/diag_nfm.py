@@ -19,7 +19,13 @@ x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda")
 n_max = (T // D + 2048 + 63) // 64 * 64
 out = torch.empty((S, n_max), dtype=torch.int16, device="cuda")
 torch.cuda.synchronize()
-obj = L.csdr_amd_nfm_create(ctx.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
+if os.environ.get("DIAG_RATES", "uniform") == "uniform":
+    obj = L.csdr_amd_nfm_create(ctx.h, S, -0.05, D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
+else:                                                     # DIAG_RATES=distinct: a rate per channel (the per-stream kernel)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import verify_configs as vc
+    rates = vc.c5_rates(S)
+    obj = L.csdr_amd_nfm_create_rates(ctx.h, S, rates.ctypes.data_as(C.c_void_p), D, taps.ctypes.data_as(C.c_void_p), taps.size, 48000, 1024, 1.0, 1.0, T)
 for _ in range(60):
     L.csdr_amd_nfm_process(obj, x.data_ptr(), 2 * T, T, out.data_ptr(), None, n_max)
 ctx.sync()
