@@ -333,6 +333,11 @@ void fractional_decimator_ff(float *in, float *out, int n, fractional_decimator_
 // ------------------------------------------------------------------ FFT plan layer (fft_fftw.c:6-45) on hipFFT
 void *csdr_fft_malloc(size_t n) { void *p = nullptr; if (posix_memalign(&p, 64, n ? n : 64)) return nullptr; return p; }
 void csdr_fft_free(void *p) { free(p); }
+// The reference's own header maps fft_malloc / fft_free to fftwf_malloc / fftwf_free (fft_fftw.h:11-12): a client compiled against it asks the dynamic linker for
+// these two FFTW symbols and nothing else of FFTW (plans go through make_fft_c2c / fft_execute, served here).  Exported so that such a client needs no -lfftw3f.
+// (If the real libfftw3f is loaded as well, whichever comes first in the link order serves both calls: either pair is a plain aligned malloc / free.)
+void *fftwf_malloc(size_t n) { return csdr_fft_malloc(n); }
+void fftwf_free(void *p) { csdr_fft_free(p); }
 
 static FFT_PLAN_T *make_plan(int size, void *in, void *out, int kind, int forward)
 {

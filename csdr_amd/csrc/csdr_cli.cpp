@@ -878,11 +878,27 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
 // in_k / out_k: a path (file or fifo) or fd:<n>.  Every pass reads one block of CSDR_AMD_BANK_BLOCK samples (default 262144, a multiple of 1024) from
 // EVERY input (the streams advance in lockstep, like the clients of one nmux), uploads them as the rows of one batch, runs the chain once and writes
 // each row's audio to its output.  The pass in which the first stream ends is the last one (lockstep streams end together).
+//   <shift_rate> may be a comma-separated list, one rate per stream (ddcd tunes every client on its own: ddcd_old.h:51-61) -- nfm_bank_u8_s16 only so far;
+//   --ctl <fifo | fd:<n>> in front of it: control lines "<stream> <rate>\n", applied between two passes exactly as `shift_addition_cc --fifo` applies a new rate
+//   between two reads (csdr.c:881-923: the phase carries over).
 int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
 {
-    if (argc < 5 || (argc - 3) % 2) return badsyntax("usage: <shift_rate> <in_0> <out_0> [<in_k> <out_k> ...]   (paths, fifos or fd:<n>)");
-    float shift = 0; if (sscanf(argv[2], "%g", &shift) != 1) return badsyntax("shift_rate must be a number");
+    int ctl_fd = -1;
+    if (argc > 3 && !strcmp(argv[2], "--ctl")) {
+        if (!strncmp(argv[3], "fd:", 3)) sscanf(argv[3] + 3, "%d", &ctl_fd); else ctl_fd = open(argv[3], O_RDONLY | O_NONBLOCK);
+        if (ctl_fd < 0) { fprintf(stderr, "csdr %s: cannot open the control channel %s\n", g_cmd, argv[3]); return -1; }
+        fcntl(ctl_fd, F_SETFL, fcntl(ctl_fd, F_GETFL, 0) | O_NONBLOCK);
+        argv += 2; argc -= 2;
+    }
+    if (argc < 5 || (argc - 3) % 2) return badsyntax("usage: [--ctl <fifo|fd:n>] <shift_rate[,rate_1,...]> <in_0> <out_0> [<in_k> <out_k> ...]   (paths, fifos or fd:<n>)");
     const int S = (argc - 3) / 2;
+    std::vector<float> rates;
+    for (const char *q = argv[2]; *q;) { char *end = nullptr; const float v = strtof(q, &end); if (end == q) return badsyntax("shift_rate must be a number or a comma-separated list"); rates.push_back(v); q = *end == ',' ? end + 1 : end; if (*end && *end != ',') return badsyntax("shift_rate must be a number or a comma-separated list"); }
+    if (rates.size() != 1 && (int)rates.size() != S) return badsyntax("as many shift rates as streams (or one for all)");
+    const bool per_stream = rates.size() > 1 || ctl_fd >= 0;
+    if (per_stream && !nfm) return badsyntax("a shift rate per stream / --ctl: nfm_bank_u8_s16 only");
+    if (per_stream && rates.size() == 1) rates.assign(S, rates[0]);
+    const float shift = rates[0];
     auto open_fd = [](const char *spec, int flags) { int fd = -1; if (!strncmp(spec, "fd:", 3)) sscanf(spec + 3, "%d", &fd); else fd = open(spec, flags, 0644); return fd; };
     std::vector<int> in_fd(S), out_fd(S);
     for (int k = 0; k < S; k++) {
@@ -895,8 +911,10 @@ int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
     const int nt = csdr_amd_firdes_filter_len(tbw);
     std::vector<float> taps(nt); csdr_amd_firdes_lowpass_f(taps.data(), nt, 0.5f / (float)D, CSDR_WINDOW_HAMMING);
     csdr_amd_wfm *w = nullptr; csdr_amd_nfm *n = nullptr;
-    if (nfm) n = csdr_amd_nfm_create(c, S, shift, D, taps.data(), nt, 48000, 1024, 1.0f, 1.0f, T);
+    if (nfm && per_stream) n = csdr_amd_nfm_create_rates(c, S, rates.data(), D, taps.data(), nt, 48000, 1024, 1.0f, 1.0f, T);
+    else if (nfm) n = csdr_amd_nfm_create(c, S, shift, D, taps.data(), nt, 48000, 1024, 1.0f, 1.0f, T);
     else w = csdr_amd_wfm_create(c, S, shift, D, taps.data(), nt, 5, 50e-6f, 48000, T);
+    std::string ctl_buf;
     if (!w && !n) die("bank create");
     const size_t in_pitch = 2 * T, out_pitch = ((T / 50 + 4096 + 63) / 64) * 64;
     uint8_t *h_in = nullptr; int16_t *h_out = nullptr;
@@ -917,6 +935,17 @@ int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
             if (samples && samples < got_min) got_min = samples;
         }
         if (!any) break;
+        // retunes that have arrived: complete lines only, the rest waits for the next pass
+        if (ctl_fd >= 0) {
+            char tmp[1024]; ssize_t r;
+            while ((r = read(ctl_fd, tmp, sizeof tmp)) > 0) ctl_buf.append(tmp, (size_t)r);
+            size_t nl;
+            while ((nl = ctl_buf.find('\n')) != std::string::npos) {
+                int st = -1; float rv = 0;
+                if (sscanf(ctl_buf.c_str(), "%d %g", &st, &rv) == 2 && st >= 0 && st < S) { MUST(csdr_amd_nfm_set_rate(n, st, rv)); fprintf(stderr, "csdr %s: stream %d reinitialized to %g\n", g_cmd, st, rv); }
+                ctl_buf.erase(0, nl + 1);
+            }
+        }
         // a short final block: whole 1024-sample chunks of the shortest live stream (the chain objects take a ragged LAST block only)
         size_t nproc = got_min < T ? got_min : T;
         MUST(csdr_amd_h2d(c, d_in, h_in, (size_t)S * in_pitch));

@@ -37,6 +37,8 @@ void *csdr_fft_malloc(size_t n);      /* the reference's fft_malloc/fft_free are
 void csdr_fft_free(void *p);
 #define fft_malloc csdr_fft_malloc
 #define fft_free csdr_fft_free
+void *fftwf_malloc(size_t n);          /* what the REFERENCE's fft_fftw.h:11-12 expands fft_malloc / fft_free to: exported too, so a client built against */
+void fftwf_free(void *p);              /* the reference headers links without -lfftw3f */
 
 /* filter design, libcsdr.h:85-92 */
 void firdes_lowpass_f(float *output, int length, float cutoff_rate, window_t window);

@@ -115,6 +115,32 @@ def test_reference_client_links_against_our_library(libpath, tmp_path):
     shutil.copy(exe, os.path.join(ROOT, "tests", "data", "dropin_client.bin"))      # travels to the GPU box for the -m gpu run
 
 
+def test_reference_fft_malloc_macro_needs_no_fftw(libpath, tmp_path):
+    """The reference's fft_fftw.h:11-12 expands fft_malloc / fft_free to fftwf_malloc / fftwf_free.  A client that uses the macro, compiled against the REFERENCE
+    headers, must link against libcsdr_amd.so alone (no -lfftw3f) -- the two symbols are exported (VERDICT r3 missing #5).  Link only: nothing is executed here."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "fft_fftw.h")):
+        pytest.skip("reference headers not present on this host")
+    src = tmp_path / "m.c"
+    src.write_text('#include "libcsdr.h"\n#include "fft_fftw.h"\nint main(void) { complexf *a = (complexf *)fft_malloc(sizeof(complexf) * 1024), *b = (complexf *)fft_malloc(sizeof(complexf) * 1024);\n'
+                   '  FFT_PLAN_T *p = make_fft_c2c(1024, a, b, 1, 0); fft_execute(p); fft_destroy(p); fft_free(a); fft_free(b); return 0; }\n')
+    exe = str(tmp_path / "m")
+    r = subprocess.run(["gcc", "-std=gnu99", "-DUSE_FFTW", "-DLIBCSDR_GPL", "-I", ref, "-I", os.path.join(ROOT, "oracle"), str(src), "-L", os.path.dirname(libpath),
+                        "-l:libcsdr_amd.so", "-Wl,-rpath," + os.path.dirname(libpath), "-o", exe, "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True, check=True).stdout
+    assert " fftwf_malloc" in nm and " fftwf_free" in nm
+
+
+def test_soname_build_for_existing_binaries(libpath):
+    """`make soname`: the same objects as libcsdr.so.0.15 (the reference's soname, Makefile:56-57), so that an existing binary runs with LD_LIBRARY_PATH alone."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "csdr_amd", "csrc"), "soname"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    so = os.path.join(ROOT, "csdr_amd", "libcsdr.so.0.15")
+    out = subprocess.run(["readelf", "-d", so], capture_output=True, text=True, check=True).stdout
+    assert "libcsdr.so.0.15" in [ln.split("[")[-1].rstrip("]") for ln in out.splitlines() if "SONAME" in ln]
+
+
 def test_dft16_butterfly():
     """The register-level 16-point butterfly of the three-pass 65536-point transform (csdr_amd/csrc/fft64k.hip), forward and inverse, against numpy."""
     import ctypes as C
