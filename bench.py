@@ -9,7 +9,13 @@ on 1024 parallel 2.4 MS/s u8 IQ streams per GPU, synthetic i.i.d. uniform u8 (SU
 signal"), inputs resident in HBM before the timed region.  One step = one block of 2344*1024 = 2 400 256 complex
 samples (1.0001 s of signal) of every stream through the whole chain (state carried from step to step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--block T] [--no-cpu-baseline] [--verify]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--block T] [--no-cpu-baseline] [--verify | --no-verify] [--no-other-configs]
+
+The line checks itself: four rows of the batch carry a real FM signal (put there BEFORE the timed loop) and are held to +-1 LSB on every sample against the CPU
+oracle after it ("verify", default; --verify adds 16 noise rows under the statistical gate of tests/verify_configs.py; --no-verify skips).  At N = 1 the line also
+carries the other BASELINE configs as short legs of their own bench scripts ("other_configs": C1 fir_decimate_cc, C3 at 1023 and 4095 taps, C4 fastddc, C5 NFM with a
+rate per channel -- each with its own verify) and two short-block operating points of this chain ("operating_points": the reference's 16384-sample block, and 65536
+streams x 10 ms), so that every config's number exists on the driver's clock.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are independent, so ranks share nothing on
 the data path (replicas of the per-GPU workload, "scaling": "weak"); barrier + max-over-ranks timing over RCCL.
@@ -49,6 +55,73 @@ def pmc_traffic(kernel_name, streams, block):
     return bc.pmc_traffic(kernel_name, {"streams_per_gpu": streams, "block_samples_per_stream": block})
 
 
+def other_configs():
+    """The other BASELINE configs as short legs of their own bench scripts (child processes of this one: inside the driver's clock), each with its --verify:
+    ms per step, the dominant kernel and its roofline fraction, whether the shape fell back, verify.ok."""
+    legs = [("C1 fir_decimate_cc 10 0.05 HAMMING, 256 x 2.4 M complexf", ["bench_fir.py", "--steps", "60"]),
+            ("C1' fir_decimate_cc 50 0.005 (801 taps), 64 x 2.4 M complexf", ["bench_fir.py", "--steps", "60", "--decimation", "50", "--tbw", "0.005", "--streams", "64"]),
+            ("C3 bandpass_fir_fft_cc 1023 taps @65536 framing, 64 x 16 blocks", ["bench_fftfilt.py", "--steps", "60", "--no-sweep", "--taps", "1023"]),
+            ("C3 bandpass_fir_fft_cc 4095 taps", ["bench_fftfilt.py", "--steps", "60", "--no-sweep", "--taps", "4095"]),
+            ("C4 fastddc 256 channels x 64 blocks, fft 65536", ["bench_fastddc.py", "--steps", "120"]),
+            ("C5 NFM chain, 512 channels x 2.4 M u8, a shift rate per channel", ["bench_nfm.py", "--steps", "60"]),
+            ("C5 NFM chain, one shift rate for all channels", ["bench_nfm.py", "--steps", "60", "--uniform-rate"])]
+    out = []
+    for name, cmd in legs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, cmd[0])] + cmd[1:] + ["--no-cpu-baseline", "--verify"], capture_output=True, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            d = json.loads(lines[-1])
+            rf = d.get("roofline", {})
+            e = {"config": name, "command": "python " + " ".join(cmd) + " --no-cpu-baseline --verify", "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
+                 "kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"), "kernel_avg_ms": rf.get("kernel_avg_ms"),
+                 "fallback": d.get("config", {}).get("fallback"), "verify_ok": d.get("verify", {}).get("ok"), "rc": r.returncode}
+            if "full_size_transform" in d:
+                e["full_size_transform_frac"] = d["full_size_transform"].get("frac")
+        except Exception as ex:  # noqa: BLE001
+            e = {"config": name, "error": str(ex)[:300]}
+        e["wall_s"] = round(time.perf_counter() - t0, 1)
+        out.append(e)
+    return out
+
+
+def operating_points(ctx, taps):
+    """The same chain object at the blocks a live receiver bank hands over (the reference's loop moves 16384 samples per read, csdr.c:189-193, 330-392): many streams,
+    short blocks.  One step = one call over all streams; state carried; inputs resident in HBM."""
+    import torch
+    L = ctx.L
+    pts = []
+    for S, T, steps in ((1024, 16384, 400), (65536, 24576, 60)):
+        pitch = 2 * T
+        x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda")
+        na_max = (T // 50 + 64 + 63) // 64 * 64
+        out = torch.empty((S, na_max), dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+        if not w:
+            pts.append({"streams": S, "block": T, "error": ctx.err()}); continue
+        for _ in range(steps // 2):
+            L.csdr_amd_wfm_process(w, x.data_ptr(), pitch, T, out.data_ptr(), None, na_max)
+        ctx.sync()
+        L.csdr_amd_wfm_set_profiling(w, 1)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            L.csdr_amd_wfm_process(w, x.data_ptr(), pitch, T, out.data_ptr(), None, na_max)
+        ctx.sync()
+        wall = time.perf_counter() - t0
+        kms = C.c_double(0); kl = C.c_long(0)
+        L.csdr_amd_wfm_kernel_time(w, C.byref(kms), C.byref(kl))
+        k_ms = kms.value / max(kl.value, 1)
+        algo = ALGO_BYTES_PER_SAMPLE * S * T
+        pts.append({"streams": S, "block_samples_per_stream": T, "block_ms_of_signal": round(T / 2400.0, 2), "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4),
+                    "value": round(S * T * steps / wall / 1e6, 1), "unit": "complex MS/s", "realtime_factor_per_stream": round((T / 2.4e6) / (wall / steps), 1),
+                    "kernel": L.csdr_amd_wfm_kernel_name(w).decode(), "kernel_avg_ms": round(k_ms, 4),
+                    "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms else None, "fallback": bool(L.csdr_amd_wfm_fallback(w))})
+        L.csdr_amd_wfm_destroy(w)
+        del x, out; torch.cuda.empty_cache()
+    return pts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,7 +135,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region: reset, one more pass over all streams with the same object / buffers, 16 full audio rows "
-                         "spread over all stream blocks against the CPU oracle on the same bytes (tests/verify_configs.py)")
+                         "spread over all stream blocks against the CPU oracle on the same bytes (tests/verify_configs.py) beside the four strict rows of the default")
+    ap.add_argument("--no-verify", action="store_true", help="skip the default check (four strict rows, +-1 LSB against the oracle)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short legs of the other BASELINE configs and the short-block operating points")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,7 +174,8 @@ def main():
     g = torch.Generator(device="cuda"); g.manual_seed(42 + rank)
     x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda", generator=g)
     strict_rows = []
-    if args.verify and rank == 0:
+    do_verify = rank == 0 and not args.no_verify
+    if do_verify:
         # rows held to +-1 LSB on every sample: a real FM signal in a few rows spread over the batch, put there BEFORE the timed loop (the kernel's work does not
         # depend on the data; the rest of the batch stays i.i.d. noise, which only a statistical gate can check: tests/verify_configs.py)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -120,6 +196,12 @@ def main():
             raise SystemExit("wfm_process: " + ctx.err())
         return n
 
+    # the first launches after idle (the GPU's clocks ramp for ~25 ms): reported beside the steady-state value, never as it
+    cold_k = min(20, args.steps)
+    ctx.sync(); tc0 = time.perf_counter()
+    for _ in range(cold_k):
+        step()
+    ctx.sync(); cold_ms = (time.perf_counter() - tc0) / max(cold_k, 1) * 1e3
     spin_steps = bc.spinup(step, ctx.sync, args.spinup_ms)
     for _ in range(args.warmup):
         step()
@@ -153,7 +235,7 @@ def main():
         res = {
             "metric": "complex MS/s in->out, WFM demod chain @2.4 MS/s x N streams",
             "value": round(msps, 1), "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_before_warmup": spin_steps,
-            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "cold_ms_per_step_first_%d_steps_after_idle" % cold_k: round(cold_ms, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: full WFM pipe u8 IQ -> s16 audio (convert_u8_f|shift_addition_cc -0.085|fir_decimate_cc 10 0.05 HAMMING|"
                                    "fmdemod_quadri_cf|fractional_decimator_ff 5|deemphasis_wfm_ff 48000 50e-6|convert_f_s16)",
@@ -162,7 +244,7 @@ def main():
                        "arithmetic": "dtype f32 = the reference's; the front end (convert_u8_f . shift . FIR, linear in the input bytes) is evaluated as three int8-digit "
                                      "v_mfma_i32_16x16x64_i8 products of the raw bytes with 23-bit fixed-point weights and exact int32 accumulation, recombined in f32 "
                                      "(1.3e-7 relative RMS against the float oracle: not narrower than the reference in effect); demodulator, de-emphasis, s16 conversion in f32",
-                       "launches_per_step": "one (k_wfm_mfma_seq: history, partial tiles, state carry inside)"},
+                       "launches_per_step": "one (k_wfm_mfma_seq: history, partial tiles, state carry inside)", "fallback": bool(L.csdr_amd_wfm_fallback(w))},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * samples_per_step_gpu,
@@ -175,17 +257,24 @@ def main():
         if tr:
             res["roofline"]["traffic"] = tr[0]
             res["roofline"]["traffic_source"] = tr[1]
-        if args.verify:
+        if do_verify:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import verify_configs as vc
             L.csdr_amd_wfm_set_profiling(w, 0)
-            res["verify"] = vc.verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, rows=[r for r in vc.pick_rows(S) if r not in strict_rows], strict_rows=strict_rows)
+            res["verify"] = vc.verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, rows=[r for r in vc.pick_rows(S) if r not in strict_rows] if args.verify else [],
+                                          strict_rows=strict_rows)
+        if world == 1 and not args.no_other_configs:
+            L.csdr_amd_wfm_destroy(w); w = None
+            del x, out_s16; torch.cuda.empty_cache()
+            res["operating_points"] = operating_points(ctx, taps)
+            res["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
-        if args.verify and not res["verify"]["ok"]:
+        if do_verify and not res["verify"]["ok"]:
             raise SystemExit("bench.py --verify: output of the timed configuration does not match the oracle: %s" % json.dumps(res["verify"]))
-    L.csdr_amd_wfm_destroy(w)
+    if w:
+        L.csdr_amd_wfm_destroy(w)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

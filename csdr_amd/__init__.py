@@ -185,6 +185,7 @@ def lib():
         L.csdr_amd_ddc_set_rate.argtypes = [vp, i, fl]
         L.csdr_amd_ddc_get_rate.restype = fl; L.csdr_amd_ddc_get_rate.argtypes = [vp, i]
         L.csdr_amd_ddc_fallback.argtypes = [vp]
+        L.csdr_amd_wfm_fallback.argtypes = [vp]
         L.csdr_amd_nfm_create_rates.restype = vp; L.csdr_amd_nfm_create_rates.argtypes = [vp, i, vp, i, vp, i, i, i, fl, fl, sz]
         L.csdr_amd_nfm_set_rate.argtypes = [vp, i, fl]
     L.csdr_amd_ddc_destroy.argtypes = [vp]

@@ -307,6 +307,7 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
         const int nt = csdr_amd_firdes_filter_len(0.05f);
         t.resize(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.05f, CSDR_WINDOW_HAMMING);
         w = csdr_amd_wfm_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024); if (!w) die("wfm_create");
+        if (csdr_amd_wfm_fallback(w)) fprintf(stderr, "csdr %s: note: this shape runs on the fallback kernels (k_wfm_front + k_wfm_back), not on the matrix-core chain kernel\n", g_cmd);
     }
     size_t out_capacity(size_t n) override { return n / 50 + 64; }
     int next_bufsize(int b) override { return b / 50; }
@@ -326,7 +327,12 @@ struct DdcFront : Stage {   // convert_u8_f | shift_addition_cc r | fir_decimate
     size_t out_capacity(size_t n) override { return n / dec + 64; }
     int next_bufsize(int b) override { return b / dec; }
     long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
-    { *cons = n; long no = csdr_amd_ddc_process(d, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (csdr_complexf *)o, cap); MUST(no); return no; }
+    {
+        *cons = n; long no = csdr_amd_ddc_process(d, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (csdr_complexf *)o, cap); MUST(no);
+        if (!noted && n >= 4096 && csdr_amd_ddc_fallback(d)) { noted = true; fprintf(stderr, "csdr %s: note: this shape runs on the plain kernel (k_ddc_direct), not on the matrix-core front end\n", g_cmd); }
+        return no;
+    }
+    bool noted = false;
 };
 
 struct NfmChain : Stage {   // the README.md:87 chain as ONE command (extension)
@@ -341,7 +347,12 @@ struct NfmChain : Stage {   // the README.md:87 chain as ONE command (extension)
     size_t out_capacity(size_t n) override { return n / dec + 4096; }
     int next_bufsize(int b) override { return b / dec; }
     long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
-    { *cons = n; long na = csdr_amd_nfm_process(w, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
+    {
+        *cons = n; long na = csdr_amd_nfm_process(w, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (int16_t *)o, nullptr, cap); MUST(na);
+        if (!noted && n >= 4096 && csdr_amd_ddc_fallback(csdr_amd_nfm_front_end(w))) { noted = true; fprintf(stderr, "csdr %s: note: the front end of this shape runs on the plain kernel (k_ddc_direct), not on the matrix-core kernel\n", g_cmd); }
+        return na;
+    }
+    bool noted = false;
 };
 
 struct DecimatingShift : Stage {   // csdr.c:851-875: one libcsdr call per the_bufsize samples, status carried between calls

@@ -305,6 +305,7 @@ int csdr_amd_wfm_reset(csdr_amd_wfm *w)
 }
 
 const char *csdr_amd_wfm_kernel_name(const csdr_amd_wfm *w) { return w->kernel_name.c_str(); }
+int csdr_amd_wfm_fallback(const csdr_amd_wfm *w) { return w->use_mfma ? 0 : 1; }
 
 int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on)
 {

@@ -375,6 +375,9 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
                           int16_t *audio_s16, float *audio_f, size_t out_pitch);
 /* name and launch count of the dominant kernel of the last process() call (bench.py roofline leg) */
 const char *csdr_amd_wfm_kernel_name(const csdr_amd_wfm *w);
+/* 1 when the object runs outside the matrix-core chain kernel (k_wfm_front + k_wfm_back: decimation x audio decimation odd, filters beyond the 256-sample window;
+ * CSDR_AMD_WFM_PATH=valu): same results at about a sixth of the rate.  The CLI prints a one-line note on stderr. */
+int csdr_amd_wfm_fallback(const csdr_amd_wfm *w);
 /* HIP-event timing of that kernel, on the context's stream: enable, run, then read the accumulated time. */
 int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on);
 int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches);

@@ -3,6 +3,7 @@
 # traffic passes (FETCH_SIZE / WRITE_SIZE, each in its own run, counters + --kernel-trace only) of one bench script's workload; raw output under
 # gpurun_out/<tag>/, summaries into gpurun_out/profiles_<tag>/ (copy them into profiles/ and commit).
 tag=$1; kern=$2; script=$3; shift 3
+[ "$script" = "bench.py" ] && set -- "$@" --no-other-configs      # the driver line's extra legs are child processes of their own: not part of this profile
 root=$GRAFT_REPO_ROOT; [ -z "$root" ] && root=$PWD
 out=$root/gpurun_out/$tag; mkdir -p $out $root/gpurun_out/profiles_$tag
 cd /tmp && export TMPDIR=/tmp; cd $root
