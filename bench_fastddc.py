@@ -3,10 +3,11 @@
 complexf input, the channels' outputs sharded across N GPUs.
 
 One step = one batch of consecutive overlap-save blocks (input_size = 57344 samples each at D=256, tbw=0.001: fft 65536,
-taps 8193, fft_inv 512) through the bank object: `--blocks` blocks on one GPU, `--blocks` x N over N GPUs -- the bank is time-sliced
-(csdr_amd_fastddc_bank_create_sharded: every rank runs the whole pipeline on its run of `--blocks` blocks, the decimated outputs are
-exchanged all-to-all so that rank r ends up with its slice of the channels; --shard channels selects the channel-sharded compute with
-the all-gathered spectra instead).  Reports wideband INPUT MS/s (whole job) and aggregate output MS/s.
+taps 8193, fft_inv 512) through the bank object.  Over N GPUs `--shard channels` (default; csdr_amd_fastddc_bank_create_sharded; BASELINE north_star's
+partitioning) shards the channels: the forward transform is split by blocks, the transposed spectra are exchanged, every rank folds its channels -- one batch of
+`--blocks` blocks per step ("scaling": "strong").  `--shard blocks` is the time-sliced schedule: every rank runs the whole pipeline on its run of `--blocks`
+blocks of a `--blocks` x N batch, the decimated outputs are exchanged all-to-all so that rank r ends up with its slice of the channels (the batch grows with N:
+"scaling": "weak (batch = blocks x N)").  Reports wideband INPUT MS/s (whole job) and aggregate output MS/s.
 --emulate-world W times ONE rank's work of a W-rank bank on one GPU (no transport) beside a bytes-per-link model of the exchange.
 
     python bench_fastddc.py [--gpus N] [--steps K] [--warmup W] [--channels 256] [--blocks 64] [--no-cpu-baseline] [--verify]
@@ -160,7 +161,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--emulate-world", type=int, default=0, help="time ONE rank's work of a world-N bank on this GPU (null transport) instead of running the bench")
     ap.add_argument("--rank", type=int, default=-1, help="with --emulate-world: the rank to time (default: every rank in turn)")
-    ap.add_argument("--shard", choices=["blocks", "channels"], default="blocks")
+    ap.add_argument("--shard", choices=["blocks", "channels"], default="channels",
+                    help="channels (default = csdr_amd_fastddc_bank_create_sharded, BASELINE north_star: channels sharded, spectra exchanged) or blocks (the time-sliced "
+                         "schedule: every rank runs the whole pipeline on its run of the batch's blocks, decimated outputs exchanged all-to-all)")
     ap.add_argument("--local-input", action="store_true", help="with --emulate-world --shard blocks: every rank is handed its own run (no input exchange)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -184,9 +187,12 @@ def main():
         raise SystemExit("bench_fastddc.py needs an MI355X; there is no CPU fallback")
     # CSDR_BENCH_SHARED_GPU=1: dry run of the multi-rank launcher contract on a box with ONE GPU (all ranks on device 0, gloo; RCCL refuses two ranks on
     # one device, so the exchange is a gloo broadcast of the natural-order spectrum through the two-object API) -- a test aid, never a measurement.
+    # CSDR_BENCH_SHARED_GPU=rccl: all ranks on device 0 as well, but the bank's exchange over the library's own RCCL communicator (torch.distributed over gloo only
+    # carries the 128-byte id and the barrier): the N > 1 RCCL call pattern on a one-GPU box, if RCCL accepts several ranks on one device.
+    shared_rccl = os.environ.get("CSDR_BENCH_SHARED_GPU") == "rccl"
     shared = os.environ.get("CSDR_BENCH_SHARED_GPU") == "1"
-    rank, local_rank, world = cd.init("gloo" if shared else None)
-    dev_index = 0 if shared else local_rank
+    rank, local_rank, world = cd.init("gloo" if (shared or shared_rccl) else None)
+    dev_index = 0 if (shared or shared_rccl) else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     stream = torch.cuda.current_stream()
@@ -204,7 +210,7 @@ def main():
         # the bank object: forward + inverse; over N GPUs the library's own RCCL communicator (the 128-byte id travels over torch.distributed) shards the
         # channels, splits the forward transform by blocks and all-gathers the transposed spectra (csdr_amd/csrc/comm.cpp)
         if world > 1:
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            idt = torch.zeros(128, dtype=torch.uint8, device="cpu" if shared_rccl else dev)
             if rank == 0:
                 idb = (C.c_char * 128)()
                 if L.csdr_amd_comm_unique_id(idb) < 0:
@@ -284,13 +290,13 @@ def main():
     L.csdr_amd_fastddc_inv_kernel_time(inv, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
     cd.barrier()
-    wall = cd.max_over_ranks(wall, dev if (world > 1 and not shared) else "cpu")
+    wall = cd.max_over_ranks(wall, dev if (world > 1 and not shared and not shared_rccl) else "cpu")
     if rank == 0:
         in_samples = nb * ddc.input_size * args.steps
         h_bytes = args.channels * ddc.fft_size * 8                         # per-channel taps_fft, read once per CALL (not per block)
         res = {"metric": "fastddc 256-channel channelizer, wideband input MS/s", "value": round(in_samples / wall / 1e6, 2), "unit": "complex MS/s (input)",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak (batch = blocks x N)" if (world > 1 and not shared and args.shard == "blocks") else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[3]: fastddc_fwd_cc + fastddc_inv_cc", "channels": args.channels, "decimation": args.decimation,
                           "transition_bw": args.tbw, "fft_size": ddc.fft_size, "fft_inv_size": ddc.fft_inv_size, "blocks_per_step": nb,
                           "parallelism": ("time slices: every rank runs the whole pipeline on its run of the batch's blocks (input sent point to point from rank 0), decimated outputs exchanged "

@@ -705,9 +705,9 @@ int csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *s
 //
 // Over several GPUs (csdr_amd_fastddc_bank_create_sharded / _sharded_by) the OUTPUT is always channel-sharded -- rank r delivers a block-distributed slice
 // of the channels, the place a client of that channel connects to -- and there are two ways to get there:
-//   CSDR_AMD_SHARD_CHANNELS  the compute is channel-sharded too: the forward transform is split by blocks, the transposed spectra are all-gathered
+//   CSDR_AMD_SHARD_CHANNELS  (default of csdr_amd_fastddc_bank_create_sharded) the compute is channel-sharded too: the forward transform is split by blocks, the transposed spectra are all-gathered
 //                            (9.1 B per input sample on every rank's links), every rank folds its channels (fastddc_mfma.hip: ddc_mfma_submit);
-//   CSDR_AMD_SHARD_BLOCKS    (default) the compute is TIME-sliced: rank r runs the whole single-GPU pipeline -- all channels -- on its run of the batch's
+//   CSDR_AMD_SHARD_BLOCKS    (opt-in, csdr_amd_fastddc_bank_create_sharded_by) the compute is TIME-sliced: rank r runs the whole single-GPU pipeline -- all channels -- on its run of the batch's
 //                            blocks, and only the decimated outputs are exchanged (all-to-all: every rank sends each peer that peer's channels of its run,
 //                            1/world of 8 B per input sample per link).  What makes it possible is that the one piece of state that crosses block boundaries,
 //                            decimating_shift_addition_cc's (remain, phase) per channel (fastddc.c:152-164), is data independent: every rank walks the chain
@@ -902,7 +902,12 @@ csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded_by(csdr_amd_ctx *ctx
 }
 csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
                                                             int window, int max_blocks, csdr_amd_comm *comm)
-{ return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, CSDR_AMD_SHARD_BLOCKS); }
+{   // Default = channel-sharded compute with the spectrum exchange (BASELINE north_star's partitioning, and the mode whose RCCL call pattern -- one group of
+    // send / recv and one all-gather per batch on ONE stream -- has run on hardware).  The time-sliced schedule (csdr_amd_fastddc_bank_create_sharded_by(...,
+    // CSDR_AMD_SHARD_BLOCKS): 6.5 x at 8 GPUs in the per-rank emulation against 1.3 x) issues its input and output exchanges from two side streams on the same
+    // communicator; until that has passed a run on >= 2 GPUs over RCCL it is opt-in.
+    return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, CSDR_AMD_SHARD_CHANNELS);
+}
 
 void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
 {
@@ -924,8 +929,14 @@ int csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *fir
 { *first = b->first_channel; *count = b->shard_mode == CSDR_AMD_SHARD_BLOCKS ? b->out_count : b->inv->n_channels; return 0; }
 int csdr_amd_fastddc_bank_shard_mode(const csdr_amd_fastddc_bank *b) { return b->world > 1 ? b->shard_mode : -1; }
 int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate)
-{   // channel = index into this rank's output slice (an unsharded bank: the channel)
-    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return fail_msg(-3, "fastddc_bank: a time-sliced bank retunes through csdr_amd_fastddc_bank_set_rate_global (every rank holds every channel)");
+{   // channel = index into this rank's OUTPUT slice (an unsharded bank: the channel) in both sharding modes.  A time-sliced bank computes every channel on every
+    // rank: there the slice index is mapped to the global channel -- but the other ranks have to hear of the retune too (csdr_amd_fastddc_bank_set_rate_global on
+    // every rank); a call on one rank only changes what THIS rank contributes to the channel's output.
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {
+        int first = 0, count = 0;
+        if (csdr_amd_fastddc_bank_channel_slice(b, &first, &count) || channel < 0 || channel >= count) return fail_msg(-3, "fastddc_bank: channel %d outside this rank's slice of %d", channel, count);
+        return csdr_amd_fastddc_inv_set_rate(b->inv, first + channel, shift_rate);
+    }
     return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
 }
 int csdr_amd_fastddc_bank_set_rate_global(csdr_amd_fastddc_bank *b, int channel, float shift_rate)
