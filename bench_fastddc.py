@@ -30,6 +30,18 @@ sys.path.insert(0, ROOT)
 import bench_common as bc  # noqa: E402
 
 
+FMT = {"cf32": ("", 8), "s16": ("_s16", 4), "u8": ("_u8", 2)}      # --input-format: entry-point suffix, bytes per complex sample
+
+
+def make_input(torch, n_samples, fmt, dev, g):
+    """the wideband stream: uniform(-1, 1) complexf, or the integer IQ pairs an SDR delivers (converted inside the forward transform)"""
+    if fmt == "s16":
+        return torch.randint(-32768, 32768, (n_samples, 2), dtype=torch.int16, device=dev, generator=g)
+    if fmt == "u8":
+        return torch.randint(0, 256, (n_samples, 2), dtype=torch.uint8, device=dev, generator=g)
+    return (torch.rand((n_samples, 2), device=dev, generator=g) * 2 - 1).contiguous()
+
+
 def verify(ctx, L, ddc, args, x, rates, first, count, nb):
     """Fresh forward / inverse objects, ONE call over the same `nb` blocks of the same input as a timed step (same kernels and tile shapes),
     16 of this rank's channels against the CPU oracle (tests/verify_configs.py)."""
@@ -43,9 +55,14 @@ def verify(ctx, L, ddc, args, x, rates, first, count, nb):
     pitch = L.csdr_amd_fastddc_inv_max_output(inv, nb) + 8
     out = torch.zeros((count, pitch, 2), dtype=torch.float32, device=x.device)
     counts = np.zeros(count, np.int32)
-    assert L.csdr_amd_fastddc_bank_process(bank, x.data_ptr(), nb, out.data_ptr(), pitch, counts.ctypes.data_as(C.c_void_p)) >= 0, ctx.err()
+    assert getattr(L, "csdr_amd_fastddc_bank_process" + FMT[args.input_format][0])(bank, x.data_ptr(), nb, out.data_ptr(), pitch, counts.ctypes.data_as(C.c_void_p)) >= 0, ctx.err()
     ctx.sync()
-    xh = x.cpu().numpy().view(np.complex64).ravel()
+    if args.input_format == "cf32":
+        xh = x.cpu().numpy().view(np.complex64).ravel()
+    else:      # the oracle sees what the reference pipeline would hand fastddc_fwd_cc: the converter's output (csdr_amd_convert_* is bit exact against it, tests/)
+        import oracle
+        conv = oracle.port().convert_s16_f if args.input_format == "s16" else oracle.port().convert_u8_f
+        xh = conv(x.cpu().numpy().ravel()).view(np.complex64)
     chans = vc.pick_rows(count)
     pspec, want = vc.fastddc_oracle_channels(xh, args.tbw, args.decimation, my_rates, chans)
     worst = 0.0
@@ -82,7 +99,8 @@ def emulate(args):
     nb = args.blocks                                                       # blocks per GLOBAL batch
     rates = (-0.5 + (np.arange(args.channels) + 0.5) / args.channels).astype(np.float32)
     g = torch.Generator(device=dev); g.manual_seed(4)
-    x = (torch.rand((nb * ddc.input_size + ddc.overlap_length, 2), device=dev, generator=g) * 2 - 1).contiguous()
+    sfx, es = FMT[args.input_format]
+    x = make_input(torch, nb * ddc.input_size + ddc.overlap_length, args.input_format, dev, g)
     mode = csdr_amd.SHARD[args.shard]
 
     def time_steps(step, n):
@@ -103,7 +121,7 @@ def emulate(args):
 
     def step1():
         for b in range(0, nb, per1):
-            if L.csdr_amd_fastddc_bank_process(bank1, x.data_ptr() + 8 * b * ddc.input_size, min(per1, nb - b), out1.data_ptr(), pitch1, None) < 0:
+            if getattr(L, "csdr_amd_fastddc_bank_process" + sfx)(bank1, x.data_ptr() + es * b * ddc.input_size, min(per1, nb - b), out1.data_ptr(), pitch1, None) < 0:
                 raise SystemExit(ctx.err())
     t1 = time_steps(step1, args.steps)
     L.csdr_amd_fastddc_bank_destroy(bank1); del out1
@@ -118,7 +136,7 @@ def emulate(args):
         f0 = C.c_int(); c0 = C.c_int(); L.csdr_amd_fastddc_bank_channel_slice(bank, C.byref(f0), C.byref(c0))
         pitch = L.csdr_amd_fastddc_bank_max_output(bank, nb) + 8
         out = torch.empty((c0.value, pitch, 2), dtype=torch.float32, device=dev)
-        submit = L.csdr_amd_fastddc_bank_submit_local if (args.local_input and mode == 1) else L.csdr_amd_fastddc_bank_submit
+        submit = getattr(L, ("csdr_amd_fastddc_bank_submit_local" if (args.local_input and mode == 1) else "csdr_amd_fastddc_bank_submit") + sfx)
 
         def step():
             if submit(bank, x.data_ptr(), nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
@@ -132,7 +150,7 @@ def emulate(args):
         L.csdr_amd_fastddc_bank_destroy(bank); L.csdr_amd_comm_destroy(comm); del out
     worst = max(t_rank.values())
     # ---- exchange model: bytes each GPU pushes through ONE of its links per batch (every peer sits behind its own link: full mesh)
-    in_b = 8.0 * nb * ddc.input_size; spec_b = 8.0 * nb * ddc.fft_size; out_b = 8.0 * nb * (ddc.post_input_size // ddc.post_decimation) * args.channels
+    in_b = float(es) * nb * ddc.input_size; spec_b = 8.0 * nb * ddc.fft_size; out_b = 8.0 * nb * (ddc.post_input_size // ddc.post_decimation) * args.channels
     per_link = {
         "input_scatter_root": in_b / W,                                    # the root sends every peer its 1/W of the stream (only when the stream lives on one GPU)
         "output_all_to_all": out_b / W / W if mode == 1 else 0.0,          # every rank sends each peer 1/W of its 1/W of the outputs
@@ -148,7 +166,7 @@ def emulate(args):
     res = {"metric": "fastddc 256-channel channelizer: ONE rank's per-batch work of a world-%d bank, emulated on one GPU" % W, "emulation": True,
            "note": "compute per rank measured alone on one MI355X with a null transport; the exchange is a bytes-per-link model, NOT a measurement; "
                    "exchange and compute overlap by construction (own streams, batch N+1's input / batch N's output under batch N's / N+1's kernels)",
-           "world": W, "shard": args.shard, "blocks_per_global_batch": nb, "channels": args.channels, "steps": args.steps,
+           "world": W, "shard": args.shard, "input_format": args.input_format, "input_bytes_per_sample": es, "blocks_per_global_batch": nb, "channels": args.channels, "steps": args.steps,
            "t1_ms_single_gpu_same_blocks": round(t1 * 1e3, 4), "t_rank_ms": {str(r): round(v * 1e3, 4) for r, v in t_rank.items()},
            "t_rank_ms_worst": round(worst * 1e3, 4), "t_rank_us_per_64_blocks": round(worst * 1e6 * 64 / nb, 2),
            "compute_only_scaling": round(t1 / worst, 2), "bytes_per_link_per_batch": {k: int(v) for k, v in per_link.items()}, "exchange_model": model,
@@ -165,6 +183,9 @@ def main():
                     help="channels (default = csdr_amd_fastddc_bank_create_sharded, BASELINE north_star: channels sharded, spectra exchanged) or blocks (the time-sliced "
                          "schedule: every rank runs the whole pipeline on its run of the batch's blocks, decimated outputs exchanged all-to-all)")
     ap.add_argument("--local-input", action="store_true", help="with --emulate-world --shard blocks: every rank is handed its own run (no input exchange)")
+    ap.add_argument("--input-format", choices=["cf32", "s16", "u8"], default="cf32",
+                    help="the wideband stream as complexf (default; SURVEY.md 8d) or as the s16 / u8 IQ pairs an SDR delivers: converted inside the forward transform "
+                         "(bit-equal to convert_s16_f / convert_u8_f in front, README.md:66-87); a sharded bank scatters the raw integers")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=3)
@@ -242,7 +263,7 @@ def main():
         if not bank:
             fwd = L.csdr_amd_fastddc_fwd_create(ctx.h, C.byref(ddc), nb)
         g = torch.Generator(device=dev); g.manual_seed(4)
-        x = (torch.rand((nb * ddc.input_size, 2), device=dev, generator=g) * 2 - 1).contiguous()
+        x = make_input(torch, nb * ddc.input_size, args.input_format, dev, g)
     xp = x.data_ptr() if x is not None else None
     torch.cuda.synchronize()
 
@@ -251,14 +272,18 @@ def main():
     # collect.  On one GPU there is nothing to hide the transforms under (the fold's workgroups hold the whole LDS of every CU; measured: 0.184 ms
     # pipelined vs 0.179 ms in order, profiles/r2f_*), so a step is one process() call.
     pipelined = bank is not None and world > 1
+    if args.input_format != "cf32" and not bank:
+        raise SystemExit("--input-format %s needs the bank object" % args.input_format)
+    bank_submit = getattr(L, "csdr_amd_fastddc_bank_submit" + FMT[args.input_format][0])
+    bank_process = getattr(L, "csdr_amd_fastddc_bank_process" + FMT[args.input_format][0])
 
     def step():
         if pipelined:
-            if L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
+            if bank_submit(bank, xp, nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
                 raise SystemExit(ctx.err())
             return
         if bank:
-            if L.csdr_amd_fastddc_bank_process(bank, xp, nb, out.data_ptr(), pitch, None) < 0:
+            if bank_process(bank, xp, nb, out.data_ptr(), pitch, None) < 0:
                 raise SystemExit(ctx.err())
             return
         if rank == 0:
@@ -273,7 +298,7 @@ def main():
         if rc < 0:
             raise SystemExit(ctx.err())
 
-    if pipelined and L.csdr_amd_fastddc_bank_submit(bank, xp, nb) < 0:      # prime the pipeline: from here on one batch is always staged
+    if pipelined and bank_submit(bank, xp, nb) < 0:      # prime the pipeline: from here on one batch is always staged
         raise SystemExit(ctx.err())
     for _ in range(args.warmup):
         step()
@@ -297,7 +322,8 @@ def main():
         res = {"metric": "fastddc 256-channel channelizer, wideband input MS/s", "value": round(in_samples / wall / 1e6, 2), "unit": "complex MS/s (input)",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak (batch = blocks x N)" if (world > 1 and not shared and args.shard == "blocks") else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[3]: fastddc_fwd_cc + fastddc_inv_cc", "channels": args.channels, "decimation": args.decimation,
+               "config": {"workload": "configs[3]: fastddc_fwd_cc + fastddc_inv_cc" + ("" if args.input_format == "cf32" else " fed %s IQ pairs (convert_%s_f fused into the forward transform)" % (args.input_format, args.input_format)),
+                          "input_format": args.input_format, "channels": args.channels, "decimation": args.decimation,
                           "transition_bw": args.tbw, "fft_size": ddc.fft_size, "fft_inv_size": ddc.fft_inv_size, "blocks_per_step": nb,
                           "parallelism": ("time slices: every rank runs the whole pipeline on its run of the batch's blocks (input sent point to point from rank 0), decimated outputs exchanged "
                                           "all-to-all so that rank r delivers its slice of the channels (RCCL, from libcsdr_amd.so)") if args.shard == "blocks" else

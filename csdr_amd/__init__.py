@@ -162,6 +162,11 @@ def lib():
     L.csdr_amd_fastddc_bank_local_blocks.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
     L.csdr_amd_fastddc_bank_overlap.argtypes = [vp]
     L.csdr_amd_fastddc_bank_submit_local.argtypes = [vp, vp, i]
+    if hasattr(L, "csdr_amd_fastddc_bank_process_s16"):
+        for nm in ("s16", "u8"):
+            getattr(L, "csdr_amd_fastddc_bank_process_" + nm).argtypes = [vp, vp, i, vp, sz, vp]
+            getattr(L, "csdr_amd_fastddc_bank_submit_" + nm).argtypes = [vp, vp, i]
+            getattr(L, "csdr_amd_fastddc_bank_submit_local_" + nm).argtypes = [vp, vp, i]
     L.csdr_amd_fastddc_bank_finish.argtypes = [vp, vp]
     L.csdr_amd_fastddc_bank_set_rate_global.argtypes = [vp, i, fl]
     L.csdr_amd_loopback_create.restype = vp; L.csdr_amd_loopback_create.argtypes = [i]
@@ -623,11 +628,12 @@ class Context:
     def fastddc_bank(self, x, tbw, decimation, shift_rates, window="HAMMING", blocks_per_call=None, retune=None, schedule=None, retunes=None):
         """forward + inverse in one object (csdr_amd_fastddc_bank_*): x = wideband samples -> list of per-channel outputs.
         retune = (call_index, channel, rate): applied before that call.  schedule = explicit list of blocks per call (instead of blocks_per_call);
-        retunes = {call_index: [(channel, rate), ...]}."""
-        x = np.ascontiguousarray(x, c64)
+        retunes = {call_index: [(channel, rate), ...]}.  x: complex64, or interleaved IQ as int16 / uint8 (csdr_amd_fastddc_bank_process_s16 / _u8)."""
+        x, sfx, es = _bank_input(x)
         rates = np.ascontiguousarray(shift_rates, f32); nc = rates.size
         ddc, _ = self.fastddc_init(tbw, decimation, 0.0)
-        nb = x.size // ddc.input_size
+        nb = (x.size if es == 8 else x.size // 2) // ddc.input_size
+        process = getattr(self.L, "csdr_amd_fastddc_bank_process" + sfx)
         per = nb if not blocks_per_call else blocks_per_call
         if schedule:
             per = max(schedule)
@@ -646,7 +652,7 @@ class Context:
             pitch = self.L.csdr_amd_fastddc_bank_max_output(bk, k) + 8
             do = self.alloc(8 * nc * pitch)
             counts = np.zeros(nc, np.int32)
-            self.check(self.L.csdr_amd_fastddc_bank_process(bk, di.at(8 * b * ddc.input_size), k, do.ptr, pitch, _hp(counts)), "fastddc_bank")
+            self.check(process(bk, di.at(es * b * ddc.input_size), k, do.ptr, pitch, _hp(counts)), "fastddc_bank")
             y = self.download(do, c64, nc * pitch).reshape(nc, pitch)
             for c in range(nc):
                 outs[c].append(y[c, :counts[c]].copy())
@@ -799,6 +805,16 @@ class Context:
 SHARD = {"channels": 0, "blocks": 1}
 
 
+def _bank_input(x):
+    """the wideband stream as the bank takes it: (array, entry-point suffix, bytes per complex sample)"""
+    x = np.asarray(x)
+    if x.dtype == np.int16:
+        return np.ascontiguousarray(x), "_s16", 4
+    if x.dtype == np.uint8:
+        return np.ascontiguousarray(x), "_u8", 2
+    return np.ascontiguousarray(x, c64), "", 8
+
+
 def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode="blocks", window="HAMMING", retunes=None, pipelined=True,
                           local_input=False, device=0):
     """The multi-rank fastddc bank (csdr_amd_fastddc_bank_create_sharded_by) run for real on ONE GPU: `world` rank threads, one Context each, joined by the
@@ -808,7 +824,8 @@ def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode
     ranks' slices)."""
     import threading
     L = lib()
-    x = np.ascontiguousarray(x, c64)
+    x, sfx, es = _bank_input(x)                          # complex64, or interleaved IQ as int16 / uint8 (the _s16 / _u8 entry points: the raw integers are scattered)
+    spc = 1 if es == 8 else 2                            # array elements per complex sample
     rates = np.ascontiguousarray(shift_rates, f32); nc = rates.size
     retunes = retunes or {}
     grp = L.csdr_amd_loopback_create(world)
@@ -843,13 +860,13 @@ def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode
                     f0 = C.c_int(); n0 = C.c_int()
                     L.csdr_amd_fastddc_bank_local_blocks(bank, nb, C.byref(f0), C.byref(n0))
                     a = (starts[k] + f0.value) * inp
-                    run = np.zeros(ovl + n0.value * inp, c64)
+                    run = np.zeros((ovl + n0.value * inp) * spc, x.dtype)          # (zeros in front of the stream: exact for complexf and s16)
                     lo = max(0, a - ovl)
-                    run[ovl - (a - lo):] = x[lo:a + n0.value * inp]
+                    run[(ovl - (a - lo)) * spc:] = x[lo * spc:(a + n0.value * inp) * spc]
                     held[k] = ctx.upload(run)
-                    ctx.check(L.csdr_amd_fastddc_bank_submit_local(bank, held[k].ptr, nb), "bank_submit_local")
+                    ctx.check(getattr(L, "csdr_amd_fastddc_bank_submit_local" + sfx)(bank, held[k].ptr, nb), "bank_submit_local")
                 else:
-                    ctx.check(L.csdr_amd_fastddc_bank_submit(bank, di.at(8 * starts[k] * inp) if di is not None else None, nb), "bank_submit")
+                    ctx.check(getattr(L, "csdr_amd_fastddc_bank_submit" + sfx)(bank, di.at(es * starts[k] * inp) if di is not None else None, nb), "bank_submit")
 
             submitted = -1
             for k in range(len(schedule)):

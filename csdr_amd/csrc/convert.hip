@@ -1,6 +1,7 @@
 // convert.hip -- sample-format converters, bit exact against the reference binary (libcsdr.c:2363-2437).
 // Pure streaming, HBM bound: 16-byte vector accesses on the float side, grid-stride over 2048 blocks.
 #include "common.hpp"
+#include "convert_dev.hpp"
 using namespace csdr_amd;
 
 namespace {
@@ -16,27 +17,7 @@ __device__ __forceinline__ int trunc_i32(double x)
     return (x > -2147483649.0 && x < 2147483648.0) ? (int)x : (int)0x80000000;
 }
 
-// ---- X -> float: one thread produces 4 floats (one 16-byte store) per step
-template <int KIND>   // 0: u8, 1: s8, 2: s16
-__device__ __forceinline__ float to_float(int raw)
-{
-    if (KIND == 0) {
-        // (float)v/(255/2.0)-1.0 in double, rounded once (libcsdr.c:2365).  For all 256 codes this equals the
-        // correctly rounded float quotient (2v-255)/255, which one Newton step on the reciprocal product
-        // reproduces exactly (checked exhaustively against the oracle in tests/): 4 VALU ops, no fp64 divide.
-        const float num = fmaf((float)raw, 2.0f, -255.0f);          // exact integer in [-255, 255]
-        const float rcp = 0x1.010102p-8f;                            // RN(1/255) = 0x3b808081
-        const float q = __fmul_rn(num, rcp);
-        const float err = fmaf(-q, 255.0f, num);                     // exact residual
-        return fmaf(err, rcp, q);
-    } else if (KIND == 1) {
-        // "/SCHAR_MAX" is a multiplication by the rounded reciprocal in the reference's -ffast-math build
-        return __fmul_rn((float)raw, 1.0f / 127.0f);
-    } else {
-        return __fmul_rn((float)raw, 1.0f / 32767.0f);
-    }
-}
-
+// ---- X -> float: one thread produces 4 floats (one 16-byte store) per step; to_float<KIND> lives in convert_dev.hpp (the channelizer's integer ingest shares it)
 template <int KIND, typename IN_T>
 __global__ __launch_bounds__(256) void k_to_float(const IN_T *__restrict__ in, float *__restrict__ out, size_t n)
 {

@@ -32,7 +32,12 @@ int ddc_mfma_set_taps(DdcMfma *m, hipStream_t st, const cf32 *d_H, int c_first, 
 // spans several GPUs; all on a side stream) followed by ddc_mfma_collect (fold + inverse transforms + scrap + residual shift on the context's stream).
 // Two calls may be staged: submit(N + 1) overlaps collect(N).
 bool ddc_mfma_can_forward(const DdcMfma *m);
-int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call, const cf32 *ext_tail = nullptr);
+// in: complexf, or -- fmt -- s16 / u8 IQ pairs converted inside the forward transform (bit-equal to convert_s16_f / convert_u8_f in front of it)
+enum { DDC_IN_CF32 = 0, DDC_IN_S16 = 1, DDC_IN_U8 = 2 };
+static inline size_t ddc_in_bytes(int fmt) { return fmt == DDC_IN_S16 ? 4 : fmt == DDC_IN_U8 ? 2 : 8; }      // per complex sample
+int ddc_mfma_submit(DdcMfma *m, const void *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call, const cf32 *ext_tail = nullptr,
+                    int fmt = DDC_IN_CF32, bool tail_in_front = false);
+int ddc_mfma_convert_samples(hipStream_t st, const void *in, int fmt, long long first, int n, cf32 *out);      // samples [first, first + n) of `in` as complexf
 // time-sliced bank (fftpath.hip): position of the next call's blocks inside a batch dealt to `world` ranks in runs of nbl blocks; the per-rank sample counts
 // offsets [world + 1][n_channels] (device, written into the caller's buffers); a batch in which this rank has no blocks
 int ddc_mfma_set_segment(DdcMfma *m, int nbl, int first, int total, int world, int *pref_cur, int *pref_next);

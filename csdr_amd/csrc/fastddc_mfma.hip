@@ -24,6 +24,7 @@
 // decimating_shift_addition_cc with the reference's float32 phasor recurrence REPLAYED (k_ddc_rot: one lane per (channel, block) chain, data
 // independent) -- the folded bins are read once, the output written once; no hipFFT plan, no [channel][block][inv] round trips.
 #include "fastddc.hpp"
+#include "convert_dev.hpp"
 #include <hip/hip_ext.h>
 #include "fft_butterflies.hpp"
 #include <math.h>
@@ -552,8 +553,19 @@ __device__ __forceinline__ void fft512_stages23(float2 *data, int t, const float
 // pass 1: 512-point transforms over n1 for 16 consecutive n2 per workgroup (128-byte runs on both sides), times W_N^(n2 k1), to Y[block][k1][n2];
 // pass 2: 128-point transforms over n2 -- one per (residue, block), input and output 1 KiB contiguous -- written straight in the fold's layout
 // Xt[residue][block][q] (q = q' with the first fft_swap_sides folded in).  The natural-order spectrum never exists; no framing copy.
-template <int NT>
-__global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ tail_out, float2 *__restrict__ Y,
+// FMT: what `in` holds -- 0 complexf, 1 s16 IQ pairs, 2 u8 IQ pairs: the reference feeds fastddc_fwd_cc from convert_s16_f / convert_u8_f (README.md:66-87, csdr.c:2255-2300);
+// converted here with the converters' own arithmetic (convert_dev.hpp: bit-equal to the two stages), so the stream crosses PCIe / xGMI at 4 or 2 bytes per sample
+// instead of 8.  The overlap in front of the first window is either `tail` (complexf: the previous call's newest samples, zeros at the stream's start, csdr.c:2279)
+// or -- tail == nullptr -- lies in front of `in` itself (a rank's run of a sharded bank: the bytes arrive with their overlap).  tail_out: complexf.
+template <int FMT> __device__ __forceinline__ float2 ddc_in_sample(const void *in, long long pos)
+{
+    if (FMT == 0) return reinterpret_cast<const float2 *>(in)[pos];
+    if (FMT == 1) { const uint32_t w = reinterpret_cast<const uint32_t *>(in)[pos]; return make_float2(to_float<2>((int16_t)(w & 0xffff)), to_float<2>((int16_t)(w >> 16))); }
+    const uint32_t w = reinterpret_cast<const uint16_t *>(in)[pos]; return make_float2(to_float<0>((int)(w & 0xff)), to_float<0>((int)(w >> 8)));
+}
+
+template <int NT, int FMT>
+__global__ __launch_bounds__(256) void k_ddc_fwd512(const void *__restrict__ in, const float2 *__restrict__ tail, float2 *__restrict__ tail_out, float2 *__restrict__ Y,
                                                     const float2 *__restrict__ g_tw, const float2 *__restrict__ g_twb, int inp, int ovl, int n_blocks, DdcChainJob cj)
 {
     // rows blockIdx.y >= n_blocks are riders -- the call's data-independent chain tables (k_ddc_chain_t's work), done beside the transforms instead of in front
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(256) void k_ddc_fwd512(const float2 *__restrict__ i
 #pragma unroll
         for (int a = 0; a < 8; a++) {
             const long long pos = base + 128LL * (64 * a + i + IW * s);
-            v[s][a] = pos < 0 ? tail[ovl + pos] : in[pos];
+            v[s][a] = (pos < 0 && tail) ? tail[ovl + pos] : ddc_in_sample<FMT>(in, pos);
             // the last window ends with the stream's newest `ovl` samples = the next call's overlap (csdr.c:2292)
             if (tail_out && b == n_blocks - 1 && pos >= tail_first) tail_out[pos - tail_first] = v[s][a];
         }
@@ -931,22 +943,40 @@ static int mfma_chains(DdcMfma *m, hipStream_t st, int k, int n_blocks, DdcChanS
 // forward transform of n_loc windows: window b starts at in[b inp - ovl] (positions < 0 come from `tail`); the result goes to Xt chunk `xt` with block pitch nbl.
 // riders != nullptr: the call's chain tables and phasor checkpoints are computed by extra workgroups of the two passes (pass 1 carries the chains, pass 2 the
 // checkpoints, which need the chains' phases: stream order) instead of by kernels of their own.
-static int mfma_forward(DdcMfma *m, hipStream_t st, const cf32 *in, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt, const DdcChainJob *riders, bool skip_pass2 = false)
+// the newest n samples of an integer stream as complexf (the next call's overlap, where the forward pass itself does not write it)
+template <int FMT> __global__ __launch_bounds__(256) void k_ddc_cvt_tail(const void *__restrict__ in, long long first, int n, float2 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ddc_in_sample<FMT>(in, first + i);
+}
+int ddc_mfma_convert_samples(hipStream_t st, const void *in, int fmt, long long first, int n, cf32 *out)
+{
+    if (fmt == 1) hipLaunchKernelGGL(k_ddc_cvt_tail<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, in, first, n, reinterpret_cast<float2 *>(out));
+    else if (fmt == 2) hipLaunchKernelGGL(k_ddc_cvt_tail<2>, dim3(cdiv(n, 256)), dim3(256), 0, st, in, first, n, reinterpret_cast<float2 *>(out));
+    else CSDR_HIP(hipMemcpyAsync(out, reinterpret_cast<const cf32 *>(in) + first, sizeof(cf32) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+static int mfma_forward(DdcMfma *m, hipStream_t st, const void *in, int fmt, const cf32 *tail, cf32 *tail_out, int n_loc, cf32 *xt, const DdcChainJob *riders, bool skip_pass2 = false)
 {
     if (n_loc <= 0) return 0;
     DdcChainJob cj; memset(&cj, 0, sizeof cj);
     if (riders) cj = *riders;
     const size_t rider_lanes = riders ? (cj.mode == 2 ? (size_t)cj.n_channels * cj.n_blocks : (size_t)cj.n_channels) : 0;      // mode 2: one lane per (block, channel) chain
     // pass 1: 16 columns n2 per workgroup (128-byte runs); CSDR_AMD_DDC_FWD=8: 64-byte runs, more workgroups per CU
-#define DDC_FWD_ARGS reinterpret_cast<const float2 *>(in), reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
+#define DDC_FWD_ARGS in, reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
                      reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc, cj
-    if (m->opt.fwd_cols == 8) {
+    if (m->opt.fwd_cols == 8 && fmt == 0) {
         const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
-        hipLaunchKernelGGL(k_ddc_fwd512<8>, dim3(16, n_loc + (riders ? cdiv(rider_lanes, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
+        hipLaunchKernelGGL((k_ddc_fwd512<8, 0>), dim3(16, n_loc + (riders ? cdiv(rider_lanes, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
     } else {
         const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
-        { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16>, lds); if (rc) return rc; }
-        hipLaunchKernelGGL(k_ddc_fwd512<16>, dim3(8, n_loc + (riders ? cdiv(rider_lanes, 8 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
+        const dim3 grid(8, n_loc + (riders ? cdiv(rider_lanes, 8 * 256) : 0));
+#define DDC_FWD_LAUNCH(F) do { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16, F>, lds); if (rc) return rc; \
+                               hipLaunchKernelGGL((k_ddc_fwd512<16, F>), grid, dim3(256), lds, st, DDC_FWD_ARGS); } while (0)
+        if (fmt == 1) DDC_FWD_LAUNCH(1); else if (fmt == 2) DDC_FWD_LAUNCH(2); else DDC_FWD_LAUNCH(0);
+#undef DDC_FWD_LAUNCH
     }
 #undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
@@ -981,8 +1011,14 @@ static bool ddc_folds_with_gemm3(const DdcMfma *m, int n_blocks)
 // inline = true (process(): submit immediately followed by collect, nothing else staged): the transforms go on the context's stream itself and only the
 // chains use the side stream, beside them -- on one GPU the forward transforms cannot overlap the previous batch's fold anyway (the fold's workgroups
 // hold the whole LDS of every CU), and a stream hand-off per kernel group costs more than it hides.
-int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call, const cf32 *ext_tail)
+int ddc_mfma_submit(DdcMfma *m, const void *in_v, const cf32 *spectra, int n_blocks, DdcChanState *d_state, const ChanGeom *d_geom, bool inline_call, const cf32 *ext_tail,
+                    int fmt, bool tail_in_front)
 {
+    // fmt: DDC_IN_CF32 / _S16 / _U8 samples in `in`.  tail_in_front: the overlap of the first window lies in front of `in` in the same format (a run of a sharded
+    // bank) -- otherwise ext_tail (complexf) or, when that is null too, the object's own carried tail.
+    if (fmt < 0 || fmt > 2) return fail_msg(-3, "fastddc: unknown input format %d", fmt);
+    const size_t es = ddc_in_bytes(fmt);
+    const uint8_t *in = reinterpret_cast<const uint8_t *>(in_v);
     if (n_blocks <= 0) return fail_msg(-3, "fastddc: nothing to submit");
     if (n_blocks > m->max_blocks) return fail_msg(-3, "fastddc: %d blocks exceed max_blocks %d", n_blocks, m->max_blocks);
     const int k = m->fill;
@@ -1034,8 +1070,9 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             const bool fuse2_off = m->opt.pass2_own;                              // CSDR_AMD_DDC_PASS2: k_ddc_fwd128 stays a kernel of its own
             const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
             // ext_tail: the overlap in front of the first window comes from the caller (a time-sliced bank: the stream before this rank's run is another rank's)
-            if (ext_tail) rc = mfma_forward(m, st, in, ext_tail, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
-            else { rc = mfma_forward(m, st, in, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2); m->flip ^= 1; }
+            if (tail_in_front) rc = mfma_forward(m, st, in, fmt, nullptr, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
+            else if (ext_tail) rc = mfma_forward(m, st, in, fmt, ext_tail, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
+            else { rc = mfma_forward(m, st, in, fmt, m->d_tail[m->flip], m->d_tail[m->flip ^ 1], n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2); m->flip ^= 1; }
             if (rc) return rc;
             m->y_holds[k] = skip2;
         } else {
@@ -1048,17 +1085,18 @@ int ddc_mfma_submit(DdcMfma *m, const cf32 *in, const cf32 *spectra, int n_block
             if (m->rank == 0) {
                 for (int g = 1; g < m->world; g++) {
                     const int g0 = first_of(g), g1 = first_of(g + 1);
-                    if (g1 > g0) { rc = cm->send(cm, in + (size_t)g0 * inp - ovl, 2 * ((size_t)(g1 - g0) * inp + ovl), g, st); if (rc) return rc; }
+                    // (the raw samples: 8, 4 or 2 bytes each -- the root's egress is what bounds the scaling of a single-ingest bank; counts in 4-byte words)
+                    if (g1 > g0) { rc = cm->send(cm, in + ((size_t)g0 * inp - ovl) * es, ((size_t)(g1 - g0) * inp + ovl) * es / 4, g, st); if (rc) return rc; }
                 }
-            } else if (n_loc > 0) { rc = cm->recv(cm, m->d_in_local, 2 * ((size_t)n_loc * inp + ovl), 0, st); if (rc) return rc; }
+            } else if (n_loc > 0) { rc = cm->recv(cm, m->d_in_local, ((size_t)n_loc * inp + ovl) * es / 4, 0, st); if (rc) return rc; }
             rc = cm->group_end(cm); if (rc) return rc;
             cf32 *chunk = m->d_Xt[k] + (size_t)m->rank * m->inv * m->nbl * m->pre;
             if (m->rank == 0) {
-                rc = mfma_forward(m, st, in, m->d_tail[m->flip], nullptr, n_loc, chunk, nullptr); if (rc) return rc;
-                // the next call's overlap = the newest ovl samples of the stream (input_size >= overlap_length at this geometry)
-                CSDR_HIP(hipMemcpyAsync(m->d_tail[m->flip ^ 1], in + (size_t)n_blocks * inp - ovl, sizeof(cf32) * (size_t)ovl, hipMemcpyDeviceToDevice, st));
+                rc = mfma_forward(m, st, in, fmt, m->d_tail[m->flip], nullptr, n_loc, chunk, nullptr); if (rc) return rc;
+                // the next call's overlap = the newest ovl samples of the stream (input_size >= overlap_length at this geometry), as complexf
+                rc = ddc_mfma_convert_samples(st, in, fmt, (long long)n_blocks * inp - ovl, ovl, m->d_tail[m->flip ^ 1]); if (rc) return rc;
                 m->flip ^= 1;
-            } else { rc = mfma_forward(m, st, m->d_in_local + ovl, m->d_in_local, nullptr, n_loc, chunk, nullptr); if (rc) return rc; }
+            } else { rc = mfma_forward(m, st, reinterpret_cast<const uint8_t *>(m->d_in_local) + (size_t)ovl * es, fmt, nullptr, nullptr, n_loc, chunk, nullptr); if (rc) return rc; }
             rc = cm->all_gather(cm, m->d_Xt[k], 2 * (size_t)m->inv * m->nbl * m->pre, st); if (rc) return rc;      // in place: every rank's chunk sits at its offset
         }
     }

@@ -724,7 +724,7 @@ struct csdr_amd_fastddc_bank {
     hipStream_t xin = nullptr, xout = nullptr;
     hipEvent_t ev_fork = nullptr, ev_in_ready[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool in_free_rec[2] = {false, false}, done_rec[2] = {false, false};
-    struct Batch { int n_glob; const cf32 *in; bool local; } batch[2]; int fill = 0, drain = 0, n_batches = 0, last_slot = -1;
+    struct Batch { int n_glob; const uint8_t *in; bool local; int fmt; } batch[2]; int fill = 0, drain = 0, n_batches = 0, last_slot = -1;
 };
 
 static void shard_slice(int n, int world, int rank, int *first, int *count)      // block distribution, counts differ by at most one (csdr_amd/dist.py: shard)
@@ -805,9 +805,11 @@ static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw
 // ---- time-sliced mode: submit = the input exchange of a batch (or nothing, when every rank is handed its own run), collect = this rank's pipeline + output exchange
 static inline int blk_first_of(const csdr_amd_fastddc_bank *b, int g, int n_glob) { const long long f = (long long)g * b->nbl; return f < n_glob ? (int)f : n_glob; }
 
-static int bank_submit_blocks(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_glob, bool local)
+static int bank_submit_blocks(csdr_amd_fastddc_bank *b, const void *in_v, int n_glob, bool local, int fmt)
 {
     if (b->n_batches == 2) return fail_msg(-3, "fastddc_bank: two batches are already staged; collect one first");
+    const uint8_t *in = reinterpret_cast<const uint8_t *>(in_v);
+    const size_t es = ddc_in_bytes(fmt);
     const csdr_fastddc_t &g = b->inv->geom[0];
     const int inp = g.input_size, ovl = g.overlap_length, slot = b->fill;
     const int b0 = blk_first_of(b, b->rank, n_glob), b1 = blk_first_of(b, b->rank + 1, n_glob), n_loc = b1 - b0;
@@ -819,13 +821,14 @@ static int bank_submit_blocks(csdr_amd_fastddc_bank *b, const csdr_complexf *in,
         if (b->rank == 0) {
             for (int p = 1; p < b->world; p++) {
                 const int p0 = blk_first_of(b, p, n_glob), p1 = blk_first_of(b, p + 1, n_glob);
-                if (p1 > p0) { rc = cm->send(cm, in + (size_t)p0 * inp - ovl, 2 * ((size_t)(p1 - p0) * inp + ovl), p, b->xin); if (rc) return rc; }
+                // (raw samples, 8 / 4 / 2 bytes each: integer ingest halves or quarters the root's egress; counts in 4-byte words)
+                if (p1 > p0) { rc = cm->send(cm, in + ((size_t)p0 * inp - ovl) * es, ((size_t)(p1 - p0) * inp + ovl) * es / 4, p, b->xin); if (rc) return rc; }
             }
-        } else if (n_loc > 0) { rc = cm->recv(cm, b->d_in_loc[slot], 2 * ((size_t)n_loc * inp + ovl), 0, b->xin); if (rc) return rc; }
+        } else if (n_loc > 0) { rc = cm->recv(cm, b->d_in_loc[slot], ((size_t)n_loc * inp + ovl) * es / 4, 0, b->xin); if (rc) return rc; }
         rc = cm->group_end(cm); if (rc) return rc;
         CSDR_HIP(hipEventRecord(b->ev_in_ready[slot], b->xin));
     }
-    b->batch[slot] = {n_glob, in, local};
+    b->batch[slot] = {n_glob, in, local, fmt};
     b->fill ^= 1; b->n_batches++;
     return 0;
 }
@@ -850,16 +853,18 @@ static int bank_collect_blocks(csdr_amd_fastddc_bank *b, csdr_complexf *out, siz
     b->pref_at = (b->pref_at + 1) % 3;
     int rc = ddc_mfma_set_segment(f->mf, b->nbl, b0, bt.n_glob, W, pref, pref_next); if (rc) return rc;
     if (n_loc > 0) {
-        const cf32 *src, *tail;
-        if (bt.local) { tail = bt.in; src = bt.in + ovl; }
-        else if (me == 0) { tail = b->d_tail_root[b->tail_flip]; src = bt.in; }
-        else { tail = b->d_in_loc[slot]; src = b->d_in_loc[slot] + ovl; }
-        rc = ddc_mfma_submit(f->mf, src, nullptr, n_loc, f->d_state, f->d_geom, true, tail); if (rc) return rc;
+        // the overlap in front of the run: with the run itself (its own format), except on the root of a scattered stream (complexf, carried between batches)
+        const size_t es = ddc_in_bytes(bt.fmt);
+        const uint8_t *src; const cf32 *tail = nullptr; bool in_front = true;
+        if (bt.local) src = bt.in + (size_t)ovl * es;
+        else if (me == 0) { tail = b->d_tail_root[b->tail_flip]; src = bt.in; in_front = false; }
+        else src = reinterpret_cast<const uint8_t *>(b->d_in_loc[slot]) + (size_t)ovl * es;
+        rc = ddc_mfma_submit(f->mf, src, nullptr, n_loc, f->d_state, f->d_geom, true, tail, bt.fmt, in_front); if (rc) return rc;
         rc = ddc_mfma_collect(f->mf, f->d_geom, b->d_out_loc[slot], b->pitch_loc, nullptr, b->ev_out_ready[slot]); if (rc < 0) return rc;
     } else { rc = ddc_mfma_skip_batch(f->mf, f->d_state, f->d_geom); if (rc) return rc; }
     const bool out_ready_recorded = n_loc > 0;                           // (by the call's last kernel itself)
     if (!bt.local && me == 0) {      // the next batch's overlap = the newest ovl samples of the stream (input_size >= overlap_length: checked at create)
-        CSDR_HIP(hipMemcpyAsync(b->d_tail_root[b->tail_flip ^ 1], bt.in + (size_t)bt.n_glob * inp - ovl, sizeof(cf32) * (size_t)ovl, hipMemcpyDeviceToDevice, st));
+        rc = ddc_mfma_convert_samples(st, bt.in, bt.fmt, (long long)bt.n_glob * inp - ovl, ovl, b->d_tail_root[b->tail_flip ^ 1]); if (rc) return rc;
         b->tail_flip ^= 1;
     }
     b->in_free_rec[slot] = true;
@@ -957,23 +962,32 @@ int csdr_amd_fastddc_bank_local_blocks(const csdr_amd_fastddc_bank *b, int n_blo
     return 0;
 }
 
-static int bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, bool inline_call)
+static int bank_submit(csdr_amd_fastddc_bank *b, const void *in, int n_blocks, bool inline_call, int fmt = DDC_IN_CF32)
 {
     if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
-    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return bank_submit_blocks(b, in, n_blocks, false);
-    if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom, inline_call);
+    if (fmt < 0 || fmt > 2) return fail_msg(-3, "fastddc_bank: unknown input format %d", fmt);
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return bank_submit_blocks(b, in, n_blocks, false, fmt);
+    if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom, inline_call, nullptr, fmt, false);
+    if (fmt != DDC_IN_CF32) return fail_msg(-3, "fastddc_bank: integer input needs the matrix-core geometry (fft 65536 / inverse 512); convert first (csdr_amd_convert_s16_f / _u8_f)");
     if (b->n_staged) return fail_msg(-3, "fastddc_bank: this geometry stages one call at a time");
-    int rc = csdr_amd_fastddc_fwd_process(b->fwd, in, b->d_spec, n_blocks); if (rc) return rc;
+    int rc = csdr_amd_fastddc_fwd_process(b->fwd, reinterpret_cast<const csdr_complexf *>(in), b->d_spec, n_blocks); if (rc) return rc;
     b->staged[0] = n_blocks; b->n_staged = 1;
     return 0;
 }
 int csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks) { return bank_submit(b, in, n_blocks, false); }
-int csdr_amd_fastddc_bank_submit_local(csdr_amd_fastddc_bank *b, const csdr_complexf *in_run, int n_blocks)
+// integer ingest: s16 / u8 IQ pairs, converted inside the forward transform exactly as convert_s16_f / convert_u8_f would (README.md:66-87: the reference feeds
+// fastddc_fwd_cc from these converters); a sharded bank scatters the raw integers
+int csdr_amd_fastddc_bank_submit_s16(csdr_amd_fastddc_bank *b, const int16_t *in_iq, int n_blocks) { return bank_submit(b, in_iq, n_blocks, false, DDC_IN_S16); }
+int csdr_amd_fastddc_bank_submit_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_iq, int n_blocks) { return bank_submit(b, in_iq, n_blocks, false, DDC_IN_U8); }
+static int bank_submit_local_fmt(csdr_amd_fastddc_bank *b, const void *in_run, int n_blocks, int fmt)
 {
     if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
     if (b->shard_mode != CSDR_AMD_SHARD_BLOCKS) return fail_msg(-3, "fastddc_bank: submit_local needs a time-sliced bank");
-    return bank_submit_blocks(b, in_run, n_blocks, true);
+    return bank_submit_blocks(b, in_run, n_blocks, true, fmt);
 }
+int csdr_amd_fastddc_bank_submit_local(csdr_amd_fastddc_bank *b, const csdr_complexf *in_run, int n_blocks) { return bank_submit_local_fmt(b, in_run, n_blocks, DDC_IN_CF32); }
+int csdr_amd_fastddc_bank_submit_local_s16(csdr_amd_fastddc_bank *b, const int16_t *in_run_iq, int n_blocks) { return bank_submit_local_fmt(b, in_run_iq, n_blocks, DDC_IN_S16); }
+int csdr_amd_fastddc_bank_submit_local_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_run_iq, int n_blocks) { return bank_submit_local_fmt(b, in_run_iq, n_blocks, DDC_IN_U8); }
 
 // the context's stream (and, with out_counts, the host) behind everything the batch collected last still has in flight on the exchange stream
 int csdr_amd_fastddc_bank_finish(csdr_amd_fastddc_bank *b, int *out_counts)
@@ -1008,14 +1022,20 @@ int csdr_amd_fastddc_bank_collect(csdr_amd_fastddc_bank *b, csdr_complexf *out, 
     return out_counts ? csdr_amd_fastddc_bank_finish(b, out_counts) : 0;
 }
 
-int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+static int bank_process_fmt(csdr_amd_fastddc_bank *b, const void *in, int fmt, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
 {
     if (n_blocks <= 0) return 0;
     if ((size_t)csdr_amd_fastddc_inv_max_output(b->inv, n_blocks) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
-    int rc = bank_submit(b, in, n_blocks, true); if (rc) return rc;
+    int rc = bank_submit(b, in, n_blocks, true, fmt); if (rc) return rc;
     rc = csdr_amd_fastddc_bank_collect(b, out, out_pitch, out_counts); if (rc) return rc;
     return out_counts ? 0 : csdr_amd_fastddc_bank_finish(b, nullptr);
 }
+int csdr_amd_fastddc_bank_process(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{ return bank_process_fmt(b, in, DDC_IN_CF32, n_blocks, out, out_pitch, out_counts); }
+int csdr_amd_fastddc_bank_process_s16(csdr_amd_fastddc_bank *b, const int16_t *in_iq, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{ return bank_process_fmt(b, in_iq, DDC_IN_S16, n_blocks, out, out_pitch, out_counts); }
+int csdr_amd_fastddc_bank_process_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_iq, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts)
+{ return bank_process_fmt(b, in_iq, DDC_IN_U8, n_blocks, out, out_pitch, out_counts); }
 
 } // extern "C"
 

@@ -333,6 +333,16 @@ int  csdr_amd_fastddc_bank_shard_mode(const csdr_amd_fastddc_bank *b);          
 int  csdr_amd_fastddc_bank_local_blocks(const csdr_amd_fastddc_bank *b, int n_blocks, int *first, int *count);
 int  csdr_amd_fastddc_bank_overlap(const csdr_amd_fastddc_bank *b);
 int  csdr_amd_fastddc_bank_submit_local(csdr_amd_fastddc_bank *b, const csdr_complexf *in_run, int n_blocks);
+/* Integer ingest: the wideband stream as s16 or u8 IQ pairs (what an SDR delivers; the reference puts convert_s16_f / convert_u8_f in front of fastddc_fwd_cc,
+ * README.md:66-87, libcsdr.c:2363-2437, csdr.c:2255-2300).  The conversion runs inside the forward transform with the converters' own arithmetic -- the outputs
+ * are bit-equal to csdr_amd_convert_s16_f / _u8_f followed by the complexf entry points -- and the stream crosses PCIe (and, in a sharded bank, the root's xGMI
+ * links) at 4 or 2 bytes per sample instead of 8.  Matrix-core geometry only (fft 65536 / inverse 512: BASELINE config 4); other geometries: convert first. */
+int  csdr_amd_fastddc_bank_process_s16(csdr_amd_fastddc_bank *b, const int16_t *in_iq, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts);
+int  csdr_amd_fastddc_bank_process_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_iq, int n_blocks, csdr_complexf *out, size_t out_pitch, int *out_counts);
+int  csdr_amd_fastddc_bank_submit_s16(csdr_amd_fastddc_bank *b, const int16_t *in_iq, int n_blocks);
+int  csdr_amd_fastddc_bank_submit_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_iq, int n_blocks);
+int  csdr_amd_fastddc_bank_submit_local_s16(csdr_amd_fastddc_bank *b, const int16_t *in_run_iq, int n_blocks);
+int  csdr_amd_fastddc_bank_submit_local_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_run_iq, int n_blocks);
 int  csdr_amd_fastddc_bank_finish(csdr_amd_fastddc_bank *b, int *out_counts);
 /* retune by GLOBAL channel number; every rank makes the same call (csdr_amd_fastddc_bank_set_rate takes an index into the rank's own slice and is refused
  * by a time-sliced bank, where every rank holds every channel) */

@@ -160,3 +160,48 @@ def test_time_sliced_bank_at_the_emulated_size(gpu, port):
     _, want = vc.fastddc_oracle_channels(x, TBW, D, rates, check)
     for c in check:
         assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < 1e-5, "channel %d vs oracle" % c
+
+
+@pytest.mark.parametrize("fmt", ["s16", "u8"])
+def test_bank_integer_ingest_is_bit_equal_to_the_converter_in_front(gpu, fmt):
+    """csdr_amd_fastddc_bank_process_s16 / _u8: the wideband stream as integer IQ pairs, converted inside the forward transform (README.md:66-87: the reference
+    runs convert_s16_f / convert_u8_f in front of fastddc_fwd_cc).  Against the device converter followed by the complexf entry point, in calls of 24 / 3 / 37
+    blocks (the carried overlap is complexf either way): the same bits on all 256 channels."""
+    ddc, _ = gpu.fastddc_init(TBW, D, 0.0)
+    nb = 64
+    rng = np.random.default_rng(91)
+    if fmt == "s16":
+        raw = rng.integers(-32768, 32768, 2 * nb * ddc.input_size, dtype=np.int16)
+        xf = gpu.convert_s16_f(raw).view(c64)
+    else:
+        raw = rng.integers(0, 256, 2 * nb * ddc.input_size, dtype=np.uint8)
+        xf = gpu.convert_u8_f(raw).view(c64)
+    rates = vc.c4_rates(NCH)
+    a = gpu.fastddc_bank(xf, TBW, D, rates, schedule=[24, 3, 37])
+    b = gpu.fastddc_bank(raw, TBW, D, rates, schedule=[24, 3, 37])
+    for c in range(NCH):
+        assert a[c].size == b[c].size and np.array_equal(a[c].view(np.uint32), b[c].view(np.uint32)), "channel %d" % c
+
+
+@pytest.mark.parametrize("mode,fmt", [("channels", "s16"), ("blocks", "s16"), ("channels", "u8"), ("blocks", "u8")])
+def test_sharded_bank_scatters_raw_integers(gpu, mode, fmt):
+    """A sharded bank fed integer samples on rank 0: the RAW integers are what crosses the links (4 or 2 bytes per sample instead of 8: the root's egress is what
+    bounds the scaling of a single-ingest bank), every rank converts its run inside its forward transform.  World 4 over the loopback communicator, batches of
+    40 / 5 / 19 blocks, every channel against the one-GPU bank on the same integers (2e-6: another summation context of the second forward pass)."""
+    import csdr_amd
+    ddc, _ = gpu.fastddc_init(TBW, D, 0.0)
+    sched = [40, 5, 19]
+    rng = np.random.default_rng(92)
+    n = 2 * sum(sched) * ddc.input_size
+    raw = rng.integers(-32768, 32768, n, dtype=np.int16) if fmt == "s16" else rng.integers(0, 256, n, dtype=np.uint8)
+    rates = vc.c4_rates(NCH)
+    single = gpu.fastddc_bank(raw, TBW, D, rates, schedule=sched)
+    outs = csdr_amd.sharded_bank_loopback(4, raw, TBW, D, rates, sched, mode=mode, pipelined=True)
+    worst = 0.0
+    for c in range(NCH):
+        assert outs[c].size == single[c].size, "channel %d" % c
+        worst = max(worst, vc.relrms(outs[c], single[c]))
+    assert worst < 2e-6, worst
+    if mode == "blocks" and fmt == "s16":               # every rank handed its own run (s16: the zeros in front of the stream are exact)
+        outs = csdr_amd.sharded_bank_loopback(4, raw, TBW, D, rates, sched, mode=mode, pipelined=True, local_input=True)
+        assert max(vc.relrms(outs[c], single[c]) for c in range(NCH)) < 2e-6
