@@ -50,6 +50,11 @@ def verify(ctx, L, ddc, args, x, rates, first, count, nb):
     import verify_configs as vc
     import torch
     my_rates = np.ascontiguousarray(rates[first:first + count])
+    # a context of its own (own non-blocking stream, as the test suite's): creating a second bank on the timed context -- which rides on torch's null stream --
+    # faulted now and then inside the create's hipFFT pass over the taps (never seen on a stream of the library's own: profiles/r4_notes.md)
+    import csdr_amd
+    torch.cuda.synchronize()
+    ctx = csdr_amd.Context(x.device.index or 0)
     bank = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
     inv = L.csdr_amd_fastddc_bank_inverse(bank)
     pitch = L.csdr_amd_fastddc_inv_max_output(inv, nb) + 8
@@ -73,6 +78,7 @@ def verify(ctx, L, ddc, args, x, rates, first, count, nb):
         worst = max(worst, vc.relrms(got[:want[c].size], want[c]))
     kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
     L.csdr_amd_fastddc_bank_destroy(bank)
+    ctx.close()
     return {"channels": chans, "blocks": nb, "max_rel_rms": worst, "tolerance": 1e-5, "kernel": kname, "ok": bool(ok and worst < 1e-5)}
 
 
@@ -355,6 +361,13 @@ def main():
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": None, "peak": bc.FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                                "note": "general kernels (geometry outside the matrix-core path): no per-kernel timing"}
         if args.verify:
+            # with the timed objects gone: two banks alive at once + integer input faulted sporadically inside the second bank's first call (open: profiles/r4_notes.md)
+            if world == 1:
+                ctx.sync(); torch.cuda.synchronize()
+                if bank:
+                    L.csdr_amd_fastddc_bank_destroy(bank); bank = None; inv = None      # (the bank owned its inverse half)
+                elif inv:
+                    L.csdr_amd_fastddc_inv_destroy(inv); inv = None
             res["verify"] = verify(ctx, L, ddc, args, x, rates, first, count, nb)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = bc.cpu_baseline("fastddc", (args.channels, args.tbw), unit="complex MS/s (input)", single_amount=1, probe_amount=4, target_wall_s=10.0,
@@ -371,7 +384,7 @@ def main():
         L.csdr_amd_fastddc_bank_destroy(bank)
         if comm:
             L.csdr_amd_comm_destroy(comm)
-    else:
+    elif inv:
         L.csdr_amd_fastddc_inv_destroy(inv)
     if fwd:
         L.csdr_amd_fastddc_fwd_destroy(fwd)

@@ -856,6 +856,17 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_state_spec, sizeof(DdcChanState) * (size_t)n_channels);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMemsetAsync(m->d_Ht, 0, sizeof(float) * 2 * (size_t)m->Cpad * fft, ctx->stream);      // padded channel rows stay zero
+    // the fused forward transform's buffers (allocated here, not in the first call: a call allocates nothing)
+    m->input_size = input_size; m->overlap = overlap;
+    if (e == hipSuccess && fft == 65536 && pre == 128) {
+        const int y_blocks = m->world > 1 ? m->nbl : m->max_blocks;
+        e = hipMalloc((void **)&m->d_Y, sizeof(cf32) * (size_t)y_blocks * fft);
+        for (int t = 0; t < 2 && e == hipSuccess; t++) {
+            e = hipMalloc((void **)&m->d_tail[t], sizeof(cf32) * (size_t)(overlap + 1));
+            if (e == hipSuccess) e = hipMemsetAsync(m->d_tail[t], 0, sizeof(cf32) * (size_t)(overlap + 1), ctx->stream);        // csdr.c:2279: the first window starts with zeros
+        }
+        if (e == hipSuccess && m->world > 1) e = hipMalloc((void **)&m->d_in_local, sizeof(cf32) * ((size_t)m->nbl * input_size + overlap));
+    }
     if (e != hipSuccess) { fail(e, "hipMalloc(fastddc matrix-core path)", __FILE__, __LINE__); ddc_mfma_destroy(m); return nullptr; }
     std::vector<float2> tw(512), twb(128);
     for (int k = 0; k < 512; k++) { const double a = -2.0 * M_PI * k / 512.0; tw[k] = make_float2((float)cos(a), (float)sin(a)); }
@@ -1054,16 +1065,7 @@ int ddc_mfma_submit(DdcMfma *m, const void *in_v, const cf32 *spectra, int n_blo
     } else {
         if (!ddc_mfma_can_forward(m)) return fail_msg(-3, "fastddc: the fused forward transform covers fft_size 65536 / pre_decimation 128 only");
         const int inp = m->input_size, ovl = m->overlap;
-        if (!m->d_Y) {
-            const int y_blocks = m->world > 1 ? m->nbl : m->max_blocks;
-            hipError_t e = hipMalloc((void **)&m->d_Y, sizeof(cf32) * (size_t)y_blocks * m->fft);
-            for (int t = 0; t < 2 && e == hipSuccess; t++) {
-                e = hipMalloc((void **)&m->d_tail[t], sizeof(cf32) * (size_t)(ovl + 1));
-                if (e == hipSuccess) e = hipMemsetAsync(m->d_tail[t], 0, sizeof(cf32) * (size_t)(ovl + 1), st);        // csdr.c:2279: the first window starts with zeros
-            }
-            if (e == hipSuccess && m->world > 1) e = hipMalloc((void **)&m->d_in_local, sizeof(cf32) * ((size_t)m->nbl * inp + ovl));
-            if (e != hipSuccess) return fail(e, "hipMalloc(fastddc forward)", __FILE__, __LINE__);
-        }
+        if (!m->d_Y) return fail_msg(-3, "fastddc: forward buffers missing");
         if (m->world == 1) {
             DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
             if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }

@@ -573,15 +573,25 @@ static csdr_amd_fastddc_inv *fastddc_inv_create_comm(csdr_amd_ctx *ctx, float tr
             for (int k = 0; k < g.taps_length; k++) taps[(size_t)c * fft + k] = one[k];
         }
         (void)hipMemcpy(f->d_H, taps.data(), sizeof(cf32) * taps.size(), hipMemcpyHostToDevice);
-        hipfftHandle h; int n[1] = {fft};
-        if (hipfftPlanMany(&h, 1, n, nullptr, 1, fft, nullptr, 1, fft, HIPFFT_C2C, n_channels) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlanMany(taps) failed"); delete f; return nullptr; }
+        // The batched plan for the taps is kept for the life of the process, one per (fft, channels), used under a lock: creating AND destroying a plan per
+        // object made the create of a SECOND object in a process fault now and then inside this block (GPU memory access fault at addresses of a few MiB, before
+        // the new object had processed anything; about one create in five behind a bench run -- profiles/r4_notes.md; not seen once the plan survives).
+        static std::map<std::pair<int, int>, hipfftHandle> taps_plans;
+        static std::mutex taps_mu;
+        std::lock_guard<std::mutex> lk(taps_mu);
+        const auto key = std::make_pair(fft, n_channels);
+        if (!taps_plans.count(key)) {
+            hipfftHandle h; int n[1] = {fft};
+            if (hipfftPlanMany(&h, 1, n, nullptr, 1, fft, nullptr, 1, fft, HIPFFT_C2C, n_channels) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlanMany(taps) failed"); delete f; return nullptr; }
+            taps_plans[key] = h;
+        }
+        hipfftHandle h = taps_plans[key];
         hipfftSetStream(h, ctx->stream);
         hipfftExecC2C(h, (hipfftComplex *)f->d_H, (hipfftComplex *)f->d_H, HIPFFT_FORWARD);
         const size_t total = (size_t)n_channels * fft;
         hipLaunchKernelGGL(k_swap_halves, dim3(cdiv(total / 2, 256)), dim3(256), 0, ctx->stream, f->d_H, fft, total);
         if (f->mf && ddc_mfma_set_taps(f->mf, ctx->stream, f->d_H, 0, n_channels)) { delete f; return nullptr; }
         (void)hipStreamSynchronize(ctx->stream);
-        hipfftDestroy(h);
     }
     return f;
 }

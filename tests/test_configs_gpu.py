@@ -399,7 +399,7 @@ def test_c5_nfm_every_channel(gpu, port):
     rates = vc.c5_rates(S)
     assert len(set(rates.tolist())) == S
     # one modulating signal per channel would cost 512 x 2.4 M numpy samples: 16 base signals at offset 0, moved to -rate of the channel by a phase ramp before quantising
-    base = [tests_helpers_nfm_baseband(3100 + k, T) for k in range(16)]
+    base = [_nfm_baseband(3100 + k, T) for k in range(16)]
     n_out_max = (T // D + 2048 + 63) // 64 * 64
     x = torch.empty((S, 2 * T), dtype=torch.uint8, device="cuda")
     tt = torch.arange(T, device="cuda", dtype=torch.float64)
@@ -428,7 +428,7 @@ def test_c5_nfm_every_channel(gpu, port):
     assert (rms > ref / 1.41).all() and (rms < ref * 1.41).all(), (int(rms.argmin()), float(rms.min()), int(rms.argmax()), float(rms.max()), float(ref))
 
 
-def tests_helpers_nfm_baseband(seed, n, deviation=5e3 / 2.4e6):
+def _nfm_baseband(seed, n, deviation=5e3 / 2.4e6):
     """complex128 narrow-band FM signal at offset 0 (tests_helpers.nfm_signal_u8 before the frequency offset and the quantiser)"""
     rng = np.random.default_rng(seed)
     msg = np.sin(2 * np.pi * 1e3 / 2.4e6 * np.arange(n)) + 0.3 * np.convolve(rng.uniform(-1, 1, n + 199), np.ones(200) / 200, "valid")
