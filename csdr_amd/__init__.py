@@ -191,6 +191,9 @@ def lib():
         L.csdr_amd_ddc_get_rate.restype = fl; L.csdr_amd_ddc_get_rate.argtypes = [vp, i]
         L.csdr_amd_ddc_fallback.argtypes = [vp]
         L.csdr_amd_wfm_fallback.argtypes = [vp]
+        L.csdr_amd_wfm_create_rates.restype = vp; L.csdr_amd_wfm_create_rates.argtypes = [vp, i, vp, i, vp, i, i, fl, i, sz]
+        L.csdr_amd_wfm_set_rate.argtypes = [vp, i, fl]
+        L.csdr_amd_wfm_get_rate.restype = fl; L.csdr_amd_wfm_get_rate.argtypes = [vp, i]
         L.csdr_amd_nfm_create_rates.restype = vp; L.csdr_amd_nfm_create_rates.argtypes = [vp, i, vp, i, vp, i, i, i, fl, fl, sz]
         L.csdr_amd_nfm_set_rate.argtypes = [vp, i, fl]
     L.csdr_amd_ddc_destroy.argtypes = [vp]
@@ -663,29 +666,37 @@ class Context:
 
     # (the multi-rank form of the bank on ONE GPU: sharded_bank_loopback below, module level -- one Context per rank thread)
 
-    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0):
-        """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call;
-        `pitch_pad` = extra bytes of row pitch (multiple of 16).
+    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0, retunes=None, want_float=True):
+        """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call (or a list of call sizes);
+        `pitch_pad` = extra bytes of row pitch (multiple of 16).  shift_rate: one float, or one per stream (csdr_amd_wfm_create_rates);
+        retunes: {call index: [(stream, rate), ...]} applied in front of that call.  want_float=False: s16 only (the kernel's line-collecting store path).
         The front-end kernel of the last call is left in `self.last_wfm_kernel`."""
         x2, squeeze = self._2d(iq_u8, np.uint8)
         s, nbytes = x2.shape; n = nbytes // 2
         pitch = (nbytes + 15) // 16 * 16 + pitch_pad
         xx = np.zeros((s, pitch), np.uint8); xx[:, :nbytes] = x2
         taps = np.ascontiguousarray(taps, f32)
-        block = n if block is None else block
-        w = self.L.csdr_amd_wfm_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, frac_rate, tau, audio_rate, max(block, 1024))
+        sched = list(block) if isinstance(block, (list, tuple)) else None
+        block = n if block is None else (max(sched) if sched else block)
+        if np.ndim(shift_rate) == 0:
+            w = self.L.csdr_amd_wfm_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, frac_rate, tau, audio_rate, max(block, 1024))
+        else:
+            rates = np.ascontiguousarray(shift_rate, f32); assert rates.size == s
+            w = self.L.csdr_amd_wfm_create_rates(self.h, s, _hp(rates), decimation, _hp(taps), taps.size, frac_rate, tau, audio_rate, max(block, 1024))
         if not w:
             raise CsdrAmdError(self.err())
         di = self.upload(xx)
-        apitch = n // (decimation * frac_rate) + 64
-        ds = self.alloc(2 * s * apitch); df = self.alloc(4 * s * apitch)
-        pos = 0; na = 0
+        apitch = (n // (decimation * frac_rate) + 64 + 63) // 64 * 64
+        ds = self.alloc(2 * s * apitch); df = self.alloc(4 * s * apitch) if want_float else None
+        pos = 0; na = 0; call = 0
         while pos < n:
-            k = min(block, n - pos)
-            got = self.check(self.L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na), apitch), "wfm_process")
+            for st, r in (retunes or {}).get(call, []):
+                self.check(self.L.csdr_amd_wfm_set_rate(w, st, r), "wfm_set_rate")
+            k = min(sched[call] if (sched and call < len(sched)) else block, n - pos); call += 1
+            got = self.check(self.L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na) if want_float else None, apitch), "wfm_process")
             pos += k; na += got
         s16 = self.download(ds, np.int16, s * apitch).reshape(s, apitch)[:, :na]
-        af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na]
+        af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na] if want_float else np.zeros((s, 0), f32)
         self.last_wfm_kernel = self.L.csdr_amd_wfm_kernel_name(w).decode()
         self.L.csdr_amd_wfm_destroy(w)
         return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())

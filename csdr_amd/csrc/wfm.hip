@@ -27,6 +27,7 @@
 //                 exact carried state.
 #include "common.hpp"
 #include "wfm_mfma.hpp"
+#include "seeds.hpp"
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -220,14 +221,30 @@ struct csdr_amd_wfm {
     float2 *d_ctab; size_t ctab_cap;
     float2 c_prev;                   // phasor seed of the previous block's last chunk (history windows)
     long long tab_first; bool tab_valid;      // the device table of seeds covers chunks [tab_first, tab_first + ctab_cap)
+    // a shift rate per stream (csdr_amd_wfm_create_rates): one table set per stream in mfma.*, chunk seeds from a seed table (seeds.hip)
+    bool ps; std::vector<float> rates, h_taps; csdr_amd::SeedTables *seeds; float *d_scales;
+    float2 *d_dtab_old; int *d_list, *d_lead_n; float *d_lead_d; std::vector<int> retuned;      // streams retuned since the last call: their first samples straddle two rates
 };
 
 extern "C" {
 
-csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps,
-                                  int taps_length, int frac_rate, float tau, int audio_rate, size_t max_block_samples)
+// tables of ONE stream of a per-stream object
+static int wfm_upload_stream_tables(csdr_amd_wfm *w, int s, float rate)
 {
-    if (n_streams <= 0 || decimation <= 0 || taps_length <= 0 || frac_rate <= 1) { fail_msg(-3, "wfm: bad parameters"); return nullptr; }
+    WfmMfmaTable t;
+    wfm_mfma_build_table(w->D, w->L, w->F, rate, w->h_taps.data(), t);
+    CSDR_HIP(hipMemcpy((uint8_t *)w->mfma.d_seq_frags + (size_t)s * t.seq_frags.size(), t.seq_frags.data(), t.seq_frags.size(), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(w->mfma.d_seq_cum + (size_t)s * t.seq_cum.size(), t.seq_cum.data(), t.seq_cum.size() * sizeof(float), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(w->mfma.d_dtab + (size_t)s * t.dtab.size(), t.dtab.data(), t.dtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(w->d_scales + s, &t.seq_scale, sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static csdr_amd_wfm *wfm_create_impl(csdr_amd_ctx *ctx, int n_streams, const float *rates, bool per_stream, int decimation, const float *host_taps,
+                                     int taps_length, int frac_rate, float tau, int audio_rate, size_t max_block_samples)
+{
+    const float shift_rate = rates ? rates[0] : 0.f;
+    if (n_streams <= 0 || decimation <= 0 || taps_length <= 0 || frac_rate <= 1 || !rates) { fail_msg(-3, "wfm: bad parameters"); return nullptr; }
     if (decimation * 1 + taps_length + 8 > HIST) { fail_msg(-3, "wfm: D + taps (%d + %d) exceed the %d-sample history", decimation, taps_length, HIST); return nullptr; }
     if (max_block_samples < 1024) max_block_samples = 1024;
     csdr_amd_wfm *w = new csdr_amd_wfm();
@@ -240,10 +257,12 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     w->d_demod = nullptr; w->d_rot = nullptr; w->d_hist = nullptr; w->d_head[0] = w->d_head[1] = nullptr; w->hflip = 0;
     w->use_mfma = false; w->d_ctab = nullptr; w->ctab_cap = 0; w->mfma.d_seq_frags = nullptr; w->mfma.d_seq_cum = nullptr; w->mfma.d_dtab = nullptr;
+    w->ps = per_stream; w->seeds = nullptr; w->d_scales = nullptr; w->d_dtab_old = nullptr; w->d_list = nullptr; w->d_lead_n = nullptr; w->d_lead_d = nullptr;
     {
         const char *force = getenv("CSDR_AMD_WFM_PATH");          // "valu" forces the VALU/LDS front end (A/B comparisons); read once, here
         w->use_mfma = !(force && !strcmp(force, "valu")) && wfm_mfma_supported(decimation, taps_length, frac_rate);
     }
+    if (per_stream && !w->use_mfma) { fail_msg(-3, "wfm_create_rates: a rate per stream needs the matrix-core chain kernel (decimation x audio decimation even, window <= 256 samples)"); delete w; return nullptr; }
     alloc((void **)&w->d_taps, sizeof(float) * taps_length);
     alloc((void **)&w->d_last[0], sizeof(float) * n_streams);
     alloc((void **)&w->d_last[1], sizeof(float) * n_streams);
@@ -258,7 +277,21 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     if (e != hipSuccess) { fail(e, "hipMalloc(wfm state)", __FILE__, __LINE__); csdr_amd_wfm_destroy(w); return nullptr; }
     (void)hipMemcpy(w->d_taps, host_taps, sizeof(float) * taps_length, hipMemcpyHostToDevice);
     w->kernel_name = "k_wfm_front";
-    if (w->use_mfma) {
+    if (w->use_mfma && per_stream) {
+        WfmMfmaTable t;
+        wfm_mfma_build_table(decimation, taps_length, frac_rate, shift_rate, host_taps, t);      // (sizes and geometry; the tables themselves per stream below)
+        w->mfma.tile_stride_bytes = t.tile_stride_bytes; w->mfma.win_off_bytes = t.win_off_bytes; w->mfma.seq_scale = t.seq_scale;
+        w->rates.assign(rates, rates + n_streams); w->h_taps.assign(host_taps, host_taps + taps_length);
+        hipError_t e2 = hipMalloc(&w->mfma.d_seq_frags, t.seq_frags.size() * (size_t)n_streams);
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_seq_cum, t.seq_cum.size() * sizeof(float) * (size_t)n_streams);
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->mfma.d_dtab, t.dtab.size() * sizeof(float2) * (size_t)n_streams);
+        if (e2 == hipSuccess) e2 = hipMalloc((void **)&w->d_scales, sizeof(float) * (size_t)n_streams);
+        if (e2 != hipSuccess) { fail(e2, "hipMalloc(wfm per-stream tables)", __FILE__, __LINE__); csdr_amd_wfm_destroy(w); return nullptr; }
+        for (int s = 0; s < n_streams; s++) if (wfm_upload_stream_tables(w, s, rates[s])) { csdr_amd_wfm_destroy(w); return nullptr; }
+        w->seeds = seeds_create(ctx, n_streams, rates, nullptr, 0, max_block_samples);
+        if (!w->seeds) { csdr_amd_wfm_destroy(w); return nullptr; }
+        w->kernel_name = "k_wfm_mfma_seq";
+    } else if (w->use_mfma) {
         WfmMfmaTable t;
         wfm_mfma_build_table(decimation, taps_length, frac_rate, shift_rate, host_taps, t);
         w->mfma.tile_stride_bytes = t.tile_stride_bytes; w->mfma.win_off_bytes = t.win_off_bytes; w->mfma.seq_scale = t.seq_scale;
@@ -278,10 +311,45 @@ csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_
     return w;
 }
 
+csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps,
+                                  int taps_length, int frac_rate, float tau, int audio_rate, size_t max_block_samples)
+{
+    return wfm_create_impl(ctx, n_streams, &shift_rate, false, decimation, host_taps, taps_length, frac_rate, tau, audio_rate, max_block_samples);
+}
+
+csdr_amd_wfm *csdr_amd_wfm_create_rates(csdr_amd_ctx *ctx, int n_streams, const float *shift_rates, int decimation, const float *host_taps,
+                                        int taps_length, int frac_rate, float tau, int audio_rate, size_t max_block_samples)
+{
+    return wfm_create_impl(ctx, n_streams, shift_rates, true, decimation, host_taps, taps_length, frac_rate, tau, audio_rate, max_block_samples);
+}
+
+// Retune of one stream between two calls = `csdr shift_addition_cc --fifo` (csdr.c:881-923): the new rate from the next block's first sample, the phase carried.
+int csdr_amd_wfm_set_rate(csdr_amd_wfm *w, int stream, float shift_rate)
+{
+    if (!w->ps) return fail_msg(-3, "wfm_set_rate: the object shares one rate (create it with csdr_amd_wfm_create_rates)");
+    if (stream < 0 || stream >= w->n_streams) return fail_msg(-3, "wfm_set_rate: stream %d out of range", stream);
+    if (w->rates[stream] == shift_rate) return 0;
+    CSDR_HIP(hipStreamSynchronize(w->ctx->stream));                   // calls in flight read this stream's tables
+    if (!w->d_dtab_old) CSDR_HIP(hipMalloc((void **)&w->d_dtab_old, sizeof(float2) * 3072 * (size_t)w->n_streams));
+    bool listed = false;
+    for (int v : w->retuned) listed |= v == stream;
+    if (!listed) {
+        CSDR_HIP(hipMemcpy(w->d_dtab_old + (size_t)stream * 3072, w->mfma.d_dtab + (size_t)stream * 3072, sizeof(float2) * 3072, hipMemcpyDeviceToDevice));
+        w->retuned.push_back(stream);
+    }
+    const int rc = wfm_upload_stream_tables(w, stream, shift_rate); if (rc) return rc;
+    w->rates[stream] = shift_rate;
+    return seeds_set_rate(w->seeds, stream, shift_rate, false);
+}
+
+float csdr_amd_wfm_get_rate(const csdr_amd_wfm *w, int stream) { return w->ps ? ((stream >= 0 && stream < w->n_streams) ? w->rates[stream] : 0.f) : w->shift_rate; }
+
 void csdr_amd_wfm_destroy(csdr_amd_wfm *w)
 {
     if (!w) return;
     (void)hipStreamSynchronize(w->ctx->stream);
+    if (w->seeds) seeds_destroy(w->seeds);
+    (void)hipFree(w->d_scales); (void)hipFree(w->d_dtab_old); (void)hipFree(w->d_lead_n); (void)hipFree(w->d_lead_d);      // (d_list lives inside d_lead_n)
     (void)hipFree(w->d_taps); (void)hipFree(w->d_demod); (void)hipFree(w->d_last[0]); (void)hipFree(w->d_last[1]);
     (void)hipFree(w->d_rot); (void)hipFree(w->d_hist); (void)hipFree(w->d_head[0]); (void)hipFree(w->d_head[1]);
     for (auto &pr : w->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -301,6 +369,8 @@ int csdr_amd_wfm_reset(csdr_amd_wfm *w)
     w->hflip = 0;
     w->B = 0; w->next_j = 0; w->last_T = 0; w->flip = 0; w->ended = false;
     w->c_prev = make_float2(1.f, 0.f); w->tab_valid = false; w->tab_first = 0;
+    w->retuned.clear();
+    if (w->seeds) { const int rc = seeds_reset(w->seeds); if (rc) return rc; }
     return 0;
 }
 
@@ -337,6 +407,12 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
     const int T = (int)block_samples;
     int rc = 0;
     const float2 *ctab_call = nullptr;
+    SeedView sv; memset(&sv, 0, sizeof sv);
+    if (w->ps) {
+        const size_t nch = ((size_t)T + 1023) / 1024;
+        rc = seeds_acquire(w->seeds, w->B / 1024 - 1, nch + 3, (T % 1024) ? 0 : nch, &sv); if (rc) return rc;
+        ctab_call = sv.ctab;
+    } else
     if (w->use_mfma) {
         // 1a. per-chunk phasor seeds C_m = (cos, sin)(starting_phase_m) with the reference's float phase bookkeeping (libcsdr_gpl.c:33-34, 48-51; chunks
         //     of 1024 per csdr.c:911-918).  The sequence depends on nothing but the shift rate, so the device holds a TABLE of it that runs far ahead of the
@@ -403,8 +479,34 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
         WfmBackArgs back;
         back.alpha = w->alpha; back.last_in = w->d_last[w->flip]; back.last_out = w->d_last[w->flip ^ 1];
         back.s16 = audio_s16; back.af = audio_f; back.out_pitch = out_pitch; back.head_in = w->d_head[w->hflip]; back.head_out = w->d_head[w->hflip ^ 1];
-        rc = wfm_mfma_launch(st, e0, e1, in, in_pitch, w->mfma, ctab_call, w->n_streams, T, w->B, w->next_j, n_audio, back);
+        WfmPerStream psa; memset(&psa, 0, sizeof psa);
+        if (w->ps) {
+            psa.tab_pitch = sv.pitch; psa.tab_len = sv.n_entries; psa.d_scales = w->d_scales;
+            // retuned streams: the audio samples whose windows start in front of the block (D (F j + 9) < B) straddle two rates
+            long n_lead = 0;
+            if (!w->retuned.empty() && n_audio > 0) {
+                const long long lim = w->B - 1 - 9LL * w->D;
+                if (lim >= 0) n_lead = (long)(lim / ((long long)w->D * w->F) - w->next_j + 1);
+                if (n_lead < 0) n_lead = 0;
+                if (n_lead > 4) n_lead = 4;
+                if (n_lead > n_audio) n_lead = n_audio;
+            }
+            if (n_lead > 0) {
+                const int nr = (int)w->retuned.size(), S = w->n_streams;
+                if (!w->d_lead_n) { CSDR_HIP(hipMalloc((void **)&w->d_lead_n, sizeof(int) * 2 * S)); w->d_list = w->d_lead_n + S; CSDR_HIP(hipMalloc((void **)&w->d_lead_d, sizeof(float) * 4 * S)); }
+                int *hl = (int *)c->pinned_acquire(sizeof(int) * (size_t)(S + nr)); if (!hl) return -2;      // [S] samples per stream, then the list: one upload
+                for (int s = 0; s < S; s++) hl[s] = 0;
+                for (int k = 0; k < nr; k++) { hl[w->retuned[k]] = (int)n_lead; hl[S + k] = w->retuned[k]; }
+                rc = c->pinned_upload(w->d_lead_n, sizeof(int) * (size_t)(S + nr)); if (rc) return rc;
+                rc = wfm_mfma_lead(st, in, in_pitch, back.head_in, w->d_taps, sv.ctab, sv.pitch, w->mfma.d_dtab, w->d_dtab_old, w->d_list, nr, w->d_lead_d,
+                                   w->D, w->L, w->F, w->B, w->next_j, (int)n_lead);
+                if (rc) return rc;
+                psa.d_lead_d = w->d_lead_d; psa.d_lead_n = w->d_lead_n;
+            }
+        }
+        rc = wfm_mfma_launch(st, e0, e1, in, in_pitch, w->mfma, ctab_call, w->n_streams, T, w->B, w->next_j, n_audio, back, w->ps ? &psa : nullptr);
         if (rc) return rc;
+        if (n_audio > 0) w->retuned.clear();
         w->hflip ^= 1;
         if (n_audio > 0) w->flip ^= 1;
     } else {

@@ -32,6 +32,7 @@
 #include "wfm_mfma.hpp"
 #include <hip/hip_ext.h>
 #include <math.h>
+#include <string.h>
 #include <stdlib.h>
 #include <complex>
 #include <vector>
@@ -195,6 +196,12 @@ struct SeqParams {
     long long two_T;                                                                  // bytes per stream of this block
     float alpha; const float *last_in; float *last_out; int16_t *s16; float *af; size_t out_pitch; long long j_first; int n_audio;
     const uint8_t *head_in; uint8_t *head_out;
+    // PS (a shift rate per stream, csdr_amd_wfm_create_rates): one workgroup = ONE stream x 16 time segments ("columns", tiles_per_seg tiles each, a whole number
+    // of 1024-chunks and of output lines apart), see k_wfm_mfma_seq
+    long long col_bytes; int col_chunks, col_audio, n_cols;      // input bytes / chunks / audio samples between column starts; columns of the call
+    size_t frag_stride, tab_pitch; int tab_len;                   // v4i per stream in `frags`; streams per chunk row of the seed table; its rows from the call's first chunk on
+    const float *scales;
+    const float *lead_d; const int *lead_n;                       // retuned streams: lead_n[stream] audio samples at the call's start come from lead_d[stream * 4 + i]
 };
 
 #ifndef SEQ_RB_KIB
@@ -236,6 +243,13 @@ __device__ unsigned long long g_wfm_prof[SEQ_NW][8];
 #define PROF_T(k)
 #endif
 
+// PS: the weights a h D^t belong to one stream, so the 16 columns of the B operand are 16 TIME SEGMENTS of that stream (ddc_mfma.hip has the same arrangement and the
+// reasoning): column starts a whole number of tiles, chunks and 64-sample output lines apart, so that the chunk-boundary variant, D^e and the line bookkeeping stay
+// the workgroup's; per column only the chunk seeds differ.  A step's six windows touch three consecutive chunks: compute wave 1 -- no wave of this kernel but
+// the loaders issues other vector memory operations -- brings the 3 x 16 seeds of a step into an LDS table two steps ahead (inline-asm loads, one step in flight:
+// a vector load queues behind the CU's LDS-DMA pieces for ~3000 cycles).  Every column but the call's first warms its de-emphasis up over two steps like a
+// segment of the shared-rate kernel; columns behind the block's end re-read column 0 and store nothing.
+template <bool PS>
 __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags, const float *__restrict__ cum,
                                                                const float2 *__restrict__ dtab, const float2 *__restrict__ ctab, SeqParams p)
 {
@@ -244,16 +258,20 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
     float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 16 x SEQ_OUTP floats
     float *lcum = lds_out + 16 * SEQ_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
+    float2 *ctl = reinterpret_cast<float2 *>(lcum + (SEQ_NGR + 1) * 16);          // PS: [2][3][16] chunk seeds of a step (class, column)
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     const bool fetches = wv >= TPG;
     const int fw = wv - TPG;                                                         // index among the fetching waves
+    const int sb = blockIdx.x;                                                       // block of 16 streams; PS: the stream
+    const int col0 = PS ? 16 * (int)blockIdx.y : 0;                                  // PS: absolute index of the workgroup's first column
+    float scale = p.scale;
+    if constexpr (PS) { frags += (size_t)sb * p.frag_stride; cum += (size_t)sb * ((SEQ_NGR + 1) * 16); dtab += (size_t)sb * 3072; ctab += sb; scale = p.scales[sb]; }
     for (int i = tid; i < (SEQ_NGR + 1) * 16; i += NTHR) lcum[i] = cum[i];
-    const int sb = blockIdx.x;
-    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg;
+    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg * (PS ? 16 : 1);      // PS: column 0's first tile
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
     if (t0 >= t1) return;
     const int n_it = (int)(t1 - t0), n_grp = (n_it + TPG - 1) / TPG;
-    const int n_warm = blockIdx.y > 0 ? 2 : 0;                                       // steps demodulated ahead of the segment to warm the de-emphasis up
+    const int n_warm = (PS || blockIdx.y > 0) ? 2 : 0;                               // steps demodulated ahead of the segment to warm the de-emphasis up
     const int last_stream = p.n_streams - 1;
     v4i A[WFM_NK * 3];
 #pragma unroll
@@ -267,24 +285,60 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     const float K = 0.340447550238101026565118445432744920253753662109375f;
     // ---- DMA ring.  Positions are bytes from the block start; they start at -1024 (the head), hence the + 2 SEQ_RB in the slot arithmetic
     const int tstride = p.stride;
-    long long wg = (t0 - (long long)n_warm * TPG) * tstride + p.win_off - p.B2;      // window start of the step's first tile
+    const long long org = PS ? (long long)col0 * p.col_bytes : 0LL;                  // PS: positions are counted from the start of the workgroup's column 0
+    long long wg = (t0 - (long long)n_warm * TPG) * tstride + p.win_off - p.B2 - org; // window start of the step's first tile
     const long long F0 = wg & ~1023LL;                                               // (floor, also for negative positions)
-    long long F_end = ((t1 - 1) * tstride + p.win_off - p.B2 + 64 * WFM_NK + 1023) & ~1023LL;
-    { const long long row_end = (p.two_T + 1023) & ~1023LL; if (F_end > row_end) F_end = row_end; }      // a partial last tile's window reaches beyond the block: those bytes feed no stored sample
+    long long F_end = ((t1 - 1) * tstride + p.win_off - p.B2 - org + 64 * WFM_NK + 1023) & ~1023LL;
+    { const long long row_end = ((p.two_T + 1023) & ~1023LL) - org; if (F_end > row_end) F_end = row_end; }      // a partial last tile's window reaches beyond the block: those bytes feed no stored sample
     long long F = F0;
     int fslot = (int)((F0 + 2 * SEQ_RB) % SEQ_RB), wslot = (int)((wg + 2 * SEQ_RB) % SEQ_RB);      // ring positions of F and of wg (wg already includes the warm-up steps)
     const uint32_t lds_in_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)lds_in;
     uint32_t voff[SPW], voff_h[SPW];
+    long long row_lim[SPW];                                                          // PS: bytes of the block from the row's column start on (wave uniform)
 #pragma unroll
     for (int r = 0; r < SPW; r++) {
-        const int srow = max(min(sb * 16 + SPW * fw + r, last_stream) - sb * 16, 0);
-        voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
-        voff_h[r] = (uint32_t)srow * (uint32_t)SEQ_HEAD + 16u * lane;
+        if constexpr (PS) {
+            voff[r] = (uint32_t)((long long)(SPW * fw + r) * p.col_bytes) + 16u * lane;      // relative to the workgroup's column 0
+            voff_h[r] = 16u * lane;
+            row_lim[r] = p.two_T - (long long)(col0 + SPW * fw + r) * p.col_bytes;
+        } else {
+            const int srow = max(min(sb * 16 + SPW * fw + r, last_stream) - sb * 16, 0);
+            voff[r] = (uint32_t)srow * (uint32_t)in_pitch + 16u * lane;
+            voff_h[r] = (uint32_t)srow * (uint32_t)SEQ_HEAD + 16u * lane;
+            row_lim[r] = 0;
+        }
     }
-    const uint8_t *sblock = in + (long long)sb * 16 * (long long)in_pitch;
-    const uint8_t *hblock = p.head_in + (size_t)sb * 16 * SEQ_HEAD;
+    const uint8_t *sblock = PS ? in + (long long)sb * (long long)in_pitch + org : in + (long long)sb * 16 * (long long)in_pitch;
+    const uint8_t *hblock = PS ? p.head_in + (size_t)sb * SEQ_HEAD : p.head_in + (size_t)sb * 16 * SEQ_HEAD;
     const bool ragged = (p.two_T & 1023) != 0;                                       // only a stream's last block
     auto row_step = [&]() {
+        if constexpr (PS) {
+            // positions are column 0's, counted from its start; the other rows read the same position of their own columns (inside the block also for F < 0).  In
+            // front of the call's very first column lies the head (1 KiB; further back -- the warm-up steps of that column, whose audio is replaced by the carried
+            // state -- any readable bytes do); rows behind the block's end re-read column 0; a ragged end is masked at the row's last 16-byte piece.
+            const uint32_t ldst = lds_in_addr + (SPW * fw) * SEQ_RP + (uint32_t)fslot;
+            const bool head = F < 0 && col0 == 0;                                    // wave uniform
+            bool plain = !head && !ragged;
+#pragma unroll
+            for (int r = 0; r < SPW; r++) plain = plain && F + 1024 <= row_lim[r];
+            if (plain) dma_rows<SPW, SEQ_RP>(voff, sblock + F, __builtin_amdgcn_readfirstlane((int)ldst));      // the common case
+            else
+#pragma unroll
+            for (int r = 0; r < SPW; r++) {
+                const bool hrow = head && (SPW * fw + r == 0 || F + 1024 > row_lim[r]);
+                const bool beyond = !hrow && F >= row_lim[r];                        // nothing of this run lies inside the block: column 0's bytes again
+                const uint8_t *sbase = hrow ? hblock : sblock + F;
+                const uint32_t vo = hrow ? voff_h[r] : (beyond ? 16u * lane : voff[r]);
+                const bool live = hrow || F + 16 * lane < (beyond ? p.two_T - org : row_lim[r]);      // (a run cut by the block's end: whole 16-byte pieces inside only; F < F_end: lane 0 is always live)
+                const uint32_t la = __builtin_amdgcn_readfirstlane((int)(ldst + r * SEQ_RP));
+                uint32_t keep;
+                if (live)
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(la) : "memory");
+            }
+            F += 1024; fslot += 1024; if (fslot >= SEQ_RB) fslot -= SEQ_RB;
+            return;
+        }
         const bool head = F < 0;                                                     // wave uniform: the run [-1024, 0)
         const uint8_t *sbase = head ? hblock : sblock + F;
         const uint32_t ldst = lds_in_addr + (SPW * fw) * SEQ_RP + (uint32_t)fslot;
@@ -325,6 +379,30 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         if (newer > 7) newer = 7;
         wait_newer(newer);
     };
+    // PS: chunk seeds of a step (window start of its first tile: wgs): class k = 0 .. 2 <-> chunk (that of the step's first window) + k, of every column; lanes 0 .. 47
+    // of compute wave 1.  Loaded one step ahead of their write into the table half the step two ahead will read (see the kernel's comment; ddc_mfma.hip's ps_load).
+    typedef float ps_v2f __attribute__((ext_vector_type(2)));
+    ps_v2f psC = {1.f, 0.f};
+    const bool ps_wave = PS && wv == 1, ps_lane = ps_wave && lane < 48;
+    auto ps_base = [&](long long wgs) { return (int)((((wgs + p.B2) >> 1) >> 10) - (p.B2 >> 11)); };      // chunk of a step's first window, relative to the block's first chunk + column 0's
+    auto ps_load = [&](long long wgs) {
+        if (ps_lane) {
+            int ci = ps_base(wgs) + 1 + (lane >> 4) + (col0 + (lane & 15)) * p.col_chunks;
+            ci = min(max(ci, 0), p.tab_len - 1);                                     // (in front of the history chunk; columns behind the block's end, steps behind the last)
+            const float2 *pc = ctab + (size_t)ci * p.tab_pitch;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(psC) : "v"(pc) : "memory");
+        }
+    };
+    auto ps_store = [&](int g) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(psC) :: "memory");
+        if (ps_lane) ctl[((g + 2) & 1) * 48 + lane] = make_float2(psC.x, psC.y);     // (g >= -2: the parity of g + 2)
+    };
+    if (ps_wave) {
+        const long long step_b = (long long)TPG * tstride;
+        ps_load(wg); ps_store(-n_warm);
+        ps_load(wg + step_b); ps_store(-n_warm + 1);
+        ps_load(wg + 2 * step_b);                                                    // in flight: the third step
+    }
     if (fetches) {
         while (F < F_end && F + 1024 <= wg + SEQ_RB) row_step();
         wait_for(wg + (long long)(TPG - 1) * tstride);
@@ -345,14 +423,19 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
 #pragma unroll
     for (int j = 1; j <= QL; j++) bp[j] = bp[j - 1] * one_minus;
     const float b2q = bp[QL] * bp[QL], b3q = b2q * bp[QL];
+    float yst_first = 0.f;                                                           // PS: the call's first column starts from the carried state at step 0 (its warm-up steps ran on whatever lay in front)
     if (iir_wave && blockIdx.y == 0) {                                               // first segment: the exact carried state (NaN reset as libcsdr.c:1092)
-        yst = p.last_in[min(s0 + col, last_stream)]; if (yst != yst) yst = 0.f;
+        yst = p.last_in[PS ? sb : min(s0 + col, last_stream)]; if (yst != yst) yst = 0.f;
+        yst_first = yst;
     }
     // the segment's audio samples, counted from its first tile's first sample (ints: this bookkeeping runs every step, on wave 0 between two barriers)
     const long long j_end = p.j_first + p.n_audio;
     const int seg_lo = (int)max(0LL, p.j_first - 4 * t0);                           // > 0 only in the call's first segment, when j_first is not a multiple of 4
     const int seg_hi = (int)min(4LL * n_it, j_end - 4 * t0);                        // samples of the segment that exist in this call
     const long long idx0 = 4 * t0 - p.j_first;                                      // output index of the segment's sample 0
+    // PS: the same per column (segment of column c = tiles t0 + c tiles_per_seg ...): only the call's first column can start late, only its last one ends early
+    auto col_lo = [&](int c) { return PS ? (col0 + c == 0 ? seg_lo : 0) : seg_lo; };
+    auto col_hi = [&](int c) { return PS ? (int)max(0LL, min(4LL * n_it, j_end - 4 * (t0 + (long long)c * p.tiles_per_seg))) : seg_hi; };
     // ---- Stores (convert_f_s16, libcsdr.c:2397, x86 truncation semantics).  Usual case (16-byte aligned rows; emit_vec): the LOADER waves take the audio out of the
     // staging ring, one step after the de-emphasis, in whole 128-byte LINES of the s16 output row (64 samples, 8 lanes x 16 bytes; lines of the OUTPUT row, whatever the
     // call's first sample is: after step g the line whose last sample lies in step g is complete -- the same step for all 16 streams; it may start up to 63 samples
@@ -371,11 +454,13 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         for (int e0 = 0; e0 < 16 * SPS; e0 += EMIT_N) {
             const int ei = e0 + tid - EMIT_T0;
             const int srow = ei / SPS, k = ei % SPS, kr = g * SPS + k;
-            if (ei >= 16 * SPS || kr < seg_lo || kr >= seg_hi || s0 + srow >= p.n_streams) continue;
+            if (ei >= 16 * SPS) continue;
+            if (PS ? (kr < col_lo(srow) || kr >= col_hi(srow)) : (kr < seg_lo || kr >= seg_hi || s0 + srow >= p.n_streams)) continue;
             const float e = lds_out[srow * SEQ_OUTP + (g % SEQ_OUTS) * SPS + k];
             const long long idx = idx0 + kr;
-            p.s16[(size_t)(s0 + srow) * p.out_pitch + idx] = (int16_t)s16_of(e);
-            if (p.af) p.af[(size_t)(s0 + srow) * p.out_pitch + idx] = e;
+            const size_t at = PS ? (size_t)sb * p.out_pitch + (size_t)srow * p.col_audio + idx : (size_t)(s0 + srow) * p.out_pitch + idx;      // (idx0 is column 0's)
+            p.s16[at] = (int16_t)s16_of(e);
+            if (p.af) p.af[at] = e;
         }
     };
 #ifdef WFM_PROF
@@ -393,12 +478,24 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
 #undef X
         int n_st = 0, st_n0 = 0;                                                     // lines held, first sample of the first one (wave uniform)
         const int srow = 8 * fw + (lane >> 3), pc = lane & 7;                        // this lane: stream row of the workgroup, 16-byte piece of a line
-        const bool row_ok = s0 + srow < p.n_streams;
-        int16_t *const orow = p.s16 + (size_t)(s0 + srow) * p.out_pitch;
+        // PS: this lane's row is a COLUMN of the stream: its own valid range [lo_r, hi_r) (the uniform decisions below use column 0's, the widest) and output offset
+        const int lo_r = col_lo(srow), hi_r = col_hi(srow);
+        const bool row_ok = PS ? hi_r > lo_r : s0 + srow < p.n_streams;
+        const size_t row_at = PS ? (size_t)sb * p.out_pitch + (size_t)srow * p.col_audio : (size_t)(s0 + srow) * p.out_pitch;      // (idx0 is column 0's)
+        int16_t *const orow = p.s16 + row_at;
         auto flush = [&]() __attribute__((always_inline)) {
-#define X(j) if (j < n_st && row_ok) *reinterpret_cast<uint4 *>(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);
-            WFM_ST_ALL(X)
+            if constexpr (PS) {
+                // a held line is whole for column 0; for the call's last column it may be cut, for columns behind the block's end it does not exist
+#define X(j) if (j < n_st && row_ok) { const int a = st_n0 + SEQ_LINE * j + 8 * pc;                                                             \
+                 if (a + 8 <= hi_r) *reinterpret_cast<uint4 *>(orow + (idx0 + a)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);        \
+                 else for (int i = 0; i < 8; i++) if (a + i < hi_r) orow[idx0 + a + i] = (int16_t)(st##j[i >> 1] >> (16 * (i & 1))); }
+                WFM_ST_ALL(X)
 #undef X
+            } else {
+#define X(j) if (j < n_st && row_ok) *reinterpret_cast<uint4 *>(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);
+                WFM_ST_ALL(X)
+#undef X
+            }
             n_st = 0;
         };
         auto take_line = [&](int g) __attribute__((always_inline)) {                                              // g = n_grp: the segment's last, incomplete line
@@ -426,14 +523,14 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 if (++n_st == NST) flush();
             } else if (row_ok) {
                 const size_t o = (size_t)(idx0 + n0);                                // (may wrap below zero in front of a cut line's first valid sample: never dereferenced there)
-                float *const arow = p.af ? p.af + (size_t)(s0 + srow) * p.out_pitch : nullptr;
-                if (n0 >= seg_lo && n0 + 8 <= seg_hi) {
+                float *const arow = p.af ? p.af + row_at : nullptr;
+                if (n0 >= lo_r && n0 + 8 <= hi_r) {
                     *reinterpret_cast<uint4 *>(orow + o) = make_uint4(w[0], w[1], w[2], w[3]);
                     if (arow) { *reinterpret_cast<float4 *>(arow + o) = make_float4(e[0], e[1], e[2], e[3]); *reinterpret_cast<float4 *>(arow + o + 4) = make_float4(e[4], e[5], e[6], e[7]); }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; i++)
-                        if (n0 + i >= seg_lo && n0 + i < seg_hi) { orow[o + i] = (int16_t)v[i]; if (arow) arow[o + i] = e[i]; }
+                        if (n0 + i >= lo_r && n0 + i < hi_r) { orow[o + i] = (int16_t)v[i]; if (arow) arow[o + i] = e[i]; }
                 }
             }
         };
@@ -500,12 +597,14 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 default: wfm_chain<WFM_NK>(A, Bf, lo_lane, acc, snap); break;
             }
             // ---- post factors and offset constants of the window's part(s)
-            const float2 C0 = ctab[chunk_rel + 1], D0 = dtab[off + 2048];
+            const int kcls = PS ? (int)chunk_rel - ps_base(wg) : 0;                   // PS: the window's chunk class in the step's seed table (0 .. 2; its second chunk: the next)
+            const float2 *ct = ctl + ((gi + 2) & 1) * 48 + kcls * 16 + col;
+            const float2 C0 = PS ? ct[0] : ctab[chunk_rel + 1], D0 = dtab[off + 2048];
             const float2 P0 = make_float2(C0.x * D0.x - C0.y * D0.y, C0.x * D0.y + C0.y * D0.x);
             float2 P1 = make_float2(0.f, 0.f);
             float k0[4], k1[4];
             if (two) {
-                const float2 C1 = ctab[chunk_rel + 2], D1 = dtab[off - 1024 + 2048];
+                const float2 C1 = PS ? ct[16] : ctab[chunk_rel + 2], D1 = dtab[off - 1024 + 2048];
                 P1 = make_float2(C1.x * D1.x - C1.y * D1.y, C1.x * D1.y + C1.y * D1.x);
                 const float4 cb = *reinterpret_cast<const float4 *>(lcum + (bo >> 4) * 16 + 4 * q);
                 k0[0] = cb.x - c_lo[0]; k0[1] = cb.y - c_lo[1]; k0[2] = cb.z - c_lo[2]; k0[3] = cb.w - c_lo[3];
@@ -515,23 +614,33 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 for (int r = 0; r < 4; r++) { k0[r] = c_hi[r] - c_lo[r]; k1[r] = 0.f; }
             }
             float pI, pQ, cI, cQ;
-            tile_rows(acc, snap, two, p.scale, k0, k1, P0, P1, pI, pQ, cI, cQ);
+            tile_rows(acc, snap, two, scale, k0, k1, P0, P1, pI, pQ, cI, cQ);
             const float dq = cQ - pQ, di = cI - pI;                                  // fmdemod_quadri_cf (libcsdr.c:1040-1071) on (previous = y[Fj+9], current = y[Fj+10])
             const float num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
             float rd = __builtin_amdgcn_rcpf(den);
             rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
-            lout[col * SEQ_OUTP + 4 * wv + q] = (den != 0.f) ? (K * num) * rd : 0.f;   // audio 4 * tile + q of stream col
+            float dval = (den != 0.f) ? (K * num) * rd : 0.f;
+            if constexpr (PS) {
+                // a retuned stream's first samples of the call: their windows reach into bytes that were rotated at the OLD rate -- evaluated with both tables
+                // by k_wfm_lead in front of this kernel
+                const long long ja = 4 * (t0 + it) + q - p.j_first;                  // this audio sample's index in the call (column 0)
+                if (p.lead_n && col0 + col == 0 && ja >= 0 && ja < p.lead_n[sb]) dval = p.lead_d[(size_t)sb * 4 + ja];
+            }
+            lout[col * SEQ_OUTP + 4 * wv + q] = dval;                                 // audio 4 * tile + q of stream col
         }
         PROF_T(0)
         const long long wg_n = wg + (long long)TPG * tstride;
         __syncthreads();
         PROF_T(2)
         if (!emit_vec) emit_scalar(gi - 1);                                                                // the previous step's audio: filtered by wave 0 before it came to this barrier
+        if (ps_wave) { ps_store(gi + 2); ps_load(wg + 3LL * TPG * tstride); }        // step gi + 2's seeds into the half step gi has finished with; in flight: step gi + 3
         PROF_T(4)
         if (iir_wave && WFM_DIAG < 5) {                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
-            const int lo = gi == 0 ? seg_lo : 0;                                     // samples [lo, hi) of the step exist in this call (warm-up steps: all)
-            const int hi = gi < 0 ? SPS : min(SPS, seg_hi - gi * SPS);
-            if (lo == 0 && (hi & 3) == 0) {
+            // (PS: per column -- lane col -- ; the scan runs when every column's range allows it)
+            if (PS && gi == 0 && col0 + col == 0) yst = yst_first;                   // the call's first column: the carried state instead of its warm-up's
+            const int lo = gi == 0 ? col_lo(col) : 0;                                // samples [lo, hi) of the step exist in this call (warm-up steps: all)
+            const int hi = gi < 0 ? SPS : max(0, min(SPS, col_hi(col) - gi * SPS));
+            if (PS ? __all(lo == 0 && (hi & 3) == 0) : (lo == 0 && (hi & 3) == 0)) {
                 float *row = lout + col * SEQ_OUTP + QL * q;                         // this lane's quarter: samples QL q .. QL q + QL - 1
                 const int nv = hi;                                                   // valid samples of the step (a multiple of 4 here; all except in a segment's last step)
                 float x[QL], z[QL], y[QL];
@@ -583,7 +692,14 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     __syncthreads();
     if (!emit_vec) emit_scalar(n_grp - 1);
     }
-    if (blockIdx.y + 1 == gridDim.y) {                                               // the call's last segment: what the next call starts from
+    if (PS && blockIdx.y + 1 == gridDim.y) {                                         // the workgroup that holds the call's last column
+        if (iir_lane && col0 + lane == p.n_cols - 1) p.last_out[sb] = yst;
+        if (tid < 32 && p.two_T >= 512 && (p.two_T & 15) == 0) {                     // the block's newest 512 bytes -> bytes 512.. of the other head buffer
+            const uint4 v = *reinterpret_cast<const uint4 *>(in + (size_t)sb * in_pitch + (p.two_T - 512) + 16 * tid);
+            *reinterpret_cast<uint4 *>(p.head_out + (size_t)sb * SEQ_HEAD + 512 + 16 * tid) = v;
+        }
+    } else
+    if (!PS && blockIdx.y + 1 == gridDim.y) {                                        // the call's last segment: what the next call starts from
         if (iir_lane && s0 + lane < p.n_streams) p.last_out[s0 + lane] = yst;
         // the block's newest 512 bytes -> bytes 512.. of the other head buffer (16 streams x 32 pieces of 16 bytes)
         if (tid < 16 * 32 && p.two_T >= 512 && (p.two_T & 15) == 0 && s0 + tid / 32 < p.n_streams) {
@@ -604,14 +720,63 @@ __global__ __launch_bounds__(256) void k_wfm_roll_head(const uint8_t *__restrict
     }
 }
 
+// Retuned streams (csdr_amd_wfm_set_rate): the call's first audio samples have windows that reach into bytes in front of the block, rotated at the OLD rate
+// (shift_addition_cc --fifo picks a new rate up between two reads, csdr.c:881-923).  Those samples -- at most four -- are evaluated here with both tables, one
+// wave per (listed stream, sample, which of y[Fj+9] / y[Fj+10]): the chain kernel takes the demodulated value from lead_d.  Seeds: row 0 of the stream's table =
+// the chunk in front of the block.
+struct LeadParams { int D, L, F; long long B, j_first; int n_lead; size_t tab_pitch, dtab_stride; };
+__global__ __launch_bounds__(128) void k_wfm_lead(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ head, const float *__restrict__ taps,
+                                                 const float2 *__restrict__ ctab, const float2 *__restrict__ dtab, const float2 *__restrict__ dtab_old,
+                                                 const int *__restrict__ list, float *__restrict__ lead_d, LeadParams p)
+{
+    __shared__ float2 yv[2];
+    const int s = list[blockIdx.y], ja = blockIdx.x, which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long j = p.j_first + ja, k = (long long)p.F * j + 9 + which;
+    const uint8_t *row = in + (size_t)s * in_pitch, *hrow = head + (size_t)s * SEQ_HEAD + 512;      // the head's second half: the 256 samples in front of the block
+    const float2 *ct = ctab + s, *dn = dtab + (size_t)s * p.dtab_stride, *dold = dtab_old + (size_t)s * p.dtab_stride;
+    const long long c0 = p.B >> 10;
+    float ai = 0.f, aq = 0.f;
+    for (int t = lane; t < p.L; t += 64) {
+        const long long n = (long long)p.D * k + t, rel = n - p.B;
+        uint32_t vi, vq;
+        if (rel < 0) { vi = hrow[2 * (rel + 256)]; vq = hrow[2 * (rel + 256) + 1]; } else { vi = row[2 * rel]; vq = row[2 * rel + 1]; }
+        const float2 C = ct[(size_t)((n >> 10) - c0 + 1) * p.tab_pitch], Dv = (rel < 0 ? dold : dn)[(int)(n & 1023) + 2048];
+        const float2 R = make_float2(C.x * Dv.x - C.y * Dv.y, C.x * Dv.y + C.y * Dv.x);
+        const float xi = fmaf((float)vi, 0x1.010102p-7f, -1.0f), xq = fmaf((float)vq, 0x1.010102p-7f, -1.0f);      // v / 127.5 - 1
+        const float h = taps[t];
+        ai = fmaf(h, xi * R.x - xq * R.y, ai); aq = fmaf(h, xq * R.x + xi * R.y, aq);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ai += __shfl_xor(ai, o, 64); aq += __shfl_xor(aq, o, 64); }
+    if (lane == 0) yv[which] = make_float2(ai, aq);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float K = 0.340447550238101026565118445432744920253753662109375f;
+        const float pI = yv[0].x, pQ = yv[0].y, cI = yv[1].x, cQ = yv[1].y;
+        const float dq = cQ - pQ, di = cI - pI, num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
+        float rd = __builtin_amdgcn_rcpf(den); rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
+        lead_d[(size_t)s * 4 + ja] = (den != 0.f) ? (K * num) * rd : 0.f;
+    }
+}
+
 } // namespace
 
 namespace csdr_amd {
 
 size_t wfm_mfma_head_bytes(int n_streams) { return (size_t)((n_streams + 15) / 16 * 16) * SEQ_HEAD; }
 
+int wfm_mfma_lead(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *head, const float *d_taps, const float2 *ctab, size_t tab_pitch, const float2 *d_dtab,
+                  const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int D, int L, int F, long long B, long long j_first, int n_lead)
+{
+    if (n_list <= 0 || n_lead <= 0) return 0;
+    LeadParams lp; lp.D = D; lp.L = L; lp.F = F; lp.B = B; lp.j_first = j_first; lp.n_lead = n_lead; lp.tab_pitch = tab_pitch; lp.dtab_stride = 3072;
+    hipLaunchKernelGGL(k_wfm_lead, dim3(n_lead, n_list), dim3(128), 0, st, in, in_pitch, head, d_taps, ctab, d_dtab, d_dtab_old, d_list, d_lead_d, lp);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
 int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const WfmMfmaDevice &dev, const float2 *ctab,
-                    int n_streams, int T, long long B, long long j_first, int n_audio, const WfmBackArgs &back)
+                    int n_streams, int T, long long B, long long j_first, int n_audio, const WfmBackArgs &back, const WfmPerStream *ps)
 {
     if (in_pitch * 16 + 4096 >= ((size_t)1 << 32)) return fail_msg(-3, "wfm: in_pitch %zu too large for the matrix-core front end (32-bit row offsets)", in_pitch);
     if (n_audio <= 0) {
@@ -620,6 +785,7 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
         return 0;
     }
     SeqParams sp;
+    memset((void *)&sp, 0, sizeof sp);
     sp.n_streams = n_streams; sp.B2 = 2 * B; sp.two_T = 2LL * T;
     sp.tile_first = j_first / 4; sp.n_tiles = (int)((j_first + n_audio - 1) / 4 - sp.tile_first + 1);
     sp.stride = dev.tile_stride_bytes; sp.win_off = dev.win_off_bytes; sp.scale = dev.seq_scale;
@@ -634,14 +800,44 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
     n_seg = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
     sp.alpha = back.alpha; sp.last_in = back.last_in; sp.last_out = back.last_out; sp.s16 = back.s16; sp.af = back.af; sp.out_pitch = back.out_pitch;
     sp.j_first = j_first; sp.n_audio = n_audio; sp.head_in = back.head_in; sp.head_out = back.head_out;
+    if (ps) {
+        // a rate per stream: grid = streams x groups of 16 columns; a column = a whole number of periods (lcm of the tile stride, a 1024-chunk and a 64-sample
+        // output line), about four workgroups per CU at most
+        const long long ts = sp.stride / 2;                                         // samples per tile (4 audio samples)
+        long long per = ts; { long long a = per, b = 1024; while (b) { const long long t = a % b; a = b; b = t; } per = per / a * 1024; }
+        int tpp = (int)(per / ts);                                                  // tiles per period
+        while ((4 * tpp) % SEQ_LINE) tpp *= 2;
+        const int n_per = (sp.n_tiles + tpp - 1) / tpp;
+        int n_ss = (4 * n_cu + n_streams - 1) / n_streams; if (n_ss < 1) n_ss = 1;
+        int np = (n_per + 16 * n_ss - 1) / (16 * n_ss); if (np < 1) np = 1;
+        sp.tiles_per_seg = np * tpp;
+        sp.n_cols = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
+        n_seg = (sp.n_cols + 15) / 16;
+        sp.col_bytes = (long long)sp.tiles_per_seg * sp.stride; sp.col_chunks = (int)(sp.col_bytes / 2048); sp.col_audio = 4 * sp.tiles_per_seg;
+        sp.frag_stride = (size_t)WFM_NK * 3 * 64; sp.tab_pitch = ps->tab_pitch; sp.tab_len = ps->tab_len; sp.scales = ps->d_scales;
+        sp.lead_d = ps->d_lead_d; sp.lead_n = ps->d_lead_n;
+        if (sp.col_bytes * 16 + 4096 >= (1LL << 32)) return fail_msg(-3, "wfm: block too large for the per-stream kernel's 32-bit row offsets");
+        const size_t ldsp = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float) + 2 * 48 * sizeof(float2);
+        { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<true>, ldsp); if (arc) return arc; }
+        if (ev_begin && ev_end)
+            hipExtLaunchKernelGGL(k_wfm_mfma_seq<true>, dim3(n_streams, n_seg), dim3(64 * SEQ_NW), ldsp, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        else
+            hipLaunchKernelGGL(k_wfm_mfma_seq<true>, dim3(n_streams, n_seg), dim3(64 * SEQ_NW), ldsp, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        CSDR_LAUNCH_CHECK();
+        if (T < 256 || (T & 7)) {
+            hipLaunchKernelGGL(k_wfm_roll_head, dim3(n_streams), dim3(256), 0, st, in, in_pitch, 2LL * T, back.head_in, back.head_out);
+            CSDR_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const size_t lds = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float);
-    { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq, lds); if (arc) return arc; }
+    { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<false>, lds); if (arc) return arc; }
     // timing events ride on the kernel's own dispatch (start / completion signal of its packet): hipEventRecord in front of and behind it would put two
     // marker packets into the stream, ~10 us of bubbles that the un-profiled path does not have
     if (ev_begin && ev_end)
-        hipExtLaunchKernelGGL(k_wfm_mfma_seq, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        hipExtLaunchKernelGGL(k_wfm_mfma_seq<false>, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
     else
-        hipLaunchKernelGGL(k_wfm_mfma_seq, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        hipLaunchKernelGGL(k_wfm_mfma_seq<false>, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
     CSDR_LAUNCH_CHECK();
     if (T < 256 || (T & 7)) {      // a block shorter than the history, or a ragged last block: the kernel's epilogue skipped the copy
         hipLaunchKernelGGL(k_wfm_roll_head, dim3(n_streams), dim3(256), 0, st, in, in_pitch, 2LL * T, back.head_in, back.head_out);

@@ -27,12 +27,18 @@ struct WfmBackArgs {
     float alpha; const float *last_in; float *last_out; int16_t *s16; float *af; size_t out_pitch; const uint8_t *head_in; uint8_t *head_out;
 };
 
+// a shift rate per stream (csdr_amd_wfm_create_rates): dev.d_seq_frags / d_seq_cum / d_dtab hold one table set per stream, the chunk seeds come from a seed table
+// (seeds.hpp: ctab[k * tab_pitch + stream]); lead: the first audio samples of retuned streams, evaluated by wfm_mfma_lead
+struct WfmPerStream { size_t tab_pitch; int tab_len; const float *d_scales; const float *d_lead_d; const int *d_lead_n; };
+
 bool wfm_mfma_supported(int D, int L, int F);
 void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *taps, WfmMfmaTable &t);
 size_t wfm_mfma_head_bytes(int n_streams);
 // One launch per call: audio j_first .. j_first + n_audio - 1 of every stream from the block in[stream * in_pitch + 2 * (0 .. T)) (global sample index B at its
 // start) and the head; ev_begin / ev_end (may be null) are recorded around the kernel.  n_audio = 0: only the head rolls.
 int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const WfmMfmaDevice &dev, const float2 *ctab,
-                    int n_streams, int T, long long B, long long j_first, int n_audio, const WfmBackArgs &back);
+                    int n_streams, int T, long long B, long long j_first, int n_audio, const WfmBackArgs &back, const WfmPerStream *ps = nullptr);
+int wfm_mfma_lead(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *head, const float *d_taps, const float2 *ctab, size_t tab_pitch, const float2 *d_dtab,
+                  const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int D, int L, int F, long long B, long long j_first, int n_lead);
 
 } // namespace csdr_amd

@@ -373,6 +373,15 @@ typedef struct csdr_amd_wfm csdr_amd_wfm;
 csdr_amd_wfm *csdr_amd_wfm_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation,
                                   const float *host_taps, int taps_length, int frac_rate,
                                   float tau, int audio_rate, size_t max_block_samples);
+/* The same with a shift rate PER STREAM and its retune between calls (the reference's unit of work is one (stream, shift_rate) pair: `csdr shift_addition_cc --fifo`,
+ * csdr.c:881-923; ddcd's per-client chains, ddcd_old.h:51-61) -- see csdr_amd_ddc_create_rates.  The chain kernel then gives a workgroup ONE stream and puts 16 time
+ * segments of it into the 16 columns of the product; full rate needs blocks of >= 16 x lcm(4 D F, 1024) samples per stream and call (409 600 at D F = 50).
+ * Needs the matrix-core kernel's shapes (csdr_amd_wfm_fallback == 0). */
+csdr_amd_wfm *csdr_amd_wfm_create_rates(csdr_amd_ctx *ctx, int n_streams, const float *shift_rates, int decimation,
+                                        const float *host_taps, int taps_length, int frac_rate,
+                                        float tau, int audio_rate, size_t max_block_samples);
+int   csdr_amd_wfm_set_rate(csdr_amd_wfm *w, int stream, float shift_rate);
+float csdr_amd_wfm_get_rate(const csdr_amd_wfm *w, int stream);
 void csdr_amd_wfm_destroy(csdr_amd_wfm *w);
 int  csdr_amd_wfm_reset(csdr_amd_wfm *w);
 /* in: u8 IQ, [n_streams][in_pitch bytes], block_samples complex samples per stream (multiple of 1024 except

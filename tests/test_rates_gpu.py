@@ -4,7 +4,7 @@ csdr.c:881-923; ddcd's per-client chains, ddcd_old.h:51-61).  Gates: relative RM
 import numpy as np
 import pytest
 from oracle import relrms
-from tests_helpers import nfm_signal_u8
+from tests_helpers import nfm_signal_u8, wfm_signal_u8
 import verify_configs as vc
 
 pytestmark = pytest.mark.gpu
@@ -133,3 +133,55 @@ def test_nfm_rates_and_retune(gpu, port):
     m = min(want.size, pcm3.shape[1])
     assert m >= want.size - 2048 and vc.s16_diff(pcm3[1, :m], want[:m]).max() <= 1
     assert np.array_equal(pcm3[0, :m], pcm2[0, :m])
+
+
+WRATES = [-0.085, 0.11, 0.25, -0.3, 0.05, 0.2, -0.1234, 0.4, -0.45, 0.0]
+
+
+@pytest.mark.parametrize("n,S,want_float", [(1024 * 517, 5, True), (1024 * 517, 4, False), (1024 * 60, 10, False), (1024 * 26 + 700, 3, True)])
+def test_wfm_rates_single_call(gpu, port, n, S, want_float):
+    """csdr_amd_wfm_create_rates: a shift rate per stream through the WFM chain kernel (one workgroup = one stream x 16 time segments).  517 chunks = 20.2 periods of
+    25600 samples -> two column groups with a partial last column and columns behind the block's end; 60 chunks = 3 columns; a ragged single-column block.  With
+    and without the float tap (the s16-only runs take the loaders' line-collecting store path).  Every stream +-1 LSB against the oracle's seven stages at its rate."""
+    taps = port.firdes_lowpass_f(79, 0.05)
+    rates = np.array(WRATES[:S], f32)
+    u8 = np.stack([wfm_signal_u8(2000 + s, n, offset=-float(rates[s])) for s in range(S)])
+    s16, af = gpu.wfm_chain(u8, rates, 10, taps, want_float=want_float)
+    assert gpu.last_wfm_kernel == "k_wfm_mfma_seq"
+    for s in range(S):
+        ps, pf = port.wfm_chain(u8[s], float(rates[s]), 10, taps)
+        m = min(ps.size, s16.shape[1])
+        assert 0 <= ps.size - s16.shape[1] <= 2 or 0 <= s16.shape[1] - ps.size <= 2
+        assert vc.s16_diff(s16[s, :m], ps[:m]).max() <= 1, "stream %d rate %g: %d" % (s, rates[s], vc.s16_diff(s16[s, :m], ps[:m]).max())
+        if want_float:
+            assert relrms(af[s, :m], pf[:m]) <= TOL
+
+
+def test_wfm_rates_blocks_and_retune(gpu, port):
+    """Consecutive calls (tables switched on the side stream, history heads, de-emphasis state across calls and columns), bit-identical to the single call; then
+    csdr_amd_wfm_set_rate between calls: new rate from the next block's first sample, phase carried (csdr.c:881-923) -- the oracle retunes its shift stage there."""
+    taps = port.firdes_lowpass_f(79, 0.05)
+    S = 4
+    sizes = [1024 * 100, 1024 * 64, 1024 * 150, 1024 * 30]
+    n = sum(sizes)
+    rates = np.array(WRATES[:S], f32)
+    u8 = np.stack([wfm_signal_u8(2100 + s, n, offset=-float(rates[s])) for s in range(S)])
+    a, _ = gpu.wfm_chain(u8, rates, 10, taps, want_float=False)
+    b, _ = gpu.wfm_chain(u8, rates, 10, taps, block=sizes, want_float=False)
+    m = min(a.shape[1], b.shape[1])
+    assert m >= a.shape[1] - 2 and vc.s16_diff(a[:, :m], b[:, :m]).max() <= 1      # (column boundaries differ between the two runs: the warm-up's 5e-8)
+    # retune stream 1 in front of the third call: its signal moves with it
+    pos = int(np.cumsum([0] + sizes)[2])
+    u8r = u8.copy()
+    u8r[1] = np.concatenate([wfm_signal_u8(2200, pos, offset=-0.11), wfm_signal_u8(2201, n - pos, offset=0.3)])
+    c, _ = gpu.wfm_chain(u8r, rates, 10, taps, block=sizes, retunes={2: [(1, -0.3)]}, want_float=False)
+    xf = port.convert_u8_f(u8r[1]).view(c64)
+    s1, ph = port.shift_addition_cc(xf[:pos], 0.11)
+    s2, _ = port.shift_addition_cc(xf[pos:], -0.3, phase=ph)
+    dec = port.fir_decimate_cc(np.concatenate([s1, s2]), 10, taps)
+    dem, _ = port.fmdemod_quadri_cf(dec)
+    aud = dem[10::5]                                       # fractional_decimator_ff 5 == x[5 k + 10] (exact at an integer rate)
+    want = port.convert_f_s16(port.deemphasis_wfm_ff(aud, 50e-6, 48000)[0])
+    m = min(want.size, c.shape[1])
+    assert m >= want.size - 4 and vc.s16_diff(c[1, :m], want[:m]).max() <= 1, vc.s16_diff(c[1, :m], want[:m]).max()
+    assert vc.s16_diff(c[0, :m], b[0, :m]).max() == 0
