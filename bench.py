@@ -91,13 +91,18 @@ def operating_points(ctx, taps):
     import torch
     L = ctx.L
     pts = []
-    for S, T, steps in ((1024, 16384, 400), (65536, 24576, 60)):
+    import numpy as np
+    for S, T, steps, per_stream in ((1024, 2344 * 1024, 100, True), (1024, 16384, 400, False), (65536, 24576, 60, False)):
         pitch = 2 * T
         x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda")
         na_max = (T // 50 + 64 + 63) // 64 * 64
         out = torch.empty((S, na_max), dtype=torch.int16, device="cuda")
         torch.cuda.synchronize()
-        w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+        if per_stream:      # the headline shape with a shift rate PER STREAM (csdr_amd_wfm_create_rates: one workgroup = one stream x 16 time segments)
+            rates = (-0.45 + 0.9 * (np.arange(S) + 0.5) / S).astype(np.float32)
+            w = L.csdr_amd_wfm_create_rates(ctx.h, S, rates.ctypes.data_as(C.c_void_p), 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+        else:
+            w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
         if not w:
             pts.append({"streams": S, "block": T, "error": ctx.err()}); continue
         for _ in range(steps // 2):
@@ -113,7 +118,7 @@ def operating_points(ctx, taps):
         L.csdr_amd_wfm_kernel_time(w, C.byref(kms), C.byref(kl))
         k_ms = kms.value / max(kl.value, 1)
         algo = ALGO_BYTES_PER_SAMPLE * S * T
-        pts.append({"streams": S, "block_samples_per_stream": T, "block_ms_of_signal": round(T / 2400.0, 2), "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4),
+        pts.append({"streams": S, "shift_rates": "per stream (1024 distinct)" if per_stream else "one for all", "block_samples_per_stream": T, "block_ms_of_signal": round(T / 2400.0, 2), "steps": steps, "ms_per_step": round(wall / steps * 1e3, 4),
                     "value": round(S * T * steps / wall / 1e6, 1), "unit": "complex MS/s", "realtime_factor_per_stream": round((T / 2.4e6) / (wall / steps), 1),
                     "kernel": L.csdr_amd_wfm_kernel_name(w).decode(), "kernel_avg_ms": round(k_ms, 4),
                     "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms else None, "fallback": bool(L.csdr_amd_wfm_fallback(w))})
