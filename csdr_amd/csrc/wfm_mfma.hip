@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
     if (t0 >= t1) return;
     const int n_it = (int)(t1 - t0), n_grp = (n_it + TPG - 1) / TPG;
+    const int n_lead = (PS && p.lead_n && blockIdx.y == 0) ? p.lead_n[sb] : 0;         // PS: audio samples at the call's start that k_wfm_lead has evaluated (a retuned stream)
     const int n_warm = (PS || blockIdx.y > 0) ? 2 : 0;                               // steps demodulated ahead of the segment to warm the de-emphasis up
     const int last_stream = p.n_streams - 1;
     v4i A[WFM_NK * 3];
@@ -318,11 +319,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             // state -- any readable bytes do); rows behind the block's end re-read column 0; a ragged end is masked at the row's last 16-byte piece.
             const uint32_t ldst = lds_in_addr + (SPW * fw) * SEQ_RP + (uint32_t)fslot;
             const bool head = F < 0 && col0 == 0;                                    // wave uniform
-            bool plain = !head && !ragged;
+            if (!head && !ragged) {                                                  // the common case: whole runs (row_lim is a multiple of 1024 like F), inside the block or behind it
+                uint32_t vo[SPW];
 #pragma unroll
-            for (int r = 0; r < SPW; r++) plain = plain && F + 1024 <= row_lim[r];
-            if (plain) dma_rows<SPW, SEQ_RP>(voff, sblock + F, __builtin_amdgcn_readfirstlane((int)ldst));      // the common case
-            else
+                for (int r = 0; r < SPW; r++) vo[r] = F < row_lim[r] ? voff[r] : 16u * lane;      // behind the block's end: column 0's bytes again (the partial last column of
+                dma_rows<SPW, SEQ_RP>(vo, sblock + F, __builtin_amdgcn_readfirstlane((int)ldst)); // a call spends a good part of its steps there: no row by row path for it)
+            } else
 #pragma unroll
             for (int r = 0; r < SPW; r++) {
                 const bool hrow = head && (SPW * fw + r == 0 || F + 1024 > row_lim[r]);
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 }
             }
         };
+        PROF_T(7)
         for (int gi = -n_warm; gi < n_grp; gi++) {
             PROF_T(0)
             const long long wg_n = wg + (long long)TPG * tstride;
@@ -551,13 +554,14 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             wg = wg_n;
         }
 #ifdef WFM_PROF
-        if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
+        if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
 #endif
         __syncthreads();
         if (WFM_DIAG < 4) { take_line(n_grp - 1); take_line(n_grp); flush(); }
 #undef WFM_ST_ALL
     } else {
     // ============================================================================ the compute waves
+    PROF_T(7)
     for (int gi = -n_warm; gi < n_grp; gi++) {
         const int it = gi * TPG + wv;
         float *lout = lds_out + ((gi + SEQ_OUTS) % SEQ_OUTS) * SPS;                   // this step's samples in every stream's ring
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 // a retuned stream's first samples of the call: their windows reach into bytes that were rotated at the OLD rate -- evaluated with both tables
                 // by k_wfm_lead in front of this kernel
                 const long long ja = 4 * (t0 + it) + q - p.j_first;                  // this audio sample's index in the call (column 0)
-                if (p.lead_n && col0 + col == 0 && ja >= 0 && ja < p.lead_n[sb]) dval = p.lead_d[(size_t)sb * 4 + ja];
+                if (n_lead > 0 && col0 + col == 0 && ja >= 0 && ja < n_lead) dval = p.lead_d[(size_t)sb * 4 + ja];      // (n_lead in a register: a vector load here waits behind the DMA ring)
             }
             lout[col * SEQ_OUTP + 4 * wv + q] = dval;                                 // audio 4 * tile + q of stream col
         }
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         wg = wg_n; wslot += TPG * tstride; if (wslot >= SEQ_RB) wslot -= SEQ_RB;
     }
 #ifdef WFM_PROF
-    if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
+    if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
 #endif
     __syncthreads();
     if (!emit_vec) emit_scalar(n_grp - 1);

@@ -19,7 +19,12 @@ x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda")
 n_max = (T // 50 + 64 + 63) // 64 * 64
 out = torch.empty((S, n_max), dtype=torch.int16, device="cuda")
 torch.cuda.synchronize()
-w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+if os.environ.get("DIAG_RATES") == "distinct":                                   # a shift rate per stream (the per-stream kernel)
+    import numpy as np
+    rates = (-0.45 + 0.9 * (np.arange(S) + 0.5) / S).astype(np.float32)
+    w = L.csdr_amd_wfm_create_rates(ctx.h, S, rates.ctypes.data_as(C.c_void_p), 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+else:
+    w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
 for _ in range(60):
     L.csdr_amd_wfm_process(w, x.data_ptr(), 2 * T, T, out.data_ptr(), None, n_max)
 ctx.sync()
@@ -38,4 +43,4 @@ print("wave " + " ".join("%10s" % n for n in names[:6]) + "   total   (cycles pe
 for wv in range(8):
     n = prof[wv * 8 + 6]
     row = [prof[wv * 8 + k] / max(n, 1) for k in range(6)]
-    print("%4d " % wv + " ".join("%10.0f" % v for v in row) + " %8.0f" % sum(row))
+    print("%4d " % wv + " ".join("%10.0f" % v for v in row) + " %8.0f" % sum(row) + "   steps per call %.0f, cycles before the first step (sum over workgroups, per call) %.0f" % (n / steps, prof[wv * 8 + 7] / steps))
