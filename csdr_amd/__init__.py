@@ -666,10 +666,13 @@ class Context:
 
     # (the multi-rank form of the bank on ONE GPU: sharded_bank_loopback below, module level -- one Context per rank thread)
 
-    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0, retunes=None, want_float=True):
+    def wfm_chain(self, iq_u8, shift_rate, decimation, taps, frac_rate=5, tau=50e-6, audio_rate=48000, block=None, pitch_pad=0, retunes=None, want_float=True,
+                  out_per_call=False):
         """iq_u8: [2n] or [streams, 2n] uint8 -> (s16 [streams, na], float audio [streams, na]); `block` = samples per call (or a list of call sizes);
         `pitch_pad` = extra bytes of row pitch (multiple of 16).  shift_rate: one float, or one per stream (csdr_amd_wfm_create_rates);
         retunes: {call index: [(stream, rate), ...]} applied in front of that call.  want_float=False: s16 only (the kernel's line-collecting store path).
+        out_per_call: every call writes at the START of the (16-byte aligned) output rows, as a streaming caller with one output buffer does -- the kernel's
+        aligned store path on every call (otherwise call k's audio follows call k - 1's in one row: aligned only by chance).
         The front-end kernel of the last call is left in `self.last_wfm_kernel`."""
         x2, squeeze = self._2d(iq_u8, np.uint8)
         s, nbytes = x2.shape; n = nbytes // 2
@@ -688,15 +691,24 @@ class Context:
         di = self.upload(xx)
         apitch = (n // (decimation * frac_rate) + 64 + 63) // 64 * 64
         ds = self.alloc(2 * s * apitch); df = self.alloc(4 * s * apitch) if want_float else None
-        pos = 0; na = 0; call = 0
+        pos = 0; na = 0; call = 0; parts_s = []; parts_f = []
         while pos < n:
             for st, r in (retunes or {}).get(call, []):
                 self.check(self.L.csdr_amd_wfm_set_rate(w, st, r), "wfm_set_rate")
             k = min(sched[call] if (sched and call < len(sched)) else block, n - pos); call += 1
-            got = self.check(self.L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na) if want_float else None, apitch), "wfm_process")
+            if out_per_call:
+                got = self.check(self.L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.ptr, df.ptr if want_float else None, apitch), "wfm_process")
+                parts_s.append(self.download(ds, np.int16, s * apitch).reshape(s, apitch)[:, :got].copy())
+                if want_float: parts_f.append(self.download(df, f32, s * apitch).reshape(s, apitch)[:, :got].copy())
+            else:
+                got = self.check(self.L.csdr_amd_wfm_process(w, di.at(2 * pos), pitch, k, ds.at(2 * na), df.at(4 * na) if want_float else None, apitch), "wfm_process")
             pos += k; na += got
-        s16 = self.download(ds, np.int16, s * apitch).reshape(s, apitch)[:, :na]
-        af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na] if want_float else np.zeros((s, 0), f32)
+        if out_per_call:
+            s16 = np.concatenate(parts_s, axis=1) if parts_s else np.zeros((s, 0), np.int16)
+            af = np.concatenate(parts_f, axis=1) if parts_f else np.zeros((s, 0), f32)
+        else:
+            s16 = self.download(ds, np.int16, s * apitch).reshape(s, apitch)[:, :na]
+            af = self.download(df, f32, s * apitch).reshape(s, apitch)[:, :na] if want_float else np.zeros((s, 0), f32)
         self.last_wfm_kernel = self.L.csdr_amd_wfm_kernel_name(w).decode()
         self.L.csdr_amd_wfm_destroy(w)
         return (s16[0].copy(), af[0].copy()) if squeeze else (s16.copy(), af.copy())

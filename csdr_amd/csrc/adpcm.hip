@@ -50,7 +50,7 @@ __global__ void k_adpcm_encode(const int16_t *__restrict__ in, uint8_t *__restri
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
-    St st{state_io[2 * s], state_io[2 * s + 1]};
+    St st{min(max(state_io[2 * s], 0), 88), state_io[2 * s + 1]};               // (a table index: clamped, see k_adpcm_decode_scan)
     const int16_t *x = in + (size_t)s * in_pitch; uint8_t *y = out + (size_t)s * out_pitch;
     for (size_t k = 0; k < n / 2; k++) { const unsigned lo = enc_one(x[2 * k], st), hi = enc_one(x[2 * k + 1], st); y[k] = (uint8_t)(lo | (hi << 4)); }
     state_io[2 * s] = st.index; state_io[2 * s + 1] = st.prev;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void k_adpcm_encode_lds(const int16_t *__restri
     const int lane = threadIdx.x, s0 = blockIdx.x * 64, s = s0 + lane;
     for (int k = lane; k < 89 + 8; k += 64) l_step[k] = c_step[k < 89 ? k : 88];      // (entries behind 88 repeat it: index + 8 needs no clamp of its own)
     const bool mine = s < n_streams;
-    int index = mine ? state_io[2 * s] : 0, prev = mine ? state_io[2 * s + 1] : 0;
+    int index = mine ? min(max(state_io[2 * s], 0), 88) : 0, prev = mine ? state_io[2 * s + 1] : 0;
     const size_t n_codes = n & ~(size_t)1;                                              // samples that yield a code (pairs: ima_adpcm.c:154-163)
     __syncthreads();
     int step = l_step[index];
@@ -140,7 +140,7 @@ __global__ void k_adpcm_decode(const uint8_t *__restrict__ in, int16_t *__restri
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
-    St st{state_io[2 * s], state_io[2 * s + 1]};
+    St st{min(max(state_io[2 * s], 0), 88), state_io[2 * s + 1]};               // (a table index: clamped, see k_adpcm_decode_scan)
     const uint8_t *x = in + (size_t)s * in_pitch; int16_t *y = out + (size_t)s * out_pitch;
     for (size_t k = 0; k < n; k++) { const unsigned b = x[k]; y[2 * k] = (int16_t)dec_one(b & 0xf, st); y[2 * k + 1] = (int16_t)dec_one((b >> 4) & 0xf, st); }
     state_io[2 * s] = st.index; state_io[2 * s + 1] = st.prev;
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void k_adpcm_decode_scan(const uint8_t *__rest
         l_pair[tid] = (m.a + 2) | (m.lo << 8) | (m.hi << 16);
     }
     const uint8_t *x = in + (size_t)s * in_pitch; int16_t *y = out + (size_t)s * out_pitch;
-    int index0 = state_io[2 * s], prev0 = state_io[2 * s + 1];       // state at the chunk's first sample (same value in every thread)
+    int index0 = cclamp(state_io[2 * s], 0, 88), prev0 = state_io[2 * s + 1];      // state at the chunk's first sample (same value in every thread); the index is a table
+                                                                                      // index from here on: a caller's value outside the table (the reference reads past its table, ima_adpcm.c:110) is clamped
     const bool in_al = (((uintptr_t)x) & 7) == 0, out_al = (((uintptr_t)y) & 15) == 0;
     __syncthreads();
     for (size_t c0 = 0; c0 < n; c0 += 256 * (DEC_S / 2)) {          // c0: first input byte of the chunk
@@ -295,8 +296,16 @@ int csdr_amd_encode_ima_adpcm_i16_u8(csdr_amd_ctx *c, const int16_t *in, uint8_t
 int csdr_amd_decode_ima_adpcm_u8_i16(csdr_amd_ctx *c, const uint8_t *in, int16_t *out, int n_streams, size_t n, size_t in_pitch, size_t out_pitch, int *state_io)
 {
     if (!n || n_streams <= 0) return 0;
-    // two parallel scans per stream (one workgroup per stream); CSDR_AMD_ADPCM_SERIAL (A/B, read once per process): one lane per stream
-    static const bool serial = getenv("CSDR_AMD_ADPCM_SERIAL") != nullptr;
+    // Two parallel scans per stream (k_adpcm_decode_scan: one 256-thread workgroup per stream, ~6 KiB of LDS tables built per workgroup, two 256-wide scans per 4096
+    // input bytes) -- or one lane per stream (k_adpcm_decode), which wins only when the streams are many AND short.  Measured (tools/bench_adpcm_decode.py, ms per
+    // call, lane per stream / scans): 65536 streams x 256 B 0.157 / 0.427; 65536 x 1024 B 0.955 / 0.433; 8192 x 1024 B 0.301 / 0.060; 4096 x 100 B 0.029 / 0.034;
+    // 2048 x 4096 B 1.21 / 0.025; 1024 x 65536 B 19.7 / 0.155.  The walk costs ~0.3 us per input byte (twice that once more than 32768 lanes share the memory
+    // system), whatever the stream count; the scans ~4 us per workgroup + ~9 us per chunk, 2048 streams in flight at a time.  The choice below is that model;
+    // CSDR_AMD_ADPCM_SERIAL / CSDR_AMD_ADPCM_SCAN force one (read once per process).
+    static const bool force_serial = getenv("CSDR_AMD_ADPCM_SERIAL") != nullptr, force_scan = getenv("CSDR_AMD_ADPCM_SCAN") != nullptr;
+    const double t_serial = 0.3 * (double)n * (n_streams > 32768 ? (double)n_streams / 32768.0 : 1.0);
+    const double t_scan = (double)(((size_t)n_streams + 2047) / 2048) * (4.0 + 9.0 * (double)((n + 4095) / 4096));
+    const bool serial = force_serial || (!force_scan && t_serial < t_scan);
     if (serial) hipLaunchKernelGGL(k_adpcm_decode, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, n, in_pitch, out_pitch, state_io);
     else hipLaunchKernelGGL(k_adpcm_decode_scan, dim3(n_streams), dim3(256), 0, c->stream, in, out, n, in_pitch, out_pitch, state_io);
     CSDR_LAUNCH_CHECK();

@@ -120,7 +120,7 @@ int c_all_gather(const DdcComm *c, void *all, size_t n, hipStream_t st)
 namespace {
 // ---- loopback implementation of the DdcComm table
 csdr_amd_comm *lc(const DdcComm *c) { return (csdr_amd_comm *)c->impl; }
-int l_barrier(csdr_amd_loopback *g) { const int rc = g->barrier(); return rc ? fail_msg(-6, "loopback communicator: a rank did not arrive within 60 s (all ranks must make the same exchange calls)") : 0; }
+int l_barrier(csdr_amd_loopback *g) { const int rc = g->barrier(); return rc ? fail_msg(-6, "loopback communicator: a rank did not arrive within 60 s, or gave up after an error of its own (all ranks must make the same exchange calls)") : 0; }
 int l_group_start(const DdcComm *c) { csdr_amd_comm *m = lc(c); m->ops.clear(); m->in_group = true; return 0; }
 int l_send(const DdcComm *c, const void *buf, size_t n, int peer, hipStream_t st)
 {
@@ -136,33 +136,48 @@ int l_recv(const DdcComm *c, void *buf, size_t n, int peer, hipStream_t st)
 }
 int l_group_end(const DdcComm *c)
 {
+    // A local error (two sends to one peer, a HIP call that fails) must not leave the other rank threads waiting 60 s at a rendezvous this rank never reaches, nor box
+    // entries marked valid for the next group: this rank's entries are cleared, the group is marked broken with a wake-up (what csdr_amd_loopback_abort does), and
+    // the first error is the one reported.
     csdr_amd_comm *m = lc(c); csdr_amd_loopback *g = m->loop;
     const int me = c->rank, W = c->world;
     m->in_group = false;
-    for (const auto &op : m->ops) if (op.send) {                      // publish: what, and when it is ready
+    int err = 0;
+    auto hip = [&](hipError_t e, const char *what) { if (e != hipSuccess && !err) err = ::csdr_amd::fail(e, what, __FILE__, __LINE__); return e == hipSuccess; };
+    auto give_up = [&]() {
+        for (const auto &op : m->ops) if (op.send) g->box[me * W + op.peer].valid = false;
+        m->ops.clear();
+        { std::lock_guard<std::mutex> lk(g->mu); g->broken = true; }
+        g->cv.notify_all();
+        return err;
+    };
+    for (const auto &op : m->ops) if (op.send && !err) {              // publish: what, and when it is ready
         const int id = me * W + op.peer;
-        if (g->box[id].valid) return fail_msg(-3, "loopback: two sends to rank %d in one group", op.peer);
-        CSDR_HIP(hipEventRecord(g->ready[id], op.st));
+        if (g->box[id].valid) { err = fail_msg(-3, "loopback: two sends to rank %d in one group", op.peer); break; }
+        if (!hip(hipEventRecord(g->ready[id], op.st), "hipEventRecord(ready)")) break;
         g->box[id] = {op.buf, op.n, true, false};
     }
-    int rc = l_barrier(g); if (rc) return rc;
+    if (err) return give_up();
+    int rc = l_barrier(g); if (rc) { err = rc; return give_up(); }
     int bad = 0;
-    for (const auto &op : m->ops) if (!op.send) {                     // pull on the receiver's stream
+    for (const auto &op : m->ops) if (!op.send && !err) {             // pull on the receiver's stream
         const int id = op.peer * W + me;
         csdr_amd_loopback::Msg &msg = g->box[id];
         if (!msg.valid || msg.n != op.n) { bad = 1; continue; }
-        CSDR_HIP(hipStreamWaitEvent(op.st, g->ready[id], 0));
-        CSDR_HIP(hipMemcpyAsync(op.buf, msg.buf, op.n * sizeof(float), hipMemcpyDeviceToDevice, op.st));
-        CSDR_HIP(hipEventRecord(g->done[id], op.st));
+        if (!hip(hipStreamWaitEvent(op.st, g->ready[id], 0), "hipStreamWaitEvent(ready)") ||
+            !hip(hipMemcpyAsync(op.buf, msg.buf, op.n * sizeof(float), hipMemcpyDeviceToDevice, op.st), "hipMemcpyAsync(loopback)") ||
+            !hip(hipEventRecord(g->done[id], op.st), "hipEventRecord(done)")) break;
         msg.taken = true;
     }
-    rc = l_barrier(g); if (rc) return rc;
+    if (err) return give_up();
+    rc = l_barrier(g); if (rc) { err = rc; return give_up(); }
     for (const auto &op : m->ops) if (op.send) {                      // the source may be reused only after the copy
         const int id = me * W + op.peer;
-        if (!g->box[id].taken) bad = 1; else CSDR_HIP(hipStreamWaitEvent(op.st, g->done[id], 0));
+        if (!g->box[id].taken) bad = 1; else hip(hipStreamWaitEvent(op.st, g->done[id], 0), "hipStreamWaitEvent(done)");
         g->box[id].valid = false;
     }
     m->ops.clear();
+    if (err) return err;
     if (bad) return fail_msg(-3, "loopback: a send / recv of rank %d had no matching partner (or the sizes differ)", me);
     return 0;
 }
@@ -286,6 +301,17 @@ int csdr_amd_comm_broadcast(csdr_amd_comm *c, void *dev_buf, size_t bytes, int r
     if (c->loop) return l_collect(c, dev_buf, bytes, root, c->ctx->stream);
     CSDR_NCCL(g_rccl.Broadcast(dev_buf, dev_buf, bytes, 1 /* ncclUint8 */, root, c->comm, c->ctx->stream));
     return 0;
+}
+
+// test hook (tests/test_sharded_gpu.py): one group with `n_sends` sends of n floats to `peer` and one receive from it -- n_sends = 2 is the local error whose
+// handling l_group_end documents
+int csdr_amd_debug_comm_exchange(csdr_amd_comm *c, const float *send_buf, float *recv_buf, size_t n, int peer, int n_sends)
+{
+    const DdcComm *d = &c->ddc;
+    int rc = d->group_start(d); if (rc) return rc;
+    for (int k = 0; k < n_sends; k++) { rc = d->send(d, send_buf, n, peer, c->ctx->stream); if (rc) return rc; }
+    rc = d->recv(d, recv_buf, n, peer, c->ctx->stream); if (rc) return rc;
+    return d->group_end(d);
 }
 
 } // extern "C"

@@ -889,7 +889,7 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
 // in_k / out_k: a path (file or fifo) or fd:<n>.  Every pass reads one block of CSDR_AMD_BANK_BLOCK samples (default 262144, a multiple of 1024) from
 // EVERY input (the streams advance in lockstep, like the clients of one nmux), uploads them as the rows of one batch, runs the chain once and writes
 // each row's audio to its output.  The pass in which the first stream ends is the last one (lockstep streams end together).
-//   <shift_rate> may be a comma-separated list, one rate per stream (ddcd tunes every client on its own: ddcd_old.h:51-61) -- nfm_bank_u8_s16 only so far;
+//   <shift_rate> may be a comma-separated list, one rate per stream (ddcd tunes every client on its own: ddcd_old.h:51-61);
 //   --ctl <fifo | fd:<n>> in front of it: control lines "<stream> <rate>\n", applied between two passes exactly as `shift_addition_cc --fifo` applies a new rate
 //   between two reads (csdr.c:881-923: the phase carries over).
 int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
@@ -907,7 +907,6 @@ int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
     for (const char *q = argv[2]; *q;) { char *end = nullptr; const float v = strtof(q, &end); if (end == q) return badsyntax("shift_rate must be a number or a comma-separated list"); rates.push_back(v); q = *end == ',' ? end + 1 : end; if (*end && *end != ',') return badsyntax("shift_rate must be a number or a comma-separated list"); }
     if (rates.size() != 1 && (int)rates.size() != S) return badsyntax("as many shift rates as streams (or one for all)");
     const bool per_stream = rates.size() > 1 || ctl_fd >= 0;
-    if (per_stream && !nfm) return badsyntax("a shift rate per stream / --ctl: nfm_bank_u8_s16 only");
     if (per_stream && rates.size() == 1) rates.assign(S, rates[0]);
     const float shift = rates[0];
     auto open_fd = [](const char *spec, int flags) { int fd = -1; if (!strncmp(spec, "fd:", 3)) sscanf(spec + 3, "%d", &fd); else fd = open(spec, flags, 0644); return fd; };
@@ -924,6 +923,7 @@ int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
     csdr_amd_wfm *w = nullptr; csdr_amd_nfm *n = nullptr;
     if (nfm && per_stream) n = csdr_amd_nfm_create_rates(c, S, rates.data(), D, taps.data(), nt, 48000, 1024, 1.0f, 1.0f, T);
     else if (nfm) n = csdr_amd_nfm_create(c, S, shift, D, taps.data(), nt, 48000, 1024, 1.0f, 1.0f, T);
+    else if (per_stream) w = csdr_amd_wfm_create_rates(c, S, rates.data(), D, taps.data(), nt, 5, 50e-6f, 48000, T);
     else w = csdr_amd_wfm_create(c, S, shift, D, taps.data(), nt, 5, 50e-6f, 48000, T);
     std::string ctl_buf;
     if (!w && !n) die("bank create");
@@ -953,7 +953,7 @@ int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
             size_t nl;
             while ((nl = ctl_buf.find('\n')) != std::string::npos) {
                 int st = -1; float rv = 0;
-                if (sscanf(ctl_buf.c_str(), "%d %g", &st, &rv) == 2 && st >= 0 && st < S) { MUST(csdr_amd_nfm_set_rate(n, st, rv)); fprintf(stderr, "csdr %s: stream %d reinitialized to %g\n", g_cmd, st, rv); }
+                if (sscanf(ctl_buf.c_str(), "%d %g", &st, &rv) == 2 && st >= 0 && st < S) { MUST(nfm ? csdr_amd_nfm_set_rate(n, st, rv) : csdr_amd_wfm_set_rate(w, st, rv)); fprintf(stderr, "csdr %s: stream %d reinitialized to %g\n", g_cmd, st, rv); }
                 ctl_buf.erase(0, nl + 1);
             }
         }

@@ -507,7 +507,8 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             if (k_now <= k_before) return;                                           // (at most one line per step: SPS < 64)
             static_assert(4 * SEQ_TPG < SEQ_LINE && SEQ_LINE == 64 && SEQ_NLD == 2, "one line per step at most; 8 streams x 8 pieces per loader");
             const int nl = emit_a + SEQ_LINE * (k_now - 1), n0 = nl + 8 * pc;        // the line's first sample, this lane's
-            if (nl + SEQ_LINE <= seg_lo || nl >= seg_hi) return;
+            if (nl + SEQ_LINE <= (PS ? 0 : seg_lo) || nl >= seg_hi) return;          // (PS: seg_lo is the call's first column's; every other column starts at its sample 0 -- a line in front of
+                                                                                     // column 0's first sample still holds the first samples of the columns behind it, cut per lane below)
             const float *src = lds_out + srow * SEQ_OUTP;
             float e[8];
 #pragma unroll

@@ -629,21 +629,23 @@ def test_cli_stream_bank(port, tmp_path, cmd):
         assert d.max() <= 1 and (d > 0).mean() < 0.05, "stream %d" % k
 
 
-def test_cli_nfm_bank_rate_per_stream_and_control_channel(port, tmp_path):
-    """`csdr nfm_bank_u8_s16 --ctl <fifo> r0,r1,r2 ...`: a shift rate per stream (ddcd tunes every client on its own, ddcd_old.h:51-61) and retunes over a control
-    channel, lines "<stream> <rate>" (the `--fifo` protocol of shift_addition_cc, csdr.c:881-893, with a stream number in front).  The line is in the fifo before
-    the process starts, so it is applied in front of the first pass: stream 1 runs at the NEW rate from its first sample (the mid-stream case, with its two-rate
-    window, is tests/test_rates_gpu.py's)."""
-    from tests_helpers import nfm_signal_u8
+@pytest.mark.parametrize("cmd", ["nfm_bank_u8_s16", "wfm_bank_u8_s16"])
+def test_cli_bank_rate_per_stream_and_control_channel(port, tmp_path, cmd):
+    """`csdr nfm_bank_u8_s16 | wfm_bank_u8_s16 --ctl <fifo> r0,r1,r2 ...`: a shift rate per stream (ddcd tunes every client on its own, ddcd_old.h:51-61) and
+    retunes over a control channel, lines "<stream> <rate>" (the `--fifo` protocol of shift_addition_cc, csdr.c:881-893, with a stream number in front).  The line
+    is in the fifo before the process starts, so it is applied in front of the first pass: stream 1 runs at the NEW rate from its first sample (the mid-stream case,
+    with its two-rate window, is tests/test_rates_gpu.py's)."""
+    from tests_helpers import nfm_signal_u8, wfm_signal_u8
+    nfm = cmd.startswith("nfm")
     n = 3 * 65536 + 5 * 1024
     rates = [-0.05, 0.3, 0.1234]
     new1 = -0.2
     eff = [rates[0], new1, rates[2]]
-    sig = [nfm_signal_u8(950 + k, n, offset=-eff[k]) for k in range(3)]
+    sig = [(nfm_signal_u8 if nfm else wfm_signal_u8)(950 + k, n, offset=-eff[k]) for k in range(3)]
     ctl = tmp_path / "ctl.fifo"; os.mkfifo(ctl)
     keep = os.open(ctl, os.O_RDWR)                      # keeps the fifo open for writing while the command runs
     os.write(keep, b"1 %g\n" % new1)
-    args = ["nfm_bank_u8_s16", "--ctl", str(ctl), ",".join("%g" % r for r in rates)]
+    args = [cmd, "--ctl", str(ctl), ",".join("%g" % r for r in rates)]
     outs = []
     for k in range(3):
         fi = tmp_path / ("in%d.u8" % k); fo = tmp_path / ("out%d.s16" % k)
@@ -658,8 +660,11 @@ def test_cli_nfm_bank_rate_per_stream_and_control_channel(port, tmp_path):
     taps48 = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
     for k in range(3):
         got = np.fromfile(outs[k], np.int16)
-        want, _ = port.nfm_chain(sig[k], eff[k], taps48)
+        if nfm:
+            want, _ = port.nfm_chain(sig[k], eff[k], taps48)
+        else:
+            want, _ = port.wfm_chain(sig[k], eff[k], 10, port.firdes_lowpass_f(79, 0.05))
         m = min(got.size, want.size)
-        assert m > 0 and abs(got.size - want.size) <= 1024
+        assert m > 0 and abs(got.size - want.size) <= (1024 if nfm else 2)
         d = np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32))
         assert d.max() <= 1 and (d > 0).mean() < 0.05, "stream %d" % k

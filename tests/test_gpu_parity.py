@@ -588,3 +588,14 @@ def test_adpcm_decode_scans_bit_exact(gpu, port):
     y = gpu.download(do, np.int16, S2 * pitch_out).reshape(S2, pitch_out)[:, :2 * n]
     for s in range(S2):
         assert np.array_equal(y[s], port.decode_ima_adpcm_u8_i16(x[s])[0])
+    # many short streams: the one-lane-per-stream kernel is chosen (adpcm.hip's estimate); a start index outside the step table is clamped to it (the reference
+    # would read past its table, ima_adpcm.c:110) -- on either kernel
+    for S3, n3 in ((16384, 100), (8, 5000)):
+        x = rng.integers(0, 256, (S3, n3), dtype=np.uint8)
+        st = np.zeros((S3, 2), np.int32); st[:, 0] = rng.integers(0, 89, S3); st[:, 1] = rng.integers(-32768, 32768, S3)
+        st[0] = (200, 5); st[1] = (-7, 5)
+        got, gs = gpu.decode_ima_adpcm_u8_i16(x, st)
+        for s_ in list(range(0, S3, 97)) + [1]:
+            i0 = min(max(int(st[s_, 0]), 0), 88)
+            want, ws = port.decode_ima_adpcm_u8_i16(x[s_], (i0, int(st[s_, 1])))
+            assert np.array_equal(got[s_], want) and [int(v) for v in gs[s_]] == [int(v) for v in ws], (S3, s_)

@@ -157,8 +157,10 @@ def test_wfm_rates_single_call(gpu, port, n, S, want_float):
             assert relrms(af[s, :m], pf[:m]) <= TOL
 
 
-def test_wfm_rates_blocks_and_retune(gpu, port):
-    """Consecutive calls (tables switched on the side stream, history heads, de-emphasis state across calls and columns), bit-identical to the single call; then
+@pytest.mark.parametrize("out_per_call", [False, True])
+def test_wfm_rates_blocks_and_retune(gpu, port, out_per_call):
+    """(out_per_call: every call stores at the start of aligned rows -- the line-collecting store path, with calls that start in the middle of a tile.)
+    Consecutive calls (tables switched on the side stream, history heads, de-emphasis state across calls and columns), bit-identical to the single call; then
     csdr_amd_wfm_set_rate between calls: new rate from the next block's first sample, phase carried (csdr.c:881-923) -- the oracle retunes its shift stage there."""
     taps = port.firdes_lowpass_f(79, 0.05)
     S = 4
@@ -167,14 +169,14 @@ def test_wfm_rates_blocks_and_retune(gpu, port):
     rates = np.array(WRATES[:S], f32)
     u8 = np.stack([wfm_signal_u8(2100 + s, n, offset=-float(rates[s])) for s in range(S)])
     a, _ = gpu.wfm_chain(u8, rates, 10, taps, want_float=False)
-    b, _ = gpu.wfm_chain(u8, rates, 10, taps, block=sizes, want_float=False)
+    b, _ = gpu.wfm_chain(u8, rates, 10, taps, block=sizes, want_float=False, out_per_call=out_per_call)
     m = min(a.shape[1], b.shape[1])
     assert m >= a.shape[1] - 2 and vc.s16_diff(a[:, :m], b[:, :m]).max() <= 1      # (column boundaries differ between the two runs: the warm-up's 5e-8)
     # retune stream 1 in front of the third call: its signal moves with it
     pos = int(np.cumsum([0] + sizes)[2])
     u8r = u8.copy()
     u8r[1] = np.concatenate([wfm_signal_u8(2200, pos, offset=-0.11), wfm_signal_u8(2201, n - pos, offset=0.3)])
-    c, _ = gpu.wfm_chain(u8r, rates, 10, taps, block=sizes, retunes={2: [(1, -0.3)]}, want_float=False)
+    c, _ = gpu.wfm_chain(u8r, rates, 10, taps, block=sizes, retunes={2: [(1, -0.3)]}, want_float=False, out_per_call=out_per_call)
     xf = port.convert_u8_f(u8r[1]).view(c64)
     s1, ph = port.shift_addition_cc(xf[:pos], 0.11)
     s2, _ = port.shift_addition_cc(xf[pos:], -0.3, phase=ph)

@@ -118,6 +118,42 @@ def test_loopback_broadcast_and_failure(gpu):
     L.csdr_amd_loopback_destroy(grp)
 
 
+def test_loopback_local_error_does_not_stall_the_group(gpu):
+    """a rank whose group fails locally (two sends to one peer) clears what it published and fails the others' rendezvous AT ONCE -- not after the 60 s of a
+    rank that never arrives; the group stays broken for later calls"""
+    import threading
+    import time
+    import ctypes as C
+    import csdr_amd
+    L = gpu.L
+    L.csdr_amd_debug_comm_exchange.restype = C.c_int
+    L.csdr_amd_debug_comm_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    grp = L.csdr_amd_loopback_create(2)
+    got = [None, None]
+
+    def rank_main(r):
+        ctx = csdr_amd.Context(0)
+        comm = L.csdr_amd_comm_create_loopback(ctx.h, grp, r)
+        a = ctx.upload(np.full(256, r + 1, np.float32)); b = ctx.alloc(1024)
+        t0 = time.perf_counter()
+        rc1 = L.csdr_amd_debug_comm_exchange(comm, a.ptr, b.ptr, 256, 1 - r, 1)          # a good group first
+        v = ctx.download(b, np.float32, 256).copy()
+        rc2 = L.csdr_amd_debug_comm_exchange(comm, a.ptr, b.ptr, 256, 1 - r, 2 if r == 0 else 1)
+        e2 = ctx.err()
+        rc3 = L.csdr_amd_debug_comm_exchange(comm, a.ptr, b.ptr, 256, 1 - r, 1)
+        got[r] = (rc1, v, rc2, e2, rc3, time.perf_counter() - t0)
+        L.csdr_amd_comm_destroy(comm); ctx.close()
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    for r in range(2):
+        rc1, v, rc2, e2, rc3, dt = got[r]
+        assert rc1 == 0 and (v == 2 - r).all()
+        assert rc2 < 0 and rc3 < 0 and dt < 10.0, got[r]
+    assert "two sends" in got[0][3] and "did not arrive" in got[1][3]
+    L.csdr_amd_loopback_destroy(grp)
+
+
 def test_null_transport_times_one_rank(gpu):
     """csdr_amd_comm_create_null: rank 3 of 8 with no peers -- the calls of a world-8 schedule go through (what bench_fastddc.py --emulate-world times)"""
     L = gpu.L
