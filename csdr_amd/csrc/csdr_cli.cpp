@@ -17,6 +17,8 @@
 // Fusion (the part of f1 that a process-per-command shell pipeline cannot give): `csdr chain "<cmd> <args> | <cmd> <args> | ..."` runs
 // the listed hot-path commands in ONE process with every intermediate stream resident in HBM (PCIe carries only the first input and the
 // last output), and replaces the README.md:66 WFM pattern by the fused matrix-core kernel.
+// Device hand-off between ADJACENT csdr processes of an unchanged shell pipeline (`csdr a | csdr b`): see "device hand-off" below -- the samples stay in
+// HBM, the pipe between the two processes carries nothing but the preamble.  Negotiated out of band, so a peer that is not this binary sees plain bytes.
 // There is no CPU fallback: without a gfx950 device the process exits with status 3 and the reason on stderr.
 #include "../../include/csdr_amd.h"
 #include <hip/hip_runtime_api.h>
@@ -31,6 +33,10 @@
 #include <unistd.h>
 #include <poll.h>
 #include <pthread.h>
+#include <sys/socket.h>
+#include <sys/stat.h>
+#include <sys/un.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -69,6 +75,7 @@ struct Stage {
     virtual int next_bufsize(int b) { return b; }                   // what the reference passes to sendbufsize() for this command
     virtual const char *ctl_format() { return nullptr; }            // scanf format of a control line, if the command has a control channel
     virtual void retune(csdr_amd_ctx *, float, float) {}
+    struct Control *ctl = nullptr;                                  // its open control channel (--fifo / --fd), polled in front of every pass (also inside `chain`)
 };
 
 struct Convert : Stage {
@@ -299,14 +306,18 @@ struct DdcInv : Stage {   // csdr.c:2302-2378
 };
 
 struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (extension: not in the reference's command list)
-    csdr_amd_wfm *w;
-    WfmChain(csdr_amd_ctx *c, float shift, size_t block)
+    csdr_amd_wfm *w; bool retunable;
+    const char *ctl_format() override { return retunable ? "%g\n" : nullptr; }       // `wfm_chain_u8_s16 --fifo <path>`: the shift stage's control channel (csdr.c:881-923)
+    void retune(csdr_amd_ctx *, float r, float) override { MUST(csdr_amd_wfm_set_rate(w, 0, r)); fprintf(stderr, "csdr %s: reinitialized to %g\n", g_cmd, r); }
+    WfmChain(csdr_amd_ctx *c, float shift, size_t block, bool with_ctl) : retunable(with_ctl)
     {
         in_elem = 2; out_elem = 2; granule = 1024;
         std::vector<float> t(79);
         const int nt = csdr_amd_firdes_filter_len(0.05f);
         t.resize(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.05f, CSDR_WINDOW_HAMMING);
-        w = csdr_amd_wfm_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024); if (!w) die("wfm_create");
+        // (with a control channel: the rate-per-stream object, whose one stream can be retuned between two calls)
+        w = with_ctl ? csdr_amd_wfm_create_rates(c, 1, &shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024) : csdr_amd_wfm_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024);
+        if (!w) die("wfm_create");
         if (csdr_amd_wfm_fallback(w)) fprintf(stderr, "csdr %s: note: this shape runs on the fallback kernels (k_wfm_front + k_wfm_back), not on the matrix-core chain kernel\n", g_cmd);
     }
     size_t out_capacity(size_t n) override { return n / 50 + 64; }
@@ -316,13 +327,16 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
 };
 
 struct DdcFront : Stage {   // convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw window as ONE command (extension): the head of the NFM / AM / SSB chains
-    csdr_amd_ddc *d; int dec;
-    DdcFront(csdr_amd_ctx *c, float shift, int D, float tbw, int window, size_t block) : dec(D)
+    csdr_amd_ddc *d; int dec; bool retunable;
+    const char *ctl_format() override { return retunable ? "%g\n" : nullptr; }
+    void retune(csdr_amd_ctx *, float r, float) override { MUST(csdr_amd_ddc_set_rate(d, 0, r)); fprintf(stderr, "csdr %s: reinitialized to %g\n", g_cmd, r); }
+    DdcFront(csdr_amd_ctx *c, float shift, int D, float tbw, int window, size_t block, bool with_ctl) : dec(D), retunable(with_ctl)
     {
         in_elem = 2; out_elem = 8; granule = 1024;
         const int nt = csdr_amd_firdes_filter_len(tbw);
         std::vector<float> t(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.5f / (float)D, window);       // csdr.c:1144-1158
-        d = csdr_amd_ddc_create(c, 1, shift, D, t.data(), nt, block + 1024); if (!d) die("ddc_create");
+        d = with_ctl ? csdr_amd_ddc_create_rates(c, 1, &shift, D, t.data(), nt, block + 1024) : csdr_amd_ddc_create(c, 1, shift, D, t.data(), nt, block + 1024);
+        if (!d) die("ddc_create");
     }
     size_t out_capacity(size_t n) override { return n / dec + 64; }
     int next_bufsize(int b) override { return b / dec; }
@@ -336,13 +350,17 @@ struct DdcFront : Stage {   // convert_u8_f | shift_addition_cc r | fir_decimate
 };
 
 struct NfmChain : Stage {   // the README.md:87 chain as ONE command (extension)
-    csdr_amd_nfm *w; int dec;
-    NfmChain(csdr_amd_ctx *c, float shift, int D, float tbw, size_t block) : dec(D)
+    csdr_amd_nfm *w; int dec; bool retunable;
+    const char *ctl_format() override { return retunable ? "%g\n" : nullptr; }
+    void retune(csdr_amd_ctx *, float r, float) override { MUST(csdr_amd_nfm_set_rate(w, 0, r)); fprintf(stderr, "csdr %s: reinitialized to %g\n", g_cmd, r); }
+    NfmChain(csdr_amd_ctx *c, float shift, int D, float tbw, size_t block, bool with_ctl) : dec(D), retunable(with_ctl)
     {
         in_elem = 2; out_elem = 2; granule = 1024;
         const int nt = csdr_amd_firdes_filter_len(tbw);
         std::vector<float> t(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.5f / (float)D, CSDR_WINDOW_HAMMING);
-        w = csdr_amd_nfm_create(c, 1, shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024); if (!w) die("nfm_create");   // fastagc_ff defaults csdr.c:1379-1391
+        w = with_ctl ? csdr_amd_nfm_create_rates(c, 1, &shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024)
+                     : csdr_amd_nfm_create(c, 1, shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024);      // fastagc_ff defaults csdr.c:1379-1391
+        if (!w) die("nfm_create");
     }
     size_t out_capacity(size_t n) override { return n / dec + 4096; }
     int next_bufsize(int b) override { return b / dec; }
@@ -564,6 +582,109 @@ struct Control {
     void wait_first(const char *fmt, float *a, float *b) { while (!poll(fmt, a, b)) usleep(10000); }
 };
 
+
+// ------------------------------------------------------------------ device hand-off between adjacent csdr processes
+// north_star: "the stdin->stdout pipe never round-trips to host between stages ... existing shell pipelines drop in unchanged".  In `csdr a | csdr b` both
+// ends of the pipe are this binary, both talk to the same GPU, and the samples a produces are already in HBM: writing them to the pipe costs a D2H copy, two
+// pipe copies and an H2D copy per stage.  Instead:
+//   * b (the consumer), first thing in main(), listens on an abstract unix socket named after the PIPE it reads (st_dev:st_ino of fd 0 -- both ends of a pipe
+//     report the same inode);
+//   * a (the producer), just before it would write its first byte, tries to connect to the socket named after fd 1.  No listener (the consumer is some other
+//     program, or stdout is no pipe): plain bytes, as ever -- a foreign peer never sees anything but the reference's wire format.  Connected: a sends HELLO with
+//     the HIP IPC handle of a ring of NBUF output slots in its device memory; b maps it (hipIpcOpenMemHandle) and answers ACK, or NAK (another device, IPC not
+//     available in this container, ...) after which both fall back to bytes;
+//   * b decides with one poll() on {stdin, listener}: a connection means hand-off, bytes (or EOF) on stdin mean a producer that writes bytes;
+//   * per block a writes its result into a free slot, waits for the kernels (stream-ordered event), sends the token {slot, bytes} over the socket; b copies
+//     the slot into its own input buffer device-to-device on its stream and returns the slot as a credit once that copy has run.  End of stream = the socket
+//     closes.  The 8-byte "csdr"+int preamble of CSDR_DYNAMIC_BUFSIZE_ON still travels through the pipe itself.
+// CSDR_AMD_IPC=0 switches the whole mechanism off; CSDR_AMD_IPC_WAIT_MS (default 50) is how long a producer keeps trying to find a listener that is not there
+// yet (a consumer of ours listens within a millisecond of its exec, long before the producer's HIP start-up is over); CSDR_AMD_IPC_VERBOSE=1 prints one line
+// per link on stderr.
+struct IpcHello { char magic[8]; int version, device; char bus_id[32]; hipIpcMemHandle_t mem; unsigned n_slots, reserved; unsigned long long slot_bytes; };
+struct IpcToken { unsigned slot, reserved; unsigned long long bytes; };
+const char IPC_MAGIC[8] = {'c', 's', 'd', 'r', 'H', 'B', 'M', '1'};
+int g_ipc_listen = -1;                       // consumer side: the listening socket named after stdin's pipe
+bool ipc_enabled() { const char *e = getenv("CSDR_AMD_IPC"); return !e || atoi(e) != 0; }
+bool ipc_verbose() { const char *e = getenv("CSDR_AMD_IPC_VERBOSE"); return e && atoi(e) != 0; }
+bool ipc_pipe_name(int fd, struct sockaddr_un *sa, socklen_t *len)
+{
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISFIFO(st.st_mode)) return false;
+    memset(sa, 0, sizeof *sa); sa->sun_family = AF_UNIX;
+    const int n = snprintf(sa->sun_path + 1, sizeof sa->sun_path - 1, "csdr_amd.pipe.%llx.%llx", (unsigned long long)st.st_dev, (unsigned long long)st.st_ino);
+    *len = (socklen_t)(offsetof(struct sockaddr_un, sun_path) + 1 + n);                 // abstract name: leading NUL, no file system entry to clean up
+    return true;
+}
+void ipc_listen_on_stdin()
+{
+    struct sockaddr_un sa; socklen_t len;
+    if (!ipc_enabled() || !ipc_pipe_name(STDIN_FILENO, &sa, &len)) return;
+    const int fd = socket(AF_UNIX, SOCK_SEQPACKET | SOCK_CLOEXEC, 0);
+    if (fd < 0) return;
+    if (bind(fd, (struct sockaddr *)&sa, len) != 0 || listen(fd, 1) != 0) { close(fd); return; }
+    g_ipc_listen = fd;
+}
+void ipc_device_id(int device, char bus_id[32]) { memset(bus_id, 0, 32); if (hipDeviceGetPCIBusId(bus_id, 32, device) != hipSuccess) bus_id[0] = 0; }
+
+// consumer: blocks until the producer has connected (-> the connected socket, ring mapped) or has started to write bytes / closed the pipe (-> -1).  Once.
+struct IpcSource { int fd = -1; char *ring = nullptr; unsigned n_slots = 0; size_t slot_bytes = 0; };
+bool g_ipc_source_decided = false; IpcSource g_ipc_source;
+IpcSource *ipc_source_decide(int device)
+{
+    if (g_ipc_source_decided) return g_ipc_source.fd >= 0 ? &g_ipc_source : nullptr;
+    g_ipc_source_decided = true;
+    if (g_ipc_listen < 0) return nullptr;
+    int conn = -1;
+    for (;;) {
+        struct pollfd pf[2] = {{g_ipc_listen, POLLIN, 0}, {STDIN_FILENO, POLLIN, 0}};
+        if (poll(pf, 2, -1) < 0) { if (errno == EINTR) continue; break; }
+        if (pf[0].revents & POLLIN) { conn = accept4(g_ipc_listen, nullptr, nullptr, SOCK_CLOEXEC); break; }      // (checked first: a producer of ours connects BEFORE it writes the preamble)
+        if (pf[1].revents) break;                                                                                  // bytes, EOF or an error on stdin: a producer that writes bytes
+    }
+    close(g_ipc_listen); g_ipc_listen = -1;
+    if (conn < 0) return nullptr;
+    IpcHello h; int ack = 0;
+    char mine[32]; ipc_device_id(device, mine);
+    void *ring = nullptr;
+    if (recv(conn, &h, sizeof h, 0) == (ssize_t)sizeof h && !memcmp(h.magic, IPC_MAGIC, 8) && h.version == 1 && mine[0] && !strncmp(h.bus_id, mine, 32) &&
+        hipIpcOpenMemHandle(&ring, h.mem, hipIpcMemLazyEnablePeerAccess) == hipSuccess) ack = 1;
+    else (void)hipGetLastError();
+    if (send(conn, &ack, sizeof ack, MSG_NOSIGNAL) != (ssize_t)sizeof ack) ack = 0;
+    if (!ack) { if (ipc_verbose()) fprintf(stderr, "csdr %s: device hand-off from the previous process refused (another device, or HIP IPC is not available): bytes through the pipe\n", g_cmd); close(conn); return nullptr; }
+    g_ipc_source.fd = conn; g_ipc_source.ring = (char *)ring; g_ipc_source.n_slots = h.n_slots; g_ipc_source.slot_bytes = (size_t)h.slot_bytes;
+    if (ipc_verbose()) fprintf(stderr, "csdr %s: input arrives by device hand-off (%u slots of %zu bytes in the previous process's HBM ring)\n", g_cmd, h.n_slots, g_ipc_source.slot_bytes);
+    return &g_ipc_source;
+}
+
+// producer: -> connected socket after HELLO / ACK, or -1 (bytes).  `ring`: n_slots * slot_bytes of device memory from hipMalloc (the base of the allocation)
+int ipc_sink_connect(int device, void *ring, unsigned n_slots, size_t slot_bytes)
+{
+    struct sockaddr_un sa; socklen_t len;
+    if (!ipc_enabled() || !ipc_pipe_name(STDOUT_FILENO, &sa, &len)) return -1;
+    long wait_ms = 50; if (const char *e = getenv("CSDR_AMD_IPC_WAIT_MS")) wait_ms = atol(e);
+    int fd = -1;
+    struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        fd = socket(AF_UNIX, SOCK_SEQPACKET | SOCK_CLOEXEC, 0);
+        if (fd < 0) return -1;
+        if (connect(fd, (struct sockaddr *)&sa, len) == 0) break;
+        close(fd); fd = -1;
+        struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000 >= wait_ms) return -1;
+        usleep(2000);
+    }
+    IpcHello h; memset(&h, 0, sizeof h);
+    memcpy(h.magic, IPC_MAGIC, 8); h.version = 1; h.device = device; ipc_device_id(device, h.bus_id); h.n_slots = n_slots; h.slot_bytes = slot_bytes;
+    int ack = 0;
+    if (hipIpcGetMemHandle(&h.mem, ring) != hipSuccess) { (void)hipGetLastError(); memset(h.magic, 0, 8); }      // (an invalid HELLO: the consumer answers NAK)
+    if (send(fd, &h, sizeof h, MSG_NOSIGNAL) != (ssize_t)sizeof h || recv(fd, &ack, sizeof ack, 0) != (ssize_t)sizeof ack || !ack) {
+        if (ipc_verbose()) fprintf(stderr, "csdr %s: device hand-off to the next process refused: bytes through the pipe\n", g_cmd);
+        close(fd); return -1;
+    }
+    if (ipc_verbose()) fprintf(stderr, "csdr %s: output leaves by device hand-off (%u slots of %zu bytes)\n", g_cmd, n_slots, slot_bytes);
+    return fd;
+}
+
 // ------------------------------------------------------------------ the streaming loop: one or more stages, intermediates in HBM
 // Host side = three threads around the GPU work so that read(), PCIe and write() overlap (the reference overlaps them with one process per
 // command): a READER fills pinned buffers from stdin, the main thread queues H2D -> kernels -> D2H on the context's stream without waiting,
@@ -571,7 +692,8 @@ struct Control {
 // Latency: the reader hands a block on as soon as `min_elems` elements have arrived (the reference's the_bufsize, csdr.c:232-247, 332, rounded up to
 // the operator's granule) and only takes more when more is ALREADY waiting in the pipe, up to CSDR_AMD_BLOCK elements: a live 2.4 MS/s or 48 kS/s
 // stream moves in the reference's own block sizes (6.8 ms / 21 ms), a file or a fast producer in large blocks.
-struct HostBuf { char *p = nullptr; size_t cap = 0, bytes = 0; bool eof = false; hipEvent_t ev = nullptr; bool pending = false; };
+struct HostBuf { char *p = nullptr; size_t cap = 0, bytes = 0; bool eof = false; hipEvent_t ev = nullptr; bool pending = false;
+                 const char *dev = nullptr; int slot = -1; };       // device hand-off: where the block lies in the producer's ring; the slot to give back once it is copied (-1: not the slot's last piece)
 struct BufQueue {
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cv = PTHREAD_COND_INITIALIZER; std::vector<HostBuf *> q;
     void push(HostBuf *b) { pthread_mutex_lock(&mu); q.push_back(b); pthread_cond_signal(&cv); pthread_mutex_unlock(&mu); }
@@ -580,6 +702,8 @@ struct BufQueue {
 struct IoThreads {
     int device = 0; size_t min_bytes = 0, max_bytes = 0;
     BufQueue free_in, full_in, free_out, full_out;
+    IpcSource *src = nullptr; BufQueue copied_in;                    // device hand-off, consumer side: blocks whose device copy is queued (their slots go back as credits)
+    int sink_fd = -1; HostBuf *sink_bufs = nullptr;                  // producer side: tokens out, credits back; sink_bufs[slot]
 };
 
 // blocks until min_bytes have arrived (or EOF / error), then keeps reading only while more is immediately available
@@ -629,9 +753,64 @@ void *writer_main(void *arg)
     }
 }
 
+// ---- device hand-off variants of the two I/O threads (+ one thread per direction for the credits)
+void *reader_ipc_main(void *arg)
+{
+    IoThreads *io = (IoThreads *)arg;
+    for (;;) {
+        IpcToken t;
+        const ssize_t r = recv(io->src->fd, &t, sizeof t, 0);
+        const bool eof = r != (ssize_t)sizeof t || t.slot >= io->src->n_slots || t.bytes > io->src->slot_bytes;
+        if (eof) { HostBuf *b = io->free_in.pop(); b->bytes = 0; b->eof = true; b->dev = nullptr; b->slot = -1; io->full_in.push(b); return nullptr; }
+        size_t off = 0;
+        do {                                                         // at most max_bytes per pass, like the byte reader: a token may be cut into several blocks
+            HostBuf *b = io->free_in.pop();
+            const size_t k = (size_t)t.bytes - off < io->max_bytes ? (size_t)t.bytes - off : io->max_bytes;
+            b->dev = io->src->ring + (size_t)t.slot * io->src->slot_bytes + off; b->bytes = k; b->eof = false;
+            off += k; b->slot = off == t.bytes ? (int)t.slot : -1;
+            io->full_in.push(b);
+        } while (off < t.bytes);
+    }
+}
+void *credit_out_main(void *arg)
+{   // consumer: a block's device copy has run -> its slot goes back to the producer
+    IoThreads *io = (IoThreads *)arg;
+    (void)hipSetDevice(io->device);
+    for (;;) {
+        HostBuf *b = io->copied_in.pop();
+        if (b->eof) return nullptr;
+        if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }
+        if (b->slot >= 0) { const int s = b->slot; (void)send(io->src->fd, &s, sizeof s, MSG_NOSIGNAL); }
+        io->free_in.push(b);
+    }
+}
+void *writer_ipc_main(void *arg)
+{
+    IoThreads *io = (IoThreads *)arg;
+    (void)hipSetDevice(io->device);
+    for (;;) {
+        HostBuf *b = io->full_out.pop();
+        if (b->eof) { shutdown(io->sink_fd, SHUT_WR); return nullptr; }
+        if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }          // the kernels that filled the slot have run
+        IpcToken t = {(unsigned)b->slot, 0u, (unsigned long long)b->bytes};
+        if (send(io->sink_fd, &t, sizeof t, MSG_NOSIGNAL) != (ssize_t)sizeof t) _exit(0);   // downstream closed: end quietly like SIGPIPE would
+    }
+}
+void *credit_in_main(void *arg)
+{   // producer: slots the consumer has copied out
+    IoThreads *io = (IoThreads *)arg;
+    for (;;) {
+        int s = -1;
+        const ssize_t r = recv(io->sink_fd, &s, sizeof s, 0);
+        if (r == 0) return nullptr;                                                         // the consumer is done (after our shutdown)
+        if (r != (ssize_t)sizeof s || s < 0) _exit(0);
+        io->free_out.push(&io->sink_bufs[s]);
+    }
+}
+
 struct Link { Stage *s; char *d_in[2] = {nullptr, nullptr}; char *d_stage = nullptr; int cur = 0; size_t cap_b = 0, have_b = 0; };   // byte counts: a pipe carries bytes,
                                                                                                                // the reader picks the element size
-int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps, Control *ctl, int in_bufsize, int device)
+int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps, int in_bufsize, int out_bufsize, int device)
 {
     const size_t n_st = stages.size();
     std::vector<Link> L(n_st);
@@ -652,9 +831,23 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
     if (min_elems % first->granule) min_elems += first->granule - min_elems % first->granule;
     if (min_elems > block) min_elems = block;
     io.min_bytes = min_elems * first->in_elem; io.max_bytes = block * first->in_elem;
+    // device hand-off with the neighbours in the shell pipeline, where they are this binary too (see above): input side decided by now or here, output side offered here
+    io.src = ipc_source_decide(device);
+    char *ring_out = nullptr;
+    const size_t slot_bytes = (cap_out * last->out_elem + 255) & ~(size_t)255;
+    {
+        struct stat so;
+        if (ipc_enabled() && fstat(STDOUT_FILENO, &so) == 0 && S_ISFIFO(so.st_mode) && hipMalloc((void **)&ring_out, NBUF * slot_bytes) == hipSuccess) {
+            io.sink_fd = ipc_sink_connect(device, ring_out, NBUF, slot_bytes);
+            if (io.sink_fd < 0) { (void)hipFree(ring_out); ring_out = nullptr; }
+        }
+    }
+    io.sink_bufs = hout;
+    send_bufsize(out_bufsize);                                       // csdr.c:375-391, through the pipe itself in either mode
     for (int k = 0; k < NBUF; k++) {
-        hin[k].cap = io.max_bytes + 64; hout[k].cap = cap_out * last->out_elem;
-        if (hipHostMalloc((void **)&hin[k].p, hin[k].cap, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&hout[k].p, hout[k].cap, hipHostMallocDefault) != hipSuccess ||
+        hin[k].cap = io.max_bytes + 64; hout[k].cap = cap_out * last->out_elem; hout[k].slot = k;
+        if ((!io.src && hipHostMalloc((void **)&hin[k].p, hin[k].cap, hipHostMallocDefault) != hipSuccess) ||
+            (io.sink_fd < 0 && hipHostMalloc((void **)&hout[k].p, hout[k].cap, hipHostMallocDefault) != hipSuccess) ||
             hipEventCreateWithFlags(&hin[k].ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&hout[k].ev, hipEventDisableTiming) != hipSuccess) {
             fprintf(stderr, "csdr %s: cannot allocate pinned host buffers\n", g_cmd); exit(3);
         }
@@ -663,8 +856,11 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
 #ifdef F_SETPIPE_SZ
     (void)fcntl(STDIN_FILENO, F_SETPIPE_SZ, 1 << 20); (void)fcntl(STDOUT_FILENO, F_SETPIPE_SZ, 1 << 20);      // fewer, larger pipe transfers (ignored for files)
 #endif
-    pthread_t th_r, th_w;
-    if (pthread_create(&th_r, nullptr, reader_main, &io) || pthread_create(&th_w, nullptr, writer_main, &io)) { fprintf(stderr, "csdr %s: cannot start the I/O threads\n", g_cmd); exit(3); }
+    pthread_t th_r, th_w, th_ci, th_co;
+    if (pthread_create(&th_r, nullptr, io.src ? reader_ipc_main : reader_main, &io) || pthread_create(&th_w, nullptr, io.sink_fd >= 0 ? writer_ipc_main : writer_main, &io) ||
+        (io.src && pthread_create(&th_co, nullptr, credit_out_main, &io)) || (io.sink_fd >= 0 && pthread_create(&th_ci, nullptr, credit_in_main, &io))) {
+        fprintf(stderr, "csdr %s: cannot start the I/O threads\n", g_cmd); exit(3);
+    }
     void *d_out = csdr_amd_malloc(c, cap_out * last->out_elem + 256);
     if (!d_out) die("device buffers");
     // After EOF the pass is repeated (a few times at most) while some stage still consumes input: an operator that works through its input in
@@ -680,13 +876,14 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             Link &l0 = L[0];
             if (l0.have_b + b->bytes > l0.cap_b) { fprintf(stderr, "csdr %s: block of %zu elements is too small for this operator (raise CSDR_AMD_BLOCK)\n", g_cmd, block); rc = 1; break; }
             if (b->bytes) {
-                if (hipMemcpyAsync(l0.d_in[l0.cur] + l0.have_b, b->p, b->bytes, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(b->ev, st) != hipSuccess) die("upload");
+                if (hipMemcpyAsync(l0.d_in[l0.cur] + l0.have_b, b->dev ? (const void *)b->dev : (const void *)b->p, b->bytes, b->dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipEventRecord(b->ev, st) != hipSuccess) die("upload");
                 b->pending = true; l0.have_b += b->bytes;
             }
-            if (!eof) io.free_in.push(b);
+            if (!eof) (io.src ? io.copied_in : io.free_in).push(b);      // (hand-off: the slot goes back once the copy has run)
         }
         bool progressed = false;
-        if (ctl && ctl->fd && first->ctl_format()) { float a, b2; if (ctl->poll(first->ctl_format(), &a, &b2)) first->retune(c, a, b2); }
+        for (Stage *s : stages) if (s->ctl && s->ctl->fd && s->ctl_format()) { float a, b2; if (s->ctl->poll(s->ctl_format(), &a, &b2)) s->retune(c, a, b2); }
         // a pass hands the first operator at most `block` elements (what the operators were sized for); what is left waits for the next pass
         size_t n_in = L[0].have_b / first->in_elem;
         const bool all_of_it = n_in <= block;
@@ -733,7 +930,8 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
             HostBuf *ob = io.free_out.pop();
             ob->bytes = (size_t)n_out * last->out_elem;
             if (ob->bytes > ob->cap) { fprintf(stderr, "csdr %s: output block larger than its staging buffer\n", g_cmd); io.free_out.push(ob); failed = true; break; }
-            if (hipMemcpyAsync(ob->p, d_out, ob->bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(ob->ev, st) != hipSuccess) die("download");
+            if (hipMemcpyAsync(ring_out ? (void *)(ring_out + (size_t)ob->slot * slot_bytes) : (void *)ob->p, d_out, ob->bytes, ring_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipEventRecord(ob->ev, st) != hipSuccess) die("download");
             ob->pending = true;
             // d_out is reused by the next pass: the download is ordered before the next kernels on the same stream
             io.full_out.push(ob);
@@ -747,6 +945,8 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
     hout[NBUF].eof = true; io.full_out.push(&hout[NBUF]);
     pthread_join(th_w, nullptr);
     (void)hipStreamSynchronize(st);
+    if (io.src) { HostBuf end; end.eof = true; io.copied_in.push(&end); pthread_join(th_co, nullptr); close(io.src->fd); }
+    if (io.sink_fd >= 0) pthread_join(th_ci, nullptr);               // the ring lives in this process: stay until the consumer has copied the last slot out (it closes the socket then)
     return rc;
 }
 
@@ -1101,22 +1301,29 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
         if (fft <= 0 || (fft & 1)) { badsyntax("fft_size must be positive and even"); return nullptr; }
         return new CompressFft(fft);
     }
-    if (cmd == "ddc_u8_cc") {
-        if (argc <= 3) { badsyntax("need required parameters (shift rate, decimation factor)"); return nullptr; }
-        float shift = 0, tbw = 0.05f; int factor = 0; sscanf(argv[2], "%g", &shift); sscanf(argv[3], "%d", &factor);
-        if (factor < 1) { badsyntax("decimation factor must be >= 1"); return nullptr; }
-        if (argc >= 5) sscanf(argv[4], "%g", &tbw);
-        const int window = argc >= 6 ? window_from(argv[5]) : CSDR_WINDOW_HAMMING;
-        return new DdcFront(c, shift, factor, tbw, window, block);
+    // the fused commands: `--fifo <path>` / `--fd <n>` stand where the shift rate stands, as in shift_addition_cc (csdr.c:881-893); the first rate is waited for
+    if (cmd == "ddc_u8_cc" || cmd == "nfm_chain_u8_s16" || cmd == "wfm_chain_u8_s16") {
+        float shift = 0;
+        int a = 3;                                                   // argv index of the first argument behind the rate
+        if (has_ctl) { float d; ctl->wait_first("%g\n", &shift, &d); a = 4; }
+        else if (argc > 2) sscanf(argv[2], "%g", &shift);
+        else if (cmd == "ddc_u8_cc") { badsyntax("need required parameters (shift rate, decimation factor)"); return nullptr; }
+        if (cmd == "ddc_u8_cc") {
+            if (argc <= a) { badsyntax("need required parameters (shift rate, decimation factor)"); return nullptr; }
+            float tbw = 0.05f; int factor = 0; sscanf(argv[a], "%d", &factor);
+            if (factor < 1) { badsyntax("decimation factor must be >= 1"); return nullptr; }
+            if (argc > a + 1) sscanf(argv[a + 1], "%g", &tbw);
+            const int window = argc > a + 2 ? window_from(argv[a + 2]) : CSDR_WINDOW_HAMMING;
+            return new DdcFront(c, shift, factor, tbw, window, block, has_ctl);
+        }
+        if (cmd == "nfm_chain_u8_s16") {
+            float tbw = 0.005f; int factor = 50;
+            if (argc > a) sscanf(argv[a], "%d", &factor);
+            if (argc > a + 1) sscanf(argv[a + 1], "%g", &tbw);
+            return new NfmChain(c, shift, factor, tbw, block, has_ctl);
+        }
+        return new WfmChain(c, shift, block, has_ctl);
     }
-    if (cmd == "nfm_chain_u8_s16") {
-        float shift = 0, tbw = 0.005f; int factor = 50;
-        if (argc > 2) sscanf(argv[2], "%g", &shift);
-        if (argc > 3) sscanf(argv[3], "%d", &factor);
-        if (argc > 4) sscanf(argv[4], "%g", &tbw);
-        return new NfmChain(c, shift, factor, tbw, block);
-    }
-    if (cmd == "wfm_chain_u8_s16") { float shift = 0; if (argc > 2) sscanf(argv[2], "%g", &shift); return new WfmChain(c, shift, block); }
     fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]);
     return nullptr;
 }
@@ -1136,7 +1343,17 @@ std::vector<std::vector<std::string>> split_chain(const char *spec)
     return out;
 }
 
-bool is_wfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *shift)
+// shift_addition_cc <rate> | shift_addition_cc --fifo <path> | shift_addition_cc --fd <n>: the tokens that stand for the rate (kept as they are in the fused command)
+bool shift_rate_args(const std::vector<std::string> &cmd, std::vector<std::string> *rate_args)
+{
+    if (cmd.size() < 3 || cmd[1] != "shift_addition_cc") return false;
+    if (cmd.size() == 4 && (cmd[2] == "--fifo" || cmd[2] == "--fd")) { rate_args->assign(cmd.begin() + 2, cmd.end()); return true; }
+    float r;
+    if (cmd.size() == 3 && sscanf(cmd[2].c_str(), "%g", &r) == 1) { char sh[64]; snprintf(sh, sizeof sh, "%.9g", r); rate_args->assign(1, sh); return true; }
+    return false;
+}
+
+bool is_wfm_pattern(const std::vector<std::vector<std::string>> &cmds, std::vector<std::string> *rate_args)
 {   // README.md:66 exactly: the shape the fused matrix-core kernel implements
     if (cmds.size() != 7) return false;
     auto is = [&](size_t k, std::initializer_list<const char *> want) {
@@ -1144,12 +1361,12 @@ bool is_wfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *sh
         size_t j = 1; for (const char *w : want) { if (w[0] != '*' && cmds[k][j] != w) return false; j++; }
         return true;
     };
-    if (!is(0, {"convert_u8_f"}) || !is(1, {"shift_addition_cc", "*"}) || !is(2, {"fir_decimate_cc", "10", "0.05", "HAMMING"}) || !is(3, {"fmdemod_quadri_cf"}) ||
+    if (!is(0, {"convert_u8_f"}) || !is(2, {"fir_decimate_cc", "10", "0.05", "HAMMING"}) || !is(3, {"fmdemod_quadri_cf"}) ||
         !is(4, {"fractional_decimator_ff", "5"}) || !is(5, {"deemphasis_wfm_ff", "48000", "50e-6"}) || !is(6, {"convert_f_s16"})) return false;
-    return sscanf(cmds[1][2].c_str(), "%g", shift) == 1;
+    return shift_rate_args(cmds[1], rate_args);
 }
 
-bool is_nfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *shift)
+bool is_nfm_pattern(const std::vector<std::vector<std::string>> &cmds, std::vector<std::string> *rate_args)
 {   // README.md:87 exactly: the shape csdr_amd_nfm implements
     if (cmds.size() != 8) return false;
     auto is = [&](size_t k, std::initializer_list<const char *> want) {
@@ -1157,20 +1374,23 @@ bool is_nfm_pattern(const std::vector<std::vector<std::string>> &cmds, float *sh
         size_t j = 1; for (const char *w : want) { if (w[0] != '*' && cmds[k][j] != w) return false; j++; }
         return true;
     };
-    if (!is(0, {"convert_u8_f"}) || !is(1, {"shift_addition_cc", "*"}) || !is(2, {"fir_decimate_cc", "50", "0.005", "HAMMING"}) || !is(3, {"fmdemod_quadri_cf"}) ||
+    if (!is(0, {"convert_u8_f"}) || !is(2, {"fir_decimate_cc", "50", "0.005", "HAMMING"}) || !is(3, {"fmdemod_quadri_cf"}) ||
         !is(4, {"limit_ff"}) || !is(5, {"deemphasis_nfm_ff", "48000"}) || !is(6, {"fastagc_ff"}) || !is(7, {"convert_f_s16"})) return false;
-    return sscanf(cmds[1][2].c_str(), "%g", shift) == 1;
+    return shift_rate_args(cmds[1], rate_args);
 }
 
 // convert_u8_f | shift_addition_cc r | fir_decimate_cc D [tbw [window]] at the head of a chain -> one ddc_u8_cc command
 bool fuse_front_end(std::vector<std::vector<std::string>> &cmds)
 {
     if (cmds.size() < 3 || cmds[0].size() != 2 || cmds[0][1] != "convert_u8_f") return false;
-    if (cmds[1].size() != 3 || cmds[1][1] != "shift_addition_cc") return false;
+    std::vector<std::string> rate_args;
+    if (!shift_rate_args(cmds[1], &rate_args)) return false;
     if (cmds[2].size() < 3 || cmds[2].size() > 5 || cmds[2][1] != "fir_decimate_cc") return false;
-    float r; int d;
-    if (sscanf(cmds[1][2].c_str(), "%g", &r) != 1 || sscanf(cmds[2][2].c_str(), "%d", &d) != 1 || d < 1) return false;
-    std::vector<std::string> fused = {"csdr", "ddc_u8_cc", cmds[1][2], cmds[2][2]};
+    int d;
+    if (sscanf(cmds[2][2].c_str(), "%d", &d) != 1 || d < 1) return false;
+    std::vector<std::string> fused = {"csdr", "ddc_u8_cc"};
+    fused.insert(fused.end(), rate_args.begin(), rate_args.end());
+    fused.push_back(cmds[2][2]);
     for (size_t k = 3; k < cmds[2].size(); k++) fused.push_back(cmds[2][k]);
     cmds.erase(cmds.begin(), cmds.begin() + 3);
     cmds.insert(cmds.begin(), fused);
@@ -1226,6 +1446,9 @@ int main(int argc, char **argv)
         return 0;
     }
     if (cmd == "fractional_decimator_ff" && argc > 2) { float r = 0; sscanf(argv[2], "%g", &r); if (r == 1) return passthrough(true, 0); }   // csdr.c:1494
+    // device hand-off from the previous process of the shell pipeline (the streaming commands only): listen before anything slow -- the producer looks for this
+    // socket when its first block is ready
+    if (cmd != "fastddc_bank_cc" && cmd != "wfm_bank_u8_s16" && cmd != "nfm_bank_u8_s16") ipc_listen_on_stdin();
     const char *dev = getenv("CSDR_AMD_DEVICE");
     csdr_amd_ctx *c = csdr_amd_ctx_create(dev ? atoi(dev) : 0, nullptr);
     if (!c) { fprintf(stderr, "csdr %s: %s\n", g_cmd, csdr_amd_last_error()); return 3; }
@@ -1233,38 +1456,42 @@ int main(int argc, char **argv)
     if (cmd == "fastddc_bank_cc") return run_bank(c, argc, argv, block);
     if (cmd == "wfm_bank_u8_s16" || cmd == "nfm_bank_u8_s16") return run_stream_bank(c, argc, argv, cmd[0] == 'n');
     std::vector<Stage *> stages; std::vector<size_t> caps;
-    Control ctl;
     std::vector<std::vector<std::string>> cmds;
     if (cmd == "chain") {
         if (argc <= 2) return badsyntax("need the pipeline as one argument: \"<cmd> <args> | <cmd> <args> ...\"");
         cmds = split_chain(argv[2]);
-        float shift = 0;
-        if (is_wfm_pattern(cmds, &shift)) {
+        std::vector<std::string> rate_args;                            // the shift rate, or --fifo <path> / --fd <n> in its place: fusion AND retune
+        if (is_wfm_pattern(cmds, &rate_args)) {
             fprintf(stderr, "csdr chain: WFM receive pattern recognised -> fused matrix-core kernel\n");
-            char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
-            cmds.assign(1, {"csdr", "wfm_chain_u8_s16", sh});
-        } else if (is_nfm_pattern(cmds, &shift) && !g_dynamic && unitround(g_fixed) == 1024) {    // (the chain object models the pipeline at the default buffer size)
+            std::vector<std::string> fused = {"csdr", "wfm_chain_u8_s16"}; fused.insert(fused.end(), rate_args.begin(), rate_args.end());
+            cmds.assign(1, fused);
+        } else if (is_nfm_pattern(cmds, &rate_args) && !g_dynamic && unitround(g_fixed) == 1024) {    // (the chain object models the pipeline at the default buffer size)
             fprintf(stderr, "csdr chain: NFM receive pattern recognised -> fused chain (matrix-core front end and de-emphasis)\n");
-            char sh[64]; snprintf(sh, sizeof sh, "%.9g", shift);
-            cmds.assign(1, {"csdr", "nfm_chain_u8_s16", sh});
+            std::vector<std::string> fused = {"csdr", "nfm_chain_u8_s16"}; fused.insert(fused.end(), rate_args.begin(), rate_args.end());
+            cmds.assign(1, fused);
         } else if (fuse_front_end(cmds)) {
             fprintf(stderr, "csdr chain: convert_u8_f | shift_addition_cc | fir_decimate_cc recognised -> fused matrix-core front end\n");
         }
     } else {
         cmds.assign(1, std::vector<std::string>(argv, argv + argc));
     }
+    if (g_dynamic) ipc_source_decide(dev ? atoi(dev) : 0);           // (before the preamble is read: a producer of ours connects first, then writes it)
     const int in_bufsize = get_bufsize(cmds[0].size() > 1 && (cmds[0][1] == "shift_addition_cc" || cmds[0][1] == "decimating_shift_addition_cc" || cmds[0][1] == "shift_addition_fc"));
     int out_bufsize = in_bufsize;
+    // every command may have its control channel, also inside `chain` (fusion and retune together): the newest complete line is applied in front of a pass
+    std::vector<Control> ctls(cmds.size());
+    bool any_ctl = false;
+    for (auto &cm : cmds) for (auto &t : cm) if (t == "--fifo" || t == "--fd") any_ctl = true;
+    if (any_ctl && block > 65536 && !getenv("CSDR_AMD_BLOCK")) block = 65536;                               // retune latency
     size_t cap = block; bool cap_is_bytes = false;
     for (size_t k = 0; k < cmds.size(); k++) {
         std::vector<char *> av; for (auto &t : cmds[k]) av.push_back(const_cast<char *>(t.c_str()));
         if (av.size() < 2) return badsyntax("empty command in chain");
-        if (cmds.size() > 1 || cmd == "chain") for (auto &t : cmds[k]) if (t == "--fifo" || t == "--fd") return badsyntax("--fifo / --fd control channels are not available inside `chain` (run the command as its own process)");
         // element size of the next command is only known once it is built; size its block for the worst case (1-byte elements) first
-        Stage *s = make_stage(c, (int)av.size(), av.data(), cap, cmds.size() == 1 ? &ctl : nullptr, out_bufsize);
+        Stage *s = make_stage(c, (int)av.size(), av.data(), cap, &ctls[k], out_bufsize);
         if (!s) return -1;
+        if (ctls[k].fd) s->ctl = &ctls[k];
         if (cap_is_bytes) cap = cap / s->in_elem;
-        if (k == 0 && ctl.fd && block > 65536 && !getenv("CSDR_AMD_BLOCK")) cap = block = 65536;        // retune latency
         if (cap < 4 * s->min_block) cap = 4 * s->min_block;
         if (cap < 2 * s->granule) cap = 2 * s->granule;
         if (k == 0) { cap -= cap % s->granule; block = cap; }
@@ -1274,8 +1501,7 @@ int main(int argc, char **argv)
         cap_is_bytes = true;
     }
     g_cmd = argv[1];
-    send_bufsize(out_bufsize);
-    const int rc = run(c, stages, caps, &ctl, in_bufsize, dev ? atoi(dev) : 0);
+    const int rc = run(c, stages, caps, in_bufsize, out_bufsize, dev ? atoi(dev) : 0);      // (sends the preamble: behind the hand-off offer to the next process)
     (void)csdr_amd_ctx_sync(c);
     return rc;
 }

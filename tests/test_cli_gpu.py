@@ -187,16 +187,18 @@ def fm_iq(rng, n):
     return np.clip(np.round(127.5 * (iq + 1)), 0, 255).astype(np.uint8)
 
 
-def wfm_pipeline(cli, iq, block=None):
+def wfm_pipeline(cli, iq, block=None, env_extra=None, stderr_dir=None):
     stages = [["convert_u8_f"], ["shift_addition_cc", "-0.085"], ["fir_decimate_cc", "10", "0.05", "HAMMING"], ["fmdemod_quadri_cf"],
               ["fractional_decimator_ff", "5"], ["deemphasis_wfm_ff", "48000", "50e-6"], ["convert_f_s16"]]
     env = dict(os.environ)
     if block:
         env["CSDR_AMD_BLOCK"] = str(block)
+    env.update(env_extra or {})
     procs = []
     prev = subprocess.PIPE
     for i, st in enumerate(stages):
-        p = subprocess.Popen([cli] + st, stdin=prev if i else subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        err = open(os.path.join(stderr_dir, "err%d.txt" % i), "wb") if stderr_dir else subprocess.DEVNULL
+        p = subprocess.Popen([cli] + st, stdin=prev if i else subprocess.PIPE, stdout=subprocess.PIPE, stderr=err, env=env)
         if i:
             procs[-1].stdout.close()
         prev = p.stdout
@@ -209,6 +211,30 @@ def wfm_pipeline(cli, iq, block=None):
     for p in procs:
         p.wait(timeout=60)
     return np.frombuffer(out, np.int16)
+
+
+def test_cli_device_handoff_between_processes(port, tmp_path):
+    """north_star: "the stdin->stdout pipe never round-trips to host between stages".  The unchanged seven-process shell pipeline of README.md:66: adjacent
+    csdr processes find each other through a socket named after the pipe between them and hand blocks over in HBM (HIP IPC ring + tokens; csdr_cli.cpp "device
+    hand-off"); the first process still reads bytes from a foreign producer, the last still writes bytes.  Same samples as with CSDR_AMD_IPC=0, bit for bit, and
+    as the oracle's chain; every inner link reports the hand-off (or, where HIP IPC is not available to the container, its refusal and the byte fallback)."""
+    iq = fm_iq(np.random.default_rng(19), 1200000)
+    want_s16, _ = port.wfm_chain(iq, -0.085, 10, port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05))
+    d1 = tmp_path / "on"; d1.mkdir()
+    on = wfm_pipeline(CLI, iq, 65536, {"CSDR_AMD_IPC_VERBOSE": "1"}, str(d1))
+    off = wfm_pipeline(CLI, iq, 65536, {"CSDR_AMD_IPC": "0"})
+    assert np.array_equal(on, off)
+    m = min(on.size, want_s16.size)
+    assert m >= want_s16.size - 2
+    d = np.abs(on[:m].astype(np.int32) - want_s16[:m].astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.01
+    errs = [open(d1 / ("err%d.txt" % i)).read() for i in range(7)]
+    handed = [("output leaves by device hand-off" in errs[i], "input arrives by device hand-off" in errs[i + 1]) for i in range(6)]
+    refused = ["refused" in e for e in errs]
+    assert all(a == b for a, b in handed), errs
+    assert all(a for a, _ in handed) or any(refused), errs         # every link hands over in HBM, or says why not
+    assert "hand-off" not in errs[0].split("output leaves")[0] and "output leaves" not in errs[6]      # the ends of the pipeline talk bytes
+    assert all(a for a, _ in handed), "HIP IPC refused on this box: " + " | ".join(errs)
 
 
 def test_cli_wfm_shell_pipeline(port):
@@ -352,6 +378,74 @@ def test_cli_fifo_retune(port, tmp_path):
     assert relrms(got[:4096], a) <= TOL and relrms(got[4096:], b) <= TOL
 
 
+def _read_until_quiet(f, quiet=1.0, limit=60.0):
+    """what a running process has written so far: reads until nothing has arrived for `quiet` seconds"""
+    import select, time
+    out = b""; t_end = time.time() + limit
+    while time.time() < t_end:
+        r, _, _ = select.select([f], [], [], quiet)
+        if not r: break
+        chunk = os.read(f.fileno(), 1 << 20)
+        if not chunk: break
+        out += chunk
+    return out
+
+
+@pytest.mark.parametrize("spec", ["wfm", "ddc", "plain"])
+def test_cli_chain_with_control_channel(port, tmp_path, spec):
+    """`--fifo` INSIDE `csdr chain` (fusion and retune together; each command of the reference has its own control channel, csdr.c:252-323): the README.md:66
+    pattern with `shift_addition_cc --fifo <path>` still becomes the fused WFM kernel, the three-command front end the fused DDC, and a chain without a fused
+    form polls the stage's channel in front of every pass.  First rate from the fifo; a line written while the process waits for input is applied from the next
+    block's first sample, phase carried (csdr.c:881-923)."""
+    from tests_helpers import wfm_signal_u8
+    fifo = str(tmp_path / "ctl"); os.mkfifo(fifo)
+    n1, n2 = 65536, 65536 + 3072
+    r1, r2 = -0.085, 0.21
+    rng = np.random.default_rng(77)
+    if spec == "plain":
+        x = crand(rng, n1 + n2); raw = x.tobytes(); cut = 8 * n1
+        chain = "shift_addition_cc --fifo %s | fmdemod_quadri_cf" % fifo
+    else:
+        u8 = np.concatenate([wfm_signal_u8(31, n1, offset=-r1), wfm_signal_u8(32, n2, offset=-r2)]); raw = u8.tobytes(); cut = 2 * n1
+        chain = "convert_u8_f | shift_addition_cc --fifo %s | fir_decimate_cc 10 0.05 HAMMING" % fifo
+        if spec == "wfm": chain += " | fmdemod_quadri_cf | fractional_decimator_ff 5 | deemphasis_wfm_ff 48000 50e-6 | convert_f_s16"
+    env = dict(os.environ, CSDR_AMD_BLOCK="65536")
+    p = subprocess.Popen([CLI, "chain", chain], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    ctl = open(fifo, "w")
+    ctl.write("%g\n" % r1); ctl.flush()
+    p.stdin.write(raw[:cut]); p.stdin.flush()
+    first = _read_until_quiet(p.stdout)
+    assert first, p.stderr.read().decode()
+    ctl.write("%g\n" % r2); ctl.flush()
+    p.stdin.write(raw[cut:]); p.stdin.close()
+    rest = p.stdout.read(); err = p.stderr.read().decode()
+    ctl.close()
+    assert p.wait(timeout=30) == 0, err
+    assert "reinitialized to 0.21" in err
+    if spec == "wfm": assert "fused matrix-core kernel" in err
+    if spec == "ddc": assert "fused matrix-core front end" in err
+    # the oracle: the shift stage retuned at sample n1, everything behind it as one stream
+    xf = x if spec == "plain" else port.convert_u8_f(u8).view(c64)
+    a, ph = port.shift_addition_cc(xf[:n1], r1)
+    b, _ = port.shift_addition_cc(xf[n1:], r2, phase=ph)
+    sh = np.concatenate([a, b])
+    if spec == "plain":
+        want = port.fmdemod_quadri_cf(sh)[0]; got = np.frombuffer(first + rest, f32)
+        assert got.size == want.size and relrms(got, want) <= TOL
+        return
+    dec = port.fir_decimate_cc(sh, 10, port.firdes_lowpass_f(79, 0.05))
+    if spec == "ddc":
+        got = np.frombuffer(first + rest, c64)
+        assert abs(got.size - dec.size) <= 1
+        m = min(got.size, dec.size); assert relrms(got[:m], dec[:m]) <= TOL
+        return
+    dem, _ = port.fmdemod_quadri_cf(dec)
+    want = port.convert_f_s16(port.deemphasis_wfm_ff(dem[10::5], 50e-6, 48000)[0])      # fractional_decimator_ff 5 == x[5 k + 10] (exact at an integer rate)
+    got = np.frombuffer(first + rest, np.int16)
+    m = min(got.size, want.size)
+    assert m >= want.size - 4 and np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32)).max() <= 1
+
+
 @pytest.mark.parametrize("cmd,fn", [("shift_addfast_cc", "shift_addfast_cc"), ("shift_unroll_cc", "shift_unroll_cc"), ("shift_addition_fc", "shift_addition_fc")])
 def test_cli_fifo_retune_other_shifters(port, tmp_path, cmd, fn):
     """csdr.c:757-792 (shift_addfast_cc), 808-843 (shift_unroll_cc), 3373-3407 (shift_addition_fc): the same --fifo protocol as shift_addition_cc --
@@ -430,7 +524,7 @@ def test_cli_live_stream_latency_and_ragged_writes(port):
 
 def test_cli_argument_validation():
     """bad arguments end with the reference's badsyntax exit status instead of a crash (SIGFPE on a zero block / decimation)"""
-    for args in (["fastagc_ff", "0"], ["fir_decimate_cc", "0"], ["fir_decimate_cc", "x"], ["chain", "shift_addition_cc --fifo /tmp/x | fir_decimate_cc 10"]):
+    for args in (["fastagc_ff", "0"], ["fir_decimate_cc", "0"], ["fir_decimate_cc", "x"]):
         p = subprocess.run([CLI] + args, input=b"", stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         assert p.returncode == 255 and p.stderr, args
 
