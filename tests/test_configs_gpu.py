@@ -348,6 +348,42 @@ def test_c2_wfm_every_stream_block_and_segment(gpu, port):
         assert 0 <= n - ps.size <= 2 and vc.s16_diff(got[:m], ps[:m]).max() <= 1, "signal %d" % k
 
 
+def test_wfm_65536_streams_in_10_ms_blocks(gpu, port):
+    """The many-streams x short-block operating point (the reference moves 1024 / 16384-sample blocks per process, csdr.c:189-193; a receiver bank that serves 65536
+    clients with 10 ms of latency hands over 24576 samples per stream and call): 65536 streams x 24576 samples per call, three consecutive calls with the state
+    carried (history heads, chunk seeds, de-emphasis), every stream one of 16 FM signals.  Replicas bit-identical -- all 4096 stream blocks of the launch, every
+    column --, the 16 distinct rows +-1 LSB against the oracle's stream on every sample.  (bench.py's operating_points times this shape.)"""
+    import torch
+    S, T, calls = 65536, 24576, 3
+    L = gpu.L
+    taps = gpu.firdes_lowpass_f(gpu.firdes_filter_len(0.05), 0.5 / 10, "HAMMING")
+    sigs = [wfm_signal_u8(2300 + k, calls * T) for k in range(16)]
+    n_audio_max = (T // 50 + 64 + 63) // 64 * 64
+    out = torch.zeros((S, n_audio_max), dtype=torch.int16, device="cuda")
+    w = L.csdr_amd_wfm_create(gpu.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
+    assert w, gpu.err()
+    got = [[] for _ in range(16)]
+    try:
+        for c in range(calls):
+            x, idx = _replicated([sg[2 * c * T:2 * (c + 1) * T] for sg in sigs], S, T)
+            n = L.csdr_amd_wfm_process(w, x.data_ptr(), 2 * T, T, out.data_ptr(), None, n_audio_max)
+            assert n > 0, gpu.err()
+            gpu.sync()
+            assert L.csdr_amd_wfm_kernel_name(w).decode() == "k_wfm_mfma_seq" and not L.csdr_amd_wfm_fallback(w)
+            first = {int(k): int(np.nonzero(idx == k)[0][0]) for k in range(16)}
+            ref_rows = out[torch.tensor([first[int(k)] for k in idx], device="cuda")]
+            assert torch.equal(out[:, :n], ref_rows[:, :n]), "call %d: replicas of one signal differ between stream blocks / columns" % c
+            for k in range(16): got[k].append(out[first[k], :n].cpu().numpy().copy())
+            del x
+    finally:
+        L.csdr_amd_wfm_destroy(w)
+    for k in range(16):
+        ps, _ = port.wfm_chain(sigs[k], -0.085, 10, taps)
+        g = np.concatenate(got[k])
+        m = min(ps.size, g.size)
+        assert 0 <= g.size - ps.size <= 2 and vc.s16_diff(g[:m], ps[:m]).max() <= 1, "signal %d" % k
+
+
 def test_c2_wfm_every_stream_in_three_calls(gpu, port):
     """The timed shape as a STREAM: the same 1024 x 2 400 256 batch handed over in three calls of unequal size (1139 + 600 + 605 chunks), s16 only, every call into
     its own aligned rows -- what bench.py's timed loop does from its second step on: the later calls start in the history, their first audio sample falls anywhere in a

@@ -67,7 +67,9 @@ report("shift_addition_cc (64 streams x 2M, gen+mix)", timeit(lambda: L.csdr_amd
        16 * S * n, S * n)
 for vname, variant, aux in (("shift_math_cc", 1, 0), ("shift_table_cc", 2, 65536), ("shift_unroll_cc", 3, 1024), ("shift_addfast_cc", 4, 0)):
     report("%s (64 streams x 2M, gen+mix; the host's sequential float phase scan is inside the timed region)" % vname,
-           timeit(lambda: L.csdr_amd_shift_cc(ctx.h, variant, -0.085, C.byref(ph), xin.data_ptr(), yout.data_ptr(), S, n, n, n, 1024, aux), reps=5, warm=1), 16 * S * n, S * n)
+           timeit(lambda: L.csdr_amd_shift_cc(ctx.h, variant, -0.085, C.byref(ph), xin.data_ptr(), yout.data_ptr(), S, n, n, n, 1024, aux), reps=5, warm=1), 16 * S * n, S * n,
+           {"bound": "serial: the reference's float phase recurrence is one sequential chain per call (math / table: one phase add + wrap per SAMPLE, on the host); the HBM roofline does not apply"}
+           if variant in (1, 2) else None)
 rot = torch.empty(2 * n + 16, dtype=torch.float32, device="cuda")
 L.csdr_amd_rotator_generate(ctx.h, 0, -0.085, C.byref(ph), rot.data_ptr(), n, 1024, 0)
 report("mix_cc only (64 streams x 2M)", timeit(lambda: L.csdr_amd_mix_cc(ctx.h, xin.data_ptr(), yout.data_ptr(), rot.data_ptr(), S, n, n, n)), 16 * S * n, S * n)
@@ -114,7 +116,8 @@ for S5, n5 in ((4096, 48000), (65536, 12000)):
     enc = torch.empty(S5 * n5 // 2, dtype=torch.uint8, device="cuda"); dec = torch.empty(S5 * n5, dtype=torch.int16, device="cuda")
     stt = torch.zeros(2 * S5, dtype=torch.int32, device="cuda")
     report("encode_ima_adpcm_i16_u8 (%d streams x %d)" % (S5, n5),
-           timeit(lambda: L.csdr_amd_encode_ima_adpcm_i16_u8(ctx.h, x16.data_ptr(), enc.data_ptr(), S5, n5, n5, n5 // 2, stt.data_ptr()), reps=3, warm=1), 2.5 * S5 * n5, S5 * n5)
+           timeit(lambda: L.csdr_amd_encode_ima_adpcm_i16_u8(ctx.h, x16.data_ptr(), enc.data_ptr(), S5, n5, n5, n5 // 2, stt.data_ptr()), reps=3, warm=1), 2.5 * S5 * n5, S5 * n5,
+           {"bound": "serial per stream: every code depends on the predictor the previous code left (ima_adpcm.c:136-152): one lane per stream, time = one stream's chain whatever the stream count; the HBM roofline does not apply"})
     report("decode_ima_adpcm_u8_i16 (%d streams x %d)" % (S5, n5),
            timeit(lambda: L.csdr_amd_decode_ima_adpcm_u8_i16(ctx.h, enc.data_ptr(), dec.data_ptr(), S5, n5 // 2, n5 // 2, n5, stt.data_ptr()), reps=3, warm=1), 2.5 * S5 * n5, S5 * n5)
     del x16, enc, dec
