@@ -127,7 +127,9 @@ def main():
         algo = (2.0 + (3.0 if fused else 8.0) / D) * S * T
         if fused:
             kname += " (fused fmdemod_quadri_cf | limit_ff epilogue)"
-        tr = bc.pmc_traffic("k_ddc_mfma", {"channels_per_gpu": S, "block_samples_per_channel": T})
+        tr = bc.pmc_traffic("k_ddc_mfma", {"channels_per_gpu": S, "block_samples_per_channel": T, "shift_rates": "uniform" if args.uniform_rate else "per channel"})
+        if not tr and args.uniform_rate:                      # (summaries older than the shift_rates key are the shared-rate kernel's)
+            tr = bc.pmc_traffic("k_ddc_mfma<13, 2, true>", {"channels_per_gpu": S, "block_samples_per_channel": T})
         traffic, traffic_src = tr if tr else (None, None)
         if traffic and not (0.8 < traffic / algo < 1.25):
             traffic, traffic_src = None, None                 # a summary of the other (fused / unfused) variant

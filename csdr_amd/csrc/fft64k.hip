@@ -246,6 +246,16 @@ int fft64k_filter_oa(hipStream_t st, const cf32 *in, size_t in_pitch, int inp, i
     return 0;
 }
 
+// the overlap-add's last step on its own (the two-pass block filter of fftfilt_lds.hip leaves out + tails like k_f64_cols_inv_oa does)
+int fft64k_tail_add(hipStream_t st, cf32 *out, size_t out_pitch, const cf32 *d_tails, const cf32 *d_carry_in, cf32 *d_carry_out, int inp, int ovl, int n_blocks, int n_streams)
+{
+    if (ovl <= 0) return 0;
+    hipLaunchKernelGGL(k_f64_tail_add, dim3((ovl + 255) / 256, n_blocks, n_streams), dim3(256), 0, st, reinterpret_cast<float2 *>(out), out_pitch,
+                       reinterpret_cast<const float2 *>(d_tails), reinterpret_cast<const float2 *>(d_carry_in), reinterpret_cast<float2 *>(d_carry_out), inp, ovl, n_blocks);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
 } // namespace csdr_amd
 
 // Test hook (tests/test_abi_cpu.py): the register-level 16-point butterfly on the CPU; in/out: 16 interleaved complex floats

@@ -794,12 +794,13 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
     sp.n_streams = n_streams; sp.B2 = 2 * B; sp.two_T = 2LL * T;
     sp.tile_first = j_first / 4; sp.n_tiles = (int)((j_first + n_audio - 1) / 4 - sp.tile_first + 1);
     sp.stride = dev.tile_stride_bytes; sp.win_off = dev.win_off_bytes; sp.scale = dev.seq_scale;
-    // grid: 16-stream blocks x time segments, about one workgroup per CU; a segment is at least 64 tiles (the two warm-up steps in front of it
-    // must stay inside the call) and a multiple of 8
+    // grid: 16-stream blocks x time segments, about one workgroup per CU; a segment is at least 24 tiles (the two warm-up steps = 12 tiles in front of it
+    // must stay inside the call; short blocks -- the reference's 16384 samples are 82 tiles -- would otherwise leave three quarters of the CUs idle) and a
+    // multiple of SEQ_TPG
     const int n_cu = current_device_cu_count();
     const int n_wsb = (n_streams + 15) / 16;
     int n_seg = (n_cu + n_wsb - 1) / n_wsb; if (n_seg < 1) n_seg = 1;
-    if (n_seg > sp.n_tiles / 64) n_seg = sp.n_tiles / 64;
+    if (n_seg > sp.n_tiles / 24) n_seg = sp.n_tiles / 24;
     if (n_seg < 1) n_seg = 1;
     sp.tiles_per_seg = ((sp.n_tiles + n_seg - 1) / n_seg + SEQ_TPG - 1) / SEQ_TPG * SEQ_TPG;
     n_seg = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;

@@ -269,6 +269,15 @@ def test_bandpass_fir_fft_paths(gpu, port, monkeypatch):
         a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=2)
         for s in range(2):
             assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, fft)) < TOL
+    # the 65536-point block in two passes (fftfilt_lds.hip "64q": radix-4 step in the time domain, 4 x 16384 points in LDS, combine) -- a measured alternative, not the default
+    monkeypatch.setenv("CSDR_AMD_FFT64Q", "1")
+    assert path_of(1023, 65536)[0] == "k_f64q_main + k_f64q_combine"
+    for ntaps, nstreams, blocks in [(1023, 11, 3), (8191, 2, 2), (32769, 1, 2)]:                 # (11 streams x 3 blocks: a ragged last group of eight blocks)
+        x = np.stack([crand(rng, (65536 - ntaps + 1) * blocks) for _ in range(nstreams)])
+        taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
+        a = gpu.bandpass_fir_fft_cc(x, taps, 65536, blocks_per_call=2)
+        for s in (0, nstreams - 1):
+            assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, 65536)) < TOL, (ntaps, s)
 
 
 def test_bandpass_one_pass_ragged(gpu, port):
