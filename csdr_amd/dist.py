@@ -4,9 +4,10 @@ on ROCm) on the GPU box, gloo in the CPU tests.
 Where the hot path shards:
   * WFM / NFM chains, converters, FIRs: streams are independent -> block-distribute streams over ranks, NO data-path
     collective (replicas).  Only the barrier and the max-over-ranks of the timing use the communicator.
-  * fastddc: the one path with an exchange.  The C library (csdr_amd/csrc/comm.cpp, fftpath.hip) offers two schedules: time slices (default: every rank
-    runs the whole pipeline on its run of a batch's blocks, the decimated outputs are exchanged all-to-all; bank_time_sliced below is its CPU model) and
-    channel slices (forward transform split by blocks, spectra all-gathered: bank_exchange below).  fastddc_sharded is the round-1 root broadcast.
+  * fastddc: the one path with an exchange.  The C library (csdr_amd/csrc/comm.cpp, fftpath.hip) offers two schedules: channel slices (the default of
+    csdr_amd_fastddc_bank_create_sharded, north_star's wording: forward transform split by blocks, spectra all-gathered, every rank folds its own channels:
+    bank_exchange below is its CPU model) and time slices (CSDR_AMD_SHARD_BLOCKS: every rank runs the whole pipeline on its run of a batch's blocks, the
+    decimated outputs are exchanged all-to-all: bank_time_sliced below; the one that scales beyond two GPUs).  fastddc_sharded is the round-1 root broadcast.
 """
 import os
 import torch
