@@ -839,11 +839,12 @@ def _bank_input(x):
 
 
 def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode="blocks", window="HAMMING", retunes=None, pipelined=True,
-                          local_input=False, device=0):
+                          local_input=False, device=0, retune_while_staged=False):
     """The multi-rank fastddc bank (csdr_amd_fastddc_bank_create_sharded_by) run for real on ONE GPU: `world` rank threads, one Context each, joined by the
     library's loopback communicator (every exchange = stream-ordered device copies).  x = the wideband stream (on rank 0; local_input: every rank is handed
     its own run of each batch instead), schedule = blocks per batch, retunes = {batch index: [(global channel, rate), ...]} applied before that batch.
-    pipelined: submit(k + 1) is queued before collect(k) wherever no retune sits in between.  Returns the per-channel outputs (all channels, gathered from the
+    pipelined: submit(k + 1) is queued before collect(k) wherever no retune sits in between -- or, with retune_while_staged, everywhere: batch k + 1's retunes are
+    then issued while batch k is still staged (they must leave batch k alone and apply from batch k + 1 on, in both sharding modes).  Returns the per-channel outputs (all channels, gathered from the
     ranks' slices)."""
     import threading
     L = lib()
@@ -893,11 +894,15 @@ def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode
 
             submitted = -1
             for k in range(len(schedule)):
-                for ch, rt in retunes.get(k, []):
-                    ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt), "bank_set_rate_global")
+                if not (retune_while_staged and k > 0):
+                    for ch, rt in retunes.get(k, []):
+                        ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt), "bank_set_rate_global")
                 if submitted < k:
                     submit(k); submitted = k
-                if pipelined and k + 1 < len(schedule) and (k + 1) not in retunes:
+                if retune_while_staged:                               # batch k is staged, not collected: the next batch's retunes arrive now
+                    for ch, rt in retunes.get(k + 1, []):
+                        ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt), "bank_set_rate_global")
+                if pipelined and k + 1 < len(schedule) and (retune_while_staged or (k + 1) not in retunes):
                     submit(k + 1); submitted = k + 1
                 pitch = L.csdr_amd_fastddc_bank_max_output(bank, schedule[k]) + 8
                 do = ctx.alloc(8 * count * pitch)

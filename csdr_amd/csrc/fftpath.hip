@@ -769,6 +769,10 @@ struct csdr_amd_fastddc_bank {
     hipEvent_t ev_fork = nullptr, ev_in_ready[2] = {nullptr, nullptr}, ev_in_free[2] = {nullptr, nullptr}, ev_out_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     bool in_free_rec[2] = {false, false}, done_rec[2] = {false, false};
     struct Batch { int n_glob; const uint8_t *in; bool local; int fmt; } batch[2]; int fill = 0, drain = 0, n_batches = 0, last_slot = -1;
+    // a retune applies from the next SUBMITTED batch on.  Time slices: a batch's chain tables are computed at its collect, so retunes that arrive while batches are
+    // staged wait here, tagged with the first batch they concern.  The other modes fix part of a batch's tables at submit and use the rest at collect: there a retune
+    // while a batch is staged is refused (seq_submit != seq_collect)
+    struct Retune { long first_batch; int channel; float rate; }; std::vector<Retune> deferred; long seq_submit = 0, seq_collect = 0;
 };
 
 static void shard_slice(int n, int world, int rank, int *first, int *count)      // block distribution, counts differ by at most one (csdr_amd/dist.py: shard)
@@ -873,13 +877,20 @@ static int bank_submit_blocks(csdr_amd_fastddc_bank *b, const void *in_v, int n_
         CSDR_HIP(hipEventRecord(b->ev_in_ready[slot], b->xin));
     }
     b->batch[slot] = {n_glob, in, local, fmt};
-    b->fill ^= 1; b->n_batches++;
+    b->fill ^= 1; b->n_batches++; b->seq_submit++;
     return 0;
 }
 
 static int bank_collect_blocks(csdr_amd_fastddc_bank *b, csdr_complexf *out, size_t out_pitch)
 {
     if (!b->n_batches) return fail_msg(-3, "fastddc_bank: nothing staged to collect");
+    for (size_t k = 0; k < b->deferred.size();) {                     // retunes that concern this batch (and were issued while an earlier one was staged)
+        if (b->deferred[k].first_batch <= b->seq_collect) {
+            const int rc = csdr_amd_fastddc_inv_set_rate(b->inv, b->deferred[k].channel, b->deferred[k].rate); if (rc) return rc;
+            b->deferred.erase(b->deferred.begin() + (long)k);
+        } else k++;
+    }
+    b->seq_collect++;
     csdr_amd_fastddc_inv *f = b->inv;
     const csdr_fastddc_t &g = f->geom[0];
     const int inp = g.input_size, ovl = g.overlap_length, slot = b->drain, W = b->world, me = b->rank;
@@ -984,14 +995,20 @@ int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float 
     if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {
         int first = 0, count = 0;
         if (csdr_amd_fastddc_bank_channel_slice(b, &first, &count) || channel < 0 || channel >= count) return fail_msg(-3, "fastddc_bank: channel %d outside this rank's slice of %d", channel, count);
+        if (b->n_batches) { b->deferred.push_back({b->seq_submit, first + channel, shift_rate}); return 0; }      // (staged batches keep the old rate)
         return csdr_amd_fastddc_inv_set_rate(b->inv, first + channel, shift_rate);
     }
+    if (b->seq_submit != b->seq_collect) return fail_msg(-3, "fastddc_bank: a batch is staged (submitted, not collected): its tables are partly fixed already -- collect it before retuning (a time-sliced bank holds such a retune back itself)");
     return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
 }
 int csdr_amd_fastddc_bank_set_rate_global(csdr_amd_fastddc_bank *b, int channel, float shift_rate)
 {   // every rank makes the same call; a rank applies it to what it computes
     if (channel < 0 || channel >= b->n_channels_total) return fail_msg(-3, "fastddc_bank: channel %d out of range", channel);
-    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
+    if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {
+        if (b->n_batches) { b->deferred.push_back({b->seq_submit, channel, shift_rate}); return 0; }                 // (staged batches keep the old rate)
+        return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
+    }
+    if (b->seq_submit != b->seq_collect) return fail_msg(-3, "fastddc_bank: a batch is staged (submitted, not collected): its tables are partly fixed already -- collect it before retuning (a time-sliced bank holds such a retune back itself)");
     if (channel < b->first_channel || channel >= b->first_channel + b->inv->n_channels) return 0;
     return csdr_amd_fastddc_inv_set_rate(b->inv, channel - b->first_channel, shift_rate);
 }
@@ -1011,11 +1028,15 @@ static int bank_submit(csdr_amd_fastddc_bank *b, const void *in, int n_blocks, b
     if (n_blocks <= 0 || n_blocks > b->max_blocks) return fail_msg(-3, "fastddc_bank: %d blocks (max_blocks %d)", n_blocks, b->max_blocks);
     if (fmt < 0 || fmt > 2) return fail_msg(-3, "fastddc_bank: unknown input format %d", fmt);
     if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) return bank_submit_blocks(b, in, n_blocks, false, fmt);
-    if (b->fused) return ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom, inline_call, nullptr, fmt, false);
+    if (b->fused) {
+        const int rc = ddc_mfma_submit(b->inv->mf, in, nullptr, n_blocks, b->inv->d_state, b->inv->d_geom, inline_call, nullptr, fmt, false);
+        if (!rc) b->seq_submit++;
+        return rc;
+    }
     if (fmt != DDC_IN_CF32) return fail_msg(-3, "fastddc_bank: integer input needs the matrix-core geometry (fft 65536 / inverse 512); convert first (csdr_amd_convert_s16_f / _u8_f)");
     if (b->n_staged) return fail_msg(-3, "fastddc_bank: this geometry stages one call at a time");
     int rc = csdr_amd_fastddc_fwd_process(b->fwd, reinterpret_cast<const csdr_complexf *>(in), b->d_spec, n_blocks); if (rc) return rc;
-    b->staged[0] = n_blocks; b->n_staged = 1;
+    b->staged[0] = n_blocks; b->n_staged = 1; b->seq_submit++;
     return 0;
 }
 int csdr_amd_fastddc_bank_submit(csdr_amd_fastddc_bank *b, const csdr_complexf *in, int n_blocks) { return bank_submit(b, in, n_blocks, false); }
@@ -1055,13 +1076,14 @@ int csdr_amd_fastddc_bank_collect(csdr_amd_fastddc_bank *b, csdr_complexf *out, 
     }
     if (!b->fused) {
         if (!b->n_staged) return fail_msg(-3, "fastddc_bank: nothing staged to collect");
-        b->n_staged = 0;
+        b->n_staged = 0; b->seq_collect++;
         return csdr_amd_fastddc_inv_process(f, b->d_spec, b->staged[0], out, out_pitch, out_counts);
     }
     const int pending = ddc_mfma_pending_blocks(f->mf);                   // validated BEFORE anything is queued that writes `out` with this pitch
     if (pending > 0 && (size_t)csdr_amd_fastddc_inv_max_output(f, pending) > out_pitch) return fail_msg(-3, "fastddc_bank: out_pitch too small");
     const int *d_cnt = nullptr;
     const int rc = ddc_mfma_collect(f->mf, f->d_geom, out, out_pitch, &d_cnt); if (rc < 0) return rc;
+    if (b->seq_collect < b->seq_submit) b->seq_collect++;
     b->last_counts = d_cnt; b->last_count_n = f->n_channels;
     return out_counts ? csdr_amd_fastddc_bank_finish(b, out_counts) : 0;
 }

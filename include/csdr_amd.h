@@ -346,8 +346,10 @@ int  csdr_amd_fastddc_bank_submit_u8(csdr_amd_fastddc_bank *b, const uint8_t *in
 int  csdr_amd_fastddc_bank_submit_local_s16(csdr_amd_fastddc_bank *b, const int16_t *in_run_iq, int n_blocks);
 int  csdr_amd_fastddc_bank_submit_local_u8(csdr_amd_fastddc_bank *b, const uint8_t *in_run_iq, int n_blocks);
 int  csdr_amd_fastddc_bank_finish(csdr_amd_fastddc_bank *b, int *out_counts);
-/* retune by GLOBAL channel number; every rank makes the same call (csdr_amd_fastddc_bank_set_rate takes an index into the rank's own slice and is refused
- * by a time-sliced bank, where every rank holds every channel) */
+/* retune by GLOBAL channel number; every rank makes the same call (csdr_amd_fastddc_bank_set_rate takes an index into the rank's own slice; in a time-sliced
+ * bank, where every rank computes every channel, a call on one rank only changes that rank's contribution).  A retune takes effect from the next SUBMITTED batch on (csdr.c:2329-2376: the new rate
+ * between two reads): a time-sliced bank holds a retune that arrives while batches are staged back until they are collected; every other bank REFUSES it then
+ * (-3: collect first) -- part of a staged batch's tables is already fixed. */
 int  csdr_amd_fastddc_bank_set_rate_global(csdr_amd_fastddc_bank *b, int channel, float shift_rate);
 /* the bank's inverse half (kernel name / profiling: csdr_amd_fastddc_inv_kernel_name, _set_profiling, _kernel_time) */
 csdr_amd_fastddc_inv *csdr_amd_fastddc_bank_inverse(csdr_amd_fastddc_bank *b);

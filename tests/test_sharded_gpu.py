@@ -70,6 +70,34 @@ def test_sharded_bank_loopback(gpu, case, mode, world):
     _check(outs, single, want)
 
 
+def test_retune_while_a_batch_is_staged(gpu, case):
+    """A retune that arrives between submit(k) and collect(k) leaves batch k alone and applies from batch k + 1 on (csdr.c:2329-2376: the new rate between two reads).
+    The time-sliced bank computes a batch's chain tables at its collect and therefore holds such a retune back: same streams as the single-GPU bank retuned between
+    the two batches.  Every other bank has part of the staged batch's tables fixed already and refuses the call until the batch is collected."""
+    import ctypes as C
+    import csdr_amd
+    x, rates, single, want = case
+    outs = csdr_amd.sharded_bank_loopback(2, x, TBW, D, rates, SCHEDULE, mode="blocks", retunes=RETUNES, pipelined=True, retune_while_staged=True)
+    _check(outs, single, want)
+    L = gpu.L
+    ddc, _ = gpu.fastddc_init(TBW, D, 0.0)
+    r4 = np.ascontiguousarray(rates[:4], np.float32)
+    bank = L.csdr_amd_fastddc_bank_create(gpu.h, TBW, D, r4.ctypes.data_as(C.c_void_p), 4, 1, 2)
+    assert bank
+    try:
+        di = gpu.upload(x[:2 * ddc.input_size])
+        assert L.csdr_amd_fastddc_bank_set_rate(bank, 1, 0.111) == 0                      # nothing staged: applied
+        assert L.csdr_amd_fastddc_bank_submit(bank, di.ptr, 2) == 0
+        assert L.csdr_amd_fastddc_bank_set_rate(bank, 1, 0.222) < 0 and "staged" in gpu.err()
+        pitch = L.csdr_amd_fastddc_bank_max_output(bank, 2) + 8
+        do = gpu.alloc(8 * 4 * pitch)
+        assert L.csdr_amd_fastddc_bank_collect(bank, do.ptr, pitch, None) == 0
+        assert L.csdr_amd_fastddc_bank_set_rate(bank, 1, 0.222) == 0
+        gpu.sync()
+    finally:
+        L.csdr_amd_fastddc_bank_destroy(bank)
+
+
 def test_sharded_bank_loopback_unpipelined_and_odd_world(gpu, case):
     """three ranks (256 channels do not divide: slices of 86 / 85 / 85; runs of 22 blocks), every batch submitted and collected in turn"""
     import csdr_amd
