@@ -646,7 +646,8 @@ IpcSource *ipc_source_decide(int device)
     IpcHello h; int ack = 0;
     char mine[32]; ipc_device_id(device, mine);
     void *ring = nullptr;
-    if (recv(conn, &h, sizeof h, 0) == (ssize_t)sizeof h && !memcmp(h.magic, IPC_MAGIC, 8) && h.version == 1 && mine[0] && !strncmp(h.bus_id, mine, 32) &&
+    const bool test_nak = getenv("CSDR_AMD_IPC_TEST_NAK") != nullptr;  // (tests: refuse as if the handle could not be opened -- the fallback to bytes after a connection)
+    if (recv(conn, &h, sizeof h, 0) == (ssize_t)sizeof h && !test_nak && !memcmp(h.magic, IPC_MAGIC, 8) && h.version == 1 && mine[0] && !strncmp(h.bus_id, mine, 32) &&
         hipIpcOpenMemHandle(&ring, h.mem, hipIpcMemLazyEnablePeerAccess) == hipSuccess) ack = 1;
     else (void)hipGetLastError();
     if (send(conn, &ack, sizeof ack, MSG_NOSIGNAL) != (ssize_t)sizeof ack) ack = 0;

@@ -238,6 +238,18 @@ def test_cli_device_handoff_between_processes(port, tmp_path):
         pytest.xfail("HIP IPC refused on this box (the byte fallback gave the same samples): " + " | ".join(e.strip() for e in errs if "refused" in e))
 
 
+def test_cli_device_handoff_refused_falls_back_to_bytes(tmp_path):
+    """The other half of the negotiation: the producer connects, the consumer cannot take the handle (another device, HIP IPC not available to it: forced here with
+    CSDR_AMD_IPC_TEST_NAK) and answers NAK -- both sides go on with bytes through the pipe they already share; same samples as without any hand-off."""
+    iq = fm_iq(np.random.default_rng(20), 300000)
+    d1 = tmp_path / "nak"; d1.mkdir()
+    nak = wfm_pipeline(CLI, iq, 65536, {"CSDR_AMD_IPC_VERBOSE": "1", "CSDR_AMD_IPC_WAIT_MS": "3000", "CSDR_AMD_IPC_TEST_NAK": "1"}, str(d1))
+    off = wfm_pipeline(CLI, iq, 65536, {"CSDR_AMD_IPC": "0"})
+    assert nak.size > 5000 and np.array_equal(nak, off)
+    errs = [open(d1 / ("err%d.txt" % i)).read() for i in range(7)]
+    assert all("hand-off to the next process refused" in errs[i] and "hand-off from the previous process refused" in errs[i + 1] for i in range(6)), errs
+
+
 def test_cli_wfm_shell_pipeline(port):
     """README.md:66 as seven processes and as the fused `wfm_chain_u8_s16`, against the oracle chain and the reference's own CLI."""
     iq = fm_iq(np.random.default_rng(9), 480000)
