@@ -96,6 +96,86 @@ __global__ __launch_bounds__(64) void k_deemph_wfm(const float *__restrict__ in,
     if (lane < rows) last_io[s0 + lane] = y;
 }
 
+// ---- the same recurrence for FEW, LONG streams (a CLI process has one: `csdr deemphasis_wfm_ff` walked its 80 000 samples per block on ONE lane -- 34 M samples/s, the
+// slowest stage of the literal README.md:66 pipeline by far).  y[k] = fl(fl(alpha x[k]) + fl(b y[k-1])) is a contraction (b = 1 - alpha < 1): a trajectory started
+// from the wrong state forgets it at the rate b^k and, once it agrees with the true one to the last bit, stays identical.  So the stream is cut into chunks of 256
+// samples, one lane each; a lane first runs over the DW_M chunks in front of its own from state zero (b^(256 DW_M) < 2^-40: the host picks DW_M, or the serial kernel
+// when none fits), notes the state it arrives with, then computes its chunk.  k_deemph_wfm_check compares every lane's arrival state with the END state its
+// predecessor computed, bit for bit: if all agree the whole stream is the sequential recurrence's, by induction from chunk 0 (which starts from the carried state).
+// Where one does not (in practice never; kept so that the result is the reference's bits, not merely close), k_deemph_wfm_fix recomputes from there on,
+// sequentially, until its end state meets the stored one again.  Bit exact like k_deemph_wfm, 2 x the arithmetic, all lanes busy.
+constexpr int DW_L = 256, DW_P = DW_L + 1;              // chunk length; LDS row pitch (conflict free for lanes walking their own rows)
+template <int M>
+__global__ __launch_bounds__(64) void k_deemph_wfm_spec(const float *__restrict__ in, float *__restrict__ out, size_t n, size_t in_pitch, size_t out_pitch, float alpha,
+                                                        const float *__restrict__ last_io, float *__restrict__ st_start, float *__restrict__ st_end, size_t n_chunks)
+{
+    extern __shared__ float dw_tile[];                               // [(M + 64) rows][DW_P]: rows 0 .. M-1 = the chunks in front of this wave's first one
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.y, c0 = (size_t)blockIdx.x * 64;
+    const float *x = in + s * in_pitch;
+    float *y_row = out + s * out_pitch;
+    const float one_minus = 1 - alpha;
+    for (int r = 0; r < M + 64; r++) {                               // coalesced: one row = 1 KiB
+        const long long c = (long long)c0 + r - M;
+        if (c < 0 || (size_t)c >= n_chunks) continue;
+#pragma unroll
+        for (int q = 0; q < DW_L / 64; q++) { const size_t k = (size_t)c * DW_L + lane + 64 * q; dw_tile[r * DW_P + lane + 64 * q] = k < n ? x[k] : 0.f; }
+    }
+    __syncthreads();
+    const size_t c = c0 + lane;
+    if (c < n_chunks) {
+        // run-in over chunks c - M .. c - 1 from state zero -- or, where the stream's first chunk is among them (c <= M), over chunks 0 .. c - 1 from the carried
+        // state (NaN reset, libcsdr.c:1092): those lanes are exact outright
+        float y = 0.f;
+        if (c <= (size_t)M) { y = last_io[s]; if (y != y) y = 0.f; }
+        for (int m = (c < (size_t)M ? (int)(M - c) : 0); m < M; m++) {
+            const float *row = dw_tile + (lane + m) * DW_P;
+            for (int k = 0; k < DW_L; k++) y = alpha * row[k] + one_minus * y;
+        }
+        st_start[s * n_chunks + c] = y;
+        float *row = dw_tile + (lane + M) * DW_P;
+        const int cols = (int)((n - c * DW_L < (size_t)DW_L) ? (n - c * DW_L) : DW_L);
+        for (int k = 0; k < cols; k++) { y = alpha * row[k] + one_minus * y; row[k] = y; }
+        st_end[s * n_chunks + c] = y;
+    }
+    __syncthreads();
+    for (int r = M; r < M + 64; r++) {
+        const size_t cc = c0 + r - M;
+        if (cc >= n_chunks) break;
+#pragma unroll
+        for (int q = 0; q < DW_L / 64; q++) { const size_t k = cc * DW_L + lane + 64 * q; if (k < n) y_row[k] = dw_tile[r * DW_P + lane + 64 * q]; }
+    }
+}
+// flags[s] = number of chunks whose arrival state is not, bit for bit, the end state of the chunk in front
+__global__ __launch_bounds__(256) void k_deemph_wfm_check(const float *__restrict__ st_start, const float *__restrict__ st_end, size_t n_chunks, unsigned *__restrict__ flags)
+{
+    const size_t s = blockIdx.y, c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 || c >= n_chunks) return;
+    if (__float_as_uint(st_start[s * n_chunks + c]) != __float_as_uint(st_end[s * n_chunks + c - 1])) atomicAdd(&flags[s], 1u);
+}
+// one thread per stream: the carried state out; and, where the check found a disagreement (in practice never), the sequential repair: chunk by chunk in order, every
+// chunk whose arrival state is not its predecessor's FINAL end state is recomputed from that state
+__global__ __launch_bounds__(64) void k_deemph_wfm_fix(const float *__restrict__ in, float *__restrict__ out, size_t n, size_t in_pitch, size_t out_pitch, float alpha,
+                                                       float *__restrict__ last_io, const float *__restrict__ st_start, float *__restrict__ st_end, size_t n_chunks,
+                                                       unsigned *__restrict__ flags, int n_streams)
+{
+    const size_t s = threadIdx.x;                                    // (fewer than 32 streams take this path)
+    if (s >= (size_t)n_streams) return;
+    const float one_minus = 1 - alpha;
+    if (flags[s]) {
+        const float *x = in + s * in_pitch; float *y_row = out + s * out_pitch;
+        const float *ss = st_start + s * n_chunks; float *se = st_end + s * n_chunks;
+        for (size_t c = 1; c < n_chunks; c++) {
+            if (__float_as_uint(ss[c]) == __float_as_uint(se[c - 1])) continue;      // computed from the right state: exact as it stands
+            float y = se[c - 1];
+            const int cols = (int)((n - c * DW_L < (size_t)DW_L) ? (n - c * DW_L) : DW_L);
+            for (int k = 0; k < cols; k++) { y = alpha * x[c * DW_L + k] + one_minus * y; y_row[c * DW_L + k] = y; }
+            se[c] = y;
+        }
+    }
+    last_io[s] = st_end[s * n_chunks + n_chunks - 1];
+}
+
 // ------------------------------------------------------------------ fastagc_ff
 // State layout per stream: [buffer_1 (block) | buffer_2 (block) | peak_1 peak_2 last_gain pad]
 __device__ __forceinline__ const float *agc_seq_block(const float *state, const float *in_row, int block, int j)
@@ -246,6 +326,31 @@ int csdr_amd_deemphasis_wfm_ff(csdr_amd_ctx *c, const float *in, float *out, int
     if (!n || n_streams <= 0) return 0;
     const float dt = (float)(1.0 / sample_rate);            // libcsdr.c:1090-1091, float after a double division
     const float alpha = dt / (tau + dt);
+    // few long streams: chunks of 256 samples on their own lanes (k_deemph_wfm_spec, bit exact); M = chunks of run-in: b^(256 M) < 2^-40
+    const double b = 1.0 - (double)alpha;
+    int M = 0;
+    if (n_streams < 32 && n >= 8 * (size_t)DW_L && b > 0.0 && b < 1.0 && in != out) for (int m : {1, 2, 4, 8}) if (256.0 * m * log2(b) < -40.0) { M = m; break; }
+    static const bool serial_env = getenv("CSDR_AMD_DEEMPH_SERIAL") != nullptr;       // (A/B, read once per process)
+    if (M && !serial_env) {
+        const size_t n_chunks = (n + DW_L - 1) / DW_L;
+        float *st = (float *)c->get_scratch(0, sizeof(float) * 2 * n_chunks * (size_t)n_streams + 256);
+        if (!st) return -2;
+        float *st_start = st, *st_end = st + n_chunks * (size_t)n_streams;
+        unsigned *flags = (unsigned *)(st_end + n_chunks * (size_t)n_streams);
+        CSDR_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * (size_t)n_streams, c->stream));
+        const dim3 grid((unsigned)cdiv(n_chunks, 64), (unsigned)n_streams);
+        const size_t lds = sizeof(float) * (size_t)(M + 64) * DW_P;
+#define DW_LAUNCH(MV) do { const int arc = csdr_amd::lds_attr_once((const void *)k_deemph_wfm_spec<MV>, lds); if (arc) return arc;                                   \
+                hipLaunchKernelGGL(k_deemph_wfm_spec<MV>, grid, dim3(64), lds, c->stream, in, out, n, in_pitch, out_pitch, alpha, (const float *)last_io, st_start, st_end, n_chunks); } while (0)
+        if (M == 1) DW_LAUNCH(1); else if (M == 2) DW_LAUNCH(2); else if (M == 4) DW_LAUNCH(4); else DW_LAUNCH(8);
+#undef DW_LAUNCH
+        CSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_deemph_wfm_check, dim3((unsigned)cdiv(n_chunks, 256), (unsigned)n_streams), dim3(256), 0, c->stream, (const float *)st_start, (const float *)st_end, n_chunks, flags);
+        CSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_deemph_wfm_fix, dim3(1), dim3(64), 0, c->stream, in, out, n, in_pitch, out_pitch, alpha, last_io, (const float *)st_start, st_end, n_chunks, flags, n_streams);
+        CSDR_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_deemph_wfm, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, n, in_pitch, out_pitch, alpha, last_io);
     CSDR_LAUNCH_CHECK();
     return 0;

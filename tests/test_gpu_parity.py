@@ -178,6 +178,15 @@ def test_deemphasis_limit_gain(gpu, port):
     for s in range(70):
         b, lb = port.deemphasis_wfm_ff(x[s], 50e-6, 48000)
         assert np.array_equal(a[s], b) and la[s] == f32(lb)          # same operations in the same order: bit exact
+    # few long streams (a CLI process has one): chunks of 256 samples on their own lanes with a run-in from state zero, checked against the predecessor's end state
+    # (audio.hip: k_deemph_wfm_spec / _check / _fix) -- still the reference's bits: a carried state, a NaN state, a ragged end, slow time constants (longer run-ins)
+    for nst, n, tau, sr, last in [(1, 100000, 50e-6, 48000, 0.37), (3, 70001, 75e-6, 48000, float("nan")), (2, 50000, 50e-6, 240000, -1.2), (1, 9000, 50e-6, 44100, 0.0),
+                                  (1, 40000, 1e-3, 48000, 0.5), (1, 40000, 2e-3, 48000, 0.5)]:      # (1e-3: a run-in of 8 chunks; 2e-3: b^(256 * 8) > 2^-40 -> the serial kernel)
+        xs = rng.uniform(-1.5, 1.5, (nst, n)).astype(f32)
+        a, la = gpu.deemphasis_wfm_ff(xs, tau, sr, last=np.full(nst, last, f32))
+        for s in range(nst):
+            b, lb = port.deemphasis_wfm_ff(xs[s], tau, sr, last)
+            assert np.array_equal(a[s], b) and la[s] == f32(lb), (nst, n, tau, sr)
     assert np.array_equal(gpu.limit_ff(x, 1.0).ravel(), port.limit_ff(x.ravel(), 1.0))
     assert np.array_equal(gpu.gain_ff(x, 0.37).ravel(), port.gain_ff(x.ravel(), 0.37))
     for sr in [48000, 44100, 8000, 11025]:
