@@ -259,20 +259,27 @@ __global__ __launch_bounds__(256) void k_agc_update(const float *__restrict__ in
 }
 
 // ------------------------------------------------------------------ fractional_decimator_ff
+// The plan holds, per output, only what the reference's sequential position bookkeeping yields: the first input sample of its window and the fractional
+// position frac = where - lo.  The Lagrange coefficients (libcsdr.c:775-785: P products of P - 1 factors each and a division, the same float operations in the same
+// order) are evaluated HERE -- building them on the host cost 4.7 ms per 400 k-sample call and made `csdr fractional_decimator_ff` the slowest stage of the literal
+// README.md:66 pipeline (87 M samples/s).
 __global__ __launch_bounds__(256) void k_fracdec(const float *__restrict__ in, float *__restrict__ out, int n_out, size_t in_pitch, size_t out_pitch,
-                                                 const int *__restrict__ lo_idx, const float *__restrict__ coef, int P,
+                                                 const int *__restrict__ lo_idx, const float *__restrict__ frac, int P, int xifirst, const float *__restrict__ denom,
                                                  const float *__restrict__ taps, int ntaps)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_out) return;
     const float *x = in + (size_t)blockIdx.y * in_pitch + lo_idx[k];
-    const float *c = coef + (size_t)k * P;
+    const float fx = frac[k];
     float acc = 0.f;
     for (int w = 0; w < P; w++) {
         float y;
         if (ntaps) { y = 0.f; for (int t = 0; t < ntaps; t++) y += taps[t] * x[w + t]; }   // fir_one_pass_ff libcsdr.c:675-680
         else y = x[w];
-        acc += c[w] * y;
+        const int a = xifirst + w;
+        float prod = 1;
+        for (int b = xifirst; b < xifirst + P; b++) if (a != b) prod *= (fx - b);
+        acc += (prod / denom[w]) * y;
     }
     out[(size_t)blockIdx.y * out_pitch + k] = acc;
 }
@@ -285,8 +292,8 @@ struct csdr_amd_fracdec {
     // cached plan
     float plan_where; int plan_n; bool plan_valid; int plan_outputs, plan_processed; float plan_where_after;
     int cli_bufsize, plan_bufsize;   // > 0: replay the CLI's loop over the_bufsize-sample windows (csdr.c:1511-1524) instead of one call over the whole array
-    std::vector<int> lo; std::vector<float> coef;
-    int *d_lo; float *d_coef; float *d_taps; size_t d_cap;
+    std::vector<int> lo; std::vector<float> frac;      // per output: first input sample of its window, fractional position (the coefficients are the kernel's)
+    int *d_lo; float *d_frac; float *d_denom; float *d_taps; size_t d_cap;
 };
 
 extern "C" {
@@ -398,7 +405,7 @@ csdr_amd_fracdec *csdr_amd_fracdec_create(float rate, int num_poly_points, const
     d->where = (float)(-d->xifirst); d->rate = rate; d->input_processed = 0;
     d->taps_length = host_taps ? taps_length : 0;
     if (d->taps_length) d->taps.assign(host_taps, host_taps + taps_length);
-    d->plan_valid = false; d->d_lo = nullptr; d->d_coef = nullptr; d->d_taps = nullptr; d->d_cap = 0; d->cli_bufsize = 0; d->plan_bufsize = 0;
+    d->plan_valid = false; d->d_lo = nullptr; d->d_frac = nullptr; d->d_denom = nullptr; d->d_taps = nullptr; d->d_cap = 0; d->cli_bufsize = 0; d->plan_bufsize = 0;
     return d;
 }
 
@@ -410,7 +417,8 @@ void csdr_amd_fracdec_destroy(csdr_amd_fracdec *d)
 {
     if (!d) return;
     if (d->d_lo) (void)hipFree(d->d_lo);
-    if (d->d_coef) (void)hipFree(d->d_coef);
+    if (d->d_frac) (void)hipFree(d->d_frac);
+    if (d->d_denom) (void)hipFree(d->d_denom);
     if (d->d_taps) (void)hipFree(d->d_taps);
     delete d;
 }
@@ -422,19 +430,14 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
     if (!(d->plan_valid && d->plan_where == d->where && d->plan_n == input_size && d->plan_bufsize == d->cli_bufsize)) {
         // Replay the reference's float position bookkeeping (libcsdr.c:762-792) on the host: it does not depend
         // on the samples, only on (where, rate, input_size).
-        d->lo.clear(); d->coef.clear();
+        d->lo.clear(); d->frac.clear();
         float where = d->where; int hi = 0;
         auto one_call = [&](int base, int size) {                       // fractional_decimator_ff over in[base .. base + size)
             for (; (hi = (int)ceilf(where)) + P + d->taps_length < size; where += d->rate) {
                 const int lo = hi - 1;
                 const float x = where - lo;
                 d->lo.push_back(base + lo);
-                int idx = 0;
-                for (int a = d->xifirst; a <= d->xilast; a++, idx++) {
-                    float prod = 1;
-                    for (int b = d->xifirst; b <= d->xilast; b++) if (a != b) prod *= (x - b);
-                    d->coef.push_back(prod / d->denom[idx]);
-                }
+                d->frac.push_back(x);
             }
             const int processed = (hi - 1) + d->xifirst;                // libcsdr.c:790-791
             where -= processed;
@@ -463,10 +466,14 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
         if (need > d->d_cap) {
             CSDR_HIP(hipStreamSynchronize(c->stream));
             if (d->d_lo) (void)hipFree(d->d_lo);
-            if (d->d_coef) (void)hipFree(d->d_coef);
+            if (d->d_frac) (void)hipFree(d->d_frac);
             d->d_cap = need + need / 2;
             CSDR_HIP(hipMalloc((void **)&d->d_lo, sizeof(int) * d->d_cap));
-            CSDR_HIP(hipMalloc((void **)&d->d_coef, sizeof(float) * d->d_cap * P));
+            CSDR_HIP(hipMalloc((void **)&d->d_frac, sizeof(float) * d->d_cap));
+        }
+        if (!d->d_denom) {
+            CSDR_HIP(hipMalloc((void **)&d->d_denom, sizeof(float) * d->denom.size()));
+            CSDR_HIP(hipMemcpy(d->d_denom, d->denom.data(), sizeof(float) * d->denom.size(), hipMemcpyHostToDevice));
         }
         if (d->taps_length && !d->d_taps) {
             CSDR_HIP(hipMalloc((void **)&d->d_taps, sizeof(float) * d->taps_length));
@@ -475,13 +482,13 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
         if (d->plan_outputs) {
             CSDR_HIP(hipStreamSynchronize(c->stream));     // previous launch may still read the old plan
             CSDR_HIP(hipMemcpy(d->d_lo, d->lo.data(), sizeof(int) * d->lo.size(), hipMemcpyHostToDevice));
-            CSDR_HIP(hipMemcpy(d->d_coef, d->coef.data(), sizeof(float) * d->coef.size(), hipMemcpyHostToDevice));
+            CSDR_HIP(hipMemcpy(d->d_frac, d->frac.data(), sizeof(float) * d->frac.size(), hipMemcpyHostToDevice));
         }
         d->plan_valid = true;
     }
     if (d->plan_outputs && n_streams > 0) {
         hipLaunchKernelGGL(k_fracdec, dim3(cdiv(d->plan_outputs, 256), n_streams), dim3(256), 0, c->stream, in, out, d->plan_outputs,
-                           in_pitch, out_pitch, d->d_lo, d->d_coef, P, d->d_taps, d->taps_length);
+                           in_pitch, out_pitch, d->d_lo, d->d_frac, P, d->xifirst, d->d_denom, d->d_taps, d->taps_length);
         CSDR_LAUNCH_CHECK();
     }
     d->input_processed = d->plan_processed;

@@ -868,6 +868,9 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
     // windows (fractional_decimator_ff) leaves a tail shorter than its window, which only the next call takes as the end of the stream.
     int extra_passes = 0, rc = 0;
     bool failed = false;
+    // CSDR_AMD_CLI_TIMING=1: wall time per stage (the stream drained around every call: a diagnostic, it serialises the process), printed at the end
+    const bool timing = getenv("CSDR_AMD_CLI_TIMING") != nullptr;
+    std::vector<double> t_stage(n_st, 0.0); std::vector<size_t> n_stage(n_st, 0);
     for (bool eof = false, again = true; again && !failed;) {
         // a new input buffer only when the first operator cannot take a whole block from what it already holds: an operator that leaves a tail per pass
         // (fir_decimate_cc, fractional_decimator_ff, deemphasis_nfm_ff) otherwise let the carry grow by that tail every pass while full blocks kept arriving
@@ -905,7 +908,10 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
                 if (nx.have_b % s->out_elem) { fprintf(stderr, "csdr chain: element sizes of \"%s\" and its consumer do not line up\n", g_cmd); failed = true; break; }
             }
             size_t consumed = 0;
+            struct timespec tq0, tq1;
+            if (timing) { (void)hipStreamSynchronize(st); clock_gettime(CLOCK_MONOTONIC, &tq0); }
             n_out = n_in ? s->process(c, d_src, n_in, dst, dst_cap, &consumed) : 0;
+            if (timing) { (void)hipStreamSynchronize(st); clock_gettime(CLOCK_MONOTONIC, &tq1); t_stage[k] += (tq1.tv_sec - tq0.tv_sec) + 1e-9 * (tq1.tv_nsec - tq0.tv_nsec); n_stage[k] += n_in; }
             if (consumed) progressed = true;
             {
                 Link &lk = L[k];
@@ -943,6 +949,7 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
     }
     // every exit goes through here: what was queued for the writer is written before the process ends
     if (failed) rc = 1;
+    if (timing) for (size_t k = 0; k < n_st; k++) fprintf(stderr, "csdr %s: stage %zu: %.3f s for %zu input elements (%.1f M elements/s)\n", g_cmd, k, t_stage[k], n_stage[k], t_stage[k] > 0 ? n_stage[k] / t_stage[k] / 1e6 : 0.0);
     hout[NBUF].eof = true; io.full_out.push(&hout[NBUF]);
     pthread_join(th_w, nullptr);
     (void)hipStreamSynchronize(st);
