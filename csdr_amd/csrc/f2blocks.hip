@@ -14,6 +14,7 @@
 //               it is an audio-rate block and parallel over streams only.
 // Built with -ffp-contract=off like the rest of the library.
 #include "common.hpp"
+#include <stdlib.h>
 #include <hipfft/hipfft.h>
 #include <math.h>
 #include <map>
@@ -189,6 +190,83 @@ __global__ void k_agc(const float *__restrict__ in, float *__restrict__ out, int
     last_gain_io[s] = last_gain;
 }
 
+// The same for FEW streams (a CLI process has one; the lane-per-stream walk above then waits for a global load and a division per sample: 3.8 M samples/s, the
+// slowest stage of the README's AM and SSB pipelines by two orders of magnitude).  One wave per stream: all lanes bring 1024 samples into LDS and form
+// reference / |x| (the state-independent division), lane 0 runs the state machine over them from LDS -- the reference's operations in the reference's order, so
+// bit exact like k_agc --, all lanes apply the gains and store.  The chain itself stays serial: it is the algorithm (libcsdr_gpl.c:163-260).
+constexpr int AGC_C = 1024;
+__global__ __launch_bounds__(64) void k_agc_coop(const float *__restrict__ in, float *__restrict__ out, size_t n, int block, size_t in_pitch, size_t out_pitch,
+                                                 float reference, float attack_rate, float decay_rate, float max_gain, short hang_time, short attack_wait_time, float alpha,
+                                                 float *__restrict__ last_gain_io)
+{
+    __shared__ float l_x[AGC_C], l_r[AGC_C];                         // samples; reference / |x|, then the gains
+    const int lane = threadIdx.x;
+    const size_t s = blockIdx.x;
+    const float *x = in + s * in_pitch;
+    float *y = out + s * out_pitch;
+    float last_gain = last_gain_io[s], gain = last_gain, last_peak = 0.f;
+    short hang_counter = 0, attack_wait_counter = 0;
+    size_t call_pos = 0;                                             // position inside the current libcsdr call (block samples each: counters and the peak estimate restart)
+    for (size_t at = 0; at < n; at += AGC_C) {
+        const int len = (int)((n - at < (size_t)AGC_C) ? n - at : AGC_C);
+        for (int k = lane; k < len; k += 64) { const float v = x[at + k]; l_x[k] = v; l_r[k] = reference / fabsf(v); }
+        __syncthreads();
+        if (lane == 0) {
+            // Branch free: every path of the reference's nested ifs is evaluated and the taken one selected -- the operations on the taken path are the
+            // reference's, so the values are; the dependent chain per sample is error -> compare -> select -> add -> two clamps -> filter (~10 operations) instead
+            // of a walk through exec-mask branches.  Eight samples' operands are read from LDS ahead of their chain.
+            const int aw_time = attack_wait_time, h_time = hang_time;
+            int hang = hang_counter, aw = attack_wait_counter;
+            for (int k0 = 0; k0 < len; k0 += 8) {
+                float xv[8], rv[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { const int k = k0 + j < len ? k0 + j : len - 1; xv[j] = l_x[k]; rv[j] = l_r[k]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (k0 + j >= len) break;
+                    float g_out;
+                    if (call_pos == 0) {                             // (uniform, once per `block` samples) a call's first sample: out[0] = last_gain * in[0]; the state
+                        hang = 0; aw = 0;                            // is set up from the carried gain
+                        gain = last_gain; last_peak = reference / last_gain;
+                        g_out = last_gain;
+                    } else {
+                        const float v = xv[j], av = fabsf(v);
+                        const float error = rv[j] - gain;
+                        const bool nz = v != 0, neg = error < 0;
+                        // error < 0: attack (with its wait counter and the peak estimate)
+                        const bool newpeak = last_peak < av;
+                        const int aw_a = newpeak ? aw_time : aw;
+                        const float lp_a = newpeak ? av : last_peak;
+                        const bool waiting = aw_a > 0;
+                        const float dg_a = waiting ? 0.f : error * attack_rate;
+                        const int aw_a2 = waiting ? aw_a - 1 : aw_a;
+                        const int hang_a = waiting ? hang : h_time;
+                        // error >= 0: decay (behind the hang counter)
+                        const bool hanging = hang > 0;
+                        const float dg_d = hanging ? 0.f : error * decay_rate;
+                        const int hang_d = hanging ? hang - 1 : hang;
+                        const float dgain = neg ? dg_a : dg_d;
+                        const float g1 = nz ? gain + dgain : gain;
+                        if (nz) { hang = neg ? hang_a : hang_d; aw = neg ? aw_a2 : aw; last_peak = neg ? lp_a : last_peak; }
+                        float g2 = g1 > max_gain ? max_gain : g1;
+                        g2 = g2 < 0 ? 0.f : g2;
+                        gain = g2 + last_gain - alpha * last_gain;
+                        g_out = gain;
+                        last_gain = gain;
+                    }
+                    l_r[k0 + j] = g_out;
+                    if (++call_pos == (size_t)block) call_pos = 0;
+                }
+            }
+            hang_counter = (short)hang; attack_wait_counter = (short)aw;
+        }
+        __syncthreads();
+        for (int k = lane; k < len; k += 64) y[at + k] = l_r[k] * l_x[k];
+        __syncthreads();
+    }
+    if (lane == 0) last_gain_io[s] = last_gain;
+}
+
 // ------------------------------------------------------------------ fft_cc framing + window
 // frame f, element i <- sample (f+1)*every - fft + i of [history | in] (overlapped mode) or f*every + i (every > fft)
 __global__ __launch_bounds__(256) void k_fft_frame(const cf32 *__restrict__ in, const cf32 *__restrict__ hist, const float *__restrict__ w, cf32 *__restrict__ frames,
@@ -280,6 +358,11 @@ int csdr_amd_agc_ff(csdr_amd_ctx *c, const float *in, float *out, int n_streams,
 {
     if (!n || n_streams <= 0) return 0;
     if (block <= 0) return fail_msg(-3, "agc_ff: block must be positive");
+    static const bool lane_env = getenv("CSDR_AMD_AGC_LANE") != nullptr;                // (A/B, read once per process)
+    if (n_streams < 64 && n >= 256 && !lane_env)
+        hipLaunchKernelGGL(k_agc_coop, dim3(n_streams), dim3(64), 0, c->stream, in, out, n, block, in_pitch, out_pitch, reference, attack_rate, decay_rate,
+                           max_gain, hang_time, attack_wait_time, gain_filter_alpha, last_gain_io);
+    else
     hipLaunchKernelGGL(k_agc, dim3(cdiv(n_streams, 64)), dim3(64), 0, c->stream, in, out, n_streams, n, block, in_pitch, out_pitch, reference, attack_rate, decay_rate,
                        max_gain, hang_time, attack_wait_time, gain_filter_alpha, last_gain_io);
     CSDR_LAUNCH_CHECK();
