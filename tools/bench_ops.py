@@ -108,6 +108,31 @@ ms = timeit(lambda: L.csdr_amd_fftfilt_process(f, xi.data_ptr(), yo.data_ptr(), 
 report("bandpass_fir_fft_cc fft=65536 taps=1023 (64 streams x 16 blocks)", ms, 16 * S4 * nb * inp, S4 * nb * inp)
 L.csdr_amd_fftfilt_destroy(f)
 
+# ---- the audio-rate operators of ONE stream (what a `csdr <command>` process of a shell pipeline runs): few streams, long in time -- the shapes whose first versions
+# (a lane per stream, coefficients built on the host) bounded the literal README.md:66 pipeline (profiles/r4_notes.md)
+n1 = 1 << 22
+x1 = (torch.rand(n1 + 64, dtype=torch.float32, device="cuda") - 0.5); y1 = torch.empty(n1 + 64, dtype=torch.float32, device="cuda")
+st1 = ctx.upload(np.zeros(4, np.float32))
+report("deemphasis_wfm_ff 48000 50e-6 (1 stream x 4 Mi: chunks on their own lanes, verified run-in, bit exact)",
+       timeit(lambda: L.csdr_amd_deemphasis_wfm_ff(ctx.h, x1.data_ptr(), y1.data_ptr(), 1, n1, n1, n1, 50e-6, 48000, st1.ptr)), 8 * n1, n1)
+L.csdr_amd_fracdec_set_where.argtypes = [C.c_void_p, C.c_float]
+for rate in (5.0, 5.5):
+    fd = L.csdr_amd_fracdec_create(rate, 12, None, 0)
+    proc = C.c_int(0)
+    def fd_step():
+        L.csdr_amd_fracdec_set_where(fd, 5.0)            # (every call a fresh plan, as the CLI's calls with their changing sizes have)
+        L.csdr_amd_fractional_decimator_ff(ctx.h, fd, x1.data_ptr(), y1.data_ptr(), 1, n1 - 8 * int(_fd_k[0] % 7), n1, n1, C.byref(proc)); _fd_k[0] += 1
+    _fd_k = [0]
+    report("fractional_decimator_ff %g (1 stream x 4 Mi, a new plan per call: the host walks the positions, the kernel evaluates the Lagrange coefficients)" % rate,
+           timeit(fd_step, reps=6, warm=1), (4 + 4 / rate) * n1, n1)
+    L.csdr_amd_fracdec_destroy(fd)
+g1 = ctx.upload(np.ones(1, np.float32))
+n_agc = 1 << 20
+report("agc_ff (1 stream x 1 Mi, calls of 1024 samples)",
+       timeit(lambda: L.csdr_amd_agc_ff(ctx.h, x1.data_ptr(), y1.data_ptr(), 1, n_agc, 1024, n_agc, n_agc, 0.2, 0.01, 0.0001, 65536.0, 200, 0, 0.999, g1.ptr), reps=3, warm=1), 8 * n_agc, n_agc,
+       {"bound": "serial per stream: a data-dependent state machine per sample (libcsdr_gpl.c:163-260) on one lane; the HBM roofline does not apply"})
+del x1, y1
+
 # ---- IMA ADPCM codec (f3): a serial state machine per stream (one lane per stream).  The call's time is the per-stream chain (~55 dependent instructions per sample at
 # one wave instruction per ~5 cycles = ~190 ns per sample) whatever the stream count, up to 2 x 1024 x 64 = 131072 streams; staging the rows through LDS for coalesced
 # accesses, the step table in LDS and spreading the streams over more waves were all measured and changed nothing (profiles/r2_notes.md)
