@@ -396,7 +396,7 @@ def _read_until_quiet(f, quiet=1.0, limit=60.0):
     import select, time
     out = b""; t_end = time.time() + limit
     while time.time() < t_end:
-        r, _, _ = select.select([f], [], [], quiet)
+        r, _, _ = select.select([f], [], [], quiet if out else max(t_end - time.time(), quiet))      # (the first bytes may take a process start-up on a cold box)
         if not r: break
         chunk = os.read(f.fileno(), 1 << 20)
         if not chunk: break
