@@ -18,6 +18,7 @@ namespace {
 // one lane per stream: entries [0, cap) of the new table.  old == nullptr: stream start (phase 0 in front of chunk 0, and the "chunk" in front of it).
 // Otherwise entries 0 and 1 are the old table's idx and idx + 1 (the history chunk and the first chunk of the call: both were advanced under the rate that was
 // valid then), everything behind advances by the current rate.
+template <bool RAISED>
 __global__ __launch_bounds__(64) void k_seed_phases(const float *__restrict__ rates, const float *__restrict__ old_ph, long idx, float *__restrict__ ph, size_t pitch, int cap, int n_streams)
 {
     const int s = blockIdx.x * 64 + threadIdx.x;
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(64) void k_seed_phases(const float *__restrict__ ra
     if (old_ph) { p0 = old_ph[(size_t)idx * pitch + s]; p1 = old_ph[(size_t)(idx + 1) * pitch + s]; }
     ph[s] = p0; ph[pitch + s] = p1;
     WrapPlan w; wrap_plan_init(w, step);
-    __builtin_amdgcn_s_setprio(3);                                    // eight waves beside the data kernels' thousands: a chain of dependent operations, let it issue
+    if (RAISED) __builtin_amdgcn_s_setprio(3);                        // eight waves beside the data kernels' thousands: a chain of dependent operations, let it issue
     float p = p1;
     for (int k = 2; k < cap; k++) {
         p = wrap_plan_apply(w, p + step);                             // libcsdr_gpl.c:48-51, exactly (seeds.hpp)
@@ -117,7 +118,10 @@ int generate(SeedTables *t, int dst, int src, long idx, long long first)
 {
     hipStream_t ss = t->side;
     if (t->free_pending[dst]) { CSDR_HIP(hipStreamWaitEvent(ss, t->ev_free[dst], 0)); t->free_pending[dst] = false; }      // the data kernels that read it have finished
-    hipLaunchKernelGGL(k_seed_phases, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
+    static const bool raised = !(getenv("CSDR_AMD_SEED_PRIO") && atoi(getenv("CSDR_AMD_SEED_PRIO")) == 0);      // (A/B, read once per process)
+    if (!raised) hipLaunchKernelGGL(k_seed_phases<false>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
+    else
+    hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
     CSDR_LAUNCH_CHECK();
     const size_t count = t->pitch * (size_t)t->cap;
     hipLaunchKernelGGL(k_seed_cossin, dim3(cdiv(count, 256)), dim3(256), 0, ss, t->d_ph[dst], t->d_c[dst], count);
