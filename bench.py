@@ -85,21 +85,29 @@ def other_configs():
     return out
 
 
-def operating_points(ctx, taps):
+def operating_points(ctx, taps, verify=True):
     """The same chain object at the blocks a live receiver bank hands over (the reference's loop moves 16384 samples per read, csdr.c:189-193, 330-392): many streams,
     short blocks.  One step = one call over all streams; state carried; inputs resident in HBM."""
     import torch
     L = ctx.L
     pts = []
     import numpy as np
+    if verify and os.path.join(ROOT, "tests") not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
     for S, T, steps, per_stream in ((1024, 2344 * 1024, 100, True), (1024, 16384, 400, False), (65536, 24576, 60, False)):
         pitch = 2 * T
         x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda")
         na_max = (T // 50 + 64 + 63) // 64 * 64
         out = torch.empty((S, na_max), dtype=torch.int16, device="cuda")
+        rates = (-0.45 + 0.9 * (np.arange(S) + 0.5) / S).astype(np.float32) if per_stream else None
+        strict_rows = []
+        if verify:          # as in the headline: a real FM signal (at -rate of its stream) in four rows spread over the batch, put there before the timed loop
+            from tests_helpers import wfm_signal_u8
+            strict_rows = sorted({r for r in (5, S // 3 + 1, (2 * S) // 3 + 2, S - 2) if 0 <= r < S})
+            for k, r in enumerate(strict_rows):
+                x[r, :2 * T] = torch.from_numpy(wfm_signal_u8(7100 + k, T, offset=-float(rates[r]) if per_stream else 0.085)).cuda()
         torch.cuda.synchronize()
         if per_stream:      # the headline shape with a shift rate PER STREAM (csdr_amd_wfm_create_rates: one workgroup = one stream x 16 time segments)
-            rates = (-0.45 + 0.9 * (np.arange(S) + 0.5) / S).astype(np.float32)
             w = L.csdr_amd_wfm_create_rates(ctx.h, S, rates.ctypes.data_as(C.c_void_p), 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
         else:
             w = L.csdr_amd_wfm_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T)
@@ -122,6 +130,14 @@ def operating_points(ctx, taps):
                     "value": round(S * T * steps / wall / 1e6, 1), "unit": "complex MS/s", "realtime_factor_per_stream": round((T / 2.4e6) / (wall / steps), 1),
                     "kernel": L.csdr_amd_wfm_kernel_name(w).decode(), "kernel_avg_ms": round(k_ms, 4),
                     "frac": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms else None, "fallback": bool(L.csdr_amd_wfm_fallback(w))})
+        if verify:          # after the timed loop: fresh-state pass of the same object / buffers, strict rows +-1 LSB and float audio <= 1e-5 against the oracle
+            import verify_configs as vc
+            L.csdr_amd_wfm_set_profiling(w, 0)
+            outf = torch.empty((S, na_max), dtype=torch.float32, device="cuda")
+            v = vc.verify_wfm(ctx, w, x, out, S, T, pitch, na_max, taps, shift_rate=rates if per_stream else -0.085, rows=[], strict_rows=strict_rows, out_f32=outf)
+            pts[-1]["verify_ok"] = v["ok"]
+            pts[-1]["verify"] = {k: v[k] for k in ("strict_rows", "strict_rows_max_abs_diff_lsb", "strict_rows_max_rel_rms", "strict_rows_samples_compared", "rows_expected_len", "rows_got_len")}
+            del outf
         L.csdr_amd_wfm_destroy(w)
         del x, out; torch.cuda.empty_cache()
     return pts
@@ -266,12 +282,14 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import verify_configs as vc
             L.csdr_amd_wfm_set_profiling(w, 0)
+            out_f32 = torch.empty((S, n_audio_max), dtype=torch.float32, device="cuda")      # the float audio of the same pass: north_star's 1e-5 gate on the strict rows
             res["verify"] = vc.verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, rows=[r for r in vc.pick_rows(S) if r not in strict_rows] if args.verify else [],
-                                          strict_rows=strict_rows)
+                                          strict_rows=strict_rows, out_f32=out_f32)
+            del out_f32
         if world == 1 and not args.no_other_configs:
             L.csdr_amd_wfm_destroy(w); w = None
             del x, out_s16; torch.cuda.empty_cache()
-            res["operating_points"] = operating_points(ctx, taps)
+            res["operating_points"] = operating_points(ctx, taps, verify=do_verify)
             res["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -839,13 +839,14 @@ def _bank_input(x):
 
 
 def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode="blocks", window="HAMMING", retunes=None, pipelined=True,
-                          local_input=False, device=0, retune_while_staged=False):
+                          local_input=False, device=0, retune_while_staged=False, superseded_retune=False):
     """The multi-rank fastddc bank (csdr_amd_fastddc_bank_create_sharded_by) run for real on ONE GPU: `world` rank threads, one Context each, joined by the
     library's loopback communicator (every exchange = stream-ordered device copies).  x = the wideband stream (on rank 0; local_input: every rank is handed
     its own run of each batch instead), schedule = blocks per batch, retunes = {batch index: [(global channel, rate), ...]} applied before that batch.
     pipelined: submit(k + 1) is queued before collect(k) wherever no retune sits in between -- or, with retune_while_staged, everywhere: batch k + 1's retunes are
-    then issued while batch k is still staged (they must leave batch k alone and apply from batch k + 1 on, in both sharding modes).  Returns the per-channel outputs (all channels, gathered from the
-    ranks' slices)."""
+    then issued while batch k is still staged (they must leave batch k alone and apply from batch k + 1 on, in both sharding modes).  superseded_retune (with
+    retune_while_staged, unpipelined): the retune issued while batch k is staged goes to a DECOY rate and the real one follows after collect(k), when nothing is
+    staged -- the held-back decoy must not be replayed on top of it at collect(k + 1).  Returns the per-channel outputs (all channels, gathered from the ranks' slices)."""
     import threading
     L = lib()
     x, sfx, es = _bank_input(x)                          # complex64, or interleaved IQ as int16 / uint8 (the _s16 / _u8 entry points: the raw integers are scattered)
@@ -901,7 +902,7 @@ def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode
                     submit(k); submitted = k
                 if retune_while_staged:                               # batch k is staged, not collected: the next batch's retunes arrive now
                     for ch, rt in retunes.get(k + 1, []):
-                        ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt), "bank_set_rate_global")
+                        ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt + 0.0517 if superseded_retune else rt), "bank_set_rate_global")
                 if pipelined and k + 1 < len(schedule) and (retune_while_staged or (k + 1) not in retunes):
                     submit(k + 1); submitted = k + 1
                 pitch = L.csdr_amd_fastddc_bank_max_output(bank, schedule[k]) + 8
@@ -909,6 +910,9 @@ def sharded_bank_loopback(world, x, tbw, decimation, shift_rates, schedule, mode
                 ctx.check(L.csdr_amd_fastddc_bank_collect(bank, do.ptr, pitch, None), "bank_collect")
                 counts = np.zeros(count, np.int32)
                 ctx.check(L.csdr_amd_fastddc_bank_finish(bank, _hp(counts)), "bank_finish")
+                if superseded_retune:                                 # nothing is staged now: the real rate, applied at once
+                    for ch, rt in retunes.get(k + 1, []):
+                        ctx.check(L.csdr_amd_fastddc_bank_set_rate_global(bank, ch, rt), "bank_set_rate_global")
                 y = ctx.download(do, c64, count * pitch).reshape(count, pitch)
                 for c in range(count):
                     mine[c].append(y[c, :counts[c]].copy())

@@ -39,6 +39,7 @@
 #include <time.h>
 #include <string>
 #include <vector>
+#include <atomic>
 
 namespace {
 
@@ -597,7 +598,7 @@ struct Control {
 //   * per block a writes its result into a free slot, waits for the kernels (stream-ordered event), sends the token {slot, bytes} over the socket; b copies
 //     the slot into its own input buffer device-to-device on its stream and returns the slot as a credit once that copy has run.  End of stream = the socket
 //     closes.  The 8-byte "csdr"+int preamble of CSDR_DYNAMIC_BUFSIZE_ON still travels through the pipe itself.
-// CSDR_AMD_IPC=0 switches the whole mechanism off; CSDR_AMD_IPC_WAIT_MS (default 50) is how long a producer keeps trying to find a listener that is not there
+// CSDR_AMD_IPC=0 switches the whole mechanism off; CSDR_AMD_IPC_WAIT_MS (default 250) is how long a producer keeps trying to find a listener that is not there
 // yet (a consumer of ours listens within a millisecond of its exec, long before the producer's HIP start-up is over); CSDR_AMD_IPC_VERBOSE=1 prints one line
 // per link on stderr.
 struct IpcHello { char magic[8]; int version, device; char bus_id[32]; hipIpcMemHandle_t mem; unsigned n_slots, reserved; unsigned long long slot_bytes; };
@@ -624,6 +625,12 @@ void ipc_listen_on_stdin()
     if (bind(fd, (struct sockaddr *)&sa, len) != 0 || listen(fd, 1) != 0) { close(fd); return; }
     g_ipc_listen = fd;
 }
+// the abstract socket name is predictable (dev:ino of the pipe): only a peer of OUR uid gets the IPC handle / is believed (SO_PEERCRED)
+bool ipc_peer_is_ours(int fd)
+{
+    struct ucred cr; socklen_t len = sizeof cr;
+    return getsockopt(fd, SOL_SOCKET, SO_PEERCRED, &cr, &len) == 0 && len == sizeof cr && cr.uid == geteuid();
+}
 void ipc_device_id(int device, char bus_id[32]) { memset(bus_id, 0, 32); if (hipDeviceGetPCIBusId(bus_id, 32, device) != hipSuccess) bus_id[0] = 0; }
 
 // consumer: blocks until the producer has connected (-> the connected socket, ring mapped) or has started to write bytes / closed the pipe (-> -1).  Once.
@@ -643,6 +650,7 @@ IpcSource *ipc_source_decide(int device)
     }
     close(g_ipc_listen); g_ipc_listen = -1;
     if (conn < 0) return nullptr;
+    if (!ipc_peer_is_ours(conn)) { close(conn); return nullptr; }
     IpcHello h; int ack = 0;
     char mine[32]; ipc_device_id(device, mine);
     void *ring = nullptr;
@@ -662,7 +670,7 @@ int ipc_sink_connect(int device, void *ring, unsigned n_slots, size_t slot_bytes
 {
     struct sockaddr_un sa; socklen_t len;
     if (!ipc_enabled() || !ipc_pipe_name(STDOUT_FILENO, &sa, &len)) return -1;
-    long wait_ms = 50; if (const char *e = getenv("CSDR_AMD_IPC_WAIT_MS")) wait_ms = atol(e);
+    long wait_ms = 250; if (const char *e = getenv("CSDR_AMD_IPC_WAIT_MS")) wait_ms = atol(e);
     int fd = -1;
     struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
     for (;;) {
@@ -674,6 +682,7 @@ int ipc_sink_connect(int device, void *ring, unsigned n_slots, size_t slot_bytes
         if ((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000 >= wait_ms) return -1;
         usleep(2000);
     }
+    if (!ipc_peer_is_ours(fd)) { close(fd); return -1; }
     IpcHello h; memset(&h, 0, sizeof h);
     memcpy(h.magic, IPC_MAGIC, 8); h.version = 1; h.device = device; ipc_device_id(device, h.bus_id); h.n_slots = n_slots; h.slot_bytes = slot_bytes;
     int ack = 0;
@@ -705,6 +714,7 @@ struct IoThreads {
     BufQueue free_in, full_in, free_out, full_out;
     IpcSource *src = nullptr; BufQueue copied_in;                    // device hand-off, consumer side: blocks whose device copy is queued (their slots go back as credits)
     int sink_fd = -1; HostBuf *sink_bufs = nullptr;                  // producer side: tokens out, credits back; sink_bufs[slot]
+    std::atomic<bool> sink_closing{false};                           // the writer has sent its last token and shut the socket down: EOF on the credit side is then the normal end
 };
 
 // blocks until min_bytes have arrived (or EOF / error), then keeps reading only while more is immediately available
@@ -762,7 +772,21 @@ void *reader_ipc_main(void *arg)
         IpcToken t;
         const ssize_t r = recv(io->src->fd, &t, sizeof t, 0);
         const bool eof = r != (ssize_t)sizeof t || t.slot >= io->src->n_slots || t.bytes > io->src->slot_bytes;
-        if (eof) { HostBuf *b = io->free_in.pop(); b->bytes = 0; b->eof = true; b->dev = nullptr; b->slot = -1; io->full_in.push(b); return nullptr; }
+        if (eof) {
+            // The handing-over producer is done.  Whatever any OTHER or later writer of the same pipe sends ( `(csdr a; csdr a2) | csdr b`: a2 finds no listener and
+            // writes bytes ) is still part of the stream: carry on in byte mode until stdin itself ends (pinned buffers are only allocated now).
+            (void)hipSetDevice(io->device);
+            for (;;) {
+                HostBuf *b = io->free_in.pop();
+                if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }
+                b->dev = nullptr; b->slot = -1;
+                if (!b->p && hipHostMalloc((void **)&b->p, b->cap, hipHostMallocDefault) != hipSuccess) { b->p = nullptr; b->bytes = 0; b->eof = true; io->full_in.push(b); return nullptr; }
+                read_some(b->p, io->min_bytes, io->max_bytes, &b->bytes, &b->eof);
+                const bool end = b->eof;
+                io->full_in.push(b);
+                if (end) return nullptr;
+            }
+        }
         size_t off = 0;
         do {                                                         // at most max_bytes per pass, like the byte reader: a token may be cut into several blocks
             HostBuf *b = io->free_in.pop();
@@ -791,7 +815,7 @@ void *writer_ipc_main(void *arg)
     (void)hipSetDevice(io->device);
     for (;;) {
         HostBuf *b = io->full_out.pop();
-        if (b->eof) { shutdown(io->sink_fd, SHUT_WR); return nullptr; }
+        if (b->eof) { io->sink_closing.store(true); shutdown(io->sink_fd, SHUT_WR); return nullptr; }
         if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }          // the kernels that filled the slot have run
         IpcToken t = {(unsigned)b->slot, 0u, (unsigned long long)b->bytes};
         if (send(io->sink_fd, &t, sizeof t, MSG_NOSIGNAL) != (ssize_t)sizeof t) _exit(0);   // downstream closed: end quietly like SIGPIPE would
@@ -803,7 +827,11 @@ void *credit_in_main(void *arg)
     for (;;) {
         int s = -1;
         const ssize_t r = recv(io->sink_fd, &s, sizeof s, 0);
-        if (r == 0) return nullptr;                                                         // the consumer is done (after our shutdown)
+        if (r < 0 && errno == EINTR) continue;
+        // EOF after our own shutdown: the consumer is done.  EOF BEFORE it: the consumer died or left mid-stream (`| head`, its own error exit) -- with every ring
+        // slot in flight the main thread sits in free_out.pop() and the writer has no token left to send, so nobody would ever see EPIPE: end quietly,
+        // as SIGPIPE ends a producer that writes bytes.
+        if (r == 0 && io->sink_closing.load()) return nullptr;
         if (r != (ssize_t)sizeof s || s < 0) _exit(0);
         io->free_out.push(&io->sink_bufs[s]);
     }

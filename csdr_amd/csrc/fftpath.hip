@@ -17,6 +17,7 @@ namespace csdr_amd { const DdcComm *csdr_amd_comm_ddc(csdr_amd_comm *c); }   // 
 #include <math.h>
 #include <vector>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string.h>
 using namespace csdr_amd;
@@ -610,10 +611,13 @@ static csdr_amd_fastddc_inv *fastddc_inv_create_comm(csdr_amd_ctx *ctx, float tr
         // The batched plan for the taps is kept for the life of the process, one per (fft, channels), used under a lock: creating AND destroying a plan per
         // object made the create of a SECOND object in a process fault now and then inside this block (GPU memory access fault at addresses of a few MiB, before
         // the new object had processed anything; about one create in five behind a bench run -- profiles/r4_notes.md; not seen once the plan survives).
-        static std::map<std::pair<int, int>, hipfftHandle> taps_plans;
+        // Keyed by the DEVICE too: a plan's twiddles, work buffer and loaded kernels live on the device that was current at its creation; the rank
+        // threads of a multi-GPU loopback bank (one context per device, equal n_channels in time-sliced mode) must not share device 0's plan.
+        static std::map<std::tuple<int, int, int>, hipfftHandle> taps_plans;
         static std::mutex taps_mu;
         std::lock_guard<std::mutex> lk(taps_mu);
-        const auto key = std::make_pair(fft, n_channels);
+        (void)hipSetDevice(ctx->device);
+        const auto key = std::make_tuple(ctx->device, fft, n_channels);
         if (!taps_plans.count(key)) {
             hipfftHandle h; int n[1] = {fft};
             if (hipfftPlanMany(&h, 1, n, nullptr, 1, fft, nullptr, 1, fft, HIPFFT_C2C, n_channels) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlanMany(taps) failed"); delete f; return nullptr; }
@@ -988,6 +992,14 @@ void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
 int csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count)
 { *first = b->first_channel; *count = b->shard_mode == CSDR_AMD_SHARD_BLOCKS ? b->out_count : b->inv->n_channels; return 0; }
 int csdr_amd_fastddc_bank_shard_mode(const csdr_amd_fastddc_bank *b) { return b->world > 1 ? b->shard_mode : -1; }
+// Nothing staged: every retune still queued concerns batches that are not submitted yet, so it takes effect now, in issue order -- BEFORE a newer retune of the
+// same channel is applied directly (left in the queue it would be replayed at the next collect on top of the newer rate: ADVICE r4).
+static int bank_flush_deferred(csdr_amd_fastddc_bank *b)
+{
+    for (const auto &d : b->deferred) { const int rc = csdr_amd_fastddc_inv_set_rate(b->inv, d.channel, d.rate); if (rc) return rc; }
+    b->deferred.clear();
+    return 0;
+}
 int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float shift_rate)
 {   // channel = index into this rank's OUTPUT slice (an unsharded bank: the channel) in both sharding modes.  A time-sliced bank computes every channel on every
     // rank: there the slice index is mapped to the global channel -- but the other ranks have to hear of the retune too (csdr_amd_fastddc_bank_set_rate_global on
@@ -996,6 +1008,7 @@ int csdr_amd_fastddc_bank_set_rate(csdr_amd_fastddc_bank *b, int channel, float 
         int first = 0, count = 0;
         if (csdr_amd_fastddc_bank_channel_slice(b, &first, &count) || channel < 0 || channel >= count) return fail_msg(-3, "fastddc_bank: channel %d outside this rank's slice of %d", channel, count);
         if (b->n_batches) { b->deferred.push_back({b->seq_submit, first + channel, shift_rate}); return 0; }      // (staged batches keep the old rate)
+        if (const int rc = bank_flush_deferred(b)) return rc;
         return csdr_amd_fastddc_inv_set_rate(b->inv, first + channel, shift_rate);
     }
     if (b->seq_submit != b->seq_collect) return fail_msg(-3, "fastddc_bank: a batch is staged (submitted, not collected): its tables are partly fixed already -- collect it before retuning (a time-sliced bank holds such a retune back itself)");
@@ -1006,6 +1019,7 @@ int csdr_amd_fastddc_bank_set_rate_global(csdr_amd_fastddc_bank *b, int channel,
     if (channel < 0 || channel >= b->n_channels_total) return fail_msg(-3, "fastddc_bank: channel %d out of range", channel);
     if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {
         if (b->n_batches) { b->deferred.push_back({b->seq_submit, channel, shift_rate}); return 0; }                 // (staged batches keep the old rate)
+        if (const int rc = bank_flush_deferred(b)) return rc;
         return csdr_amd_fastddc_inv_set_rate(b->inv, channel, shift_rate);
     }
     if (b->seq_submit != b->seq_collect) return fail_msg(-3, "fastddc_bank: a batch is staged (submitted, not collected): its tables are partly fixed already -- collect it before retuning (a time-sliced bank holds such a retune back itself)");

@@ -329,6 +329,11 @@ int csdr_amd_wfm_set_rate(csdr_amd_wfm *w, int stream, float shift_rate)
     if (!w->ps) return fail_msg(-3, "wfm_set_rate: the object shares one rate (create it with csdr_amd_wfm_create_rates)");
     if (stream < 0 || stream >= w->n_streams) return fail_msg(-3, "wfm_set_rate: stream %d out of range", stream);
     if (w->rates[stream] == shift_rate) return 0;
+    // The audio samples whose windows reach back across the retune instant are recomputed with both tables (k_wfm_lead); d_lead_d holds 4 per stream.  A window
+    // spans D + L - 1 samples and audio samples lie D F apart: shapes with more straddling samples than that (short D F under a long filter) would get the
+    // samples beyond the fourth from the new table alone -- not csdr.c:881-923's semantics -- so they are refused instead (10 / 79 / 5 has at most 3).
+    if ((w->D + w->L - 1) / (w->D * w->F) + 2 > 4)
+        return fail_msg(-3, "wfm_set_rate: live retune is not available for decimation %d, %d taps, audio decimation %d (more than 4 audio samples straddle a retune)", w->D, w->L, w->F);
     CSDR_HIP(hipStreamSynchronize(w->ctx->stream));                   // calls in flight read this stream's tables
     if (!w->d_dtab_old) CSDR_HIP(hipMalloc((void **)&w->d_dtab_old, sizeof(float2) * 3072 * (size_t)w->n_streams));
     bool listed = false;

@@ -250,6 +250,56 @@ def test_cli_device_handoff_refused_falls_back_to_bytes(tmp_path):
     assert all("hand-off to the next process refused" in errs[i] and "hand-off from the previous process refused" in errs[i + 1] for i in range(6)), errs
 
 
+def test_cli_device_handoff_consumer_dies_midstream():
+    """`csdr a | csdr b` with device hand-off, b killed in the middle of an endless stream while all ring slots are in flight -- a byte pipe would
+    end `a` with SIGPIPE; the hand-off's credit socket must do the same (EOF on the credit side BEFORE the producer's own shutdown = the consumer is gone) instead of
+    leaving `a` blocked on a free slot forever."""
+    import signal
+    import threading
+    import time
+    env = dict(os.environ, CSDR_AMD_BLOCK="65536", CSDR_AMD_IPC_WAIT_MS="3000", CSDR_AMD_IPC_VERBOSE="1")
+    a = subprocess.Popen([CLI, "convert_u8_f"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    b = subprocess.Popen([CLI, "shift_addition_cc", "0.1"], stdin=a.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+    a.stdout.close()
+    chunk = np.random.default_rng(31).integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+
+    def feed():
+        try:
+            while True:
+                a.stdin.write(chunk)
+        except (BrokenPipeError, OSError, ValueError):
+            pass
+    t = threading.Thread(target=feed, daemon=True); t.start()
+    got = 0
+    while got < (8 << 20):                                           # the stream is flowing: 8 MB of output seen
+        d = b.stdout.read(1 << 20)
+        assert d, "consumer ended early"
+        got += len(d)
+    b.send_signal(signal.SIGKILL); b.wait(timeout=10)
+    try:
+        a.wait(timeout=20)                                           # (before the fix: never)
+    except subprocess.TimeoutExpired:
+        a.kill(); a.wait()
+        raise AssertionError("the producer stayed blocked after its hand-off consumer was killed: " + a.stderr.read().decode()[-400:])
+    t.join(timeout=10)
+    assert not t.is_alive()
+
+
+def test_cli_handoff_then_bytes_from_a_second_writer(port, tmp_path):
+    """`(csdr a < f1; csdr a < f2) | csdr b` -- the first producer hands over in HBM, the second finds no listener any more and writes bytes into the
+    same pipe: b must carry on in byte mode after the hand-off socket's EOF until stdin itself ends (the reference's b sees one stream, csdr.c:232-247)."""
+    rng = np.random.default_rng(32)
+    x1 = rng.integers(0, 256, 300000, dtype=np.uint8); x2 = rng.integers(0, 256, 200000, dtype=np.uint8)
+    f1 = tmp_path / "f1.u8"; f2 = tmp_path / "f2.u8"; x1.tofile(f1); x2.tofile(f2)
+    env = dict(os.environ, CSDR_AMD_BLOCK="65536", CSDR_AMD_IPC_WAIT_MS="3000")
+    cmd = "(%s convert_u8_f < %s; %s convert_u8_f < %s) | %s convert_f_u8" % (CLI, f1, CLI, f2, CLI)
+    p = subprocess.run(["bash", "-c", cmd], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    want = port.convert_f_u8(port.convert_u8_f(np.concatenate([x1, x2])))
+    got = np.frombuffer(p.stdout, np.uint8)
+    assert got.size == want.size and np.array_equal(got, want)
+
+
 def test_cli_wfm_shell_pipeline(port):
     """README.md:66 as seven processes and as the fused `wfm_chain_u8_s16`, against the oracle chain and the reference's own CLI."""
     iq = fm_iq(np.random.default_rng(9), 480000)

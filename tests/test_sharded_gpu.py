@@ -98,6 +98,16 @@ def test_retune_while_a_batch_is_staged(gpu, case):
         L.csdr_amd_fastddc_bank_destroy(bank)
 
 
+def test_a_held_back_retune_does_not_override_a_newer_one(gpu, case):
+    """time-sliced bank, retune A of a channel issued while batch k is staged (held back for collect(k + 1)), then -- after collect(k), nothing
+    staged -- retune B of the same channel, applied at once.  The queue must not replay A on top of B at collect(k + 1): the streams are those of the single-GPU bank
+    retuned to B between the two batches."""
+    import csdr_amd
+    x, rates, single, want = case
+    outs = csdr_amd.sharded_bank_loopback(2, x, TBW, D, rates, SCHEDULE, mode="blocks", retunes=RETUNES, pipelined=False, retune_while_staged=True, superseded_retune=True)
+    _check(outs, single, want)
+
+
 def test_sharded_bank_loopback_unpipelined_and_odd_world(gpu, case):
     """three ranks (256 channels do not divide: slices of 86 / 85 / 85; runs of 22 blocks), every batch submitted and collected in turn"""
     import csdr_amd

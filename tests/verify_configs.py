@@ -36,7 +36,7 @@ def summarize(diffs, n_expected, n_got):
             "rows_expected_len": int(n_expected), "rows_got_len": int(n_got)}
 
 
-def verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, shift_rate=-0.085, decimation=10, rows=None, strict_rows=()):
+def verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, shift_rate=-0.085, decimation=10, rows=None, strict_rows=(), out_f32=None):
     """Fresh-state pass of the SAME object / buffers / launch configuration as the timed steps (csdr_amd_wfm_reset, one
     csdr_amd_wfm_process over all S streams x T samples), then `rows` full audio rows against oracle.port().wfm_chain on the same bytes.
     Gate on the bench's own input (i.i.d. uniform u8 = band-limited noise after the FIR): < 5 % of the s16 samples differ at all, < 0.5 % by
@@ -48,33 +48,42 @@ def verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, shift_rate=-0
     FM signal, where the denominator stays near 0.49) are held to max <= 1 LSB.
     The HIP path may emit the last one or two audio samples of a block EARLIER than the reference's fractional_decimator_ff, whose loop
     waits for num_poly_points samples of look-ahead it never uses at an integer rate (libcsdr.c:763): a stream sees identical samples, only
-    the block boundary moves, so 0 <= got - expected <= 2 is accepted and the common prefix compared."""
+    the block boundary moves, so 0 <= got - expected <= 2 is accepted and the common prefix compared.
+    shift_rate: one float, or one per stream (an object made by csdr_amd_wfm_create_rates; the caller's strict rows then carry a signal at -rate of that stream).
+    out_f32 (a [S, n_audio_max] float32 device buffer): the pass also writes the float audio (the chain's output in front of convert_f_s16) and the strict rows are
+    ALSO held to north_star's float gate, relative RMS <= 1e-5 over the whole row against the oracle's float audio (`strict_rows_max_rel_rms`)."""
     import oracle
     port = oracle.port()
     L = ctx.L
     rc = L.csdr_amd_wfm_reset(w)
     assert rc == 0, ctx.err()
-    n = L.csdr_amd_wfm_process(w, x.data_ptr(), pitch, T, out_s16.data_ptr(), None, n_audio_max)
+    n = L.csdr_amd_wfm_process(w, x.data_ptr(), pitch, T, out_s16.data_ptr(), out_f32.data_ptr() if out_f32 is not None else None, n_audio_max)
     assert n >= 0, ctx.err()
     ctx.sync()
     rows = pick_rows(S) if rows is None else rows
-    diffs = []; n_ref = -1; strict_max = 0
+    diffs = []; n_ref = -1; strict_max = 0; strict_rms = 0.0; strict_n = 0
     for r in list(rows) + list(strict_rows):
         u8 = x[r, :2 * T].cpu().numpy()
-        ps, _ = port.wfm_chain(u8, shift_rate, decimation, taps)
+        ps, pf = port.wfm_chain(u8, float(shift_rate[r]) if np.ndim(shift_rate) else shift_rate, decimation, taps)
         got = out_s16[r, :n].cpu().numpy()
         n_ref = ps.size
         m = min(ps.size, got.size)
         d = s16_diff(got[:m], ps[:m])
         if r in strict_rows:
-            strict_max = max(strict_max, int(d.max()))
+            strict_max = max(strict_max, int(d.max()) if d.size else 0); strict_n += int(d.size)
+            if out_f32 is not None and m:
+                strict_rms = max(strict_rms, relrms(out_f32[r, :m].cpu().numpy(), pf[:m]))
         else:
             diffs.append(d)
     res = summarize(diffs, n_ref, n)
-    res["rows"] = list(rows); res["strict_rows"] = list(strict_rows); res["strict_rows_max_abs_diff_lsb"] = strict_max
+    res["rows"] = list(rows); res["strict_rows"] = list(strict_rows); res["strict_rows_max_abs_diff_lsb"] = strict_max; res["strict_rows_samples_compared"] = strict_n
+    if out_f32 is not None:
+        res["strict_rows_max_rel_rms"] = float("%.3g" % strict_rms)
     res["kernel"] = L.csdr_amd_wfm_kernel_name(w).decode()
-    res["gate"] = "frac_nonzero < 0.05, frac_over_1_lsb < 0.005 (noise input: ill-conditioned demodulator, see tests/verify_configs.py), strict rows max <= 1 LSB, 0 <= got_len - expected_len <= 2"
-    res["ok"] = bool(0 <= n - n_ref <= 2 and res["frac_over_1_lsb"] < 5e-3 and res["frac_nonzero"] < 0.05 and strict_max <= 1)
+    res["gate"] = ("frac_nonzero < 0.05, frac_over_1_lsb < 0.005 (noise input: ill-conditioned demodulator, see tests/verify_configs.py), strict rows max <= 1 LSB"
+                   + (" and float audio rel. RMS <= 1e-5" if out_f32 is not None else "") + ", 0 <= got_len - expected_len <= 2")
+    res["ok"] = bool(0 <= n - n_ref <= 2 and res["frac_over_1_lsb"] < 5e-3 and res["frac_nonzero"] < 0.05 and strict_max <= 1 and strict_rms <= 1e-5
+                     and (strict_n > 0 or not strict_rows))
     return res
 
 
