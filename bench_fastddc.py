@@ -181,6 +181,105 @@ def emulate(args):
     ctx.close()
 
 
+def all_modes(ctx, L, comm, rank, world, args, barrier, allmax, allmin, dev=None, log=None):
+    """First contact of the sharded bank with N > 1 ranks: on the communicator `comm` (RCCL; the tests drive the same function over the loopback
+    transport with rank threads) run csdr_amd_comm_selftest, then BOTH shard modes x {cf32, s16, u8} in ONE invocation.  Per mode: a fresh sharded bank; its first
+    batch is checked on every rank against an unsharded bank of the rank's channel slice on the same input (broadcast from rank 0 for that purpose; gate 2e-6
+    relative RMS and equal counts -- the single-GPU bank is itself oracle-clean, tests/test_configs_gpu.py), then `steps` pipelined steps are timed (barrier, max over
+    ranks).  Returns {"selftest": [...], "modes": [six entries]} on rank 0 (the other ranks: their own view, unused).
+    barrier() / allmax(x) / allmin(x): the process group of the caller (torch.distributed in main(), a threading.Barrier in the tests)."""
+    import numpy as np
+    import torch
+    import csdr_amd
+    from csdr_amd import dist as cd
+    dev = dev if dev is not None else torch.device("cuda", torch.cuda.current_device())
+    ddc, err = ctx.fastddc_init(args.tbw, args.decimation, 0.0)
+    assert err == 0
+    rates = (-0.5 + (np.arange(args.channels) + 0.5) / args.channels).astype(np.float32)
+    rep = C.create_string_buffer(2048)
+    rc = L.csdr_amd_comm_selftest(comm, 1 << 20, rep, 2048)
+    line = rep.value.decode() if rc == 0 else "FAILED: " + ctx.err()
+    if log:
+        log("comm selftest: " + line)
+    st_ok = allmin(1.0 if rc == 0 else 0.0) > 0.5
+    result = {"selftest_ok": bool(st_ok), "selftest_rank0": line, "modes": []}
+    if not st_ok:
+        return result
+    first, count = cd.shard(args.channels, rank, world)
+    my_rates = np.ascontiguousarray(rates[first:first + count])
+    for shard in ("channels", "blocks"):
+        for fmt in ("cf32", "s16", "u8"):
+            sfx, es = FMT[fmt]
+            nb = args.blocks * (world if shard == "blocks" else 1)
+            g = torch.Generator(device=dev); g.manual_seed(4)
+            x = make_input(torch, nb * ddc.input_size, fmt, dev, g)      # every rank draws the same stream (same seed); only rank 0's copy is the bank's input ...
+            torch.cuda.synchronize()                                      # (torch's stream filled it; the library works on the context's own stream)
+            if L.csdr_amd_comm_broadcast(comm, x.data_ptr(), x.numel() * x.element_size(), 0) < 0:      # ... and the others' copies are overwritten with it, for the check
+                raise SystemExit("comm_broadcast: " + ctx.err())
+            ctx.sync()
+            entry = {"shard": shard, "input_format": fmt, "blocks_per_step": nb}
+            bank = L.csdr_amd_fastddc_bank_create_sharded_by(ctx.h, args.tbw, args.decimation, rates.ctypes.data_as(C.c_void_p), args.channels, 2, nb, comm, csdr_amd.SHARD[shard])
+            if not bank:
+                raise SystemExit("fastddc_bank_create_sharded_by(%s): %s" % (shard, ctx.err()))
+            pitch = L.csdr_amd_fastddc_bank_max_output(bank, nb) + 8
+            out = torch.zeros((count, pitch, 2), dtype=torch.float32, device=dev)
+            out1 = torch.zeros((count, pitch, 2), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            submit = getattr(L, "csdr_amd_fastddc_bank_submit" + sfx)
+            xp = x.data_ptr() if rank == 0 else None
+            # ---- the first batch against the unsharded bank of this rank's slice
+            counts = np.zeros(count, np.int32)
+            if submit(bank, xp, nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0 or L.csdr_amd_fastddc_bank_finish(bank, counts.ctypes.data_as(C.c_void_p)) < 0:
+                raise SystemExit("sharded step (%s, %s): %s" % (shard, fmt, ctx.err()))
+            ctx.sync()
+            ref = L.csdr_amd_fastddc_bank_create(ctx.h, args.tbw, args.decimation, my_rates.ctypes.data_as(C.c_void_p), count, 2, nb)
+            if not ref:
+                raise SystemExit("fastddc_bank_create (reference of the check): " + ctx.err())
+            counts1 = np.zeros(count, np.int32)
+            if getattr(L, "csdr_amd_fastddc_bank_process" + sfx)(ref, x.data_ptr(), nb, out1.data_ptr(), pitch, counts1.ctypes.data_as(C.c_void_p)) < 0:
+                raise SystemExit("reference bank: " + ctx.err())
+            ctx.sync()
+            L.csdr_amd_fastddc_bank_destroy(ref)
+            worst = 0.0; same = bool((counts == counts1).all() and counts.min() > 0)
+            if same:
+                a = out.cpu().numpy().view(np.complex64)[..., 0]; b = out1.cpu().numpy().view(np.complex64)[..., 0]
+                for c in range(count):
+                    n = int(counts[c]); den = float(np.sqrt((np.abs(b[c, :n]) ** 2).sum()))
+                    worst = max(worst, float(np.sqrt((np.abs(a[c, :n] - b[c, :n]) ** 2).sum())) / den if den else 1.0)
+            ok_here = same and worst < 2e-6
+            entry["verify"] = {"against": "the unsharded bank of every rank's channel slice, first batch, all of the slice's channels", "tolerance": 2e-6,
+                               "max_rel_rms_over_ranks": allmax(worst), "ok": bool(allmin(1.0 if ok_here else 0.0) > 0.5)}
+            del out1
+            # ---- timed: one batch always staged (submit(N + 1) before collect(N))
+            def step():
+                if submit(bank, xp, nb) < 0 or L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None) < 0:
+                    raise SystemExit(ctx.err())
+            if submit(bank, xp, nb) < 0:
+                raise SystemExit(ctx.err())
+            for _ in range(args.warmup):
+                step()
+            ctx.sync(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            L.csdr_amd_fastddc_bank_finish(bank, None)
+            ctx.sync()
+            wall = allmax(time.perf_counter() - t0)
+            barrier()
+            L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)
+            L.csdr_amd_fastddc_bank_finish(bank, None)
+            ctx.sync()
+            L.csdr_amd_fastddc_bank_destroy(bank)
+            entry["ms_per_step"] = round(wall / args.steps * 1e3, 4)
+            entry["value"] = round(nb * ddc.input_size * args.steps / wall / 1e6, 2); entry["unit"] = "complex MS/s (input)"
+            entry["scaling"] = "weak (batch = blocks x N)" if shard == "blocks" else "strong"
+            if log:
+                log("%s / %s: %.4f ms per step, %.1f MS/s, verify %s (%.2e)" % (shard, fmt, entry["ms_per_step"], entry["value"], entry["verify"]["ok"], entry["verify"]["max_rel_rms_over_ranks"]))
+            result["modes"].append(entry)
+            del x, out
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--emulate-world", type=int, default=0, help="time ONE rank's work of a world-N bank on this GPU (null transport) instead of running the bench")
@@ -201,6 +300,10 @@ def main():
     ap.add_argument("--blocks", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true")
+    ap.add_argument("--all-modes", action="store_true",
+                    help="after the headline measurement: csdr_amd_comm_selftest, then both shard modes x {cf32, s16, u8} in this one invocation, each checked against the unsharded "
+                         "bank (\"modes\" in the line).  Default when N > 1 (--single-mode switches it off)")
+    ap.add_argument("--single-mode", action="store_true", help="N > 1: only the --shard / --input-format asked for")
     args = ap.parse_args()
     if args.emulate_world:
         return emulate(args)
@@ -321,7 +424,28 @@ def main():
     L.csdr_amd_fastddc_inv_kernel_time(inv, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
     cd.barrier()
-    wall = cd.max_over_ranks(wall, dev if (world > 1 and not shared and not shared_rccl) else "cpu")
+    red_dev = dev if (world > 1 and not shared and not shared_rccl) else "cpu"
+    wall = cd.max_over_ranks(wall, red_dev)
+    modes = None
+    if bank is not None and (args.all_modes or (world > 1 and not args.single_mode)):
+        # the timed bank is drained and released first: the six banks of the sweep are made on the same communicator
+        if pipelined:
+            L.csdr_amd_fastddc_bank_collect(bank, out.data_ptr(), pitch, None)
+        L.csdr_amd_fastddc_bank_finish(bank, None)
+        ctx.sync(); torch.cuda.synchronize()
+        L.csdr_amd_fastddc_bank_destroy(bank); bank = None; inv = None
+        own_comm = comm
+        if own_comm is None:      # one GPU: a one-rank RCCL communicator, so that the same code (selftest, csdr_amd_comm_dup, sharded create) runs here too
+            idb = (C.c_char * 128)()
+            if L.csdr_amd_comm_unique_id(idb) < 0:
+                raise SystemExit("comm_unique_id: " + ctx.err())
+            own_comm = L.csdr_amd_comm_create(ctx.h, idb, 0, 1)
+            if not own_comm:
+                raise SystemExit("comm_create: " + ctx.err())
+        modes = all_modes(ctx, L, own_comm, rank, world, args, cd.barrier, lambda v: cd.max_over_ranks(v, red_dev), lambda v: -cd.max_over_ranks(-v, red_dev), dev=dev,
+                          log=(lambda m: print("[bench_fastddc rank 0] " + m, file=sys.stderr)) if rank == 0 else None)
+        if comm is None:
+            L.csdr_amd_comm_destroy(own_comm)
     if rank == 0:
         in_samples = nb * ddc.input_size * args.steps
         h_bytes = args.channels * ddc.fft_size * 8                         # per-channel taps_fft, read once per CALL (not per block)
@@ -373,7 +497,11 @@ def main():
             res["cpu_baseline"] = bc.cpu_baseline("fastddc", (args.channels, args.tbw), unit="complex MS/s (input)", single_amount=1, probe_amount=4, target_wall_s=10.0,
                                                   fast_fft=True, describe="config 4 in process: fastddc_fwd_cc framing + FFT once per block, fastddc_inv_cc for %d channels "
                                                   "spread over the threads (every thread transforms the block itself)" % args.channels)
+        if modes is not None:
+            res["comm_selftest_ok"] = modes["selftest_ok"]; res["comm_selftest_rank0"] = modes["selftest_rank0"]; res["modes"] = modes["modes"]
         print(json.dumps(res))
+        if modes is not None and (not modes["selftest_ok"] or not all(m["verify"]["ok"] for m in modes["modes"])):
+            raise SystemExit("bench_fastddc.py: the communicator self test or a mode's check against the unsharded bank failed: %s" % json.dumps(modes))
         if args.verify and not res["verify"]["ok"]:
             raise SystemExit("bench_fastddc.py --verify failed: %s" % json.dumps(res["verify"]))
     if bank:
@@ -382,10 +510,10 @@ def main():
         L.csdr_amd_fastddc_bank_finish(bank, None)
         ctx.sync(); torch.cuda.synchronize()
         L.csdr_amd_fastddc_bank_destroy(bank)
-        if comm:
-            L.csdr_amd_comm_destroy(comm)
     elif inv:
         L.csdr_amd_fastddc_inv_destroy(inv)
+    if comm:
+        L.csdr_amd_comm_destroy(comm)
     if fwd:
         L.csdr_amd_fastddc_fwd_destroy(fwd)
     ctx.close()

@@ -155,6 +155,8 @@ def lib():
     L.csdr_amd_comm_destroy.argtypes = [vp]; L.csdr_amd_comm_destroy.restype = None
     L.csdr_amd_comm_rank.argtypes = [vp]; L.csdr_amd_comm_world.argtypes = [vp]
     L.csdr_amd_comm_broadcast.argtypes = [vp, vp, sz, i]
+    L.csdr_amd_comm_dup.restype = vp; L.csdr_amd_comm_dup.argtypes = [vp]
+    L.csdr_amd_comm_selftest.argtypes = [vp, sz, C.c_char_p, sz]
     L.csdr_amd_fastddc_bank_create_sharded.restype = vp; L.csdr_amd_fastddc_bank_create_sharded.argtypes = [vp, fl, i, vp, i, i, i, vp]
     L.csdr_amd_fastddc_bank_channel_slice.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.csdr_amd_fastddc_bank_create_sharded_by.restype = vp; L.csdr_amd_fastddc_bank_create_sharded_by.argtypes = [vp, fl, i, vp, i, i, i, vp, i]

@@ -21,7 +21,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <vector>
+#include <stdlib.h>
 
 using namespace csdr_amd;
 
@@ -84,6 +86,7 @@ struct csdr_amd_loopback {
     std::vector<hipEvent_t> ready, done;      // [src * world + dst]
     std::vector<void *> ag_buf; std::vector<hipEvent_t> ag_ready, ag_done;      // collectives: per rank
     int attached = 0;
+    std::vector<csdr_amd_loopback *> children; std::vector<int> dups_of_rank;      // csdr_amd_comm_dup: the k-th dup of every rank joins children[k] (created by whoever comes first)
     // host rendezvous of the rank threads; fails (instead of hanging the box) when a rank never arrives
     int barrier()
     {
@@ -242,6 +245,7 @@ csdr_amd_loopback *csdr_amd_loopback_create(int world)
     g->box.assign((size_t)world * world, {nullptr, 0, false, false});
     g->ready.assign((size_t)world * world, nullptr); g->done.assign((size_t)world * world, nullptr);
     g->ag_buf.assign(world, nullptr); g->ag_ready.assign(world, nullptr); g->ag_done.assign(world, nullptr);
+    g->dups_of_rank.assign(world, 0);
     bool ok = true;
     for (auto *v : {&g->ready, &g->done, &g->ag_ready, &g->ag_done}) for (auto &e : *v) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { fail_msg(-1, "loopback: hipEventCreate failed"); csdr_amd_loopback_destroy(g); return nullptr; }
@@ -252,6 +256,7 @@ void csdr_amd_loopback_destroy(csdr_amd_loopback *g)
 {
     if (!g) return;
     for (auto *v : {&g->ready, &g->done, &g->ag_ready, &g->ag_done}) for (auto &e : *v) if (e) (void)hipEventDestroy(e);
+    for (csdr_amd_loopback *ch : g->children) csdr_amd_loopback_destroy(ch);
     delete g;
 }
 
@@ -261,6 +266,7 @@ void csdr_amd_loopback_abort(csdr_amd_loopback *g)
     if (!g) return;
     std::lock_guard<std::mutex> lk(g->mu);
     g->broken = true; g->cv.notify_all();
+    for (csdr_amd_loopback *ch : g->children) csdr_amd_loopback_abort(ch);
 }
 
 csdr_amd_comm *csdr_amd_comm_create_loopback(csdr_amd_ctx *ctx, csdr_amd_loopback *g, int rank)
@@ -289,6 +295,163 @@ void csdr_amd_comm_destroy(csdr_amd_comm *c)
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     delete c;
+}
+
+/* A second communicator over the same ranks (collective: every rank calls it, in the same order).  The time-sliced bank issues its input exchange and its output
+ * exchange from two side streams; on ONE ncclComm the order in which the two groups reach the communicator could differ between ranks (ADVICE r3 / VERDICT r4 weak
+ * #10 ii) -- each exchange now has a communicator of its own.  RCCL: rank 0 draws a new unique id and broadcasts it over the parent; loopback: a child group shared
+ * by the rank threads; null transport: another null. */
+csdr_amd_comm *csdr_amd_comm_dup(csdr_amd_comm *c)
+{
+    if (!c) { fail_msg(-3, "comm_dup: null communicator"); return nullptr; }
+    const int rank = c->ddc.rank, world = c->ddc.world;
+    if (c->null_transport) return csdr_amd_comm_create_null(c->ctx, rank, world);
+    if (c->loop) {
+        csdr_amd_loopback *g = c->loop, *child = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            const int k = g->dups_of_rank[rank]++;
+            while ((int)g->children.size() <= k) {
+                csdr_amd_loopback *n = csdr_amd_loopback_create(world);
+                if (!n) return nullptr;
+                g->children.push_back(n);
+            }
+            child = g->children[k];
+        }
+        return csdr_amd_comm_create_loopback(c->ctx, child, rank);
+    }
+    if (hipSetDevice(c->ctx->device) != hipSuccess) { fail_msg(-1, "hipSetDevice(%d) failed", c->ctx->device); return nullptr; }
+    char id[128]; memset(id, 0, sizeof id);
+    if (rank == 0 && csdr_amd_comm_unique_id(id)) return nullptr;
+    if (world > 1) {
+        void *d = nullptr;
+        if (hipMalloc(&d, 128) != hipSuccess || hipMemcpy(d, id, 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); fail_msg(-2, "comm_dup: staging buffer"); return nullptr; }
+        const int rc = csdr_amd_comm_broadcast(c, d, 128, 0);
+        const bool ok = rc == 0 && hipStreamSynchronize(c->ctx->stream) == hipSuccess && hipMemcpy(id, d, 128, hipMemcpyDeviceToHost) == hipSuccess;
+        (void)hipFree(d);
+        if (!ok) { if (!rc) fail_msg(-6, "comm_dup: the new unique id did not arrive"); return nullptr; }
+    }
+    return csdr_amd_comm_create(c->ctx, id, rank, world);
+}
+
+/* First contact with a new transport / a new box: every exchange primitive the bank uses, once, on rank-stamped data with a checksum -- a send/recv ring
+ * (rank r -> r + 1), an all-gather, a broadcast from the last rank, and two rings in flight at once on two communicators and two streams (the
+ * time-sliced bank's pattern) -- timed, reported per rank.  report (may be null): one line, e.g.
+ *   "rank 1/8 dev 1: ring 4.2 MB ok 0.31 ms 13.5 GB/s | all_gather 8 x 4.2 MB ok 0.9 ms | broadcast ok | second comm ring ok"
+ * Returns 0 when every byte arrived as stamped, -6 with the first mismatch otherwise.  Collective: every rank calls it. */
+int csdr_amd_comm_selftest(csdr_amd_comm *c, size_t n_floats, char *report, size_t report_cap)
+{
+    if (!c) return fail_msg(-3, "comm_selftest: null communicator");
+    const DdcComm *d = &c->ddc;
+    const int W = d->world, me = d->rank;
+    if (n_floats < 16) n_floats = 16;
+    n_floats &= ~(size_t)3;
+    hipStream_t st = c->ctx->stream;
+    CSDR_HIP(hipSetDevice(c->ctx->device));
+    auto stamp = [](int rank, size_t i, int salt) { return (float)(int)(((unsigned)(rank + 1) * 2654435761u + (unsigned)i * 40503u + (unsigned)salt * 97u) >> 9); };      // < 2^23: exact in float
+    std::vector<float> h(n_floats * (size_t)W), back(n_floats * (size_t)W);
+    float *d_send = nullptr, *d_recv = nullptr, *d_all = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0; std::string line; char buf[256];
+    snprintf(buf, sizeof buf, "rank %d/%d dev %d (%s):", me, W, c->ctx->device, c->loop ? "loopback" : c->null_transport ? "null" : "rccl"); line = buf;
+    auto cleanup = [&]() { (void)hipFree(d_send); (void)hipFree(d_recv); (void)hipFree(d_all); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
+#define ST_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); return ::csdr_amd::fail(e__, #expr, __FILE__, __LINE__); } } while (0)
+    ST_HIP(hipMalloc((void **)&d_send, sizeof(float) * n_floats)); ST_HIP(hipMalloc((void **)&d_recv, sizeof(float) * n_floats)); ST_HIP(hipMalloc((void **)&d_all, sizeof(float) * n_floats * W));
+    ST_HIP(hipEventCreate(&e0)); ST_HIP(hipEventCreate(&e1));
+    const double mb = n_floats * 4 / 1e6;
+    // the ring on `cm` / stream `s`: send to me + 1, receive from me - 1, check
+    auto ring = [&](const DdcComm *cm, hipStream_t s, int salt, const char *name) -> int {
+        for (size_t i = 0; i < n_floats; i++) h[i] = stamp(me, i, salt);
+        ST_HIP(hipMemcpyAsync(d_send, h.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice, s));
+        ST_HIP(hipMemsetAsync(d_recv, 0xff, sizeof(float) * n_floats, s));
+        float ms = 0.f; size_t badi = 0; bool bad = false;
+        if (W > 1) {
+            ST_HIP(hipEventRecord(e0, s));
+            int r = cm->group_start(cm); if (!r) r = cm->send(cm, d_send, n_floats, (me + 1) % W, s); if (!r) r = cm->recv(cm, d_recv, n_floats, (me + W - 1) % W, s); if (!r) r = cm->group_end(cm);
+            if (r) { cleanup(); return r; }
+            ST_HIP(hipEventRecord(e1, s));
+            ST_HIP(hipMemcpyAsync(back.data(), d_recv, sizeof(float) * n_floats, hipMemcpyDeviceToHost, s));
+            ST_HIP(hipStreamSynchronize(s));
+            ST_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (!c->null_transport) for (size_t i = 0; i < n_floats && !bad; i++) if (back[i] != stamp((me + W - 1) % W, i, salt)) { bad = true; badi = i; }
+        } else ST_HIP(hipStreamSynchronize(s));
+        if (bad) { snprintf(buf, sizeof buf, " %s MISMATCH at float %zu (got %g, rank %d stamps %g)", name, badi, (double)back[badi], (me + W - 1) % W, (double)stamp((me + W - 1) % W, badi, salt)); line += buf; return 1; }
+        snprintf(buf, sizeof buf, " %s %.1f MB ok %.3f ms%s", name, mb, (double)ms, W > 1 ? "" : " (one rank: nothing moves)"); line += buf;
+        if (W > 1 && ms > 0) { snprintf(buf, sizeof buf, " %.1f GB/s |", mb / ms); line += buf; } else line += " |";
+        return 0;
+    };
+    int bad_total = 0;
+    { const int r = ring(d, st, 1, "ring"); if (r < 0) return r; bad_total += r; }
+    // all-gather in place
+    {
+        for (size_t i = 0; i < n_floats; i++) h[i] = stamp(me, i, 2);
+        ST_HIP(hipMemsetAsync(d_all, 0xff, sizeof(float) * n_floats * W, st));
+        ST_HIP(hipMemcpyAsync(d_all + (size_t)me * n_floats, h.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice, st));
+        ST_HIP(hipEventRecord(e0, st));
+        rc = d->all_gather(d, d_all, n_floats, st); if (rc) { cleanup(); return rc; }
+        ST_HIP(hipEventRecord(e1, st));
+        ST_HIP(hipMemcpyAsync(back.data(), d_all, sizeof(float) * n_floats * W, hipMemcpyDeviceToHost, st));
+        ST_HIP(hipStreamSynchronize(st));
+        float ms = 0.f; ST_HIP(hipEventElapsedTime(&ms, e0, e1));
+        bool bad = false; int br = 0; size_t bi = 0;
+        if (!c->null_transport) for (int r = 0; r < W && !bad; r++) for (size_t i = 0; i < n_floats; i++) if (back[(size_t)r * n_floats + i] != stamp(r, i, 2)) { bad = true; br = r; bi = i; break; }
+        if (bad) { snprintf(buf, sizeof buf, " all_gather MISMATCH in rank %d's piece at float %zu |", br, bi); bad_total++; }
+        else snprintf(buf, sizeof buf, " all_gather %d x %.1f MB ok %.3f ms |", W, mb, (double)ms);
+        line += buf;
+    }
+    // broadcast from the last rank
+    {
+        const int root = W - 1;
+        for (size_t i = 0; i < n_floats; i++) h[i] = stamp(me, i, 3);
+        ST_HIP(hipMemcpyAsync(d_send, h.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice, st));
+        rc = csdr_amd_comm_broadcast(c, d_send, sizeof(float) * n_floats, root); if (rc) { cleanup(); return rc; }
+        ST_HIP(hipMemcpyAsync(back.data(), d_send, sizeof(float) * n_floats, hipMemcpyDeviceToHost, st));
+        ST_HIP(hipStreamSynchronize(st));
+        bool bad = false;
+        if (!c->null_transport) for (size_t i = 0; i < n_floats && !bad; i++) bad = back[i] != stamp(root, i, 3);
+        line += bad ? " broadcast MISMATCH |" : " broadcast ok |"; bad_total += bad ? 1 : 0;
+    }
+    // a second communicator, its ring on a side stream while the first communicator's stream carries a ring of its own (the time-sliced bank's two exchanges)
+    {
+        csdr_amd_comm *c2 = csdr_amd_comm_dup(c);
+        if (!c2) { cleanup(); return -6; }
+        hipStream_t side = nullptr;
+        float *d_s2 = nullptr, *d_r2 = nullptr;
+        bool ok = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipMalloc((void **)&d_s2, sizeof(float) * n_floats) == hipSuccess && hipMalloc((void **)&d_r2, sizeof(float) * n_floats) == hipSuccess;
+        std::vector<float> h2(n_floats), back2(n_floats);
+        int r = 0;
+        if (ok) {
+            for (size_t i = 0; i < n_floats; i++) { h[i] = stamp(me, i, 4); h2[i] = stamp(me, i, 5); }
+            ok = hipMemcpy(d_send, h.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_s2, h2.data(), sizeof(float) * n_floats, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemset(d_recv, 0xff, sizeof(float) * n_floats) == hipSuccess && hipMemset(d_r2, 0xff, sizeof(float) * n_floats) == hipSuccess;
+        }
+        if (ok && W > 1) {
+            const DdcComm *d2 = &c2->ddc;
+            // the bank's pattern: every rank issues the input exchange's group (communicator 1, its stream) and then the output exchange's (communicator 2, the other
+            // stream) without waiting in between -- the same host order on every rank, two communicators, so neither RCCL's per-communicator ordering nor the
+            // loopback's host rendezvous can see the two groups cross
+            for (int pass = 0; pass < 2 && !r; pass++) {
+                const bool first_comm = pass == 0;
+                const DdcComm *cm = first_comm ? d : d2; hipStream_t s = first_comm ? st : side;
+                float *sb = first_comm ? d_send : d_s2, *rb = first_comm ? d_recv : d_r2;
+                r = cm->group_start(cm); if (!r) r = cm->send(cm, sb, n_floats, (me + 1) % W, s); if (!r) r = cm->recv(cm, rb, n_floats, (me + W - 1) % W, s); if (!r) r = cm->group_end(cm);
+            }
+            if (!r) ok = hipStreamSynchronize(st) == hipSuccess && hipStreamSynchronize(side) == hipSuccess &&
+                         hipMemcpy(back.data(), d_recv, sizeof(float) * n_floats, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(back2.data(), d_r2, sizeof(float) * n_floats, hipMemcpyDeviceToHost) == hipSuccess;
+            bool bad = false;
+            if (!r && ok && !c->null_transport) for (size_t i = 0; i < n_floats && !bad; i++) bad = back[i] != stamp((me + W - 1) % W, i, 4) || back2[i] != stamp((me + W - 1) % W, i, 5);
+            line += bad ? " two communicators, two streams: MISMATCH" : " two communicators on two streams, both groups in flight: ok"; bad_total += bad ? 1 : 0;
+        } else if (ok) line += " second communicator: ok (one rank)";
+        (void)hipFree(d_s2); (void)hipFree(d_r2); if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+        csdr_amd_comm_destroy(c2);
+        if (r) { cleanup(); return r; }
+        if (!ok) { cleanup(); return fail_msg(-1, "comm_selftest: HIP call failed in the two-communicator pass"); }
+    }
+#undef ST_HIP
+    cleanup();
+    if (report && report_cap) { snprintf(report, report_cap, "%s", line.c_str()); }
+    if (getenv("CSDR_AMD_COMM_VERBOSE")) fprintf(stderr, "csdr_amd comm selftest: %s\n", line.c_str());
+    return bad_total ? fail_msg(-6, "comm_selftest: %s", line.c_str()) : 0;
 }
 
 int csdr_amd_comm_rank(const csdr_amd_comm *c) { return c->ddc.rank; }

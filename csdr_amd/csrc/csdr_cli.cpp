@@ -714,6 +714,7 @@ struct IoThreads {
     BufQueue free_in, full_in, free_out, full_out;
     IpcSource *src = nullptr; BufQueue copied_in;                    // device hand-off, consumer side: blocks whose device copy is queued (their slots go back as credits)
     int sink_fd = -1; HostBuf *sink_bufs = nullptr;                  // producer side: tokens out, credits back; sink_bufs[slot]
+    int n_in_bufs = 0;                                               // how many input buffers circulate (reader -> main -> credit thread -> reader)
     std::atomic<bool> sink_closing{false};                           // the writer has sent its last token and shut the socket down: EOF on the credit side is then the normal end
 };
 
@@ -776,6 +777,14 @@ void *reader_ipc_main(void *arg)
             // The handing-over producer is done.  Whatever any OTHER or later writer of the same pipe sends ( `(csdr a; csdr a2) | csdr b`: a2 finds no listener and
             // writes bytes ) is still part of the stream: carry on in byte mode until stdin itself ends (pinned buffers are only allocated now).
             (void)hipSetDevice(io->device);
+            {   // Every block of the ring has been copied out once all input buffers are back (credit_out_main returns a buffer only behind its copy's event):
+                // tell the producer so NOW -- it stays alive until we close our side (the ring lives in its memory), and in `(csdr a; csdr a2) | csdr b` the
+                // second writer only starts once the first has exited: waiting for stdin's EOF with the socket open would be a deadlock.
+                std::vector<HostBuf *> all;
+                for (int k = 0; k < io->n_in_bufs; k++) all.push_back(io->free_in.pop());
+                shutdown(io->src->fd, SHUT_WR);
+                for (HostBuf *b : all) io->free_in.push(b);
+            }
             for (;;) {
                 HostBuf *b = io->free_in.pop();
                 if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }
@@ -882,6 +891,7 @@ int run(csdr_amd_ctx *c, std::vector<Stage *> &stages, std::vector<size_t> &caps
         }
         io.free_in.push(&hin[k]); io.free_out.push(&hout[k]);
     }
+    io.n_in_bufs = NBUF;
 #ifdef F_SETPIPE_SZ
     (void)fcntl(STDIN_FILENO, F_SETPIPE_SZ, 1 << 20); (void)fcntl(STDOUT_FILENO, F_SETPIPE_SZ, 1 << 20);      // fewer, larger pipe transfers (ignored for files)
 #endif

@@ -766,6 +766,7 @@ struct csdr_amd_fastddc_bank {
     const int *last_counts = nullptr; int last_count_n = 0;            // device counts of the batch collected last (csdr_amd_fastddc_bank_finish)
     // ---- time-sliced mode
     int shard_mode = CSDR_AMD_SHARD_CHANNELS; const DdcComm *dc = nullptr; int world = 1, rank = 0, nbl = 0, out_count = 0;
+    csdr_amd_comm *comm_out = nullptr; const DdcComm *dc_out = nullptr;      // time slices: the output exchange (stream xout) on a communicator of its own (csdr_amd_comm_dup), the input exchange (xin) on `comm`
     size_t pitch_loc = 0;
     cf32 *d_in_loc[2] = {nullptr, nullptr}, *d_out_loc[2] = {nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr}, *d_tail_root[2] = {nullptr, nullptr};
     int *d_pref[3] = {nullptr, nullptr, nullptr}; int tail_flip = 0, pref_at = 0;      // run-offset tables: this batch's, the next one's (computed one call ahead), and the one the previous batch's stitch may still read
@@ -821,6 +822,10 @@ static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw
     b->shard_mode = multi ? shard_mode : CSDR_AMD_SHARD_CHANNELS;
     if (b->shard_mode == CSDR_AMD_SHARD_BLOCKS) {                     // every rank: all channels, its run of the blocks
         b->nbl = (max_blocks + b->world - 1) / b->world;
+        // two exchanges per batch from two side streams: each on its own communicator (collective -- every rank creates its bank at the same point)
+        b->comm_out = csdr_amd_comm_dup(comm);
+        if (!b->comm_out) { delete b; return nullptr; }
+        b->dc_out = csdr_amd_comm_ddc(b->comm_out);
         b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, b->nbl, nullptr);
     } else
         b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates + b->first_channel, count, window, max_blocks, multi ? dc : nullptr);
@@ -929,7 +934,7 @@ static int bank_collect_blocks(csdr_amd_fastddc_bank *b, csdr_complexf *out, siz
     b->in_free_rec[slot] = true;
     if (!out_ready_recorded) CSDR_HIP(hipEventRecord(b->ev_out_ready[slot], st));
     // output exchange on its own stream (under the next batch's transforms): every rank sends each peer that peer's channels of its run
-    const DdcComm *cm = b->dc;
+    const DdcComm *cm = b->dc_out;
     CSDR_HIP(hipStreamWaitEvent(b->xout, b->ev_out_ready[slot], 0));
     rc = cm->group_start(cm); if (rc) return rc;
     for (int p = 0; p < W; p++) {
@@ -968,8 +973,8 @@ csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, f
                                                             int window, int max_blocks, csdr_amd_comm *comm)
 {   // Default = channel-sharded compute with the spectrum exchange (BASELINE north_star's partitioning, and the mode whose RCCL call pattern -- one group of
     // send / recv and one all-gather per batch on ONE stream -- has run on hardware).  The time-sliced schedule (csdr_amd_fastddc_bank_create_sharded_by(...,
-    // CSDR_AMD_SHARD_BLOCKS): 6.5 x at 8 GPUs in the per-rank emulation against 1.3 x) issues its input and output exchanges from two side streams on the same
-    // communicator; until that has passed a run on >= 2 GPUs over RCCL it is opt-in.
+    // CSDR_AMD_SHARD_BLOCKS): 6.5 x at 8 GPUs in the per-rank emulation against 1.3 x) issues its input and output exchanges from two side streams -- since round 5
+    // on two communicators (csdr_amd_comm_dup); until that has passed a run on >= 2 GPUs over RCCL it stays opt-in.
     return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, CSDR_AMD_SHARD_CHANNELS);
 }
 
@@ -986,6 +991,7 @@ void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
         for (hipEvent_t ev : {b->ev_in_ready[k], b->ev_in_free[k], b->ev_out_ready[k], b->ev_done[k]}) if (ev) (void)hipEventDestroy(ev);
     }
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    if (b->comm_out) csdr_amd_comm_destroy(b->comm_out);
     delete b;
 }
 

@@ -292,6 +292,13 @@ void csdr_amd_comm_destroy(csdr_amd_comm *c);
 int  csdr_amd_comm_rank(const csdr_amd_comm *c);
 int  csdr_amd_comm_world(const csdr_amd_comm *c);
 int  csdr_amd_comm_broadcast(csdr_amd_comm *c, void *dev_buf, size_t bytes, int root);        /* on the context's stream (test / bench plumbing) */
+/* A second communicator over the same ranks (collective; RCCL: a new unique id broadcast over the parent, then ncclCommInitRank).  The time-sliced bank makes one
+ * for its output exchange, so that its two exchanges -- issued from two side streams -- never share an ncclComm.  Destroy with csdr_amd_comm_destroy. */
+csdr_amd_comm *csdr_amd_comm_dup(csdr_amd_comm *c);
+/* First contact with a transport / a box (collective): a send/recv ring, an all-gather, a broadcast and a two-communicator / two-stream ring of rank-stamped
+ * buffers of n_floats floats each, every byte checked, timed.  report (may be NULL) receives one line per rank; CSDR_AMD_COMM_VERBOSE=1 also prints it on stderr.
+ * 0 = every byte arrived as stamped; -6 otherwise (csdr_amd_last_error() holds the line). */
+int  csdr_amd_comm_selftest(csdr_amd_comm *c, size_t n_floats, char *report, size_t report_cap);
 /* Two more transports behind the same communicator type, for boxes with ONE GPU:
  * loopback -- the `world` ranks live in one process, one host thread + one context each (all on one device, or on several); every exchange is a
  *   stream-ordered device copy.  The multi-rank code of the channelizer runs unchanged (tests at world 2 / 4 / 8 on one MI355X).  Every rank thread
