@@ -92,14 +92,27 @@ def pmc_traffic(kernel_name, match):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summaries (profiles/*_pmc_traffic.json, written by
     tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same command).  A bench cannot read PMCs itself;
     the value is reported only when a summary exists for the same kernel and a workload dict containing every key/value of `match`."""
-    best = None
+    import re
+    best = None; best_round = -1
+    squash = lambda t: str(t).split(" (")[0].replace(" ", "")
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         try:
             d = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
         w = d.get("workload", {})
-        if d.get("kernel", "").startswith(kernel_name) and all(w.get(k) == v for k, v in match.items()):
+        m = re.match(r"r(\d+)", os.path.basename(f))
+        rnd = int(m.group(1)) if m else 0
+        # the SAME kernel instance (k_fftfilt_lds<4096> is not k_fftfilt_lds<8192>; a summary over several kernels -- "a + b" -- never stands for one of them), the
+        # same workload, and the NEWEST round's file: a line must not pick up an older round's figure when a newer pass exists (VERDICT r4 weak #9)
+        kn = squash(kernel_name)
+        parts = [squash(p.strip()) for p in str(d.get("kernel", "")).split(" + ") if p.strip()]
+        bases = {p.split("<")[0] for p in parts}
+        if not parts or (len(parts) > 1 and len(bases) < len(parts)):      # a sum over template instances of ONE kernel (a sweep): never one launch's traffic
+            continue
+        same = all(p == kn or ("<" not in kn and (p.split("<")[0] == kn or (len(parts) > 1 and p.startswith(kn)))) for p in parts)
+        if same and all(w.get(key) == v for key, v in match.items()) and rnd >= best_round:
+            best_round = rnd
             best = (d["traffic_bytes_per_launch"], "profiles/" + os.path.basename(f) + " (rocprofv3 PMC passes, FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)")
     return best
 
