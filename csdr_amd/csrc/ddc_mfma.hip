@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
     ps_v2f psC = {1.f, 0.f}, psD = {1.f, 0.f}, psK = {1.f, 0.f};
     float2 psP = make_float2(1.f, 0.f);
     const int ps_e = (2 * team + (w == rb ? 1 : 0)) * 64 + lane;
-    int ps_tab_pitch = PS ? (int)p.tab_pitch : 0, ps_tab_len = p.tab_len;            // (seed tables hold < 2^31 entries; opaque copies as above: no s_load inside the loop)
+    int ps_tab_pitch = PS ? (int)p.tab_pitch : 0, ps_tab_len = p.tab_len;            // (seed tables hold < 2^31 entries; opaque copies as below: no s_load inside the loop)
     if constexpr (PS) asm volatile("" : "+v"(ps_tab_pitch), "+v"(ps_tab_len));
     auto ps_load = [&](long long wgn) {
         const int tcol = ps_e & 15, side = (ps_e >> 4) & 1, w2 = (ps_e >> 5) & 3;
@@ -505,11 +505,11 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
     __syncthreads();
     const uint8_t *lrow = lds_in + col * RP;
     const int kk_seg = (int)(8 * t0 - p.k_out0);                                     // output index of the segment's first tile's first output (< 0: a partial first tile)
-    // ---- round 5: what the epilogue needs of the kernel's arguments, in registers of the lane that uses it.  The kernel holds 106 scalar registers and spills 26; the
+    // ---- round 5: what the epilogue needs of the kernel's arguments, in registers of the lane that uses it.  The kernel holds 106 scalar registers and spilled 26; the
     // compiler re-read these arguments from memory INSIDE the tile loop (six s_load + s_waitcnt lgkmcnt(0) per tile in the role waves, which are the last at every
     // barrier) and rebuilt three 64-bit plane addresses per store.  Opaque copies ("+v") cannot be rematerialised from the argument block.
-    const int e_stream = PS ? sb : sb * 16 + col;
     typedef float e_v2f __attribute__((ext_vector_type(2))); typedef __attribute__((address_space(1))) e_v2f *gp_f2; typedef __attribute__((address_space(1))) int8_t *gp_i8;      // (global pointers: behind an opaque asm a generic pointer means flat_store)
+    const int e_stream = PS ? sb : sb * 16 + col;
     gp_f2 e_ybase = (gp_f2)(out + (size_t)e_stream * out_pitch);                     // y of output kk at e_ybase[kk]
     gp_i8 e_pl0 = nullptr, e_pl1 = nullptr, e_pl2 = nullptr;
     float e_max_amp = 0.f, e_q_per_amp = 0.f;
@@ -523,128 +523,41 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
 #ifdef DDC_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
 #endif
-    // ---- what follows a group's barrier: the fetching waves refill the ring space the group has freed, the role waves reduce the four K-range shares of the group's
-    // tiles and run the epilogue.  Round 5 (DDC_STAGGER): team 1 does this right behind the barrier, as before -- team 0 only AFTER its next tile's products.  A SIMD
-    // hosts one wave of each team (wave k and wave k + 4: one with an epilogue role, one that fetches); with both teams in the same phase at the same time the two waves
-    // read LDS together, XOR together, queue at the matrix pipe together and then both leave it idle (per-wave cycle profile, profiles/r3_nfm_wave_cycles.txt:
-    // 2200-2900 cycles per tile in a phase that is ~1000 cycles of issue for one wave alone).  Staggered, one wave's products run under the other's epilogue
-    // stores / DMA issue.  Nothing else moves: a group's partial sums stay valid until the products of the group after next (two buffers), the hand-over of the last
-    // sample between groups (ylast) is written by team 1 one barrier before team 0 reads it, and the ring space refilled is older than the CURRENT group's windows.
-    auto post_group = [&](const int gi, const long long wg_p) {
-        const int it = gi * NT + team;
-        const bool active = it < n_it;
-        float4 *rbuf = red + ((gi & 1) * NT + team) * (WPT * 64);
-        const long long wg_n = wg_p + (long long)NT * tstride;
-#if DDC_DIAG != 2
-        if (fetches && gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + RB) row_step(); }
-#endif
-        DPROF_T(3)
-        // ---- reduction of the four K-range shares and store.  Plain front end: the waves of a team take turns.  FUSE: TWO fixed waves of the team share the epilogue
-        // -- role A demodulates the tile's even outputs (it needs the predecessor logic), role B the odd ones; fmdemod_quadri_cf | limit_ff + the digit split is two
-        // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
-        const bool role_a = ROLES ? w == ra : w == gi % WPT, role_b = ROLES && w == rb;
-        if (PS && has_role) { ps_mul(); ps_load(wg_p + 3LL * NT * tstride); }          // psP = group gi + 2; in flight: group gi + 3
-#ifndef DDC_NOSTORE
-#define DDC_NOSTORE 0       // experiment (timing only): 1 = no epilogue, nothing stored (what the stores cost the input stream)
-#endif
-        if (active && (role_a || role_b) && !DDC_NOSTORE) {
-            const float4 yy = ddc_reduce<WPT>(rbuf + lane);                           // (y0.re, y0.im, y1.re, y1.im): outputs 2q, 2q + 1 of stream col
-            const int stream = e_stream;
-            const float2 y0 = make_float2(yy.x, yy.y), y1 = make_float2(yy.z, yy.w);
-            const int kk = kk_seg + 8 * it + 2 * q + (PS ? col * 8 * p.tiles_per_seg : 0);  // index of y0 in the call's outputs; the first / last tile of a call may be partial
-            const bool ok0 = (unsigned)kk < (unsigned)e_n_out, ok1 = (unsigned)(kk + 1) < (unsigned)e_n_out;
-            if (!FUSE) {
-                if (stream < p.n_streams) {
-                    gp_f2 dst = e_ybase + kk;
-                    if (ok0 && (!PS || role_a)) dst[0] = e_v2f{y0.x, y0.y};                         // (PS: the two role waves share the stores)
-                    if (ok1 && (!PS || role_b)) dst[1] = e_v2f{y1.x, y1.y};
-                }
-            } else if (role_a) {
-                // predecessor of output 2q: lane (col, q - 1)'s second output; for q = 0 the previous tile's last output
-                float2 prev = make_float2(__shfl_up(y1.x, 16), __shfl_up(y1.y, 16));
-                if (q == 0 && it > 0) {
-                    if (team > 0) {                                                  // same group, previous team: its partial sums are complete (same barrier)
-                        const float4 pv = ddc_reduce<WPT>(red + ((gi & 1) * NT + team - 1) * (WPT * 64) + 48 + col);
-                        prev = make_float2(pv.z, pv.w);
-                    } else prev = ylast[((gi - 1) & 1) * 16 + col];                  // previous group's last team: handed over (double buffered: the writer of this group is on its way)
-                }
-                if (team == NT - 1 && q == 3) ylast[(gi & 1) * 16 + col] = y1;
-                if (stream < p.n_streams) {
-                    // complex samples k_nfm_demod_boundary needs: the call's first output and every segment's first one (their predecessors live elsewhere), the segments'
-                    // last ones (the next segment's predecessor) and the call's last one (the next call's)
-                    gp_f2 ydst = e_ybase + kk;
-                    const bool seg_first = it == 0 && q == 0;
-                    if (ok0 && (seg_first || kk == 0 || kk == e_n_out - 1 || kk < e_n_lead)) ydst[0] = e_v2f{y0.x, y0.y};
-                    if (ok0 && !seg_first && kk != 0) {
-                        int dg[3];
-                        nfm_demod_digits(y0, prev, e_max_amp, e_q_per_amp, dg);
-                        e_pl0[kk] = (int8_t)dg[0]; e_pl1[kk] = (int8_t)dg[1]; e_pl2[kk] = (int8_t)dg[2];
-                    }
-                }
-            } else {                                                                 // role B: the odd outputs (their predecessor is this lane's own even one)
-                if (stream < p.n_streams) {
-                    gp_f2 ydst = e_ybase + kk;
-                    const bool seg_last = it == n_it - 1 && q == 3;
-                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == e_n_out - 1 || kk + 1 < e_n_lead)) ydst[1] = e_v2f{y1.x, y1.y};
-                    if (ok1 && kk + 1 != 0) {
-                        int dg[3];
-                        nfm_demod_digits(y1, y0, e_max_amp, e_q_per_amp, dg);
-                        e_pl0[kk + 1] = (int8_t)dg[0]; e_pl1[kk + 1] = (int8_t)dg[1]; e_pl2[kk + 1] = (int8_t)dg[2];
-                    }
-                }
-            }
-        }
-        DPROF_T(4)
-    };
-#ifndef DDC_STAGGER
-#define DDC_STAGGER 0     // measured (profiles/r5_notes.md): shared-rate kernel 0.6731 -> 0.6704 ms (nothing), per-stream kernel 0.725 -> 0.868 ms (its role waves' table loads come due later)
-#endif
-#ifndef DDC_EARLY_B
-#define DDC_EARLY_B 0     // experiment: a tile's nine LDS reads issued in FRONT of the previous group's epilogue / ring refill (their latency under that work)
-#endif
-#ifndef DDC_ROLE_PRIO
-#define DDC_ROLE_PRIO 0   // experiment: s_setprio for the waves with an epilogue role (the last at every barrier)
-#endif
-    if (DDC_ROLE_PRIO && ROLES && has_role) __builtin_amdgcn_s_setprio(DDC_ROLE_PRIO);
-    const bool late_post = DDC_STAGGER && NT == 2 && team == 0;                        // wave uniform
+    // Round 5, measured and NOT kept (profiles/r5_notes.md; the code of the experiments is in git history, commit "ddc: staggered teams ..."): the two teams in different
+    // phases (team 0 runs a group's epilogue / ring refill only after its next tile's products: shared-rate kernel 0.673 -> 0.670 ms, per-stream 0.725 -> 0.868), a
+    // tile's LDS reads issued in front of the previous group's epilogue (+3 %), s_setprio for the role waves (+-0).
     for (int gi = 0; gi < n_grp; gi++, wg += (long long)NT * tstride) {
         const int it = gi * NT + team;                                               // this team's tile of the group
         const bool active = it < n_it;
         const long long ws = wg + (long long)team * tstride;                         // window start of this team's tile
-        const bool do_tile = active && nact > 0 && !(DDC_DIAG == 3 && has_role) && !(DDC_DIAG == 4 && fetches);   // (nact is loop invariant: waves beyond a short window have nothing to add)
-        // ---- B fragments of this wave's K-range from the ring
-        // (round 5, SQ counters in profiles/r5_nfm_pmc_issue.json: ~200 vector instructions per 27 matrix products and wave.  The ring position of a K-step was three
-        // vector instructions -- add, mask, add -- in front of every read: 27 per tile; the wave's 9 reads only wrap around the ring's end in 1 tile of 14, so the
-        // common case is ONE address and nine immediate offsets.)
-        v4i Bf[DDC_NKW];
-        auto load_b = [&]() {
-            const int b0 = __builtin_amdgcn_readfirstlane((int)(ws & (RB - 1)) + 64 * DDC_NKW * w);      // wave uniform
-            if (b0 + 64 * DDC_NKW <= RB) {                                           // (16 q <= 48 stays inside the last K-step's 64 bytes)
-                const uint8_t *pb = lrow + b0 + 16 * q;
-#pragma unroll
-                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(pb + 64 * ks);
-                asm volatile("" ::: "memory");                                       // (keeps these reads in this branch: merged with the other branch's they get nine computed addresses again)
-            } else {
-                const int base = b0 + 16 * q;
-#pragma unroll
-                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1)));
-            }
-        };
-        if (DDC_EARLY_B && DDC_DIAG != 1 && do_tile) load_b();
-        if (!late_post && gi > 0) post_group(gi - 1, wg - (long long)NT * tstride);
 #if DDC_DIAG == 1
         float4 part = make_float4((float)it, 0.f, 0.f, 0.f);
 #else
         float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (do_tile) {
-            if (!DDC_EARLY_B) load_b();
-#pragma unroll
-            for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] ^= (int)0x80808080;
+        if (active && nact > 0 && !(DDC_DIAG == 3 && has_role) && !(DDC_DIAG == 4 && fetches)) {   // (nact is loop invariant: waves beyond a short window have nothing to add)
             const long long n0 = p.B + (ws >> 1);                                    // global index of the tile's first sample
             const WaveGeom g = ddc_wave_geom(n0, w);
             const int kb = __builtin_amdgcn_readfirstlane(g.kb), half = __builtin_amdgcn_readfirstlane(g.half);
             const int chunk_rel = (int)(g.chunk - (p.B >> 10));                      // -1: the previous block's last chunk (history); -2: in front of it (feeds only outputs that are not stored)
             const int ci0 = max(chunk_rel + 1, 0);                                   // table row of side 0
+            // ---- B fragments of this wave's K-range from the ring
+            // (round 5, SQ counters in profiles/r5_nfm_pmc_issue.json: ~200 vector instructions per 27 matrix products and wave.  The ring position of a K-step was three
+            // vector instructions -- add, mask, add -- in front of every read: 27 per tile; the wave's 9 reads only wrap around the ring's end in 1 tile of 14, so the
+            // common case is ONE address and nine immediate offsets.)
+            const int b0 = __builtin_amdgcn_readfirstlane((int)(ws & (RB - 1)) + 64 * DDC_NKW * w);      // wave uniform
+            v4i Bf[DDC_NKW];
+            if (b0 + 64 * DDC_NKW <= RB) {                                           // (16 q <= 48 stays inside the last K-step's 64 bytes)
+                const uint8_t *pb = lrow + b0 + 16 * q;
+#pragma unroll
+                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(pb + 64 * ks);
+                asm volatile("" ::: "memory");                                       // (keeps these reads in this branch: merged with the other branch's they get nine computed addresses again)
+#pragma unroll
+                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] ^= (int)0x80808080;
+            } else {
+                const int base = b0 + 16 * q;
+#pragma unroll
+                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
+            }
             // ---- one accumulator chain per digit; snapshot at the chunk boundary.  (round 5: the tile without a boundary in this K-range -- 72 % of them -- is its own
             // straight-line path: merged with the ten boundary variants it paid 12 moves for a snapshot it does not have.)
             v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3];
@@ -705,19 +618,77 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
 #endif
         float4 *rbuf = red + ((gi & 1) * NT + team) * (WPT * 64);
         rbuf[w * 64 + lane] = part;
-        DPROF_T(0)
-        if (late_post && gi > 0) post_group(gi - 1, wg - (long long)NT * tstride);
         if (PS && has_role && gi + 1 < n_grp) ps_store(gi + 1);
-        // ---- the next group's windows must have landed before anyone passes the barrier
+        // ---- the next group's windows must have landed before anyone passes the barrier; the ring space behind them is refilled right after
         const long long wg_n = wg + (long long)NT * tstride;
+        DPROF_T(0)
 #if DDC_DIAG != 2
         if (fetches && gi + 1 < n_grp) wait_for(wg_n + (long long)(NT - 1) * tstride);
 #endif
         DPROF_T(1)
         __syncthreads();
         DPROF_T(2)
+#if DDC_DIAG != 2
+        if (fetches && gi + 1 < n_grp) { while (F < F_end && F + 1024 <= wg_n + RB) row_step(); }
+#endif
+        DPROF_T(3)
+        // ---- reduction of the four K-range shares and store.  Plain front end: the waves of a team take turns.  FUSE: TWO fixed waves of the team share the epilogue
+        // -- role A demodulates the tile's even outputs (it needs the predecessor logic), role B the odd ones; fmdemod_quadri_cf | limit_ff + the digit split is two
+        // thirds of the work --, the other two waves fetch.  Both roles sum the same partials in the same order: the values are those of a one-wave epilogue, bit for bit.
+        const bool role_a = ROLES ? w == ra : w == gi % WPT, role_b = ROLES && w == rb;
+        if (PS && has_role) { ps_mul(); ps_load(wg + 3LL * NT * tstride); }          // psP = group gi + 2; in flight: group gi + 3
+#ifndef DDC_NOSTORE
+#define DDC_NOSTORE 0       // experiment (timing only): 1 = no epilogue, nothing stored (what the stores cost the input stream)
+#endif
+        if (active && (role_a || role_b) && !DDC_NOSTORE) {
+            const float4 yy = ddc_reduce<WPT>(rbuf + lane);                           // (y0.re, y0.im, y1.re, y1.im): outputs 2q, 2q + 1 of stream col
+            const int stream = e_stream;
+            const float2 y0 = make_float2(yy.x, yy.y), y1 = make_float2(yy.z, yy.w);
+            const int kk = kk_seg + 8 * it + 2 * q + (PS ? col * 8 * p.tiles_per_seg : 0);  // index of y0 in the call's outputs; the first / last tile of a call may be partial
+            const bool ok0 = (unsigned)kk < (unsigned)e_n_out, ok1 = (unsigned)(kk + 1) < (unsigned)e_n_out;
+            if (!FUSE) {
+                if (stream < p.n_streams) {
+                    gp_f2 dst = e_ybase + kk;
+                    if (ok0 && (!PS || role_a)) dst[0] = e_v2f{y0.x, y0.y};           // (PS: the two role waves share the stores)
+                    if (ok1 && (!PS || role_b)) dst[1] = e_v2f{y1.x, y1.y};
+                }
+            } else if (role_a) {
+                // predecessor of output 2q: lane (col, q - 1)'s second output; for q = 0 the previous tile's last output
+                float2 prev = make_float2(__shfl_up(y1.x, 16), __shfl_up(y1.y, 16));
+                if (q == 0 && it > 0) {
+                    if (team > 0) {                                                  // same group, previous team: its partial sums are complete (same barrier)
+                        const float4 pv = ddc_reduce<WPT>(red + ((gi & 1) * NT + team - 1) * (WPT * 64) + 48 + col);
+                        prev = make_float2(pv.z, pv.w);
+                    } else prev = ylast[((gi - 1) & 1) * 16 + col];                  // previous group's last team: handed over (double buffered: the writer of this group is on its way)
+                }
+                if (team == NT - 1 && q == 3) ylast[(gi & 1) * 16 + col] = y1;
+                if (stream < p.n_streams) {
+                    // complex samples k_nfm_demod_boundary needs: the call's first output and every segment's first one (their predecessors live elsewhere), the segments'
+                    // last ones (the next segment's predecessor) and the call's last one (the next call's)
+                    gp_f2 ydst = e_ybase + kk;
+                    const bool seg_first = it == 0 && q == 0;
+                    if (ok0 && (seg_first || kk == 0 || kk == e_n_out - 1 || kk < e_n_lead)) ydst[0] = e_v2f{y0.x, y0.y};
+                    if (ok0 && !seg_first && kk != 0) {
+                        int dg[3];
+                        nfm_demod_digits(y0, prev, e_max_amp, e_q_per_amp, dg);
+                        e_pl0[kk] = (int8_t)dg[0]; e_pl1[kk] = (int8_t)dg[1]; e_pl2[kk] = (int8_t)dg[2];
+                    }
+                }
+            } else {                                                                 // role B: the odd outputs (their predecessor is this lane's own even one)
+                if (stream < p.n_streams) {
+                    gp_f2 ydst = e_ybase + kk;
+                    const bool seg_last = it == n_it - 1 && q == 3;
+                    if (ok1 && (seg_last || kk + 1 == 0 || kk + 1 == e_n_out - 1 || kk + 1 < e_n_lead)) ydst[1] = e_v2f{y1.x, y1.y};
+                    if (ok1 && kk + 1 != 0) {
+                        int dg[3];
+                        nfm_demod_digits(y1, y0, e_max_amp, e_q_per_amp, dg);
+                        e_pl0[kk + 1] = (int8_t)dg[0]; e_pl1[kk + 1] = (int8_t)dg[1]; e_pl2[kk + 1] = (int8_t)dg[2];
+                    }
+                }
+            }
+        }
+        DPROF_T(4)
     }
-    post_group(n_grp - 1, wg - (long long)NT * tstride);                               // (the loop's increment has moved wg one group beyond the last)
 #ifdef DDC_PROF
     if (lane == 0 && wv < 16) { for (int k = 0; k < 5; k++) atomicAdd(&g_ddc_prof[wv][k], (unsigned long long)prof[k]); atomicAdd(&g_ddc_prof[wv][5], (unsigned long long)n_grp); }
 #endif
