@@ -119,6 +119,9 @@ int generate(SeedTables *t, int dst, int src, long idx, long long first)
     hipStream_t ss = t->side;
     if (t->free_pending[dst]) { CSDR_HIP(hipStreamWaitEvent(ss, t->ev_free[dst], 0)); t->free_pending[dst] = false; }      // the data kernels that read it have finished
     static const bool raised = !(getenv("CSDR_AMD_SEED_PRIO") && atoi(getenv("CSDR_AMD_SEED_PRIO")) == 0);      // (A/B, read once per process)
+    // TIMING EXPERIMENT ONLY (wrong seeds from the second table on): what the generator's side-stream work costs the data kernels = the ceiling of any speed-up of it
+    static const bool freeze = getenv("CSDR_AMD_SEED_FREEZE") != nullptr;
+    if (freeze && src >= 0) { CSDR_HIP(hipEventRecord(t->ev_ready[dst], ss)); t->first[dst] = first; t->valid[dst] = true; return 0; }
     if (!raised) hipLaunchKernelGGL(k_seed_phases<false>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
     else
     hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
