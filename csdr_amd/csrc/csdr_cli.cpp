@@ -734,14 +734,32 @@ void file_input_init()
     g_file_in.regular = k > 1; g_file_in.pos = at; g_file_in.threads = k;
 }
 struct PreadJob { char *dst; size_t len; off_t off; size_t got; };
-void *pread_main(void *arg)
+void pread_all(PreadJob *j)
 {
-    PreadJob *j = (PreadJob *)arg; j->got = 0;
+    j->got = 0;
     while (j->got < j->len) {
         const ssize_t r = pread(STDIN_FILENO, j->dst + j->got, j->len - j->got, j->off + (off_t)j->got);
         if (r < 0) { if (errno == EINTR) continue; break; }
         if (r == 0) break;
         j->got += (size_t)r;
+    }
+}
+// helper threads that live as long as the process (started at the first parallel read: a thread per block and slice cost more than it saved at 2-MiB blocks)
+struct PreadPool {
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER; pthread_cond_t cv_go = PTHREAD_COND_INITIALIZER, cv_done = PTHREAD_COND_INITIALIZER;
+    PreadJob *jobs = nullptr; int n_jobs = 0, next = 0, done = 0; unsigned long gen = 0; int n_threads = 0;
+} g_pool;
+void *pread_pool_main(void *)
+{
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen || g_pool.next >= g_pool.n_jobs) { if (g_pool.gen != seen && g_pool.next >= g_pool.n_jobs) seen = g_pool.gen; pthread_cond_wait(&g_pool.cv_go, &g_pool.mu); }
+        PreadJob *j = &g_pool.jobs[g_pool.next++];
+        pthread_mutex_unlock(&g_pool.mu);
+        pread_all(j);
+        pthread_mutex_lock(&g_pool.mu);
+        if (++g_pool.done == g_pool.n_jobs) pthread_cond_signal(&g_pool.cv_done);
     }
     return nullptr;
 }
@@ -749,14 +767,30 @@ void *pread_main(void *arg)
 void read_file_parallel(char *buf, size_t max_bytes, size_t *got, bool *eof)
 {
     const int K = g_file_in.threads;
-    PreadJob jobs[16]; pthread_t th[16];
+    PreadJob jobs[16];
     size_t slice = (max_bytes / K + 4095) & ~(size_t)4095; if (slice == 0) slice = max_bytes;
     int n = 0;
     for (size_t at = 0; at < max_bytes && n < K; at += slice, n++) jobs[n] = {buf + at, at + slice <= max_bytes ? slice : max_bytes - at, g_file_in.pos + (off_t)at, 0};
-    bool started[16] = {false};
-    for (int i = 1; i < n; i++) started[i] = pthread_create(&th[i], nullptr, pread_main, &jobs[i]) == 0;
-    pread_main(&jobs[0]);
-    for (int i = 1; i < n; i++) { if (started[i]) pthread_join(th[i], nullptr); else pread_main(&jobs[i]); }
+    if (g_pool.n_threads == 0) {                                      // (only this thread starts the pool)
+        for (int i = 1; i < K; i++) { pthread_t t; if (pthread_create(&t, nullptr, pread_pool_main, nullptr) == 0) { pthread_detach(t); g_pool.n_threads++; } }
+        if (g_pool.n_threads == 0) g_pool.n_threads = -1;             // no helpers: this thread reads every slice
+    }
+    if (g_pool.n_threads > 0 && n > 1) {
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.jobs = jobs; g_pool.n_jobs = n; g_pool.next = 1; g_pool.done = 1; g_pool.gen++;      // slice 0 is this thread's
+        pthread_cond_broadcast(&g_pool.cv_go);
+        pthread_mutex_unlock(&g_pool.mu);
+        pread_all(&jobs[0]);
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.next < g_pool.n_jobs) {                         // (fewer helpers than slices, or none awake yet: take what is left)
+            PreadJob *j = &g_pool.jobs[g_pool.next++];
+            pthread_mutex_unlock(&g_pool.mu); pread_all(j); pthread_mutex_lock(&g_pool.mu);
+            g_pool.done++;
+        }
+        while (g_pool.done < g_pool.n_jobs) pthread_cond_wait(&g_pool.cv_done, &g_pool.mu);
+        g_pool.n_jobs = 0; g_pool.jobs = nullptr;
+        pthread_mutex_unlock(&g_pool.mu);
+    } else for (int i = 0; i < n; i++) pread_all(&jobs[i]);
     size_t have = 0; bool end = false;
     for (int i = 0; i < n && !end; i++) { have += jobs[i].got; if (jobs[i].got < jobs[i].len) end = true; }
     g_file_in.pos += (off_t)have;
@@ -767,7 +801,7 @@ void read_file_parallel(char *buf, size_t max_bytes, size_t *got, bool *eof)
 // blocks until min_bytes have arrived (or EOF / error), then keeps reading only while more is immediately available
 void read_some(char *buf, size_t min_bytes, size_t max_bytes, size_t *got, bool *eof)
 {
-    if (g_file_in.regular && max_bytes >= ((size_t)1 << 20)) { read_file_parallel(buf, max_bytes, got, eof); return; }
+    if (g_file_in.regular && max_bytes >= ((size_t)4 << 20)) { read_file_parallel(buf, max_bytes, got, eof); return; }
     size_t have = 0; *eof = false;
     while (have < max_bytes) {
         if (have >= min_bytes) {
@@ -872,7 +906,13 @@ void *writer_ipc_main(void *arg)
     (void)hipSetDevice(io->device);
     for (;;) {
         HostBuf *b = io->full_out.pop();
-        if (b->eof) { io->sink_closing.store(true); shutdown(io->sink_fd, SHUT_WR); return nullptr; }
+        if (b->eof) {
+            // the last token is out: close OUR end of the pipe too, now -- the consumer carries on reading bytes from stdin after the hand-off's end (another writer of the
+            // same pipe may follow), and without this it saw stdin's EOF only when this process had torn its HIP context down: the seven tear-downs of the README.md:66
+            // pipeline ran one after the other (+0.3 s per run, tools/bench_cli.sh)
+            io->sink_closing.store(true); shutdown(io->sink_fd, SHUT_WR); (void)close(STDOUT_FILENO);
+            return nullptr;
+        }
         if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }          // the kernels that filled the slot have run
         IpcToken t = {(unsigned)b->slot, 0u, (unsigned long long)b->bytes};
         if (send(io->sink_fd, &t, sizeof t, MSG_NOSIGNAL) != (ssize_t)sizeof t) _exit(0);   // downstream closed: end quietly like SIGPIPE would

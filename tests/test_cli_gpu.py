@@ -302,13 +302,13 @@ def test_cli_handoff_then_bytes_from_a_second_writer(port, tmp_path):
 
 def test_cli_regular_file_input_with_parallel_readers(port, tmp_path):
     """`csdr ... < file`: the block's bytes come from CSDR_AMD_READERS threads with pread() on disjoint slices (one reader thread copied 7 GS/s out of the page cache,
-    a third of `cat`: VERDICT r4 #7).  A file whose length is no multiple of the block, the slice or the page; blocks of 2 Mi and of 300 k elements (the second below
-    the 1 MiB threshold: plain read() on the same descriptor); 1 / 3 / 4 readers: the same bytes out, and the oracle's."""
+    a third of `cat`: VERDICT r4 #7).  A file whose length is no multiple of the block, the slice or the page; blocks of 4 Mi and of 300 k elements (the second below
+    the 4 MiB threshold: plain read() on the same descriptor); 1 / 3 / 4 readers: the same bytes out, and the oracle's."""
     rng = np.random.default_rng(33)
-    x = rng.integers(0, 256, 5 * (1 << 20) + 12345, dtype=np.uint8)
+    x = rng.integers(0, 256, 9 * (1 << 20) + 12345, dtype=np.uint8)
     f = tmp_path / "in.u8"; x.tofile(f)
     want = port.convert_u8_f(x)
-    for block in (2 << 20, 300000):
+    for block in (4 << 20, 300000):
         outs = []
         for readers in ("1", "3", "4"):
             env = dict(os.environ, CSDR_AMD_BLOCK=str(block), CSDR_AMD_READERS=readers)

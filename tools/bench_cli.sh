@@ -13,19 +13,19 @@ for name, reps in (("/tmp/iq_a.u8", 20), ("/tmp/iq_b.u8", 80)):
 PY
 # best of three runs (the first process on a cold box pays the HIP start-up of the whole image: that is not a streaming rate)
 run() { local best=1e9; for i in 1 2 3; do local s=$(date +%s.%N); "$@" > /dev/null 2>/dev/null; local e=$(date +%s.%N); best=$(python -c "print(min($best, $e - $s))"); done; echo $best; }
-csdr_amd/csdr wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8 > /dev/null 2>&1    # warm the box
+${CSDR_BIN:-csdr_amd/csdr} wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8 > /dev/null 2>&1    # warm the box
 LEGS=${LEGS:-fused chain pipe7 ref cat}     # which parts to run
 has() { case " $LEGS " in *" $1 "*) return 0;; esac; return 1; }
 WFM='convert_u8_f | shift_addition_cc -0.085 | fir_decimate_cc 10 0.05 HAMMING | fmdemod_quadri_cf | fractional_decimator_ff 5.5 | deemphasis_wfm_ff 48000 50e-6 | convert_f_s16'
 for b in 262144 1048576 4194304; do
   has fused || break
   export CSDR_AMD_BLOCK=$b
-  ta=$(run sh -c 'csdr_amd/csdr wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8'); tb=$(run sh -c 'csdr_amd/csdr wfm_chain_u8_s16 -0.085 < /tmp/iq_b.u8')
+  ta=$(run sh -c '${CSDR_BIN:-csdr_amd/csdr} wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8'); tb=$(run sh -c '${CSDR_BIN:-csdr_amd/csdr} wfm_chain_u8_s16 -0.085 < /tmp/iq_b.u8')
   python -c "ta, tb = $ta, $tb; r = (1920e6 - 480e6) / (tb - ta); print('wfm_chain_u8_s16 block=$b: %.0f MS/s streaming, start-up %.2f s (480 M samples %.2f s, 1920 M samples %.2f s)' % (r / 1e6, ta - 480e6 / r, ta, tb))"
 done
 export CSDR_AMD_BLOCK=4194304
 if has chain; then
-ta=$(run sh -c "csdr_amd/csdr chain '$WFM' < /tmp/iq_a.u8"); tb=$(run sh -c "csdr_amd/csdr chain '$WFM' < /tmp/iq_b.u8")
+ta=$(run sh -c "${CSDR_BIN:-csdr_amd/csdr} chain '$WFM' < /tmp/iq_a.u8"); tb=$(run sh -c "${CSDR_BIN:-csdr_amd/csdr} chain '$WFM' < /tmp/iq_b.u8")
 python -c "ta, tb = $ta, $tb; r = (1920e6 - 480e6) / (tb - ta); print('chain of seven unfused commands block=4194304: %.0f MS/s streaming, start-up %.2f s' % (r / 1e6, ta - 480e6 / r))"
 fi
 # the LITERAL shell pipeline of README.md:66: seven processes of this csdr, adjacent ones handing blocks over in HBM (csdr_cli.cpp "device hand-off"), the same with
@@ -34,7 +34,7 @@ PIPE7() { echo "$1 convert_u8_f < $2 | $1 shift_addition_cc -0.085 | $1 fir_deci
 for ipc in 1 0; do
   has pipe7 || break
   export CSDR_AMD_IPC=$ipc
-  ta=$(run timeout 120 sh -c "$(PIPE7 csdr_amd/csdr /tmp/iq_a.u8)"); tb=$(run timeout 120 sh -c "$(PIPE7 csdr_amd/csdr /tmp/iq_b.u8)")
+  ta=$(run timeout 120 sh -c "$(PIPE7 ${CSDR_BIN:-csdr_amd/csdr} /tmp/iq_a.u8)"); tb=$(run timeout 120 sh -c "$(PIPE7 ${CSDR_BIN:-csdr_amd/csdr} /tmp/iq_b.u8)")
   python -c "ta, tb = $ta, $tb; r = (1920e6 - 480e6) / (tb - ta); print('seven csdr processes in a shell pipeline, CSDR_AMD_IPC=$ipc (1 = device hand-off between the processes, 0 = bytes through the pipes), block=4194304: %.0f MS/s streaming, start-up %.2f s (480 M samples %.2f s, 1920 M samples %.2f s)' % (r / 1e6, ta - 480e6 / r, ta, tb))"
 done
 unset CSDR_AMD_IPC
