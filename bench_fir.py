@@ -86,7 +86,7 @@ def main():
         samples = S * T * args.steps * world
         algo = (8.0 + 8.0 / D) * S * T
         k_ms = ev_ms / args.steps                                             # one kernel per step: the HIP-event time per step IS the kernel's
-        kname = "k_fir_poly" if nt <= 128 else ("k_fir_generic" if os.environ.get("CSDR_AMD_FIR_MFMA_OFF") else "k_fir_mfma")
+        kname = L.csdr_amd_fir_last_kernel().decode()                          # what the timed calls launched (k_fir_poly, k_fir_mfma3, ...)
         res = {"metric": "complex MS/s in, fir_decimate_cc %d %g HAMMING @2.4 MS/s x N streams" % (D, args.tbw), "value": round(samples / wall / 1e6, 1),
                "unit": "complex MS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps_before_warmup": spin_steps, "ms_per_step": round(wall / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -114,6 +114,7 @@ def lib():
     L.csdr_amd_shift_cc.argtypes = [vp, i, fl, C.POINTER(fl), vp, vp, i, sz, sz, sz, i, i]
     L.csdr_amd_decimating_shift_addition_cc.argtypes = [vp, vp, vp, i, i, sz, sz, vp, i, vp]
     L.csdr_amd_fir_decimate_cc.argtypes = [vp, vp, vp, i, i, sz, sz, i, vp, i]
+    L.csdr_amd_fir_last_kernel.restype = C.c_char_p; L.csdr_amd_fir_last_kernel.argtypes = []
     L.csdr_amd_fir_ff.argtypes = [vp, vp, vp, i, i, sz, sz, vp, i]
     L.csdr_amd_fmdemod_quadri_cf.argtypes = [vp, vp, vp, i, sz, sz, sz, vp]
     L.csdr_amd_limit_ff.argtypes = [vp, vp, vp, sz, fl]

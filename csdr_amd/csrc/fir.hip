@@ -477,16 +477,20 @@ const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_si
 // (global_load_lds_dwordx4, 1 KiB per wave instruction, no staging registers: ~110 registers, TWO eight-wave workgroups per CU, one in its products while the other's
 // window lands).  The XOR swizzle works on 16-byte granules (mask 28 instead of 30: a DMA piece is linear in LDS, so the permutation is applied to the SOURCE granule of
 // each lane, inside its own 128-byte line); lanes past the stream's end re-read its last granule (finite values under zero weights).
-template <int MAXB>
-__global__ __launch_bounds__(512, 4) void k_fir_mfma3(const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_size, size_t in_pitch, size_t out_pitch,
+#ifndef FIR3_DIAG
+#define FIR3_DIAG 0     // timing experiments: 1 = no products, 2 = no window fetch after the first tile
+#endif
+template <int MAXB, int NW, bool DB>                                 // NW = 8: two workgroups per CU, one window each; NW = 16 (DB): ONE workgroup per CU, four waves per SIMD,
+__global__ __launch_bounds__(64 * NW, 4) void k_fir_mfma3(              // two windows -- the next tile lands during this tile's products
+const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_size, size_t in_pitch, size_t out_pitch,
                                                       int D, const float *__restrict__ taps, int L, int tiles_per_wg)
 {
     extern __shared__ float4 lds_raw[];
-    constexpr int NT = 8, NW = 8, NTHR = 512, TO = 16 * NT;
+    constexpr int NT = 8, NTHR = 64 * NW, TO = 16 * NT, PPW = 64 / NW;      // DMA pieces per wave (of up to 64)
     const int PAD = 15 * D, KT = 15 * D + L, steps = (KT + 3) / 4, nblk = (steps + 3) / 4;
     const int n_pieces = (8 * (16 * D * (NT - 1) + 16 * nblk + 8) + 1023) >> 10;      // 1-KiB DMA pieces of the window (<= 16 nblk + 16 D (NT - 1) + 8 samples)
     float *xw = reinterpret_cast<float *>(lds_raw);
-    float *hz = xw + 256 * n_pieces;                                  // PAD zeros, the taps, zeros up to 16 nblk + 16 floats
+    float *hz = xw + 256 * n_pieces * (DB ? 2 : 1);                   // PAD zeros, the taps, zeros up to 16 nblk + 16 floats
     float *red = hz + PAD + 16 * nblk + 16;                           // NW x 256 partial results
     const size_t s = blockIdx.y;
     const int t = threadIdx.x;
@@ -495,27 +499,27 @@ __global__ __launch_bounds__(512, 4) void k_fir_mfma3(const float2 *__restrict__
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
     const uint8_t *row_base = reinterpret_cast<const uint8_t *>(in + s * in_pitch);
     const uint32_t xw_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)xw;
-    // ---- DMA: wave w moves pieces 8 w .. 8 w + 7; lane l of piece p fills LDS granule Gd = 64 p + l with source granule Gd ^ ((Gd >> 5) & 7)
-    uint32_t gsrc[8];
+    // ---- DMA: wave w moves pieces PPW w .. PPW w + PPW - 1; lane l of piece p fills LDS granule Gd = 64 p + l with source granule Gd ^ ((Gd >> 5) & 7)
+    uint32_t gsrc[PPW];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { const uint32_t gd = 64u * (8u * wave + r) + lane; gsrc[r] = gd ^ ((gd >> 5) & 7u); }      // row = gd >> 3; the readers' mask is (row & 28) floats = ((row >> 2) & 7) granules
-    auto stage = [&](int tile) {
+    for (int r = 0; r < PPW; r++) { const uint32_t gd = 64u * ((uint32_t)PPW * wave + r) + lane; gsrc[r] = gd ^ ((gd >> 5) & 7u); }      // row = gd >> 3; the readers' mask is (row & 28) floats = ((row >> 2) & 7) granules
+    auto stage = [&](int tile, uint32_t buf_bytes) {
         const long long first = (long long)tile * TO * D;             // first sample of the window (even: 16-byte granules of the row)
         const long long gmax = ((long long)input_size - first - 2) >> 1;      // last granule that lies inside the stream
-        uint32_t vo[8];
+        uint32_t vo[PPW];
 #pragma unroll
-        for (int r = 0; r < 8; r++) vo[r] = 16u * (uint32_t)min((long long)gsrc[r], gmax > 0 ? gmax : 0LL);
+        for (int r = 0; r < PPW; r++) vo[r] = 16u * (uint32_t)min((long long)gsrc[r], gmax > 0 ? gmax : 0LL);
         const uint8_t *sbase = row_base + first * 8;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            if (8 * wave + r >= n_pieces) break;                      // (wave uniform)
-            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(xw_addr + 1024u * (8u * wave + r)));
+        for (int r = 0; r < PPW; r++) {
+            if (PPW * wave + r >= n_pieces) break;                    // (wave uniform)
+            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(xw_addr + buf_bytes + 1024u * ((uint32_t)PPW * wave + r)));
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(vo[r]), "s"(sbase), "s"(la) : "memory");
         }
     };
-    stage(tile0);
+    stage(tile0, 0u);
     for (int k = t; k < PAD + 16 * nblk + 16; k += NTHR) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
     const int b_lo = wave * nblk / NW, b_hi = (wave + 1) * nblk / NW;   // this wave's blocks of four K-steps (wave uniform)
     const int n = lane & 15, g = n >> 1, part = n & 1;
@@ -530,50 +534,51 @@ __global__ __launch_bounds__(512, 4) void k_fir_mfma3(const float2 *__restrict__
     }
     const int c = 2 * kk + part;
     const int h_last = D * g + b_hi - 1 + (b_hi == b_lo);              // (blocks beyond the wave's range re-read its last one: multiplied by zero)
-    static_assert(MAXB % 2 == 0, "batches of two blocks");
     for (int tile = tile0; tile < tile1; tile++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the window
         __syncthreads();                                              // everybody's; and the previous tile's partial sums have been read
+        const uint32_t cur_buf = DB ? (uint32_t)((tile - tile0) & 1) * 1024u * (uint32_t)n_pieces : 0u;
+        if (DB && tile + 1 < tile1 && FIR3_DIAG != 2) stage(tile + 1, (1024u * (uint32_t)n_pieces) - cur_buf);      // the other window: every wave has left the tile before last
         f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         int hi = D * g + b_lo;
         asm volatile("" : "+v"(hi));                                  // (per tile: otherwise every B address is hoisted out of the tile loop)
+        // batches of two blocks (eight B reads in flight, then eight products), the next batch's reads issued before this batch's products; an odd last block on its own
         float bA[8], bB[8];
-        auto issue = [&](float (&bv)[8], int blk0) {
+        auto issue = [&](float (&bv)[8], int blk0, const int nb) {
 #pragma unroll
             for (int jj = 0; jj < 2; jj++) {
+                if (jj >= nb) break;
                 const int h2 = min(blk0 + jj, h_last);
                 const int m = h2 & 28;
-                const uint32_t a0 = xw_addr + ((uint32_t)h2 << 7) + ((uint32_t)(c ^ m) << 2);
+                const uint32_t a0 = xw_addr + cur_buf + ((uint32_t)h2 << 7) + ((uint32_t)(c ^ m) << 2);
 #pragma unroll
                 for (int u = 0; u < 4; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(bv[4 * jj + u]) : "v"(a0 ^ (uint32_t)(u << 5)) : "memory");
             }
         };
-        issue(bA, hi);
+        constexpr int NBATCH = (MAXB + 1) / 2;                       // batch q covers blocks 2 q, 2 q + 1 (the last one only 2 q when MAXB is odd)
+        auto blocks_of = [](int q) { return (2 * q + 1 < MAXB) ? 2 : 1; };
+        if (FIR3_DIAG != 1) issue(bA, hi, blocks_of(0));
 #pragma unroll
-        for (int j = 0; j < MAXB; j += 4) {
-            if (j + 2 < MAXB) issue(bB, hi + j + 2);
-            if (j + 2 < MAXB) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bA[0]), "+v"(bA[1]), "+v"(bA[2]), "+v"(bA[3]), "+v"(bA[4]), "+v"(bA[5]), "+v"(bA[6]), "+v"(bA[7]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bA[0]), "+v"(bA[1]), "+v"(bA[2]), "+v"(bA[3]), "+v"(bA[4]), "+v"(bA[5]), "+v"(bA[6]), "+v"(bA[7]));
+        for (int q = 0; q < (FIR3_DIAG == 1 ? 0 : NBATCH); q++) {
+            float (&cur)[8] = (q & 1) ? bB : bA;
+            float (&nxt)[8] = (q & 1) ? bA : bB;
+            const int nbc = blocks_of(q);
+            if (q + 1 < NBATCH) {
+                const int nbn = blocks_of(q + 1);
+                issue(nxt, hi + 2 * (q + 1), nbn);
+                if (nbn == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * j + u], bA[u], acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * j + u + 1], bA[u + 1], acc1, 0, 0, 0);
-            }
-            if (j + 2 < MAXB) {
-                if (j + 4 < MAXB) issue(bA, hi + j + 4);
-                if (j + 4 < MAXB) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bB[0]), "+v"(bB[1]), "+v"(bB[2]), "+v"(bB[3]), "+v"(bB[4]), "+v"(bB[5]), "+v"(bB[6]), "+v"(bB[7]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bB[0]), "+v"(bB[1]), "+v"(bB[2]), "+v"(bB[3]), "+v"(bB[4]), "+v"(bB[5]), "+v"(bB[6]), "+v"(bB[7]));
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * (j + 2) + u], bB[u], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * (j + 2) + u + 1], bB[u + 1], acc1, 0, 0, 0);
-                }
+            for (int u = 0; u < 4 * nbc; u += 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[8 * q + u], cur[u], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[8 * q + u + 1], cur[u + 1], acc1, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r] + acc1[r];
         __syncthreads();                                              // every wave has left the window: the next one may land
-        if (tile + 1 < tile1) stage(tile + 1);
+        if (!DB && tile + 1 < tile1 && FIR3_DIAG != 2) stage(tile + 1, 0u);
         if (t < 256) {   // C layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (i)
             const int r = t >> 6, ln = t & 63;
             float sum = red[t];
@@ -597,7 +602,12 @@ static int pick_tile(int D, int ntaps, int floats_per_sample, int n_out)
     return to < 1 ? 1 : to;
 }
 
+static thread_local const char *g_fir_last_kernel = "";
+
 extern "C" {
+
+/* which kernel the calling thread's last csdr_amd_fir_decimate_cc launched (bench_fir.py's roofline.kernel; "" before the first call) */
+const char *csdr_amd_fir_last_kernel(void) { return g_fir_last_kernel; }
 
 int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_complexf *out, int n_streams, int input_size,
                              size_t in_pitch, size_t out_pitch, int decimation, const float *taps, int taps_length)
@@ -611,6 +621,7 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     if (!force_generic && poly_cfg(decimation, taps_length, 8, g)) {
         launch_poly<float2>(c, g, (const float2 *)in, (float2 *)out, n_out, n_streams, in_pitch, out_pitch, decimation, taps, taps_length);
         CSDR_LAUNCH_CHECK();
+        g_fir_last_kernel = "k_fir_poly";
         return n_out;
     }
     if (!mfma_off) {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
@@ -638,14 +649,26 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
             // k_fir_mfma3: the window by LDS-DMA.  Needs: 8 outputs groups, <= 14 blocks per wave, the window + slack inside 64 KiB, 16-byte aligned stream rows
             static const bool mfma3_off = getenv("CSDR_AMD_FIR_MFMA3") && atoi(getenv("CSDR_AMD_FIR_MFMA3")) == 0;
             {
-                const int per_wave8 = (nblk + 7) / 8 + 1;
+                const int per_wave8 = (nblk + 7) / 8 + 1;      // (<= 14 blocks per wave)
                 const long win_samples = 16L * decimation * 7 + 16L * nblk + 8;
                 const size_t lds3 = (((size_t)8 * win_samples + 1023) & ~(size_t)1023) + sizeof(float) * (15 * (size_t)decimation + 16 * (size_t)nblk + 16 + 2048);
-                if (!mfma3_off && nt == 8 && per_wave8 <= 14 && win_samples <= 8192 && (in_pitch % 2) == 0 && (input_size % 2) == 0 && (((uintptr_t)in) & 15) == 0 && lds3 <= 80 * 1024) {
-                    const int arc = lds_attr_once((const void *)k_fir_mfma3<14>, lds3); if (arc) return arc;
-                    hipLaunchKernelGGL((k_fir_mfma3<14>), grid, dim3(512), lds3, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,
-                                       decimation, taps, taps_length, tpw);
+                if (!mfma3_off && nt == 8 && per_wave8 <= 15 && win_samples <= 8192 && (in_pitch % 2) == 0 && (input_size % 2) == 0 && (((uintptr_t)in) & 15) == 0 && lds3 <= 80 * 1024) {
+                    static const int mfma3_waves = getenv("CSDR_AMD_FIR_MFMA3_WAVES") ? atoi(getenv("CSDR_AMD_FIR_MFMA3_WAVES")) : 8;      // 8 (two workgroups per CU) or 16 (one, two windows)
+                    const size_t win_bytes = ((size_t)8 * win_samples + 1023) & ~(size_t)1023;
+                    const size_t lds4 = 2 * win_bytes + sizeof(float) * (15 * (size_t)decimation + 16 * (size_t)nblk + 16 + 4096);
+#define FIR_MFMA3(MB, NWV, DBV, LDSV) do { const int arc = lds_attr_once((const void *)k_fir_mfma3<MB, NWV, DBV>, LDSV); if (arc) return arc;                                                      \
+                    hipLaunchKernelGGL((k_fir_mfma3<MB, NWV, DBV>), grid, dim3(64 * NWV), LDSV, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,        \
+                                       decimation, taps, taps_length, tpw); } while (0)
+                    if (mfma3_waves == 16 && lds4 <= 160 * 1024 - 512 && (nblk + 15) / 16 <= 7) {
+                        const int need16 = (nblk + 15) / 16;
+                        if (need16 <= 4) FIR_MFMA3(4, 16, true, lds4); else if (need16 <= 5) FIR_MFMA3(5, 16, true, lds4); else if (need16 <= 6) FIR_MFMA3(6, 16, true, lds4); else FIR_MFMA3(7, 16, true, lds4);
+                    } else {
+                    const int need = (nblk + 7) / 8;                 // the largest wave share: wave w takes blocks [w nblk / 8, (w + 1) nblk / 8)
+                    if (need <= 8) FIR_MFMA3(8, 8, false, lds3); else if (need <= 10) FIR_MFMA3(10, 8, false, lds3); else if (need <= 12) FIR_MFMA3(12, 8, false, lds3); else if (need <= 13) FIR_MFMA3(13, 8, false, lds3); else FIR_MFMA3(14, 8, false, lds3);
+                    }
+#undef FIR_MFMA3
                     CSDR_LAUNCH_CHECK();
+                    g_fir_last_kernel = "k_fir_mfma3";
                     return n_out;
                 }
             }
@@ -659,12 +682,14 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
                 else FIR_MFMA2(32, 26, 4, 1);
 #undef FIR_MFMA2
                 CSDR_LAUNCH_CHECK();
+                g_fir_last_kernel = "k_fir_mfma2";
                 return n_out;
             }
             if (nt == 8) FIR_MFMA_NS(8); else if (nt == 4) FIR_MFMA_NS(4); else if (nt == 2) FIR_MFMA_NS(2); else FIR_MFMA_NS(1);
 #undef FIR_MFMA_NS
 #undef FIR_MFMA
             CSDR_LAUNCH_CHECK();
+            g_fir_last_kernel = "k_fir_mfma";
             return n_out;
         }
     }
@@ -676,6 +701,7 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     hipLaunchKernelGGL((k_fir_generic<true>), grid, dim3(256), win_bytes + 16, c->stream, (const float *)in, (float *)out, n_out, to,
                        in_pitch, out_pitch, decimation, taps, taps_length);
     CSDR_LAUNCH_CHECK();
+    g_fir_last_kernel = "k_fir_generic";
     return n_out;
 }
 

@@ -120,6 +120,9 @@ void csdr_amd_shift_addition_init(float rate, float *out3);
 /* ------------------------------------------------------------------ FIR decimator
  * fir_decimate_cc libcsdr.c:528-549: out[s][o] = sum_t in[s][D*o+t]*taps[t] for all o with D*o+taps<=input_size.
  * Returns the number of outputs per stream (>=0) or a negative error.  taps: DEVICE pointer. */
+/* the kernel the calling thread's last csdr_amd_fir_decimate_cc launched: k_fir_poly (short filters), k_fir_mfma3 / k_fir_mfma (long filters on the fp32 matrix cores),
+ * k_fir_generic */
+const char *csdr_amd_fir_last_kernel(void);
 int csdr_amd_fir_decimate_cc(csdr_amd_ctx *ctx, const csdr_complexf *in, csdr_complexf *out,
                              int n_streams, int input_size, size_t in_pitch, size_t out_pitch,
                              int decimation, const float *taps, int taps_length);
