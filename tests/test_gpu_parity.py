@@ -128,6 +128,36 @@ def test_fir_decimate(gpu, port, D, ntaps):
     assert relrms(a, b) < TOL
 
 
+@pytest.mark.parametrize("D,ntaps", [(50, 801), (32, 513), (20, 401)])
+def test_fir_decimate_long_filter_dma_kernel(gpu, port, D, ntaps):
+    """k_fir_mfma3 (round 5: taps operand in registers, window by LDS-DMA, swizzle applied to the source granules): long filters on complexf with an EVEN stream
+    length take it -- several tiles of 128 outputs with a ragged last one, five streams, a stream shorter than one tile --, an odd length stays on k_fir_mfma (the
+    DMA moves 16-byte granules); all against the oracle, and the two kernels against each other."""
+    rng = np.random.default_rng(4321)
+    taps = port.firdes_lowpass_f(ntaps, 0.5 / D)
+    n_even = 128 * D * 3 + ntaps + D * 37 + ((ntaps + D) % 2)        # three full tiles and 37 / 38 outputs more
+    n_even += n_even % 2
+    xs = np.stack([crand(rng, n_even) for _ in range(5)])
+    ys = gpu.fir_decimate_cc(xs, D, taps)
+    assert gpu.L.csdr_amd_fir_last_kernel() == b"k_fir_mfma3"
+    for s in range(5):
+        want = port.fir_decimate_cc(xs[s], D, taps)
+        assert ys[s].size == want.size and relrms(ys[s], want) < TOL, s
+    x_odd = xs[0][:n_even - 1]
+    y_odd = gpu.fir_decimate_cc(x_odd, D, taps)
+    assert gpu.L.csdr_amd_fir_last_kernel() == b"k_fir_mfma"
+    w_odd = port.fir_decimate_cc(x_odd, D, taps)
+    assert y_odd.size == w_odd.size and relrms(y_odd, w_odd) < TOL
+    m = min(y_odd.size, ys[0].size)
+    assert relrms(y_odd[:m], ys[0][:m]) < 2e-6                        # the same sums up to the K-split points
+    n_short = ntaps + D * 20 + ((ntaps + D * 20) % 2)                # 21 outputs: one partial tile, most of the window behind the stream's end
+    x1 = crand(rng, n_short)
+    y1 = gpu.fir_decimate_cc(x1, D, taps)
+    assert gpu.L.csdr_amd_fir_last_kernel() == b"k_fir_mfma3"
+    w1 = port.fir_decimate_cc(x1, D, taps)
+    assert y1.size == w1.size and relrms(y1, w1) < TOL
+
+
 def test_fir_decimate_c1_and_edges(gpu, port):
     rng = np.random.default_rng(1234)
     x = crand(rng, 16384)                                          # BASELINE config 1
