@@ -515,7 +515,8 @@ const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_si
             if (PPW * wave + r >= n_pieces) break;                    // (wave uniform)
             const uint32_t la = __builtin_amdgcn_readfirstlane((int)(xw_addr + buf_bytes + 1024u * ((uint32_t)PPW * wave + r)));
             uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+            // (no `nt`: the window's first L - 1 samples were the previous tile's last ones, fetched by this very workgroup a few microseconds ago -- they should come from L2)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(vo[r]), "s"(sbase), "s"(la) : "memory");
         }
     };
