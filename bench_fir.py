@@ -55,13 +55,16 @@ def main():
     taps_h = ctx.firdes_lowpass_f(nt, 0.5 / D, "HAMMING")                      # csdr.c:1144-1158
     taps = ctx.upload(taps_h)
     g = torch.Generator(device="cuda"); g.manual_seed(1234 + rank)
-    x = (torch.rand((S, T, 2), device="cuda", generator=g) * 2 - 1).contiguous()
-    opitch = T // D + 8
+    pad = int(os.environ.get("CSDR_BENCH_PITCH_PAD", "0"))                       # experiments: extra samples of row pitch (channel / bank spreading of the 256 concurrent rows)
+    xbuf = (torch.rand((S, T + pad, 2), device="cuda", generator=g) * 2 - 1).contiguous()
+    x = xbuf
+    in_pitch = T + pad
+    opitch = T // D + 8 + int(os.environ.get("CSDR_BENCH_OPITCH_PAD", "0"))
     y = torch.empty((S, opitch, 2), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
 
     def step():
-        n = L.csdr_amd_fir_decimate_cc(ctx.h, x.data_ptr(), y.data_ptr(), S, T, T, opitch, D, taps.ptr, nt)
+        n = L.csdr_amd_fir_decimate_cc(ctx.h, x.data_ptr(), y.data_ptr(), S, T, in_pitch, opitch, D, taps.ptr, nt)
         if n < 0:
             raise SystemExit("fir_decimate_cc: " + ctx.err())
         return n

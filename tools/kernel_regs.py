@@ -11,7 +11,8 @@ for path in sys.argv[1:]:
             dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
         except Exception:
             dn = name
-        dn = re.sub(r"\(.*", "", dn).replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+        dn = dn.replace("(anonymous namespace)::", "").replace("void ", "")
+        dn = re.sub(r"\(.*", "", dn)[:60]
         m = re.search(r"^" + re.escape(name) + r":.*?s_endpgm", t, re.S | re.M)
         txt = m.group(0) if m else ""
         print("%-60s vgpr %3s sgpr %3s s-spill %3s v-spill %3s lds %6s | s_load %3d lane-spill %3d scratch %3d mfma %4d" % (
