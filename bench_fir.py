@@ -59,12 +59,23 @@ def main():
     xbuf = (torch.rand((S, T + pad, 2), device="cuda", generator=g) * 2 - 1).contiguous()
     x = xbuf
     in_pitch = T + pad
+    x_ptr = x.data_ptr()
+    if os.environ.get("CSDR_BENCH_ALLOC") == "contig":      # experiment: the input in physically contiguous memory (hipExtMallocWithFlags(hipDeviceMallocContiguous)) instead of torch's block
+        hip = C.CDLL("libamdhip64.so")
+        pc = C.c_void_p()
+        nbytes = xbuf.numel() * 4
+        rc = hip.hipExtMallocWithFlags(C.byref(pc), C.c_size_t(nbytes), C.c_uint(0x4))
+        if rc != 0:
+            raise SystemExit("hipExtMallocWithFlags(contiguous) failed: %d" % rc)
+        hip.hipMemcpy(pc, C.c_void_p(xbuf.data_ptr()), C.c_size_t(nbytes), C.c_int(3))
+        torch.cuda.synchronize()
+        x_ptr = pc.value
     opitch = T // D + 8 + int(os.environ.get("CSDR_BENCH_OPITCH_PAD", "0"))
     y = torch.empty((S, opitch, 2), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
 
     def step():
-        n = L.csdr_amd_fir_decimate_cc(ctx.h, x.data_ptr(), y.data_ptr(), S, T, in_pitch, opitch, D, taps.ptr, nt)
+        n = L.csdr_amd_fir_decimate_cc(ctx.h, x_ptr, y.data_ptr(), S, T, in_pitch, opitch, D, taps.ptr, nt)
         if n < 0:
             raise SystemExit("fir_decimate_cc: " + ctx.err())
         return n
