@@ -649,7 +649,17 @@ __global__ __launch_bounds__(256, 3) void k_fir_mfma5(const float2 *__restrict__
     const int h0 = D * (NT * wave + g);                               // a >> 5 of this wave's tile, group g, block 0
     const int h_last = h0 + nblk - 1;
     typedef float e_v2f __attribute__((ext_vector_type(2))); typedef __attribute__((address_space(1))) e_v2f *gp_f2;
+#ifndef FIR5_DIAG
+#define FIR5_DIAG 0     // timing experiment: 1 = every tile's outputs go to the stream's first tile (stores that never leave L2): what the output stream costs
+#endif
+#ifndef FIR5_HOLD
+#define FIR5_HOLD 4
+#endif
+#ifndef FIR5_NT
+#define FIR5_NT 0
+#endif
     gp_f2 obase = (gp_f2)(out + s * out_pitch);
+    e_v2f hold[FIR5_HOLD][2];
     for (int step = step0; step < step1; step++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces (and its stores of the previous step)
         __syncthreads();
@@ -693,17 +703,33 @@ __global__ __launch_bounds__(256, 3) void k_fir_mfma5(const float2 *__restrict__
         }
         __syncthreads();                                              // every wave has left the window: the next one may land
         if (step + 1 < step1) stage(step + 1);
-        if (tile < n_tiles) {
-            // C layout: column = lane & 15 = (g, part), row = 4 kk + r: output 16 g + 4 kk + r of the tile.  Even lanes take rows 0, 1, odd lanes rows 2, 3, as float2
+        // C layout: column = lane & 15 = (g, part), row = 4 kk + r: output 16 g + 4 kk + r of the tile.  Even lanes take rows 0, 1, odd lanes rows 2, 3, as float2.
+        // The outputs of FIR5_HOLD consecutive steps wait in registers and leave together: beside a saturated read stream the memory charges a thin stream of stores by the
+        // store EVENT (config 1 without its output stream: 0.89 ms instead of 1.08, for 9 % of the bytes) -- four steps = 16 KiB contiguous per workgroup burst.
+        {
             float v[4], o[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) v[r] = acc[r] + acc1[r];
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = __shfl_xor(v[r], 1);   // the other part of the same output
-            const int ob = tile * TO + 16 * g + 4 * kk + (part ? 2 : 0);
-            const e_v2f y0 = part ? e_v2f{o[2], v[2]} : e_v2f{v[0], o[0]}, y1 = part ? e_v2f{o[3], v[3]} : e_v2f{v[1], o[1]};
-            if (ob < n_out) obase[ob] = y0;
-            if (ob + 1 < n_out) obase[ob + 1] = y1;
+            const int hs = (step - step0) % FIR5_HOLD;
+#pragma unroll
+            for (int q = 0; q < FIR5_HOLD; q++) if (q == hs) {
+                hold[q][0] = part ? e_v2f{o[2], v[2]} : e_v2f{v[0], o[0]};
+                hold[q][1] = part ? e_v2f{o[3], v[3]} : e_v2f{v[1], o[1]};
+            }
+            if (hs == FIR5_HOLD - 1 || step + 1 == step1) {
+#pragma unroll
+                for (int q = 0; q < FIR5_HOLD; q++) {
+                    if (q > hs) break;
+                    const int tq = (step - hs + q) * TPI + wave;
+                    const int ob = (FIR5_DIAG == 1 ? 0 : tq) * TO + 16 * g + 4 * kk + (part ? 2 : 0);
+                    if (tq < n_tiles) {
+                        if (ob < n_out) { if (FIR5_NT) __builtin_nontemporal_store(hold[q][0], &obase[ob]); else obase[ob] = hold[q][0]; }
+                        if (ob + 1 < n_out) { if (FIR5_NT) __builtin_nontemporal_store(hold[q][1], &obase[ob + 1]); else obase[ob + 1] = hold[q][1]; }
+                    }
+                }
+            }
         }
     }
 }
