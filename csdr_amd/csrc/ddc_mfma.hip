@@ -258,6 +258,12 @@ __device__ __forceinline__ float4 ddc_reduce(const float4 *b)
     return r;
 }
 
+#ifndef DDC_ASM_READS
+#define DDC_ASM_READS 0     // 1 = the common tile as one hand-ordered line: nine ds_read_b128 back to back, then per K-step its own s_waitcnt, XOR and three products (so the first
+                            // products run under the later reads' latency).  Parity green; measured round 5 against the plain loads (interleaved A/B, 2 x 200 steps each): per
+                            // stream rates 0.719 / 0.727 ms vs 0.709 / 0.719, one rate 0.673 / 0.674 vs 0.668 / 0.665 -- no gain, a little worse (the SIMD's other wave already
+                            // covers that latency).  Kept switchable, off.
+#endif
 #ifndef DDC_RING_PAD
 #define DDC_RING_PAD 32       // bytes between the streams' rings beyond the ring itself (see k_ddc_mfma)
 #endif
@@ -546,37 +552,58 @@ __global__ __launch_bounds__(64 * DDC_WPT * NT) void k_ddc_mfma(const uint8_t *_
             // common case is ONE address and nine immediate offsets.)
             const int b0 = __builtin_amdgcn_readfirstlane((int)(ws & (RB - 1)) + 64 * DDC_NKW * w);      // wave uniform
             v4i Bf[DDC_NKW];
-            if (b0 + 64 * DDC_NKW <= RB) {                                           // (16 q <= 48 stays inside the last K-step's 64 bytes)
-                const uint8_t *pb = lrow + b0 + 16 * q;
-#pragma unroll
-                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(pb + 64 * ks);
-                asm volatile("" ::: "memory");                                       // (keeps these reads in this branch: merged with the other branch's they get nine computed addresses again)
-#pragma unroll
-                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] ^= (int)0x80808080;
-            } else {
-                const int base = b0 + 16 * q;
-#pragma unroll
-                for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
-            }
-            // ---- one accumulator chain per digit; snapshot at the chunk boundary.  (round 5: the tile without a boundary in this K-range -- 72 % of them -- is its own
-            // straight-line path: merged with the ten boundary variants it paid 12 moves for a snapshot it does not have.)
             v4i acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, snap[3];
             const bool lo_lane = half && q < 2;
             const bool two = kb < DDC_NKW;                                            // == g.two (ddc_wave_geom), as the branch the chains were picked by
-            if (!two) ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap);                   // (snap untouched and unused)
-            else {
+            const bool fast = b0 + 64 * DDC_NKW <= RB;                                // (16 q <= 48 stays inside the last K-step's 64 bytes)
+#if DDC_ASM_READS
+            if (fast && !two) {
+                // The common tile (no ring wrap inside the wave's nine reads, no chunk boundary in its K-range: two tiles in three) as ONE straight line: nine reads
+                // issued back to back, then per K-step its own wait, its XOR and its three products -- the first products run under the later reads' latency.
+                // (Reads as plain loads were followed by one s_waitcnt lgkmcnt(0) and all 36 XORs in front of the first product.)
+                const uint32_t pa = (uint32_t)(size_t)(__attribute__((address_space(3))) const uint8_t *)(lrow + b0 + 16 * q);
 #pragma unroll
-                for (int l = 0; l < 3; l++) snap[l] = v4i{0, 0, 0, 0};
-                switch (kb) {
-                    case 0: ddc_chain<0>(A, Bf, lo_lane, acc, snap); break;
-                    case 1: ddc_chain<1>(A, Bf, lo_lane, acc, snap); break;
-                    case 2: ddc_chain<2>(A, Bf, lo_lane, acc, snap); break;
-                    case 3: ddc_chain<3>(A, Bf, lo_lane, acc, snap); break;
-                    case 4: ddc_chain<(4 < DDC_NKW ? 4 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
-                    case 5: ddc_chain<(5 < DDC_NKW ? 5 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
-                    case 6: ddc_chain<(6 < DDC_NKW ? 6 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
-                    case 7: ddc_chain<(7 < DDC_NKW ? 7 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
-                    default: ddc_chain<(8 < DDC_NKW ? 8 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                for (int ks = 0; ks < DDC_NKW; ks++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Bf[ks]) : "v"(pa), "n"(64 * ks) : "memory");
+#pragma unroll
+                for (int ks = 0; ks < DDC_NKW; ks++) {
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(Bf[ks]) : "n"(DDC_NKW - 1 - ks));
+                    Bf[ks] ^= (int)0x80808080;
+#pragma unroll
+                    for (int l = 0; l < 3; l++) acc[l] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[ks * 3 + l], Bf[ks], acc[l], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                               // (without it the scheduler pulls six of the nine waits in front of the first product)
+                }
+            } else
+#endif
+            {
+                if (fast) {
+                    const uint8_t *pb = lrow + b0 + 16 * q;
+#pragma unroll
+                    for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(pb + 64 * ks);
+                    asm volatile("" ::: "memory");                                   // (keeps these reads in this branch: merged with the other branch's they get nine computed addresses again)
+#pragma unroll
+                    for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] ^= (int)0x80808080;
+                } else {
+                    const int base = b0 + 16 * q;
+#pragma unroll
+                    for (int ks = 0; ks < DDC_NKW; ks++) Bf[ks] = *reinterpret_cast<const v4i *>(lrow + ((base + 64 * ks) & (RB - 1))) ^ (int)0x80808080;
+                }
+                // ---- one accumulator chain per digit; snapshot at the chunk boundary.  (round 5: the tile without a boundary in this K-range -- 72 % of them -- is its own
+                // straight-line path: merged with the ten boundary variants it paid 12 moves for a snapshot it does not have.)
+                if (!two) ddc_chain<DDC_NKW>(A, Bf, lo_lane, acc, snap);               // (snap untouched and unused)
+                else {
+#pragma unroll
+                    for (int l = 0; l < 3; l++) snap[l] = v4i{0, 0, 0, 0};
+                    switch (kb) {
+                        case 0: ddc_chain<0>(A, Bf, lo_lane, acc, snap); break;
+                        case 1: ddc_chain<1>(A, Bf, lo_lane, acc, snap); break;
+                        case 2: ddc_chain<2>(A, Bf, lo_lane, acc, snap); break;
+                        case 3: ddc_chain<3>(A, Bf, lo_lane, acc, snap); break;
+                        case 4: ddc_chain<(4 < DDC_NKW ? 4 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                        case 5: ddc_chain<(5 < DDC_NKW ? 5 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                        case 6: ddc_chain<(6 < DDC_NKW ? 6 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                        case 7: ddc_chain<(7 < DDC_NKW ? 7 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                        default: ddc_chain<(8 < DDC_NKW ? 8 : DDC_NKW)>(A, Bf, lo_lane, acc, snap); break;
+                    }
                 }
             }
             // ---- this wave's share of rows 4q .. 4q+3 = (Re, Im) of outputs 2q and 2q+1, after the post factors
