@@ -85,7 +85,7 @@ def other_configs():
     return out
 
 
-def operating_points(ctx, taps, verify=True):
+def operating_points(ctx, taps, verify=True, only=None):
     """The same chain object at the blocks a live receiver bank hands over (the reference's loop moves 16384 samples per read, csdr.c:189-193, 330-392): many streams,
     short blocks.  One step = one call over all streams; state carried; inputs resident in HBM."""
     import torch
@@ -94,7 +94,9 @@ def operating_points(ctx, taps, verify=True):
     import numpy as np
     if verify and os.path.join(ROOT, "tests") not in sys.path:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-    for S, T, steps, per_stream in ((1024, 2344 * 1024, 100, True), (1024, 16384, 400, False), (65536, 24576, 60, False)):
+    for i_pt, (S, T, steps, per_stream) in enumerate(((1024, 2344 * 1024, 100, True), (1024, 16384, 400, False), (65536, 24576, 60, False))):
+        if only is not None and i_pt not in only:
+            continue
         pitch = 2 * T
         x = torch.randint(0, 256, (S, pitch), dtype=torch.uint8, device="cuda")
         na_max = (T // 50 + 64 + 63) // 64 * 64

@@ -19,19 +19,25 @@ namespace {
 // Otherwise entries 0 and 1 are the old table's idx and idx + 1 (the history chunk and the first chunk of the call: both were advanced under the rate that was
 // valid then), everything behind advances by the current rate.
 template <bool RAISED>
-__global__ __launch_bounds__(64) void k_seed_phases(const float *__restrict__ rates, const float *__restrict__ old_ph, long idx, float *__restrict__ ph, size_t pitch, int cap, int n_streams)
+__global__ __launch_bounds__(1024) void k_seed_phases(const float *__restrict__ rates, const float *__restrict__ old_ph, long idx, float *__restrict__ ph, size_t pitch, int k0, int k1, int n_streams)
 {
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    // entries [k0, k1) of the new table (k0 == 2: the table's start, entries 0 and 1 included; a later slice continues from entry k0 - 1, which the slice in front of it
+    // on the same stream has written)
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_streams) return;
     const float inc = (rates[s] * 2) * PI_F;                          // shift_addition_init libcsdr_gpl.c:83-86 (as ddc_mfma.hip / wfm.hip)
     const float step = inc * (float)1024;
-    float p0 = 0.f, p1 = 0.f;
-    if (old_ph) { p0 = old_ph[(size_t)idx * pitch + s]; p1 = old_ph[(size_t)(idx + 1) * pitch + s]; }
-    ph[s] = p0; ph[pitch + s] = p1;
+    float p;
+    if (k0 == 2) {
+        float p0 = 0.f, p1 = 0.f;
+        if (old_ph) { p0 = old_ph[(size_t)idx * pitch + s]; p1 = old_ph[(size_t)(idx + 1) * pitch + s]; }
+        ph[s] = p0; ph[pitch + s] = p1;
+        p = p1;
+    } else
+        p = ph[(size_t)(k0 - 1) * pitch + s];
     WrapPlan w; wrap_plan_init(w, step);
     if (RAISED) __builtin_amdgcn_s_setprio(3);                        // eight waves beside the data kernels' thousands: a chain of dependent operations, let it issue
-    float p = p1;
-    for (int k = 2; k < cap; k++) {
+    for (int k = k0; k < k1; k++) {
         p = wrap_plan_apply(w, p + step);                             // libcsdr_gpl.c:48-51, exactly (seeds.hpp)
         ph[(size_t)k * pitch + s] = p;
     }
@@ -122,9 +128,19 @@ int generate(SeedTables *t, int dst, int src, long idx, long long first)
     // TIMING EXPERIMENT ONLY (wrong seeds from the second table on): what the generator's side-stream work costs the data kernels = the ceiling of any speed-up of it
     static const bool freeze = getenv("CSDR_AMD_SEED_FREEZE") != nullptr;
     if (freeze && src >= 0) { CSDR_HIP(hipEventRecord(t->ev_ready[dst], ss)); t->first[dst] = first; t->valid[dst] = true; return 0; }
-    if (!raised) hipLaunchKernelGGL(k_seed_phases<false>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
-    else
-    hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, t->cap, t->n);
+    // lanes per workgroup: a wave of this kernel is a chain of dependent operations that occupies its SIMD for the whole table (milliseconds), and a CU that holds one
+    // cannot take a workgroup of the per-stream WFM kernel (2 x 256 registers per SIMD).  64 = a wave per CU on sixteen CUs; 512 = two waves per SIMD on two CUs.
+    static const int blk = [] { const char *e = getenv("CSDR_AMD_SEED_BLOCK"); const int v = e ? atoi(e) : 64; return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 64; }();
+    // slices: the table in `slices` launches of cap / slices entries each, in order on the side stream -- between two of them the CU is free again (see the sweep in
+    // profiles/r5_notes.md: a resident generator wave keeps a whole CU away from the per-stream WFM kernel, whose 1024 workgroups are exactly four rounds on 256 CUs)
+    static const int slices = [] { const char *e = getenv("CSDR_AMD_SEED_SLICES"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4096 ? v : 1; }();
+    const int per = (t->cap - 2 + slices - 1) / slices;
+    for (int k0 = 2; k0 < t->cap || k0 == 2; k0 += per > 0 ? per : 1) {
+        const int k1 = k0 + per < t->cap ? k0 + per : t->cap;
+        if (!raised) hipLaunchKernelGGL(k_seed_phases<false>, dim3(cdiv(t->n, blk)), dim3(blk), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, k0, k1, t->n);
+        else hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, blk)), dim3(blk), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, k0, k1, t->n);
+        if (per <= 0) break;
+    }
     CSDR_LAUNCH_CHECK();
     const size_t count = t->pitch * (size_t)t->cap;
     hipLaunchKernelGGL(k_seed_cossin, dim3(cdiv(count, 256)), dim3(256), 0, ss, t->d_ph[dst], t->d_c[dst], count);

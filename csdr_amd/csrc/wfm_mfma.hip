@@ -815,6 +815,7 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
         while ((4 * tpp) % SEQ_LINE) tpp *= 2;
         const int n_per = (sp.n_tiles + tpp - 1) / tpp;
         int n_ss = (4 * n_cu + n_streams - 1) / n_streams; if (n_ss < 1) n_ss = 1;
+        { static const int split = getenv("CSDR_AMD_WFM_PS_SPLIT") ? atoi(getenv("CSDR_AMD_WFM_PS_SPLIT")) : 1; if (split > 1) n_ss *= split; }      // (experiment: shorter columns)
         int np = (n_per + 16 * n_ss - 1) / (16 * n_ss); if (np < 1) np = 1;
         sp.tiles_per_seg = np * tpp;
         sp.n_cols = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
