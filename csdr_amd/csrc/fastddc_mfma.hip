@@ -51,7 +51,7 @@ struct DdcMfma {
     cf32 *d_Xt[2]; float2 *d_R[2]; int *d_blk_remain[2], *d_blk_off[2], *d_counts[2]; float *d_blk_phase[2];
     int pending_blocks[2]; int fill, drain;                            // set being filled next / folded next
     bool inline_set[2], chains_on_side[2];
-    bool gemm_three = false;
+    bool gemm_three = false, gemm_narrow = false;
     bool y_holds[2] = {false, false};                                  // set k's spectra are still pass-1 output in d_Y (the fold runs pass 2 itself)
     // the NEXT call's chain tables, computed one call ahead by riders of the inverse-transform kernel (data independent; valid for process() calls of equal size
     // with no retune in between).  On the side stream beside the fold they cost more than they hid: 0.182 vs 0.167 ms per step.
@@ -373,6 +373,92 @@ __global__ __launch_bounds__(512, 2) void k_ddc_gemm3(const float *__restrict__ 
         r = rn; cur ^= 1;
     }
     store_bins(r_prev);
+}
+
+// k_ddc_gemm3n: the same product for FEW channel rows -- a bank of up to 128 channels, or one rank's slice of a channel-sharded bank (32 of 256 at eight ranks).
+// k_ddc_gemm3 gives each of its eight waves 32 channels and lets all of them share the staged spectra: with 32 channels seven waves multiply a copy nobody stores, and
+// the rank's fold costs what the whole bank's does (75 us; the emulated channel-shard scaling of 1.3 x at eight ranks).  Here a workgroup is NW = channels / 32 waves
+// (1, 2 or 4) x ONE residue x 32 blocks: 33 KiB of LDS, no second buffer, nothing persistent -- four workgroups per CU overlap one another's staging, products and
+// bin stores, and 512 residues x (blocks / 32) workgroups fill the chip by themselves.  Operand layouts, the three-product form, the taps fetches by hand and the bin
+// stores are k_ddc_gemm3's (non-FWD: the spectra are complete, the forward transform's second pass runs as its own kernel).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_ddc_gemm3n(const float *__restrict__ Ht, const float2 *__restrict__ Xt, float2 *__restrict__ Ct,
+                                                        const ChanGeom *__restrict__ geom, int inv, int Cpad, int n_channels, int nbp, int nbl, int n_blocks, float scale)
+{
+    extern __shared__ float4 xs_all[];                              // [32 rows][65] float4
+    constexpr int PRE = 128, G = PRE / 4, P4 = PRE / 2 + 1, ROWS = 32, RPW = ROWS / NW, AD = 8;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = blockIdx.x;
+    const int c_base = ((int)blockIdx.y * NW + wave) * 32, b_base = blockIdx.z * ROWS;
+    const int i = lane & 31, hi = lane >> 5;
+    const size_t gstride = (size_t)Cpad * 2;                          // float4 per k-group
+    const bool active = c_base < Cpad;
+    const int c_eff = min(c_base, Cpad - 32);                         // (a wave past the last channel tile multiplies a copy nobody stores)
+    const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t *)xs_all;
+    typedef float g3_v4f __attribute__((ext_vector_type(4)));
+    auto taps_fetch = [&](g3_v4f &dst, const float4 *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); };
+    const float4 *ap = reinterpret_cast<const float4 *>(Ht) + ((size_t)r * G * Cpad + c_eff + i) * 2 + hi;
+    g3_v4f a[AD];
+#pragma unroll
+    for (int d = 0; d < AD; d++) taps_fetch(a[d], ap + (size_t)d * gstride);
+    // rows wave * RPW .. + RPW - 1 of the residue: one 1-KiB piece per row (blocks past the end re-read the last one: their columns are never stored)
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int row = wave * RPW + k, b = min(b_base + row, n_blocks - 1);
+        const float2 *src = Xt + (((size_t)(b / nbl) * inv + r) * nbl + (b % nbl)) * PRE + 2 * lane;      // 16 bytes per lane
+        const uint32_t la = __builtin_amdgcn_readfirstlane((int)(lds_base + (uint32_t)row * P4 * 16u));
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(la) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's rows (and its first taps) have landed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (NW > 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[p][e] = 0.f;
+    const float4 *xrow = xs_all + i * P4 + hi;
+    float4 xn = xrow[0];                                              // the spectra operand of k-group GG + 1 is read from LDS while group GG multiplies
+#define DDC_STEP3N(AV, GG)                                                                                                 \
+    {                                                                                                                      \
+        const float hs0 = (AV).x + (AV).y, hs1 = (AV).z + (AV).w;                                                          \
+        const float4 xv = xn; xn = xrow[2 * min((GG) + 1, G - 1)];                                                         \
+        const float xs0 = xv.x + xv.y, xs1 = xv.z + xv.w;                                                                  \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, xv.x, acc[0], 0, 0, 0);                                      \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).y, xv.y, acc[1], 0, 0, 0);                                      \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hs0, xs0, acc[2], 0, 0, 0);                                          \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).z, xv.z, acc[0], 0, 0, 0);                                      \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, xv.w, acc[1], 0, 0, 0);                                      \
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(hs1, xs1, acc[2], 0, 0, 0);                                          \
+    }
+    static_assert(G % AD == 0 && G >= 2 * AD, "k loop");
+#pragma unroll
+    for (int g = 0; g < G - AD; g += AD) {
+#pragma unroll
+        for (int d = 0; d < AD; d++) { G3_TAPS_READY(a[d], AD - 1); const g3_v4f av = a[d]; taps_fetch(a[d], ap + (size_t)(g + AD + d) * gstride); DDC_STEP3N(av, g + d); }
+    }
+#define G3N_LAST(D) { G3_TAPS_READY(a[D], AD - 1 - (D)); const g3_v4f av = a[D]; DDC_STEP3N(av, G - AD + (D)); }      /* the last AD groups: nothing new is fetched */
+    G3N_LAST(0) G3N_LAST(1) G3N_LAST(2) G3N_LAST(3) G3N_LAST(4) G3N_LAST(5) G3N_LAST(6) G3N_LAST(7)
+#undef G3N_LAST
+#undef DDC_STEP3N
+    if (!active) return;
+    // C / D layout of the 32 x 32 tile: column = lane & 31 (block), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel)
+    int mm[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int c = min(c_base + (e & 3) + 8 * (e >> 2) + 4 * hi, n_channels - 1);
+        mm[e] = (r - geom[c].offsetbin) & (inv - 1);                  // inv is 512 here (a power of two)
+    }
+    if (b_base + i >= n_blocks) return;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int c = c_base + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        if (c >= n_channels) continue;
+        const float p1 = acc[0][e], p2 = acc[1][e], p3 = acc[2][e];
+        Ct[((size_t)mm[e] * Cpad + c) * nbp + b_base + i] = make_float2((p1 - p2) * scale, (p3 - p1 - p2) * scale);
+    }
 }
 #undef G3_TAPS_READY
 
@@ -1016,6 +1102,13 @@ static bool ddc_folds_with_gemm3(const DdcMfma *m, int n_blocks)
     return persist && m->pre == 128 && m->opt.gemm != 3;
 }
 
+// few channel rows (a small bank, a rank's slice of a channel-sharded one): k_ddc_gemm3n; CSDR_AMD_DDC_NARROW=0 keeps the eight-wave kernel
+static bool ddc_fold_is_narrow(const DdcMfma *m, int n_blocks)
+{
+    static const bool off = getenv("CSDR_AMD_DDC_NARROW") && atoi(getenv("CSDR_AMD_DDC_NARROW")) == 0;
+    return !off && m->Cpad <= 128 && (m->inv & (m->inv - 1)) == 0 && ddc_folds_with_gemm3(m, n_blocks);
+}
+
 // Stage one call: `in` = n_blocks x input_size NEW wideband samples (on rank 0 of a sharded bank; ignored elsewhere), or `spectra` = the natural
 // [n_blocks][fft] spectra of csdr fastddc_fwd_cc (single GPU only).  Runs on the side stream: chains, [scatter of the input windows by blocks -> local
 // forward transforms -> all-gather of the transposed spectra], into the set that collect() folds next.  At most two calls may be staged.
@@ -1070,7 +1163,7 @@ int ddc_mfma_submit(DdcMfma *m, const void *in_v, const cf32 *spectra, int n_blo
             DdcChainJob job = mfma_chain_job(m, k, n_blocks, d_state, d_geom);
             if (spec_hit) { job.mode = 2; job.state_out = m->d_state_spec; }
             const bool fuse2_off = m->opt.pass2_own;                              // CSDR_AMD_DDC_PASS2: k_ddc_fwd128 stays a kernel of its own
-            const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
+            const bool skip2 = inl && !fuse2_off && ddc_folds_with_gemm3(m, n_blocks) && !ddc_fold_is_narrow(m, n_blocks);      // the fold runs pass 2 itself (d_Y is this call's until its collect())
             // ext_tail: the overlap in front of the first window comes from the caller (a time-sliced bank: the stream before this rank's run is another rank's)
             if (tail_in_front) rc = mfma_forward(m, st, in, fmt, nullptr, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
             else if (ext_tail) rc = mfma_forward(m, st, in, fmt, ext_tail, nullptr, n_blocks, m->d_Xt[k], ride ? &job : nullptr, skip2);
@@ -1108,7 +1201,7 @@ int ddc_mfma_submit(DdcMfma *m, const void *in_v, const cf32 *spectra, int n_blo
     return 0;
 }
 
-const char *ddc_mfma_kernel_name(const DdcMfma *m) { return m->gemm_three ? "k_ddc_gemm3" : "k_ddc_gemm"; }
+const char *ddc_mfma_kernel_name(const DdcMfma *m) { return m->gemm_three ? (m->gemm_narrow ? "k_ddc_gemm3n" : "k_ddc_gemm3") : "k_ddc_gemm"; }
 int ddc_mfma_set_profiling(DdcMfma *m, int on) { m->profiling = on != 0; m->ev_used = 0; m->prof_ms = 0; m->prof_launches = 0; return 0; }
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches)
 {
@@ -1158,7 +1251,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
                            reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); } while (0)
     // three-product form with LDS-DMA staging: pre_decimation 128 (a spectra row = one 1-KiB piece), persistent shape; CSDR_AMD_DDC_GEMM=persist4 keeps the four-product kernel
     const bool three = ddc_folds_with_gemm3(m, n_blocks);
-    m->gemm_three = three;
+    m->gemm_three = three; m->gemm_narrow = false;
     if (three) {
         // the second pass of the forward transform inside the fold: one GPU, process() (pass 1's output Y belongs to this call), submit() skipped k_ddc_fwd128
         const bool fwd = m->y_holds[k];
@@ -1166,7 +1259,16 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
 #define DDC_GEMM3_LAUNCH(NBTV, FV) do { const int rc = lds_attr_once((const void *)k_ddc_gemm3<NBTV, FV>, lds_use); if (rc) return rc;                     \
         hipLaunchKernelGGL((k_ddc_gemm3<NBTV, FV>), grid_use, dim3(512), lds_use, st, m->d_Ht, src, reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->Cpad, m->C,  \
                            m->nbp, m->nbl, n_blocks, scale, m->d_tw); } while (0)
-        if (nbt == 2) { if (fwd) DDC_GEMM3_LAUNCH(2, true); else DDC_GEMM3_LAUNCH(2, false); }
+        m->gemm_narrow = !fwd && ddc_fold_is_narrow(m, n_blocks);
+        if (m->gemm_narrow) {
+            const dim3 gn(m->inv, 1, cdiv(n_blocks, 32));
+            const size_t ldsn = (size_t)32 * (m->pre / 2 + 1) * sizeof(float4);
+#define DDC_GEMM3N_LAUNCH(NWV) hipLaunchKernelGGL((k_ddc_gemm3n<NWV>), gn, dim3(64 * NWV), ldsn, st, m->d_Ht, src, reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->Cpad, m->C, \
+                                                  m->nbp, m->nbl, n_blocks, scale)
+            if (m->Cpad <= 32) DDC_GEMM3N_LAUNCH(1); else if (m->Cpad <= 64) DDC_GEMM3N_LAUNCH(2); else DDC_GEMM3N_LAUNCH(4);
+#undef DDC_GEMM3N_LAUNCH
+        }
+        else if (nbt == 2) { if (fwd) DDC_GEMM3_LAUNCH(2, true); else DDC_GEMM3_LAUNCH(2, false); }
         else          { if (fwd) DDC_GEMM3_LAUNCH(1, true); else DDC_GEMM3_LAUNCH(1, false); }
 #undef DDC_GEMM3_LAUNCH
     }

@@ -86,7 +86,7 @@ def test_c4_bank_fused_forward(gpu, port):
     x = (rng.uniform(-1, 1, ddc.input_size * nb + 100) + 1j * rng.uniform(-1, 1, ddc.input_size * nb + 100)).astype(c64)
     rates = np.concatenate([vc.c4_rates(256)[3::8][:32], np.array([0.0, -0.2222, 0.3711, 0.125, 0.4999], f32)])
     outs = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=40, retune=(1, 35, 0.0517))
-    assert gpu.last_ddc_kernel in ("k_ddc_gemm", "k_ddc_gemm3")
+    assert gpu.last_ddc_kernel in ("k_ddc_gemm", "k_ddc_gemm3", "k_ddc_gemm3n")          # (37 channels: the fold of few channel rows since round 5)
     pspec, want = vc.fastddc_oracle_channels(x, tbw, D, rates, [c for c in range(nch) if c != 35])
     for c, w in want.items():
         assert outs[c].size == w.size, "channel %d" % c
@@ -629,6 +629,23 @@ def test_c4_bank_at_the_timed_size(gpu, port):
     assert gpu.last_ddc_kernel == "k_ddc_gemm3" and len(check) >= 36
     for c in check:
         assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < TOL, "channel %d" % c
+
+
+@pytest.mark.parametrize("nch,nb", [(32, 64), (5, 64), (33, 40), (64, 64), (100, 7), (128, 96)])
+def test_c4_bank_of_few_channels(gpu, port, nch, nb):
+    """config 4's geometry with few channels -- a small bank, or what one rank of a channel-sharded bank folds (32 of 256 at eight ranks): the fold kernel of one /
+    two / four waves per residue and 32 blocks (k_ddc_gemm3n), ragged channel and block tiles, every channel against the oracle"""
+    tbw, D = 0.001, 256
+    ddc, _ = gpu.fastddc_init(tbw, D, 0.0)
+    rng = np.random.default_rng(1000 * nch + nb)
+    x = (rng.uniform(-1, 1, ddc.input_size * nb) + 1j * rng.uniform(-1, 1, ddc.input_size * nb)).astype(c64)
+    rates = vc.c4_rates(256)[rng.permutation(256)[:nch]]
+    check = list(range(nch)) if nch <= 40 else sorted(set(list(range(0, nch, 5)) + [1, 31, 32, 33, 63, 64, 65, nch - 2, nch - 1]) & set(range(nch)))
+    _, want = vc.fastddc_oracle_channels(x, tbw, D, rates, check)
+    outs = gpu.fastddc_bank(x, tbw, D, rates, blocks_per_call=nb)
+    assert gpu.last_ddc_kernel == "k_ddc_gemm3n"
+    for c in check:
+        assert outs[c].size == want[c].size and vc.relrms(outs[c], want[c]) < TOL, "channel %d of %d" % (c, nch)
 
 
 class _Plan(C.Structure):        # fft_fftw.h:14-20
