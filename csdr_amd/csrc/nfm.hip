@@ -68,7 +68,11 @@ __global__ __launch_bounds__(64) void k_nfm_demod_boundary(const cf32 *__restric
 // planes, 0.16 ms); the 12 weight fragments (4 K-steps x 3 digits of the Toeplitz band) stay in registers; each wave takes every fourth tile.
 // MFMA result layout: lane (col, q) holds outputs 4q .. 4q+3 of channel col.
 constexpr int NFM_FIR_SPAN = 64;                                   // tiles per workgroup (1024 outputs)
-constexpr int NFM_FIR_ROW = 16 * NFM_FIR_SPAN + 64 * NFM_FIR_NK;   // staged bytes per channel and plane (1280)
+#ifndef NFM_FIR_SUB_N
+#define NFM_FIR_SUB_N 32
+#endif
+constexpr int NFM_FIR_SUB = NFM_FIR_SUB_N;                         // tiles staged at a time: the span in SPAN / SUB passes (64: 61 KiB of LDS, two workgroups per CU; 32: 37 KiB, four)
+constexpr int NFM_FIR_ROW = 16 * NFM_FIR_SUB + 64 * NFM_FIR_NK;    // staged bytes per channel and plane
 constexpr int NFM_FIR_RP = NFM_FIR_ROW + 16;                       // LDS pitch: odd multiple of 16 bytes (the 16 channels of a B read hit different banks)
 
 // peaks != nullptr (fastagc block = the workgroup's span of 1024 outputs): the workgroup also leaves max |out| of its span per channel at
@@ -83,49 +87,53 @@ __global__ __launch_bounds__(256) void k_nfm_deemph_mfma(const int8_t *__restric
     v4i A[NFM_FIR_NK * 3];
 #pragma unroll
     for (int i = 0; i < NFM_FIR_NK * 3; i++) A[i] = frags[i * 64 + lane];
-    const int tile0 = blockIdx.x * NFM_FIR_SPAN;
-    const int nt = min(NFM_FIR_SPAN, n_tiles - tile0);
-    // stage [3 planes][16 channels][NFM_FIR_ROW] (rows of channels past the last one re-read it; bytes behind the valid samples meet zero weights)
     const int last = n_streams - 1;
-    for (int i = tid; i < 3 * 16 * (NFM_FIR_ROW / 16); i += 256) {
-        const int piece = i % (NFM_FIR_ROW / 16), r = (i / (NFM_FIR_ROW / 16)) % 16, pl = i / (16 * (NFM_FIR_ROW / 16));
-        const int stream = min((int)blockIdx.y * 16 + r, last);
-        *reinterpret_cast<v4i *>(lds + (pl * 16 + r) * NFM_FIR_RP + 16 * piece) =
-            *reinterpret_cast<const v4i *>(planes + (size_t)pl * plane_bytes + (size_t)stream * dl_pitch + (size_t)tile0 * 16 + 16 * piece);
-    }
-    __syncthreads();
     const int stream = (int)blockIdx.y * 16 + col;
     const int8_t *row = lds + col * NFM_FIR_RP + 16 * q;
     float pmax = 0.f;
-    for (int t = wv; t < nt; t += 4) {
-        const int8_t *src = row + 16 * t;
-        v4i acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-        for (int ks = 0; ks < NFM_FIR_NK; ks++) {
-            const v4i x0 = *reinterpret_cast<const v4i *>(src + 64 * ks), x1 = *reinterpret_cast<const v4i *>(src + 64 * ks + 16 * NFM_FIR_RP),
-                      x2 = *reinterpret_cast<const v4i *>(src + 64 * ks + 32 * NFM_FIR_RP);
-            const v4i w0 = A[ks * 3], w1 = A[ks * 3 + 1], w2 = A[ks * 3 + 2];
-            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x0, acc[0], 0, 0, 0);          // 2^32
-            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x1, acc[1], 0, 0, 0);          // 2^24
-            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x0, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x2, acc[2], 0, 0, 0);          // 2^16
-            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x1, acc[2], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, x0, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x2, acc[3], 0, 0, 0);          // 2^8
-            acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, x1, acc[3], 0, 0, 0);
+    for (int sub = 0; sub < NFM_FIR_SPAN / NFM_FIR_SUB; sub++) {
+        const int tile0 = blockIdx.x * NFM_FIR_SPAN + sub * NFM_FIR_SUB;
+        const int nt = min(NFM_FIR_SUB, n_tiles - tile0);
+        if (nt <= 0) break;                                           // (uniform)
+        if (sub) __syncthreads();                                     // everyone has read the previous pass's rows
+        // stage [3 planes][16 channels][NFM_FIR_ROW] (rows of channels past the last one re-read it; bytes behind the valid samples meet zero weights)
+        for (int i = tid; i < 3 * 16 * (NFM_FIR_ROW / 16); i += 256) {
+            const int piece = i % (NFM_FIR_ROW / 16), r = (i / (NFM_FIR_ROW / 16)) % 16, pl = i / (16 * (NFM_FIR_ROW / 16));
+            const int st = min((int)blockIdx.y * 16 + r, last);
+            *reinterpret_cast<v4i *>(lds + (pl * 16 + r) * NFM_FIR_RP + 16 * piece) =
+                *reinterpret_cast<const v4i *>(planes + (size_t)pl * plane_bytes + (size_t)st * dl_pitch + (size_t)tile0 * 16 + 16 * piece);
         }
-        float4 r;
-        float *rv = reinterpret_cast<float *>(&r);
+        __syncthreads();
+        for (int t = wv; t < nt; t += 4) {
+            const int8_t *src = row + 16 * t;
+            v4i acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float v = fmaf((float)acc[0][j], 256.0f, (float)acc[1][j]);
-            v = fmaf(v, 256.0f, (float)acc[2][j]);
-            v = fmaf(v, 256.0f, (float)acc[3][j]);
-            rv[j] = v * scale;
+            for (int ks = 0; ks < NFM_FIR_NK; ks++) {
+                const v4i x0 = *reinterpret_cast<const v4i *>(src + 64 * ks), x1 = *reinterpret_cast<const v4i *>(src + 64 * ks + 16 * NFM_FIR_RP),
+                          x2 = *reinterpret_cast<const v4i *>(src + 64 * ks + 32 * NFM_FIR_RP);
+                const v4i w0 = A[ks * 3], w1 = A[ks * 3 + 1], w2 = A[ks * 3 + 2];
+                acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x0, acc[0], 0, 0, 0);          // 2^32
+                acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x1, acc[1], 0, 0, 0);          // 2^24
+                acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x0, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w0, x2, acc[2], 0, 0, 0);          // 2^16
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x1, acc[2], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, x0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w1, x2, acc[3], 0, 0, 0);          // 2^8
+                acc[3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(w2, x1, acc[3], 0, 0, 0);
+            }
+            float4 r;
+            float *rv = reinterpret_cast<float *>(&r);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float v = fmaf((float)acc[0][j], 256.0f, (float)acc[1][j]);
+                v = fmaf(v, 256.0f, (float)acc[2][j]);
+                v = fmaf(v, 256.0f, (float)acc[3][j]);
+                rv[j] = v * scale;
+            }
+            if (stream < n_streams)
+                *reinterpret_cast<float4 *>(out + (size_t)stream * out_pitch + 16 * (size_t)(tile0 + t) + 4 * q) = r;
+            pmax = fmaxf(fmaxf(pmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
-        if (stream < n_streams)
-            *reinterpret_cast<float4 *>(out + (size_t)stream * out_pitch + 16 * (size_t)(tile0 + t) + 4 * q) = r;
-        pmax = fmaxf(fmaxf(pmax, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
     if (peaks) {                                                      // uniform
         pmax = fmaxf(pmax, __shfl_xor(pmax, 16)); pmax = fmaxf(pmax, __shfl_xor(pmax, 32));      // over q: the channel's outputs of this wave's tiles
