@@ -238,6 +238,7 @@ constexpr int SEQ_HEAD = 1024;             // bytes of the per-stream head (one 
 #ifdef WFM_PROF
 // diagnostic build (tools/diag_wfm.sh): shader-clock cycles per wave summed over the launch: [wave][compute, wait vmcnt, barrier, DMA issue, emit, de-emphasis, steps]
 __device__ unsigned long long g_wfm_prof[SEQ_NW][8];
+__device__ unsigned long long g_wfm_life[SEQ_NW][4];      // per wave, summed over workgroups: cycles from kernel entry to the first step, inside the step loop, behind it; workgroups
 #define PROF_T(k) { const long long t_now = __builtin_readcyclecounter(); prof[k] += t_now - t_prev; t_prev = t_now; }
 #else
 #define PROF_T(k)
@@ -261,6 +262,10 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     float2 *ctl = reinterpret_cast<float2 *>(lcum + (SEQ_NGR + 1) * 16);          // PS: [2][3][16] chunk seeds of a step (class, column)
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     const bool fetches = wv >= TPG;
+#ifdef WFM_PROF
+    const long long t_entry = __builtin_readcyclecounter();
+    long long t_first = t_entry, t_last = t_entry;
+#endif
     const int fw = wv - TPG;                                                         // index among the fetching waves
     const int sb = blockIdx.x;                                                       // block of 16 streams; PS: the stream
     const int col0 = PS ? 16 * (int)blockIdx.y : 0;                                  // PS: absolute index of the workgroup's first column
@@ -538,6 +543,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             }
         };
         PROF_T(7)
+#ifdef WFM_PROF
+        t_first = __builtin_readcyclecounter();
+#endif
+        // (Round 5, measured and dropped: a dozen steps before its end a workgroup touched the head and first 2 KiB per stream of workgroup id + 256 -- the one that runs
+        // next on this XCD -- so that its first windows would wait in L2: 6.8 us pass between kernel entry and the first step (tools/diag_wfm_life.py), a sixth of a
+        // workgroup's life at 65536 x 24576.  65536 x 24576: 0.674 -> 0.697 ms (0.685 with the touches switched off: the code alone cost 1.6 %).)
         for (int gi = -n_warm; gi < n_grp; gi++) {
             PROF_T(0)
             const long long wg_n = wg + (long long)TPG * tstride;
@@ -556,6 +567,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         }
 #ifdef WFM_PROF
         if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
+        t_last = __builtin_readcyclecounter();
 #endif
         __syncthreads();
         if (WFM_DIAG < 4) { take_line(n_grp - 1); take_line(n_grp); flush(); }
@@ -563,6 +575,9 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     } else {
     // ============================================================================ the compute waves
     PROF_T(7)
+#ifdef WFM_PROF
+    t_first = __builtin_readcyclecounter();
+#endif
     for (int gi = -n_warm; gi < n_grp; gi++) {
         const int it = gi * TPG + wv;
         float *lout = lds_out + ((gi + SEQ_OUTS) % SEQ_OUTS) * SPS;                   // this step's samples in every stream's ring
@@ -693,6 +708,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     }
 #ifdef WFM_PROF
     if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_wfm_prof[wv][k], (unsigned long long)prof[k]);
+    t_last = __builtin_readcyclecounter();
 #endif
     __syncthreads();
     if (!emit_vec) emit_scalar(n_grp - 1);
@@ -713,6 +729,14 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             *reinterpret_cast<uint4 *>(p.head_out + (size_t)(s0 + srow) * SEQ_HEAD + 512 + 16 * piece) = v;
         }
     }
+#ifdef WFM_PROF
+    if (lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // (the wave's stores have left)
+        const long long t_exit = __builtin_readcyclecounter();
+        atomicAdd(&g_wfm_life[wv][0], (unsigned long long)(t_first - t_entry)); atomicAdd(&g_wfm_life[wv][1], (unsigned long long)(t_last - t_first));
+        atomicAdd(&g_wfm_life[wv][2], (unsigned long long)(t_exit - t_last)); atomicAdd(&g_wfm_life[wv][3], 1ULL);
+    }
+#endif
 }
 
 // the history of a call that produced no audio (a block shorter than one tile's reach): the head buffers still have to roll
@@ -860,6 +884,12 @@ extern "C" int csdr_amd_debug_wfm_prof(unsigned long long *out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wfm_prof), sizeof(unsigned long long) * SEQ_NW * 8) != hipSuccess) return -1;
     if (reset) { static unsigned long long z[SEQ_NW * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wfm_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+extern "C" int csdr_amd_debug_wfm_life(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wfm_life), sizeof(unsigned long long) * SEQ_NW * 4) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[SEQ_NW * 4]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wfm_life), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #endif
