@@ -25,7 +25,7 @@ namespace csdr_amd {
 //     subtraction, the one rounded subtraction that leaves the group, and a select -- eight dependent operations instead of a loop.  Below 16 (ties occur there): at most three plain steps.
 // tests/test_abi_cpu.py runs the host build of this against the loop.
 struct WrapPlan {
-    float t1[5], t2[5], k0[5], k1[5], k2[5];      // k1 = k0 + c_e, k2 = k1 + c_e (exact)
+    float t1[5], t2[5], k0[5];
 };
 
 __host__ __device__ inline void wrap_plan_init(WrapPlan &w, float step)
@@ -44,8 +44,8 @@ __host__ __device__ inline void wrap_plan_init(WrapPlan &w, float step)
         while (lop + (n0 + 1) * ce[i] <= amin) n0 += 1;
         while (n0 > 0 && lop + n0 * ce[i] > amin) n0 -= 1;
         w.t1[i] = (float)(lop + (n0 + 1) * ce[i]); w.t2[i] = (float)(lop + (n0 + 2) * ce[i]);      // exact: multiples of the grid below 2^(e+1)
-        w.k0[i] = (float)(n0 * ce[i]); w.k1[i] = w.k0[i] + (float)ce[i]; w.k2[i] = w.k1[i] + (float)ce[i];
-        if (hi <= lo[i]) { w.t1[i] = w.t2[i] = 8192.f; w.k0[i] = w.k1[i] = w.k2[i] = 0.f; }         // never entered
+        w.k0[i] = (float)(n0 * ce[i]);
+        if (hi <= lo[i]) { w.t1[i] = w.t2[i] = 8192.f; w.k0[i] = 0.f; }                             // never entered
     }
 }
 
@@ -54,20 +54,15 @@ __host__ __device__ inline float wrap_plan_apply(const WrapPlan &w, float x)
 {
     const float PI = (float)3.14159265358979323846, C2 = 2 * PI;
     float a = fabsf(x);
-    // Round 5: the three possible results of a group side by side, then picked -- the dependent chain of a group is subtraction, subtraction, two selects (the
-    // compares run beside the subtractions) instead of compare, select, two additions, two subtractions, select: the generator is one long chain of dependent
-    // operations per stream (~10 cycles each), nothing else.  (Selects between VALUES: a select between two array elements becomes a load through a selected address.)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define CSDR_WRAP_KEEP(v) asm volatile("" : "+v"(v))
-#else
-#define CSDR_WRAP_KEEP(v)
-#endif
+    // (sums, not selects between table entries: the compiler turns a select of two array elements into a load through a selected ADDRESS, and the plan into scratch
+    // memory -- one memory round trip per group.  Round 5, measured and dropped: the three possible results of a group side by side, then picked -- a dependent chain
+    // of 29 instead of 46 operations per chunk step, bit-exact on 48 M values (tools/probes/plan_check.c), but 74 instead of ~62 instructions: the generator is ONE wave
+    // per SIMD, every instruction of which occupies the SIMD for its four cycles whether it depends on the previous one or not -- k_seed_phases 1.59 -> 1.74 ms.)
 #define CSDR_WRAP_GROUP(I, LO, CE)                                                                                    \
     {                                                                                                                 \
-        float r0 = (a - w.k0[I]) - C2, r1 = (a - w.k1[I]) - C2, r2 = (a - w.k2[I]) - C2;   /* exact bulk (n0 + 0..2) c_e, then the (rounded) step that leaves the group */ \
-        CSDR_WRAP_KEEP(r1); CSDR_WRAP_KEEP(r2);              /* (or the compiler picks k first and computes one result: one more operation in the chain) */ \
-        const float hi2 = a >= w.t2[I] ? r2 : r1, lo2 = a >= LO ? r0 : a;                        /* (t2 > t1 > LO) */         \
-        a = a >= w.t1[I] ? hi2 : lo2;                                                                                 \
+        const float k = (w.k0[I] + (a >= w.t1[I] ? CE : 0.f)) + (a >= w.t2[I] ? CE : 0.f);   /* exact: (n0 + 0..2) c_e */ \
+        const float r = (a - k) - C2;                                 /* exact bulk, then the (rounded) step that leaves the group */ \
+        a = a >= LO ? r : a;                                                                                          \
     }
     CSDR_WRAP_GROUP(0, 512.f, 0x1.922p+2f)
     CSDR_WRAP_GROUP(1, 256.f, 0x1.921f8p+2f)
@@ -75,7 +70,6 @@ __host__ __device__ inline float wrap_plan_apply(const WrapPlan &w, float x)
     CSDR_WRAP_GROUP(3, 32.f, 0x1.921fbp+2f)
     CSDR_WRAP_GROUP(4, 16.f, 0x1.921fb8p+2f)
 #undef CSDR_WRAP_GROUP
-#undef CSDR_WRAP_KEEP
 #pragma unroll
     for (int i = 0; i < 3; i++) a = a > PI ? a - C2 : a;              // from below 16
     return x < 0 ? 0.0f - a : a;                                      // (-c + c is +0 in the loop as well)
