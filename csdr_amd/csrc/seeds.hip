@@ -102,6 +102,9 @@ struct csdr_amd::SeedTables {
     hipEvent_t ev_ready[2], ev_free[2]; bool free_pending[2];
     int cur;
     bool fresh, dirty;
+    // few streams (the CLI's one): the phase chain runs on the HOST (the same wrap_plan code, host build: ~25 ns per chunk step against ~130 ns for a lane of
+    // k_seed_phases, whose one wave leaves 63 lanes idle) into pinned shadows of the two tables, uploaded on the side stream
+    bool host_chain; float *h_ph[2]; bool h_used[2];
 };
 
 namespace {
@@ -124,6 +127,20 @@ int generate(SeedTables *t, int dst, int src, long idx, long long first)
 {
     hipStream_t ss = t->side;
     if (t->free_pending[dst]) { CSDR_HIP(hipStreamWaitEvent(ss, t->ev_free[dst], 0)); t->free_pending[dst] = false; }      // the data kernels that read it have finished
+    if (t->host_chain) {
+        if (t->h_used[dst]) CSDR_HIP(hipEventSynchronize(t->ev_ready[dst]));       // the previous upload out of this shadow has run (long ago)
+        float *h = t->h_ph[dst]; const float *o = src >= 0 ? t->h_ph[src] : nullptr;
+        for (int s = 0; s < t->n; s++) {
+            const float inc = (t->rates[s] * 2) * PI_F, step = inc * (float)1024;  // as k_seed_phases
+            const float p0 = o ? o[(size_t)idx * t->pitch + s] : 0.f, p1 = o ? o[(size_t)(idx + 1) * t->pitch + s] : 0.f;
+            h[s] = p0; h[t->pitch + s] = p1;
+            WrapPlan w; wrap_plan_init(w, step);
+            float p = p1;
+            for (int k = 2; k < t->cap; k++) { p = wrap_plan_apply(w, p + step); h[(size_t)k * t->pitch + s] = p; }
+        }
+        CSDR_HIP(hipMemcpyAsync(t->d_ph[dst], h, sizeof(float) * t->pitch * (size_t)t->cap, hipMemcpyHostToDevice, ss));
+        t->h_used[dst] = true;
+    }
     static const bool raised = !(getenv("CSDR_AMD_SEED_PRIO") && atoi(getenv("CSDR_AMD_SEED_PRIO")) == 0);      // (A/B, read once per process)
     // TIMING EXPERIMENT ONLY (wrong seeds from the second table on): what the generator's side-stream work costs the data kernels = the ceiling of any speed-up of it
     static const bool freeze = getenv("CSDR_AMD_SEED_FREEZE") != nullptr;
@@ -135,7 +152,7 @@ int generate(SeedTables *t, int dst, int src, long idx, long long first)
     // profiles/r5_notes.md: a resident generator wave keeps a whole CU away from the per-stream WFM kernel, whose 1024 workgroups are exactly four rounds on 256 CUs)
     static const int slices = [] { const char *e = getenv("CSDR_AMD_SEED_SLICES"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4096 ? v : 1; }();
     const int per = (t->cap - 2 + slices - 1) / slices;
-    for (int k0 = 2; k0 < t->cap || k0 == 2; k0 += per > 0 ? per : 1) {
+    for (int k0 = 2; !t->host_chain && (k0 < t->cap || k0 == 2); k0 += per > 0 ? per : 1) {
         const int k1 = k0 + per < t->cap ? k0 + per : t->cap;
         if (!raised) hipLaunchKernelGGL(k_seed_phases<false>, dim3(cdiv(t->n, blk)), dim3(blk), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, k0, k1, t->n);
         else hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, blk)), dim3(blk), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, k0, k1, t->n);
@@ -171,7 +188,13 @@ SeedTables *seeds_create(csdr_amd_ctx *ctx, int n_streams, const float *rates, c
     for (int b = 0; b < 2; b++) { t->d_ph[b] = nullptr; t->d_c[b] = nullptr; t->d_corr[b] = nullptr; t->ev_ready[b] = nullptr; t->ev_free[b] = nullptr; t->valid[b] = false; t->free_pending[b] = false; t->first[b] = 0; }
     t->rates.assign(rates, rates + n_streams); t->corr_row.assign(n_streams, -1);
     t->cur = 0; t->fresh = true; t->dirty = false;
+    t->h_ph[0] = t->h_ph[1] = nullptr; t->h_used[0] = t->h_used[1] = false;
+    { const char *eh = getenv("CSDR_AMD_SEED_HOST"); const int max_host = eh ? atoi(eh) : 2; t->host_chain = n_streams <= max_host; }      // (0: always the device chain)
     hipError_t e = hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
+    for (int b = 0; b < 2 && e == hipSuccess && t->host_chain; b++) {
+        e = hipHostMalloc((void **)&t->h_ph[b], sizeof(float) * t->pitch * t->cap, hipHostMallocDefault);
+        if (e == hipSuccess) memset(t->h_ph[b], 0, sizeof(float) * t->pitch * t->cap);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_rates, sizeof(float) * t->pitch);
     if (e == hipSuccess) e = hipMalloc((void **)&t->d_corr_row, sizeof(int) * t->pitch);
     for (int b = 0; b < 2 && e == hipSuccess; b++) {
@@ -199,6 +222,7 @@ void seeds_destroy(SeedTables *t)
         if (t->ev_free[b]) (void)hipEventDestroy(t->ev_free[b]);
     }
     (void)hipFree(t->d_rates); (void)hipFree(t->d_corr_row); (void)hipFree(t->d_row_stream);
+    for (int b = 0; b < 2; b++) if (t->h_ph[b]) (void)hipHostFree(t->h_ph[b]);
     if (t->side) (void)hipStreamDestroy(t->side);
     delete t;
 }
