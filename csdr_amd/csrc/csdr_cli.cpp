@@ -316,8 +316,12 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
         std::vector<float> t(79);
         const int nt = csdr_amd_firdes_filter_len(0.05f);
         t.resize(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.05f, CSDR_WINDOW_HAMMING);
-        // (with a control channel: the rate-per-stream object, whose one stream can be retuned between two calls)
-        w = with_ctl ? csdr_amd_wfm_create_rates(c, 1, &shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024) : csdr_amd_wfm_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024);
+        // The rate-per-stream object, always: its one stream can be retuned between two calls (control channel), and its kernel spreads ONE stream over the 16 columns of
+        // a tile (16 time segments) where the shared-rate kernel fills one of 16 -- a 4 M-sample block took the latter 0.41 ms, 10 GS/s before a byte was read
+        // (CSDR_AMD_CLI_TIMING, round 5).  CSDR_AMD_CLI_SHARED=1: the shared-rate object as before.
+        // Blocks under 1 Mi samples stay on the shared-rate object (256 Ki: 3.8 against 2.5 GS/s: per call the rate-per-stream object also looks its seeds up).
+        w = (with_ctl || (block >= (1u << 20) && !getenv("CSDR_AMD_CLI_SHARED"))) ? csdr_amd_wfm_create_rates(c, 1, &shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024)
+                                                         : csdr_amd_wfm_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, block + 1024);
         if (!w) die("wfm_create");
         if (csdr_amd_wfm_fallback(w)) fprintf(stderr, "csdr %s: note: this shape runs on the fallback kernels (k_wfm_front + k_wfm_back), not on the matrix-core chain kernel\n", g_cmd);
     }
@@ -359,7 +363,7 @@ struct NfmChain : Stage {   // the README.md:87 chain as ONE command (extension)
         in_elem = 2; out_elem = 2; granule = 1024;
         const int nt = csdr_amd_firdes_filter_len(tbw);
         std::vector<float> t(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.5f / (float)D, CSDR_WINDOW_HAMMING);
-        w = with_ctl ? csdr_amd_nfm_create_rates(c, 1, &shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024)
+        w = (with_ctl || (block >= (1u << 20) && !getenv("CSDR_AMD_CLI_SHARED"))) ? csdr_amd_nfm_create_rates(c, 1, &shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024)      // (as WfmChain)
                      : csdr_amd_nfm_create(c, 1, shift, D, t.data(), nt, 48000, 1024, 1.0f, 1.0f, block + 1024);      // fastagc_ff defaults csdr.c:1379-1391
         if (!w) die("nfm_create");
     }
@@ -1241,7 +1245,9 @@ int run_stream_bank(csdr_amd_ctx *c, int argc, char **argv, bool nfm)
     std::vector<float> rates;
     for (const char *q = argv[2]; *q;) { char *end = nullptr; const float v = strtof(q, &end); if (end == q) return badsyntax("shift_rate must be a number or a comma-separated list"); rates.push_back(v); q = *end == ',' ? end + 1 : end; if (*end && *end != ',') return badsyntax("shift_rate must be a number or a comma-separated list"); }
     if (rates.size() != 1 && (int)rates.size() != S) return badsyntax("as many shift rates as streams (or one for all)");
-    const bool per_stream = rates.size() > 1 || ctl_fd >= 0;
+    // (fewer than 16 streams: the rate-per-stream object also when they share one rate -- its kernel fills all 16 columns of a tile with time segments of ONE stream,
+    // the shared-rate kernel needs 16 streams to fill them)
+    const bool per_stream = rates.size() > 1 || ctl_fd >= 0 || (S < 16 && !getenv("CSDR_AMD_CLI_SHARED"));
     if (per_stream && rates.size() == 1) rates.assign(S, rates[0]);
     const float shift = rates[0];
     auto open_fd = [](const char *spec, int flags) { int fd = -1; if (!strncmp(spec, "fd:", 3)) sscanf(spec + 3, "%d", &fd); else fd = open(spec, flags, 0644); return fd; };

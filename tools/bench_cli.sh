@@ -17,11 +17,13 @@ ${CSDR_BIN:-csdr_amd/csdr} wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8 > /dev/null 2>
 LEGS=${LEGS:-fused chain pipe7 ref cat}     # which parts to run
 has() { case " $LEGS " in *" $1 "*) return 0;; esac; return 1; }
 WFM='convert_u8_f | shift_addition_cc -0.085 | fir_decimate_cc 10 0.05 HAMMING | fmdemod_quadri_cf | fractional_decimator_ff 5.5 | deemphasis_wfm_ff 48000 50e-6 | convert_f_s16'
-for b in 262144 1048576 4194304; do
+for rep in $(seq 1 ${REPS:-1}); do
+for b in ${BLOCKS:-262144 1048576 4194304}; do
   has fused || break
   export CSDR_AMD_BLOCK=$b
   ta=$(run sh -c '${CSDR_BIN:-csdr_amd/csdr} wfm_chain_u8_s16 -0.085 < /tmp/iq_a.u8'); tb=$(run sh -c '${CSDR_BIN:-csdr_amd/csdr} wfm_chain_u8_s16 -0.085 < /tmp/iq_b.u8')
   python -c "ta, tb = $ta, $tb; r = (1920e6 - 480e6) / (tb - ta); print('wfm_chain_u8_s16 block=$b: %.0f MS/s streaming, start-up %.2f s (480 M samples %.2f s, 1920 M samples %.2f s)' % (r / 1e6, ta - 480e6 / r, ta, tb))"
+done
 done
 export CSDR_AMD_BLOCK=4194304
 if has chain; then
@@ -31,7 +33,7 @@ fi
 # the LITERAL shell pipeline of README.md:66: seven processes of this csdr, adjacent ones handing blocks over in HBM (csdr_cli.cpp "device hand-off"), the same with
 # the hand-off switched off (bytes through every pipe: D2H + pipe + H2D per stage), and the reference's own binary (built by oracle/Makefile) on the same file
 PIPE7() { echo "$1 convert_u8_f < $2 | $1 shift_addition_cc -0.085 | $1 fir_decimate_cc 10 0.05 HAMMING | $1 fmdemod_quadri_cf | $1 fractional_decimator_ff 5 | $1 deemphasis_wfm_ff 48000 50e-6 | $1 convert_f_s16"; }
-for ipc in 1 0; do
+for ipc in ${IPCS:-1 0}; do
   has pipe7 || break
   export CSDR_AMD_IPC=$ipc
   ta=$(run timeout 120 sh -c "$(PIPE7 ${CSDR_BIN:-csdr_amd/csdr} /tmp/iq_a.u8)"); tb=$(run timeout 120 sh -c "$(PIPE7 ${CSDR_BIN:-csdr_amd/csdr} /tmp/iq_b.u8)")
