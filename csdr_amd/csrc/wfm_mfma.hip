@@ -406,8 +406,22 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     };
     if (ps_wave) {
         const long long step_b = (long long)TPG * tstride;
-        ps_load(wg); ps_store(-n_warm);
-        ps_load(wg + step_b); ps_store(-n_warm + 1);
+        // the first two steps' seeds in flight together (one after the other they cost the workgroup 3.7 us in front of its first step: tools/diag_wfm_life.py)
+        ps_v2f c0 = {1.f, 0.f}, c1 = {1.f, 0.f};
+        if (ps_lane) {
+            auto entry = [&](long long wgs) {
+                int ci = ps_base(wgs) + 1 + (lane >> 4) + (col0 + (lane & 15)) * p.col_chunks;
+                ci = min(max(ci, 0), p.tab_len - 1);
+                return ctab + (size_t)ci * p.tab_pitch;
+            };
+            const float2 *pa = entry(wg), *pb = entry(wg + step_b);
+            asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off" : "+v"(c0), "+v"(c1) : "v"(pa), "v"(pb) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(c0), "+v"(c1) :: "memory");
+        if (ps_lane) {                                                               // (n_warm = 2: steps -2 and -1 -> halves 0 and 1)
+            ctl[((-n_warm + 2) & 1) * 48 + lane] = make_float2(c0.x, c0.y);
+            ctl[((-n_warm + 1 + 2) & 1) * 48 + lane] = make_float2(c1.x, c1.y);
+        }
         ps_load(wg + 2 * step_b);                                                    // in flight: the third step
     }
     if (fetches) {
