@@ -291,6 +291,40 @@ def test_phase_chain_plan_is_the_reference_loop(libpath, port):
             assert out[k].view(np.uint32) == ph.view(np.uint32), (float(rate), k)
 
 
+def test_phase_chain_plan_on_two_million_values(libpath):
+    """The same plan against the loop on 2000 random rates x 1000 chunks (the loop vectorised over the rates in numpy float32; tools/probes/plan_check.c is the
+    48 M-value form of this check)."""
+    import numpy as np
+    fn = C.CDLL(libpath).csdr_amd_debug_phase_chain
+    fn.restype = None; fn.argtypes = [C.c_float, C.c_float, C.c_int, C.c_void_p]
+    pi = np.float32(3.14159265358979323846); two_pi = np.float32(2) * pi
+    rng = np.random.default_rng(11)
+    R, n = 2000, 1000
+    rates = rng.uniform(-0.5, 0.5, R).astype(np.float32)
+    rates[::97] = (np.array([16, 32, 64, 256, 512, 1024, 2048])[np.arange(len(rates[::97])) % 7] / (2 * np.pi * 1024)).astype(np.float32)      # binade edges of the step
+    ph0 = np.where(np.arange(R) % 2 == 1, rng.uniform(-3.14, 3.14, R), 0.0).astype(np.float32)
+    got = np.zeros((R, n), np.float32)
+    row = np.zeros(n, np.float32)
+    for i in range(R):
+        fn(float(rates[i]), float(ph0[i]), n, row.ctypes.data); got[i] = row
+    step = ((rates * np.float32(2)) * pi) * np.float32(1024)
+    assert step.dtype == np.float32
+    ph = ph0.copy()
+    for k in range(n):
+        x = (ph + step).astype(np.float32)
+        while True:                                                   # libcsdr_gpl.c:50-51, every subtraction rounded to float
+            hi = x > pi
+            if not hi.any(): break
+            x = np.where(hi, (x - two_pi).astype(np.float32), x)
+        while True:
+            lo = x < -pi
+            if not lo.any(): break
+            x = np.where(lo, (x + two_pi).astype(np.float32), x)
+        ph = x
+        bad = np.nonzero(got[:, k].view(np.uint32) != ph.view(np.uint32))[0]
+        assert bad.size == 0, (k, float(rates[bad[0]]))
+
+
 def test_fft64q_two_pass_block_on_cpu(libpath):
     """The literal 65536-point block of apply_fir_fft_cc (libcsdr.c:814-849) as the device computes it in two passes (fftfilt_lds.hip "64q": radix-4 step in the
     time domain, four 16384-point transforms with the bin product in LDS, four-point combine) -- the same stage functions run thread by thread on the CPU
