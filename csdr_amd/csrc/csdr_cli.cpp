@@ -328,7 +328,8 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
     size_t out_capacity(size_t n) override { return n / 50 + 64; }
     int next_bufsize(int b) override { return b / 50; }
     long process(csdr_amd_ctx *, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
-    { *cons = n; long na = csdr_amd_wfm_process(w, (const uint8_t *)i, 2 * n, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
+    {   // (one stream: the pitch only has to satisfy the 16-byte rule -- a stream's last block can have any length)
+        *cons = n; long na = csdr_amd_wfm_process(w, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
 };
 
 struct DdcFront : Stage {   // convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw window as ONE command (extension): the head of the NFM / AM / SSB chains

@@ -339,6 +339,34 @@ def test_cli_wfm_shell_pipeline(port):
         assert d.max() <= 1 and np.mean(d != 0) < 0.01
 
 
+def test_cli_chain_commands_at_large_blocks(port):
+    """From 1 Mi-sample blocks on (the default is 4 Mi) the single-stream chain commands run the rate-per-stream objects (one stream as 16 time segments per tile,
+    chunk seeds from a host-side phase chain): `wfm_chain_u8_s16` and `nfm_chain_u8_s16` over 2.6 M samples in blocks of 1 Mi (two full blocks and a ragged one,
+    state and seed tables carried) against the oracle chains; CSDR_AMD_CLI_SHARED=1 (the shared-rate object) must give the same samples within the same gate."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests_helpers import nfm_signal_u8
+    n = 2 * 1048576 + 500000 + 333
+    iq = fm_iq(np.random.default_rng(19), n)
+    want, _ = port.wfm_chain(iq, -0.085, 10, port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05))
+    for extra in ({}, {"CSDR_AMD_CLI_SHARED": "1"}):
+        env = dict(os.environ, CSDR_AMD_BLOCK=str(1048576), **extra)
+        p = subprocess.run([CLI, "wfm_chain_u8_s16", "-0.085"], input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+        assert p.returncode == 0, p.stderr.decode()
+        got = np.frombuffer(p.stdout, np.int16)
+        m = min(got.size, want.size)
+        assert m >= want.size - 2 and got.size <= want.size + 2
+        d = np.abs(got[:m].astype(np.int32) - want[:m].astype(np.int32))
+        assert d.max() <= 1 and np.mean(d != 0) < 0.01, (extra, int(d.max()))
+    iqn = nfm_signal_u8(78, n, offset=-0.11)
+    dtaps = np.load(os.path.join(ROOT, "tests", "golden", "nfm_deemph_taps.npz"))["sr48000"]
+    wantn, _ = port.nfm_chain(iqn, 0.11, dtaps)
+    gotn = np.frombuffer(run(["nfm_chain_u8_s16", 0.11], iqn, 1048576), np.int16)
+    assert gotn.size == wantn.size
+    dn = np.abs(gotn.astype(np.int32) - wantn.astype(np.int32))
+    assert dn.max() <= 1 and np.mean(dn != 0) < 0.01
+
+
 # ---------------------------------------------------------------- f1: protocol, control channel, in-process chains
 def test_cli_decimating_shift_addition(port):
     """csdr.c:851-875: one library call per the_bufsize (16384 by default) samples, status carried."""
