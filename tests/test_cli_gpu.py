@@ -367,6 +367,22 @@ def test_cli_chain_commands_at_large_blocks(port):
     assert dn.max() <= 1 and np.mean(dn != 0) < 0.01
 
 
+def test_cli_every_command_at_the_default_block():
+    """tools/probes/cli_default_block_sweep.py as a test: the 22 hot-path commands on a ragged 5.25 M-element input at the DEFAULT block (4 Mi elements per read -- what a
+    user gets; the tests above stream in small blocks) against the same commands at 64 Ki blocks: every run exits 0, equal lengths, results equal within float rounding."""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probes", "cli_default_block_sweep.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-2000:]
+    rows = [l for l in out.splitlines() if " default " in l and " 64Ki " in l]
+    assert len(rows) >= 22, out[-2000:]
+    for l in rows:
+        f = l.split()
+        i = f.index("default")
+        na, nb, rel = int(f[i + 1]), int(f[i + 3]), float(f[i + 5])
+        assert na == nb and na > 0 and rel < 2e-5, l
+
+
 # ---------------------------------------------------------------- f1: protocol, control channel, in-process chains
 def test_cli_decimating_shift_addition(port):
     """csdr.c:851-875: one library call per the_bufsize (16384 by default) samples, status carried."""
