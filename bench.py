@@ -12,7 +12,9 @@ samples (1.0001 s of signal) of every stream through the whole chain (state carr
     python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--block T] [--no-cpu-baseline] [--verify | --no-verify] [--no-other-configs]
 
 The line checks itself: four rows of the batch carry a real FM signal (put there BEFORE the timed loop) and are held to +-1 LSB on every sample against the CPU
-oracle after it ("verify", default; --verify adds 16 noise rows under the statistical gate of tests/verify_configs.py; --no-verify skips).  At N = 1 the line also
+oracle after it, and 16 rows of the noise batch spread over all stream blocks go through the statistical gate of tests/verify_configs.py ("verify", default;
+--strict-rows-only drops the noise rows; --no-verify skips).  The exit code is non-zero when the headline OR any operating point OR any other config's leg fails its
+verify or crashes ("all_legs_verified").  At N = 1 the line also
 carries the other BASELINE configs as short legs of their own bench scripts ("other_configs": C1 fir_decimate_cc, C3 at 1023 and 4095 taps, C4 fastddc, C5 NFM with a
 rate per channel -- each with its own verify) and two short-block operating points of this chain ("operating_points": the reference's 16384-sample block, and 65536
 streams x 10 ms), so that every config's number exists on the driver's clock.
@@ -156,10 +158,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1024)
     ap.add_argument("--block", type=int, default=2344 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true",
-                    help="after the timed region: reset, one more pass over all streams with the same object / buffers, 16 full audio rows "
-                         "spread over all stream blocks against the CPU oracle on the same bytes (tests/verify_configs.py) beside the four strict rows of the default")
-    ap.add_argument("--no-verify", action="store_true", help="skip the default check (four strict rows, +-1 LSB against the oracle)")
+    ap.add_argument("--verify", action="store_true", help="kept for old command lines: the full check is the default now")
+    ap.add_argument("--strict-rows-only", action="store_true", help="check only the four planted FM rows (+-1 LSB, <= 1e-5), not the 16 noise rows")
+    ap.add_argument("--no-verify", action="store_true", help="skip the default check: after the timed region, reset, one more pass over all streams with the same object / "
+                         "buffers; four planted FM rows held to +-1 LSB and <= 1e-5 on every sample and 16 full audio rows of the noise batch spread over all stream "
+                         "blocks under the statistical gate of tests/verify_configs.py, all against the CPU oracle on the same bytes")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short legs of the other BASELINE configs and the short-block operating points")
     args = ap.parse_args()
 
@@ -285,7 +288,7 @@ def main():
             import verify_configs as vc
             L.csdr_amd_wfm_set_profiling(w, 0)
             out_f32 = torch.empty((S, n_audio_max), dtype=torch.float32, device="cuda")      # the float audio of the same pass: north_star's 1e-5 gate on the strict rows
-            res["verify"] = vc.verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, rows=[r for r in vc.pick_rows(S) if r not in strict_rows] if args.verify else [],
+            res["verify"] = vc.verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, rows=[] if args.strict_rows_only else [r for r in vc.pick_rows(S) if r not in strict_rows],
                                           strict_rows=strict_rows, out_f32=out_f32)
             del out_f32
         if world == 1 and not args.no_other_configs:
@@ -295,9 +298,21 @@ def main():
             res["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        # every leg must have verified: a failed or crashed leg turns the run red (the line is still printed first, with the failure inside it)
+        bad = []
+        if do_verify:
+            if not res["verify"]["ok"]:
+                bad.append("headline verify: %s" % json.dumps(res["verify"]))
+            for e in res.get("operating_points", []):
+                if e.get("error") or e.get("verify_ok") is not True:
+                    bad.append("operating point %s x %s: %s" % (e.get("streams"), e.get("block_samples_per_stream", e.get("block")), e.get("error") or "verify_ok=%r" % e.get("verify_ok")))
+            for e in res.get("other_configs", []):
+                if e.get("error") or e.get("verify_ok") is not True or e.get("rc") != 0:
+                    bad.append("%s: %s" % (e.get("config"), e.get("error") or "verify_ok=%r rc=%r" % (e.get("verify_ok"), e.get("rc"))))
+        res["all_legs_verified"] = (not bad) if do_verify else None
         print(json.dumps(res))
-        if do_verify and not res["verify"]["ok"]:
-            raise SystemExit("bench.py --verify: output of the timed configuration does not match the oracle: %s" % json.dumps(res["verify"]))
+        if bad:
+            raise SystemExit("bench.py: a leg did not verify against the oracle:\n  " + "\n  ".join(bad))
     if w:
         L.csdr_amd_wfm_destroy(w)
     ctx.close()

@@ -9,6 +9,7 @@ where neither /root/reference nor a toolchain for it is needed) and compares wit
 
     python tests/golden/make_golden.py        # rewrites ref_vectors.npz
     python tests/golden/make_golden.py nfm    # rewrites nfm_cli_vectors.npz (the NFM chain as a process pipeline of the reference binary)
+    python tests/golden/make_golden.py baseline   # rewrites baseline_vectors.npz: the reference at the BASELINE geometries (C3 fft 65536, C4 D = 256 / tbw 0.001, C5 rates)
 """
 import os
 import subprocess
@@ -45,9 +46,86 @@ def make_nfm_cli():
     print("wrote nfm_cli_vectors.npz: %d input samples, %d audio samples" % (iq.size // 2, keep))
 
 
+# ---------------------------------------------------------------- the reference at the BASELINE geometries (inputs are regenerated from their seeds, never stored)
+C3_TAPS = (1023, 4095)
+C3_BLOCKS = 3
+C4_CHANNELS = (0, 97, 255)          # of 256, channel c at shift_rate = -0.5 + (c + 0.5)/256
+C4_BLOCKS = 5
+C5_RATES = (0.25, 0.05, -0.4321)
+C5_SAMPLES = 1024 * 200
+
+
+def c3_input(ntaps):
+    return crand(np.random.default_rng(3000 + ntaps), C3_BLOCKS * (65537 - ntaps))
+
+
+def c3_keep(ntaps):
+    """Output indexes kept per block: the whole overlap region (where the previous block's tail is added, libcsdr.c:843-848), the block's end, every 61st sample between."""
+    inp = 65537 - ntaps
+    one = np.unique(np.concatenate([np.arange(0, ntaps + 105), np.arange(ntaps + 105, inp - 256, 61), np.arange(inp - 256, inp)]))
+    return np.concatenate([b * inp + one for b in range(C3_BLOCKS)])
+
+
+def c4_input():
+    return crand(np.random.default_rng(4), C4_BLOCKS * 57344)
+
+
+def c4_spec_keep():
+    return np.arange(0, 65536, 97)
+
+
+def c5_input(k):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests_helpers import nfm_signal_u8
+    return nfm_signal_u8(5000 + k, C5_SAMPLES, offset=-C5_RATES[k])
+
+
+def make_baseline():
+    """tests/golden/baseline_vectors.npz: outputs of the UNMODIFIED reference at the sizes BASELINE.json names.
+    C3: apply_fir_fft_cc at fft 65536 with 1023 / 4095 taps (libcsdr.c:814-849 driven like csdr.c:1846-1880), three blocks, a subset of the output samples.
+    C4: fastddc at decimation 256 / transition_bw 0.001 (fft 65536, taps 8193, fft_inv 512; fastddc.c:38-166, csdr.c:2255-2378): every 97th bin of five forward spectra,
+        the complete output of three channels over five blocks.
+    C5: README.md:87 as eight processes of the reference binary at three shift rates; the audio every complete run agrees on."""
+    assert oracle.Ref.available(), "oracle/_ref/libcsdr_ref.so is missing (needs /root/reference; run `make -C oracle`)"
+    R = oracle.ref()
+    g = {}
+    for nt in C3_TAPS:
+        taps = R.firdes_bandpass_c(nt, -0.1, 0.2)
+        y = R.bandpass_fir_fft_cc(c3_input(nt), taps, 65536)
+        assert y.size == C3_BLOCKS * (65537 - nt)
+        g["c3_taps_%d" % nt] = taps
+        g["c3_out_%d" % nt] = y[c3_keep(nt)].copy()
+    x = c4_input()
+    d0, err = R.fastddc_init(0.001, 256, 0.0)
+    assert err == 0 and d0.fft_size == 65536 and d0.input_size == 57344 and d0.fft_inv_size == 512
+    spec = R.fastddc_fwd_cc(x, d0)
+    g["c4_spec_subset"] = spec[:, c4_spec_keep()].copy()
+    for c in C4_CHANNELS:
+        rate = float(np.float32(-0.5 + (c + 0.5) / 256))
+        dc, err = R.fastddc_init(0.001, 256, rate)
+        assert err == 0
+        g["c4_out_ch%d" % c] = R.fastddc_inv_cc(spec, dc, R.fastddc_taps_fft(dc, rate, 256))
+        g["c4_geometry_ch%d" % c] = np.array([dc.pre_decimation, dc.post_decimation, dc.taps_length, dc.overlap_length, dc.fft_size, dc.fft_inv_size, dc.input_size,
+                                               dc.post_input_size, dc.startbin, dc.offsetbin, dc.scrap], np.int64)
+    cli = os.path.join(ROOT, "oracle", "_ref", "csdr")
+    keep = ((C5_SAMPLES - 801) // 50 + 1 + 1024 - 201) // 1024 * 1024
+    for k, rate in enumerate(C5_RATES):
+        cmds = ("convert_u8_f", "shift_addition_cc %r" % rate, "fir_decimate_cc 50 0.005 HAMMING", "fmdemod_quadri_cf", "limit_ff", "deemphasis_nfm_ff 48000", "fastagc_ff", "convert_f_s16")
+        pipe = " | ".join("%s %s" % (cli, c) for c in cmds)
+        out = subprocess.run(pipe, shell=True, input=c5_input(k).tobytes(), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout
+        s16 = np.frombuffer(out[:len(out) // 2 * 2], np.int16)
+        assert s16.size >= keep
+        g["c5_s16_rate%d" % k] = s16[:keep].copy()
+    path = os.path.join(ROOT, "tests", "golden", "baseline_vectors.npz")
+    np.savez_compressed(path, **g)
+    print("wrote %s: %d arrays, %.0f KB" % (path, len(g), os.path.getsize(path) / 1024))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "nfm":
         return make_nfm_cli()
+    if len(sys.argv) > 1 and sys.argv[1] == "baseline":
+        return make_baseline()
     assert oracle.Ref.available(), "oracle/_ref/libcsdr_ref.so is missing (needs /root/reference; run `make -C oracle`)"
     R = oracle.ref()
     rng = np.random.default_rng(20260924)
