@@ -185,6 +185,26 @@ def lib():
     L.csdr_amd_wfm_reset.argtypes = [vp]
     L.csdr_amd_wfm_process.restype = C.c_long; L.csdr_amd_wfm_process.argtypes = [vp, vp, sz, sz, vp, vp, sz]
     L.csdr_amd_wfm_kernel_name.restype = C.c_char_p; L.csdr_amd_wfm_kernel_name.argtypes = [vp]
+    ll = C.c_longlong; db = C.c_double
+    L.csdr_amd_wfm_ring_create.restype = vp; L.csdr_amd_wfm_ring_create.argtypes = [vp, i, fl, i, vp, i, i, fl, i, sz, i]
+    L.csdr_amd_wfm_ring_destroy.argtypes = [vp]; L.csdr_amd_wfm_ring_destroy.restype = None
+    L.csdr_amd_wfm_ring_reset.argtypes = [vp]
+    L.csdr_amd_wfm_ring_acquire.argtypes = [vp, ll, db]
+    L.csdr_amd_wfm_ring_input.restype = vp; L.csdr_amd_wfm_ring_input.argtypes = [vp, ll, C.POINTER(sz)]
+    L.csdr_amd_wfm_ring_submit.restype = ll; L.csdr_amd_wfm_ring_submit.argtypes = [vp]
+    L.csdr_amd_wfm_ring_wait.restype = C.c_long; L.csdr_amd_wfm_ring_wait.argtypes = [vp, ll, db]
+    L.csdr_amd_wfm_ring_output.restype = vp; L.csdr_amd_wfm_ring_output.argtypes = [vp, ll, C.POINTER(sz)]
+    L.csdr_amd_wfm_ring_set_rate.argtypes = [vp, fl]
+    L.csdr_amd_wfm_ring_get_rate.restype = fl; L.csdr_amd_wfm_ring_get_rate.argtypes = [vp]
+    L.csdr_amd_wfm_ring_set_timeouts.argtypes = [vp, db, db]
+    L.csdr_amd_wfm_ring_resident.argtypes = [vp]
+    L.csdr_amd_wfm_ring_stop.argtypes = [vp]
+    L.csdr_amd_wfm_ring_slots.argtypes = [vp]
+    L.csdr_amd_wfm_ring_grid.argtypes = [vp]
+    L.csdr_amd_wfm_ring_launches.restype = C.c_long; L.csdr_amd_wfm_ring_launches.argtypes = [vp]
+    L.csdr_amd_wfm_ring_submitted.restype = ll; L.csdr_amd_wfm_ring_submitted.argtypes = [vp]
+    L.csdr_amd_wfm_ring_block_times.argtypes = [vp, ll, C.POINTER(db), C.POINTER(db)]
+    L.csdr_amd_wfm_ring_replay.argtypes = [vp, C.c_long, vp, vp]
     L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
     L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.csdr_amd_ddc_create.restype = vp; L.csdr_amd_ddc_create.argtypes = [vp, i, fl, i, vp, i, sz]
@@ -750,6 +770,57 @@ class Context:
         self.last_ddc_kernel = self.L.csdr_amd_ddc_kernel_name(d).decode()
         self.L.csdr_amd_ddc_destroy(d)
         return y[0].copy() if squeeze else y.copy()
+
+    def wfm_ring_chain(self, iq_u8, shift_rate, decimation, taps, block=16384, n_slots=8, frac_rate=5, tau=50e-6, audio_rate=48000, retunes=None, in_flight=None,
+                       idle_us=None, life_ms=None, pause_every=None, pause_s=0.0):
+        """The resident form (csdr_amd_wfm_ring_*): iq_u8 [streams, 2n] uint8, n a multiple of `block` -> s16 [streams, na] (all blocks' audio in stream order).
+        Blocks are copied into the input ring slot by slot (hipMemcpy H2D), posted, and collected `in_flight` (default n_slots - 2) blocks later.
+        retunes: {block index: rate} applied in front of that block.  pause_every / pause_s: sleep so long every so many blocks (the grid leaves and is relaunched).
+        Leaves (launches, grid) in self.last_ring."""
+        import time
+        x2, squeeze = self._2d(iq_u8, np.uint8)
+        s, nbytes = x2.shape; n = nbytes // 2
+        assert n % block == 0
+        nb = n // block
+        taps = np.ascontiguousarray(taps, f32)
+        r = self.L.csdr_amd_wfm_ring_create(self.h, s, shift_rate, decimation, _hp(taps), taps.size, frac_rate, tau, audio_rate, block, n_slots)
+        if not r:
+            raise CsdrAmdError(self.err())
+        try:
+            if idle_us is not None or life_ms is not None:
+                self.check(self.L.csdr_amd_wfm_ring_set_timeouts(r, 200.0 if idle_us is None else idle_us, 250.0 if life_ms is None else life_ms), "ring_set_timeouts")
+            depth = (n_slots - 2) if in_flight is None else in_flight
+            outs = []; pitch = C.c_size_t(0); opitch = C.c_size_t(0)
+
+            def collect(k):
+                na = self.check(self.L.csdr_amd_wfm_ring_wait(r, k, 0.0), "ring_wait")
+                po = self.L.csdr_amd_wfm_ring_output(r, k, C.byref(opitch))
+                buf = np.empty((s, opitch.value), np.int16)
+                self.check(self.L.csdr_amd_d2h(self.h, _hp(buf), po, buf.nbytes), "d2h")
+                outs.append(buf[:, :na].copy())
+            for k in range(nb):
+                if retunes and k in retunes:
+                    while len(outs) < k:
+                        collect(len(outs))
+                    self.check(self.L.csdr_amd_wfm_ring_set_rate(r, retunes[k]), "ring_set_rate")
+                if pause_every and k and k % pause_every == 0:
+                    time.sleep(pause_s)
+                self.check(self.L.csdr_amd_wfm_ring_acquire(r, k, 0.0), "ring_acquire")
+                pi = self.L.csdr_amd_wfm_ring_input(r, k, C.byref(pitch))
+                blk = np.zeros((s, pitch.value), np.uint8); blk[:, :2 * block] = x2[:, 2 * k * block:2 * (k + 1) * block]
+                self.check(self.L.csdr_amd_h2d(self.h, pi, _hp(blk), blk.nbytes), "h2d")
+                got = self.L.csdr_amd_wfm_ring_submit(r)
+                if got != k:
+                    raise CsdrAmdError("ring_submit: %d (%s)" % (got, self.err()))
+                while len(outs) + depth <= k:
+                    collect(len(outs))
+            while len(outs) < nb:
+                collect(len(outs))
+            self.last_ring = {"launches": self.L.csdr_amd_wfm_ring_launches(r), "grid": self.L.csdr_amd_wfm_ring_grid(r)}
+        finally:
+            self.L.csdr_amd_wfm_ring_destroy(r)
+        y = np.concatenate(outs, axis=1)
+        return y[0].copy() if squeeze else y
 
     def nfm_chain(self, iq_u8, shift_rate, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024, block=None, retunes=None):
         """BASELINE config 5 / README.md:87 through the chain object csdr_amd_nfm_* (matrix-core front end + audio-rate back end):

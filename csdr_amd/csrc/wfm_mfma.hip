@@ -250,16 +250,44 @@ __device__ unsigned long long g_wfm_life[SEQ_NW][4];      // per wave, summed ov
 // the loaders issues other vector memory operations -- brings the 3 x 16 seeds of a step into an LDS table two steps ahead (inline-asm loads, one step in flight:
 // a vector load queues behind the CU's LDS-DMA pieces for ~3000 cycles).  Every column but the call's first warms its de-emphasis up over two steps like a
 // segment of the shared-rate kernel; columns behind the block's end re-read column 0 and store nothing.
-template <bool PS>
+// RES (the resident form, csdr_amd_wfm_ring_*: north_star's "persistent-kernel ring buffer"; the reference's unit of work is one the_bufsize block per loop iteration,
+// csdr.c:189-193, 232-247, 330-392): ONE grid stays on the GPU and walks a ring of blocks.  The host posts a block by writing its descriptor -- tagged 64-byte lines in
+// host-coherent memory: the block's chunk seeds -- ; a workgroup takes the work items (block k, 16-stream group sb) with item = k n_wsb + sb = its id (mod the grid), polls
+// the descriptor of its next block (s_sleep between polls), runs this kernel's body on it and counts the item in; the workgroup that completes a block writes the block's
+// done line (host memory).  Weights, prefix table and the LDS ring stay with the workgroup.  State between blocks: NONE -- every block warms its de-emphasis up over the
+// two steps in front of it, read from the previous block's slot of the input ring (what every segment but the first of a long call does anyway), and its first partial
+// tile is recomputed from there; so a workgroup that leaves can be replaced by a new launch at any block boundary: it leaves when the host says stop, when no block
+// arrived for idle_ticks, or when the launch is older than life_ticks (a stalled host or a bug cannot hold the GPU), by raising `exiting` for all others and storing its
+// next item.  The host relaunches on demand (wfm_ring.hip).
+constexpr int RES_WARM = 48;              // audio samples in front of a block over which a retune's de-emphasis state is rebuilt (0.706^48 = 5e-8)
+struct ResCtl {
+    const uint32_t *desc;                  // host: [n_slots][desc_lines][16]: dword 0 = tag of the block, 1 = lead samples (a retune), 2.. = 7 x (cos, sin) of chunks first_chunk - 4 ...
+    const uint32_t *ctrl;                  // host: [0] = stop
+    uint32_t *done;                        // host: [n_slots][16]: tag, n_audio, t_first (2), t_done (2)
+    unsigned *cnt;                         // device [n_slots]: items of the block in that slot that are finished
+    unsigned long long *t_first;           // device [n_slots]: earliest start of an item of the block (wall clock ticks)
+    unsigned long long *next_item;         // device [grid]: the item a workgroup takes next
+    unsigned *exiting;                     // device: a workgroup has left
+    const uint8_t *in_ring; int16_t *out_ring; size_t in_slot_bytes, out_slot_elems;
+    int n_slots, desc_lines, n_wsb, T, D, L, F;
+    long long idle_ticks, life_ticks;
+    const float *lead_d;                   // [n_streams][4]: a retuned stream's first audio samples of the block (k_wfm_lead)
+    const float *lead_state;               // [n_streams]: the de-emphasis state in front of the first block behind a retune
+};
+__device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ uint32_t res_tag(long long k) { return (uint32_t)((unsigned long long)k % 0xfffffffeull) + 1u; }
+
+template <bool PS, bool RES = false>
 __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__restrict__ in, size_t in_pitch, const v4i *__restrict__ frags, const float *__restrict__ cum,
-                                                               const float2 *__restrict__ dtab, const float2 *__restrict__ ctab, SeqParams p)
+                                                               const float2 *__restrict__ dtab, const float2 *__restrict__ ctab, SeqParams p_in, ResCtl rc)
 {
+    static_assert(!(PS && RES), "the resident form exists for the shared-rate kernel");
     constexpr int TPG = SEQ_TPG, SPW = 16 / SEQ_NLW, NTHR = 64 * SEQ_NW;              // tiles per step; streams fetched per fetching wave in a row-step
     extern __shared__ float4 lds_raw[];
     uint8_t *lds_in = reinterpret_cast<uint8_t *>(lds_raw);
     float *lds_out = reinterpret_cast<float *>(lds_in + 16 * SEQ_RP);                // 16 x SEQ_OUTP floats
     float *lcum = lds_out + 16 * SEQ_OUTP;                                       // prefix table (a global vector load inside the loop would drain the DMA ring)
-    float2 *ctl = reinterpret_cast<float2 *>(lcum + (SEQ_NGR + 1) * 16);          // PS: [2][3][16] chunk seeds of a step (class, column)
+    float2 *ctl = reinterpret_cast<float2 *>(lcum + (SEQ_NGR + 1) * 16);          // PS: [2][3][16] chunk seeds of a step (class, column);  RES: [2 words of control][chunk seeds of the block]
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, col = lane & 15, q = lane >> 4;
     const bool fetches = wv >= TPG;
 #ifdef WFM_PROF
@@ -267,18 +295,9 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     long long t_first = t_entry, t_last = t_entry;
 #endif
     const int fw = wv - TPG;                                                         // index among the fetching waves
-    const int sb = blockIdx.x;                                                       // block of 16 streams; PS: the stream
-    const int col0 = PS ? 16 * (int)blockIdx.y : 0;                                  // PS: absolute index of the workgroup's first column
-    float scale = p.scale;
-    if constexpr (PS) { frags += (size_t)sb * p.frag_stride; cum += (size_t)sb * ((SEQ_NGR + 1) * 16); dtab += (size_t)sb * 3072; ctab += sb; scale = p.scales[sb]; }
+    float scale = p_in.scale;
+    if constexpr (PS) { const int sbp = blockIdx.x; frags += (size_t)sbp * p_in.frag_stride; cum += (size_t)sbp * ((SEQ_NGR + 1) * 16); dtab += (size_t)sbp * 3072; ctab += sbp; scale = p_in.scales[sbp]; }
     for (int i = tid; i < (SEQ_NGR + 1) * 16; i += NTHR) lcum[i] = cum[i];
-    const long long t0 = p.tile_first + (long long)blockIdx.y * p.tiles_per_seg * (PS ? 16 : 1);      // PS: column 0's first tile
-    long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
-    if (t0 >= t1) return;
-    const int n_it = (int)(t1 - t0), n_grp = (n_it + TPG - 1) / TPG;
-    const int n_lead = (PS && p.lead_n && blockIdx.y == 0) ? p.lead_n[sb] : 0;         // PS: audio samples at the call's start that k_wfm_lead has evaluated (a retuned stream)
-    const int n_warm = (PS || blockIdx.y > 0) ? 2 : 0;                               // steps demodulated ahead of the segment to warm the de-emphasis up
-    const int last_stream = p.n_streams - 1;
     v4i A[WFM_NK * 3];
 #pragma unroll
     for (int s = 0; s < WFM_NK * 3; s++) A[s] = frags[s * 64 + lane];
@@ -289,6 +308,91 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         c_lo[0] = a.x; c_lo[1] = a.y; c_lo[2] = a.z; c_lo[3] = a.w; c_hi[0] = b.x; c_hi[1] = b.y; c_hi[2] = b.z; c_hi[3] = b.w;
     }
     const float K = 0.340447550238101026565118445432744920253753662109375f;
+    // ---- RES: the walk over the work items
+    SeqParams p_res;
+    if constexpr (RES) p_res = p_in;
+    const SeqParams &p = RES ? p_res : p_in;
+    unsigned long long item = 0;
+    long long res_t_launch = 0;
+    uint32_t *const rctl = reinterpret_cast<uint32_t *>(ctl);                        // RES: [0] = go / leave, [1] = lead samples
+    const float2 *const lseed = ctl + 1;                                             // RES: seeds of chunks first_chunk - 4 ...
+    if constexpr (RES) { item = rc.next_item[blockIdx.x]; res_t_launch = wall_clock64(); }
+    for (;;) {                                                                       // (not RES: one pass)
+    int res_slot = 0, res_lead = 0; long long res_k = 0; bool res_retuned = false;
+    const uint8_t *pblock = nullptr;                                                 // RES: the previous block's rows of this stream group (what lies in front of the block)
+    if constexpr (RES) {
+        res_k = (long long)(item / (unsigned)rc.n_wsb);
+        res_slot = (int)(res_k % rc.n_slots);
+        if (wv == 0) {
+            const uint32_t *dsc = rc.desc + (size_t)res_slot * rc.desc_lines * 16;
+            const uint32_t tag = res_tag(res_k);
+            const int nd = rc.desc_lines * 16;
+            const long long t_wait = wall_clock64();
+            uint32_t state = 0;
+            for (;;) {
+                uint32_t v[4] = {0u, 0u, 0u, 0u};
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int d = lane + 64 * j;
+                    if (d < nd) { v[j] = sys_load(dsc + d); if ((d & 15) == 0 && v[j] != tag) ok = false; }
+                }
+                const bool ready = __all(ok);
+                const uint32_t ex = __hip_atomic_load(rc.exiting, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long now = wall_clock64();
+                const bool old = now - res_t_launch > rc.life_ticks;
+                if (ready && !ex && !old) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int d = lane + 64 * j, w = d & 15;
+                        if (d < nd && w >= 2) rctl[2 + (d >> 4) * 14 + (w - 2)] = v[j];                 // seed floats (cos, sin) x 7 per line -> lseed[]
+                        if (d == 1) rctl[1] = v[j];
+                    }
+                    state = 1; break;
+                }
+                const uint32_t stop = sys_load(rc.ctrl);
+                if (ex || old || stop || now - t_wait > rc.idle_ticks) { state = 2; break; }
+                __builtin_amdgcn_s_sleep(24);
+            }
+            if (lane == 0) rctl[0] = state;
+        }
+        __syncthreads();
+        if (rctl[0] != 1u) {
+            if (tid == 0) { __hip_atomic_store(rc.exiting, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc.next_item[blockIdx.x] = item; }
+            return;
+        }
+        res_lead = (int)(rctl[1] & 0xffu); res_retuned = (rctl[1] >> 8) & 1u;
+        // the block's geometry (what csdr_amd_wfm_process derives on the host, wfm.hip): audio samples that become computable with block k
+        auto j_hi = [&](long long kk) -> long long {
+            if (kk < 0) return -1;
+            const long long avail_last = (kk + 1) * rc.T - 1;
+            if (avail_last - (rc.L - 1) < 0) return -1;
+            const long long k_max = (avail_last - (rc.L - 1)) / rc.D;
+            return k_max >= 10 ? (k_max - 10) / rc.F : -1;
+        };
+        const long long jp = j_hi(res_k - 1), jn = j_hi(res_k);
+        p_res.B2 = 2 * res_k * rc.T;
+        p_res.j_first = jp + 1; p_res.n_audio = (int)(jn - jp);
+        p_res.tile_first = p_res.j_first / 4; p_res.n_tiles = (int)((p_res.j_first + p_res.n_audio - 1) / 4 - p_res.tile_first + 1);
+        p_res.tiles_per_seg = p_res.n_tiles;
+        p_res.s16 = rc.out_ring + (size_t)res_slot * rc.out_slot_elems;
+        if (tid == 0) atomicMin(rc.t_first + res_slot, (unsigned long long)wall_clock64());
+    }
+    const int sb = RES ? (int)(item % (unsigned)rc.n_wsb) : (int)blockIdx.x;         // block of 16 streams; PS: the stream
+    const int seg_y = RES ? 0 : (int)blockIdx.y;                                      // time segment of the call (RES: a block is one segment)
+    const int col0 = PS ? 16 * seg_y : 0;                                            // PS: absolute index of the workgroup's first column
+    if constexpr (RES) {
+        in = rc.in_ring + (size_t)res_slot * rc.in_slot_bytes;
+        pblock = rc.in_ring + (size_t)((res_slot + rc.n_slots - 1) % rc.n_slots) * rc.in_slot_bytes + (long long)sb * 16 * (long long)in_pitch;
+    }
+    const long long t0 = p.tile_first + (long long)seg_y * p.tiles_per_seg * (PS ? 16 : 1);      // PS: column 0's first tile
+    long long t1 = t0 + p.tiles_per_seg; if (t1 > p.tile_first + p.n_tiles) t1 = p.tile_first + p.n_tiles;
+    if (!RES && t0 >= t1) return;
+    const int n_it = (int)(t1 - t0), n_grp = (n_it + TPG - 1) / TPG;
+    const int n_lead = RES ? res_lead : ((PS && p.lead_n && seg_y == 0) ? p.lead_n[sb] : 0);      // PS / RES: audio samples at the call's start that k_wfm_lead has evaluated (a retuned stream)
+    const int n_warm = RES ? ((res_k > 0 && !res_retuned) ? 2 : 0) : ((PS || seg_y > 0) ? 2 : 0);       // steps demodulated ahead of the segment to warm the de-emphasis up (RES: the first
+                                                                                     // block behind a retune gets its state from k_wfm_lead_state: the samples in front of it want the old weights)
+    const int last_stream = p.n_streams - 1;
     // ---- DMA ring.  Positions are bytes from the block start; they start at -1024 (the head), hence the + 2 SEQ_RB in the slot arithmetic
     const int tstride = p.stride;
     const long long org = PS ? (long long)col0 * p.col_bytes : 0LL;                  // PS: positions are counted from the start of the workgroup's column 0
@@ -343,6 +447,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
                                  : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(la) : "memory");
             }
+            F += 1024; fslot += 1024; if (fslot >= SEQ_RB) fslot -= SEQ_RB;
+            return;
+        }
+        if constexpr (RES) {                                                         // in front of the block lies the previous block's slot of the input ring; blocks are whole chunks
+            const uint8_t *sb_res = F < 0 ? pblock + (p.two_T + F) : sblock + F;
+            dma_rows<SPW, SEQ_RP>(voff, sb_res, __builtin_amdgcn_readfirstlane((int)(lds_in_addr + (SPW * fw) * SEQ_RP + (uint32_t)fslot)));
             F += 1024; fslot += 1024; if (fslot >= SEQ_RB) fslot -= SEQ_RB;
             return;
         }
@@ -445,10 +555,11 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     for (int j = 1; j <= QL; j++) bp[j] = bp[j - 1] * one_minus;
     const float b2q = bp[QL] * bp[QL], b3q = b2q * bp[QL];
     float yst_first = 0.f;                                                           // PS: the call's first column starts from the carried state at step 0 (its warm-up steps ran on whatever lay in front)
-    if (iir_wave && blockIdx.y == 0) {                                               // first segment: the exact carried state (NaN reset as libcsdr.c:1092)
+    if (!RES && iir_wave && seg_y == 0) {                                            // first segment: the exact carried state (NaN reset as libcsdr.c:1092)
         yst = p.last_in[PS ? sb : min(s0 + col, last_stream)]; if (yst != yst) yst = 0.f;
         yst_first = yst;
     }
+    if (RES && iir_wave && res_retuned) yst = rc.lead_state[min(s0 + col, last_stream)];
     // the segment's audio samples, counted from its first tile's first sample (ints: this bookkeeping runs every step, on wave 0 between two barriers)
     const long long j_end = p.j_first + p.n_audio;
     const int seg_lo = (int)max(0LL, p.j_first - 4 * t0);                           // > 0 only in the call's first segment, when j_first is not a multiple of 4
@@ -490,7 +601,8 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     if (fetches) {
         // ======================================================================== the loader waves: fetch, and take the finished audio out
         typedef unsigned wfm_u4 __attribute__((ext_vector_type(4)));
-        constexpr int NST = 44;                                                      // lines held per stream: 5.5 KiB, 176 registers (32 / 40 / 44 lines: 0.859 / 0.848 / 0.849 ms; 48: 256 registers and spills)
+        constexpr int NST = RES ? 8 : 44;                                            // lines held per stream: 5.5 KiB, 176 registers (32 / 40 / 44 lines: 0.859 / 0.848 / 0.849 ms; 48: 256 registers and spills)
+                                                                                     // (RES: short blocks -- 16384 samples are five lines --, and the registers are wanted for the walk)
         // (named registers, written through selects: any array or switch form went to scratch memory)
 #define WFM_ST_ALL(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) \
                       X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43)
@@ -507,13 +619,13 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         auto flush = [&]() __attribute__((always_inline)) {
             if constexpr (PS) {
                 // a held line is whole for column 0; for the call's last column it may be cut, for columns behind the block's end it does not exist
-#define X(j) if (j < n_st && row_ok) { const int a = st_n0 + SEQ_LINE * j + 8 * pc;                                                             \
+#define X(j) if (j < NST && j < n_st && row_ok) { const int a = st_n0 + SEQ_LINE * j + 8 * pc;                                                             \
                  if (a + 8 <= hi_r) *reinterpret_cast<uint4 *>(orow + (idx0 + a)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);        \
                  else for (int i = 0; i < 8; i++) if (a + i < hi_r) orow[idx0 + a + i] = (int16_t)(st##j[i >> 1] >> (16 * (i & 1))); }
                 WFM_ST_ALL(X)
 #undef X
             } else {
-#define X(j) if (j < n_st && row_ok) *reinterpret_cast<uint4 *>(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);
+#define X(j) if (j < NST && j < n_st && row_ok) *reinterpret_cast<uint4 *>(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);
                 WFM_ST_ALL(X)
 #undef X
             }
@@ -539,7 +651,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                               (unsigned)(v[4] & 0xffff) | ((unsigned)v[5] << 16), (unsigned)(v[6] & 0xffff) | ((unsigned)v[7] << 16)};
             if (nl >= seg_lo && nl + SEQ_LINE <= seg_hi && !p.af) {                  // a whole line (wave uniform): held
                 if (n_st == 0) st_n0 = nl;
-#define X(k) st##k = n_st == k ? w : st##k;           // (selects: a switch became a store through a pointer and sent the registers to scratch memory)
+#define X(k) if (k < NST) st##k = n_st == k ? w : st##k;           // (selects: a switch became a store through a pointer and sent the registers to scratch memory)
                 WFM_ST_ALL(X)
 #undef X
                 if (++n_st == NST) flush();
@@ -633,12 +745,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             // ---- post factors and offset constants of the window's part(s)
             const int kcls = PS ? (int)chunk_rel - ps_base(wg) : 0;                   // PS: the window's chunk class in the step's seed table (0 .. 2; its second chunk: the next)
             const float2 *ct = ctl + ((gi + 2) & 1) * 48 + kcls * 16 + col;
-            const float2 C0 = PS ? ct[0] : ctab[chunk_rel + 1], D0 = dtab[off + 2048];
+            const float2 C0 = PS ? ct[0] : (RES ? lseed[chunk_rel + 4] : ctab[chunk_rel + 1]), D0 = dtab[off + 2048];
             const float2 P0 = make_float2(C0.x * D0.x - C0.y * D0.y, C0.x * D0.y + C0.y * D0.x);
             float2 P1 = make_float2(0.f, 0.f);
             float k0[4], k1[4];
             if (two) {
-                const float2 C1 = PS ? ct[16] : ctab[chunk_rel + 2], D1 = dtab[off - 1024 + 2048];
+                const float2 C1 = PS ? ct[16] : (RES ? lseed[chunk_rel + 5] : ctab[chunk_rel + 2]), D1 = dtab[off - 1024 + 2048];
                 P1 = make_float2(C1.x * D1.x - C1.y * D1.y, C1.x * D1.y + C1.y * D1.x);
                 const float4 cb = *reinterpret_cast<const float4 *>(lcum + (bo >> 4) * 16 + 4 * q);
                 k0[0] = cb.x - c_lo[0]; k0[1] = cb.y - c_lo[1]; k0[2] = cb.z - c_lo[2]; k0[3] = cb.w - c_lo[3];
@@ -660,6 +772,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 const long long ja = 4 * (t0 + it) + q - p.j_first;                  // this audio sample's index in the call (column 0)
                 if (n_lead > 0 && col0 + col == 0 && ja >= 0 && ja < n_lead) dval = p.lead_d[(size_t)sb * 4 + ja];      // (n_lead in a register: a vector load here waits behind the DMA ring)
             }
+            if constexpr (RES) {                                                     // the first block after a retune: the samples whose windows straddle the two rates
+                if (n_lead > 0) {
+                    const long long ja = 4 * (t0 + it) + q - p.j_first;
+                    if (ja >= 0 && ja < n_lead) dval = rc.lead_d[(size_t)min(sb * 16 + col, last_stream) * 4 + ja];
+                }
+            }
             lout[col * SEQ_OUTP + 4 * wv + q] = dval;                                 // audio 4 * tile + q of stream col
         }
         PROF_T(0)
@@ -672,7 +790,8 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         if (iir_wave && WFM_DIAG < 5) {                                              // this step's 32 samples of stream s0 + col through the de-emphasis, in place
             // (PS: per column -- lane col -- ; the scan runs when every column's range allows it)
             if (PS && gi == 0 && col0 + col == 0) yst = yst_first;                   // the call's first column: the carried state instead of its warm-up's
-            const int lo = gi == 0 ? col_lo(col) : 0;                                // samples [lo, hi) of the step exist in this call (warm-up steps: all)
+            const int lo = (gi == 0 && !(RES && n_warm)) ? col_lo(col) : 0;          // samples [lo, hi) of the step exist in this call (warm-up steps: all; RES: a block's first, partial tile
+                                                                                     // continues the recurrence of the warm-up over the samples in front of the block -- they are not stored)
             const int hi = gi < 0 ? SPS : max(0, min(SPS, col_hi(col) - gi * SPS));
             if (PS ? __all(lo == 0 && (hi & 3) == 0) : (lo == 0 && (hi & 3) == 0)) {
                 float *row = lout + col * SEQ_OUTP + QL * q;                         // this lane's quarter: samples QL q .. QL q + QL - 1
@@ -727,14 +846,14 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     __syncthreads();
     if (!emit_vec) emit_scalar(n_grp - 1);
     }
-    if (PS && blockIdx.y + 1 == gridDim.y) {                                         // the workgroup that holds the call's last column
+    if (PS && seg_y + 1 == (int)gridDim.y) {                                         // the workgroup that holds the call's last column
         if (iir_lane && col0 + lane == p.n_cols - 1) p.last_out[sb] = yst;
         if (tid < 32 && p.two_T >= 512 && (p.two_T & 15) == 0) {                     // the block's newest 512 bytes -> bytes 512.. of the other head buffer
             const uint4 v = *reinterpret_cast<const uint4 *>(in + (size_t)sb * in_pitch + (p.two_T - 512) + 16 * tid);
             *reinterpret_cast<uint4 *>(p.head_out + (size_t)sb * SEQ_HEAD + 512 + 16 * tid) = v;
         }
     } else
-    if (!PS && blockIdx.y + 1 == gridDim.y) {                                        // the call's last segment: what the next call starts from
+    if (!PS && !RES && seg_y + 1 == (int)gridDim.y) {                                // the call's last segment: what the next call starts from
         if (iir_lane && s0 + lane < p.n_streams) p.last_out[s0 + lane] = yst;
         // the block's newest 512 bytes -> bytes 512.. of the other head buffer (16 streams x 32 pieces of 16 bytes)
         if (tid < 16 * 32 && p.two_T >= 512 && (p.two_T & 15) == 0 && s0 + tid / 32 < p.n_streams) {
@@ -751,6 +870,26 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         atomicAdd(&g_wfm_life[wv][2], (unsigned long long)(t_exit - t_last)); atomicAdd(&g_wfm_life[wv][3], 1ULL);
     }
 #endif
+    if constexpr (!RES) break;
+    else {
+        // the item's audio is on its way: make it visible beyond this XCD's L2, count the item in; whoever completes the block tells the host
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned c = __hip_atomic_fetch_add(rc.cnt + res_slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (c + 1 == (unsigned)rc.n_wsb) {
+                const unsigned long long tf = __hip_atomic_exchange(rc.t_first + res_slot, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), td = (unsigned long long)wall_clock64();
+                __hip_atomic_store(rc.cnt + res_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t *dn = rc.done + (size_t)res_slot * 16;
+                __hip_atomic_store(dn + 1, (uint32_t)p.n_audio, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dn + 2, (uint32_t)tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dn + 3, (uint32_t)(tf >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dn + 4, (uint32_t)td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dn + 5, (uint32_t)(td >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(dn, res_tag(res_k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        item += gridDim.x;
+    }
+    }
 }
 
 // the history of a call that produced no audio (a block shorter than one tile's reach): the head buffers still have to roll
@@ -767,23 +906,23 @@ __global__ __launch_bounds__(256) void k_wfm_roll_head(const uint8_t *__restrict
 // (shift_addition_cc --fifo picks a new rate up between two reads, csdr.c:881-923).  Those samples -- at most four -- are evaluated here with both tables, one
 // wave per (listed stream, sample, which of y[Fj+9] / y[Fj+10]): the chain kernel takes the demodulated value from lead_d.  Seeds: row 0 of the stream's table =
 // the chunk in front of the block.
-struct LeadParams { int D, L, F; long long B, j_first; int n_lead; size_t tab_pitch, dtab_stride; };
+struct LeadParams { int D, L, F; long long B, j_first, c_first; int n_lead, ja0; float *warm; size_t tab_pitch, dtab_stride, ct_stride, head_pitch, head_off; };      // (a ring's tables are shared: strides 0; its history
+                                                                                                                                               //  is the previous slot's tail)
 __global__ __launch_bounds__(128) void k_wfm_lead(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ head, const float *__restrict__ taps,
                                                  const float2 *__restrict__ ctab, const float2 *__restrict__ dtab, const float2 *__restrict__ dtab_old,
                                                  const int *__restrict__ list, float *__restrict__ lead_d, LeadParams p)
 {
     __shared__ float2 yv[2];
-    const int s = list[blockIdx.y], ja = blockIdx.x, which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = list[blockIdx.y], ja = (int)blockIdx.x + p.ja0, which = threadIdx.x >> 6, lane = threadIdx.x & 63;      // (ja < 0: a ring's warm-up samples in front of the block)
     const long long j = p.j_first + ja, k = (long long)p.F * j + 9 + which;
-    const uint8_t *row = in + (size_t)s * in_pitch, *hrow = head + (size_t)s * SEQ_HEAD + 512;      // the head's second half: the 256 samples in front of the block
-    const float2 *ct = ctab + s, *dn = dtab + (size_t)s * p.dtab_stride, *dold = dtab_old + (size_t)s * p.dtab_stride;
-    const long long c0 = p.B >> 10;
+    const uint8_t *row = in + (size_t)s * in_pitch, *hrow = head + (size_t)s * p.head_pitch + p.head_off;      // (the head's second half:) the 256 samples in front of the block
+    const float2 *ct = ctab + (size_t)s * p.ct_stride, *dn = dtab + (size_t)s * p.dtab_stride, *dold = dtab_old + (size_t)s * p.dtab_stride;
     float ai = 0.f, aq = 0.f;
     for (int t = lane; t < p.L; t += 64) {
         const long long n = (long long)p.D * k + t, rel = n - p.B;
         uint32_t vi, vq;
         if (rel < 0) { vi = hrow[2 * (rel + 256)]; vq = hrow[2 * (rel + 256) + 1]; } else { vi = row[2 * rel]; vq = row[2 * rel + 1]; }
-        const float2 C = ct[(size_t)((n >> 10) - c0 + 1) * p.tab_pitch], Dv = (rel < 0 ? dold : dn)[(int)(n & 1023) + 2048];
+        const float2 C = ct[(size_t)((n >> 10) - p.c_first) * p.tab_pitch], Dv = (rel < 0 ? dold : dn)[(int)(n & 1023) + 2048];
         const float2 R = make_float2(C.x * Dv.x - C.y * Dv.y, C.x * Dv.y + C.y * Dv.x);
         const float xi = fmaf((float)vi, 0x1.010102p-7f, -1.0f), xq = fmaf((float)vq, 0x1.010102p-7f, -1.0f);      // v / 127.5 - 1
         const float h = taps[t];
@@ -798,8 +937,19 @@ __global__ __launch_bounds__(128) void k_wfm_lead(const uint8_t *__restrict__ in
         const float pI = yv[0].x, pQ = yv[0].y, cI = yv[1].x, cQ = yv[1].y;
         const float dq = cQ - pQ, di = cI - pI, num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
         float rd = __builtin_amdgcn_rcpf(den); rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
-        lead_d[(size_t)s * 4 + ja] = (den != 0.f) ? (K * num) * rd : 0.f;
+        const float dv = (den != 0.f) ? (K * num) * rd : 0.f;
+        if (ja >= 0) lead_d[(size_t)s * 4 + ja] = dv; else p.warm[(size_t)s * RES_WARM + (ja + RES_WARM)] = dv;
     }
+}
+
+// a ring's retune: the de-emphasis state in front of the block (libcsdr.c:1081-1097) from the RES_WARM samples k_wfm_lead has demodulated there with the old tables
+__global__ __launch_bounds__(64) void k_wfm_lead_state(const float *__restrict__ warm, float *__restrict__ state, int n_streams, float alpha)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_streams) return;
+    float y = 0.f;
+    for (int i = 0; i < RES_WARM; i++) y = alpha * warm[(size_t)s * RES_WARM + i] + (1 - alpha) * y;
+    state[s] = y;
 }
 
 } // namespace
@@ -813,7 +963,27 @@ int wfm_mfma_lead(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint
 {
     if (n_list <= 0 || n_lead <= 0) return 0;
     LeadParams lp; lp.D = D; lp.L = L; lp.F = F; lp.B = B; lp.j_first = j_first; lp.n_lead = n_lead; lp.tab_pitch = tab_pitch; lp.dtab_stride = 3072;
+    lp.ct_stride = 1; lp.head_pitch = SEQ_HEAD; lp.head_off = 512; lp.c_first = (B >> 10) - 1; lp.ja0 = 0; lp.warm = nullptr;
     hipLaunchKernelGGL(k_wfm_lead, dim3(n_lead, n_list), dim3(128), 0, st, in, in_pitch, head, d_taps, ctab, d_dtab, d_dtab_old, d_list, d_lead_d, lp);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
+// the same for a ring (csdr_amd_wfm_ring_set_rate): one table set and one seed sequence for all streams (ctab[0] = the chunk in front of the block), the samples in front of
+// the block = the previous slot's last 512 bytes per row
+// ctab[0] = chunk (B >> 10) - 4.  Also the RES_WARM audio samples in front of the block (old tables only) and from them the de-emphasis state there (d_state[stream]): a
+// ring's blocks carry no state, and the warm-up the grid would run over those samples uses the NEW weights.
+int wfm_mfma_lead_shared(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *prev, size_t two_T, const float *d_taps, const float2 *ctab, const float2 *d_dtab,
+                         const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, float *d_warm, float *d_state, float alpha,
+                         int D, int L, int F, long long B, long long j_first, int n_lead)
+{
+    if (n_list <= 0) return 0;
+    if (j_first < RES_WARM) return fail_msg(-3, "wfm ring: a retune needs %d audio samples in front of the block", RES_WARM);
+    LeadParams lp; lp.D = D; lp.L = L; lp.F = F; lp.B = B; lp.j_first = j_first; lp.n_lead = n_lead; lp.tab_pitch = 1; lp.dtab_stride = 0;
+    lp.ct_stride = 0; lp.head_pitch = in_pitch; lp.head_off = two_T - 512; lp.c_first = (B >> 10) - 4; lp.ja0 = -RES_WARM; lp.warm = d_warm;
+    hipLaunchKernelGGL(k_wfm_lead, dim3(n_lead + RES_WARM, n_list), dim3(128), 0, st, in, in_pitch, prev, d_taps, ctab, d_dtab, d_dtab_old, d_list, d_lead_d, lp);
+    CSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_wfm_lead_state, dim3((n_list + 63) / 64), dim3(64), 0, st, d_warm, d_state, n_list, alpha);
     CSDR_LAUNCH_CHECK();
     return 0;
 }
@@ -829,6 +999,7 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
     }
     SeqParams sp;
     memset((void *)&sp, 0, sizeof sp);
+    ResCtl no_res; memset((void *)&no_res, 0, sizeof no_res);
     sp.n_streams = n_streams; sp.B2 = 2 * B; sp.two_T = 2LL * T;
     sp.tile_first = j_first / 4; sp.n_tiles = (int)((j_first + n_audio - 1) / 4 - sp.tile_first + 1);
     sp.stride = dev.tile_stride_bytes; sp.win_off = dev.win_off_bytes; sp.scale = dev.seq_scale;
@@ -865,9 +1036,9 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
         const size_t ldsp = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float) + 2 * 48 * sizeof(float2);
         { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<true>, ldsp); if (arc) return arc; }
         if (ev_begin && ev_end)
-            hipExtLaunchKernelGGL(k_wfm_mfma_seq<true>, dim3(n_streams, n_seg), dim3(64 * SEQ_NW), ldsp, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+            hipExtLaunchKernelGGL(k_wfm_mfma_seq<true>, dim3(n_streams, n_seg), dim3(64 * SEQ_NW), ldsp, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp, no_res);
         else
-            hipLaunchKernelGGL(k_wfm_mfma_seq<true>, dim3(n_streams, n_seg), dim3(64 * SEQ_NW), ldsp, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+            hipLaunchKernelGGL(k_wfm_mfma_seq<true>, dim3(n_streams, n_seg), dim3(64 * SEQ_NW), ldsp, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp, no_res);
         CSDR_LAUNCH_CHECK();
         if (T < 256 || (T & 7)) {
             hipLaunchKernelGGL(k_wfm_roll_head, dim3(n_streams), dim3(256), 0, st, in, in_pitch, 2LL * T, back.head_in, back.head_out);
@@ -880,9 +1051,9 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
     // timing events ride on the kernel's own dispatch (start / completion signal of its packet): hipEventRecord in front of and behind it would put two
     // marker packets into the stream, ~10 us of bubbles that the un-profiled path does not have
     if (ev_begin && ev_end)
-        hipExtLaunchKernelGGL(k_wfm_mfma_seq<false>, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        hipExtLaunchKernelGGL(k_wfm_mfma_seq<false>, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, ev_begin, ev_end, 0, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp, no_res);
     else
-        hipLaunchKernelGGL(k_wfm_mfma_seq<false>, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp);
+        hipLaunchKernelGGL(k_wfm_mfma_seq<false>, dim3(n_wsb, n_seg), dim3(64 * SEQ_NW), lds, st, in, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab, ctab, sp, no_res);
     CSDR_LAUNCH_CHECK();
     if (T < 256 || (T & 7)) {      // a block shorter than the history, or a ragged last block: the kernel's epilogue skipped the copy
         hipLaunchKernelGGL(k_wfm_roll_head, dim3(n_streams), dim3(256), 0, st, in, in_pitch, 2LL * T, back.head_in, back.head_out);
@@ -890,6 +1061,30 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
     }
     return 0;
 }
+
+// The resident form: `grid` workgroups that walk the ring described by rv until they are told to stop, see nothing for rv.idle_ticks, or are older than rv.life_ticks
+// (k_wfm_mfma_seq<false, true>).  ev_end (may be null) is recorded behind the launch: it fires when the last workgroup has left.
+int wfm_mfma_launch_resident(hipStream_t st, hipEvent_t ev_end, const WfmMfmaDevice &dev, int n_streams, size_t in_pitch, float alpha, size_t out_pitch, const WfmResident &rv, int grid)
+{
+    if (in_pitch * 16 + 4096 >= ((size_t)1 << 32)) return fail_msg(-3, "wfm ring: in_pitch %zu too large (32-bit row offsets)", in_pitch);
+    SeqParams sp; memset((void *)&sp, 0, sizeof sp);
+    sp.n_streams = n_streams; sp.two_T = 2LL * rv.T; sp.stride = dev.tile_stride_bytes; sp.win_off = dev.win_off_bytes; sp.scale = dev.seq_scale;
+    sp.alpha = alpha; sp.out_pitch = out_pitch;
+    ResCtl rc; memset((void *)&rc, 0, sizeof rc);
+    rc.desc = rv.desc; rc.ctrl = rv.ctrl; rc.done = rv.done; rc.cnt = rv.cnt; rc.t_first = rv.t_first; rc.next_item = rv.next_item; rc.exiting = rv.exiting;
+    rc.in_ring = rv.in_ring; rc.out_ring = rv.out_ring; rc.in_slot_bytes = rv.in_slot_bytes; rc.out_slot_elems = rv.out_slot_elems;
+    rc.n_slots = rv.n_slots; rc.desc_lines = rv.desc_lines; rc.n_wsb = (n_streams + 15) / 16; rc.T = rv.T; rc.D = rv.D; rc.L = rv.L; rc.F = rv.F;
+    rc.idle_ticks = rv.idle_ticks; rc.life_ticks = rv.life_ticks; rc.lead_d = rv.lead_d; rc.lead_state = rv.lead_state;
+    if (rv.desc_lines < 1 || rv.desc_lines > 16) return fail_msg(-3, "wfm ring: %d descriptor lines", rv.desc_lines);
+    const size_t lds = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float) + 8 + (size_t)rv.desc_lines * 14 * sizeof(float);
+    { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<false, true>, lds); if (arc) return arc; }
+    hipLaunchKernelGGL((k_wfm_mfma_seq<false, true>), dim3(grid), dim3(64 * SEQ_NW), lds, st, (const uint8_t *)nullptr, in_pitch, (const v4i *)dev.d_seq_frags, dev.d_seq_cum, dev.d_dtab,
+                       (const float2 *)nullptr, sp, rc);
+    CSDR_LAUNCH_CHECK();
+    if (ev_end) CSDR_HIP(hipEventRecord(ev_end, st));
+    return 0;
+}
+int wfm_resident_max_grid() { return current_device_cu_count(); }      // one workgroup per CU: eight waves of up to 256 registers fill a CU's register files
 
 } // namespace csdr_amd
 

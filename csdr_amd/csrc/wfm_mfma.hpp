@@ -31,6 +31,22 @@ struct WfmBackArgs {
 // (seeds.hpp: ctab[k * tab_pitch + stream]); lead: the first audio samples of retuned streams, evaluated by wfm_mfma_lead
 struct WfmPerStream { size_t tab_pitch; int tab_len; const float *d_scales; const float *d_lead_d; const int *d_lead_n; };
 
+// the resident form (csdr_amd_wfm_ring_*, wfm_ring.hip): what the persistent grid of k_wfm_mfma_seq<false, true> walks
+struct WfmResident {
+    const uint32_t *desc, *ctrl; uint32_t *done;                      // host-coherent: descriptor lines, stop word, done lines
+    unsigned *cnt; unsigned long long *t_first, *next_item; unsigned *exiting;      // device
+    const uint8_t *in_ring; int16_t *out_ring; size_t in_slot_bytes, out_slot_elems;
+    int n_slots, desc_lines, T, D, L, F;
+    long long idle_ticks, life_ticks;
+    const float *lead_d, *lead_state;
+};
+constexpr int WFM_RES_WARM = 48;   // = RES_WARM (wfm_mfma.hip)
+int wfm_mfma_launch_resident(hipStream_t st, hipEvent_t ev_end, const WfmMfmaDevice &dev, int n_streams, size_t in_pitch, float alpha, size_t out_pitch, const WfmResident &rv, int grid);
+int wfm_resident_max_grid();
+int wfm_mfma_lead_shared(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *prev, size_t two_T, const float *d_taps, const float2 *ctab, const float2 *d_dtab,
+                         const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, float *d_warm, float *d_state, float alpha,
+                         int D, int L, int F, long long B, long long j_first, int n_lead);
+
 bool wfm_mfma_supported(int D, int L, int F);
 void wfm_mfma_build_table(int D, int L, int F, float shift_rate, const float *taps, WfmMfmaTable &t);
 size_t wfm_mfma_head_bytes(int n_streams);

@@ -415,6 +415,51 @@ int csdr_amd_wfm_fallback(const csdr_amd_wfm *w);
 int csdr_amd_wfm_set_profiling(csdr_amd_wfm *w, int on);
 int csdr_amd_wfm_kernel_time(csdr_amd_wfm *w, double *total_ms, long *launches);
 
+/* ------------------------------------------------------------------ the RESIDENT form of the fused WFM chain: a persistent grid walking a ring of blocks
+ * (north_star: "a persistent-kernel ring buffer so the stdin->stdout pipe never round-trips to host between stages").  The reference's unit of work is one
+ * the_bufsize block -- 16384 samples -- per loop iteration of every stage (csdr.c:189-193, 232-247, 330-392); a kernel launch per such block spends most of its time
+ * outside the data (launch gap, kernel entry, the de-emphasis warm-up of the time segments a short call is cut into).  A ring object owns
+ *     an input ring   [n_slots][n_streams][pitch]  u8 IQ in device memory  -- block seq of every stream lies in slot seq mod n_slots,
+ *     an output ring  [n_slots][n_streams][pitch]  s16 audio in device memory,
+ * and ONE grid that stays on the GPU, polls block descriptors in host memory (no launch, no stream operation per block) and tells the host through a done word
+ * per slot.  Same arithmetic and the same samples as csdr_amd_wfm_process on the same stream cut into the same blocks (tests/test_ring_gpu.py: >= 1000 consecutive
+ * 16384-sample blocks with a retune in the middle against the oracle).  Protocol per block:
+ *     seq = csdr_amd_wfm_ring_submitted(r);
+ *     csdr_amd_wfm_ring_acquire(r, seq, 0);                      -- waits until slot seq mod n_slots may be overwritten (blocks seq - n_slots and seq - n_slots + 1 finished:
+ *                                                                   a block's input stays the NEXT block's history)
+ *     write [n_streams][2 block_samples] bytes to csdr_amd_wfm_ring_input(r, seq, &pitch)   (any producer: hipMemcpy, a kernel, a peer through HIP IPC) and complete it;
+ *     csdr_amd_wfm_ring_submit(r);                               -- posts the block (a store to host memory; relaunches the grid if it has left)
+ *     n = csdr_amd_wfm_ring_wait(r, seq, 0);                     -- audio samples per stream of that block, in csdr_amd_wfm_ring_output(r, seq, &pitch); valid until
+ *                                                                   block seq + n_slots is posted.  Up to n_slots - 2 blocks may be in flight.
+ * The grid never holds the GPU against a silent host: it leaves by itself when no block arrived for idle_us (default 200) or when it is older than life_ms (default
+ * 250), and is relaunched by the next submit / wait; no state lives in it (every block warms its de-emphasis up over the 48 audio samples in front of it).  While it is
+ * resident it occupies every CU it runs on (one workgroup per CU): other kernels of the process wait for it to leave.
+ * block_samples: a multiple of 1024, 4096 .. 65536.  Retune: csdr.c:881-923 semantics (from the next posted block's first sample, phase carried). */
+typedef struct csdr_amd_wfm_ring csdr_amd_wfm_ring;
+csdr_amd_wfm_ring *csdr_amd_wfm_ring_create(csdr_amd_ctx *ctx, int n_streams, float shift_rate, int decimation, const float *host_taps, int taps_length, int frac_rate,
+                                            float tau, int audio_rate, size_t block_samples, int n_slots);
+void csdr_amd_wfm_ring_destroy(csdr_amd_wfm_ring *r);
+int  csdr_amd_wfm_ring_reset(csdr_amd_wfm_ring *r);                                    /* stream start: block 0 next, phase 0 */
+int  csdr_amd_wfm_ring_acquire(csdr_amd_wfm_ring *r, long long seq, double timeout_s);  /* timeout_s <= 0: 10 s */
+uint8_t *csdr_amd_wfm_ring_input(csdr_amd_wfm_ring *r, long long seq, size_t *pitch_bytes);
+long long csdr_amd_wfm_ring_submit(csdr_amd_wfm_ring *r);                              /* returns the block's sequence number, < 0 on error */
+long csdr_amd_wfm_ring_wait(csdr_amd_wfm_ring *r, long long seq, double timeout_s);    /* audio samples per stream, < 0 on error / timeout */
+const int16_t *csdr_amd_wfm_ring_output(csdr_amd_wfm_ring *r, long long seq, size_t *pitch_samples);
+int  csdr_amd_wfm_ring_set_rate(csdr_amd_wfm_ring *r, float shift_rate);               /* drains the ring, rebuilds the weight set; from the next posted block on */
+float csdr_amd_wfm_ring_get_rate(const csdr_amd_wfm_ring *r);
+int  csdr_amd_wfm_ring_set_timeouts(csdr_amd_wfm_ring *r, double idle_us, double life_ms);
+int  csdr_amd_wfm_ring_resident(csdr_amd_wfm_ring *r);                                 /* 1 while the grid is on the GPU */
+int  csdr_amd_wfm_ring_stop(csdr_amd_wfm_ring *r);                                     /* asks the grid to leave and waits for it (posted blocks are finished first) */
+int  csdr_amd_wfm_ring_slots(const csdr_amd_wfm_ring *r);
+int  csdr_amd_wfm_ring_grid(const csdr_amd_wfm_ring *r);                               /* workgroups of the resident grid */
+long csdr_amd_wfm_ring_launches(const csdr_amd_wfm_ring *r);                           /* launches of the grid so far */
+long long csdr_amd_wfm_ring_submitted(const csdr_amd_wfm_ring *r);
+/* benchmark / soak aid: posts n_blocks blocks whose inputs are what lies in the ring's slots, as fast as the ring takes them, waits for the last one; t_first_us /
+ * t_done_us (NULL or n_blocks doubles) receive every block's start / completion on the device clock */
+int  csdr_amd_wfm_ring_replay(csdr_amd_wfm_ring *r, long n_blocks, double *t_first_us, double *t_done_us);
+/* device clock (microseconds, arbitrary origin) at which the first workgroup took an item of block seq and at which its last item was finished */
+int  csdr_amd_wfm_ring_block_times(csdr_amd_wfm_ring *r, long long seq, double *t_first_us, double *t_done_us);
+
 /* ------------------------------------------------------------------ fused receiver front end (head of the NFM / AM / SSB chains, BASELINE config 5)
  * README.md:87, 95, 110:  convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw window
  * (libcsdr.c:2363-2368, libcsdr_gpl.c:27-52 in the CLI's 1024-sample chunks csdr.c:911-918, libcsdr.c:528-549 with the CLI's re-feed loop
