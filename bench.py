@@ -16,8 +16,8 @@ oracle after it, and 16 rows of the noise batch spread over all stream blocks go
 --strict-rows-only drops the noise rows; --no-verify skips).  The exit code is non-zero when the headline OR any operating point OR any other config's leg fails its
 verify or crashes ("all_legs_verified").  At N = 1 the line also
 carries the other BASELINE configs as short legs of their own bench scripts ("other_configs": C1 fir_decimate_cc, C3 at 1023 and 4095 taps, C4 fastddc, C5 NFM with a
-rate per channel -- each with its own verify) and two short-block operating points of this chain ("operating_points": the reference's 16384-sample block, and 65536
-streams x 10 ms), so that every config's number exists on the driver's clock.
+rate per channel -- each with its own verify) and short-block operating points of this chain ("operating_points": the reference's 16384-sample block -- one launch per
+block, and through the resident ring csdr_amd_wfm_ring_* --, and 65536 streams x 10 ms), so that every config's number exists on the driver's clock.
 
 N > 1: launched by torch.distributed.run, one rank per GPU; streams are independent, so ranks share nothing on
 the data path (replicas of the per-GPU workload, "scaling": "weak"); barrier + max-over-ranks timing over RCCL.
@@ -145,6 +145,63 @@ def operating_points(ctx, taps, verify=True, only=None):
         L.csdr_amd_wfm_destroy(w)
         del x, out; torch.cuda.empty_cache()
     return pts
+
+
+def resident_point(ctx, taps, verify=True, S=1024, T=16384, n_slots=8, blocks=4000):
+    """The reference's own block (16384 samples per read, csdr.c:189-193, 330-392) through the RESIDENT form of the chain (csdr_amd_wfm_ring_*: one persistent grid walks
+    a ring of blocks, no launch per block): `blocks` consecutive blocks of S streams posted as fast as the ring takes them (inputs resident in the ring's slots).  Time per
+    block from the DEVICE clock: completion of the last block minus completion of the first timed one, over the blocks between (there is no kernel launch to put events
+    around); the host's wall clock beside it."""
+    import numpy as np
+    import torch
+    L = ctx.L
+    r = L.csdr_amd_wfm_ring_create(ctx.h, S, -0.085, 10, taps.ctypes.data_as(C.c_void_p), taps.size, 5, 50e-6, 48000, T, n_slots)
+    if not r:
+        return {"streams": S, "block_samples_per_stream": T, "resident": True, "error": ctx.err()}
+    try:
+        pitch = C.c_size_t(0)
+        x = torch.randint(0, 256, (S, 2 * T), dtype=torch.uint8, device="cuda")
+        for k in range(n_slots):
+            pi = L.csdr_amd_wfm_ring_input(r, k, C.byref(pitch))
+            blk = torch.zeros((S, pitch.value), dtype=torch.uint8, device="cuda"); blk[:, :2 * T] = x
+            torch.cuda.synchronize()
+            if L.csdr_amd_d2d(ctx.h, pi, blk.data_ptr(), blk.numel()) or L.csdr_amd_ctx_sync(ctx.h):
+                return {"streams": S, "block_samples_per_stream": T, "resident": True, "error": ctx.err()}
+        del x, blk; torch.cuda.empty_cache(); torch.cuda.synchronize()
+        if L.csdr_amd_wfm_ring_replay(r, blocks // 4, None, None):                     # warm-up (clocks, first launch)
+            return {"streams": S, "block_samples_per_stream": T, "resident": True, "error": ctx.err()}
+        td = np.zeros(blocks, np.float64); tf = np.zeros(blocks, np.float64)
+        l0 = L.csdr_amd_wfm_ring_launches(r)
+        t0 = time.perf_counter()
+        rc = L.csdr_amd_wfm_ring_replay(r, blocks, tf.ctypes.data_as(C.c_void_p), td.ctypes.data_as(C.c_void_p))
+        wall = time.perf_counter() - t0
+        if rc:
+            return {"streams": S, "block_samples_per_stream": T, "resident": True, "error": ctx.err()}
+        skip = 2 * n_slots
+        per_block_us = (td[-1] - td[skip]) / (blocks - 1 - skip)
+        algo = ALGO_BYTES_PER_SAMPLE * S * T
+        e = {"streams": S, "shift_rates": "one for all", "block_samples_per_stream": T, "block_ms_of_signal": round(T / 2400.0, 2), "resident": True,
+             "steps": blocks, "ms_per_step": round(wall / blocks * 1e3, 5), "value": round(S * T * blocks / wall / 1e6, 1), "unit": "complex MS/s",
+             "realtime_factor_per_stream": round((T / 2.4e6) / (wall / blocks), 1),
+             "kernel": "k_wfm_mfma_seq<false, true> (resident grid of %d workgroups, %d slots; %d launches during the %d timed blocks)"
+                       % (L.csdr_amd_wfm_ring_grid(r), n_slots, L.csdr_amd_wfm_ring_launches(r) - l0, blocks),
+             "kernel_avg_ms": round(per_block_us * 1e-3, 5), "kernel_time": "device clock, completion to completion per block (no launch to time)",
+             "block_latency_us_median": round(float(np.median(td - tf)), 2),
+             "frac": round(algo / (per_block_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "fallback": False}
+        st = np.zeros(4, np.float64)
+        if L.csdr_amd_wfm_ring_stats(r, st.ctypes.data_as(C.c_void_p)) == 0:
+            e["us_per_item_waiting_body_completion"] = [round(float(v), 2) for v in st[:3]]
+        if verify:
+            if os.path.join(ROOT, "tests") not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import verify_configs as vc
+            v = vc.verify_wfm_ring(ctx, r, S, T, taps)
+            e["verify_ok"] = v["ok"]
+            e["verify"] = {k: v[k] for k in ("blocks", "samples_compared", "frac_nonzero", "frac_over_1_lsb", "strict_rows", "strict_rows_max_abs_diff_lsb", "strict_rows_samples_compared",
+                                             "rows_expected_len", "rows_got_len")}
+        return e
+    finally:
+        L.csdr_amd_wfm_ring_destroy(r)
 
 
 def main():
@@ -295,6 +352,7 @@ def main():
             L.csdr_amd_wfm_destroy(w); w = None
             del x, out_s16; torch.cuda.empty_cache()
             res["operating_points"] = operating_points(ctx, taps, verify=do_verify)
+            res["operating_points"].append(resident_point(ctx, taps, verify=do_verify))
             res["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -205,6 +205,7 @@ def lib():
     L.csdr_amd_wfm_ring_submitted.restype = ll; L.csdr_amd_wfm_ring_submitted.argtypes = [vp]
     L.csdr_amd_wfm_ring_block_times.argtypes = [vp, ll, C.POINTER(db), C.POINTER(db)]
     L.csdr_amd_wfm_ring_replay.argtypes = [vp, C.c_long, vp, vp]
+    L.csdr_amd_wfm_ring_stats.argtypes = [vp, vp]
     L.csdr_amd_wfm_set_profiling.argtypes = [vp, i]
     L.csdr_amd_wfm_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.csdr_amd_ddc_create.restype = vp; L.csdr_amd_ddc_create.argtypes = [vp, i, fl, i, vp, i, sz]

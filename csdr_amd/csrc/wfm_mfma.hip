@@ -273,6 +273,8 @@ struct ResCtl {
     long long idle_ticks, life_ticks;
     const float *lead_d;                   // [n_streams][4]: a retuned stream's first audio samples of the block (k_wfm_lead)
     const float *lead_state;               // [n_streams]: the de-emphasis state in front of the first block behind a retune
+    unsigned long long *stats;             // device [grid][4]: ticks spent waiting for a block, in the body, in the completion; items (accumulated over launches)
+    int fence_mode;                        // experiments: 0 = write-through stores, no fence (default), 3 = plus one system fence per item, 2 = plus one by every thread
 };
 __device__ __forceinline__ uint32_t sys_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ uint32_t res_tag(long long k) { return (uint32_t)((unsigned long long)k % 0xfffffffeull) + 1u; }
@@ -316,7 +318,28 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     long long res_t_launch = 0;
     uint32_t *const rctl = reinterpret_cast<uint32_t *>(ctl);                        // RES: [0] = go / leave, [1] = lead samples
     const float2 *const lseed = ctl + 1;                                             // RES: seeds of chunks first_chunk - 4 ...
-    if constexpr (RES) { item = rc.next_item[blockIdx.x]; res_t_launch = wall_clock64(); }
+    long long st_wait = 0, st_body = 0, st_done = 0, st_items = 0, st_t = 0;        // RES: thread 0's clock readings
+    if constexpr (RES) { item = rc.next_item[blockIdx.x]; res_t_launch = wall_clock64(); st_t = res_t_launch; }
+    // RES, thread 0: the previous item's completion in flight (its count returns while the next block's descriptor is polled); wave 0: the next descriptor's lines
+    bool pend = false; unsigned pend_c = 0; int pend_slot = 0, pend_n = 0; long long pend_k = 0;
+    uint32_t pre_v[4] = {0u, 0u, 0u, 0u}; bool pre_valid = false;
+    auto res_complete = [&]() {
+        if constexpr (RES) {
+            if (tid == 0 && pend) {
+                pend = false;
+                if (pend_c + 1 == (unsigned)rc.n_wsb) {                              // this workgroup completed the block: every item's audio is in memory (write-through stores, waited for)
+                    const unsigned long long tf = __hip_atomic_exchange(rc.t_first + pend_slot, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), td = (unsigned long long)wall_clock64();
+                    __hip_atomic_store(rc.cnt + pend_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t *dn = rc.done + (size_t)pend_slot * 16;
+                    __hip_atomic_store(dn + 1, (uint32_t)pend_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dn + 2, (uint32_t)tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dn + 3, (uint32_t)(tf >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(dn + 4, (uint32_t)td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dn + 5, (uint32_t)(td >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the line's fields have left before its tag does
+                    __hip_atomic_store(dn, res_tag(pend_k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    };
     for (;;) {                                                                       // (not RES: one pass)
     int res_slot = 0, res_lead = 0; long long res_k = 0; bool res_retuned = false;
     const uint8_t *pblock = nullptr;                                                 // RES: the previous block's rows of this stream group (what lies in front of the block)
@@ -329,16 +352,22 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             const int nd = rc.desc_lines * 16;
             const long long t_wait = wall_clock64();
             uint32_t state = 0;
-            for (;;) {
-                uint32_t v[4] = {0u, 0u, 0u, 0u};
+            for (bool first = true;; first = false) {
+                uint32_t v[4];
+                if (first && pre_valid) {                                            // the lines this wave asked for while the previous item's audio was on its way out
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = pre_v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int d = lane + 64 * j; v[j] = d < nd ? sys_load(dsc + d) : 0u; }
+                }
+                const uint32_t ex = __hip_atomic_load(rc.exiting, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t stop = sys_load(rc.ctrl);
+                res_complete();                                                      // the previous item's count has come back by now: the block's done line, if it was the last
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int d = lane + 64 * j;
-                    if (d < nd) { v[j] = sys_load(dsc + d); if ((d & 15) == 0 && v[j] != tag) ok = false; }
-                }
+                for (int j = 0; j < 4; j++) { const int d = lane + 64 * j; if (d < nd && (d & 15) == 0 && v[j] != tag) ok = false; }
                 const bool ready = __all(ok);
-                const uint32_t ex = __hip_atomic_load(rc.exiting, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const long long now = wall_clock64();
                 const bool old = now - res_t_launch > rc.life_ticks;
                 if (ready && !ex && !old) {
@@ -350,17 +379,22 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                     }
                     state = 1; break;
                 }
-                const uint32_t stop = sys_load(rc.ctrl);
                 if (ex || old || stop || now - t_wait > rc.idle_ticks) { state = 2; break; }
                 __builtin_amdgcn_s_sleep(24);
             }
+            pre_valid = false;
             if (lane == 0) rctl[0] = state;
         }
         __syncthreads();
         if (rctl[0] != 1u) {
-            if (tid == 0) { __hip_atomic_store(rc.exiting, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc.next_item[blockIdx.x] = item; }
+            if (tid == 0) {
+                __hip_atomic_store(rc.exiting, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rc.next_item[blockIdx.x] = item;
+                unsigned long long *sp = rc.stats + (size_t)blockIdx.x * 4;
+                sp[0] += (unsigned long long)st_wait; sp[1] += (unsigned long long)st_body; sp[2] += (unsigned long long)st_done; sp[3] += (unsigned long long)st_items;
+            }
             return;
         }
+        if (tid == 0) { const long long t = wall_clock64(); st_wait += t - st_t; st_t = t; }
         res_lead = (int)(rctl[1] & 0xffu); res_retuned = (rctl[1] >> 8) & 1u;
         // the block's geometry (what csdr_amd_wfm_process derives on the host, wfm.hip): audio samples that become computable with block k
         auto j_hi = [&](long long kk) -> long long {
@@ -376,7 +410,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
         p_res.tile_first = p_res.j_first / 4; p_res.n_tiles = (int)((p_res.j_first + p_res.n_audio - 1) / 4 - p_res.tile_first + 1);
         p_res.tiles_per_seg = p_res.n_tiles;
         p_res.s16 = rc.out_ring + (size_t)res_slot * rc.out_slot_elems;
-        if (tid == 0) atomicMin(rc.t_first + res_slot, (unsigned long long)wall_clock64());
+        if (tid == 0) (void)__hip_atomic_fetch_min(rc.t_first + res_slot, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int sb = RES ? (int)(item % (unsigned)rc.n_wsb) : (int)blockIdx.x;         // block of 16 streams; PS: the stream
     const int seg_y = RES ? 0 : (int)blockIdx.y;                                      // time segment of the call (RES: a block is one segment)
@@ -577,6 +611,17 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
     // Lines cut by the call's first / last sample or the segment's ends, and every line when the float audio is wanted too, are stored at once.
     const bool emit_vec = ((((size_t)p.s16 | (size_t)p.af) & 15) == 0) && (p.out_pitch & 7) == 0;
     const int emit_a = (int)((SEQ_LINE - (idx0 & (SEQ_LINE - 1))) & (SEQ_LINE - 1));  // segment samples n = emit_a (mod 64) start a line
+    // RES: the audio is stored WRITE-THROUGH (sc0 sc1: system scope), so that "every store acknowledged" means "in memory" and an item can be counted in without writing
+    // the XCD's L2 back (one such write-back per item cost 4-8 us of every workgroup's 50: profiles/r6_notes.md)
+    typedef unsigned wfm_st4 __attribute__((ext_vector_type(4)));
+    auto put16 = [&](int16_t *dst, unsigned a, unsigned b, unsigned c, unsigned d) __attribute__((always_inline)) {
+        if constexpr (RES) { const wfm_st4 v = {a, b, c, d}; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory"); }
+        else *reinterpret_cast<uint4 *>(dst) = make_uint4(a, b, c, d);
+    };
+    auto put2 = [&](int16_t *dst, int v) __attribute__((always_inline)) {
+        if constexpr (RES) asm volatile("global_store_short %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+        else *dst = (int16_t)v;
+    };
     auto s16_of = [](float e) { const float scaled = e * 32767.0f; return (scaled >= -2147483648.0f && scaled < 2147483648.0f) ? (int)scaled : (int)0x80000000; };
     // rows or pitches that are not 16-byte aligned: sample by sample, by the compute waves except wave 0 (which runs the de-emphasis)
     constexpr int EMIT_T0 = 64, EMIT_N = 64 * (TPG - 1);
@@ -625,7 +670,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 WFM_ST_ALL(X)
 #undef X
             } else {
-#define X(j) if (j < NST && j < n_st && row_ok) *reinterpret_cast<uint4 *>(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc)) = make_uint4(st##j[0], st##j[1], st##j[2], st##j[3]);
+#define X(j) if (j < NST && j < n_st && row_ok) put16(orow + (idx0 + st_n0 + SEQ_LINE * j + 8 * pc), st##j[0], st##j[1], st##j[2], st##j[3]);
                 WFM_ST_ALL(X)
 #undef X
             }
@@ -659,12 +704,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 const size_t o = (size_t)(idx0 + n0);                                // (may wrap below zero in front of a cut line's first valid sample: never dereferenced there)
                 float *const arow = p.af ? p.af + row_at : nullptr;
                 if (n0 >= lo_r && n0 + 8 <= hi_r) {
-                    *reinterpret_cast<uint4 *>(orow + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    put16(orow + o, w[0], w[1], w[2], w[3]);
                     if (arow) { *reinterpret_cast<float4 *>(arow + o) = make_float4(e[0], e[1], e[2], e[3]); *reinterpret_cast<float4 *>(arow + o + 4) = make_float4(e[4], e[5], e[6], e[7]); }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; i++)
-                        if (n0 + i >= lo_r && n0 + i < hi_r) { orow[o + i] = (int16_t)v[i]; if (arow) arow[o + i] = e[i]; }
+                        if (n0 + i >= lo_r && n0 + i < hi_r) { put2(orow + (o + i), v[i]); if (arow) arow[o + i] = e[i]; }
                 }
             }
         };
@@ -872,22 +917,28 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
 #endif
     if constexpr (!RES) break;
     else {
-        // the item's audio is on its way: make it visible beyond this XCD's L2, count the item in; whoever completes the block tells the host
-        __threadfence_system();
+        // The item's audio is on its way (write-through stores: put16 / put2): once every wave's stores are acknowledged the item is counted in; the count comes
+        // back while wave 0 polls the next block's descriptor (res_complete), whose lines it asks for NOW -- the round trip over PCIe runs beside the loaders' last stores.
+        if (tid == 0) { const long long t = wall_clock64(); st_body += t - st_t; st_t = t; }
+        if (wv == 0) {
+            const unsigned long long nx = item + gridDim.x;
+            const long long nk = (long long)(nx / (unsigned)rc.n_wsb);
+            const uint32_t *dsc = rc.desc + (size_t)(nk % rc.n_slots) * rc.desc_lines * 16;
+            const int nd = rc.desc_lines * 16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int d = lane + 64 * j; pre_v[j] = d < nd ? sys_load(dsc + d) : 0u; }
+            pre_valid = true;
+        }
+        if (rc.fence_mode == 2) __threadfence_system();
+        if (wv != 0 || !emit_vec) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0 stores nothing on the vector path: it need not wait for its descriptor lines here)
         __syncthreads();
         if (tid == 0) {
-            const unsigned c = __hip_atomic_fetch_add(rc.cnt + res_slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (c + 1 == (unsigned)rc.n_wsb) {
-                const unsigned long long tf = __hip_atomic_exchange(rc.t_first + res_slot, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), td = (unsigned long long)wall_clock64();
-                __hip_atomic_store(rc.cnt + res_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t *dn = rc.done + (size_t)res_slot * 16;
-                __hip_atomic_store(dn + 1, (uint32_t)p.n_audio, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(dn + 2, (uint32_t)tf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dn + 3, (uint32_t)(tf >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(dn + 4, (uint32_t)td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(dn + 5, (uint32_t)(td >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(dn, res_tag(res_k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            if (rc.fence_mode == 3) __threadfence_system();                          // (experiment switch: the L2 write-back that plain stores would need)
+            pend_c = __hip_atomic_fetch_add(rc.cnt + res_slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend = true; pend_slot = res_slot; pend_n = p.n_audio; pend_k = res_k;
         }
         item += gridDim.x;
+        if (tid == 0) { const long long t = wall_clock64(); st_done += t - st_t; st_t = t; st_items++; }
     }
     }
 }
@@ -1074,7 +1125,7 @@ int wfm_mfma_launch_resident(hipStream_t st, hipEvent_t ev_end, const WfmMfmaDev
     rc.desc = rv.desc; rc.ctrl = rv.ctrl; rc.done = rv.done; rc.cnt = rv.cnt; rc.t_first = rv.t_first; rc.next_item = rv.next_item; rc.exiting = rv.exiting;
     rc.in_ring = rv.in_ring; rc.out_ring = rv.out_ring; rc.in_slot_bytes = rv.in_slot_bytes; rc.out_slot_elems = rv.out_slot_elems;
     rc.n_slots = rv.n_slots; rc.desc_lines = rv.desc_lines; rc.n_wsb = (n_streams + 15) / 16; rc.T = rv.T; rc.D = rv.D; rc.L = rv.L; rc.F = rv.F;
-    rc.idle_ticks = rv.idle_ticks; rc.life_ticks = rv.life_ticks; rc.lead_d = rv.lead_d; rc.lead_state = rv.lead_state;
+    rc.idle_ticks = rv.idle_ticks; rc.life_ticks = rv.life_ticks; rc.lead_d = rv.lead_d; rc.lead_state = rv.lead_state; rc.stats = rv.stats; rc.fence_mode = rv.fence_mode;
     if (rv.desc_lines < 1 || rv.desc_lines > 16) return fail_msg(-3, "wfm ring: %d descriptor lines", rv.desc_lines);
     const size_t lds = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float) + 8 + (size_t)rv.desc_lines * 14 * sizeof(float);
     { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<false, true>, lds); if (arc) return arc; }

@@ -39,6 +39,7 @@ struct WfmResident {
     int n_slots, desc_lines, T, D, L, F;
     long long idle_ticks, life_ticks;
     const float *lead_d, *lead_state;
+    unsigned long long *stats; int fence_mode;
 };
 constexpr int WFM_RES_WARM = 48;   // = RES_WARM (wfm_mfma.hip)
 int wfm_mfma_launch_resident(hipStream_t st, hipEvent_t ev_end, const WfmMfmaDevice &dev, int n_streams, size_t in_pitch, float alpha, size_t out_pitch, const WfmResident &rv, int grid);

@@ -42,7 +42,7 @@ struct csdr_amd_wfm_ring {
     uint8_t *d_in; int16_t *d_out;
     uint32_t *h_block;                 // host-coherent: [desc: N * lines * 16][ctrl: 16][done: N * 16]
     uint32_t *h_desc, *h_ctrl, *h_done;
-    unsigned *d_cnt, *d_exiting; unsigned long long *d_tfirst, *d_next;
+    unsigned *d_cnt, *d_exiting; unsigned long long *d_tfirst, *d_next, *d_stats; int fence_mode;
     hipStream_t rs; hipEvent_t ev_exit;
     bool launched;
     long long submitted;               // blocks posted so far (the next block's sequence number)
@@ -76,7 +76,7 @@ static int ring_ensure_running(csdr_amd_wfm_ring *r)
     rv.desc = r->h_desc; rv.ctrl = r->h_ctrl; rv.done = r->h_done; rv.cnt = r->d_cnt; rv.t_first = r->d_tfirst; rv.next_item = r->d_next; rv.exiting = r->d_exiting;
     rv.in_ring = r->d_in; rv.out_ring = r->d_out; rv.in_slot_bytes = (size_t)r->S * r->in_pitch; rv.out_slot_elems = (size_t)r->S * r->out_pitch;
     rv.n_slots = r->N; rv.desc_lines = r->lines; rv.T = r->T; rv.D = r->D; rv.L = r->L; rv.F = r->F;
-    rv.idle_ticks = r->idle_ticks; rv.life_ticks = r->life_ticks; rv.lead_d = r->d_lead_d; rv.lead_state = r->d_state;
+    rv.idle_ticks = r->idle_ticks; rv.life_ticks = r->life_ticks; rv.lead_d = r->d_lead_d; rv.lead_state = r->d_state; rv.stats = r->d_stats; rv.fence_mode = r->fence_mode;
     CSDR_HIP(hipMemsetAsync(r->d_exiting, 0, sizeof(unsigned), r->rs));
     const int rc = wfm_mfma_launch_resident(r->rs, r->ev_exit, r->mfma, r->S, r->in_pitch, r->alpha, r->out_pitch, rv, r->grid);
     if (rc) return rc;
@@ -130,7 +130,7 @@ void csdr_amd_wfm_ring_destroy(csdr_amd_wfm_ring *r)
     if (r->rs) { (void)ring_stop(r); (void)hipStreamSynchronize(r->rs); }
     (void)hipFree(r->mfma.d_seq_frags); (void)hipFree(r->mfma.d_seq_cum); (void)hipFree(r->mfma.d_dtab); (void)hipFree(r->d_dtab_old);
     (void)hipFree(r->d_taps); (void)hipFree(r->d_lead_seeds); (void)hipFree(r->d_lead_d); (void)hipFree(r->d_warm); (void)hipFree(r->d_state); (void)hipFree(r->d_list);
-    (void)hipFree(r->d_in); (void)hipFree(r->d_out); (void)hipFree(r->d_cnt); (void)hipFree(r->d_exiting); (void)hipFree(r->d_tfirst); (void)hipFree(r->d_next);
+    (void)hipFree(r->d_in); (void)hipFree(r->d_out); (void)hipFree(r->d_cnt); (void)hipFree(r->d_exiting); (void)hipFree(r->d_tfirst); (void)hipFree(r->d_next); (void)hipFree(r->d_stats);
     if (r->h_block) (void)hipHostFree(r->h_block);
     if (r->ev_exit) (void)hipEventDestroy(r->ev_exit);
     if (r->rs) (void)hipStreamDestroy(r->rs);
@@ -144,6 +144,7 @@ int csdr_amd_wfm_ring_reset(csdr_amd_wfm_ring *r)
     memset(r->h_block, 0, sizeof(uint32_t) * ((size_t)r->N * r->lines * 16 + 16 + (size_t)r->N * 16));
     CSDR_HIP(hipMemset(r->d_cnt, 0, sizeof(unsigned) * r->N));
     CSDR_HIP(hipMemset(r->d_tfirst, 0xff, sizeof(unsigned long long) * r->N));
+    CSDR_HIP(hipMemset(r->d_stats, 0, sizeof(unsigned long long) * 4 * r->grid));
     std::vector<unsigned long long> ni(r->grid);
     for (int w = 0; w < r->grid; w++) ni[w] = (unsigned long long)w;
     CSDR_HIP(hipMemcpy(r->d_next, ni.data(), sizeof(unsigned long long) * r->grid, hipMemcpyHostToDevice));
@@ -176,7 +177,7 @@ csdr_amd_wfm_ring *csdr_amd_wfm_ring_create(csdr_amd_ctx *ctx, int n_streams, fl
     r->grid = (int)(want < wfm_resident_max_grid() ? want : wfm_resident_max_grid());
     { const char *g = getenv("CSDR_AMD_RING_GRID"); if (g && atoi(g) > 0 && atoi(g) < r->grid) r->grid = atoi(g); }
     r->d_taps = nullptr; r->d_dtab_old = nullptr; r->d_lead_seeds = nullptr; r->d_lead_d = nullptr; r->d_warm = nullptr; r->d_state = nullptr; r->d_list = nullptr; r->d_in = nullptr; r->d_out = nullptr;
-    r->h_block = nullptr; r->d_cnt = nullptr; r->d_exiting = nullptr; r->d_tfirst = nullptr; r->d_next = nullptr; r->rs = nullptr; r->ev_exit = nullptr;
+    r->h_block = nullptr; r->d_cnt = nullptr; r->d_exiting = nullptr; r->d_tfirst = nullptr; r->d_next = nullptr; r->d_stats = nullptr; r->fence_mode = getenv("CSDR_AMD_RING_FENCE") ? atoi(getenv("CSDR_AMD_RING_FENCE")) : 0; r->rs = nullptr; r->ev_exit = nullptr;
     r->launched = false; r->launches = 0; r->submitted = 0; r->pending_lead = false;
     int khz = 100000; if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
     r->clock_khz = khz;
@@ -196,6 +197,7 @@ csdr_amd_wfm_ring *csdr_amd_wfm_ring_create(csdr_amd_ctx *ctx, int n_streams, fl
     alloc((void **)&r->d_exiting, sizeof(unsigned));
     alloc((void **)&r->d_tfirst, sizeof(unsigned long long) * n_slots);
     alloc((void **)&r->d_next, sizeof(unsigned long long) * r->grid);
+    alloc((void **)&r->d_stats, sizeof(unsigned long long) * 4 * r->grid);
     const size_t hwords = (size_t)n_slots * r->lines * 16 + 16 + (size_t)n_slots * 16;
     if (e == hipSuccess) e = hipHostMalloc((void **)&r->h_block, sizeof(uint32_t) * hwords, hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->rs, hipStreamNonBlocking);
@@ -388,5 +390,19 @@ int csdr_amd_wfm_ring_set_rate(csdr_amd_wfm_ring *r, float shift_rate)
 }
 
 float csdr_amd_wfm_ring_get_rate(const csdr_amd_wfm_ring *r) { return r->rate; }
+
+// Where the grid's time went since the last reset (stops the grid to read its counters): microseconds per work item spent waiting for a block, in the chain's body,
+// in the completion (write-back, counting in), averaged over all workgroups; out[3] = items.
+int csdr_amd_wfm_ring_stats(csdr_amd_wfm_ring *r, double out[4])
+{
+    int rc = ring_stop(r); if (rc) return rc;
+    std::vector<unsigned long long> st((size_t)4 * r->grid);
+    CSDR_HIP(hipMemcpy(st.data(), r->d_stats, sizeof(unsigned long long) * st.size(), hipMemcpyDeviceToHost));
+    unsigned long long sum[4] = {0, 0, 0, 0};
+    for (int w = 0; w < r->grid; w++) for (int i = 0; i < 4; i++) sum[i] += st[(size_t)4 * w + i];
+    for (int i = 0; i < 3; i++) out[i] = sum[3] ? (double)sum[i] * 1000.0 / r->clock_khz / (double)sum[3] : 0.0;
+    out[3] = (double)sum[3];
+    return 0;
+}
 
 } // extern "C"

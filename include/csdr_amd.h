@@ -454,6 +454,9 @@ int  csdr_amd_wfm_ring_slots(const csdr_amd_wfm_ring *r);
 int  csdr_amd_wfm_ring_grid(const csdr_amd_wfm_ring *r);                               /* workgroups of the resident grid */
 long csdr_amd_wfm_ring_launches(const csdr_amd_wfm_ring *r);                           /* launches of the grid so far */
 long long csdr_amd_wfm_ring_submitted(const csdr_amd_wfm_ring *r);
+/* where the grid's time went since the last reset (stops the grid): out[0..2] = microseconds per work item (block x 16-stream group) spent waiting for a block, in the
+ * chain's body, in the completion; out[3] = items */
+int  csdr_amd_wfm_ring_stats(csdr_amd_wfm_ring *r, double out[4]);
 /* benchmark / soak aid: posts n_blocks blocks whose inputs are what lies in the ring's slots, as fast as the ring takes them, waits for the last one; t_first_us /
  * t_done_us (NULL or n_blocks doubles) receive every block's start / completion on the device clock */
 int  csdr_amd_wfm_ring_replay(csdr_amd_wfm_ring *r, long n_blocks, double *t_first_us, double *t_done_us);

@@ -47,8 +47,10 @@ def test_ring_against_oracle_and_chain_object(gpu, port):
     taps = _taps(port)
     sigs = [wfm_signal_u8(9100 + s, nb * BLOCK) for s in range(4)]
     x = np.stack([sigs[s % 4] for s in range(S)])
-    y = gpu.wfm_ring_chain(x, -0.085, 10, taps, block=BLOCK, n_slots=8)
-    assert gpu.last_ring["grid"] == 2 * 6
+    # idle_us 20 ms: the grid (12 workgroups: the copies run beside it) stays resident across the collects -- the audio the host reads is what the grid's write-through
+    # stores put into memory, not what a kernel end flushed
+    y = gpu.wfm_ring_chain(x, -0.085, 10, taps, block=BLOCK, n_slots=8, idle_us=20000.0)
+    assert gpu.last_ring["grid"] == 2 * 6 and gpu.last_ring["launches"] <= 3
     for s in range(4):
         want, _ = port.wfm_chain(sigs[s], -0.085, 10, taps)
         _lsb_check(y[s], want, "stream %d" % s)

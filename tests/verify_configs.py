@@ -87,6 +87,58 @@ def verify_wfm(ctx, w, x, out_s16, S, T, pitch, n_audio_max, taps, shift_rate=-0
     return res
 
 
+def verify_wfm_ring(ctx, ring, S, T, taps, shift_rate=-0.085, decimation=10, n_blocks=6, noise_rows=12, seed=7200):
+    """The resident form (csdr_amd_wfm_ring_*) at the bench's shape: reset, n_blocks consecutive blocks of S streams -- four rows a real FM signal (held to +-1 LSB on every
+    sample), the rest i.i.d. noise of which `noise_rows` rows spread over the stream groups go through verify_wfm's statistical gate -- written into the input ring slot by
+    slot, posted, collected, against oracle.port().wfm_chain on each checked row's n_blocks * T samples."""
+    import oracle
+    import torch
+    from tests_helpers import wfm_signal_u8
+    port = oracle.port()
+    L = ctx.L
+    assert n_blocks <= L.csdr_amd_wfm_ring_slots(ring) - 2
+    assert L.csdr_amd_wfm_ring_reset(ring) == 0, ctx.err()
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    x = torch.randint(0, 256, (S, 2 * T * n_blocks), dtype=torch.uint8, device="cuda", generator=g)
+    strict_rows = sorted({r for r in (5, S // 3 + 1, (2 * S) // 3 + 2, S - 2) if 0 <= r < S})
+    for k, r in enumerate(strict_rows):
+        x[r] = torch.from_numpy(wfm_signal_u8(seed + 1 + k, T * n_blocks, offset=-shift_rate)).cuda()
+    rows = [r for r in pick_rows(S, want=noise_rows) if r not in strict_rows]
+    pitch = C.c_size_t(0); opitch = C.c_size_t(0)
+    for k in range(n_blocks):
+        assert L.csdr_amd_wfm_ring_acquire(ring, k, 0.0) == 0, ctx.err()
+        pi = L.csdr_amd_wfm_ring_input(ring, k, C.byref(pitch))
+        blk = torch.zeros((S, pitch.value), dtype=torch.uint8, device="cuda"); blk[:, :2 * T] = x[:, 2 * T * k:2 * T * (k + 1)]
+        torch.cuda.synchronize()
+        assert L.csdr_amd_d2d(ctx.h, pi, blk.data_ptr(), blk.numel()) == 0 and L.csdr_amd_ctx_sync(ctx.h) == 0, ctx.err()
+        assert L.csdr_amd_wfm_ring_submit(ring) == k, ctx.err()
+    outs = []
+    for k in range(n_blocks):
+        na = L.csdr_amd_wfm_ring_wait(ring, k, 0.0)
+        assert na > 0, ctx.err()
+        po = L.csdr_amd_wfm_ring_output(ring, k, C.byref(opitch))
+        buf = np.empty((S, opitch.value), np.int16)
+        assert L.csdr_amd_d2h(ctx.h, buf.ctypes.data_as(C.c_void_p), po, buf.nbytes) == 0, ctx.err()
+        outs.append(buf[:, :na].copy())
+    y = np.concatenate(outs, axis=1)
+    diffs = []; strict_max = 0; strict_n = 0; n_ref = -1
+    for r in rows + strict_rows:
+        ps, _ = port.wfm_chain(x[r].cpu().numpy(), shift_rate, decimation, taps)
+        n_ref = ps.size
+        m = min(ps.size, y.shape[1])
+        d = s16_diff(y[r, :m], ps[:m])
+        if r in strict_rows:
+            strict_max = max(strict_max, int(d.max())); strict_n += int(d.size)
+        else:
+            diffs.append(d)
+    res = summarize(diffs, n_ref, y.shape[1])
+    res["rows"] = rows; res["strict_rows"] = strict_rows; res["strict_rows_max_abs_diff_lsb"] = strict_max; res["strict_rows_samples_compared"] = strict_n
+    res["blocks"] = n_blocks
+    res["gate"] = "frac_nonzero < 0.05, frac_over_1_lsb < 0.005 (noise rows), strict rows max <= 1 LSB, 0 <= got_len - expected_len <= 2"
+    res["ok"] = bool(0 <= y.shape[1] - n_ref <= 2 and res["frac_over_1_lsb"] < 5e-3 and res["frac_nonzero"] < 0.05 and strict_max <= 1 and strict_n > 0)
+    return res
+
+
 def verify_nfm(ctx, obj, x, out_s16, S, T, pitch, n_out_max, shift_rate=-0.05, decimation=50, tbw=0.005, audio_rate=48000, agc_block=1024, rows=None, strict_rows=()):
     """Same for the NFM chain object: reset, one pass over all S channels, `rows` full s16 rows against oracle.port().nfm_chain (same gates
     and the same reason as verify_wfm; limit_ff bounds the ill-conditioned samples, so the largest differences are tens of LSB, not thousands)."""
