@@ -332,6 +332,54 @@ struct WfmChain : Stage {   // the fused README.md:66 chain as ONE command (exte
         *cons = n; long na = csdr_amd_wfm_process(w, (const uint8_t *)i, (2 * n + 127) & ~(size_t)127, n, (int16_t *)o, nullptr, cap); MUST(na); return na; }
 };
 
+// `CSDR_AMD_RESIDENT=1 csdr wfm_chain_u8_s16 <shift_rate>`: the same chain through the RESIDENT form (csdr_amd_wfm_ring_*): one persistent grid walks a ring of
+// the reference's own blocks -- 16384 samples per read, csdr.c:189-193, 330-392 -- , no kernel launch per block; a live stream (a block every 6.8 ms at 2.4 MS/s) keeps
+// the grid on the GPU between blocks (idle time 20 ms), a stalled one lets it go.  Whole blocks only: what is left of the stream behind its last whole block is dropped at
+// EOF, as the reference's stages drop a partial the_bufsize read (csdr.c:232-247).
+struct WfmRingStage : Stage {
+    csdr_amd_wfm_ring *r; size_t T; bool retunable;
+    const char *ctl_format() override { return retunable ? "%g\n" : nullptr; }
+    void retune(csdr_amd_ctx *, float rt, float) override { MUST(csdr_amd_wfm_ring_set_rate(r, rt)); fprintf(stderr, "csdr %s: reinitialized to %g\n", g_cmd, rt); }
+    WfmRingStage(csdr_amd_ctx *c, float shift, bool with_ctl) : T(16384), retunable(with_ctl)
+    {
+        in_elem = 2; out_elem = 2; granule = T; flush_partial = false; min_block = T / 4;
+        const int nt = csdr_amd_firdes_filter_len(0.05f);
+        std::vector<float> t(nt); csdr_amd_firdes_lowpass_f(t.data(), nt, 0.05f, CSDR_WINDOW_HAMMING);
+        r = csdr_amd_wfm_ring_create(c, 1, shift, 10, t.data(), nt, 5, 50e-6f, 48000, T, 8);
+        if (!r) die("wfm_ring_create");
+        MUST(csdr_amd_wfm_ring_set_timeouts(r, 20000.0, 1000.0));
+        fprintf(stderr, "csdr %s: resident grid (%d workgroups), ring of %d blocks of %zu samples\n", g_cmd, csdr_amd_wfm_ring_grid(r), csdr_amd_wfm_ring_slots(r), T);
+    }
+    ~WfmRingStage() { csdr_amd_wfm_ring_destroy(r); }
+    size_t out_capacity(size_t n) override { return n / 50 + 64; }
+    int next_bufsize(int b) override { return b / 50; }
+    long process(csdr_amd_ctx *c, const void *i, size_t n, void *o, size_t cap, size_t *cons) override
+    {
+        const size_t nb = n / T; *cons = nb * T;
+        const int depth = csdr_amd_wfm_ring_slots(r) - 2;
+        long total = 0;
+        for (size_t b0 = 0; b0 < nb; b0 += depth) {                  // groups of as many blocks as the ring holds in flight: inputs in, posted, collected in order
+            const size_t nbk = nb - b0 < (size_t)depth ? nb - b0 : (size_t)depth;
+            const long long s0 = csdr_amd_wfm_ring_submitted(r);
+            for (size_t b = 0; b < nbk; b++) {
+                MUST(csdr_amd_wfm_ring_acquire(r, s0 + (long long)b, 0));
+                size_t pitch; uint8_t *slot = csdr_amd_wfm_ring_input(r, s0 + (long long)b, &pitch);
+                MUST(csdr_amd_d2d(c, slot, (const uint8_t *)i + 2 * T * (b0 + b), 2 * T));
+            }
+            MUST(csdr_amd_ctx_sync(c));                              // the blocks lie in their slots before they are posted
+            for (size_t b = 0; b < nbk; b++) { const long long k = csdr_amd_wfm_ring_submit(r); MUST((int)(k < 0 ? k : 0)); }
+            for (size_t b = 0; b < nbk; b++) {
+                const long na = csdr_amd_wfm_ring_wait(r, s0 + (long long)b, 0); MUST((int)(na < 0 ? na : 0));
+                if ((size_t)(total + na) > cap) die("wfm ring: output buffer too small");
+                size_t op; const int16_t *out = csdr_amd_wfm_ring_output(r, s0 + (long long)b, &op);
+                MUST(csdr_amd_d2d(c, (int16_t *)o + total, out, 2 * (size_t)na));
+                total += na;
+            }
+        }
+        return total;
+    }
+};
+
 struct DdcFront : Stage {   // convert_u8_f | shift_addition_cc r | fir_decimate_cc D tbw window as ONE command (extension): the head of the NFM / AM / SSB chains
     csdr_amd_ddc *d; int dec; bool retunable;
     const char *ctl_format() override { return retunable ? "%g\n" : nullptr; }
@@ -1464,6 +1512,7 @@ Stage *make_stage(csdr_amd_ctx *c, int argc, char **argv, size_t block, Control 
             if (argc > a + 1) sscanf(argv[a + 1], "%g", &tbw);
             return new NfmChain(c, shift, factor, tbw, block, has_ctl);
         }
+        { const char *rs = getenv("CSDR_AMD_RESIDENT"); if (rs && atoi(rs)) return new WfmRingStage(c, shift, has_ctl); }
         return new WfmChain(c, shift, block, has_ctl);
     }
     fprintf(stderr, "csdr: function \"%s\" is not part of the MI355X hot path (see --help)\n", argv[1]);

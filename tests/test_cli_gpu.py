@@ -728,6 +728,58 @@ def test_cli_live_stream_latency_and_ragged_writes(port):
     assert np.array_equal(got, port.limit_ff(x, 0.7))
 
 
+def test_cli_resident_chain_on_a_live_stream(port):
+    """CSDR_AMD_RESIDENT=1 csdr wfm_chain_u8_s16: the chain through the resident ring (one persistent grid, no launch per block) on a LIVE 2.4 MS/s stream -- a
+    16384-sample block every 6.8 ms, as the reference's stages read them (csdr.c:189-193, 330-392): every block's audio comes back before the next block is due (the
+    reference's own latency is a block), the grid stays on the GPU between blocks, the stream equals the oracle's."""
+    import threading
+    import time
+    T, nb = 16384, 60
+    iq = fm_iq(np.random.default_rng(31), nb * T + 5000)                   # (5000 samples behind the last whole block: dropped at EOF like a partial read, csdr.c:232-247)
+    env = dict(os.environ, CSDR_AMD_RESIDENT="1"); env.pop("CSDR_AMD_BLOCK", None)
+    p = subprocess.Popen([CLI, "wfm_chain_u8_s16", "-0.085"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    got = []; stamps = []
+
+    def reader():
+        while True:
+            chunk = p.stdout.read1(65536) if hasattr(p.stdout, "read1") else p.stdout.read(4096)
+            if not chunk:
+                return
+            got.append(chunk); stamps.append((time.perf_counter(), sum(len(c) for c in got) // 2))
+    th = threading.Thread(target=reader); th.start()
+    sent = []
+    t_next = time.perf_counter() + 0.5                                      # (the process starts up first)
+    raw = iq.tobytes()
+    for k in range(nb):
+        while time.perf_counter() < t_next:
+            time.sleep(0.0005)
+        p.stdin.write(raw[2 * T * k:2 * T * (k + 1)]); p.stdin.flush()
+        sent.append(time.perf_counter())
+        t_next += T / 2.4e6
+    time.sleep(0.05)
+    tail_at = len(stamps)
+    p.stdin.write(raw[2 * T * nb:]); p.stdin.close()
+    th.join(timeout=60)
+    assert p.wait(timeout=60) == 0
+    err = p.stderr.read().decode()
+    assert "resident grid" in err, err
+    out = np.frombuffer(b"".join(got), np.int16)
+    want, _ = port.wfm_chain(iq[:2 * T * nb], -0.085, 10, port.firdes_lowpass_f(port.firdes_filter_len(0.05), 0.05))
+    m = min(out.size, want.size)
+    assert 0 <= out.size - want.size <= 2
+    d = np.abs(out[:m].astype(np.int32) - want[:m].astype(np.int32))
+    assert d.max() <= 1 and np.mean(d != 0) < 0.01
+    # latency: block k's last audio sample is j_hi(k) = ((k + 1) T - 79) // 10 - 10) // 5; when did the output reach that count?
+    lat = []
+    for k in range(5, nb):
+        need = (((k + 1) * T - 79) // 10 - 10) // 5 + 1
+        t_out = next((t for t, n in stamps[:tail_at] if n >= need), None)
+        assert t_out is not None, "block %d's audio did not arrive while the stream was live" % k
+        lat.append(t_out - sent[k])
+    assert np.median(lat) < T / 2.4e6, "median latency %.2f ms" % (1e3 * np.median(lat))      # before the next block is due: the reference's own latency is a block
+    print("resident chain on a live stream: median %.2f ms, max %.2f ms from a block's last byte to its audio" % (1e3 * np.median(lat), 1e3 * max(lat)))
+
+
 def test_cli_argument_validation():
     """bad arguments end with the reference's badsyntax exit status instead of a crash (SIGFPE on a zero block / decimation)"""
     for args in (["fastagc_ff", "0"], ["fir_decimate_cc", "0"], ["fir_decimate_cc", "x"]):
