@@ -15,6 +15,7 @@
 // RCCL is loaded on demand (dlopen of librccl.so.1: the copy torch already mapped when the caller is a torch process, the system one otherwise), so
 // the single-GPU library and the CLI do not depend on it.
 #include "fastddc.hpp"
+#include <rccl/rccl.h>      // types and enum values only (the entry points are dlsym'ed): a change of RCCL's ABI is a compile error here, not a crash at the first N > 1 run
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
@@ -29,23 +30,21 @@ using namespace csdr_amd;
 
 namespace {
 
-typedef int ncclResult_t;
-typedef void *ncclComm_t;
-struct ncclUniqueId { char internal[128]; };
-enum { ncclFloat32 = 7 };                                             // rccl.h ncclDataType_t: ncclFloat = 7
-
+// every pointer has the type rccl.h declares for that entry point (decltype): argument lists, ncclDataType_t, ncclUniqueId and the enum values ncclFloat32 / ncclUint8
+// come from the header the library was built against
+static_assert(sizeof(ncclUniqueId) == 128, "csdr_amd_comm_unique_id hands out 128 bytes (include/csdr_amd.h)");
 struct Rccl {
     void *lib = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 Rccl g_rccl; std::mutex g_rccl_mu;
 
@@ -86,7 +85,9 @@ struct csdr_amd_loopback {
     std::vector<hipEvent_t> ready, done;      // [src * world + dst]
     std::vector<void *> ag_buf; std::vector<hipEvent_t> ag_ready, ag_done;      // collectives: per rank
     int attached = 0;
-    std::vector<csdr_amd_loopback *> children; std::vector<int> dups_of_rank;      // csdr_amd_comm_dup: the k-th dup of every rank joins children[k] (created by whoever comes first)
+    // csdr_amd_comm_dup: a rank's dup joins the lowest-numbered child group it holds no communicator of (created by whoever comes first; every rank makes its dup /
+    // destroy calls in the same order, so all ranks pick the same child); a destroyed dup gives its place back, so create / destroy cycles reuse the children
+    std::vector<csdr_amd_loopback *> children; std::vector<std::vector<char>> child_in_use;      // [rank][child]
     // host rendezvous of the rank threads; fails (instead of hanging the box) when a rank never arrives
     int barrier()
     {
@@ -102,6 +103,7 @@ struct csdr_amd_loopback {
 struct csdr_amd_comm {
     csdr_amd_ctx *ctx; ncclComm_t comm; DdcComm ddc;
     csdr_amd_loopback *loop = nullptr; bool null_transport = false;
+    csdr_amd_loopback *dup_parent = nullptr; int dup_index = -1;      // a loopback dup: the parent group and the child's index in it
     struct Op { bool send; void *buf; size_t n; int peer; hipStream_t st; };
     std::vector<Op> ops; bool in_group = false;
 };
@@ -245,7 +247,7 @@ csdr_amd_loopback *csdr_amd_loopback_create(int world)
     g->box.assign((size_t)world * world, {nullptr, 0, false, false});
     g->ready.assign((size_t)world * world, nullptr); g->done.assign((size_t)world * world, nullptr);
     g->ag_buf.assign(world, nullptr); g->ag_ready.assign(world, nullptr); g->ag_done.assign(world, nullptr);
-    g->dups_of_rank.assign(world, 0);
+    g->child_in_use.assign(world, std::vector<char>());
     bool ok = true;
     for (auto *v : {&g->ready, &g->done, &g->ag_ready, &g->ag_done}) for (auto &e : *v) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok) { fail_msg(-1, "loopback: hipEventCreate failed"); csdr_amd_loopback_destroy(g); return nullptr; }
@@ -294,6 +296,11 @@ void csdr_amd_comm_destroy(csdr_amd_comm *c)
     if (!c) return;
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->dup_parent && c->dup_index >= 0) {                         // the child group's place is free again for this rank
+        std::lock_guard<std::mutex> lk(c->dup_parent->mu);
+        std::vector<char> &use = c->dup_parent->child_in_use[c->ddc.rank];
+        if (c->dup_index < (int)use.size()) use[c->dup_index] = 0;
+    }
     delete c;
 }
 
@@ -308,21 +315,34 @@ csdr_amd_comm *csdr_amd_comm_dup(csdr_amd_comm *c)
     if (c->null_transport) return csdr_amd_comm_create_null(c->ctx, rank, world);
     if (c->loop) {
         csdr_amd_loopback *g = c->loop, *child = nullptr;
+        int k = 0;
         {
             std::lock_guard<std::mutex> lk(g->mu);
-            const int k = g->dups_of_rank[rank]++;
+            std::vector<char> &use = g->child_in_use[rank];
+            while (k < (int)use.size() && use[k]) k++;
             while ((int)g->children.size() <= k) {
                 csdr_amd_loopback *n = csdr_amd_loopback_create(world);
-                if (!n) return nullptr;
+                if (!n) return nullptr;                                   // (nothing has been marked yet)
                 g->children.push_back(n);
             }
             child = g->children[k];
         }
-        return csdr_amd_comm_create_loopback(c->ctx, child, rank);
+        csdr_amd_comm *d = csdr_amd_comm_create_loopback(c->ctx, child, rank);
+        if (!d) return nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            std::vector<char> &use = g->child_in_use[rank];
+            if ((int)use.size() <= k) use.resize(k + 1, 0);
+            use[k] = 1;
+        }
+        d->dup_parent = g; d->dup_index = k;
+        return d;
     }
     if (hipSetDevice(c->ctx->device) != hipSuccess) { fail_msg(-1, "hipSetDevice(%d) failed", c->ctx->device); return nullptr; }
+    // rank 0 ALWAYS takes part in the broadcast: when it cannot draw an id it sends zeros, which every rank (itself included) reads as the failure -- nobody is left
+    // waiting in a collective the root never entered
     char id[128]; memset(id, 0, sizeof id);
-    if (rank == 0 && csdr_amd_comm_unique_id(id)) return nullptr;
+    if (rank == 0 && csdr_amd_comm_unique_id(id)) memset(id, 0, sizeof id);
     if (world > 1) {
         void *d = nullptr;
         if (hipMalloc(&d, 128) != hipSuccess || hipMemcpy(d, id, 128, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); fail_msg(-2, "comm_dup: staging buffer"); return nullptr; }
@@ -331,6 +351,7 @@ csdr_amd_comm *csdr_amd_comm_dup(csdr_amd_comm *c)
         (void)hipFree(d);
         if (!ok) { if (!rc) fail_msg(-6, "comm_dup: the new unique id did not arrive"); return nullptr; }
     }
+    { bool zero = true; for (int i = 0; i < 128; i++) zero = zero && id[i] == 0; if (zero) { if (rank != 0) fail_msg(-6, "comm_dup: rank 0 could not draw a unique id"); return nullptr; } }
     return csdr_amd_comm_create(c->ctx, id, rank, world);
 }
 
@@ -462,7 +483,7 @@ int csdr_amd_comm_broadcast(csdr_amd_comm *c, void *dev_buf, size_t bytes, int r
 {
     if (c->ddc.world == 1 || c->null_transport) return 0;
     if (c->loop) return l_collect(c, dev_buf, bytes, root, c->ctx->stream);
-    CSDR_NCCL(g_rccl.Broadcast(dev_buf, dev_buf, bytes, 1 /* ncclUint8 */, root, c->comm, c->ctx->stream));
+    CSDR_NCCL(g_rccl.Broadcast(dev_buf, dev_buf, bytes, ncclUint8, root, c->comm, c->ctx->stream));
     return 0;
 }
 

@@ -829,7 +829,7 @@ static csdr_amd_fastddc_bank *bank_create(csdr_amd_ctx *ctx, float transition_bw
         b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates, n_channels, window, b->nbl, nullptr);
     } else
         b->inv = fastddc_inv_create_comm(ctx, transition_bw, decimation, host_shift_rates + b->first_channel, count, window, max_blocks, multi ? dc : nullptr);
-    if (!b->inv) { delete b; return nullptr; }
+    if (!b->inv) { csdr_amd_fastddc_bank_destroy(b); return nullptr; }      // (destroy: a BLOCKS-mode bank already holds its second communicator)
     b->fused = ddc_mfma_can_forward(b->inv->mf);
     if (multi && !b->fused) { fail_msg(-3, "fastddc_bank: sharding needs the geometry of the matrix-core path (fft_size 65536, fft_inv_size 512)"); csdr_amd_fastddc_bank_destroy(b); return nullptr; }
     const csdr_fastddc_t g = b->inv->geom[0];

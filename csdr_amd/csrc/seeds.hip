@@ -141,23 +141,11 @@ int generate(SeedTables *t, int dst, int src, long idx, long long first)
         CSDR_HIP(hipMemcpyAsync(t->d_ph[dst], h, sizeof(float) * t->pitch * (size_t)t->cap, hipMemcpyHostToDevice, ss));
         t->h_used[dst] = true;
     }
-    static const bool raised = !(getenv("CSDR_AMD_SEED_PRIO") && atoi(getenv("CSDR_AMD_SEED_PRIO")) == 0);      // (A/B, read once per process)
-    // TIMING EXPERIMENT ONLY (wrong seeds from the second table on): what the generator's side-stream work costs the data kernels = the ceiling of any speed-up of it
-    static const bool freeze = getenv("CSDR_AMD_SEED_FREEZE") != nullptr;
-    if (freeze && src >= 0) { CSDR_HIP(hipEventRecord(t->ev_ready[dst], ss)); t->first[dst] = first; t->valid[dst] = true; return 0; }
-    // lanes per workgroup: a wave of this kernel is a chain of dependent operations that occupies its SIMD for the whole table (milliseconds), and a CU that holds one
-    // cannot take a workgroup of the per-stream WFM kernel (2 x 256 registers per SIMD).  64 = a wave per CU on sixteen CUs; 512 = two waves per SIMD on two CUs.
-    static const int blk = [] { const char *e = getenv("CSDR_AMD_SEED_BLOCK"); const int v = e ? atoi(e) : 64; return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 64; }();
-    // slices: the table in `slices` launches of cap / slices entries each, in order on the side stream -- between two of them the CU is free again (see the sweep in
-    // profiles/r5_notes.md: a resident generator wave keeps a whole CU away from the per-stream WFM kernel, whose 1024 workgroups are exactly four rounds on 256 CUs)
-    static const int slices = [] { const char *e = getenv("CSDR_AMD_SEED_SLICES"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4096 ? v : 1; }();
-    const int per = (t->cap - 2 + slices - 1) / slices;
-    for (int k0 = 2; !t->host_chain && (k0 < t->cap || k0 == 2); k0 += per > 0 ? per : 1) {
-        const int k1 = k0 + per < t->cap ? k0 + per : t->cap;
-        if (!raised) hipLaunchKernelGGL(k_seed_phases<false>, dim3(cdiv(t->n, blk)), dim3(blk), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, k0, k1, t->n);
-        else hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, blk)), dim3(blk), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, k0, k1, t->n);
-        if (per <= 0) break;
-    }
+    // One launch of 64-lane workgroups (a wave per CU on sixteen CUs at 1024 streams), wave priority raised: a wave of this kernel is a chain of dependent operations that
+    // occupies its SIMD for the whole table (milliseconds), and a CU that holds one cannot take a workgroup of the per-stream WFM kernel (2 x 256 registers per SIMD).
+    // Round 5 measured the alternatives (larger workgroups on fewer CUs, the table in slices, normal priority, the generator switched off as a ceiling: profiles/r5_notes.md);
+    // none paid, their switches are gone.
+    if (!t->host_chain) hipLaunchKernelGGL(k_seed_phases<true>, dim3(cdiv(t->n, 64)), dim3(64), 0, ss, t->d_rates, src >= 0 ? t->d_ph[src] : nullptr, idx, t->d_ph[dst], t->pitch, 2, t->cap, t->n);
     CSDR_LAUNCH_CHECK();
     const size_t count = t->pitch * (size_t)t->cap;
     hipLaunchKernelGGL(k_seed_cossin, dim3(cdiv(count, 256)), dim3(256), 0, ss, t->d_ph[dst], t->d_c[dst], count);

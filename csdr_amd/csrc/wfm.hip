@@ -329,11 +329,8 @@ int csdr_amd_wfm_set_rate(csdr_amd_wfm *w, int stream, float shift_rate)
     if (!w->ps) return fail_msg(-3, "wfm_set_rate: the object shares one rate (create it with csdr_amd_wfm_create_rates)");
     if (stream < 0 || stream >= w->n_streams) return fail_msg(-3, "wfm_set_rate: stream %d out of range", stream);
     if (w->rates[stream] == shift_rate) return 0;
-    // The audio samples whose windows reach back across the retune instant are recomputed with both tables (k_wfm_lead); d_lead_d holds 4 per stream.  A window
-    // spans D + L - 1 samples and audio samples lie D F apart: shapes with more straddling samples than that (short D F under a long filter) would get the
-    // samples beyond the fourth from the new table alone -- not csdr.c:881-923's semantics -- so they are refused instead (10 / 79 / 5 has at most 3).
-    if ((w->D + w->L - 1) / (w->D * w->F) + 2 > 4)
-        return fail_msg(-3, "wfm_set_rate: live retune is not available for decimation %d, %d taps, audio decimation %d (more than 4 audio samples straddle a retune)", w->D, w->L, w->F);
+    // The audio samples whose windows reach back across the retune instant are recomputed with both tables (k_wfm_lead): a window spans D + L - 1 samples and audio
+    // samples lie D F apart, so d_lead_d holds wfm_lead_max(D, L, F) per stream (10 / 79 / 5: 3; ADVICE r5: sized from the shape, no shape is refused).
     CSDR_HIP(hipStreamSynchronize(w->ctx->stream));                   // calls in flight read this stream's tables
     if (!w->d_dtab_old) CSDR_HIP(hipMalloc((void **)&w->d_dtab_old, sizeof(float2) * 3072 * (size_t)w->n_streams));
     bool listed = false;
@@ -488,22 +485,23 @@ long csdr_amd_wfm_process(csdr_amd_wfm *w, const uint8_t *in, size_t in_pitch, s
         if (w->ps) {
             psa.tab_pitch = sv.pitch; psa.tab_len = sv.n_entries; psa.d_scales = w->d_scales;
             // retuned streams: the audio samples whose windows start in front of the block (D (F j + 9) < B) straddle two rates
-            long n_lead = 0;
+            long n_lead = 0; const int lead_max = wfm_lead_max(w->D, w->L, w->F);
+            psa.lead_stride = lead_max;
             if (!w->retuned.empty() && n_audio > 0) {
                 const long long lim = w->B - 1 - 9LL * w->D;
                 if (lim >= 0) n_lead = (long)(lim / ((long long)w->D * w->F) - w->next_j + 1);
                 if (n_lead < 0) n_lead = 0;
-                if (n_lead > 4) n_lead = 4;
+                if (n_lead > lead_max) n_lead = lead_max;
                 if (n_lead > n_audio) n_lead = n_audio;
             }
             if (n_lead > 0) {
                 const int nr = (int)w->retuned.size(), S = w->n_streams;
-                if (!w->d_lead_n) { CSDR_HIP(hipMalloc((void **)&w->d_lead_n, sizeof(int) * 2 * S)); w->d_list = w->d_lead_n + S; CSDR_HIP(hipMalloc((void **)&w->d_lead_d, sizeof(float) * 4 * S)); }
+                if (!w->d_lead_n) { CSDR_HIP(hipMalloc((void **)&w->d_lead_n, sizeof(int) * 2 * S)); w->d_list = w->d_lead_n + S; CSDR_HIP(hipMalloc((void **)&w->d_lead_d, sizeof(float) * (size_t)lead_max * S)); }
                 int *hl = (int *)c->pinned_acquire(sizeof(int) * (size_t)(S + nr)); if (!hl) return -2;      // [S] samples per stream, then the list: one upload
                 for (int s = 0; s < S; s++) hl[s] = 0;
                 for (int k = 0; k < nr; k++) { hl[w->retuned[k]] = (int)n_lead; hl[S + k] = w->retuned[k]; }
                 rc = c->pinned_upload(w->d_lead_n, sizeof(int) * (size_t)(S + nr)); if (rc) return rc;
-                rc = wfm_mfma_lead(st, in, in_pitch, back.head_in, w->d_taps, sv.ctab, sv.pitch, w->mfma.d_dtab, w->d_dtab_old, w->d_list, nr, w->d_lead_d,
+                rc = wfm_mfma_lead(st, in, in_pitch, back.head_in, w->d_taps, sv.ctab, sv.pitch, w->mfma.d_dtab, w->d_dtab_old, w->d_list, nr, w->d_lead_d, lead_max,
                                    w->D, w->L, w->F, w->B, w->next_j, (int)n_lead);
                 if (rc) return rc;
                 psa.d_lead_d = w->d_lead_d; psa.d_lead_n = w->d_lead_n;

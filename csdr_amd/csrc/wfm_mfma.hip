@@ -201,7 +201,7 @@ struct SeqParams {
     long long col_bytes; int col_chunks, col_audio, n_cols;      // input bytes / chunks / audio samples between column starts; columns of the call
     size_t frag_stride, tab_pitch; int tab_len;                   // v4i per stream in `frags`; streams per chunk row of the seed table; its rows from the call's first chunk on
     const float *scales;
-    const float *lead_d; const int *lead_n;                       // retuned streams: lead_n[stream] audio samples at the call's start come from lead_d[stream * 4 + i]
+    const float *lead_d; const int *lead_n; int lead_stride;      // retuned streams: lead_n[stream] audio samples at the call's start come from lead_d[stream * lead_stride + i]
 };
 
 #ifndef SEQ_RB_KIB
@@ -271,7 +271,7 @@ struct ResCtl {
     const uint8_t *in_ring; int16_t *out_ring; size_t in_slot_bytes, out_slot_elems;
     int n_slots, desc_lines, n_wsb, T, D, L, F;
     long long idle_ticks, life_ticks;
-    const float *lead_d;                   // [n_streams][4]: a retuned stream's first audio samples of the block (k_wfm_lead)
+    const float *lead_d; int lead_stride;  // [n_streams][lead_stride]: a retuned stream's first audio samples of the block (k_wfm_lead)
     const float *lead_state;               // [n_streams]: the de-emphasis state in front of the first block behind a retune
     unsigned long long *stats;             // device [grid][4]: ticks spent waiting for a block, in the body, in the completion; items (accumulated over launches)
     int fence_mode;                        // experiments: 0 = write-through stores, no fence (default), 3 = plus one system fence per item, 2 = plus one by every thread
@@ -815,12 +815,12 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                 // a retuned stream's first samples of the call: their windows reach into bytes that were rotated at the OLD rate -- evaluated with both tables
                 // by k_wfm_lead in front of this kernel
                 const long long ja = 4 * (t0 + it) + q - p.j_first;                  // this audio sample's index in the call (column 0)
-                if (n_lead > 0 && col0 + col == 0 && ja >= 0 && ja < n_lead) dval = p.lead_d[(size_t)sb * 4 + ja];      // (n_lead in a register: a vector load here waits behind the DMA ring)
+                if (n_lead > 0 && col0 + col == 0 && ja >= 0 && ja < n_lead) dval = p.lead_d[(size_t)sb * p.lead_stride + ja];      // (n_lead in a register: a vector load here waits behind the DMA ring)
             }
             if constexpr (RES) {                                                     // the first block after a retune: the samples whose windows straddle the two rates
                 if (n_lead > 0) {
                     const long long ja = 4 * (t0 + it) + q - p.j_first;
-                    if (ja >= 0 && ja < n_lead) dval = rc.lead_d[(size_t)min(sb * 16 + col, last_stream) * 4 + ja];
+                    if (ja >= 0 && ja < n_lead) dval = rc.lead_d[(size_t)min(sb * 16 + col, last_stream) * rc.lead_stride + ja];
                 }
             }
             lout[col * SEQ_OUTP + 4 * wv + q] = dval;                                 // audio 4 * tile + q of stream col
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(256) void k_wfm_roll_head(const uint8_t *__restrict
 // (shift_addition_cc --fifo picks a new rate up between two reads, csdr.c:881-923).  Those samples -- at most four -- are evaluated here with both tables, one
 // wave per (listed stream, sample, which of y[Fj+9] / y[Fj+10]): the chain kernel takes the demodulated value from lead_d.  Seeds: row 0 of the stream's table =
 // the chunk in front of the block.
-struct LeadParams { int D, L, F; long long B, j_first, c_first; int n_lead, ja0; float *warm; size_t tab_pitch, dtab_stride, ct_stride, head_pitch, head_off; };      // (a ring's tables are shared: strides 0; its history
+struct LeadParams { int D, L, F; long long B, j_first, c_first; int n_lead, ja0, lead_stride; float *warm; size_t tab_pitch, dtab_stride, ct_stride, head_pitch, head_off; };      // (a ring's tables are shared: strides 0; its history
                                                                                                                                                //  is the previous slot's tail)
 __global__ __launch_bounds__(128) void k_wfm_lead(const uint8_t *__restrict__ in, size_t in_pitch, const uint8_t *__restrict__ head, const float *__restrict__ taps,
                                                  const float2 *__restrict__ ctab, const float2 *__restrict__ dtab, const float2 *__restrict__ dtab_old,
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(128) void k_wfm_lead(const uint8_t *__restrict__ in
         const float dq = cQ - pQ, di = cI - pI, num = cI * dq - cQ * di, den = cI * cI + cQ * cQ;
         float rd = __builtin_amdgcn_rcpf(den); rd = fmaf(fmaf(-den, rd, 1.0f), rd, rd);
         const float dv = (den != 0.f) ? (K * num) * rd : 0.f;
-        if (ja >= 0) lead_d[(size_t)s * 4 + ja] = dv; else p.warm[(size_t)s * RES_WARM + (ja + RES_WARM)] = dv;
+        if (ja >= 0) lead_d[(size_t)s * p.lead_stride + ja] = dv; else p.warm[(size_t)s * RES_WARM + (ja + RES_WARM)] = dv;
     }
 }
 
@@ -1010,11 +1010,11 @@ namespace csdr_amd {
 size_t wfm_mfma_head_bytes(int n_streams) { return (size_t)((n_streams + 15) / 16 * 16) * SEQ_HEAD; }
 
 int wfm_mfma_lead(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *head, const float *d_taps, const float2 *ctab, size_t tab_pitch, const float2 *d_dtab,
-                  const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int D, int L, int F, long long B, long long j_first, int n_lead)
+                  const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int lead_stride, int D, int L, int F, long long B, long long j_first, int n_lead)
 {
     if (n_list <= 0 || n_lead <= 0) return 0;
     LeadParams lp; lp.D = D; lp.L = L; lp.F = F; lp.B = B; lp.j_first = j_first; lp.n_lead = n_lead; lp.tab_pitch = tab_pitch; lp.dtab_stride = 3072;
-    lp.ct_stride = 1; lp.head_pitch = SEQ_HEAD; lp.head_off = 512; lp.c_first = (B >> 10) - 1; lp.ja0 = 0; lp.warm = nullptr;
+    lp.ct_stride = 1; lp.head_pitch = SEQ_HEAD; lp.head_off = 512; lp.c_first = (B >> 10) - 1; lp.ja0 = 0; lp.warm = nullptr; lp.lead_stride = lead_stride;
     hipLaunchKernelGGL(k_wfm_lead, dim3(n_lead, n_list), dim3(128), 0, st, in, in_pitch, head, d_taps, ctab, d_dtab, d_dtab_old, d_list, d_lead_d, lp);
     CSDR_LAUNCH_CHECK();
     return 0;
@@ -1025,13 +1025,13 @@ int wfm_mfma_lead(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint
 // ctab[0] = chunk (B >> 10) - 4.  Also the RES_WARM audio samples in front of the block (old tables only) and from them the de-emphasis state there (d_state[stream]): a
 // ring's blocks carry no state, and the warm-up the grid would run over those samples uses the NEW weights.
 int wfm_mfma_lead_shared(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *prev, size_t two_T, const float *d_taps, const float2 *ctab, const float2 *d_dtab,
-                         const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, float *d_warm, float *d_state, float alpha,
+                         const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int lead_stride, float *d_warm, float *d_state, float alpha,
                          int D, int L, int F, long long B, long long j_first, int n_lead)
 {
     if (n_list <= 0) return 0;
     if (j_first < RES_WARM) return fail_msg(-3, "wfm ring: a retune needs %d audio samples in front of the block", RES_WARM);
     LeadParams lp; lp.D = D; lp.L = L; lp.F = F; lp.B = B; lp.j_first = j_first; lp.n_lead = n_lead; lp.tab_pitch = 1; lp.dtab_stride = 0;
-    lp.ct_stride = 0; lp.head_pitch = in_pitch; lp.head_off = two_T - 512; lp.c_first = (B >> 10) - 4; lp.ja0 = -RES_WARM; lp.warm = d_warm;
+    lp.ct_stride = 0; lp.head_pitch = in_pitch; lp.head_off = two_T - 512; lp.c_first = (B >> 10) - 4; lp.ja0 = -RES_WARM; lp.warm = d_warm; lp.lead_stride = lead_stride;
     hipLaunchKernelGGL(k_wfm_lead, dim3(n_lead + RES_WARM, n_list), dim3(128), 0, st, in, in_pitch, prev, d_taps, ctab, d_dtab, d_dtab_old, d_list, d_lead_d, lp);
     CSDR_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_wfm_lead_state, dim3((n_list + 63) / 64), dim3(64), 0, st, d_warm, d_state, n_list, alpha);
@@ -1075,14 +1075,13 @@ int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, cons
         while ((4 * tpp) % SEQ_LINE) tpp *= 2;
         const int n_per = (sp.n_tiles + tpp - 1) / tpp;
         int n_ss = (4 * n_cu + n_streams - 1) / n_streams; if (n_ss < 1) n_ss = 1;
-        { static const int split = getenv("CSDR_AMD_WFM_PS_SPLIT") ? atoi(getenv("CSDR_AMD_WFM_PS_SPLIT")) : 1; if (split > 1) n_ss *= split; }      // (experiment: shorter columns)
         int np = (n_per + 16 * n_ss - 1) / (16 * n_ss); if (np < 1) np = 1;
         sp.tiles_per_seg = np * tpp;
         sp.n_cols = (sp.n_tiles + sp.tiles_per_seg - 1) / sp.tiles_per_seg;
         n_seg = (sp.n_cols + 15) / 16;
         sp.col_bytes = (long long)sp.tiles_per_seg * sp.stride; sp.col_chunks = (int)(sp.col_bytes / 2048); sp.col_audio = 4 * sp.tiles_per_seg;
         sp.frag_stride = (size_t)WFM_NK * 3 * 64; sp.tab_pitch = ps->tab_pitch; sp.tab_len = ps->tab_len; sp.scales = ps->d_scales;
-        sp.lead_d = ps->d_lead_d; sp.lead_n = ps->d_lead_n;
+        sp.lead_d = ps->d_lead_d; sp.lead_n = ps->d_lead_n; sp.lead_stride = ps->lead_stride;
         if (sp.col_bytes * 16 + 4096 >= (1LL << 32)) return fail_msg(-3, "wfm: block too large for the per-stream kernel's 32-bit row offsets");
         const size_t ldsp = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float) + 2 * 48 * sizeof(float2);
         { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<true>, ldsp); if (arc) return arc; }
@@ -1125,7 +1124,7 @@ int wfm_mfma_launch_resident(hipStream_t st, hipEvent_t ev_end, const WfmMfmaDev
     rc.desc = rv.desc; rc.ctrl = rv.ctrl; rc.done = rv.done; rc.cnt = rv.cnt; rc.t_first = rv.t_first; rc.next_item = rv.next_item; rc.exiting = rv.exiting;
     rc.in_ring = rv.in_ring; rc.out_ring = rv.out_ring; rc.in_slot_bytes = rv.in_slot_bytes; rc.out_slot_elems = rv.out_slot_elems;
     rc.n_slots = rv.n_slots; rc.desc_lines = rv.desc_lines; rc.n_wsb = (n_streams + 15) / 16; rc.T = rv.T; rc.D = rv.D; rc.L = rv.L; rc.F = rv.F;
-    rc.idle_ticks = rv.idle_ticks; rc.life_ticks = rv.life_ticks; rc.lead_d = rv.lead_d; rc.lead_state = rv.lead_state; rc.stats = rv.stats; rc.fence_mode = rv.fence_mode;
+    rc.idle_ticks = rv.idle_ticks; rc.life_ticks = rv.life_ticks; rc.lead_d = rv.lead_d; rc.lead_stride = rv.lead_stride; rc.lead_state = rv.lead_state; rc.stats = rv.stats; rc.fence_mode = rv.fence_mode;
     if (rv.desc_lines < 1 || rv.desc_lines > 16) return fail_msg(-3, "wfm ring: %d descriptor lines", rv.desc_lines);
     const size_t lds = (size_t)16 * SEQ_RP + 16 * SEQ_OUTP * sizeof(float) + (SEQ_NGR + 1) * 16 * sizeof(float) + 8 + (size_t)rv.desc_lines * 14 * sizeof(float);
     { const int arc = lds_attr_once((const void *)k_wfm_mfma_seq<false, true>, lds); if (arc) return arc; }

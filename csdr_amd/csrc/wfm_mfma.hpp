@@ -29,7 +29,9 @@ struct WfmBackArgs {
 
 // a shift rate per stream (csdr_amd_wfm_create_rates): dev.d_seq_frags / d_seq_cum / d_dtab hold one table set per stream, the chunk seeds come from a seed table
 // (seeds.hpp: ctab[k * tab_pitch + stream]); lead: the first audio samples of retuned streams, evaluated by wfm_mfma_lead
-struct WfmPerStream { size_t tab_pitch; int tab_len; const float *d_scales; const float *d_lead_d; const int *d_lead_n; };
+struct WfmPerStream { size_t tab_pitch; int tab_len; const float *d_scales; const float *d_lead_d; const int *d_lead_n; int lead_stride; };
+// audio samples whose windows can straddle a retune: a window spans D + L - 1 samples, audio samples lie D F apart
+inline int wfm_lead_max(int D, int L, int F) { return (D + L - 1) / (D * F) + 2; }
 
 // the resident form (csdr_amd_wfm_ring_*, wfm_ring.hip): what the persistent grid of k_wfm_mfma_seq<false, true> walks
 struct WfmResident {
@@ -38,14 +40,14 @@ struct WfmResident {
     const uint8_t *in_ring; int16_t *out_ring; size_t in_slot_bytes, out_slot_elems;
     int n_slots, desc_lines, T, D, L, F;
     long long idle_ticks, life_ticks;
-    const float *lead_d, *lead_state;
+    const float *lead_d, *lead_state; int lead_stride;
     unsigned long long *stats; int fence_mode;
 };
 constexpr int WFM_RES_WARM = 48;   // = RES_WARM (wfm_mfma.hip)
 int wfm_mfma_launch_resident(hipStream_t st, hipEvent_t ev_end, const WfmMfmaDevice &dev, int n_streams, size_t in_pitch, float alpha, size_t out_pitch, const WfmResident &rv, int grid);
 int wfm_resident_max_grid();
 int wfm_mfma_lead_shared(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *prev, size_t two_T, const float *d_taps, const float2 *ctab, const float2 *d_dtab,
-                         const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, float *d_warm, float *d_state, float alpha,
+                         const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int lead_stride, float *d_warm, float *d_state, float alpha,
                          int D, int L, int F, long long B, long long j_first, int n_lead);
 
 bool wfm_mfma_supported(int D, int L, int F);
@@ -56,6 +58,6 @@ size_t wfm_mfma_head_bytes(int n_streams);
 int wfm_mfma_launch(hipStream_t st, hipEvent_t ev_begin, hipEvent_t ev_end, const uint8_t *in, size_t in_pitch, const WfmMfmaDevice &dev, const float2 *ctab,
                     int n_streams, int T, long long B, long long j_first, int n_audio, const WfmBackArgs &back, const WfmPerStream *ps = nullptr);
 int wfm_mfma_lead(hipStream_t st, const uint8_t *in, size_t in_pitch, const uint8_t *head, const float *d_taps, const float2 *ctab, size_t tab_pitch, const float2 *d_dtab,
-                  const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int D, int L, int F, long long B, long long j_first, int n_lead);
+                  const float2 *d_dtab_old, const int *d_list, int n_list, float *d_lead_d, int lead_stride, int D, int L, int F, long long B, long long j_first, int n_lead);
 
 } // namespace csdr_amd

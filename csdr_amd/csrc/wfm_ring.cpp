@@ -76,7 +76,7 @@ static int ring_ensure_running(csdr_amd_wfm_ring *r)
     rv.desc = r->h_desc; rv.ctrl = r->h_ctrl; rv.done = r->h_done; rv.cnt = r->d_cnt; rv.t_first = r->d_tfirst; rv.next_item = r->d_next; rv.exiting = r->d_exiting;
     rv.in_ring = r->d_in; rv.out_ring = r->d_out; rv.in_slot_bytes = (size_t)r->S * r->in_pitch; rv.out_slot_elems = (size_t)r->S * r->out_pitch;
     rv.n_slots = r->N; rv.desc_lines = r->lines; rv.T = r->T; rv.D = r->D; rv.L = r->L; rv.F = r->F;
-    rv.idle_ticks = r->idle_ticks; rv.life_ticks = r->life_ticks; rv.lead_d = r->d_lead_d; rv.lead_state = r->d_state; rv.stats = r->d_stats; rv.fence_mode = r->fence_mode;
+    rv.idle_ticks = r->idle_ticks; rv.life_ticks = r->life_ticks; rv.lead_d = r->d_lead_d; rv.lead_stride = wfm_lead_max(r->D, r->L, r->F); rv.lead_state = r->d_state; rv.stats = r->d_stats; rv.fence_mode = r->fence_mode;
     CSDR_HIP(hipMemsetAsync(r->d_exiting, 0, sizeof(unsigned), r->rs));
     const int rc = wfm_mfma_launch_resident(r->rs, r->ev_exit, r->mfma, r->S, r->in_pitch, r->alpha, r->out_pitch, rv, r->grid);
     if (rc) return rc;
@@ -187,7 +187,7 @@ csdr_amd_wfm_ring *csdr_amd_wfm_ring_create(csdr_amd_ctx *ctx, int n_streams, fl
     auto alloc = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void **)&r->d_taps, sizeof(float) * taps_length);
     alloc((void **)&r->d_lead_seeds, sizeof(float2) * 8);
-    alloc((void **)&r->d_lead_d, sizeof(float) * 4 * n_streams);
+    alloc((void **)&r->d_lead_d, sizeof(float) * (size_t)wfm_lead_max(decimation, taps_length, frac_rate) * n_streams);
     alloc((void **)&r->d_warm, sizeof(float) * WFM_RES_WARM * n_streams);
     alloc((void **)&r->d_state, sizeof(float) * n_streams);
     alloc((void **)&r->d_list, sizeof(int) * n_streams);
@@ -300,14 +300,14 @@ long long csdr_amd_wfm_ring_submit(csdr_amd_wfm_ring *r)
         long nl = 0;
         if (lim >= 0) nl = (long)(lim / ((long long)r->D * r->F) - j_first + 1);
         if (nl < 0) nl = 0;
-        if (nl > 4) nl = 4;
+        if (nl > wfm_lead_max(r->D, r->L, r->F)) nl = wfm_lead_max(r->D, r->L, r->F);
         if (nl > n_audio) nl = n_audio;
         n_lead = (int)nl; retuned = 1;
         {
             rc = ring_stop(r); if (rc) return rc;
             CSDR_HIP(hipMemcpy(r->d_lead_seeds, seeds.data(), sizeof(float2) * 8, hipMemcpyHostToDevice));          // [0] = chunk first - 4
             const uint8_t *in = r->d_in + (size_t)slot * r->S * r->in_pitch, *prev = r->d_in + (size_t)((slot + r->N - 1) % r->N) * r->S * r->in_pitch;
-            rc = wfm_mfma_lead_shared(r->rs, in, r->in_pitch, prev, (size_t)2 * r->T, r->d_taps, r->d_lead_seeds, r->mfma.d_dtab, r->d_dtab_old, r->d_list, r->S, r->d_lead_d,
+            rc = wfm_mfma_lead_shared(r->rs, in, r->in_pitch, prev, (size_t)2 * r->T, r->d_taps, r->d_lead_seeds, r->mfma.d_dtab, r->d_dtab_old, r->d_list, r->S, r->d_lead_d, wfm_lead_max(r->D, r->L, r->F),
                                       r->d_warm, r->d_state, r->alpha, r->D, r->L, r->F, k * r->T, j_first, n_lead);
             if (rc) return rc;
             CSDR_HIP(hipStreamSynchronize(r->rs));
@@ -377,8 +377,6 @@ int csdr_amd_wfm_ring_replay(csdr_amd_wfm_ring *r, long n_blocks, double *t_firs
 int csdr_amd_wfm_ring_set_rate(csdr_amd_wfm_ring *r, float shift_rate)
 {
     if (shift_rate == r->rate) return 0;
-    if ((r->D + r->L - 1) / (r->D * r->F) + 2 > 4)
-        return fail_msg(-3, "wfm ring: live retune is not available for decimation %d, %d taps, audio decimation %d (more than 4 audio samples straddle a retune)", r->D, r->L, r->F);
     int rc;
     for (long long k = r->submitted - r->N; k < r->submitted; k++) if (k >= 0) { rc = ring_wait_block(r, k, 0); if (rc) return rc; }
     rc = ring_stop(r); if (rc) return rc;
