@@ -9,7 +9,7 @@ cache resident).  The headline `value` is at `--taps` (default 1023); `sweep` ho
 The interface keeps the reference's framing (blocks of 65537 - taps samples, state carried); behind it the library serves filters of <= 4096 taps with
 ONE pass over HBM (fftfilt_lds.hip: the same linear convolution by overlap-save with 4096 / 8192 / 16384-point transforms that fit a CU's LDS -- a 65536-point
 transform cannot, and needs three passes).  The line says which path ran (`config.method`, `roofline.kernel`); `full_size_transform` is the same step
-through the literal 65536-point block transform (three passes, fft64k.hip; `--method full` makes that one the headline; CSDR_AMD_FFT64Q=1: the measured two-pass alternative).
+through the literal 65536-point block transform (three passes, fft64k.hip; `--method full` makes that one the headline).
 
     python bench_fftfilt.py [--gpus N] [--steps K] [--warmup W] [--streams 64] [--blocks 16] [--taps 1023] [--method auto|full] [--no-sweep] [--verify]
 """
@@ -142,7 +142,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "configs[2]: bandpass_fir_fft_cc overlap-add, fft 65536, taps %d (firdes_bandpass_c -0.1 0.2 HAMMING)" % args.taps,
                           "streams_per_gpu": S, "blocks_per_step": nb, "input_size": inp, "taps": args.taps,
-                          "method": ("one pass: overlap-save windows of %d points in LDS behind the 65536-point framing" % window) if window else ("65536-point block transform in two passes (4 x 16384 points in LDS + a combine pass)" if "f64q" in kname else "65536-point transform, three passes"),
+                          "method": ("one pass: overlap-save windows of %d points in LDS behind the 65536-point framing" % window) if window else "65536-point transform, three passes",
                           "parallelism": "streams sharded, no data-path collective"},
                "roofline": {"bound": "hbm", "kernel": kname,
                             "achieved": round(algo / (k_ms * 1e-3) / 1e9, 1), "peak": bc.HBM_PEAK_GBS, "unit": "GB/s",

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <stdarg.h>
 #include <math.h>
 #include <stdio.h>
@@ -786,13 +787,13 @@ void file_input_init()
     if (k < 1) k = 1; if (k > 16) k = 16;
     g_file_in.regular = k > 1; g_file_in.pos = at; g_file_in.threads = k;
 }
-struct PreadJob { char *dst; size_t len; off_t off; size_t got; };
+struct PreadJob { char *dst; size_t len; off_t off; size_t got; int err; };
 void pread_all(PreadJob *j)
 {
-    j->got = 0;
+    j->got = 0; j->err = 0;
     while (j->got < j->len) {
         const ssize_t r = pread(STDIN_FILENO, j->dst + j->got, j->len - j->got, j->off + (off_t)j->got);
-        if (r < 0) { if (errno == EINTR) continue; break; }
+        if (r < 0) { if (errno == EINTR) continue; j->err = errno; break; }      // an I/O error is not the end of the file: reported by read_file_parallel
         if (r == 0) break;
         j->got += (size_t)r;
     }
@@ -845,7 +846,14 @@ void read_file_parallel(char *buf, size_t max_bytes, size_t *got, bool *eof)
         pthread_mutex_unlock(&g_pool.mu);
     } else for (int i = 0; i < n; i++) pread_all(&jobs[i]);
     size_t have = 0; bool end = false;
-    for (int i = 0; i < n && !end; i++) { have += jobs[i].got; if (jobs[i].got < jobs[i].len) end = true; }
+    for (int i = 0; i < n && !end; i++) {
+        have += jobs[i].got;
+        if (jobs[i].err) {                                            // not an end of file: say so and fail, instead of a silently truncated stream with exit status 0
+            fprintf(stderr, "csdr %s: read error on stdin at offset %lld (%s)\n", g_cmd, (long long)(jobs[i].off + (off_t)jobs[i].got), strerror(jobs[i].err));
+            exit(5);
+        }
+        if (jobs[i].got < jobs[i].len) end = true;
+    }
     g_file_in.pos += (off_t)have;
     (void)lseek(STDIN_FILENO, g_file_in.pos, SEEK_SET);               // (a later plain read() -- another command sharing the descriptor -- continues behind what was taken)
     *got = have; *eof = end;
@@ -893,7 +901,7 @@ void *writer_main(void *arg)
         size_t done = 0;
         while (done < b->bytes) {
             ssize_t r = write(STDOUT_FILENO, b->p + done, b->bytes - done);
-            if (r < 0) { if (errno == EINTR) continue; _exit(0); }                  // downstream closed: end quietly like SIGPIPE would
+            if (r < 0) { if (errno == EINTR) continue; _exit(128 + SIGPIPE); }      // downstream closed: end quietly, with the status a SIGPIPE death reports to the shell (141)
             done += (size_t)r;
         }
         io->free_out.push(b);
@@ -963,12 +971,15 @@ void *writer_ipc_main(void *arg)
             // the last token is out: close OUR end of the pipe too, now -- the consumer carries on reading bytes from stdin after the hand-off's end (another writer of the
             // same pipe may follow), and without this it saw stdin's EOF only when this process had torn its HIP context down: the seven tear-downs of the README.md:66
             // pipeline ran one after the other (+0.3 s per run, tools/bench_cli.sh)
-            io->sink_closing.store(true); shutdown(io->sink_fd, SHUT_WR); (void)close(STDOUT_FILENO);
+            // (descriptor 1 stays OCCUPIED -- /dev/null dup2'ed onto it: a bare close() would hand the number to the next open() / socket() of the runtime's tear-down,
+            //  and a late write to stdout would land in an unrelated file: ADVICE r5)
+            io->sink_closing.store(true); shutdown(io->sink_fd, SHUT_WR);
+            { const int nul = open("/dev/null", O_WRONLY); if (nul >= 0) { (void)dup2(nul, STDOUT_FILENO); if (nul != STDOUT_FILENO) (void)close(nul); } else (void)close(STDOUT_FILENO); }
             return nullptr;
         }
         if (b->pending) { (void)hipEventSynchronize(b->ev); b->pending = false; }          // the kernels that filled the slot have run
         IpcToken t = {(unsigned)b->slot, 0u, (unsigned long long)b->bytes};
-        if (send(io->sink_fd, &t, sizeof t, MSG_NOSIGNAL) != (ssize_t)sizeof t) _exit(0);   // downstream closed: end quietly like SIGPIPE would
+        if (send(io->sink_fd, &t, sizeof t, MSG_NOSIGNAL) != (ssize_t)sizeof t) _exit(128 + SIGPIPE);   // downstream closed: end quietly, with SIGPIPE's status
     }
 }
 void *credit_in_main(void *arg)
@@ -982,7 +993,7 @@ void *credit_in_main(void *arg)
         // slot in flight the main thread sits in free_out.pop() and the writer has no token left to send, so nobody would ever see EPIPE: end quietly,
         // as SIGPIPE ends a producer that writes bytes.
         if (r == 0 && io->sink_closing.load()) return nullptr;
-        if (r != (ssize_t)sizeof s || s < 0) _exit(0);
+        if (r != (ssize_t)sizeof s || s < 0) _exit(128 + SIGPIPE);      // (a truncated pipeline does not report success: ADVICE r5)
         io->free_out.push(&io->sink_bufs[s]);
     }
 }

@@ -60,7 +60,8 @@ struct DdcMfma {
     // fused forward transform (65536 = 512 x 128): intermediate Y[block][k1][n2], the kept overlap tail of the input stream, W_65536^lo table
     cf32 *d_Y, *d_tail[2]; float2 *d_twb; int flip, input_size, overlap;
     // A/B switches, read ONCE when the object is created: a call never looks at the environment
-    struct Opt { bool fwd_off, riders_off, spec_off, pass2_own, ifft_full, ifft16; int chains_side, fwd_cols, gemm; } opt;      // gemm: 0 default, 1 simple, 2 persist, 3 persist4
+    struct Opt { bool fwd_off, riders_off, spec_off, pass2_own; } opt;      // test hooks (tests/test_configs_gpu.py::test_c4_bank_alternative_paths): each turns one default choice off, so that the
+                                                                            // path other conditions select (a sharded bank, a size change, > 4096 channels) is crossed on one GPU
     // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
     bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -916,10 +917,6 @@ DdcMfma *ddc_mfma_create(csdr_amd_ctx *ctx, int fft, int inv, int pre, int n_cha
         o.fwd_off = getenv("CSDR_AMD_DDC_FWD_OFF") != nullptr;
         o.riders_off = getenv("CSDR_AMD_DDC_RIDERS_OFF") != nullptr; o.spec_off = getenv("CSDR_AMD_DDC_SPEC_OFF") != nullptr;
         o.pass2_own = getenv("CSDR_AMD_DDC_PASS2") != nullptr;
-        o.chains_side = getenv("CSDR_AMD_DDC_CHAINS") ? atoi(getenv("CSDR_AMD_DDC_CHAINS")) : 0;
-        const char *fv = getenv("CSDR_AMD_DDC_FWD"); o.fwd_cols = (fv && atoi(fv) == 8) ? 8 : 16;
-        const char *iv = getenv("CSDR_AMD_DDC_IFFT"); o.ifft_full = iv && strstr(iv, "512"); o.ifft16 = iv && strstr(iv, "16");
-        const char *ge = getenv("CSDR_AMD_DDC_GEMM"); o.gemm = !ge ? 0 : !strcmp(ge, "simple") ? 1 : !strcmp(ge, "persist4") ? 3 : !strncmp(ge, "persist", 7) ? 2 : 0;
     }
     m->nbl = m->world > 1 ? (max_blocks + m->world - 1) / m->world : m->nbp;
     const size_t xt_elems = (size_t)m->world * inv * m->nbl * pre;
@@ -1061,13 +1058,10 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const void *in, int fmt, con
     DdcChainJob cj; memset(&cj, 0, sizeof cj);
     if (riders) cj = *riders;
     const size_t rider_lanes = riders ? (cj.mode == 2 ? (size_t)cj.n_channels * cj.n_blocks : (size_t)cj.n_channels) : 0;      // mode 2: one lane per (block, channel) chain
-    // pass 1: 16 columns n2 per workgroup (128-byte runs); CSDR_AMD_DDC_FWD=8: 64-byte runs, more workgroups per CU
+    // pass 1: 16 columns n2 per workgroup (128-byte runs)
 #define DDC_FWD_ARGS in, reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
                      reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc, cj
-    if (m->opt.fwd_cols == 8 && fmt == 0) {
-        const size_t lds = (size_t)(8 * I512<8>::pitch + 512 + 128) * sizeof(float2);
-        hipLaunchKernelGGL((k_ddc_fwd512<8, 0>), dim3(16, n_loc + (riders ? cdiv(rider_lanes, 16 * 256) : 0)), dim3(256), lds, st, DDC_FWD_ARGS);
-    } else {
+    {
         const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
         const dim3 grid(8, n_loc + (riders ? cdiv(rider_lanes, 8 * 256) : 0));
 #define DDC_FWD_LAUNCH(F) do { const int rc = lds_attr_once((const void *)k_ddc_fwd512<16, F>, lds); if (rc) return rc; \
@@ -1098,8 +1092,7 @@ static bool ddc_folds_with_gemm3(const DdcMfma *m, int n_blocks)
     const int per_res = (int)(cdiv(m->Cpad, 256) * cdiv(n_blocks, 32 * nbt));
     int slots = current_device_cu_count() / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
     bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
-    if (m->opt.gemm == 1) persist = false; else if (m->opt.gemm >= 2 && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true;
-    return persist && m->pre == 128 && m->opt.gemm != 3;
+    return persist && m->pre == 128;
 }
 
 // few channel rows (a small bank, a rank's slice of a channel-sharded one): k_ddc_gemm3n; CSDR_AMD_DDC_NARROW=0 keeps the eight-wave kernel
@@ -1129,7 +1122,7 @@ int ddc_mfma_submit(DdcMfma *m, const void *in_v, const cf32 *spectra, int n_blo
     if (m->pending_blocks[k]) return fail_msg(-3, "fastddc: two calls are already staged; collect one first");
     hipStream_t mainst = m->ctx->stream;
     const bool inl = inline_call && m->world == 1 && !m->pending_blocks[k ^ 1];
-    const int chains_side = m->opt.chains_side;      // 1: the chains on the side stream beside the transforms (measured: 0.190 vs 0.186 ms per step)
+    const int chains_side = 0;                        // (1 = the chains on the side stream beside the transforms: measured 0.190 vs 0.186 ms per step, round 3; never selected)
     hipStream_t st = inl ? mainst : m->side;
     int rc = 0;
     const bool riders_off = m->opt.riders_off, spec_off = m->opt.spec_off;
@@ -1237,19 +1230,18 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
         CSDR_HIP(hipEventRecord(e0, st));
     }
     // persistent form (one workgroup per CU walks several residues, double-buffered spectra) when a residue's spectra fit the register staging
-    // and there are at least two residues per workgroup; CSDR_AMD_DDC_GEMM=simple / persist overrides
+    // and there are at least two residues per workgroup
     const int n_cu = current_device_cu_count();
     const int per_res = (int)(grid.y * grid.z);
     int slots = n_cu / per_res; if (slots < 1) slots = 1; if (slots > m->inv) slots = m->inv;
     bool persist = m->pre <= 128 && 2 * lds <= 160 * 1024 - 512 && slots * 2 <= m->inv;
-    if (m->opt.gemm == 1) persist = false; else if (m->opt.gemm >= 2 && m->pre <= 128 && 2 * lds <= 160 * 1024 - 512) persist = true;
     const size_t lds_use = persist ? 2 * lds : lds;
     const dim3 grid_use(persist ? (unsigned)slots : grid.x, grid.y, grid.z);
 #define DDC_GEMM_LAUNCH(NBTV, PV) do {                                                                                                               \
         if (lds_use > 64 * 1024) { const int rc = lds_attr_once((const void *)k_ddc_gemm<NBTV, PV>, lds_use); if (rc) return rc; }                    \
         hipLaunchKernelGGL((k_ddc_gemm<NBTV, PV>), grid_use, dim3(512), lds_use, st, m->d_Ht, reinterpret_cast<const float2 *>(m->d_Xt[k]),           \
                            reinterpret_cast<float2 *>(m->d_Ct), d_geom, m->inv, m->pre, m->Cpad, m->C, m->nbp, m->nbl, n_blocks, scale); } while (0)
-    // three-product form with LDS-DMA staging: pre_decimation 128 (a spectra row = one 1-KiB piece), persistent shape; CSDR_AMD_DDC_GEMM=persist4 keeps the four-product kernel
+    // three-product form with LDS-DMA staging: pre_decimation 128 (a spectra row = one 1-KiB piece), persistent shape; other geometries keep the four-product kernel k_ddc_gemm
     const bool three = ddc_folds_with_gemm3(m, n_blocks);
     m->gemm_three = three; m->gemm_narrow = false;
     if (three) {
@@ -1277,22 +1269,15 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
 #undef DDC_GEMM_LAUNCH
     CSDR_LAUNCH_CHECK();
     if (e1) CSDR_HIP(hipEventRecord(e1, st));
-    // inverse transforms.  post_decimation 2 (every power-of-two decimation): half-size transforms of the aliased bins; CSDR_AMD_DDC_IFFT = 512 keeps
-    // the full-size form, "16" whole 128-byte bin lines per workgroup (16 blocks) instead of half lines (8 blocks, more workgroups per CU)
-    const bool full = m->post_dec != 2 || m->opt.ifft_full;
-    const bool nt16 = m->opt.ifft16;
+    // inverse transforms.  post_decimation 2 (every power-of-two decimation): half-size transforms of the aliased bins; otherwise the full-size form.  Half 128-byte
+    // bin lines per workgroup (8 blocks: more workgroups per CU than whole lines -- the <16> instantiations measured slower in round 2 and are gone)
+    const bool full = m->post_dec != 2;
     const int pairs = m->C * cdiv(n_blocks, 16);
-    const dim3 g16(cdiv(n_blocks, 16), m->C), g8(cdiv(pairs, 8) * 16);
+    const dim3 g8(cdiv(pairs, 8) * 16);
 #define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R[k], m->d_tw, m->d_blk_remain[k], m->d_blk_off[k], d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in
     DdcChainJob ahead; memset(&ahead, 0, sizeof ahead);
-    if (full && nt16) {
-        const size_t lds2 = (size_t)(16 * I512<16>::pitch + I512<16>::tw_n) * sizeof(float2);
-        { const int rc = lds_attr_once((const void *)k_ddc_ifft512_post<16>, lds2); if (rc) return rc; }
-        hipLaunchKernelGGL(k_ddc_ifft512_post<16>, g16, dim3(256), lds2, st, DDC_IFFT_ARGS, m->post_dec);
-    } else if (full) {
+    if (full) {
         hipLaunchKernelGGL(k_ddc_ifft512_post<8>, g8, dim3(256), (size_t)(8 * I512<8>::pitch + I512<8>::tw_n) * sizeof(float2), st, DDC_IFFT_ARGS, m->post_dec);
-    } else if (nt16) {
-        hipLaunchKernelGGL(k_ddc_ifft256d_post<16>, g16, dim3(256), (size_t)(16 * I256<16>::pitch + 512) * sizeof(float2), st, DDC_IFFT_ARGS, ahead, 0);
     } else {
         int n_riders = 0;
         if (m->ahead_ok && m->inline_set[k] && m->last_state && m->C <= 16 * 256) {      // the next call's chain tables into the other set, state into the shadow

@@ -319,11 +319,6 @@ int fftfilt_lds_reset(FftfiltLds *p, hipStream_t st);
 int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch);
 const char *fftfilt_lds_kernel_name(const FftfiltLds *p);
 int fftfilt_lds_window(const FftfiltLds *p);
-struct Fft64q;                                // fftfilt_lds.hip: the 65536-point block in two passes (4 x 16384 in LDS + a combine pass)
-Fft64q *fft64q_create(hipStream_t st, const cf32 *taps, int taps_len);
-void fft64q_destroy(Fft64q *p);
-int fft64q_set_taps(Fft64q *p, hipStream_t st, const cf32 *taps, int taps_len);
-int fft64q_filter(Fft64q *p, hipStream_t st, const cf32 *in, size_t in_pitch, int inp, int ovl, int n_blocks, int ns, cf32 *d_work, cf32 *d_tails, cf32 *out, size_t out_pitch);
 int fft64k_tail_add(hipStream_t st, cf32 *out, size_t out_pitch, const cf32 *d_tails, const cf32 *d_carry_in, cf32 *d_carry_out, int inp, int ovl, int n_blocks, int n_streams);
 int fft64k_upload_tables(float2 *d_tw);
 int fft64k_transpose_taps(hipStream_t st, const cf32 *d_taps_fft, cf32 *d_taps_fft_t);
@@ -340,7 +335,6 @@ struct csdr_amd_fftfilt {
     cf32 *d_taps_fft_t; float2 *d_tw;      // fft_size 65536: taps spectrum in [k1][k2] order and the twiddle tables of the three-pass transform (fft64k.hip)
     int flip;
     hipfftHandle plan_one, plan_batch; int plan_batch_n;
-    csdr_amd::Fft64q *q64;                 // fft_size 65536 with CSDR_AMD_FFT64Q=1: the two-pass block filter instead of the three-pass transform of fft64k.hip
     csdr_amd::FftfiltLds *lds;             // taps short enough for LDS-sized windows: the one-pass kernel of fftfilt_lds.hip (every other buffer stays unallocated)
 };
 
@@ -367,7 +361,6 @@ int csdr_amd_fftfilt_set_taps(csdr_amd_fftfilt *f, const csdr_complexf *host_tap
     CSDR_HIP(hipStreamSynchronize(f->ctx->stream));
     CSDR_HIP(hipMemcpy(f->d_taps_fft, pad.data(), sizeof(cf32) * f->fft, hipMemcpyHostToDevice));
     CSDR_FFT(hipfftExecC2C(f->plan_one, (hipfftComplex *)f->d_taps_fft, (hipfftComplex *)f->d_taps_fft, HIPFFT_FORWARD));
-    if (f->q64) { const int rc = fft64q_set_taps(f->q64, f->ctx->stream, host_taps, taps_length); if (rc) return rc; }
     if (f->d_taps_fft_t) return fft64k_transpose_taps(f->ctx->stream, f->d_taps_fft, f->d_taps_fft_t);
     return 0;
 }
@@ -379,7 +372,6 @@ csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const
     csdr_amd_fftfilt *f = new csdr_amd_fftfilt();
     f->ctx = ctx; f->fft = fft_size; f->taps_len = taps_length; f->inp = fft_size - taps_length + 1; f->ovl = taps_length - 1;
     f->n_streams = n_streams; f->max_blocks = max_blocks; f->flip = 0; f->plan_batch_n = 0;
-    f->q64 = nullptr;
     f->lds = nullptr; f->d_taps_fft = f->d_pad = f->d_td = f->d_carry[0] = f->d_carry[1] = f->d_taps_fft_t = nullptr; f->d_tw = nullptr; f->plan_one = 0;
     if (const int win = fftfilt_lds_pick(taps_length)) {
         f->lds = fftfilt_lds_create(ctx->stream, win, host_taps, taps_length, n_streams);
@@ -401,13 +393,6 @@ csdr_amd_fftfilt *csdr_amd_fftfilt_create(csdr_amd_ctx *ctx, int fft_size, const
     if (e != hipSuccess) { fail(e, "hipMalloc(fftfilt)", __FILE__, __LINE__); delete f; return nullptr; }
     if (hipfftPlan1d(&f->plan_one, fft_size, HIPFFT_C2C, 1) != HIPFFT_SUCCESS) { fail_msg(-5, "hipfftPlan1d(%d) failed", fft_size); delete f; return nullptr; }
     hipfftSetStream(f->plan_one, ctx->stream);
-    // CSDR_AMD_FFT64Q=1: the two-pass form (4 x 16384 points in LDS + a combine pass, fftfilt_lds.hip "64q": 32 B per sample over HBM instead of 48) -- measured
-    // SLOWER than the three passes (0.83 against 0.70 ms per 64 x 16 blocks, profiles/r4_notes.md: the block transform is bound by fp32 vector adds, and one
-    // 1024-thread workgroup per CU exposes its loads and stores), so the three-pass form stays the default
-    if (f->d_taps_fft_t && f->ovl <= f->inp && getenv("CSDR_AMD_FFT64Q") && atoi(getenv("CSDR_AMD_FFT64Q")) != 0) {
-        f->q64 = fft64q_create(ctx->stream, host_taps, taps_length);
-        if (!f->q64) { csdr_amd_fftfilt_destroy(f); return nullptr; }
-    }
     if (csdr_amd_fftfilt_set_taps(f, host_taps, taps_length) || csdr_amd_fftfilt_reset(f)) { delete f; return nullptr; }
     return f;
 }
@@ -420,13 +405,12 @@ void csdr_amd_fftfilt_destroy(csdr_amd_fftfilt *f)
     hipfftDestroy(f->plan_one); if (f->plan_batch_n) hipfftDestroy(f->plan_batch);
     (void)hipFree(f->d_taps_fft); (void)hipFree(f->d_pad); (void)hipFree(f->d_td); (void)hipFree(f->d_carry[0]); (void)hipFree(f->d_carry[1]);
     (void)hipFree(f->d_taps_fft_t); (void)hipFree(f->d_tw);
-    fft64q_destroy(f->q64);
     delete f;
 }
 
 int csdr_amd_fftfilt_input_size(const csdr_amd_fftfilt *f) { return f->inp; }
 /* which path serves this filter: the one-pass kernel's name and its window size, or "" / 0 */
-const char *csdr_amd_fftfilt_kernel_name(const csdr_amd_fftfilt *f) { return f->lds ? fftfilt_lds_kernel_name(f->lds) : f->q64 ? "k_f64q_main + k_f64q_combine" : ""; }
+const char *csdr_amd_fftfilt_kernel_name(const csdr_amd_fftfilt *f) { return f->lds ? fftfilt_lds_kernel_name(f->lds) : ""; }
 int csdr_amd_fftfilt_window(const csdr_amd_fftfilt *f) { return f->lds ? fftfilt_lds_window(f->lds) : 0; }
 
 int csdr_amd_fftfilt_reset(csdr_amd_fftfilt *f)
@@ -446,23 +430,6 @@ int csdr_amd_fftfilt_process(csdr_amd_fftfilt *f, const csdr_complexf *in, csdr_
     if (f->lds) return fftfilt_lds_process(f->lds, st, in, in_pitch, (long)n_blocks * f->inp, out, out_pitch);
     const int batch = f->n_streams * n_blocks;
     int rc = 0;
-    if (f->q64) {
-        // the literal 65536-point block in two passes (fftfilt_lds.hip "64q"), group by group so that the intermediates (0.5 MiB per block, written by pass A and
-        // read by pass B) stay in the 256 MiB Infinity Cache; then the pass over the overlap regions
-        static const long group_env = getenv("CSDR_AMD_FFT64K_GROUP") ? atol(getenv("CSDR_AMD_FFT64K_GROUP")) : 256;
-        int sg = f->n_streams;
-        if (group_env > 0) { sg = (int)(group_env / n_blocks); if (sg < 1) sg = 1; if (sg > f->n_streams) sg = f->n_streams; }
-        for (int s0 = 0; s0 < f->n_streams; s0 += sg) {
-            const int ns = (f->n_streams - s0 < sg) ? f->n_streams - s0 : sg;
-            rc = fft64q_filter(f->q64, st, in + (size_t)s0 * in_pitch, in_pitch, f->inp, f->ovl, n_blocks, ns, f->d_pad + (size_t)s0 * n_blocks * f->fft,
-                               f->d_td + (size_t)s0 * n_blocks * f->ovl, out + (size_t)s0 * out_pitch, out_pitch);
-            if (rc) return rc;
-        }
-        rc = fft64k_tail_add(st, out, out_pitch, f->d_td, f->d_carry[f->flip], f->d_carry[f->flip ^ 1], f->inp, f->ovl, n_blocks, f->n_streams);
-        if (rc) return rc;
-        if (f->ovl > 0) f->flip ^= 1;
-        return 0;
-    }
     if (f->d_taps_fft_t && f->ovl <= f->inp) {
         // three passes + a pass over the overlap regions only; the inverse pass writes the output itself (d_td only holds the blocks' tails)
         rc = fft64k_filter_oa(st, in, in_pitch, f->inp, f->ovl, n_blocks, f->n_streams, f->d_pad, f->d_taps_fft_t, f->d_tw, f->d_td, f->d_carry[f->flip], f->d_carry[f->flip ^ 1], out, out_pitch);

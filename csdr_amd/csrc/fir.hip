@@ -246,7 +246,7 @@ static void launch_poly(csdr_amd_ctx *c, const PolyCfg &g, const T *in, T *out, 
 {
     // few, fat workgroups: ~16 resident-wave generations per CU at most; each walks a contiguous range of tiles with the next tile's loads in flight
     const int n_tiles = cdiv(n_out, 64 * g.R);
-    static const long want = getenv("CSDR_AMD_FIR_WGS") ? atol(getenv("CSDR_AMD_FIR_WGS")) : 256L * 7 * 8;
+    const long want = 256L * 7 * 8;
     const int per = (int)(((long)n_tiles * n_streams + want - 1) / want);
     const int tiles_per_wg = per < 1 ? 1 : per;
     dim3 grid(cdiv(n_tiles, tiles_per_wg), (unsigned)n_streams);
@@ -337,137 +337,6 @@ __global__ __launch_bounds__(256) void k_fir_mfma(const float2 *__restrict__ in,
         }
         // the next tile overwrites xw / red: everyone has read them (the reads above precede this barrier in program order of every wave)
         __syncthreads();
-    }
-}
-
-// k_fir_mfma2 (round 5): the same product with the TAPS OPERAND RESIDENT IN REGISTERS.  A[i][k] = h[k - D i] depends on the lane and the K-step only -- not on the
-// tile, not on the workgroup -- yet k_fir_mfma read it from LDS for every product (two 4-byte reads + ~4 address instructions per v_mfma), and the compiler, short of
-// registers beside the 64 staging registers, funnelled the eight A values of a batch through ONE register pair: three `s_waitcnt lgkmcnt(0)` in the middle of every
-// eight products (ISA of k_fir_mfma<8, 32>): ~680 cycles per eight products where the matrix pipe needs 256.  Here a wave loads its MAXS A values once per workgroup
-// (a workgroup walks up to 16 tiles), the K loop is fully unrolled (register-indexed A), a batch is eight B reads in flight followed by eight products on two
-// alternating accumulators, and the waves' K-ranges are whole blocks of four steps, so that the XOR swizzle of a block's four B addresses is one mask.
-// Zero padding makes the surplus steps of the last wave exact zeros.  Same sums per (wave, accumulator) order as k_fir_mfma up to the split points: fp32 rounding noise.
-template <int NT, int NS, int MAXB, int NW, int PD>                  // MAXB: blocks of four K-steps per wave (upper bound, compile time); NW waves per workgroup (the K split);
-__global__ __launch_bounds__(64 * NW, (NW == 8 && PD == 0) ? 4 : 2) void k_fir_mfma2(      // PD: how many tiles ahead the window is fetched into registers (0: after the tile, 1, 2)
-const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_size, size_t in_pitch, size_t out_pitch,
-                                                   int D, const float *__restrict__ taps, int L, int tiles_per_wg)
-{
-    extern __shared__ float4 lds_raw[];
-    constexpr int NTHR = 64 * NW;
-    const int TO = 16 * NT, W = (TO - 1) * D + L, PAD = 15 * D, KT = 15 * D + L, steps = (KT + 3) / 4, nblk = (steps + 3) / 4;
-    const int XW = (2 * (W + 8) + 63) & ~31;                           // window floats incl. the slack the surplus steps of the last block may read (zeros)
-    float *xw = reinterpret_cast<float *>(lds_raw);
-    float *hz = xw + XW;                                              // PAD zeros, the taps, zeros up to 16 nblk + 16 floats
-    float *red = hz + PAD + 16 * nblk + 16;                           // NW x 256 partial results
-    const size_t s = blockIdx.y;
-    const int t = threadIdx.x;
-    const int n_tiles = (n_out + TO - 1) / TO, tile0 = blockIdx.x * tiles_per_wg, tile1 = min(tile0 + tiles_per_wg, n_tiles);
-    if (tile0 >= n_tiles) return;
-    const float2 *base = in + s * in_pitch;
-    // two register sets: the windows of the next TWO tiles are in flight (PREF; with the taps resident a tile's products take ~3600 cycles, less than a fetch under load)
-    float2 v0[NS], v1[PD == 2 ? NS : 1];
-    auto fetch = [&](float2 (&v)[NS], int tile) {
-        const int first = tile * TO * D;
-#pragma unroll
-        for (int u = 0; u < NS; u++) { const int k = NTHR * u + t; v[u] = (k < W && first + k < input_size) ? base[(size_t)first + k] : make_float2(0.f, 0.f); }
-    };
-    fetch(v0, tile0);
-    if constexpr (PD == 2) { if (tile0 + 1 < tile1) fetch(reinterpret_cast<float2 (&)[NS]>(v1), tile0 + 1); }
-    for (int k = t; k < PAD + 16 * nblk + 16; k += NTHR) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
-    for (int k = W + 8 + t; 2 * k < XW; k += NTHR) { const int a = 2 * k; *reinterpret_cast<float2 *>(xw + (a ^ ((a >> 5) & 30))) = make_float2(0.f, 0.f); }      // (the same swizzle as the staging, which stops at W + 8 samples: never written again)
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
-    const int b_lo = wave * nblk / NW, b_hi = (wave + 1) * nblk / NW;   // this wave's blocks of four steps (wave uniform)
-    const int n = lane & 15, g = n >> 1, part = n & 1;
-    const float bm = g < NT ? 1.f : 0.f;
-    __syncthreads();                                                  // hz is complete
-    // ---- the resident A operand: step 4 (b_lo + j) + u of this wave, zero beyond its range (and beyond the band: hz is zero padded)
-    float A[4 * MAXB];
-    {
-        const float *ap = hz + PAD + kk - D * i + 16 * b_lo;
-#pragma unroll
-        for (int j = 0; j < MAXB; j++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) A[4 * j + u] = (b_lo + j < b_hi) ? ap[16 * j + 4 * u] : 0.f;
-    }
-    // ---- B addresses: float address a = 32 (D g' + blk) + (c + 8 u), c = 2 kk + part < 8, swizzled a ^ ((a >> 5) & 30): inside a block of four steps a >> 5 is one value
-    const int gq = g < NT ? g : 0;
-    const int c = 2 * kk + part;
-    const int h_last = D * gq + b_hi - 1 + (b_hi == b_lo);             // (blocks beyond the wave's range re-read its last one: multiplied by zero)
-    const uint32_t xw_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)xw;
-    static_assert(MAXB % 2 == 0, "batches of two blocks");
-#ifndef FIR2_DIAG
-#define FIR2_DIAG 0     // timing experiments: 1 = no products, 2 = the window staged for the first tile only, 3 = no global fetch after the first
-#endif
-    auto one_tile = [&](const int tile, float2 (&v)[NS]) {
-#pragma unroll
-        for (int u = 0; u < NS; u++) {
-            if (FIR2_DIAG == 2 && tile != tile0) break;
-            const int k = NTHR * u + t;
-            if (k < W + 8) { const int a = 2 * k; *reinterpret_cast<float2 *>(xw + (a ^ ((a >> 5) & 30))) = v[u]; }
-        }
-        __syncthreads();
-        if (PD > 0 && tile + PD < tile1 && FIR2_DIAG != 3) fetch(v, tile + PD);        // in flight during the products (PD = 2: this tile's and the next tile's)
-        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        int hi = D * gq + b_lo;                                        // a >> 5 of the block
-        asm volatile("" : "+v"(hi));                                  // (per tile: otherwise every B address is hoisted out of the tile loop -- 386 registers, one wave per SIMD)
-        // A batch = two blocks = eight B reads in flight, then eight products; the NEXT batch's reads are issued before this batch's products (two register sets).
-        // The reads are inline asm with the wait counted by hand: written as plain loads the compiler, minimising live ranges, serialised them
-        // (ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma, one LDS round trip per product).
-        float bA[8], bB[8];
-        auto issue = [&](float (&bv)[8], int blk0) {
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int h2 = min(blk0 + jj, h_last);
-                const int m = h2 & 30;
-                const uint32_t a0 = xw_addr + ((uint32_t)h2 << 7) + ((uint32_t)(c ^ m) << 2);      // byte address of step u = 0; step u: the (u ^ (m >> 3))-th quarter of the row
-#pragma unroll
-                for (int u = 0; u < 4; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(bv[4 * jj + u]) : "v"(a0 ^ (uint32_t)(u << 5)) : "memory");
-            }
-        };
-        if (FIR2_DIAG != 1) issue(bA, hi);
-#pragma unroll
-        for (int j = 0; j < (FIR2_DIAG == 1 ? 0 : MAXB); j += 4) {  // two batches per trip
-            if (j + 2 < MAXB) issue(bB, hi + j + 2);
-            if (j + 2 < MAXB) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bA[0]), "+v"(bA[1]), "+v"(bA[2]), "+v"(bA[3]), "+v"(bA[4]), "+v"(bA[5]), "+v"(bA[6]), "+v"(bA[7]));
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bA[0]), "+v"(bA[1]), "+v"(bA[2]), "+v"(bA[3]), "+v"(bA[4]), "+v"(bA[5]), "+v"(bA[6]), "+v"(bA[7]));
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * j + u], NT == 8 ? bA[u] : bA[u] * bm, acc, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * j + u + 1], NT == 8 ? bA[u + 1] : bA[u + 1] * bm, acc1, 0, 0, 0);
-            }
-            if (j + 2 < MAXB) {
-                if (j + 4 < MAXB) issue(bA, hi + j + 4);
-                if (j + 4 < MAXB) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bB[0]), "+v"(bB[1]), "+v"(bB[2]), "+v"(bB[3]), "+v"(bB[4]), "+v"(bB[5]), "+v"(bB[6]), "+v"(bB[7]));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bB[0]), "+v"(bB[1]), "+v"(bB[2]), "+v"(bB[3]), "+v"(bB[4]), "+v"(bB[5]), "+v"(bB[6]), "+v"(bB[7]));
-#pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * (j + 2) + u], NT == 8 ? bB[u] : bB[u] * bm, acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[4 * (j + 2) + u + 1], NT == 8 ? bB[u + 1] : bB[u + 1] * bm, acc1, 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) red[wave * 256 + r * 64 + lane] = acc[r] + acc1[r];
-        __syncthreads();
-        if (t < 256) {   // C layout: column = lane & 15 (n), row = 4 (lane >> 4) + reg (i)
-            const int r = t >> 6, ln = t & 63;
-            float sum = red[t];
-#pragma unroll
-            for (int wv = 1; wv < NW; wv++) sum += red[256 * wv + t];
-            const int nn = ln & 15, gg = nn >> 1, pp = nn & 1, ii = 4 * (ln >> 4) + r;
-            const int o = tile * TO + 16 * gg + ii;
-            if (gg < NT && o < n_out) reinterpret_cast<float *>(out + s * out_pitch + o)[pp] = sum;
-        }
-        __syncthreads();
-        if (PD == 0 && tile + 1 < tile1) fetch(v, tile + 1);
-    };
-    if constexpr (PD == 2) {
-        for (int tile = tile0; tile < tile1; tile += 2) {
-            one_tile(tile, v0);
-            if (tile + 1 < tile1) one_tile(tile + 1, reinterpret_cast<float2 (&)[NS]>(v1));
-        }
-    } else {
-        for (int tile = tile0; tile < tile1; tile++) one_tile(tile, v0);
     }
 }
 
@@ -592,148 +461,6 @@ const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_si
     }
 }
 
-// k_fir_mfma5 (round 5): SHORT filters on complexf (15 D + taps <= 256: fir_decimate_cc 10 / 79, BASELINE config 1) with k_fir_mfma3's means.  A tile of 128 outputs
-// reads only ~11 KiB here, so the K range is NOT split: each of the four waves owns a whole tile of its own (all 15-16 blocks of four K-steps, the taps operand -- the
-// same for every wave -- resident in 64 registers, no reduction through LDS), a workgroup step is FOUR consecutive tiles behind one window of ~43 KiB that arrives by
-// LDS-DMA (three workgroups per CU: while one multiplies, the others' windows land), two barriers per four tiles.  The band is 34 % dense: three times the flops of the
-// scalar kernel, on a pipe that has the room (k_fir_poly: 18 of 157 TFLOP/s).  Outputs leave as float2 (re from the even column's lane, im from its odd neighbour).
-template <int MAXB>
-__global__ __launch_bounds__(256, 3) void k_fir_mfma5(const float2 *__restrict__ in, float2 *__restrict__ out, int n_out, int input_size, size_t in_pitch, size_t out_pitch,
-                                                      int D, const float *__restrict__ taps, int L, int steps_per_wg)
-{
-    extern __shared__ float4 lds_raw[];
-    constexpr int NT = 8, NW = 4, NTHR = 256, TO = 16 * NT, TPI = 4;   // tiles per workgroup step
-    const int PAD = 15 * D, KT = 15 * D + L, ksteps = (KT + 3) / 4, nblk = (ksteps + 3) / 4;
-    const int n_pieces = (8 * (TO * D * (TPI - 1) + 16 * D * (NT - 1) + 16 * nblk + 8) + 1023) >> 10;      // 1-KiB DMA pieces of a step's window
-    const int ppw = (n_pieces + NW - 1) / NW;                          // pieces per wave (<= 16)
-    float *xw = reinterpret_cast<float *>(lds_raw);
-    float *hz = xw + 256 * n_pieces;                                  // PAD zeros, the taps, zeros up to 16 nblk + 16 floats
-    const size_t s = blockIdx.y;
-    const int t = threadIdx.x;
-    const int n_tiles = (n_out + TO - 1) / TO, n_steps = (n_tiles + TPI - 1) / TPI;
-    const int step0 = blockIdx.x * steps_per_wg, step1 = min(step0 + steps_per_wg, n_steps);
-    if (step0 >= n_steps) return;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
-    const uint8_t *row_base = reinterpret_cast<const uint8_t *>(in + s * in_pitch);
-    const uint32_t xw_addr = (uint32_t)(size_t)(__attribute__((address_space(3))) float *)xw;
-    auto stage = [&](int step) {
-        const long long first = (long long)step * TPI * TO * D;       // first sample of the window (even)
-        long long gmax = ((long long)input_size - first - 2) >> 1;    // last granule inside the stream
-        if (gmax < 0) gmax = 0;
-        const uint8_t *sbase = row_base + first * 8;
-        for (int r = 0; r < ppw; r++) {
-            const int piece = ppw * wave + r;
-            if (piece >= n_pieces) break;                             // (wave uniform)
-            const uint32_t gd = 64u * (uint32_t)piece + lane;
-            const uint32_t gs = gd ^ ((gd >> 5) & 7u);                // the readers' swizzle, on 16-byte granules, applied to the source
-            const uint32_t vo = 16u * (uint32_t)min((long long)gs, gmax);
-            const uint32_t la = __builtin_amdgcn_readfirstlane((int)(xw_addr + 1024u * (uint32_t)piece));
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(vo), "s"(sbase), "s"(la) : "memory");
-        }
-    };
-    stage(step0);
-    for (int k = t; k < PAD + 16 * nblk + 16; k += NTHR) { const int ti = k - PAD; hz[k] = (ti >= 0 && ti < L) ? taps[ti] : 0.f; }
-    const int n = lane & 15, g = n >> 1, part = n & 1;
-    __syncthreads();                                                  // hz is complete
-    float A[4 * MAXB];
-    {
-        const float *ap = hz + PAD + kk - D * i;
-#pragma unroll
-        for (int j = 0; j < MAXB; j++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) A[4 * j + u] = (j < nblk) ? ap[16 * j + 4 * u] : 0.f;
-    }
-    const int c = 2 * kk + part;
-    const int h0 = D * (NT * wave + g);                               // a >> 5 of this wave's tile, group g, block 0
-    const int h_last = h0 + nblk - 1;
-    typedef float e_v2f __attribute__((ext_vector_type(2))); typedef __attribute__((address_space(1))) e_v2f *gp_f2;
-#ifndef FIR5_DIAG
-#define FIR5_DIAG 0     // timing experiment: 1 = every tile's outputs go to the stream's first tile (stores that never leave L2): what the output stream costs
-#endif
-#ifndef FIR5_HOLD
-#define FIR5_HOLD 4
-#endif
-#ifndef FIR5_NT
-#define FIR5_NT 0
-#endif
-    gp_f2 obase = (gp_f2)(out + s * out_pitch);
-    e_v2f hold[FIR5_HOLD][2];
-    for (int step = step0; step < step1; step++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces (and its stores of the previous step)
-        __syncthreads();
-        const int tile = step * TPI + wave;
-        f32x4_mfma acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (tile < n_tiles) {                                          // (wave uniform)
-            int hi = h0;
-            asm volatile("" : "+v"(hi));
-            float bA[8], bB[8];
-            auto issue = [&](float (&bv)[8], int blk0, const int nb) {
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++) {
-                    if (jj >= nb) break;
-                    const int h2 = min(blk0 + jj, h_last);
-                    const int m = h2 & 28;
-                    const uint32_t a0 = xw_addr + ((uint32_t)h2 << 7) + ((uint32_t)(c ^ m) << 2);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(bv[4 * jj + u]) : "v"(a0 ^ (uint32_t)(u << 5)) : "memory");
-                }
-            };
-            constexpr int NBATCH = (MAXB + 1) / 2;
-            auto blocks_of = [](int q) { return (2 * q + 1 < MAXB) ? 2 : 1; };
-            issue(bA, hi, blocks_of(0));
-#pragma unroll
-            for (int q = 0; q < NBATCH; q++) {
-                float (&cur)[8] = (q & 1) ? bB : bA;
-                float (&nxt)[8] = (q & 1) ? bA : bB;
-                const int nbc = blocks_of(q);
-                if (q + 1 < NBATCH) {
-                    const int nbn = blocks_of(q + 1);
-                    issue(nxt, hi + 2 * (q + 1), nbn);
-                    if (nbn == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-                    else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-                } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-#pragma unroll
-                for (int u = 0; u < 4 * nbc; u += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[8 * q + u], cur[u], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[8 * q + u + 1], cur[u + 1], acc1, 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();                                              // every wave has left the window: the next one may land
-        if (step + 1 < step1) stage(step + 1);
-        // C layout: column = lane & 15 = (g, part), row = 4 kk + r: output 16 g + 4 kk + r of the tile.  Even lanes take rows 0, 1, odd lanes rows 2, 3, as float2.
-        // The outputs of FIR5_HOLD consecutive steps wait in registers and leave together: beside a saturated read stream the memory charges a thin stream of stores by the
-        // store EVENT (config 1 without its output stream: 0.89 ms instead of 1.08, for 9 % of the bytes) -- four steps = 16 KiB contiguous per workgroup burst.
-        {
-            float v[4], o[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] = acc[r] + acc1[r];
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = __shfl_xor(v[r], 1);   // the other part of the same output
-            const int hs = (step - step0) % FIR5_HOLD;
-#pragma unroll
-            for (int q = 0; q < FIR5_HOLD; q++) if (q == hs) {
-                hold[q][0] = part ? e_v2f{o[2], v[2]} : e_v2f{v[0], o[0]};
-                hold[q][1] = part ? e_v2f{o[3], v[3]} : e_v2f{v[1], o[1]};
-            }
-            if (hs == FIR5_HOLD - 1 || step + 1 == step1) {
-#pragma unroll
-                for (int q = 0; q < FIR5_HOLD; q++) {
-                    if (q > hs) break;
-                    const int tq = (step - hs + q) * TPI + wave;
-                    const int ob = (FIR5_DIAG == 1 ? 0 : tq) * TO + 16 * g + 4 * kk + (part ? 2 : 0);
-                    if (tq < n_tiles) {
-                        if (ob < n_out) { if (FIR5_NT) __builtin_nontemporal_store(hold[q][0], &obase[ob]); else obase[ob] = hold[q][0]; }
-                        if (ob + 1 < n_out) { if (FIR5_NT) __builtin_nontemporal_store(hold[q][1], &obase[ob + 1]); else obase[ob + 1] = hold[q][1]; }
-                    }
-                }
-            }
-        }
-    }
-}
-
 } // namespace
 
 static int pick_tile(int D, int ntaps, int floats_per_sample, int n_out)
@@ -760,32 +487,16 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
     const int n_out = (input_size - taps_length) / decimation + 1;     // libcsdr.c:536-538 loop bound
     PolyCfg g;
     // (the FIR entry points are plain functions: their A/B switches are read once per process)
-    static const bool force_generic = getenv("CSDR_AMD_FIR_GENERIC") != nullptr, mfma_off = getenv("CSDR_AMD_FIR_MFMA_OFF") != nullptr;
-    {   // short filters on the matrix cores behind an LDS-DMA window (k_fir_mfma5): 15 D + taps <= 256, even stream length, 16-byte aligned rows.  OPT-IN
-        // (CSDR_AMD_FIR_MFMA5=1): measured on config 1 it runs exactly as fast as k_fir_poly -- 0.971 vs 0.964 ms on a process whose buffers sit well, 1.091 vs 1.081 on
-        // one whose do not (the same box, the same clocks: profiles/r5_notes.md) -- i.e. config 1 is bound by the memory system for this access pattern, not by the kernel
-        static const bool mfma5_off = !(getenv("CSDR_AMD_FIR_MFMA5") && atoi(getenv("CSDR_AMD_FIR_MFMA5")) == 1);
-        const int KT = 15 * decimation + taps_length, nblk5 = ((KT + 3) / 4 + 3) / 4;
-        const long win = 128L * decimation * 3 + 16L * decimation * 7 + 16L * nblk5 + 8;
-        const size_t lds5 = (((size_t)8 * win + 1023) & ~(size_t)1023) + sizeof(float) * (15 * (size_t)decimation + 16 * (size_t)nblk5 + 16);
-        if (!mfma5_off && !force_generic && nblk5 <= 16 && nblk5 >= 2 && lds5 <= 52 * 1024 && (in_pitch % 2) == 0 && (input_size % 2) == 0 && (((uintptr_t)in) & 15) == 0 && n_out >= 128) {
-            const int n_tiles = cdiv(n_out, 128), n_steps = cdiv(n_tiles, 4);
-            int spw = (int)(((long)n_steps * n_streams + 6143) / 6144); if (spw < 1) spw = 1; if (spw > 32) spw = 32;      // ~6144 workgroups (3 per CU x 8 rounds), each a run of consecutive steps
-            const dim3 grid(cdiv(n_steps, spw), (unsigned)n_streams);
-            hipLaunchKernelGGL((k_fir_mfma5<16>), grid, dim3(256), lds5, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,
-                               decimation, taps, taps_length, spw);
-            CSDR_LAUNCH_CHECK();
-            g_fir_last_kernel = "k_fir_mfma5";
-            return n_out;
-        }
-    }
+    static const bool force_generic = getenv("CSDR_AMD_FIR_GENERIC") != nullptr;      // (A/B and the generic kernel's own parity test)
+    // (Short filters -- config 1's 10 / 79 -- stay on k_fir_poly: the matrix-core construction of the long-filter kernel was ported to that shape in round 5 (k_fir_mfma5) and ran
+    //  exactly as fast: experiments/fir_mfma5.hip.)
     if (!force_generic && poly_cfg(decimation, taps_length, 8, g)) {
         launch_poly<float2>(c, g, (const float2 *)in, (float2 *)out, n_out, n_streams, in_pitch, out_pitch, decimation, taps, taps_length);
         CSDR_LAUNCH_CHECK();
         g_fir_last_kernel = "k_fir_poly";
         return n_out;
     }
-    if (!mfma_off) {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
+    {   // long filters: banded product on the fp32 matrix cores (NT groups of 16 outputs per workgroup, window <= ~64 KiB)
         for (int nt = 8; nt >= 1; nt >>= 1) {
             const int W = (16 * nt - 1) * decimation + taps_length, steps = (15 * decimation + taps_length + 3) / 4;
             const size_t lds = sizeof(float) * (2 * (size_t)(W + 8) + 32 + 15 * (size_t)decimation + 4 * (size_t)steps + 4 + 1024);
@@ -798,53 +509,25 @@ int csdr_amd_fir_decimate_cc(csdr_amd_ctx *c, const csdr_complexf *in, csdr_comp
             hipLaunchKernelGGL((k_fir_mfma<NTV, NSV>), grid, dim3(256), lds, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,   \
                                decimation, taps, taps_length, tpw); } while (0)
 #define FIR_MFMA_NS(NTV) do { if (ns <= 8) FIR_MFMA(NTV, 8); else if (ns <= 16) FIR_MFMA(NTV, 16); else FIR_MFMA(NTV, 32); } while (0)
-            // round 5: the taps operand in registers (k_fir_mfma2) where a wave's K-range fits 26 blocks of four steps (<= 1664 K values per workgroup: 50 / 801 has 1551)
-            // and the tile is 64 or 128 outputs; CSDR_AMD_FIR_MFMA2=0 keeps the round-2 kernel (A/B)
-            static const bool mfma2_off = !(getenv("CSDR_AMD_FIR_MFMA2") && atoi(getenv("CSDR_AMD_FIR_MFMA2")) == 1);      // register-staged variant: measured slower than the round-2 kernel, opt-in
-            static const int mfma2_waves = getenv("CSDR_AMD_FIR_MFMA2_WAVES") ? atoi(getenv("CSDR_AMD_FIR_MFMA2_WAVES")) : 4;      // 4 or 8 waves per workgroup (A/B)
-            static const int mfma2_pd = getenv("CSDR_AMD_FIR_MFMA2_PD") ? atoi(getenv("CSDR_AMD_FIR_MFMA2_PD")) : 1;               // prefetch depth (A/B)
-            const int nw = mfma2_waves == 8 ? 8 : 4;
-            const int nblk = (steps + 3) / 4, per_wave = (nblk + nw - 1) / nw + 1;
-            const int xwf = (2 * (W + 8) + 63) & ~31, ns2 = cdiv(W + 8, 64 * nw);
-            const size_t lds2 = sizeof(float) * ((size_t)xwf + 15 * (size_t)decimation + 16 * (size_t)nblk + 16 + 256 * (size_t)nw);
+            const int nblk = (steps + 3) / 4;
             // k_fir_mfma3: the window by LDS-DMA.  Needs: 8 outputs groups, <= 14 blocks per wave, the window + slack inside 64 KiB, 16-byte aligned stream rows
-            static const bool mfma3_off = getenv("CSDR_AMD_FIR_MFMA3") && atoi(getenv("CSDR_AMD_FIR_MFMA3")) == 0;
             {
                 const int per_wave8 = (nblk + 7) / 8 + 1;      // (<= 14 blocks per wave)
                 const long win_samples = 16L * decimation * 7 + 16L * nblk + 8;
                 const size_t lds3 = (((size_t)8 * win_samples + 1023) & ~(size_t)1023) + sizeof(float) * (15 * (size_t)decimation + 16 * (size_t)nblk + 16 + 2048);
-                if (!mfma3_off && nt == 8 && per_wave8 <= 15 && win_samples <= 8192 && (in_pitch % 2) == 0 && (input_size % 2) == 0 && (((uintptr_t)in) & 15) == 0 && lds3 <= 80 * 1024) {
-                    static const int mfma3_waves = getenv("CSDR_AMD_FIR_MFMA3_WAVES") ? atoi(getenv("CSDR_AMD_FIR_MFMA3_WAVES")) : 8;      // 8 (two workgroups per CU) or 16 (one, two windows)
-                    const size_t win_bytes = ((size_t)8 * win_samples + 1023) & ~(size_t)1023;
-                    const size_t lds4 = 2 * win_bytes + sizeof(float) * (15 * (size_t)decimation + 16 * (size_t)nblk + 16 + 4096);
+                if (nt == 8 && per_wave8 <= 15 && win_samples <= 8192 && (in_pitch % 2) == 0 && (input_size % 2) == 0 && (((uintptr_t)in) & 15) == 0 && lds3 <= 80 * 1024) {
+                    // two eight-wave workgroups per CU, one window each.  (Round 5 also measured ONE sixteen-wave workgroup with two windows -- k_fir_mfma3<.., 16, true> --:
+                    // slower, profiles/r5_notes.md; it is no longer instantiated.)
 #define FIR_MFMA3(MB, NWV, DBV, LDSV) do { const int arc = lds_attr_once((const void *)k_fir_mfma3<MB, NWV, DBV>, LDSV); if (arc) return arc;                                                      \
                     hipLaunchKernelGGL((k_fir_mfma3<MB, NWV, DBV>), grid, dim3(64 * NWV), LDSV, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch,        \
                                        decimation, taps, taps_length, tpw); } while (0)
-                    if (mfma3_waves == 16 && lds4 <= 160 * 1024 - 512 && (nblk + 15) / 16 <= 7) {
-                        const int need16 = (nblk + 15) / 16;
-                        if (need16 <= 4) FIR_MFMA3(4, 16, true, lds4); else if (need16 <= 5) FIR_MFMA3(5, 16, true, lds4); else if (need16 <= 6) FIR_MFMA3(6, 16, true, lds4); else FIR_MFMA3(7, 16, true, lds4);
-                    } else {
                     const int need = (nblk + 7) / 8;                 // the largest wave share: wave w takes blocks [w nblk / 8, (w + 1) nblk / 8)
                     if (need <= 8) FIR_MFMA3(8, 8, false, lds3); else if (need <= 10) FIR_MFMA3(10, 8, false, lds3); else if (need <= 12) FIR_MFMA3(12, 8, false, lds3); else if (need <= 13) FIR_MFMA3(13, 8, false, lds3); else FIR_MFMA3(14, 8, false, lds3);
-                    }
 #undef FIR_MFMA3
                     CSDR_LAUNCH_CHECK();
                     g_fir_last_kernel = "k_fir_mfma3";
                     return n_out;
                 }
-            }
-            if (!mfma2_off && nt == 8 && per_wave <= (nw == 8 ? 14 : 26) && ns2 <= (nw == 8 ? 16 : 32) && lds2 <= 76 * 1024) {
-#define FIR_MFMA2(NSV, MB, NWV, PDV) do { if (lds2 > 64 * 1024) { const int arc = lds_attr_once((const void *)k_fir_mfma2<8, NSV, MB, NWV, PDV>, lds2); if (arc) return arc; }            \
-            hipLaunchKernelGGL((k_fir_mfma2<8, NSV, MB, NWV, PDV>), grid, dim3(64 * NWV), lds2, c->stream, (const float2 *)in, (float2 *)out, n_out, input_size, in_pitch, out_pitch, \
-                               decimation, taps, taps_length, tpw); } while (0)
-                if (nw == 8) { if (mfma2_pd == 2) FIR_MFMA2(16, 14, 8, 2); else FIR_MFMA2(16, 14, 8, 1); }
-                else if (ns2 <= 16) FIR_MFMA2(16, 26, 4, 1);
-                else if (mfma2_pd == 0) FIR_MFMA2(32, 26, 4, 0);
-                else FIR_MFMA2(32, 26, 4, 1);
-#undef FIR_MFMA2
-                CSDR_LAUNCH_CHECK();
-                g_fir_last_kernel = "k_fir_mfma2";
-                return n_out;
             }
             if (nt == 8) FIR_MFMA_NS(8); else if (nt == 4) FIR_MFMA_NS(4); else if (nt == 2) FIR_MFMA_NS(2); else FIR_MFMA_NS(1);
 #undef FIR_MFMA_NS

@@ -530,7 +530,6 @@ int csdr_amd_debug_wfm_seq_tile(int D, int L, int F, float shift_rate, const flo
 void csdr_amd_debug_dft16(const float *in32, float *out32, int inverse);
 /* Test hook: the 8-point butterfly of the channelizer's 512-point inverse transforms (fastddc_mfma.hip) on the CPU; 8 interleaved complex floats */
 int  csdr_amd_debug_fftfilt_lds(int n, const float *taps_iq, int taps_len, const float *x_iq, long m_new, float *y_iq);   /* CPU run of the one-pass filter kernel's stages */
-int  csdr_amd_debug_fft64q(const float *taps_iq, int taps_len, const float *x_iq, int inp, float *y_iq);   /* CPU run of the two-pass 65536-point block (k_f64q_main + k_f64q_combine): y = 65536 samples */
 void csdr_amd_debug_dft8(const float *in16, float *out16, int inverse);
 /* Test hook: the channelizer's residual-shift bookkeeping (decimating_shift_addition_cc's (remain, phase) per block, libcsdr_gpl.c:153-158) over n_blocks blocks on the
  * CPU; mode 0 = the general step, mode 1 = the constant-step fast path of the kernels (-1 when it does not apply).  phases_out[b] = phase in front of block b. */

@@ -323,23 +323,3 @@ def test_phase_chain_plan_on_two_million_values(libpath):
         ph = x
         bad = np.nonzero(got[:, k].view(np.uint32) != ph.view(np.uint32))[0]
         assert bad.size == 0, (k, float(rates[bad[0]]))
-
-
-def test_fft64q_two_pass_block_on_cpu(libpath):
-    """The literal 65536-point block of apply_fir_fft_cc (libcsdr.c:814-849) as the device computes it in two passes (fftfilt_lds.hip "64q": radix-4 step in the
-    time domain, four 16384-point transforms with the bin product in LDS, four-point combine) -- the same stage functions run thread by thread on the CPU
-    (csdr_amd_debug_fft64q) against numpy's transform of the zero-padded block: own samples and tail."""
-    import numpy as np
-    L = C.CDLL(libpath)
-    L.csdr_amd_debug_fft64q.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    rng = np.random.default_rng(64)
-    for nt in (4095, 9001):
-        taps = ((rng.normal(size=nt) + 1j * rng.normal(size=nt)) / nt).astype(np.complex64)
-        inp = 65536 - nt + 1
-        x = (rng.uniform(-1, 1, inp) + 1j * rng.uniform(-1, 1, inp)).astype(np.complex64)
-        y = np.zeros(65536, np.complex64)
-        assert L.csdr_amd_debug_fft64q(taps.ctypes.data, nt, x.ctypes.data, inp, y.ctypes.data) == 0
-        xp = np.zeros(65536, np.complex128); xp[:inp] = x
-        tp = np.zeros(65536, np.complex128); tp[:nt] = taps
-        want = np.fft.ifft(np.fft.fft(xp) * np.fft.fft(tp))
-        assert np.sqrt(np.mean(np.abs(y - want) ** 2) / np.mean(np.abs(want) ** 2)) < 2e-6

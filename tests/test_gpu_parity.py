@@ -158,36 +158,6 @@ def test_fir_decimate_long_filter_dma_kernel(gpu, port, D, ntaps):
     assert y1.size == w1.size and relrms(y1, w1) < TOL
 
 
-def test_fir_short_filter_matrix_kernel_in_a_subprocess(port):
-    """k_fir_mfma5 (round 5, opt-in with CSDR_AMD_FIR_MFMA5=1 -- the switch is read once per process, hence the subprocess): fir_decimate_cc 10 / 79 as a banded product
-    on the fp32 matrix cores behind an LDS-DMA window, four tiles of 128 outputs per workgroup step.  Three streams x (nine tiles + 37 outputs), a partial last step, a
-    stream end inside the window: against the oracle."""
-    import subprocess
-    import sys
-    import os
-    code = r"""
-import numpy as np, sys
-sys.path.insert(0, %r)
-import torch, csdr_amd, oracle
-from oracle import relrms
-ctx = csdr_amd.Context(0); port = oracle.port()
-rng = np.random.default_rng(77)
-taps = port.firdes_lowpass_f(79, 0.05)
-n = 128 * 10 * 9 + 79 + 10 * 37 + 1
-n += n %% 2
-xs = np.stack([(rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64) for _ in range(3)])
-ys = ctx.fir_decimate_cc(xs, 10, taps)
-assert ctx.L.csdr_amd_fir_last_kernel() == b"k_fir_mfma5", ctx.L.csdr_amd_fir_last_kernel()
-for s in range(3):
-    want = port.fir_decimate_cc(xs[s], 10, taps)
-    assert ys[s].size == want.size and relrms(ys[s], want) < 1e-5, (s, relrms(ys[s], want))
-print("ok", ys.shape)
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CSDR_AMD_FIR_MFMA5="1")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=180)
-    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-600:]
-
-
 def test_fir_decimate_c1_and_edges(gpu, port):
     rng = np.random.default_rng(1234)
     x = crand(rng, 16384)                                          # BASELINE config 1
@@ -338,15 +308,6 @@ def test_bandpass_fir_fft_paths(gpu, port, monkeypatch):
         a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=2)
         for s in range(2):
             assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, fft)) < TOL
-    # the 65536-point block in two passes (fftfilt_lds.hip "64q": radix-4 step in the time domain, 4 x 16384 points in LDS, combine) -- a measured alternative, not the default
-    monkeypatch.setenv("CSDR_AMD_FFT64Q", "1")
-    assert path_of(1023, 65536)[0] == "k_f64q_main + k_f64q_combine"
-    for ntaps, nstreams, blocks in [(1023, 11, 3), (8191, 2, 2), (32769, 1, 2)]:                 # (11 streams x 3 blocks: a ragged last group of eight blocks)
-        x = np.stack([crand(rng, (65536 - ntaps + 1) * blocks) for _ in range(nstreams)])
-        taps = port.firdes_bandpass_c(ntaps, -0.1, 0.2)
-        a = gpu.bandpass_fir_fft_cc(x, taps, 65536, blocks_per_call=2)
-        for s in (0, nstreams - 1):
-            assert relrms(a[s], port.bandpass_fir_fft_cc(x[s], taps, 65536)) < TOL, (ntaps, s)
 
 
 def test_bandpass_one_pass_ragged(gpu, port):
