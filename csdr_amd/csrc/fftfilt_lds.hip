@@ -107,6 +107,26 @@ FFL_HD void ffl_mid(float2 *lds, const float2 *tws, int t)
 }
 
 // ---- centre: last forward stage (L = R, stride 1) from LDS, bin product with the taps spectrum (slot order: Hperm[slot * T + t]), first inverse stage back to LDS
+// A thread's R points are consecutive.  R = 16 under pad-one-per-eight (the 16384-point plan): lane stride 18 points = 36 dwords, as 8-byte accesses only 16 different
+// bank pairs per 32 lanes -- every access a two-way conflict (SQ_LDS_BANK_CONFLICT = 52 % of the LDS's active cycles at 4095 taps, profiles/r6_fftfilt_pmc_issue.json).
+// As 16-byte accesses of the aligned pairs the same stride is conflict free (16 lanes x 4 banks, starting banks = the 16 multiples of 4): points 0-7 are four aligned
+// pairs, 8 and 15 stay single, 9-14 are three pairs.
+template <int PS> FFL_HD void ffl_pair_load(float2 &a, float2 &b, const float2 *p)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    const float4 v = *reinterpret_cast<const float4 *>(p); a = make_float2(v.x, v.y); b = make_float2(v.z, v.w);
+#else
+    a = p[0]; b = p[1];
+#endif
+}
+template <int PS> FFL_HD void ffl_pair_store(float2 *p, float2 a, float2 b)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    *reinterpret_cast<float4 *>(p) = make_float4(a.x, a.y, b.x, b.y);
+#else
+    p[0] = a; p[1] = b;
+#endif
+}
 template <int N, int R>
 FFL_HD void ffl_centre(float2 *lds, const float2 *hperm, int t)
 {
@@ -115,14 +135,34 @@ FFL_HD void ffl_centre(float2 *lds, const float2 *hperm, int t)
     for (int u = 0; u < U; u++) {
         const int q = t + G::T * u, base = q * R;
         float2 a[R];
+        if constexpr (R == 16 && PS == 3) {
+            float2 *p0 = lds + ffl_pad<PS>(base);                       // 18 q: even; points j < 8 at p0 + j, points j >= 8 at p0 + j + 1
 #pragma unroll
-        for (int j = 0; j < R; j++) a[j] = lds[ffl_pad<PS>(base + j)];
+            for (int j = 0; j < 8; j += 2) ffl_pair_load<PS>(a[j], a[j + 1], p0 + j);
+            a[8] = p0[9];
+#pragma unroll
+            for (int j = 9; j < 15; j += 2) ffl_pair_load<PS>(a[j], a[j + 1], p0 + j + 1);
+            a[15] = p0[16];
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) a[j] = lds[ffl_pad<PS>(base + j)];
+        }
         FflDft<R, false>::run(a);
 #pragma unroll
         for (int k = 0; k < R; k++) a[k] = cmul(a[k], hperm[(size_t)(u * R + k) * G::T + t]);      // libcsdr.c:826-830 (and 836-839: the 1/N is in the table)
         FflDft<R, true>::run(a);
+        if constexpr (R == 16 && PS == 3) {
+            float2 *p0 = lds + ffl_pad<PS>(base);
 #pragma unroll
-        for (int j = 0; j < R; j++) lds[ffl_pad<PS>(base + j)] = a[j];
+            for (int j = 0; j < 8; j += 2) ffl_pair_store<PS>(p0 + j, a[j], a[j + 1]);
+            p0[9] = a[8];
+#pragma unroll
+            for (int j = 9; j < 15; j += 2) ffl_pair_store<PS>(p0 + j + 1, a[j], a[j + 1]);
+            p0[16] = a[15];
+        } else {
+#pragma unroll
+            for (int j = 0; j < R; j++) lds[ffl_pad<PS>(base + j)] = a[j];
+        }
     }
 }
 
@@ -174,6 +214,12 @@ template <int N> int ffl_slot_position(int slot, int t)
 // Buffer loads / stores with the hardware range check do the edges: a window's samples in front of the call's input come from the history (a second
 // descriptor), samples behind its end read as zero, results outside [0, m_new) are dropped -- no divergent branch anywhere.  (The LLVM intrinsics are declared
 // directly, see fir.hip.)
+// The phases exchange data through LDS only.  __syncthreads() is a workgroup-scope fence over EVERY address space: it puts `s_waitcnt vmcnt(0)` in front of the
+// barrier, i.e. every barrier drains the global loads and stores in flight -- the previous window's 16 output stores at this window's first barrier, and a prefetch of the
+// next window could never fly under the butterflies at all (round 6: found when the 512-thread form of the 16384-point window ran SLOWER with the prefetch than without).
+// Here: LDS operations complete (lgkmcnt), then the barrier; global memory operations stay in flight across it.
+__device__ __forceinline__ void ffl_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N>
 __device__ __forceinline__ void ffl_load_window(float2 (&v)[16], const float2 *x, const float2 *h, int w0, int k1p, int m_new, int t)
 {
@@ -204,70 +250,91 @@ __device__ __forceinline__ void ffl_prefetch_issue(ffl_f32x2 (&nx)[16], const fl
 #pragma unroll
     for (int j = 0; j < 16; j++) { const int vo = v0 + T * 8 * j; asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(nx[j]) : "v"(vo), "s"(rx) : "memory"); }
 }
+template <int INFLIGHT>
 __device__ __forceinline__ void ffl_prefetch_ready(ffl_f32x2 (&nx)[16])
 {
-    asm volatile("s_waitcnt vmcnt(16)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(nx[4]), "+v"(nx[5]), "+v"(nx[6]), "+v"(nx[7]),
-                                         "+v"(nx[8]), "+v"(nx[9]), "+v"(nx[10]), "+v"(nx[11]), "+v"(nx[12]), "+v"(nx[13]), "+v"(nx[14]), "+v"(nx[15]));
+    asm volatile("s_waitcnt vmcnt(%16)" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[2]), "+v"(nx[3]), "+v"(nx[4]), "+v"(nx[5]), "+v"(nx[6]), "+v"(nx[7]),
+                                         "+v"(nx[8]), "+v"(nx[9]), "+v"(nx[10]), "+v"(nx[11]), "+v"(nx[12]), "+v"(nx[13]), "+v"(nx[14]), "+v"(nx[15]) : "n"(INFLIGHT));
 }
 
-template <int N, bool PF, int MINWG, bool HOIST>
-__global__ __launch_bounds__(N / 16, MINWG) void k_fftfilt_lds(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, int m_new,
+// LPT (round 6): logical threads per physical thread.  The stage functions are written for N / 16 logical threads of 16 points each; with LPT = 2 a physical thread runs
+// two of them one after the other (t and t + N / 32), so a 16384-point window is ONE workgroup of 512 threads = two waves per SIMD with 256 registers each instead of four
+// with 128: room for the next window's 32 input samples per thread in flight under this window's butterflies (PF), half as many waves at every barrier.  Counters of the
+// 1024-thread form (profiles/r6_fftfilt_pmc_issue.json): the vector ALU busy 46 % of the kernel's time, every wave parked (barrier / waitcnt) 52 % of its life -- one
+// workgroup per CU whose memory phase and butterflies do not overlap at all.
+template <int N, bool PF, int MINWG, bool HOIST, int LPT = 1>
+__global__ __launch_bounds__(N / 16 / LPT, MINWG) void k_fftfilt_lds(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, int m_new,
                                                         int n_chunks, int n_windows, float2 *__restrict__ out, size_t out_pitch, const float2 *hperm,
                                                         const float2 *__restrict__ g_tw1, const float2 *__restrict__ g_tws)
 {
     using G = FflGeom<N>;
+    constexpr int TP = G::T / LPT;                                      // physical threads
     extern __shared__ float4 ffl_raw[];
     float2 *lds = reinterpret_cast<float2 *>(ffl_raw), *tws = lds + G::DATA;
     const int t = threadIdx.x;
-    for (int i = t; i < G::TWN; i += G::T) tws[i] = g_tws[i];
-    float2 w1 = g_tw1[t];
+    for (int i = t; i < G::TWN; i += TP) tws[i] = g_tws[i];
+    float2 w1[LPT];
+#pragma unroll
+    for (int h = 0; h < LPT; h++) w1[h] = g_tw1[t + h * TP];
     const int V = N - k1p;
     const int per_xcd = (n_windows + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;      // gridDim.x is a multiple of 8
     const int w_end = min(n_windows, (xcd + 1) * per_xcd);
     int w = xcd * per_xcd + (blockIdx.x >> 3);
     if (w >= w_end) return;
-    float2 v[16]; ffl_f32x2 nx[16];
+    float2 v[LPT][16]; ffl_f32x2 nx[LPT][16];
     {
         const int s = w / n_chunks, c = w - s * n_chunks;
-        ffl_load_window<N>(v, in + (size_t)s * in_pitch, hist + (size_t)s * k1p, c * V - k1p, k1p, m_new, t);
+#pragma unroll
+        for (int h = 0; h < LPT; h++) ffl_load_window<N>(v[h], in + (size_t)s * in_pitch, hist + (size_t)s * k1p, c * V - k1p, k1p, m_new, t + h * TP);
     }
     for (; w < w_end; w += stride) {
         const int s = w / n_chunks, c = w - s * n_chunks;
         if (!HOIST) {                                                   // keep the loop-invariant twiddle powers and taps spectrum OUT of registers (residency over reuse)
-            asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+#pragma unroll
+            for (int h = 0; h < LPT; h++) asm volatile("" : "+v"(w1[h].x), "+v"(w1[h].y));
             asm volatile("" : "+s"(hperm));
         }
-        ffl_first<N>(v, lds, w1, t);
+#pragma unroll
+        for (int h = 0; h < LPT; h++) ffl_first<N>(v[h], lds, w1[h], t + h * TP);
         const int wn = w + stride;
         // the window prefetched: the next one if there is one and it lies inside the call's input (a stream's first window, which starts in the history, is loaded the
         // ordinary way below); otherwise this one again, ignored -- the fetches are unconditional so that no branch surrounds a value in flight
         int sn = wn / n_chunks, cn = wn - sn * n_chunks;
         const bool pre = PF && wn < w_end && cn > 0;
         if (!pre) { sn = s; cn = c; }
-        if (PF) ffl_prefetch_issue<N>(nx, in + (size_t)sn * in_pitch, cn * V - k1p, m_new, t);
-        __syncthreads();
-        FflMidPhases<N>::template run<0>(lds, tws, hperm, t); __syncthreads();
-        FflMidPhases<N>::template run<1>(lds, tws, hperm, t); __syncthreads();
-        FflMidPhases<N>::template run<2>(lds, tws, hperm, t); __syncthreads();
-        if constexpr (FflMidPhases<N>::COUNT == 5) {
-            FflMidPhases<N>::template run<3>(lds, tws, hperm, t); __syncthreads();
-            FflMidPhases<N>::template run<4>(lds, tws, hperm, t); __syncthreads();
+        if (PF) {
+#pragma unroll
+            for (int h = 0; h < LPT; h++) ffl_prefetch_issue<N>(nx[h], in + (size_t)sn * in_pitch, cn * V - k1p, m_new, t + h * TP);
         }
-        ffl_last<N>(v, lds, w1, t);
-        __syncthreads();                                                // the next window's first stage overwrites the exchange buffer
+        ffl_barrier();
+#define FFL_PHASE(K) { _Pragma("unroll") for (int h = 0; h < LPT; h++) FflMidPhases<N>::template run<K>(lds, tws, hperm, t + h * TP); ffl_barrier(); }
+        FFL_PHASE(0) FFL_PHASE(1) FFL_PHASE(2)
+        if constexpr (FflMidPhases<N>::COUNT == 5) { FFL_PHASE(3) FFL_PHASE(4) }
+#undef FFL_PHASE
         // results n = k1p .. N-1 of the window are outputs c V + (n - k1p): descriptor based at output c V, range = what is left of the call
         const unsigned long long by = (unsigned long long)(out + (size_t)s * out_pitch + (size_t)c * V);
         const ffl_i32x4 ry = {(int)(unsigned)by, (int)((by >> 32) & 0xffffu), (m_new - c * V) * 8, 0x00020000};
-        const int vy = (t - k1p) * 8;                                   // negative (the window's overlap part) -> dropped
 #pragma unroll
-        for (int j = 0; j < 16; j++) { const ffl_f32x2 r = {v[j].x, v[j].y}; ffl_buf_store(r, ry, vy + G::T * 8 * j, 0, 0); }
-        if (PF) ffl_prefetch_ready(nx);
+        for (int h = 0; h < LPT; h++) {
+            ffl_last<N>(v[h], lds, w1[h], t + h * TP);
+            if (h + 1 == LPT) ffl_barrier();                          // the next window's first stage overwrites the exchange buffer
+            const int vy = (t + h * TP - k1p) * 8;                      // negative (the window's overlap part) -> dropped
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const ffl_f32x2 r = {v[h][j].x, v[h][j].y}; ffl_buf_store(r, ry, vy + G::T * 8 * j, 0, 0); }
+        }
+        if (PF) {                                                       // the loads were issued before every store of this window: all 16 LPT stores may stay in flight
+            if constexpr (LPT == 1) ffl_prefetch_ready<16>(nx[0]);
+            else { ffl_prefetch_ready<32>(nx[0]); ffl_prefetch_ready<32>(nx[LPT - 1]); }
+        }
         if (pre) {
 #pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = make_float2(nx[j].x, nx[j].y);
+            for (int h = 0; h < LPT; h++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) v[h][j] = make_float2(nx[h][j].x, nx[h][j].y);
         } else if (wn < w_end) {
             const int s2 = wn / n_chunks, c2 = wn - s2 * n_chunks;
-            ffl_load_window<N>(v, in + (size_t)s2 * in_pitch, hist + (size_t)s2 * k1p, c2 * V - k1p, k1p, m_new, t);
+#pragma unroll
+            for (int h = 0; h < LPT; h++) ffl_load_window<N>(v[h], in + (size_t)s2 * in_pitch, hist + (size_t)s2 * k1p, c2 * V - k1p, k1p, m_new, t + h * TP);
         }
     }
 }
@@ -424,21 +491,21 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
 const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
 int fftfilt_lds_window(const FftfiltLds *p) { return p->n; }
 
-template <int N, bool PF, int MINWG, bool HOIST>
+template <int N, bool PF, int MINWG, bool HOIST, int LPT = 1>
 static int ffl_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
 {
     using G = FflGeom<N>;
-    int rc = lds_attr_once((const void *)k_fftfilt_lds<N, PF, MINWG, HOIST>, G::LDS_BYTES); if (rc) return rc;
+    int rc = lds_attr_once((const void *)k_fftfilt_lds<N, PF, MINWG, HOIST, LPT>, G::LDS_BYTES); if (rc) return rc;
     const int V = N - p->k1p;
     const int n_chunks = (int)((m_new + V - 1) / V);
     const long n_windows = (long)n_chunks * p->n_streams;
     if (n_windows > 0x7fffffffL || m_new > (1L << 27)) return fail_msg(-3, "fftfilt: call too large (2^27 samples per stream at most)");
-    constexpr int wpe = N / 16 / 64 / 4;                               // waves per SIMD of one workgroup (MINWG counts waves per SIMD)
+    constexpr int wpe = N / 16 / LPT / 64 / 4;                         // waves per SIMD of one workgroup (MINWG counts waves per SIMD)
     constexpr int by_regs = MINWG / wpe > 0 ? MINWG / wpe : 1, by_lds = (int)(160 * 1024 / G::LDS_BYTES);
     long grid = (long)current_device_cu_count() * (by_regs < by_lds ? by_regs : by_lds);
     if (grid > n_windows) grid = n_windows;
     grid = (grid + 7) & ~7L;
-    hipLaunchKernelGGL((k_fftfilt_lds<N, PF, MINWG, HOIST>), dim3((unsigned)grid), dim3(G::T), G::LDS_BYTES, st, (const float2 *)in, in_pitch,
+    hipLaunchKernelGGL((k_fftfilt_lds<N, PF, MINWG, HOIST, LPT>), dim3((unsigned)grid), dim3(G::T / LPT), G::LDS_BYTES, st, (const float2 *)in, in_pitch,
                        (const float2 *)p->d_hist[p->flip], p->k1p, (int)m_new, n_chunks, (int)n_windows, (float2 *)out, out_pitch, (const float2 *)p->d_hperm,
                        (const float2 *)p->d_tw1, (const float2 *)p->d_tws);
     CSDR_LAUNCH_CHECK();
@@ -463,7 +530,10 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
         if (mode == 2) rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
         else if (mode == 4) rc = ffl_launch<8192, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);      // (the second __launch_bounds__ argument is waves per SIMD: 4 = 128 registers = TWO workgroups per CU)
         else rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
-    } else rc = ffl_launch<16384, false, 1, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+    } else if (mode == 1) rc = ffl_launch<16384, false, 1, false>(p, st, in, in_pitch, m_new, out, out_pitch);      // (A/B: the 1024-thread form of rounds 2-5)
+    // 512 threads, two logical threads each, no prefetch: 0.490 against 0.513 ms (1024 threads) per 64 x 16 blocks at 4095 taps on one box.  WITH the next window's 32
+    // samples per thread in flight (PF) the compiler, at 256 registers, serialises the centre phase's 32 loads of the taps spectrum: 0.601 ms -- not instantiated.
+    else rc = ffl_launch<16384, false, 1, false, 2>(p, st, in, in_pitch, m_new, out, out_pitch);
     if (rc) return rc;
     if (p->k1p > 0) {
         hipLaunchKernelGGL(k_fftfilt_hist, dim3(cdiv(p->k1p, 256), p->n_streams), dim3(256), 0, st, (const float2 *)in, in_pitch, (const float2 *)p->d_hist[p->flip],
