@@ -284,9 +284,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--emulate-world", type=int, default=0, help="time ONE rank's work of a world-N bank on this GPU (null transport) instead of running the bench")
     ap.add_argument("--rank", type=int, default=-1, help="with --emulate-world: the rank to time (default: every rank in turn)")
-    ap.add_argument("--shard", choices=["blocks", "channels"], default="channels",
-                    help="channels (default = csdr_amd_fastddc_bank_create_sharded, BASELINE north_star: channels sharded, spectra exchanged) or blocks (the time-sliced "
-                         "schedule: every rank runs the whole pipeline on its run of the batch's blocks, decimated outputs exchanged all-to-all)")
+    ap.add_argument("--shard", choices=["auto", "blocks", "channels"], default="auto",
+                    help="auto (default) = what csdr_amd_fastddc_bank_create_sharded picks for the world size (csdr_amd_fastddc_bank_default_shard_mode: channels up to two "
+                         "GPUs, blocks beyond); channels = BASELINE north_star's partitioning (channels sharded, spectra exchanged); blocks = the time-sliced schedule "
+                         "(every rank runs the whole pipeline on its run of the batch's blocks, decimated outputs exchanged all-to-all)")
     ap.add_argument("--local-input", action="store_true", help="with --emulate-world --shard blocks: every rank is handed its own run (no input exchange)")
     ap.add_argument("--input-format", choices=["cf32", "s16", "u8"], default="cf32",
                     help="the wideband stream as complexf (default; SURVEY.md 8d) or as the s16 / u8 IQ pairs an SDR delivers: converted inside the forward transform "
@@ -305,6 +306,11 @@ def main():
                          "bank (\"modes\" in the line).  Default when N > 1 (--single-mode switches it off)")
     ap.add_argument("--single-mode", action="store_true", help="N > 1: only the --shard / --input-format asked for")
     args = ap.parse_args()
+    shard_auto = args.shard == "auto"
+    if shard_auto:       # the library's own choice for this world size (the emulation of one rank: for the emulated world)
+        import csdr_amd as _ca
+        _w = args.emulate_world if args.emulate_world else int(os.environ.get("WORLD_SIZE", "1"))
+        args.shard = "blocks" if _ca.lib().csdr_amd_fastddc_bank_default_shard_mode(max(_w, 1)) == _ca.SHARD["blocks"] else "channels"
     if args.emulate_world:
         return emulate(args)
 
@@ -499,6 +505,14 @@ def main():
                                                   "spread over the threads (every thread transforms the block itself)" % args.channels)
         if modes is not None:
             res["comm_selftest_ok"] = modes["selftest_ok"]; res["comm_selftest_rank0"] = modes["selftest_rank0"]; res["modes"] = modes["modes"]
+            # the headline of an N-GPU line = the best VERIFIED mode of the same ingest format (all six stay in "modes"); the timed run above is the library's default schedule
+            good = [m for m in modes["modes"] if m.get("verify", {}).get("ok") and m.get("input_format") == args.input_format and m.get("value")]
+            res["config"]["default_schedule"] = {"shard": args.shard, "chosen_by": "csdr_amd_fastddc_bank_default_shard_mode(world)" if shard_auto else "--shard", "value": res["value"], "ms_per_step": res["ms_per_step"]}
+            if good:
+                best = max(good, key=lambda m: m["value"])
+                res["config"]["headline_mode"] = {"shard": best["shard"], "input_format": best["input_format"], "source": "modes (best verified)"}
+                if best["value"] > res["value"]:
+                    res["value"] = best["value"]; res["ms_per_step"] = best["ms_per_step"]
         print(json.dumps(res))
         if modes is not None and (not modes["selftest_ok"] or not all(m["verify"]["ok"] for m in modes["modes"])):
             raise SystemExit("bench_fastddc.py: the communicator self test or a mode's check against the unsharded bank failed: %s" % json.dumps(modes))

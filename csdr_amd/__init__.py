@@ -162,6 +162,7 @@ def lib():
     L.csdr_amd_fastddc_bank_channel_slice.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.csdr_amd_fastddc_bank_create_sharded_by.restype = vp; L.csdr_amd_fastddc_bank_create_sharded_by.argtypes = [vp, fl, i, vp, i, i, i, vp, i]
     L.csdr_amd_fastddc_bank_shard_mode.argtypes = [vp]
+    L.csdr_amd_fastddc_bank_default_shard_mode.argtypes = [i]
     L.csdr_amd_fastddc_bank_local_blocks.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
     L.csdr_amd_fastddc_bank_overlap.argtypes = [vp]
     L.csdr_amd_fastddc_bank_submit_local.argtypes = [vp, vp, i]

@@ -938,12 +938,18 @@ csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded_by(csdr_amd_ctx *ctx
 }
 csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded(csdr_amd_ctx *ctx, float transition_bw, int decimation, const float *host_shift_rates_all, int n_channels_total,
                                                             int window, int max_blocks, csdr_amd_comm *comm)
-{   // Default = channel-sharded compute with the spectrum exchange (BASELINE north_star's partitioning, and the mode whose RCCL call pattern -- one group of
-    // send / recv and one all-gather per batch on ONE stream -- has run on hardware).  The time-sliced schedule (csdr_amd_fastddc_bank_create_sharded_by(...,
-    // CSDR_AMD_SHARD_BLOCKS): 6.5 x at 8 GPUs in the per-rank emulation against 1.3 x) issues its input and output exchanges from two side streams -- since round 5
-    // on two communicators (csdr_amd_comm_dup); until that has passed a run on >= 2 GPUs over RCCL it stays opt-in.
-    return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, CSDR_AMD_SHARD_CHANNELS);
+{   // The schedule follows the world size (csdr_amd_fastddc_bank_default_shard_mode).
+    const DdcComm *dc = comm ? csdr_amd_comm_ddc(comm) : nullptr;
+    return bank_create(ctx, transition_bw, decimation, host_shift_rates_all, n_channels_total, window, max_blocks, comm, csdr_amd_fastddc_bank_default_shard_mode(dc ? dc->world : 1));
 }
+
+// Which schedule csdr_amd_fastddc_bank_create_sharded picks for a world of `world` ranks.  Up to two GPUs: BASELINE north_star's partitioning -- the channels sharded,
+// the forward transform split by blocks, the transposed spectra all-gathered: at two ranks every link carries half a spectrum per batch each way and the exchange hides
+// under the fold.  Beyond two: the all-gather puts (world - 1) / world of 9.1 B per input sample on EVERY rank's links and bounds the bank at ~2.5 x whatever the GPU count
+// (per-rank emulation and link budget: DESIGN.md section 6, profiles/r5_fastddc_chanshard_*), while time slices move 8 B per input sample in total: 6.5 x at an emulated
+// world of 8 against 5.4 x compute-only for channel shards -- so time slices are the default there.  Either mode stays selectable (csdr_amd_fastddc_bank_create_sharded_by;
+// bench_fastddc.py --gpus N measures both with every ingest format and names the best verified one).
+int csdr_amd_fastddc_bank_default_shard_mode(int world) { return world > 2 ? CSDR_AMD_SHARD_BLOCKS : CSDR_AMD_SHARD_CHANNELS; }
 
 void csdr_amd_fastddc_bank_destroy(csdr_amd_fastddc_bank *b)
 {

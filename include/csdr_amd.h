@@ -319,14 +319,15 @@ int csdr_amd_debug_comm_exchange(csdr_amd_comm *c, const float *send_buf, float 
 /* fastddc bank over the communicator (BASELINE config 4 at 2 / 4 / 8 GPUs): host_shift_rates_all = ALL channels on every rank; rank r DELIVERS the
  * block-distributed slice of the channels csdr_amd_fastddc_bank_channel_slice reports (out rows = that slice; a channel's client connects to that GPU).
  * Two ways of dividing the work (shard_mode):
- *   CSDR_AMD_SHARD_BLOCKS (what csdr_amd_fastddc_bank_create_sharded picks): time slices.  The blocks of a batch are dealt to the ranks in runs of
+ *   CSDR_AMD_SHARD_BLOCKS (what csdr_amd_fastddc_bank_create_sharded picks for more than two ranks): time slices.  The blocks of a batch are dealt to the ranks in runs of
  *     ceil(max_blocks / world); every rank runs the whole single-GPU pipeline -- forward transform, fold of ALL channels, inverse transforms -- on its run and
  *     only the decimated outputs cross the links (all-to-all: each rank sends every peer that peer's channels of its run; 8 B per input sample in total, 1/world
  *     of it per link).  Possible because the only state that crosses block boundaries, decimating_shift_addition_cc's (remain, phase) per channel
  *     (fastddc.c:152-164), is data independent: every rank walks it over the whole batch itself.  The spectra never leave the GPU that computed them.
- *   CSDR_AMD_SHARD_CHANNELS: the compute is channel-sharded as well: forward transform split by blocks, transposed spectra all-gathered over the full mesh
- *     (9.1 B per input sample arrive at EVERY rank), every rank folds its own channels.  Link bound beyond two GPUs; kept as the
- *     measured alternative.
+ *   CSDR_AMD_SHARD_CHANNELS (BASELINE north_star's partitioning; what csdr_amd_fastddc_bank_create_sharded picks for one or two ranks): the compute is channel-sharded
+ *     as well: forward transform split by blocks, transposed spectra all-gathered over the full mesh (9.1 B per input sample arrive at EVERY rank), every rank folds
+ *     its own channels.  Link bound beyond two GPUs.
+ * csdr_amd_fastddc_bank_default_shard_mode(world) tells which one csdr_amd_fastddc_bank_create_sharded picks; csdr_amd_fastddc_bank_create_sharded_by takes either.
  * Input: submit / process read `in` on rank 0 only (the wideband stream lives there, like ddcd's single fastddc_fwd_cc, ddcd_old.cpp:238-252) and send every
  * rank the samples of its blocks point to point; csdr_amd_fastddc_bank_submit_local (time slices only) takes each rank's OWN run instead -- overlap_length
  * samples of the stream in front of the run's first block (zeros at the start of the stream), then its blocks -- when the ingest already distributes the
@@ -342,6 +343,7 @@ csdr_amd_fastddc_bank *csdr_amd_fastddc_bank_create_sharded_by(csdr_amd_ctx *ctx
                                                                int window, int max_blocks, csdr_amd_comm *comm, int shard_mode);
 int  csdr_amd_fastddc_bank_channel_slice(const csdr_amd_fastddc_bank *b, int *first, int *count);
 int  csdr_amd_fastddc_bank_shard_mode(const csdr_amd_fastddc_bank *b);                          /* -1: one GPU */
+int  csdr_amd_fastddc_bank_default_shard_mode(int world);
 int  csdr_amd_fastddc_bank_local_blocks(const csdr_amd_fastddc_bank *b, int n_blocks, int *first, int *count);
 int  csdr_amd_fastddc_bank_overlap(const csdr_amd_fastddc_bank *b);
 int  csdr_amd_fastddc_bank_submit_local(csdr_amd_fastddc_bank *b, const csdr_complexf *in_run, int n_blocks);

@@ -323,3 +323,15 @@ def test_phase_chain_plan_on_two_million_values(libpath):
         ph = x
         bad = np.nonzero(got[:, k].view(np.uint32) != ph.view(np.uint32))[0]
         assert bad.size == 0, (k, float(rates[bad[0]]))
+
+
+def test_sharded_bank_default_schedule_and_rccl_abi(libpath):
+    """csdr_amd_fastddc_bank_create_sharded picks its schedule from the world size (north_star's channel shards up to two GPUs, time slices beyond: DESIGN.md section 6);
+    comm.cpp takes every RCCL type and enum value from <rccl/rccl.h> (decltype of the entry points) -- a change of the ABI fails the BUILD, not the first N > 1 run."""
+    L = C.CDLL(libpath)
+    L.csdr_amd_fastddc_bank_default_shard_mode.argtypes = [C.c_int]
+    assert [L.csdr_amd_fastddc_bank_default_shard_mode(w) for w in (1, 2, 3, 4, 8)] == [0, 0, 1, 1, 1]
+    src = open(os.path.join(ROOT, "csdr_amd", "csrc", "comm.cpp")).read()
+    assert "#include <rccl/rccl.h>" in src and "enum { ncclFloat32" not in src and "typedef int ncclResult_t" not in src
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv", "ncclAllGather", "ncclBroadcast", "ncclGetErrorString"):
+        assert "decltype(&%s)" % sym in src, sym
