@@ -53,6 +53,8 @@ struct csdr_amd_ctx {
     void *pinned; size_t pinned_bytes; hipEvent_t pinned_ev; bool pinned_in_flight;
     void *pinned_acquire(size_t bytes);
     int pinned_upload(void *dst_dev, size_t bytes);
+    // shift_math_cc / shift_table_cc: the per-sample phase scan of the NEXT call, running on a helper thread while this call's kernels run (shift.hip: ShiftAhead)
+    void *shift_ahead; void (*shift_ahead_free)(void *);
 };
 
 // ---- LDS-DMA row-step shared by the ring kernels (wfm_mfma.hip, ddc_mfma.hip).  Device code only.

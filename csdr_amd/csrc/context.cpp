@@ -111,6 +111,7 @@ csdr_amd_ctx *csdr_amd_ctx_create(int device, void *hip_stream)
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreateWithFlags(&c->pinned_ev, hipEventDisableTiming) != hipSuccess) { fail_msg(-1, "hipEventCreate failed"); delete c; return nullptr; }
     c->pinned = nullptr; c->pinned_bytes = 0; c->pinned_in_flight = false;
+    c->shift_ahead = nullptr; c->shift_ahead_free = nullptr;
     return c;
 }
 
@@ -120,6 +121,7 @@ void csdr_amd_ctx_destroy(csdr_amd_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     drop_fft_plans(c->stream);
+    if (c->shift_ahead && c->shift_ahead_free) c->shift_ahead_free(c->shift_ahead);
     for (int i = 0; i < SCRATCH_SLOTS; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); (void)hipEventDestroy(c->pinned_ev);
     if (c->pinned) (void)hipHostFree(c->pinned);

@@ -200,7 +200,14 @@ csdr_amd_wfm_ring *csdr_amd_wfm_ring_create(csdr_amd_ctx *ctx, int n_streams, fl
     alloc((void **)&r->d_stats, sizeof(unsigned long long) * 4 * r->grid);
     const size_t hwords = (size_t)n_slots * r->lines * 16 + 16 + (size_t)n_slots * 16;
     if (e == hipSuccess) e = hipHostMalloc((void **)&r->h_block, sizeof(uint32_t) * hwords, hipHostMallocCoherent | hipHostMallocMapped);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->rs, hipStreamNonBlocking);
+    // The grid's stream gets a PRIORITY of its own: HIP multiplexes a process's streams onto a few hardware queues (four by default), and whatever shares a queue with the
+    // resident grid waits behind it until it leaves -- a block's input copy then takes idle_us instead of microseconds (seen in the test suite once earlier tests had used up
+    // the queues: 35 launches for 40 blocks).  Queues are per priority level, so a high-priority stream never shares one with the default-priority streams of the caller.
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) e = hipStreamCreateWithPriority(&r->rs, hipStreamNonBlocking, hi);
+        else e = hipStreamCreateWithFlags(&r->rs, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_exit, hipEventDisableTiming);
     if (e != hipSuccess) { fail(e, "wfm ring: allocation", __FILE__, __LINE__); csdr_amd_wfm_ring_destroy(r); return nullptr; }
     r->h_desc = r->h_block; r->h_ctrl = r->h_desc + (size_t)n_slots * r->lines * 16; r->h_done = r->h_ctrl + 16;
