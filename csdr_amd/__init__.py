@@ -178,6 +178,7 @@ def lib():
     L.csdr_amd_loopback_abort.argtypes = [vp]; L.csdr_amd_loopback_abort.restype = None
     L.csdr_amd_comm_create_loopback.restype = vp; L.csdr_amd_comm_create_loopback.argtypes = [vp, vp, i]
     L.csdr_amd_comm_create_null.restype = vp; L.csdr_amd_comm_create_null.argtypes = [vp, i, i]
+    L.csdr_amd_comm_create_ipc.restype = vp; L.csdr_amd_comm_create_ipc.argtypes = [vp, C.c_char_p, i, i]
     L.csdr_amd_fastddc_inv_kernel_name.restype = C.c_char_p; L.csdr_amd_fastddc_inv_kernel_name.argtypes = [vp]
     L.csdr_amd_fastddc_inv_set_profiling.argtypes = [vp, i]
     L.csdr_amd_fastddc_inv_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]

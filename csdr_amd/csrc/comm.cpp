@@ -17,6 +17,13 @@
 #include "fastddc.hpp"
 #include <rccl/rccl.h>      // types and enum values only (the entry points are dlsym'ed): a change of RCCL's ABI is a compile error here, not a crash at the first N > 1 run
 #include <dlfcn.h>
+#include <errno.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <sys/un.h>
+#include <time.h>
+#include <unistd.h>
+#include <map>
 #include <stdio.h>
 #include <string.h>
 #include <chrono>
@@ -104,6 +111,9 @@ struct csdr_amd_comm {
     csdr_amd_ctx *ctx; ncclComm_t comm; DdcComm ddc;
     csdr_amd_loopback *loop = nullptr; bool null_transport = false;
     csdr_amd_loopback *dup_parent = nullptr; int dup_index = -1;      // a loopback dup: the parent group and the child's index in it
+    // ---- the inter-PROCESS transport (csdr_amd_comm_create_ipc): a unix socket per peer, peers' buffers mapped through HIP IPC
+    bool ipc = false; std::string ipc_prefix; int ipc_dups = 0; int listen_fd = -1; std::vector<int> peer_fd;
+    std::map<std::string, void *> ipc_open;                               // opened handles (a handle opens once per process)
     struct Op { bool send; void *buf; size_t n; int peer; hipStream_t st; };
     std::vector<Op> ops; bool in_group = false;
 };
@@ -205,6 +215,99 @@ int l_collect(csdr_amd_comm *m, void *buf, size_t n_bytes, int root, hipStream_t
     return 0;                                                         // (the next collective re-records the events only behind its own first rendezvous: every wait above is queued by then)
 }
 int l_all_gather(const DdcComm *c, void *all, size_t n, hipStream_t st) { return c->world == 1 ? 0 : l_collect(lc(c), all, n * sizeof(float), -1, st); }
+// ---- ranks as PROCESSES on one box (csdr_amd_comm_create_ipc): the same table over unix sockets + HIP IPC.  RCCL refuses two ranks on one device
+// (profiles/r4_rccl_two_ranks_one_gpu.txt), the loopback transport's ranks are threads of one process -- neither crosses the process boundary that `csdr fastddc_bank_cc`
+// started once per GPU crosses (CSDR_AMD_RANK / _WORLD / _COMM_FILE, csdr_cli.cpp).  A test transport: every group is host synchronous.  Protocol of one group: a sender
+// waits for its stream, then tells the peer {IPC handle of the allocation, offset, floats}; the receiver maps the handle (once), copies on ITS stream, waits, answers
+// with one byte; the sender returns when every peer has answered (its buffer is free again).  All sends go out before any receive is served: the messages are small,
+// the sockets buffer them, no order of ranks can deadlock.
+struct IpcMsg { char handle[HIP_IPC_HANDLE_SIZE]; unsigned long long offset, n_floats; };
+int i_fail(const char *what) { return fail_msg(-6, "ipc communicator: %s (%s)", what, strerror(errno)); }
+int i_write_all(int fd, const void *p, size_t n) { const char *c = (const char *)p; while (n) { const ssize_t r = send(fd, c, n, MSG_NOSIGNAL); if (r < 0) { if (errno == EINTR) continue; return -1; } c += r; n -= (size_t)r; } return 0; }
+int i_read_all(int fd, void *p, size_t n)
+{
+    char *c = (char *)p;
+    while (n) {
+        struct pollfd pf = {fd, POLLIN, 0};
+        const int pr = poll(&pf, 1, 60000);                            // a peer that died or never makes the matching call: fail instead of hanging the box
+        if (pr == 0) { errno = ETIMEDOUT; return -1; }
+        if (pr < 0) { if (errno == EINTR) continue; return -1; }
+        const ssize_t r = recv(fd, c, n, 0);
+        if (r == 0) { errno = ECONNRESET; return -1; }
+        if (r < 0) { if (errno == EINTR) continue; return -1; }
+        c += r; n -= (size_t)r;
+    }
+    return 0;
+}
+int i_send_one(csdr_amd_comm *m, const void *buf, size_t n, int peer, hipStream_t st)
+{
+    CSDR_HIP(hipStreamSynchronize(st));                                // the data is there before the peer is told
+    void *base = nullptr; size_t size = 0;
+    CSDR_HIP(hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)buf));
+    IpcMsg msg; memset(&msg, 0, sizeof msg);
+    hipIpcMemHandle_t h; CSDR_HIP(hipIpcGetMemHandle(&h, base));
+    memcpy(msg.handle, &h, sizeof h); msg.offset = (unsigned long long)((const char *)buf - (const char *)base); msg.n_floats = n;
+    return i_write_all(m->peer_fd[peer], &msg, sizeof msg) ? i_fail("send to a peer") : 0;
+}
+int i_recv_one(csdr_amd_comm *m, void *buf, size_t n, int peer, hipStream_t st)
+{
+    IpcMsg msg;
+    if (i_read_all(m->peer_fd[peer], &msg, sizeof msg)) return i_fail("no message from a peer within 60 s");
+    if (msg.n_floats != n) return fail_msg(-3, "ipc communicator: rank %d sends %llu floats, rank %d expects %zu", peer, msg.n_floats, m->ddc.rank, n);
+    const std::string key(msg.handle, sizeof msg.handle);
+    void *base = nullptr;
+    auto it = m->ipc_open.find(key);
+    if (it != m->ipc_open.end()) base = it->second;
+    else {
+        hipIpcMemHandle_t h; memcpy(&h, msg.handle, sizeof h);
+        CSDR_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+        m->ipc_open[key] = base;
+    }
+    CSDR_HIP(hipMemcpyAsync(buf, (const char *)base + msg.offset, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    CSDR_HIP(hipStreamSynchronize(st));
+    const char ack = 1;
+    return i_write_all(m->peer_fd[peer], &ack, 1) ? i_fail("acknowledge to a peer") : 0;
+}
+int i_wait_ack(csdr_amd_comm *m, int peer) { char a = 0; return (i_read_all(m->peer_fd[peer], &a, 1) || a != 1) ? i_fail("no acknowledgement from a peer") : 0; }
+int i_group_start(const DdcComm *c) { csdr_amd_comm *m = lc(c); m->ops.clear(); m->in_group = true; return 0; }
+int i_send(const DdcComm *c, const void *buf, size_t n, int peer, hipStream_t st)
+{
+    csdr_amd_comm *m = lc(c);
+    if (!m->in_group || peer < 0 || peer >= c->world || peer == c->rank) return fail_msg(-3, "ipc send: outside a group or bad peer %d", peer);
+    m->ops.push_back({true, const_cast<void *>(buf), n, peer, st}); return 0;
+}
+int i_recv(const DdcComm *c, void *buf, size_t n, int peer, hipStream_t st)
+{
+    csdr_amd_comm *m = lc(c);
+    if (!m->in_group || peer < 0 || peer >= c->world || peer == c->rank) return fail_msg(-3, "ipc recv: outside a group or bad peer %d", peer);
+    m->ops.push_back({false, buf, n, peer, st}); return 0;
+}
+int i_group_end(const DdcComm *c)
+{
+    csdr_amd_comm *m = lc(c);
+    m->in_group = false;
+    int rc = 0;
+    // Acknowledgements and messages share a socket per peer: a rank both sends to and receives from the same peer (a ring of two), so the order on each socket is
+    // fixed: my message, then -- read side -- the peer's message, my acknowledgement, then the peer's acknowledgement.
+    for (const auto &op : m->ops) if (op.send && !rc) rc = i_send_one(m, op.buf, op.n, op.peer, op.st);
+    for (const auto &op : m->ops) if (!op.send && !rc) rc = i_recv_one(m, op.buf, op.n, op.peer, op.st);
+    for (const auto &op : m->ops) if (op.send && !rc) rc = i_wait_ack(m, op.peer);
+    m->ops.clear();
+    return rc;
+}
+// every rank's piece [rank n, (rank + 1) n) of `all` to every other rank (root < 0), or the root's [0, n) to everybody
+int i_collect(csdr_amd_comm *m, void *buf, size_t n_bytes, int root, hipStream_t st)
+{
+    const int me = m->ddc.rank, W = m->ddc.world;
+    if (n_bytes % 4) return fail_msg(-3, "ipc communicator: collective of %zu bytes (whole floats only)", n_bytes);
+    const size_t n = n_bytes / 4;
+    int rc = 0;
+    for (int p = 0; p < W && !rc; p++) if (p != me && (root < 0 || me == root)) rc = i_send_one(m, (const char *)buf + (root < 0 ? (size_t)me * n_bytes : 0), n, p, st);
+    for (int p = 0; p < W && !rc; p++) if (p != me && (root < 0 || p == root)) rc = i_recv_one(m, (char *)buf + (root < 0 ? (size_t)p * n_bytes : 0), n, p, st);
+    for (int p = 0; p < W && !rc; p++) if (p != me && (root < 0 || me == root)) rc = i_wait_ack(m, p);
+    return rc;
+}
+int i_all_gather(const DdcComm *c, void *all, size_t n, hipStream_t st) { return c->world == 1 ? 0 : i_collect(lc(c), all, n * sizeof(float), -1, st); }
 // ---- no transport at all: ONE rank of a world-N schedule timed alone (bench_fastddc.py --emulate-world); nothing moves, results are meaningless
 int n_ok(const DdcComm *) { return 0; }
 int n_send(const DdcComm *, const void *, size_t, int, hipStream_t) { return 0; }
@@ -281,6 +384,48 @@ csdr_amd_comm *csdr_amd_comm_create_loopback(csdr_amd_ctx *ctx, csdr_amd_loopbac
     return c;
 }
 
+/* Ranks as processes on one box, any devices (in the tests: all on device 0).  path_prefix: a filesystem path all ranks see; rank r listens on "<prefix>.<r>" and
+ * connects to every lower rank (60 s for the peers to appear).  Collective. */
+csdr_amd_comm *csdr_amd_comm_create_ipc(csdr_amd_ctx *ctx, const char *path_prefix, int rank, int world)
+{
+    if (!path_prefix || world < 1 || world > 64 || rank < 0 || rank >= world) { fail_msg(-3, "ipc comm: bad rank %d of %d", rank, world); return nullptr; }
+    csdr_amd_comm *c = new csdr_amd_comm();
+    c->ctx = ctx; c->comm = nullptr; c->ipc = true; c->ipc_prefix = path_prefix;
+    c->ddc.rank = rank; c->ddc.world = world; c->ddc.impl = c;
+    c->ddc.group_start = i_group_start; c->ddc.group_end = i_group_end; c->ddc.send = i_send; c->ddc.recv = i_recv; c->ddc.all_gather = i_all_gather;
+    c->peer_fd.assign(world, -1);
+    auto addr_of = [&](int r, sockaddr_un &a) { memset(&a, 0, sizeof a); a.sun_family = AF_UNIX; snprintf(a.sun_path, sizeof a.sun_path, "%s.%d", path_prefix, r); };
+    auto bail = [&](const char *what) { i_fail(what); csdr_amd_comm_destroy(c); return (csdr_amd_comm *)nullptr; };
+    sockaddr_un me_a; addr_of(rank, me_a);
+    if (strlen(path_prefix) + 8 >= sizeof me_a.sun_path) { fail_msg(-3, "ipc comm: path too long"); csdr_amd_comm_destroy(c); return nullptr; }
+    c->listen_fd = socket(AF_UNIX, SOCK_STREAM, 0);
+    (void)unlink(me_a.sun_path);
+    if (c->listen_fd < 0 || bind(c->listen_fd, (sockaddr *)&me_a, sizeof me_a) || listen(c->listen_fd, world)) return bail("listen");
+    for (int p = 0; p < rank; p++) {                                   // connect to the lower ranks ...
+        sockaddr_un a; addr_of(p, a);
+        int fd = -1;
+        for (int tries = 0; tries < 6000; tries++) {
+            fd = socket(AF_UNIX, SOCK_STREAM, 0);
+            if (fd >= 0 && connect(fd, (sockaddr *)&a, sizeof a) == 0) break;
+            if (fd >= 0) close(fd);
+            fd = -1; usleep(10000);
+        }
+        if (fd < 0) return bail("a lower rank did not appear within 60 s");
+        const int r32 = rank;
+        if (i_write_all(fd, &r32, sizeof r32)) { close(fd); return bail("hello"); }
+        c->peer_fd[p] = fd;
+    }
+    for (int k = rank + 1; k < world; k++) {                           // ... and accept the higher ones (in whatever order they come)
+        struct pollfd pf = {c->listen_fd, POLLIN, 0};
+        if (poll(&pf, 1, 60000) <= 0) { errno = ETIMEDOUT; return bail("a higher rank did not connect within 60 s"); }
+        const int fd = accept(c->listen_fd, nullptr, nullptr);
+        int r32 = -1;
+        if (fd < 0 || i_read_all(fd, &r32, sizeof r32) || r32 <= rank || r32 >= world || c->peer_fd[r32] >= 0) { if (fd >= 0) close(fd); return bail("accept"); }
+        c->peer_fd[r32] = fd;
+    }
+    return c;
+}
+
 csdr_amd_comm *csdr_amd_comm_create_null(csdr_amd_ctx *ctx, int rank, int world)
 {
     if (world < 1 || rank < 0 || rank >= world) { fail_msg(-3, "comm: bad rank %d of %d", rank, world); return nullptr; }
@@ -296,6 +441,11 @@ void csdr_amd_comm_destroy(csdr_amd_comm *c)
     if (!c) return;
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->ipc) {
+        for (auto &kv : c->ipc_open) (void)hipIpcCloseMemHandle(kv.second);
+        for (int fd : c->peer_fd) if (fd >= 0) close(fd);
+        if (c->listen_fd >= 0) { close(c->listen_fd); char path[160]; snprintf(path, sizeof path, "%s.%d", c->ipc_prefix.c_str(), c->ddc.rank); (void)unlink(path); }
+    }
     if (c->dup_parent && c->dup_index >= 0) {                         // the child group's place is free again for this rank
         std::lock_guard<std::mutex> lk(c->dup_parent->mu);
         std::vector<char> &use = c->dup_parent->child_in_use[c->ddc.rank];
@@ -313,6 +463,7 @@ csdr_amd_comm *csdr_amd_comm_dup(csdr_amd_comm *c)
     if (!c) { fail_msg(-3, "comm_dup: null communicator"); return nullptr; }
     const int rank = c->ddc.rank, world = c->ddc.world;
     if (c->null_transport) return csdr_amd_comm_create_null(c->ctx, rank, world);
+    if (c->ipc) { const std::string pre = c->ipc_prefix + ".dup" + std::to_string(c->ipc_dups++); return csdr_amd_comm_create_ipc(c->ctx, pre.c_str(), rank, world); }      // (every rank counts its dups alike)
     if (c->loop) {
         csdr_amd_loopback *g = c->loop, *child = nullptr;
         int k = 0;
@@ -374,7 +525,7 @@ int csdr_amd_comm_selftest(csdr_amd_comm *c, size_t n_floats, char *report, size
     float *d_send = nullptr, *d_recv = nullptr, *d_all = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0; std::string line; char buf[256];
-    snprintf(buf, sizeof buf, "rank %d/%d dev %d (%s):", me, W, c->ctx->device, c->loop ? "loopback" : c->null_transport ? "null" : "rccl"); line = buf;
+    snprintf(buf, sizeof buf, "rank %d/%d dev %d (%s):", me, W, c->ctx->device, c->loop ? "loopback" : c->null_transport ? "null" : c->ipc ? "ipc" : "rccl"); line = buf;
     auto cleanup = [&]() { (void)hipFree(d_send); (void)hipFree(d_recv); (void)hipFree(d_all); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); };
 #define ST_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { cleanup(); return ::csdr_amd::fail(e__, #expr, __FILE__, __LINE__); } } while (0)
     ST_HIP(hipMalloc((void **)&d_send, sizeof(float) * n_floats)); ST_HIP(hipMalloc((void **)&d_recv, sizeof(float) * n_floats)); ST_HIP(hipMalloc((void **)&d_all, sizeof(float) * n_floats * W));
@@ -483,6 +634,7 @@ int csdr_amd_comm_broadcast(csdr_amd_comm *c, void *dev_buf, size_t bytes, int r
 {
     if (c->ddc.world == 1 || c->null_transport) return 0;
     if (c->loop) return l_collect(c, dev_buf, bytes, root, c->ctx->stream);
+    if (c->ipc) return i_collect(c, dev_buf, (bytes + 3) & ~(size_t)3, root, c->ctx->stream);      // (whole floats: the callers' buffers are padded)
     CSDR_NCCL(g_rccl.Broadcast(dev_buf, dev_buf, bytes, ncclUint8, root, c->comm, c->ctx->stream));
     return 0;
 }

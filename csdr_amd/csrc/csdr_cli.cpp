@@ -1191,7 +1191,16 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
     if (multi) {
         const char *cf = getenv("CSDR_AMD_COMM_FILE");
         if (!cf && world > 1) return badsyntax("CSDR_AMD_COMM_FILE must name a file every rank can reach");
+        // CSDR_AMD_COMM=ipc: the ranks are processes on ONE box joined by unix sockets named after CSDR_AMD_COMM_FILE and HIP IPC (csdr_amd_comm_create_ipc) -- RCCL refuses
+        // two ranks per device, so this is how the per-rank bootstrap of this command is exercised on a single GPU (tests/test_cli_gpu.py); default: RCCL over xGMI
+        const char *ct = getenv("CSDR_AMD_COMM");
+        const bool use_ipc = ct && !strcmp(ct, "ipc");
         char id[128];
+        if (use_ipc) {
+            if (!cf) return badsyntax("CSDR_AMD_COMM=ipc needs CSDR_AMD_COMM_FILE (the sockets' path prefix)");
+            comm = csdr_amd_comm_create_ipc(c, cf, rank, world);
+            if (!comm) die("communicator (ipc)");
+        } else
         if (rank == 0) {
             if (csdr_amd_comm_unique_id(id)) die("communicator id");
             if (cf) { std::string tmp = std::string(cf) + ".tmp"; FILE *f = fopen(tmp.c_str(), "wb"); if (!f || fwrite(id, 1, 128, f) != 128) die("cannot write CSDR_AMD_COMM_FILE"); fclose(f); if (rename(tmp.c_str(), cf)) die("rename CSDR_AMD_COMM_FILE"); }
@@ -1200,9 +1209,13 @@ int run_bank(csdr_amd_ctx *c, int argc, char **argv, size_t block)
             for (int tries = 0; tries < 6000 && !ok; tries++) { FILE *f = fopen(cf, "rb"); if (f) { ok = fread(id, 1, 128, f) == 128; fclose(f); } if (!ok) usleep(10000); }
             if (!ok) die("timed out waiting for CSDR_AMD_COMM_FILE");
         }
-        comm = csdr_amd_comm_create(c, id, rank, world);
+        if (!use_ipc) comm = csdr_amd_comm_create(c, id, rank, world);
         if (!comm) die("communicator");
-        bank = csdr_amd_fastddc_bank_create_sharded(c, tbw, D, rates.data(), n_ch, window, nb_max, comm);
+        // the schedule: the library's choice for this world size (channel shards up to two ranks, time slices beyond), or CSDR_AMD_SHARD=channels|blocks
+        const char *sh = getenv("CSDR_AMD_SHARD");
+        const int mode = (sh && !strcmp(sh, "blocks")) ? CSDR_AMD_SHARD_BLOCKS : (sh && !strcmp(sh, "channels")) ? CSDR_AMD_SHARD_CHANNELS : csdr_amd_fastddc_bank_default_shard_mode(world);
+        bank = csdr_amd_fastddc_bank_create_sharded_by(c, tbw, D, rates.data(), n_ch, window, nb_max, comm, mode);
+        if (bank) fprintf(stderr, "csdr fastddc_bank_cc: rank %d of %d, %s transport, schedule: %s\n", rank, world, use_ipc ? "ipc" : "rccl", mode == CSDR_AMD_SHARD_BLOCKS ? "time slices" : "channel shards");
         if (bank) csdr_amd_fastddc_bank_channel_slice(bank, &first, &count);
     } else bank = csdr_amd_fastddc_bank_create(c, tbw, D, rates.data(), n_ch, window, nb_max);
     if (!bank) die("fastddc_bank create");

@@ -314,6 +314,10 @@ void csdr_amd_loopback_destroy(csdr_amd_loopback *g);
 void csdr_amd_loopback_abort(csdr_amd_loopback *g);                 /* a rank thread gave up: fail the others' rendezvous at once */
 csdr_amd_comm *csdr_amd_comm_create_loopback(csdr_amd_ctx *ctx, csdr_amd_loopback *g, int rank);
 csdr_amd_comm *csdr_amd_comm_create_null(csdr_amd_ctx *ctx, int rank, int world);
+/* The ranks as PROCESSES on one box (RCCL refuses two ranks per device; the loopback's ranks are threads): unix sockets named "<path_prefix>.<rank>" + HIP IPC mappings
+ * of the peers' buffers.  A test transport (every group is host synchronous) for what only separate processes exercise: `csdr fastddc_bank_cc` started once per rank
+ * (CSDR_AMD_COMM=ipc with CSDR_AMD_RANK / _WORLD / _COMM_FILE).  Collective; 60 s for the peers to appear. */
+csdr_amd_comm *csdr_amd_comm_create_ipc(csdr_amd_ctx *ctx, const char *path_prefix, int rank, int world);
 /* test hook: one send/receive group with `peer` (n floats each way; n_sends = 2 provokes the local error whose handling comm.cpp's l_group_end documents) */
 int csdr_amd_debug_comm_exchange(csdr_amd_comm *c, const float *send_buf, float *recv_buf, size_t n, int peer, int n_sends);
 /* fastddc bank over the communicator (BASELINE config 4 at 2 / 4 / 8 GPUs): host_shift_rates_all = ALL channels on every rank; rank r DELIVERS the

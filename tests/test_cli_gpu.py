@@ -908,6 +908,58 @@ def test_cli_fastddc_bank_multi_rank_mode(tmp_path):
         assert a.size == b.size and a.size > 0 and relrms(b, a) <= 2e-6
 
 
+@pytest.mark.parametrize("world,shard", [(2, "channels"), (2, "blocks"), (3, "auto")])
+def test_cli_fastddc_bank_as_separate_processes(tmp_path, world, shard):
+    """The multi-GPU form of `csdr fastddc_bank_cc` as it is deployed -- the SAME command line started once per rank with CSDR_AMD_RANK / CSDR_AMD_WORLD / CSDR_AMD_COMM_FILE
+    (ddcd_old.cpp:238-252, 474-492: one process per client there) -- as `world` real PROCESSES on the one GPU of this box, joined by the inter-process transport
+    (CSDR_AMD_COMM=ipc: unix sockets + HIP IPC; RCCL refuses two ranks per device): per-rank bootstrap, the per-batch header broadcast with a retune in it, each rank opening
+    only its clients' outputs, both schedules (channel shards with the spectrum exchange, time slices with the output exchange; "auto" = the library's choice for the
+    world size).  Every channel's file must hold what the single-process command writes."""
+    rng = np.random.default_rng(28)
+    D, tbw, nch, nblk = 256, 0.001, 7, 6
+    inp = 57344
+    x = crand(rng, nblk * inp + 5)
+    rates = [0.11, -0.2, 0.3, 0.0, -0.4321, 0.05, 0.25]
+    base = ["fastddc_bank_cc", D, tbw, "HAMMING"]
+
+    def run_one(tag, envs):
+        outs = [str(tmp_path / ("%s_ch%d.bin" % (tag, k))) for k in range(nch)]
+        fifo = str(tmp_path / ("ctl_" + tag)); os.mkfifo(fifo)
+        procs = []
+        for r, extra in enumerate(envs):
+            args = base + [fifo if r == 0 else "-"]
+            for o, rt in zip(outs, rates):
+                args += [o, rt]
+            env = dict(os.environ, CSDR_AMD_BLOCK=str(2 * inp), **extra)
+            procs.append(subprocess.Popen([CLI] + [str(a) for a in args], stdin=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env))
+        ctl = open(fifo, "w")
+        ctl.write("3 0.25\n5 -0.125\n"); ctl.flush()                    # applied before the first batch, by every rank
+        procs[0].stdin.write(x.tobytes()); procs[0].stdin.close()
+        errs = []
+        for pr in procs:
+            rc = pr.wait(timeout=180)
+            errs.append(pr.stderr.read().decode())
+            assert rc == 0, errs[-1][-1500:]
+        ctl.close()
+        return [np.fromfile(o, c64) for o in outs], errs
+
+    want, _ = run_one("plain", [{}])
+    comm = str(tmp_path / "comm")
+    envs = [{"CSDR_AMD_RANK": str(r), "CSDR_AMD_WORLD": str(world), "CSDR_AMD_COMM": "ipc", "CSDR_AMD_COMM_FILE": comm, **({} if shard == "auto" else {"CSDR_AMD_SHARD": shard})} for r in range(world)]
+    got, errs = run_one("w%d_%s" % (world, shard), envs)
+    expect = {"channels": "channel shards", "blocks": "time slices", "auto": "time slices" if world > 2 else "channel shards"}[shard]
+    served = []
+    for r, e in enumerate(errs):
+        assert "rank %d of %d, ipc transport, schedule: %s" % (r, world, expect) in e, e[-800:]
+        m = [ln for ln in e.splitlines() if "serves channels" in ln]
+        assert m, e[-800:]
+        lo, hi = [int(v) for v in m[0].split("serves channels")[1].split("..")]
+        served += list(range(lo, hi + 1))
+    assert sorted(served) == list(range(nch))                          # every client is served by exactly one rank
+    for k, (a, b) in enumerate(zip(want, got)):
+        assert a.size == b.size and a.size > 0 and relrms(b, a) <= 2e-6, "channel %d" % k
+
+
 def test_cli_fastddc_bank(port, tmp_path):
     import time
     rng = np.random.default_rng(17)
