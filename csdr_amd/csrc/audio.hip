@@ -284,6 +284,25 @@ __global__ __launch_bounds__(256) void k_fracdec(const float *__restrict__ in, f
     out[(size_t)blockIdx.y * out_pitch + k] = acc;
 }
 
+// The plan ON THE DEVICE (round 6).  The reference's position bookkeeping is the float recurrence where <- where + rate (libcsdr.c:763), restarted per call / per CLI
+// window with where <- where - input_processed (:790-791).  When where and rate are both multiples of 2^q and every position stays below 2^(q + 24) -- every integer
+// and half-integer rate (5, 5.5, 2.5 ...) at the block sizes in use -- each of those adds is EXACT, so position k of a window is where_0 + k rate with no rounding: a
+// lane evaluates it directly.  The host then only walks the WINDOWS (closed form per window; one window without the CLI's loop), uploads 16 bytes per window instead of
+// 8 bytes per output, and the call no longer waits for the stream.  Rates that are not exact in float (3.3 ...) keep the host walk: their positions are the recurrence's.
+struct FdWin { int base; float w0; int first_out; int count; };
+__global__ __launch_bounds__(256) void k_fracdec_plan(const FdWin *__restrict__ win, int n_win, int n_out, float rate, int *__restrict__ lo_idx, float *__restrict__ frac)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_out) return;
+    int a = 0, b = n_win - 1;                                            // the last window whose first output is <= k
+    while (a < b) { const int m = (a + b + 1) >> 1; if (win[m].first_out <= k) a = m; else b = m - 1; }
+    const FdWin w = win[a];
+    const float where = __fmaf_rn((float)(k - w.first_out), rate, w.w0);      // exact (see above): one rounding of an exactly representable value
+    const int lo = (int)ceilf(where) - 1;                                // libcsdr.c:763-766: index_high = ceilf(where), FD_INDEX_LOW = index_high - 1
+    lo_idx[k] = w.base + lo;
+    frac[k] = where - (float)lo;                                         // :774 float xwhere = d->where - FD_INDEX_LOW
+}
+
 } // namespace
 
 struct csdr_amd_fracdec {
@@ -294,6 +313,7 @@ struct csdr_amd_fracdec {
     int cli_bufsize, plan_bufsize;   // > 0: replay the CLI's loop over the_bufsize-sample windows (csdr.c:1511-1524) instead of one call over the whole array
     std::vector<int> lo; std::vector<float> frac;      // per output: first input sample of its window, fractional position (the coefficients are the kernel's)
     int *d_lo; float *d_frac; float *d_denom; float *d_taps; size_t d_cap;
+    FdWin *d_win; size_t win_cap;                       // exact rates: the windows of the plan (the outputs' positions are evaluated on the device)
 };
 
 extern "C" {
@@ -405,7 +425,7 @@ csdr_amd_fracdec *csdr_amd_fracdec_create(float rate, int num_poly_points, const
     d->where = (float)(-d->xifirst); d->rate = rate; d->input_processed = 0;
     d->taps_length = host_taps ? taps_length : 0;
     if (d->taps_length) d->taps.assign(host_taps, host_taps + taps_length);
-    d->plan_valid = false; d->d_lo = nullptr; d->d_frac = nullptr; d->d_denom = nullptr; d->d_taps = nullptr; d->d_cap = 0; d->cli_bufsize = 0; d->plan_bufsize = 0;
+    d->plan_valid = false; d->d_lo = nullptr; d->d_frac = nullptr; d->d_denom = nullptr; d->d_taps = nullptr; d->d_cap = 0; d->cli_bufsize = 0; d->plan_bufsize = 0; d->d_win = nullptr; d->win_cap = 0;
     return d;
 }
 
@@ -420,6 +440,7 @@ void csdr_amd_fracdec_destroy(csdr_amd_fracdec *d)
     if (d->d_frac) (void)hipFree(d->d_frac);
     if (d->d_denom) (void)hipFree(d->d_denom);
     if (d->d_taps) (void)hipFree(d->d_taps);
+    if (d->d_win) (void)hipFree(d->d_win);
     delete d;
 }
 
@@ -432,7 +453,29 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
         // on the samples, only on (where, rate, input_size).
         d->lo.clear(); d->frac.clear();
         float where = d->where; int hi = 0;
+        // exponent of the lowest set bit of a float (a large number for 0): both where and rate on the lattice 2^q, q <= 0 (input_processed is an integer)
+        auto lsb_exp = [](float v) { if (v == 0.f) return 127; uint32_t u; memcpy(&u, &v, 4); const int ef = (int)((u >> 23) & 255); uint32_t m = (u & 0x7fffff) | (ef ? 0x800000u : 0u);
+                                     return (ef ? ef : 1) - 127 - 23 + __builtin_ctz(m); };
+        int q = lsb_exp(where) < lsb_exp(d->rate) ? lsb_exp(where) : lsb_exp(d->rate); if (q > 0) q = 0;
+        const int win_size = (d->cli_bufsize > 0 && input_size >= d->cli_bufsize) ? d->cli_bufsize : input_size;
+        const bool exact = q > -40 && ldexp(1.0, q + 24) > (double)win_size + fabs((double)d->rate) + P + d->taps_length + 4 && where >= 0.f;
+        std::vector<FdWin> wins;
+        int n_out = 0;
+        // one call of fractional_decimator_ff over in[base .. base + size), exact rates: K outputs from where, then where <- where_K - processed, in closed form
+        auto one_call_exact = [&](int base, int size) {
+            const int m = size - P - d->taps_length;                     // the loop runs while ceilf(where) < m, i.e. where <= m - 1
+            const double w0 = where, r = d->rate;
+            long K = 0;
+            if (w0 <= (double)(m - 1)) { K = (long)floor(((double)(m - 1) - w0) / r) + 1; while (K > 0 && w0 + (double)(K - 1) * r > (double)(m - 1)) K--; while (w0 + (double)K * r <= (double)(m - 1)) K++; }
+            if (K > 0) { wins.push_back(FdWin{base, where, n_out, (int)K}); n_out += (int)K; }
+            const float w_end = (float)(w0 + (double)K * r);              // exact
+            hi = (int)ceilf(w_end);
+            const int processed = (hi - 1) + d->xifirst;
+            where = w_end - (float)processed;
+            return processed;
+        };
         auto one_call = [&](int base, int size) {                       // fractional_decimator_ff over in[base .. base + size)
+            if (exact) return one_call_exact(base, size);
             for (; (hi = (int)ceilf(where)) + P + d->taps_length < size; where += d->rate) {
                 const int lo = hi - 1;
                 const float x = where - lo;
@@ -460,9 +503,9 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
             d->plan_where_after = where;
         }
         d->plan_bufsize = d->cli_bufsize;
-        d->plan_outputs = (int)d->lo.size();
+        d->plan_outputs = exact ? n_out : (int)d->lo.size();
         d->plan_where = d->where; d->plan_n = input_size;
-        const size_t need = d->lo.size() + 1;
+        const size_t need = (size_t)d->plan_outputs + 1;
         if (need > d->d_cap) {
             CSDR_HIP(hipStreamSynchronize(c->stream));
             if (d->d_lo) (void)hipFree(d->d_lo);
@@ -479,7 +522,21 @@ int csdr_amd_fractional_decimator_ff(csdr_amd_ctx *c, csdr_amd_fracdec *d, const
             CSDR_HIP(hipMalloc((void **)&d->d_taps, sizeof(float) * d->taps_length));
             CSDR_HIP(hipMemcpy(d->d_taps, d->taps.data(), sizeof(float) * d->taps_length, hipMemcpyHostToDevice));
         }
-        if (d->plan_outputs) {
+        if (d->plan_outputs && exact) {
+            // stream ordered: the window table through the context's pinned staging (an earlier launch that still reads the old plan is in front of it on the stream)
+            if (wins.size() > d->win_cap) {
+                CSDR_HIP(hipStreamSynchronize(c->stream));
+                if (d->d_win) (void)hipFree(d->d_win);
+                d->win_cap = wins.size() + wins.size() / 2 + 16;
+                CSDR_HIP(hipMalloc((void **)&d->d_win, sizeof(FdWin) * d->win_cap));
+            }
+            FdWin *hw = (FdWin *)c->pinned_acquire(sizeof(FdWin) * wins.size());
+            if (!hw) return -2;
+            memcpy(hw, wins.data(), sizeof(FdWin) * wins.size());
+            const int urc = c->pinned_upload(d->d_win, sizeof(FdWin) * wins.size()); if (urc) return urc;
+            hipLaunchKernelGGL(k_fracdec_plan, dim3(cdiv(d->plan_outputs, 256)), dim3(256), 0, c->stream, d->d_win, (int)wins.size(), d->plan_outputs, d->rate, d->d_lo, d->d_frac);
+            CSDR_LAUNCH_CHECK();
+        } else if (d->plan_outputs) {
             CSDR_HIP(hipStreamSynchronize(c->stream));     // previous launch may still read the old plan
             CSDR_HIP(hipMemcpy(d->d_lo, d->lo.data(), sizeof(int) * d->lo.size(), hipMemcpyHostToDevice));
             CSDR_HIP(hipMemcpy(d->d_frac, d->frac.data(), sizeof(float) * d->frac.size(), hipMemcpyHostToDevice));

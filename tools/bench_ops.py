@@ -66,7 +66,7 @@ ph = C.c_float(0.0)
 report("shift_addition_cc (64 streams x 2M, gen+mix)", timeit(lambda: L.csdr_amd_shift_cc(ctx.h, 0, -0.085, C.byref(ph), xin.data_ptr(), yout.data_ptr(), S, n, n, n, 1024, 0)),
        16 * S * n, S * n)
 for vname, variant, aux in (("shift_math_cc", 1, 0), ("shift_table_cc", 2, 65536), ("shift_unroll_cc", 3, 1024), ("shift_addfast_cc", 4, 0)):
-    report("%s (64 streams x 2M, gen+mix; the host's sequential float phase scan is inside the timed region)" % vname,
+    report("%s (64 streams x 2M, gen+mix; math / table: the host's sequential float phase scan -- run ahead on a helper thread -- bounds a tight loop of calls)" % vname,
            timeit(lambda: L.csdr_amd_shift_cc(ctx.h, variant, -0.085, C.byref(ph), xin.data_ptr(), yout.data_ptr(), S, n, n, n, 1024, aux), reps=5, warm=1), 16 * S * n, S * n,
            {"bound": "serial: the reference's float phase recurrence is one sequential chain per call (math / table: one phase add + wrap per SAMPLE, on the host); the HBM roofline does not apply"}
            if variant in (1, 2) else None)
@@ -123,7 +123,7 @@ for rate in (5.0, 5.5):
         L.csdr_amd_fracdec_set_where(fd, 5.0)            # (every call a fresh plan, as the CLI's calls with their changing sizes have)
         L.csdr_amd_fractional_decimator_ff(ctx.h, fd, x1.data_ptr(), y1.data_ptr(), 1, n1 - 8 * int(_fd_k[0] % 7), n1, n1, C.byref(proc)); _fd_k[0] += 1
     _fd_k = [0]
-    report("fractional_decimator_ff %g (1 stream x 4 Mi, a new plan per call: the host walks the positions, the kernel evaluates the Lagrange coefficients)" % rate,
+    report("fractional_decimator_ff %g (1 stream x 4 Mi, a new plan per call: exact rates -- the host walks the WINDOWS in closed form, the device evaluates positions and Lagrange coefficients)" % rate,
            timeit(fd_step, reps=6, warm=1), (4 + 4 / rate) * n1, n1)
     L.csdr_amd_fracdec_destroy(fd)
 g1 = ctx.upload(np.ones(1, np.float32))
