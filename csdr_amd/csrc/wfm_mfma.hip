@@ -352,19 +352,30 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
             const int nd = rc.desc_lines * 16;
             const long long t_wait = wall_clock64();
             uint32_t state = 0;
-            for (bool first = true;; first = false) {
-                uint32_t v[4];
-                if (first && pre_valid) {                                            // the lines this wave asked for while the previous item's audio was on its way out
+            // Polling costs PCIe reads: 256 idle workgroups that each re-read a whole descriptor (256 B) and the stop word every microsecond are ~40 GB/s -- the link's own
+            // rate; on a box whose host memory sits far from the GPU that traffic tripled every workgroup's waiting time and slowed the busy ones' stores and prefetches
+            // (round 6: 0.52 of the roofline on one box, 0.22 on another).  So: the lines asked for at the end of the previous item are looked at first (the usual case: the
+            // block is already posted); after that a poll reads ONE word -- line 0's tag --, the whole descriptor only once that word matches, the stop word every eighth
+            // poll, and the pause between polls grows from ~0.6 to ~5 us.
+            for (int iter = 0;; iter++) {
+                uint32_t v[4] = {0u, 0u, 0u, 0u};
+                bool have = false;
+                if (iter == 0 && pre_valid) {                                        // the lines this wave asked for while the previous item's audio was on its way out
 #pragma unroll
                     for (int j = 0; j < 4; j++) v[j] = pre_v[j];
+                    have = true;
                 } else {
+                    const uint32_t t0 = sys_load(dsc);                               // (uniform address: one request)
+                    if (t0 == tag) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { const int d = lane + 64 * j; v[j] = d < nd ? sys_load(dsc + d) : 0u; }
+                        for (int j = 0; j < 4; j++) { const int d = lane + 64 * j; v[j] = d < nd ? sys_load(dsc + d) : 0u; }
+                        have = true;
+                    }
                 }
                 const uint32_t ex = __hip_atomic_load(rc.exiting, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t stop = sys_load(rc.ctrl);
+                const uint32_t stop = (iter & 7) == 7 ? sys_load(rc.ctrl) : 0u;
                 res_complete();                                                      // the previous item's count has come back by now: the block's done line, if it was the last
-                bool ok = true;
+                bool ok = have;
 #pragma unroll
                 for (int j = 0; j < 4; j++) { const int d = lane + 64 * j; if (d < nd && (d & 15) == 0 && v[j] != tag) ok = false; }
                 const bool ready = __all(ok);
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(64 * SEQ_NW) void k_wfm_mfma_seq(const uint8_t *__r
                     state = 1; break;
                 }
                 if (ex || old || stop || now - t_wait > rc.idle_ticks) { state = 2; break; }
-                __builtin_amdgcn_s_sleep(24);
+                if (iter < 2) __builtin_amdgcn_s_sleep(24); else if (iter < 6) __builtin_amdgcn_s_sleep(64); else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(100); }
             }
             pre_valid = false;
             if (lane == 0) rctl[0] = state;

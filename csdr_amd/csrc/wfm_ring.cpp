@@ -205,7 +205,8 @@ csdr_amd_wfm_ring *csdr_amd_wfm_ring_create(csdr_amd_ctx *ctx, int n_streams, fl
     // the queues: 35 launches for 40 blocks).  Queues are per priority level, so a high-priority stream never shares one with the default-priority streams of the caller.
     if (e == hipSuccess) {
         int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) e = hipStreamCreateWithPriority(&r->rs, hipStreamNonBlocking, hi);
+        const char *pe = getenv("CSDR_AMD_RING_PRIO");                      // (A/B: 0 = a default-priority stream)
+        if (!(pe && atoi(pe) == 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) e = hipStreamCreateWithPriority(&r->rs, hipStreamNonBlocking, hi);
         else e = hipStreamCreateWithFlags(&r->rs, hipStreamNonBlocking);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_exit, hipEventDisableTiming);
