@@ -151,7 +151,7 @@ def main():
                "sweep": sweep}
         if other is not None:
             res["full_size_transform"] = other
-        tr = bc.pmc_traffic("k_fftfilt_lds" if window else "k_f64", {"streams_per_gpu": S, "blocks_per_step": nb, "taps": args.taps})
+        tr = bc.pmc_traffic(kname.split("<")[0] if window else "k_f64", {"streams_per_gpu": S, "blocks_per_step": nb, "taps": args.taps})
         if tr:
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = tr
         if ver is not None:

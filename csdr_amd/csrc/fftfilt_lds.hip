@@ -424,6 +424,288 @@ void ffl_host_run(const cf32 *taps, int taps_len, const cf32 *x, long m_new, cf3
     }
 }
 
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ one wave per window (4096 points)
+#include "fftfilt_wave.hpp"
+
+namespace {
+
+// Lane l of a wave holds the rows n1 = fw_pi(l) of the 64 x 64 window (both in the time half, n = n1 + 64 n2, and in the frequency half, k = 64 k1 + k2 with
+// k2 = fw_pi(l)): the order in which 16-byte loads of two neighbouring samples, halves swapped between lanes l and l + 32, leave them (see fw_rows_to_regs).
+FFL_HD constexpr int fw_pi(int l) { return 2 * (l & 31) + (l >> 5); }
+FFL_HD constexpr int fw_pi_inv(int r) { return (r >> 1) + 32 * (r & 1); }
+// taps spectrum in the order pass 1 asks for it: radix-16 group g (g = k1 & 3), pair m of its outputs k1 = g + 4 (2 m), g + 4 (2 m + 1), lane l: 16 bytes
+FFL_HD constexpr int fw_h_index(int k1, int l) { return (((k1 & 3) * 8 + (k1 >> 3)) * 64 + l) * 2 + ((k1 >> 2) & 1); }
+
+// hw[fw_h_index(k1, lane)] = H[64 k1 + fw_pi(lane)] / N;  tw[e * 64 + lane]: e < 3: W^(n (e + 1)), e >= 3: W^(4 n (e - 2)), n = fw_pi(lane), W = exp(-2 pi i / 4096)
+void fw_host_tables(const cf32 *taps, int taps_len, std::vector<float2> &hw, std::vector<float2> &tw)
+{
+    std::vector<double> re(FW_N, 0.0), im(FW_N, 0.0);
+    for (int k = 0; k < taps_len; k++) { re[k] = taps[k].i; im[k] = taps[k].q; }
+    host_dft_pow2(re, im);
+    hw.resize(FW_N); tw.resize((size_t)FW_TWE * 64);
+    for (int k1 = 0; k1 < 64; k1++)
+        for (int l = 0; l < 64; l++) { const int f = 64 * k1 + fw_pi(l); hw[fw_h_index(k1, l)] = make_float2((float)(re[f] / FW_N), (float)(im[f] / FW_N)); }
+    for (int e = 0; e < FW_TWE; e++)
+        for (int l = 0; l < 64; l++) {
+            const int p = e < 3 ? e + 1 : 4 * (e - 2);
+            const double a = -2.0 * M_PI * (double)(fw_pi(l) * p) / FW_N;
+            tw[(size_t)e * 64 + l] = make_float2((float)cos(a), (float)sin(a));
+        }
+}
+
+// wave-private 64 x 64 transpose of one float per (lane, register): with rows and columns numbered by fw_pi, register r of the lane of row a -> register a of the lane
+// of row r.  Lane l writes register r to LDS row l, column fw_pi_inv(r); lane l reads column l of every row p into register fw_pi(p): both sides conflict free
+// (row pitch 65), the permutation costs nothing (register names).  LDS operations of one wave execute in order, so the reads see the writes without a barrier; the
+// wavefront-scope fences only keep the COMPILER from moving a read above a write it cannot see the other lanes make.
+template <bool IM> __device__ __forceinline__ void fw_transpose_half(fw_pk2 (&v)[64], float *L, int lane)
+{
+    float *wr = L + lane * FW_LP;
+#pragma unroll
+    for (int r = 0; r < 64; r++) wr[fw_pi_inv(r)] = IM ? v[r].y : v[r].x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float *rd = L + lane;
+#pragma unroll
+    for (int p = 0; p < 64; p++) { const float x = rd[p * FW_LP]; if (IM) v[fw_pi(p)].y = x; else v[fw_pi(p)].x = x; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void fw_transpose(fw_pk2 (&v)[64], float *L, int lane) { fw_transpose_half<false>(v, L, lane); fw_transpose_half<true>(v, L, lane); }
+
+// The device forms of the passes.  A wave's 256 registers hold one window (128) and little else, and a wave cannot prefetch what it has no room for -- so what the
+// first version waited for, it waited for in full: the taps spectrum as 64 load-wait-multiply round trips to the L2 (25 of its 37 us per window), then, batched, still
+// 3 us; the next window's samples 8 us.  And a wave has 63 memory operations in flight at most: 64 stores + 64 loads of 8 bytes per lane made the loads wait for the
+// stores to retire (two memory latencies, ~4 us each, per window, wherever the schedule put them).  Now:
+//  * 16 bytes per lane and operation -- two neighbouring samples -- for window, results and spectrum: 32 + 32 + 32 operations per window.  A 16-byte load gives lane l
+//    the samples 2 l, 2 l + 1 (+ 128 j); one v_permlane32_swap per register pair (lanes >= 32 hand their first sample to lanes < 32 for the second one of those) turns
+//    that into rows n1 = fw_pi(l) with two consecutive j per operation, and the same swap undoes it in front of the stores;
+//  * pass 1: the spectrum values of a radix-16 group are requested one group ahead, by hand (two sets of 16 registers), and waited for behind the group's butterflies;
+//  * the twiddle bases live in LDS (one table per workgroup), not in 36 registers: that is what pays for the second set;
+//  * pass 3: the moment two radix-16 groups' 32 result rows are stored, the same 32 rows of the NEXT window are requested into the registers just freed.  Rows of
+//    groups g, g + 1 are j = g, g + 1 (mod 4), which is what the next pass 0's first step (radix 4 over rows n2, n2 + 16, n2 + 32, n2 + 48) consumes together.
+typedef float ffl_f32x4 __attribute__((ext_vector_type(4)));
+__device__ ffl_f32x4 ffl_buf_load4(ffl_i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void ffl_buf_store4(ffl_f32x4 v, ffl_i32x4 rsrc, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+// P = (sample 2 l, rows j), Q = (sample 2 l + 1, rows j) in lanes l < 32 / (2 l - 64, rows j + 1), (2 l - 63, rows j + 1) in lanes l >= 32  <->
+// P = (n1, row j), Q = (n1, row j + 1) with n1 = fw_pi(l): lanes [32, 64) of P change places with lanes [0, 32) of Q.  Its own inverse.
+__device__ __forceinline__ void fw_swap_halves(fw_pk2 &P, fw_pk2 &Q)
+{
+    const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(P.x), __float_as_uint(Q.x), false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(P.y), __float_as_uint(Q.y), false, false);
+    P = fw_pk2{__uint_as_float(rx[0]), __uint_as_float(ry[0])}; Q = fw_pk2{__uint_as_float(rx[1]), __uint_as_float(ry[1])};
+}
+
+__device__ __forceinline__ void fw_h_issue(ffl_f32x4 (&h)[8], ffl_i32x4 rh, int voff, int g)
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(h[m]) : "v"(voff), "s"(rh), "s"((g * 8 + m) * 1024) : "memory");
+}
+template <int INFLIGHT> __device__ __forceinline__ void fw_h_ready(ffl_f32x4 (&h)[8])
+{
+    asm volatile("s_waitcnt vmcnt(%8)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]), "+v"(h[6]), "+v"(h[7]) : "n"(INFLIGHT));
+}
+__device__ __forceinline__ void fw_h_mul(fw_pk2 (&v)[64], const ffl_f32x4 (&h)[8], int g)                          // group g: v[16 g + k2] = X[k1 = g + 4 k2]
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++) {                                       // libcsdr.c:826-830 (and 836-839: the 1/N is in the table)
+        v[16 * g + 2 * m] = fw_pk_cmul<false>(v[16 * g + 2 * m], fw_pk2{h[m].x, h[m].y});
+        v[16 * g + 2 * m + 1] = fw_pk_cmul<false>(v[16 * g + 2 * m + 1], fw_pk2{h[m].z, h[m].w});
+    }
+}
+__device__ __forceinline__ void fw_pass1_dev(fw_pk2 (&v)[64], const float2 *hw, int lane)
+{
+    const unsigned long long bh = (unsigned long long)hw;
+    const ffl_i32x4 rh = {(int)(unsigned)bh, (int)((bh >> 32) & 0xffffu), FW_N * 8, 0x00020000};
+    const int voff = lane * 16;
+    ffl_f32x4 ha[8], hb[8];
+    fw_h_issue(ha, rh, voff, 0);
+    fw_pk_dft64_head<false>(v);
+    fw_h_issue(hb, rh, voff, 1);
+    fw_pk_dft16<0, false>(v); fw_h_ready<8>(ha); fw_h_mul(v, ha, 0); fw_h_issue(ha, rh, voff, 2);
+    fw_pk_dft16<16, false>(v); fw_h_ready<8>(hb); fw_h_mul(v, hb, 1); fw_h_issue(hb, rh, voff, 3);
+    fw_pk_dft16<32, false>(v); fw_h_ready<8>(ha); fw_h_mul(v, ha, 2);
+    fw_pk_dft16<48, false>(v); fw_h_ready<0>(hb); fw_h_mul(v, hb, 3);
+    fw_pk_dft64_tail(v);
+}
+
+// the lane's twiddle bases from the workgroup's table in LDS (tl = table + lane): the 18 values are live inside this function only
+template <bool CONJ> __device__ __forceinline__ void fw_twiddle_lds(fw_pk2 (&v)[64], const fw_pk2 *tl)
+{
+    fw_pk2 tw[FW_TWE];
+#pragma unroll
+    for (int e = 0; e < FW_TWE; e++) tw[e] = tl[e * 64];
+    fw_pk_twiddle<CONJ>(v, tw);
+}
+
+struct FwRows {                                                          // where a window's samples are: buffer descriptor + the lane's byte offset of sample 2 lane
+    ffl_i32x4 r; int v0;
+};
+// half h of a window's rows: the row pairs (4 m + 2 h, 4 m + 2 h + 1), m = 0..15 -- nx[2 m + h] = samples 2 lane, 2 lane + 1 (+ 128 (2 m + h))
+__device__ __forceinline__ void fw_load_half(ffl_f32x4 (&nx)[32], const FwRows &x, int h)
+{
+#pragma unroll
+    for (int m = 0; m < 16; m++) nx[2 * m + h] = ffl_buf_load4(x.r, x.v0 + 1024 * (2 * m + h), 0, 0);
+}
+__device__ __forceinline__ void fw_rows_to_regs(fw_pk2 (&v)[64], const ffl_f32x4 (&nx)[32])
+{
+#pragma unroll
+    for (int jp = 0; jp < 32; jp++) {
+        fw_pk2 P = {nx[jp].x, nx[jp].y}, Q = {nx[jp].z, nx[jp].w};
+        fw_swap_halves(P, Q);
+        v[2 * jp] = P; v[2 * jp + 1] = Q;
+    }
+}
+// pass 3, the stores of this window and the loads of the next one, half by half (group k1's outputs are the rows k1 + 4 k2)
+template <int H> __device__ __forceinline__ void fw_pass3_half(fw_pk2 (&v)[64], const FwRows &y, ffl_f32x4 (&nx)[32], const FwRows &xn)
+{
+    constexpr int h = H;
+    {
+        fw_pk_dft16<32 * H, true>(v); fw_pk_dft16<32 * H + 16, true>(v);
+#pragma unroll
+        for (int m = 0; m < 16; m++) {                                  // rows 4 m + 2 h (group 2 h, k2 = m) and 4 m + 2 h + 1 (group 2 h + 1, k2 = m)
+            fw_pk2 P = v[16 * (2 * h) + m], Q = v[16 * (2 * h + 1) + m];
+            fw_swap_halves(P, Q);
+            const ffl_f32x4 r = {P.x, P.y, Q.x, Q.y};
+            ffl_buf_store4(r, y.r, y.v0 + 1024 * (2 * m + h), 0, 0);
+        }
+        fw_load_half(nx, xn, h);
+    }
+}
+__device__ __forceinline__ void fw_pass3_dev(fw_pk2 (&v)[64], const FwRows &y, ffl_f32x4 (&nx)[32], const FwRows &xn)
+{
+    fw_pk_dft64_head<true>(v);
+    fw_pass3_half<0>(v, y, nx, xn); fw_pass3_half<1>(v, y, nx, xn);
+}
+
+#ifdef FW_PROF
+// -DFW_PROF (tools/probes/fw_prof.py): 100-MHz clock stamps between the phases of wave 0 of every workgroup, summed; every stamp pins the window's registers so that
+// no arithmetic drifts across it.
+__device__ unsigned long long g_fw_prof[8];
+__device__ __forceinline__ void fw_pin(fw_pk2 (&v)[64])
+{
+#pragma unroll
+    for (int j = 0; j < 64; j += 8)
+        asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j + 1].x), "+v"(v[j + 1].y), "+v"(v[j + 2].x), "+v"(v[j + 2].y), "+v"(v[j + 3].x), "+v"(v[j + 3].y),
+                          "+v"(v[j + 4].x), "+v"(v[j + 4].y), "+v"(v[j + 5].x), "+v"(v[j + 5].y), "+v"(v[j + 6].x), "+v"(v[j + 6].y), "+v"(v[j + 7].x), "+v"(v[j + 7].y) :: "memory");
+}
+#define FW_T(k) { fw_pin(v); long long t_now; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now) :: "memory"); fw_pin(v); prof[k] += t_now - t_prev; t_prev = t_now; }
+#else
+#define FW_T(k)
+#endif
+
+// Windows are dealt like the 256-thread kernel's: every XCD a contiguous range, consecutive waves consecutive windows (the taps - 1 samples two neighbours share come
+// from that XCD's L2).  Edges by the buffer range check: samples in front of the call's input come from the history (second descriptor, the stream's first window only),
+// samples behind its end read as zero, results outside [0, m_new) are dropped.  m_new is even (fw_launch), so a 16-byte access never straddles an edge.
+__global__ __launch_bounds__(64 * FW_WAVES, 2) void k_fftfilt_wave(const float2 *__restrict__ in, size_t in_pitch, const float2 *__restrict__ hist, int k1p, int m_new,
+                                                                    int n_chunks, int n_windows, float2 *__restrict__ out, size_t out_pitch, const float2 *__restrict__ hw,
+                                                                    const float2 *__restrict__ g_tw)
+{
+    extern __shared__ float4 ffl_raw[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform: window, stream and descriptors stay in scalar registers)
+    float *L = reinterpret_cast<float *>(ffl_raw) + wv * 64 * FW_LP;
+    float2 *twl = reinterpret_cast<float2 *>(reinterpret_cast<float *>(ffl_raw) + FW_WAVES * 64 * FW_LP);
+    for (int i = threadIdx.x; i < FW_TWE * 64; i += 64 * FW_WAVES) twl[i] = g_tw[i];
+    __syncthreads();                                                    // the kernel's only barrier
+    const fw_pk2 *tl = reinterpret_cast<const fw_pk2 *>(twl) + lane;
+    const int V = FW_N - k1p;
+    const int per_xcd = (n_windows + 7) >> 3, xcd = blockIdx.x & 7, stride = (gridDim.x >> 3) * FW_WAVES;      // gridDim.x is a multiple of 8
+    const int w_end = min(n_windows, (xcd + 1) * per_xcd);
+    int w = xcd * per_xcd + (blockIdx.x >> 3) * FW_WAVES + wv;
+    if (w >= w_end) return;
+    auto rows_in = [&](int win) {                                       // window `win` of the input (negative offset -> out of range as unsigned -> 0)
+        const int s = win / n_chunks, c = win - s * n_chunks;
+        const unsigned long long bx = (unsigned long long)(in + (size_t)s * in_pitch);
+        return FwRows{ffl_i32x4{(int)(unsigned)bx, (int)((bx >> 32) & 0xffffu), m_new * 8, 0x00020000}, (c * V - k1p + 2 * lane) * 8};
+    };
+    ffl_f32x4 nx[32];
+    {
+        const FwRows x0 = rows_in(w);
+        fw_load_half(nx, x0, 0); fw_load_half(nx, x0, 1);
+    }
+#ifdef FW_PROF
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = wall_clock64();
+#endif
+    for (;;) {
+        const int s = w / n_chunks, c = w - s * n_chunks, w0 = c * V - k1p;
+        fw_pk2 v[64];
+        fw_rows_to_regs(v, nx);
+        if (w0 < 0) {                                                   // uniform: the stream's first window
+            const unsigned long long bh = (unsigned long long)(hist + (size_t)s * k1p);
+            const ffl_i32x4 rh = {(int)(unsigned)bh, (int)((bh >> 32) & 0xffffu), k1p * 8, 0x00020000};
+            const int vh = (k1p + w0 + fw_pi(lane)) * 8;
+#pragma unroll
+            for (int j = 0; j < 64; j++) { const ffl_f32x2 r = ffl_buf_load(rh, vh + 512 * j, 0, 0); v[j].x += r.x; v[j].y += r.y; }
+        }
+#ifdef FW_PROF
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        FW_T(0)
+        fw_pk_dft64<false>(v); fw_twiddle_lds<false>(v, tl);
+        FW_T(1)
+        fw_transpose(v, L, lane);
+        FW_T(2)
+        fw_pass1_dev(v, hw, lane);
+        FW_T(3)
+        fw_pk_dft64<true>(v); fw_twiddle_lds<true>(v, tl);
+        FW_T(4)
+        fw_transpose(v, L, lane);
+        FW_T(5)
+        // results n = k1p .. N-1 of the window are outputs c V + (n - k1p): descriptor based at output c V, range = what is left of the call; samples in front of
+        // k1p (the window's overlap part) have negative offsets and are dropped
+        const unsigned long long by = (unsigned long long)(out + (size_t)s * out_pitch + (size_t)c * V);
+        const FwRows y = {ffl_i32x4{(int)(unsigned)by, (int)((by >> 32) & 0xffffu), (m_new - c * V) * 8, 0x00020000}, (2 * lane - k1p) * 8};
+        const int wn = w + stride;
+        const bool more = wn < w_end;
+        const FwRows xn = rows_in(more ? wn : w);                       // (the last window: this one again, ignored -- no branch around values in flight)
+        fw_pass3_dev(v, y, nx, xn);
+        FW_T(6)
+#ifdef FW_PROF
+        prof[7] += 1;
+#endif
+        if (!more) break;
+        w = wn;
+    }
+#ifdef FW_PROF
+    if (threadIdx.x == 0) for (int k = 0; k < 8; k++) atomicAdd(&g_fw_prof[k], (unsigned long long)prof[k]);
+#endif
+}
+
+// the wave kernel's algorithm on the CPU: same pass functions and tables, lane after lane, the transposes as the index maps of fw_transpose_half
+void fw_host_run(const cf32 *taps, int taps_len, const cf32 *x, long m_new, cf32 *y)
+{
+    std::vector<float2> hw, twt; fw_host_tables(taps, taps_len, hw, twt);
+    const int k1p = (taps_len - 1 + 15) & ~15, V = FW_N - k1p;
+    const long n_chunks = (m_new + V - 1) / V;
+    std::vector<float2> a((size_t)64 * 64), b((size_t)64 * 64);
+    auto lane_tw = [&](int l, float2 (&tw)[FW_TWE]) { for (int e = 0; e < FW_TWE; e++) tw[e] = twt[(size_t)e * 64 + l]; };
+    for (long c = 0; c < n_chunks; c++) {
+        const long w0 = c * V - k1p;
+        for (int l = 0; l < 64; l++) {
+            float2 v[64], tw[FW_TWE]; lane_tw(l, tw);
+            for (int j = 0; j < 64; j++) { const long p = w0 + fw_pi(l) + 64 * j; v[j] = (p < 0 || p >= m_new) ? make_float2(0.f, 0.f) : make_float2(x[p].i, x[p].q); }
+            fw_pass0(v, tw);
+            for (int r = 0; r < 64; r++) a[(size_t)l * 64 + fw_pi_inv(r)] = v[r];
+        }
+        for (int l = 0; l < 64; l++) {
+            float2 v[64], h[64], tw[FW_TWE]; lane_tw(l, tw);
+            for (int p = 0; p < 64; p++) v[fw_pi(p)] = a[(size_t)p * 64 + l];
+            for (int k1 = 0; k1 < 64; k1++) h[k1] = hw[fw_h_index(k1, l)];
+            fw_pass1(v, h, 1);
+            fw_pass2(v, tw);
+            for (int r = 0; r < 64; r++) b[(size_t)l * 64 + fw_pi_inv(r)] = v[r];
+        }
+        for (int l = 0; l < 64; l++) {
+            float2 v[64];
+            for (int p = 0; p < 64; p++) v[fw_pi(p)] = b[(size_t)p * 64 + l];
+            fw_pass3(v);
+            for (int j = 0; j < 64; j++) {
+                const int n = fw_pi(l) + 64 * j; const long o = c * V + n - k1p;
+                if (n >= k1p && o < m_new) y[o] = cf32{v[j].x, v[j].y};
+            }
+        }
+    }
+}
 
 } // namespace
 
@@ -432,6 +714,7 @@ namespace csdr_amd {
 struct FftfiltLds {
     int n, taps_len, k1p, n_streams;
     float2 *d_hperm, *d_tw1, *d_tws, *d_hist[2]; int flip;
+    float2 *d_hw, *d_twl; bool wave;                // the wave-per-window kernel's tables (4096-point windows)
     int mode;                                       // CSDR_AMD_FFTFILT_LDS_MODE (A/B: prefetch / residency variant of the 4096-point kernel), read at create
 };
 
@@ -449,12 +732,19 @@ void fftfilt_lds_destroy(FftfiltLds *p)
 {
     if (!p) return;
     (void)hipFree(p->d_hperm); (void)hipFree(p->d_tw1); (void)hipFree(p->d_tws); (void)hipFree(p->d_hist[0]); (void)hipFree(p->d_hist[1]);
+    (void)hipFree(p->d_hw); (void)hipFree(p->d_twl);
     delete p;
 }
 
 int fftfilt_lds_set_taps(FftfiltLds *p, hipStream_t st, const cf32 *taps, int taps_len)
 {
     std::vector<float2> hperm, tw1, tws;
+    if (p->wave) {
+        std::vector<float2> hw, twl; fw_host_tables(taps, taps_len, hw, twl);
+        CSDR_HIP(hipStreamSynchronize(st));
+        CSDR_HIP(hipMemcpy(p->d_hw, hw.data(), sizeof(float2) * hw.size(), hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(p->d_twl, twl.data(), sizeof(float2) * twl.size(), hipMemcpyHostToDevice));
+    }                                                                   // (and the 256-thread kernel's tables: it takes the calls with an odd sample count)
     if (p->n == 4096) ffl_host_tables<4096>(taps, taps_len, hperm, tw1, tws);
     else if (p->n == 8192) ffl_host_tables<8192>(taps, taps_len, hperm, tw1, tws);
     else ffl_host_tables<16384>(taps, taps_len, hperm, tw1, tws);
@@ -478,8 +768,11 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
     FftfiltLds *p = new FftfiltLds();
     p->n = n; p->taps_len = taps_len; p->k1p = (taps_len - 1 + 15) & ~15; p->n_streams = n_streams; p->flip = 0;
     p->mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
-    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = nullptr;
+    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = p->d_hw = p->d_twl = nullptr;
+    p->wave = n == 4096 && (p->mode == 0 || p->mode == 6);        // 4096-point windows: one wave per window; CSDR_AMD_FFTFILT_LDS_MODE=5 (A/B): the 256-thread kernel of rounds 2-5
     hipError_t e = hipMalloc((void **)&p->d_hperm, sizeof(float2) * n);
+    if (p->wave && e == hipSuccess) e = hipMalloc((void **)&p->d_hw, sizeof(float2) * FW_N);
+    if (p->wave && e == hipSuccess) e = hipMalloc((void **)&p->d_twl, sizeof(float2) * FW_TWE * 64);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw1, sizeof(float2) * (n / 16));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tws, sizeof(float2) * (n / 16));
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&p->d_hist[i], sizeof(float2) * (size_t)n_streams * (p->k1p + 16));
@@ -488,7 +781,7 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
     return p;
 }
 
-const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
+const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->wave ? "k_fftfilt_wave" : p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
 int fftfilt_lds_window(const FftfiltLds *p) { return p->n; }
 
 template <int N, bool PF, int MINWG, bool HOIST, int LPT = 1>
@@ -512,6 +805,24 @@ static int ffl_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_p
     return 0;
 }
 
+static int fw_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
+{
+    constexpr size_t lds_bytes = (size_t)FW_WAVES * 64 * FW_LP * sizeof(float) + (size_t)FW_TWE * 64 * sizeof(float2);      // transposes + the workgroup's twiddle table
+    int rc = lds_attr_once((const void *)k_fftfilt_wave, lds_bytes); if (rc) return rc;
+    const int V = FW_N - p->k1p;
+    const int n_chunks = (int)((m_new + V - 1) / V);
+    const long n_windows = (long)n_chunks * p->n_streams;
+    if (n_windows > 0x7fffffffL || m_new > (1L << 27)) return fail_msg(-3, "fftfilt: call too large (2^27 samples per stream at most)");
+    long grid = (long)current_device_cu_count() * (8 / FW_WAVES);      // eight waves per CU: two per SIMD at 256 registers
+    const long need = (n_windows + FW_WAVES - 1) / FW_WAVES;
+    if (grid > need) grid = need;
+    grid = (grid + 7) & ~7L;
+    hipLaunchKernelGGL(k_fftfilt_wave, dim3((unsigned)grid), dim3(64 * FW_WAVES), lds_bytes, st, (const float2 *)in, in_pitch, (const float2 *)p->d_hist[p->flip], p->k1p,
+                       (int)m_new, n_chunks, (int)n_windows, (float2 *)out, out_pitch, (const float2 *)p->d_hw, (const float2 *)p->d_twl);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
 // m_new new samples per stream in, m_new filtered samples out
 int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
 {
@@ -521,7 +832,8 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     // 64 x 16 blocks; three workgroups 0.346, prefetching variants 0.33-0.36); 8192-point windows with one 512-thread workgroup that prefetches the next window
     // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
     const int mode = p->mode;
-    if (p->n == 4096) {
+    if (p->wave && !(m_new & 1)) rc = fw_launch(p, st, in, in_pitch, m_new, out, out_pitch);      // (16-byte accesses: an even sample count; odd ones take the 256-thread kernel)
+    else if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
         else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
         else if (mode == 4) rc = ffl_launch<4096, true, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
@@ -547,10 +859,23 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
 
 } // namespace csdr_amd
 
+#ifdef FW_PROF
+extern "C" int csdr_amd_debug_fw_prof(unsigned long long *out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fw_prof), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fw_prof), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 // Test hook (CPU, no device): the LDS kernel's algorithm -- same stage functions, same tables -- on m_new samples of one stream from the zero state.
 extern "C" int csdr_amd_debug_fftfilt_lds(int n, const float *taps_iq, int taps_len, const float *x_iq, long m_new, float *y_iq)
 {
     const cf32 *taps = reinterpret_cast<const cf32 *>(taps_iq), *x = reinterpret_cast<const cf32 *>(x_iq); cf32 *y = reinterpret_cast<cf32 *>(y_iq);
+    if (n == -4096) {                                                   // the wave-per-window form of the 4096-point window
+        if (taps_len < 1 || ((taps_len - 1 + 15) & ~15) >= FW_N) return -3;
+        fw_host_run(taps, taps_len, x, m_new, y); return 0;
+    }
     if (taps_len < 1 || ((taps_len - 1 + 15) & ~15) >= n) return -3;
     if (n == 4096) ffl_host_run<4096>(taps, taps_len, x, m_new, y);
     else if (n == 8192) ffl_host_run<8192>(taps, taps_len, x, m_new, y);

@@ -291,7 +291,7 @@ def test_bandpass_fir_fft_paths(gpu, port, monkeypatch):
         name, win = L.csdr_amd_fftfilt_kernel_name(f).decode(), L.csdr_amd_fftfilt_window(f)
         L.csdr_amd_fftfilt_destroy(f)
         return name, win
-    assert path_of(63, 65536) == ("k_fftfilt_lds<4096>", 4096) and path_of(1023, 65536)[1] == 4096
+    assert path_of(63, 65536) == ("k_fftfilt_wave", 4096) and path_of(1023, 65536)[1] == 4096
     assert path_of(1025, 65536)[1] == 4096 and path_of(1041, 65536)[1] == 8192 and path_of(2047, 65536)[1] == 8192 and path_of(4095, 65536)[1] == 16384
     assert path_of(8191, 65536) == ("", 0)
     # a filter too long for LDS windows: the 65536-point path

@@ -32,16 +32,18 @@ template <int KIND> __global__ __launch_bounds__(1024) void k(float *out, long l
 }
 template <int KIND> void run(const char *name)
 {
-    float *out; long long *cyc; hipMalloc(&out, 4 * 1024 * 1024); hipMalloc(&cyc, 8 * 1024);
-    for (int threads : {256, 512, 1024}) {
+    float *out; long long *cyc; hipMalloc(&out, 16 * 1024 * 1024); hipMalloc(&cyc, 8 * 1024);
+    for (int cfg = 0; cfg < 6; cfg++) {
+        const int threads = cfg < 3 ? (256 << cfg) : 256, blocks = cfg < 3 ? 256 : (256 << (cfg - 2));
         const int iters = 200;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        k<KIND><<<256, threads>>>(out, cyc, 10); hipDeviceSynchronize();
-        hipEventRecord(e0); k<KIND><<<256, threads>>>(out, cyc, iters); hipEventRecord(e1); hipDeviceSynchronize();
+        k<KIND><<<blocks, threads>>>(out, cyc, 10); hipDeviceSynchronize();
+        hipEventRecord(e0); k<KIND><<<blocks, threads>>>(out, cyc, iters); hipEventRecord(e1); hipDeviceSynchronize();
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long c[1]; hipMemcpy(c, cyc, 8, hipMemcpyDeviceToHost);
-        const double insts_per_simd = (double)iters * REP * 8 * (threads / 256);
-        printf("%-14s waves/SIMD %d: %.3f ms, %.2f ns per wave-instruction per SIMD, clock64 ticks per instruction %.3f\n", name, threads / 256, ms, ms * 1e6 / insts_per_simd, (double)c[0] / insts_per_simd);
+        const int wps = threads / 256 * (blocks / 256);
+        const double insts_per_simd = (double)iters * REP * 8 * wps, own = (double)iters * REP * 8;
+        printf("%-14s %4d blocks x %4d threads = %d waves/SIMD: %.3f ms, %.2f ns per wave-instruction per SIMD, wave 0's clock64 ticks per own instruction %.3f\n", name, blocks, threads, wps, ms, ms * 1e6 / insts_per_simd, (double)c[0] / own);
     }
 }
-int main() { run<0>("v_add_f32"); run<6>("v_mul_f32"); run<1>("v_fma_f32"); run<2>("v_pk_add_f32"); run<4>("v_pk_mul_f32"); run<3>("v_pk_fma_f32"); run<5>("v_pk_add opsel"); return 0; }
+int main() { run<0>("v_add_f32"); run<1>("v_fma_f32"); run<2>("v_pk_add_f32"); run<3>("v_pk_fma_f32"); return 0; }
