@@ -203,17 +203,19 @@ def test_nfm_deemph_digit_planes():
     assert fn(12345, 1.0, x.ctypes.data, out.ctypes.data) == -1
 
 
-@pytest.mark.parametrize("n,ntaps,m", [(4096, 63, 9000), (4096, 1023, 7000), (8192, 1023, 20000), (8192, 2047, 13000), (16384, 4095, 30000), (4096, 1, 4097), (8192, 500, 100)])
+@pytest.mark.parametrize("n,ntaps,m", [(4096, 63, 9000), (4096, 1023, 7000), (8192, 1023, 20000), (8192, 2047, 13000), (16384, 4095, 30000), (4096, 1, 4097), (8192, 500, 100),
+                                        (-4096, 63, 9000), (-4096, 1023, 7000), (-4096, 1, 4097), (-4096, 500, 100)])
 def test_fftfilt_lds_stages_on_cpu(n, ntaps, m):
     """The one-pass FFT filter kernel (fftfilt_lds.hip) is built from __host__ __device__ stage functions: the CPU runs the same index algebra (in-place
     decimation-in-frequency stages, taps spectrum in digit-reversed slot order, mirrored inverse stages, overlap-save windows) thread by thread and must
-    reproduce the linear convolution bandpass_fir_fft_cc computes (libcsdr.c:814-849)."""
+    reproduce the linear convolution bandpass_fir_fft_cc computes (libcsdr.c:814-849).  n = -4096: the wave-per-window form of the 4096-point window (fftfilt_wave.hpp:
+    64 lanes x 64 points, rows numbered by fw_pi, the transposes as the index maps the kernel uses, the spectrum in the order its 16-byte loads ask for it)."""
     import numpy as np
     import csdr_amd
     L = csdr_amd.lib()
     f = L.csdr_amd_debug_fftfilt_lds
     f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p]; f.restype = C.c_int
-    rng = np.random.default_rng(n + ntaps)
+    rng = np.random.default_rng(abs(n) + ntaps)
     h = ((rng.standard_normal(ntaps) + 1j * rng.standard_normal(ntaps)) / ntaps).astype(np.complex64)
     x = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
     y = np.zeros(m, np.complex64)
@@ -221,6 +223,7 @@ def test_fftfilt_lds_stages_on_cpu(n, ntaps, m):
     want = np.convolve(x.astype(np.complex128), h.astype(np.complex128))[:m]
     assert np.sqrt(np.mean(np.abs(y - want) ** 2) / np.mean(np.abs(want) ** 2)) < 2e-6
     assert f(4096, h.ctypes.data, 5000, x.ctypes.data, m, y.ctypes.data) != 0        # taps that do not fit the window are refused
+    assert f(-4096, h.ctypes.data, 5000, x.ctypes.data, m, y.ctypes.data) != 0
 
 
 def test_ddc_chain_fast_path_is_bit_identical(libpath, port):
