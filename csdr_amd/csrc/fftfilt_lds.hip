@@ -709,12 +709,39 @@ void fw_host_run(const cf32 *taps, int taps_len, const cf32 *x, long m_new, cf32
 
 } // namespace
 
+// ------------------------------------------------------------------------------------------------ a team of waves per window (8192 / 16384 points)
+#include "fftfilt_team.hpp"
+
+namespace {
+
+template <int M>
+void ft_host_tables(const cf32 *taps, int taps_len, std::vector<float2> &hw, std::vector<float2> &tw1, std::vector<float2> &tw2)
+{
+    using G = FtGeom<M>;
+    std::vector<double> re(G::N, 0.0), im(G::N, 0.0);
+    for (int k = 0; k < taps_len; k++) { re[k] = taps[k].i; im[k] = taps[k].q; }
+    host_dft_pow2(re, im);
+    hw.resize(G::N); tw1.resize((size_t)FW_TWE * G::T); tw2.resize((size_t)FW_TWE * M);
+    for (int p = 0; p < G::T; p++)
+        for (int kc = 0; kc < 64; kc++) {
+            const int ka = p >> G::LOGM, kd = ft_slot_kd(p & (M - 1), M), f = ka + 64 * (kc + 64 * kd);
+            hw[ft_h_index<M>(kc, p)] = make_float2((float)(re[f] / G::N), (float)(im[f] / G::N));
+        }
+    for (int e = 0; e < FW_TWE; e++) {
+        const int pw = e < 3 ? e + 1 : 4 * (e - 2);
+        for (int p = 0; p < G::T; p++) { const double a = -2.0 * M_PI * (double)((long)ft_logical(p) * pw) / G::N; tw1[(size_t)e * G::T + p] = make_float2((float)cos(a), (float)sin(a)); }
+        for (int m = 0; m < M; m++) { const double a = -2.0 * M_PI * (double)(m * pw) / G::T; tw2[(size_t)e * M + m] = make_float2((float)cos(a), (float)sin(a)); }
+    }
+}
+
+} // namespace
+
 namespace csdr_amd {
 
 struct FftfiltLds {
     int n, taps_len, k1p, n_streams;
     float2 *d_hperm, *d_tw1, *d_tws, *d_hist[2]; int flip;
-    float2 *d_hw, *d_twl; bool wave;                // the wave-per-window kernel's tables (4096-point windows)
+    float2 *d_hw, *d_twl, *d_tw2; bool wave, team;  // the tables of the wave-per-window kernel (4096-point windows) / of the team kernel (8192, 16384)
     int mode;                                       // CSDR_AMD_FFTFILT_LDS_MODE (A/B: prefetch / residency variant of the 4096-point kernel), read at create
 };
 
@@ -732,7 +759,7 @@ void fftfilt_lds_destroy(FftfiltLds *p)
 {
     if (!p) return;
     (void)hipFree(p->d_hperm); (void)hipFree(p->d_tw1); (void)hipFree(p->d_tws); (void)hipFree(p->d_hist[0]); (void)hipFree(p->d_hist[1]);
-    (void)hipFree(p->d_hw); (void)hipFree(p->d_twl);
+    (void)hipFree(p->d_hw); (void)hipFree(p->d_twl); (void)hipFree(p->d_tw2);
     delete p;
 }
 
@@ -745,6 +772,14 @@ int fftfilt_lds_set_taps(FftfiltLds *p, hipStream_t st, const cf32 *taps, int ta
         CSDR_HIP(hipMemcpy(p->d_hw, hw.data(), sizeof(float2) * hw.size(), hipMemcpyHostToDevice));
         CSDR_HIP(hipMemcpy(p->d_twl, twl.data(), sizeof(float2) * twl.size(), hipMemcpyHostToDevice));
     }                                                                   // (and the 256-thread kernel's tables: it takes the calls with an odd sample count)
+    if (p->team) {
+        std::vector<float2> hw, t1, t2;
+        if (p->n == 8192) ft_host_tables<2>(taps, taps_len, hw, t1, t2); else ft_host_tables<4>(taps, taps_len, hw, t1, t2);
+        CSDR_HIP(hipStreamSynchronize(st));
+        CSDR_HIP(hipMemcpy(p->d_hw, hw.data(), sizeof(float2) * hw.size(), hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(p->d_twl, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
+        CSDR_HIP(hipMemcpy(p->d_tw2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+    }
     if (p->n == 4096) ffl_host_tables<4096>(taps, taps_len, hperm, tw1, tws);
     else if (p->n == 8192) ffl_host_tables<8192>(taps, taps_len, hperm, tw1, tws);
     else ffl_host_tables<16384>(taps, taps_len, hperm, tw1, tws);
@@ -768,11 +803,13 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
     FftfiltLds *p = new FftfiltLds();
     p->n = n; p->taps_len = taps_len; p->k1p = (taps_len - 1 + 15) & ~15; p->n_streams = n_streams; p->flip = 0;
     p->mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
-    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = p->d_hw = p->d_twl = nullptr;
+    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = p->d_hw = p->d_twl = p->d_tw2 = nullptr;
     p->wave = n == 4096 && (p->mode == 0 || p->mode == 6);        // 4096-point windows: one wave per window; CSDR_AMD_FFTFILT_LDS_MODE=5 (A/B): the 256-thread kernel of rounds 2-5
+    p->team = (n == 8192 || n == 16384) && (p->mode == 0 || p->mode == 6);      // a team of 2 / 4 waves per window; CSDR_AMD_FFTFILT_LDS_MODE=5: the 512-thread kernels of rounds 2-6
     hipError_t e = hipMalloc((void **)&p->d_hperm, sizeof(float2) * n);
-    if (p->wave && e == hipSuccess) e = hipMalloc((void **)&p->d_hw, sizeof(float2) * FW_N);
-    if (p->wave && e == hipSuccess) e = hipMalloc((void **)&p->d_twl, sizeof(float2) * FW_TWE * 64);
+    if ((p->wave || p->team) && e == hipSuccess) e = hipMalloc((void **)&p->d_hw, sizeof(float2) * n);
+    if ((p->wave || p->team) && e == hipSuccess) e = hipMalloc((void **)&p->d_twl, sizeof(float2) * FW_TWE * (n / 64));
+    if (p->team && e == hipSuccess) e = hipMalloc((void **)&p->d_tw2, sizeof(float2) * FW_TWE * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tw1, sizeof(float2) * (n / 16));
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_tws, sizeof(float2) * (n / 16));
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&p->d_hist[i], sizeof(float2) * (size_t)n_streams * (p->k1p + 16));
@@ -781,7 +818,7 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
     return p;
 }
 
-const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->wave ? "k_fftfilt_wave" : p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
+const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->wave ? "k_fftfilt_wave" : p->team ? (p->n == 8192 ? "k_fftfilt_team<2>" : "k_fftfilt_team<4>") : p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
 int fftfilt_lds_window(const FftfiltLds *p) { return p->n; }
 
 template <int N, bool PF, int MINWG, bool HOIST, int LPT = 1>
@@ -823,6 +860,24 @@ static int fw_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pi
     return 0;
 }
 
+template <int M>
+static int ft_launch(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
+{
+    using G = FtGeom<M>;
+    int rc = lds_attr_once((const void *)k_fftfilt_team<M>, G::LDS_BYTES); if (rc) return rc;
+    const int V = G::N - p->k1p;
+    const int n_chunks = (int)((m_new + V - 1) / V);
+    const long n_windows = (long)n_chunks * p->n_streams;
+    if (n_windows > 0x7fffffffL || m_new > (1L << 27)) return fail_msg(-3, "fftfilt: call too large (2^27 samples per stream at most)");
+    long grid = (long)current_device_cu_count() * (8 / M);             // eight waves per CU: two per SIMD at 256 registers
+    if (grid > n_windows) grid = n_windows;
+    grid = (grid + 7) & ~7L;
+    hipLaunchKernelGGL(k_fftfilt_team<M>, dim3((unsigned)grid), dim3(64 * M), G::LDS_BYTES, st, (const float2 *)in, in_pitch, (const float2 *)p->d_hist[p->flip], p->k1p,
+                       (int)m_new, n_chunks, (int)n_windows, (float2 *)out, out_pitch, (const float2 *)p->d_hw, (const float2 *)p->d_twl, (const float2 *)p->d_tw2);
+    CSDR_LAUNCH_CHECK();
+    return 0;
+}
+
 // m_new new samples per stream in, m_new filtered samples out
 int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in_pitch, long m_new, cf32 *out, size_t out_pitch)
 {
@@ -833,6 +888,7 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
     const int mode = p->mode;
     if (p->wave && !(m_new & 1)) rc = fw_launch(p, st, in, in_pitch, m_new, out, out_pitch);      // (16-byte accesses: an even sample count; odd ones take the 256-thread kernel)
+    else if (p->team && !(m_new & 1)) rc = p->n == 8192 ? ft_launch<2>(p, st, in, in_pitch, m_new, out, out_pitch) : ft_launch<4>(p, st, in, in_pitch, m_new, out, out_pitch);
     else if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
         else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
