@@ -70,7 +70,7 @@ def test_bench_lookup_prefers_the_newest_round_and_one_instance():
     import sys
     sys.path.insert(0, ROOT)
     import bench_common as bc
-    got = bc.pmc_traffic("k_fftfilt_lds", {"streams_per_gpu": 64, "blocks_per_step": 16, "taps": 1023})
+    got = bc.pmc_traffic("k_fftfilt_wave", {"streams_per_gpu": 64, "blocks_per_step": 16, "taps": 1023})      # (round 6: the 1023-tap instance is k_fftfilt_wave)
     if got is None:
         return
     rounds = [_round_of(f) for f in glob.glob(os.path.join(PROF, "r*_fftfilt*_pmc_traffic.json"))]

@@ -34,7 +34,7 @@ for step in "$@"; do
     prof_nfm)     timeout 900 bash tools/profile_bench.sh ${tag}_nfm k_ddc_mfma bench_nfm.py 2>&1 | tail -12 | cut -c1-200 ;;
     prof_fir)     timeout 900 bash tools/profile_bench.sh ${tag}_fir k_fir_poly bench_fir.py 2>&1 | tail -8 | cut -c1-200 ;;
     prof_fir50)   timeout 900 bash tools/profile_bench.sh ${tag}_fir50 k_fir_mfma bench_fir.py --decimation 50 --tbw 0.005 --streams 64 2>&1 | tail -8 | cut -c1-200 ;;
-    prof_fftfilt) timeout 900 bash tools/profile_bench.sh ${tag}_fftfilt k_fftfilt_lds bench_fftfilt.py 2>&1 | tail -8 | cut -c1-200 ;;
+    prof_fftfilt) timeout 900 bash tools/profile_bench.sh ${tag}_fftfilt k_fftfilt_ bench_fftfilt.py 2>&1 | tail -8 | cut -c1-200 ;;
     prof_fastddc) timeout 900 bash tools/profile_bench.sh ${tag}_fastddc k_ddc_gemm3 bench_fastddc.py 2>&1 | tail -10 | cut -c1-200 ;;
     ops)        timeout 600 python tools/bench_ops.py > $out/${tag}_ops.jsonl 2> $out/ops.err; cut -c1-200 $out/${tag}_ops.jsonl ;;
     cmd:*)      bash -c "${step#cmd:}" ;;
