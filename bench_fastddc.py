@@ -429,6 +429,11 @@ def main():
     kms = C.c_double(0); kl = C.c_long(0)
     L.csdr_amd_fastddc_inv_kernel_time(inv, C.byref(kms), C.byref(kl))
     kname = L.csdr_amd_fastddc_inv_kernel_name(inv).decode()
+    stage_ms = {}
+    for stg in (1, 2):
+        sm = C.c_double(0); sl = C.c_long(0)
+        L.csdr_amd_fastddc_inv_stage_time(inv, stg, C.byref(sm), C.byref(sl))
+        stage_ms[stg] = sm.value / sl.value if sl.value else 0.0
     cd.barrier()
     red_dev = dev if (world > 1 and not shared and not shared_rccl) else "cpu"
     wall = cd.max_over_ranks(wall, red_dev)
@@ -487,6 +492,18 @@ def main():
                 # matrix pipe is busy for 3/4 of this fraction
                 res["roofline"]["executed_flops_per_launch"] = 0.75 * flops
                 res["roofline"]["matrix_pipe_frac"] = round(0.75 * tf / bc.FP32_PEAK_TFLOPS, 4)
+            # the two kernels around the fold, each with its own HBM roofline (HIP events around every launch, csdr_amd_fastddc_inv_stage_time): pass 1 of the forward
+            # transform reads the step's new samples and writes the 512 x 128 intermediate; the inverse transforms read the folded bins and write the decimated channels
+            es = {"cf32": 8, "s16": 4, "u8": 2}.get(args.input_format, 8)
+            others = []
+            for stg, nm, byts in ((1, "k_ddc_fwd512", float(es) * ddc.input_size * nb + 8.0 * ddc.fft_size * nb),
+                                  (2, "k_ddc_ifft256d_post" if ddc.post_decimation == 2 else "k_ddc_ifft512_post",
+                                   8.0 * ddc.fft_inv_size * count * nb + 8.0 * (ddc.post_input_size // ddc.post_decimation) * count * nb)):
+                if stage_ms.get(stg, 0) > 0:
+                    others.append({"kernel": nm, "bound": "hbm", "kernel_avg_ms": round(stage_ms[stg], 4), "algorithmic_bytes_per_launch": byts,
+                                   "achieved_GBps": round(byts / (stage_ms[stg] * 1e-3) / 1e9, 1), "frac": round(byts / (stage_ms[stg] * 1e-3) / 1e9 / bc.HBM_PEAK_GBS, 4)})
+            if others:
+                res["roofline"]["other_kernels"] = others
         else:
             res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": None, "peak": bc.FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                                "note": "general kernels (geometry outside the matrix-core path): no per-kernel timing"}

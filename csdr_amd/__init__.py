@@ -182,6 +182,7 @@ def lib():
     L.csdr_amd_fastddc_inv_kernel_name.restype = C.c_char_p; L.csdr_amd_fastddc_inv_kernel_name.argtypes = [vp]
     L.csdr_amd_fastddc_inv_set_profiling.argtypes = [vp, i]
     L.csdr_amd_fastddc_inv_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.csdr_amd_fastddc_inv_stage_time.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.csdr_amd_wfm_create.restype = vp; L.csdr_amd_wfm_create.argtypes = [vp, i, fl, i, vp, i, i, fl, i, sz]
     L.csdr_amd_wfm_destroy.argtypes = [vp]
     L.csdr_amd_wfm_reset.argtypes = [vp]

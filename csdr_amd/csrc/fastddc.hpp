@@ -46,6 +46,7 @@ int ddc_mfma_skip_batch(DdcMfma *m, DdcChanState *d_state, const ChanGeom *d_geo
 int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_pitch, const int **d_counts, hipEvent_t after_inverse = nullptr);      // after_inverse: recorded when the call's last kernel completes
 int ddc_mfma_set_profiling(DdcMfma *m, int on);
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches);
+int ddc_mfma_stage_time(DdcMfma *m, int stage, double *total_ms, long *launches);
 const char *ddc_mfma_kernel_name(const DdcMfma *m);       // the fold kernel the last collect() launched
 
 } // namespace csdr_amd

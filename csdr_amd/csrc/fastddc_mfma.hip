@@ -65,7 +65,19 @@ struct DdcMfma {
     // HIP-event timing of the fold kernel on the context's stream (bench_fastddc.py's roofline leg)
     bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // the same for the forward transform's first pass (stage 1: k_ddc_fwd512) and the inverse transforms (stage 2: k_ddc_ifft256d_post / k_ddc_ifft512_post)
+    struct StageProf { size_t used = 0; double ms = 0; long launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pool; } stage[2];
 };
+
+static int ddc_stage_begin(DdcMfma *m, int s, hipStream_t st, hipEvent_t *e1)
+{
+    *e1 = nullptr;
+    if (!m->profiling) return 0;
+    DdcMfma::StageProf &p = m->stage[s];
+    if (p.used == p.pool.size()) { hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b)); p.pool.emplace_back(a, b); }
+    CSDR_HIP(hipEventRecord(p.pool[p.used].first, st)); *e1 = p.pool[p.used].second; p.used++;
+    return 0;
+}
 
 namespace {
 
@@ -1061,6 +1073,8 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const void *in, int fmt, con
     // pass 1: 16 columns n2 per workgroup (128-byte runs)
 #define DDC_FWD_ARGS in, reinterpret_cast<const float2 *>(tail), reinterpret_cast<float2 *>(tail_out), \
                      reinterpret_cast<float2 *>(m->d_Y), m->d_tw, m->d_twb, m->input_size, m->overlap, n_loc, cj
+    hipEvent_t pe1 = nullptr;
+    { const int rc = ddc_stage_begin(m, 0, st, &pe1); if (rc) return rc; }
     {
         const size_t lds = (size_t)(16 * I512<16>::pitch + 512 + 128) * sizeof(float2);
         const dim3 grid(8, n_loc + (riders ? cdiv(rider_lanes, 8 * 256) : 0));
@@ -1071,6 +1085,7 @@ static int mfma_forward(DdcMfma *m, hipStream_t st, const void *in, int fmt, con
     }
 #undef DDC_FWD_ARGS
     CSDR_LAUNCH_CHECK();
+    if (pe1) CSDR_HIP(hipEventRecord(pe1, st));
     const bool rot_rides = !skip_pass2 && riders && cj.mode == 1 && (size_t)cj.n_channels * cj.n_blocks <= 512u * 256u;      // mode 2: pass 1 did the checkpoints
     if (!rot_rides) cj.R = nullptr;
     if (!skip_pass2)
@@ -1195,7 +1210,26 @@ int ddc_mfma_submit(DdcMfma *m, const void *in_v, const cf32 *spectra, int n_blo
 }
 
 const char *ddc_mfma_kernel_name(const DdcMfma *m) { return m->gemm_three ? (m->gemm_narrow ? "k_ddc_gemm3n" : "k_ddc_gemm3") : "k_ddc_gemm"; }
-int ddc_mfma_set_profiling(DdcMfma *m, int on) { m->profiling = on != 0; m->ev_used = 0; m->prof_ms = 0; m->prof_launches = 0; return 0; }
+int ddc_mfma_set_profiling(DdcMfma *m, int on)
+{
+    m->profiling = on != 0; m->ev_used = 0; m->prof_ms = 0; m->prof_launches = 0;
+    for (auto &p : m->stage) { p.used = 0; p.ms = 0; p.launches = 0; }
+    return 0;
+}
+// stage 1: the forward transform's first pass (k_ddc_fwd512), stage 2: the inverse transforms + scrap + residual shift (k_ddc_ifft256d_post / k_ddc_ifft512_post)
+int ddc_mfma_stage_time(DdcMfma *m, int stage, double *total_ms, long *launches)
+{
+    if (stage < 1 || stage > 2) return -3;
+    DdcMfma::StageProf &p = m->stage[stage - 1];
+    for (size_t k = 0; k < p.used; k++) {
+        CSDR_HIP(hipEventSynchronize(p.pool[k].second));
+        float ms = 0; CSDR_HIP(hipEventElapsedTime(&ms, p.pool[k].first, p.pool[k].second));
+        p.ms += ms; p.launches++;
+    }
+    p.used = 0;
+    *total_ms = p.ms; *launches = p.launches;
+    return 0;
+}
 int ddc_mfma_kernel_time(DdcMfma *m, double *total_ms, long *launches)
 {
     for (size_t k = 0; k < m->ev_used; k++) {
@@ -1274,6 +1308,8 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     const bool full = m->post_dec != 2;
     const int pairs = m->C * cdiv(n_blocks, 16);
     const dim3 g8(cdiv(pairs, 8) * 16);
+    hipEvent_t pe2 = nullptr;
+    { const int rc = ddc_stage_begin(m, 1, st, &pe2); if (rc) return rc; }
 #define DDC_IFFT_ARGS reinterpret_cast<const float2 *>(m->d_Ct), reinterpret_cast<float2 *>(out), out_pitch, m->d_R[k], m->d_tw, m->d_blk_remain[k], m->d_blk_off[k], d_geom, m->Cpad, m->nbp, n_blocks, m->C, m->scrap, m->post_in
     DdcChainJob ahead; memset(&ahead, 0, sizeof ahead);
     if (full) {
@@ -1295,6 +1331,7 @@ int ddc_mfma_collect(DdcMfma *m, const ChanGeom *d_geom, cf32 *out, size_t out_p
     }
 #undef DDC_IFFT_ARGS
     CSDR_LAUNCH_CHECK();
+    if (pe2) CSDR_HIP(hipEventRecord(pe2, st));
     if (after_inverse) CSDR_HIP(hipEventRecord(after_inverse, st));     // (the other inverse-transform variants)
     if (d_counts) *d_counts = m->d_counts[k];
     m->pending_blocks[k] = 0; m->drain ^= 1;

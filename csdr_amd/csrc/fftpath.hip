@@ -647,6 +647,11 @@ int csdr_amd_fastddc_inv_kernel_time(csdr_amd_fastddc_inv *f, double *total_ms, 
     *total_ms = 0; *launches = 0;
     return f->mf ? ddc_mfma_kernel_time(f->mf, total_ms, launches) : 0;
 }
+int csdr_amd_fastddc_inv_stage_time(csdr_amd_fastddc_inv *f, int stage, double *total_ms, long *launches)
+{
+    *total_ms = 0; *launches = 0;
+    return f->mf ? ddc_mfma_stage_time(f->mf, stage, total_ms, launches) : 0;
+}
 
 int csdr_amd_fastddc_inv_geometry(const csdr_amd_fastddc_inv *f, int channel, csdr_fastddc_t *ddc)
 {
