@@ -66,13 +66,14 @@ struct DdcMfma {
     bool profiling = false; size_t ev_used = 0; double prof_ms = 0; long prof_launches = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     // the same for the forward transform's first pass (stage 1: k_ddc_fwd512) and the inverse transforms (stage 2: k_ddc_ifft256d_post / k_ddc_ifft512_post)
+    bool profile_stages = false;
     struct StageProf { size_t used = 0; double ms = 0; long launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pool; } stage[2];
 };
 
 static int ddc_stage_begin(DdcMfma *m, int s, hipStream_t st, hipEvent_t *e1)
 {
     *e1 = nullptr;
-    if (!m->profiling) return 0;
+    if (!m->profiling || !m->profile_stages) return 0;
     DdcMfma::StageProf &p = m->stage[s];
     if (p.used == p.pool.size()) { hipEvent_t a, b; CSDR_HIP(hipEventCreate(&a)); CSDR_HIP(hipEventCreate(&b)); p.pool.emplace_back(a, b); }
     CSDR_HIP(hipEventRecord(p.pool[p.used].first, st)); *e1 = p.pool[p.used].second; p.used++;
@@ -1213,6 +1214,7 @@ const char *ddc_mfma_kernel_name(const DdcMfma *m) { return m->gemm_three ? (m->
 int ddc_mfma_set_profiling(DdcMfma *m, int on)
 {
     m->profiling = on != 0; m->ev_used = 0; m->prof_ms = 0; m->prof_launches = 0;
+    m->profile_stages = on == 2;                                         // (2: the kernels around the fold too -- two more event pairs per call, not for a timed region)
     for (auto &p : m->stage) { p.used = 0; p.ms = 0; p.launches = 0; }
     return 0;
 }

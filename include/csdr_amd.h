@@ -267,7 +267,7 @@ int  csdr_amd_fastddc_inv_process(csdr_amd_fastddc_inv *f, const csdr_complexf *
 const char *csdr_amd_fastddc_inv_kernel_name(const csdr_amd_fastddc_inv *f);
 int  csdr_amd_fastddc_inv_set_profiling(csdr_amd_fastddc_inv *f, int on);
 int  csdr_amd_fastddc_inv_kernel_time(csdr_amd_fastddc_inv *f, double *total_ms, long *launches);
-/* the same for the kernels around it (profiling on): stage 1 = the forward transform's first pass (k_ddc_fwd512), stage 2 = the inverse transforms with scrap and residual
+/* the same for the kernels around it (csdr_amd_fastddc_inv_set_profiling(f, 2): two more event pairs per call): stage 1 = the forward transform's first pass (k_ddc_fwd512), stage 2 = the inverse transforms with scrap and residual
  * shift (k_ddc_ifft256d_post / k_ddc_ifft512_post) */
 int  csdr_amd_fastddc_inv_stage_time(csdr_amd_fastddc_inv *f, int stage, double *total_ms, long *launches);
 /* Both halves in one object = the ddcd topology (ddcd_old.cpp:238-252, 474-492: one `csdr fastddc_fwd_cc` feeding N `csdr fastddc_inv_cc --fd` clients)
