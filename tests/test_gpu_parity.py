@@ -263,6 +263,23 @@ def test_bandpass_fir_fft_c3(gpu, port, ntaps):
     assert relrms(a[:20000], direct) < TOL
 
 
+@pytest.mark.parametrize("ntaps", [500, 2000, 4000])
+def test_bandpass_fir_fft_even_taps_mix_the_kernels(gpu, port, ntaps):
+    """An even tap count makes the block (fft_size - taps + 1) odd.  The wave / team kernels of the one-pass filter move 16 bytes per lane and take the calls with an
+    even sample count; odd ones go to the 256- / 512-thread kernels.  Five blocks in calls of 2, 2, 1 (and 3, 2; and one by one) cross both kinds on ONE object: the
+    state they hand each other is the same last taps - 1 input samples, so every split gives the oracle's stream (libcsdr.c:814-849)."""
+    rng = np.random.default_rng(ntaps)
+    fft = 16384; inp = fft - ntaps + 1
+    assert inp % 2 == 1
+    x = np.stack([crand(rng, inp * 5) for _ in range(3)])
+    taps = port.firdes_bandpass_c(ntaps, -0.2, 0.1)
+    want = [port.bandpass_fir_fft_cc(x[s], taps, fft) for s in range(3)]
+    for per_call in (2, 3, 1, 5):
+        a = gpu.bandpass_fir_fft_cc(x, taps, fft, blocks_per_call=per_call)
+        for s in range(3):
+            assert relrms(a[s], want[s]) < TOL, (per_call, s)
+
+
 def test_bandpass_fir_fft_c3_streams(gpu, port):
     """fft 65536 (the three-pass transform of fft64k.hip) on several streams, blocks split over calls; the hipFFT path gives the same result."""
     rng = np.random.default_rng(33)
