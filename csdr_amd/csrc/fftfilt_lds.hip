@@ -741,6 +741,7 @@ namespace csdr_amd {
 struct FftfiltLds {
     int n, taps_len, k1p, n_streams;
     float2 *d_hperm, *d_tw1, *d_tws, *d_hist[2]; int flip;
+    const char *last;                               // the window kernel the last call ran (a call's size and parity pick it)
     float2 *d_hw, *d_twl, *d_tw2; bool wave, team;  // the tables of the wave-per-window kernel (4096-point windows) / of the team kernel (8192, 16384)
     int mode;                                       // CSDR_AMD_FFTFILT_LDS_MODE (A/B: prefetch / residency variant of the 4096-point kernel), read at create
 };
@@ -803,7 +804,7 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
     FftfiltLds *p = new FftfiltLds();
     p->n = n; p->taps_len = taps_len; p->k1p = (taps_len - 1 + 15) & ~15; p->n_streams = n_streams; p->flip = 0;
     p->mode = getenv("CSDR_AMD_FFTFILT_LDS_MODE") ? atoi(getenv("CSDR_AMD_FFTFILT_LDS_MODE")) : 0;
-    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = p->d_hw = p->d_twl = p->d_tw2 = nullptr;
+    p->d_hperm = p->d_tw1 = p->d_tws = p->d_hist[0] = p->d_hist[1] = p->d_hw = p->d_twl = p->d_tw2 = nullptr; p->last = nullptr;
     p->wave = n == 4096 && (p->mode == 0 || p->mode == 6);        // 4096-point windows: one wave per window; CSDR_AMD_FFTFILT_LDS_MODE=5 (A/B): the 256-thread kernel of rounds 2-5
     p->team = (n == 8192 || n == 16384) && (p->mode == 0 || p->mode == 6);      // a team of 2 / 4 waves per window; CSDR_AMD_FFTFILT_LDS_MODE=5: the 512-thread kernels of rounds 2-6
     hipError_t e = hipMalloc((void **)&p->d_hperm, sizeof(float2) * n);
@@ -818,7 +819,7 @@ FftfiltLds *fftfilt_lds_create(hipStream_t st, int n, const cf32 *taps, int taps
     return p;
 }
 
-const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->wave ? "k_fftfilt_wave" : p->team ? (p->n == 8192 ? "k_fftfilt_team<2>" : "k_fftfilt_team<4>") : p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
+const char *fftfilt_lds_kernel_name(const FftfiltLds *p) { return p->last ? p->last : p->wave ? "k_fftfilt_wave" : p->team ? (p->n == 8192 ? "k_fftfilt_team<2>" : "k_fftfilt_team<4>") : p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>"; }
 int fftfilt_lds_window(const FftfiltLds *p) { return p->n; }
 
 template <int N, bool PF, int MINWG, bool HOIST, int LPT = 1>
@@ -887,7 +888,12 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     // 64 x 16 blocks; three workgroups 0.346, prefetching variants 0.33-0.36); 8192-point windows with one 512-thread workgroup that prefetches the next window
     // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
     const int mode = p->mode;
-    if (p->wave && !(m_new & 1)) rc = fw_launch(p, st, in, in_pitch, m_new, out, out_pitch);      // (16-byte accesses: an even sample count; odd ones take the 256-thread kernel)
+    // the wave kernel from four windows per wave on: below that its one or two rounds take a window's full latency with a quarter of the 256-thread kernel's waves on it
+    // (1 stream x 64 blocks = 1345 windows: 0.028 against 0.024 ms; 5380 windows 0.075 / 0.067; 10760 equal; 21520 0.266 / 0.285 -- tools/probes/fftfilt_sizes.py)
+    const bool wave_pays = p->wave && (p->mode == 6 || (m_new + (FW_N - p->k1p) - 1) / (FW_N - p->k1p) * p->n_streams >= 8192);
+    const char *old_name = p->n == 4096 ? "k_fftfilt_lds<4096>" : p->n == 8192 ? "k_fftfilt_lds<8192>" : "k_fftfilt_lds<16384>";
+    p->last = p->wave && !(m_new & 1) && wave_pays ? "k_fftfilt_wave" : p->team && !(m_new & 1) ? (p->n == 8192 ? "k_fftfilt_team<2>" : "k_fftfilt_team<4>") : old_name;
+    if (p->wave && !(m_new & 1) && wave_pays) rc = fw_launch(p, st, in, in_pitch, m_new, out, out_pitch);      // (16-byte accesses: an even sample count; odd ones take the 256-thread kernel)
     else if (p->team && !(m_new & 1)) rc = p->n == 8192 ? ft_launch<2>(p, st, in, in_pitch, m_new, out, out_pitch) : ft_launch<4>(p, st, in, in_pitch, m_new, out, out_pitch);
     else if (p->n == 4096) {
         if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
