@@ -15,10 +15,15 @@ __device__ void bs4(f4 v, i4 rsrc, int voff, int soff, int aux) __asm("llvm.amdg
 template <int MODE, int WAVES> __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k(const float *__restrict__ in, float *__restrict__ out, int n_windows, long in_bytes)
 {
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long bi = (unsigned long long)in, bo = (unsigned long long)out;
+#ifdef INTERLEAVED
+    const int w_end = n_windows, stride = gridDim.x * WAVES;            // consecutive windows on consecutive workgroups (= round robin over the XCDs)
+    for (int w = blockIdx.x * WAVES + wv; w < w_end; w += stride) {
+#else
     const int per_xcd = (n_windows + 7) >> 3, xcd = blockIdx.x & 7, stride = (gridDim.x >> 3) * WAVES;
     const int w_end = min(n_windows, (xcd + 1) * per_xcd);
-    const unsigned long long bi = (unsigned long long)in, bo = (unsigned long long)out;
     for (int w = xcd * per_xcd + (blockIdx.x >> 3) * WAVES + wv; w < w_end; w += stride) {
+#endif
         const unsigned long long a = bi + (unsigned long long)w * 24576, b = bo + (unsigned long long)w * 24576;
         const i4 rx = {(int)(unsigned)a, (int)((a >> 32) & 0xffffu), 32768, 0x00020000};
         const i4 ry = {(int)(unsigned)b, (int)((b >> 32) & 0xffffu), 24576, 0x00020000};
