@@ -743,7 +743,7 @@ struct FftfiltLds {
     float2 *d_hperm, *d_tw1, *d_tws, *d_hist[2]; int flip;
     const char *last;                               // the window kernel the last call ran (a call's size and parity pick it)
     float2 *d_hw, *d_twl, *d_tw2; bool wave, team;  // the tables of the wave-per-window kernel (4096-point windows) / of the team kernel (8192, 16384)
-    int mode;                                       // CSDR_AMD_FFTFILT_LDS_MODE (A/B: prefetch / residency variant of the 4096-point kernel), read at create
+    int mode;                                       // CSDR_AMD_FFTFILT_LDS_MODE (A/B: 5 = the kernels of rounds 2-5, 6 = the wave kernel at every call size), read at create
 };
 
 // window size for a filter of taps_len taps: the smallest plan that keeps >= 3/4 of every window as output; 0 = none fits (the caller keeps its other paths)
@@ -884,10 +884,6 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
 {
     if (m_new <= 0) return 0;
     int rc;
-    // Measured on one box (profiles/r2_notes.md): 4096-point windows run best with four resident workgroups per CU and no register prefetch (0.318 ms per
-    // 64 x 16 blocks; three workgroups 0.346, prefetching variants 0.33-0.36); 8192-point windows with one 512-thread workgroup that prefetches the next window
-    // and keeps the twiddle powers and the taps spectrum in registers.  CSDR_AMD_FFTFILT_LDS_MODE=1 selects the prefetching variant for 4096 too.
-    const int mode = p->mode;
     // the wave kernel from four windows per wave on: below that its one or two rounds take a window's full latency with a quarter of the 256-thread kernel's waves on it
     // (1 stream x 64 blocks = 1345 windows: 0.028 against 0.024 ms; 5380 windows 0.075 / 0.067; 10760 equal; 21520 0.266 / 0.285 -- tools/probes/fftfilt_sizes.py)
     const bool wave_pays = p->wave && (p->mode == 6 || (m_new + (FW_N - p->k1p) - 1) / (FW_N - p->k1p) * p->n_streams >= 8192);
@@ -895,18 +891,11 @@ int fftfilt_lds_process(FftfiltLds *p, hipStream_t st, const cf32 *in, size_t in
     p->last = p->wave && !(m_new & 1) && wave_pays ? "k_fftfilt_wave" : p->team && !(m_new & 1) ? (p->n == 8192 ? "k_fftfilt_team<2>" : "k_fftfilt_team<4>") : old_name;
     if (p->wave && !(m_new & 1) && wave_pays) rc = fw_launch(p, st, in, in_pitch, m_new, out, out_pitch);      // (16-byte accesses: an even sample count; odd ones take the 256-thread kernel)
     else if (p->team && !(m_new & 1)) rc = p->n == 8192 ? ft_launch<2>(p, st, in, in_pitch, m_new, out, out_pitch) : ft_launch<4>(p, st, in, in_pitch, m_new, out, out_pitch);
-    else if (p->n == 4096) {
-        if (mode == 1) rc = ffl_launch<4096, true, 2, true>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else if (mode == 3) rc = ffl_launch<4096, true, 3, false>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else if (mode == 4) rc = ffl_launch<4096, true, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else rc = ffl_launch<4096, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
-    } else if (p->n == 8192) {
-        if (mode == 2) rc = ffl_launch<8192, false, 2, false>(p, st, in, in_pitch, m_new, out, out_pitch);
-        else if (mode == 4) rc = ffl_launch<8192, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);      // (the second __launch_bounds__ argument is waves per SIMD: 4 = 128 registers = TWO workgroups per CU)
-        else rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
-    } else if (mode == 1) rc = ffl_launch<16384, false, 1, false>(p, st, in, in_pitch, m_new, out, out_pitch);      // (A/B: the 1024-thread form of rounds 2-5)
-    // 512 threads, two logical threads each, no prefetch: 0.490 against 0.513 ms (1024 threads) per 64 x 16 blocks at 4095 taps on one box.  WITH the next window's 32
-    // samples per thread in flight (PF) the compiler, at 256 registers, serialises the centre phase's 32 loads of the taps spectrum: 0.601 ms -- not instantiated.
+    // The kernels of rounds 2-5 (odd sample counts, small calls at 4096 points, CSDR_AMD_FFTFILT_LDS_MODE=5), each in the one form that measured best (profiles/r2_notes.md,
+    // r6_notes.md; the prefetch / residency variants that lost -- modes 1-4 of earlier rounds -- are gone): 4096 points: four resident workgroups per CU, no register
+    // prefetch; 8192: one 512-thread workgroup that prefetches the next window and keeps twiddle powers and spectrum in registers; 16384: 512 threads x two logical threads.
+    else if (p->n == 4096) rc = ffl_launch<4096, false, 4, false>(p, st, in, in_pitch, m_new, out, out_pitch);
+    else if (p->n == 8192) rc = ffl_launch<8192, true, 1, true>(p, st, in, in_pitch, m_new, out, out_pitch);
     else rc = ffl_launch<16384, false, 1, false, 2>(p, st, in, in_pitch, m_new, out, out_pitch);
     if (rc) return rc;
     if (p->k1p > 0) {
