@@ -734,6 +734,76 @@ void ft_host_tables(const cf32 *taps, int taps_len, std::vector<float2> &hw, std
     }
 }
 
+// the team kernel's algorithm on the CPU: its tables (ft_host_tables), its index maps (ft_logical, the exchanges' addresses t <-> (k_a, m), ft_slot_kd, ft_h_index) and the
+// scalar forms of its passes, thread after thread; the radix-M step over the M lanes of a group written out as the kernel's two butterfly stages
+template <int M>
+void ft_host_run(const cf32 *taps, int taps_len, const cf32 *x, long m_new, cf32 *y)
+{
+    using G = FtGeom<M>;
+    constexpr int T = G::T, N = G::N;
+    std::vector<float2> hw, t1, t2; ft_host_tables<M>(taps, taps_len, hw, t1, t2);
+    const int k1p = (taps_len - 1 + 15) & ~15, V = N - k1p;
+    const long n_chunks = (m_new + V - 1) / V;
+    std::vector<float2> lds((size_t)64 * G::P), regs((size_t)T * 64);
+    auto tw_of = [&](const std::vector<float2> &tab, int stride, int idx, float2 (&tw)[FW_TWE]) { for (int e = 0; e < FW_TWE; e++) tw[e] = tab[(size_t)e * stride + idx]; };
+    auto bfly = [](float2 x, float2 p, float sig) { return make_float2(p.x + sig * x.x, p.y + sig * x.y); };
+    auto radix_lanes = [&](float2 (&q)[M], bool inv) {                   // q[m]: the M lanes of a group, in place (ft_radix_lanes)
+        float2 a[M];
+        if (M == 2) { a[0] = bfly(q[0], q[1], 1.f); a[1] = bfly(q[1], q[0], -1.f); }
+        else if (!inv) {
+            float2 s[4]; for (int m = 0; m < 4; m++) s[m] = bfly(q[m], q[m ^ 2], (m & 2) ? -1.f : 1.f);
+            s[3] = make_float2(s[3].y, -s[3].x);
+            for (int m = 0; m < 4; m++) a[m] = bfly(s[m], s[m ^ 1], (m & 1) ? -1.f : 1.f);
+        } else {
+            float2 s[4]; for (int m = 0; m < 4; m++) s[m] = bfly(q[m], q[m ^ 1], (m & 1) ? -1.f : 1.f);
+            s[3] = make_float2(-s[3].y, s[3].x);
+            for (int m = 0; m < 4; m++) a[m] = bfly(s[m], s[m ^ 2], (m & 2) ? -1.f : 1.f);
+        }
+        for (int m = 0; m < M; m++) q[m] = a[m];
+    };
+    for (long c = 0; c < n_chunks; c++) {
+        const long w0 = c * V - k1p;
+        for (int p = 0; p < T; p++) {                                    // pass 0 and the exchange's writes: a[k_a P + t]
+            const int t = ft_logical(p);
+            float2 v[64], tw[FW_TWE]; tw_of(t1, T, p, tw);
+            for (int j = 0; j < 64; j++) { const long n = w0 + t + (long)T * j; v[j] = (n < 0 || n >= m_new) ? make_float2(0.f, 0.f) : make_float2(x[n].i, x[n].q); }
+            dft64<false>(v); fw_twiddle<false>(v, tw);
+            for (int r = 0; r < 64; r++) lds[(size_t)r * G::P + t] = v[r];
+        }
+        for (int p = 0; p < T; p++) {                                    // reads b[M i], pass 1, x W_T^(m k_c)
+            float2 v[64], tw[FW_TWE]; tw_of(t2, M, p & (M - 1), tw);
+            for (int i = 0; i < 64; i++) v[i] = lds[(size_t)(p >> G::LOGM) * G::P + (p & (M - 1)) + M * i];
+            dft64<false>(v); fw_twiddle<false>(v, tw);
+            for (int r = 0; r < 64; r++) regs[(size_t)p * 64 + r] = v[r];
+        }
+        for (int g = 0; g < T / M; g++)                                  // radix M over the group's lanes, x spectrum, inverse
+            for (int r = 0; r < 64; r++) {
+                float2 q[M];
+                for (int m = 0; m < M; m++) q[m] = regs[(size_t)(M * g + m) * 64 + r];
+                radix_lanes(q, false);
+                for (int m = 0; m < M; m++) q[m] = cmul(q[m], hw[ft_h_index<M>(r, M * g + m)]);
+                radix_lanes(q, true);
+                for (int m = 0; m < M; m++) regs[(size_t)(M * g + m) * 64 + r] = q[m];
+            }
+        for (int p = 0; p < T; p++) {                                    // x conj W_T^(m k_c), pass 2, the exchange back: writes b[M i]
+            float2 v[64], tw[FW_TWE]; tw_of(t2, M, p & (M - 1), tw);
+            for (int r = 0; r < 64; r++) v[r] = regs[(size_t)p * 64 + r];
+            fw_twiddle<true>(v, tw); dft64<true>(v);
+            for (int i = 0; i < 64; i++) lds[(size_t)(p >> G::LOGM) * G::P + (p & (M - 1)) + M * i] = v[i];
+        }
+        for (int p = 0; p < T; p++) {                                    // reads a[k_a P + t], x conj W_N^(t k_a), pass 3
+            const int t = ft_logical(p);
+            float2 v[64], tw[FW_TWE]; tw_of(t1, T, p, tw);
+            for (int r = 0; r < 64; r++) v[r] = lds[(size_t)r * G::P + t];
+            fw_twiddle<true>(v, tw); dft64<true>(v);
+            for (int j = 0; j < 64; j++) {
+                const int n = t + T * j; const long o = c * V + n - k1p;
+                if (n >= k1p && o < m_new) y[o] = cf32{v[j].x, v[j].y};
+            }
+        }
+    }
+}
+
 } // namespace
 
 namespace csdr_amd {
@@ -923,6 +993,11 @@ extern "C" int csdr_amd_debug_fw_prof(unsigned long long *out8, int reset)
 extern "C" int csdr_amd_debug_fftfilt_lds(int n, const float *taps_iq, int taps_len, const float *x_iq, long m_new, float *y_iq)
 {
     const cf32 *taps = reinterpret_cast<const cf32 *>(taps_iq), *x = reinterpret_cast<const cf32 *>(x_iq); cf32 *y = reinterpret_cast<cf32 *>(y_iq);
+    if (n == -8192 || n == -16384) {                                    // the team form of the 8192- / 16384-point windows
+        if (taps_len < 1 || ((taps_len - 1 + 15) & ~15) >= -n) return -3;
+        if (n == -8192) ft_host_run<2>(taps, taps_len, x, m_new, y); else ft_host_run<4>(taps, taps_len, x, m_new, y);
+        return 0;
+    }
     if (n == -4096) {                                                   // the wave-per-window form of the 4096-point window
         if (taps_len < 1 || ((taps_len - 1 + 15) & ~15) >= FW_N) return -3;
         fw_host_run(taps, taps_len, x, m_new, y); return 0;

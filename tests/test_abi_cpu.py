@@ -204,12 +204,15 @@ def test_nfm_deemph_digit_planes():
 
 
 @pytest.mark.parametrize("n,ntaps,m", [(4096, 63, 9000), (4096, 1023, 7000), (8192, 1023, 20000), (8192, 2047, 13000), (16384, 4095, 30000), (4096, 1, 4097), (8192, 500, 100),
-                                        (-4096, 63, 9000), (-4096, 1023, 7000), (-4096, 1, 4097), (-4096, 500, 100)])
+                                        (-4096, 63, 9000), (-4096, 1023, 7000), (-4096, 1, 4097), (-4096, 500, 100),
+                                        (-8192, 2047, 13000), (-8192, 1023, 9000), (-16384, 4095, 30000), (-16384, 3000, 14000)])
 def test_fftfilt_lds_stages_on_cpu(n, ntaps, m):
     """The one-pass FFT filter kernel (fftfilt_lds.hip) is built from __host__ __device__ stage functions: the CPU runs the same index algebra (in-place
     decimation-in-frequency stages, taps spectrum in digit-reversed slot order, mirrored inverse stages, overlap-save windows) thread by thread and must
     reproduce the linear convolution bandpass_fir_fft_cc computes (libcsdr.c:814-849).  n = -4096: the wave-per-window form of the 4096-point window (fftfilt_wave.hpp:
-    64 lanes x 64 points, rows numbered by fw_pi, the transposes as the index maps the kernel uses, the spectrum in the order its 16-byte loads ask for it)."""
+    64 lanes x 64 points, rows numbered by fw_pi, the transposes as the index maps the kernel uses, the spectrum in the order its 16-byte loads ask for it);
+    n = -8192 / -16384: the team form (fftfilt_team.hpp: 128 / 256 threads x 64 points, the exchanges' address maps, the radix-2 / radix-4 step over neighbouring lanes as its
+    two butterfly stages with lane 3's rotation, the spectrum by (register pair, thread) with the k_d slots bit-reversed, both twiddle tables)."""
     import numpy as np
     import csdr_amd
     L = csdr_amd.lib()
